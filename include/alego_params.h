@@ -1,0 +1,172 @@
+/*
+ * alego_params.h — every tunable of the A-LeGO-LOAM per-scan hot path as one POD.
+ *
+ * The reference has no runtime configuration: all of these are compile-time
+ * constants (include/alego/utility.h:50-73) or literals inside the node bodies
+ * (listed per field below).  Defaults written by alego_default_params() are the
+ * reference values; the sensor geometry (n_scan, horizon_scan, ang_res_*) is a
+ * runtime parameter because BASELINE.json's configs use 16x1800 and 64x2048
+ * while the reference compiles in 16x4000.
+ *
+ * This header is the data contract shared by the C-ABI library
+ * (include/alego_mi355x.h) and by the parity oracle (oracle/); it contains no
+ * code of either.
+ */
+#ifndef ALEGO_PARAMS_H_
+#define ALEGO_PARAMS_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum alego_laser_type { ALEGO_LASER_UNIFORM = 0, /* LSLIDAR_C16 formula, imageProjection.cpp:80 */
+                        ALEGO_LASER_RFANS_16M = 1 /* piece-wise ring table, IP.cpp:142-172 */ };
+
+typedef struct alego_params {
+  /* ---- sensor geometry: utility.h:50-58 ---- */
+  int32_t n_scan;            /* N_SCAN = 16                          utility.h:50 */
+  int32_t horizon_scan;      /* Horizon_SCAN = int(360/ang_res_x+.5) utility.h:55 */
+  double ang_res_x;          /* 0.09 deg                             utility.h:51 */
+  double ang_res_y;          /* 2.0 deg                              utility.h:52 */
+  double ang_bottom;         /* 15.0 deg                             utility.h:56 */
+  int32_t ground_scan_id;    /* 10                                   utility.h:57 */
+  int32_t laser_type;        /* alego_laser_type; nodelet = UNIFORM  utility.h:81 */
+  double sensor_mount_ang;   /* 0.0                                  utility.h:58 */
+  double ground_angle_thres; /* 10.0 deg        imageProjection.cpp:127 */
+  /* ---- segmentation: utility.h:60-65 ---- */
+  double seg_alpha_x;        /* rad(ang_res_x)                       utility.h:60 */
+  double seg_alpha_y;        /* rad(ang_res_y)                       utility.h:61 */
+  double seg_theta;          /* 1.047                                utility.h:63 */
+  int32_t seg_valid_point_num; /* 5                                  utility.h:64 */
+  int32_t seg_valid_line_num;  /* 3                                  utility.h:65 */
+  int32_t seg_big_num;       /* 30              imageProjection.cpp:283 */
+  /* ---- input filter (standalone IP.cpp only) ---- */
+  int32_t near_filter;       /* 0 nodelet / 1 IP.cpp:117 */
+  double near_thres;         /* 1.0 m           IP.cpp:117 */
+  /* ---- feature extraction: laserOdometry.cpp:122-293 ---- */
+  int32_t occl_col_diff;     /* 10              laserOdometry.cpp:137 */
+  double occl_depth;         /* 0.5             laserOdometry.cpp:140 */
+  double parallel_ratio;     /* 0.02            laserOdometry.cpp:154 */
+  int32_t occl_f32;          /* 0 = nodelet (double depth1/2, laserOdometry.cpp:134), 1 = LO.cpp:203 (float) */
+  int32_t n_sectors;         /* 6               laserOdometry.cpp:175 */
+  int32_t sector_formula;    /* 0 = laserOdometry.cpp:177-178, 1 = LO.cpp:245-249 */
+  double edge_thres;         /* 0.1             laserOdometry.cpp:192 */
+  double surf_thres;         /* 0.1             laserOdometry.cpp:242 */
+  int32_t n_sharp;           /* 2               laserOdometry.cpp:196 */
+  int32_t n_less_sharp;      /* 20              laserOdometry.cpp:202 */
+  int32_t n_flat;            /* 4               laserOdometry.cpp:248 */
+  int32_t suppress_radius;   /* 5               laserOdometry.cpp:211 */
+  int32_t suppress_col_diff; /* 10              laserOdometry.cpp:214 */
+  float less_flat_leaf;      /* 0.4 m           laserOdometry.cpp:290 */
+  int32_t sort_mode;         /* 0 = total order (curvature, index); 1 = libstdc++ std::sort
+                                tie order (oracle only — SURVEY.md C.1) */
+  /* ---- scan-to-scan odometry: laserOdometry.cpp:328-508 ---- */
+  double nearest_feature_dist; /* 25.0 (squared) utility.h:73 */
+  int32_t ring_window;       /* 2               laserOdometry.cpp:350,441 */
+  double huber_delta;        /* 0.1             laserOdometry.cpp:331, laserMapping.cpp:363 */
+  int32_t lo_min_corr;       /* 10              laserOdometry.cpp:410,484 */
+  int32_t lo_iters_surf;     /* 5               laserOdometry.cpp:415 */
+  int32_t lo_iters_corner;   /* 5 (README says 10) laserOdometry.cpp:489 */
+  /* ---- scan-to-map registration: laserMapping.cpp:37-49,348-479 ---- */
+  float lm_leaf_corner;      /* 0.4             laserMapping.cpp:37 */
+  float lm_leaf_surf;        /* 0.8             laserMapping.cpp:38 */
+  float lm_leaf_outlier;     /* 1.0             laserMapping.cpp:39 */
+  double min_keyframe_dist;  /* 1.0 (squared compare) laserMapping.cpp:43,501-504 */
+  int32_t recent_keyframe_num; /* 50            laserMapping.cpp:48 */
+  int32_t lm_every;          /* 2               laserMapping.cpp:112 */
+  int32_t lm_outer_iters;    /* 2               laserMapping.cpp:360 */
+  int32_t lm_max_iters;      /* 20              laserMapping.cpp:470 */
+  double knn_max_dist;       /* 1.0 (squared)   laserMapping.cpp:376,426 */
+  double line_ratio;         /* 3.0             laserMapping.cpp:403 */
+  double line_half_len;      /* 0.1             laserMapping.cpp:406-407 */
+  double plane_tol;          /* 0.2             laserMapping.cpp:446 */
+  int32_t lm_min_corner;     /* 10              laserMapping.cpp:350 */
+  int32_t lm_min_surf;       /* 100             laserMapping.cpp:350 */
+  int32_t lm_min_map_corner; /* 10              laserMapping.cpp:350 */
+} alego_params;
+
+/* Fill `p` with the reference defaults for an n_scan x horizon_scan sensor.
+ * horizon_scan <= 0 selects the reference geometry 16 x 4000 (ang_res_x 0.09).
+ * For n_scan == 64 the HDL-64E-shaped constants of SURVEY.md §8d config 5 are
+ * used (ang_res_y 26.8/63, ang_bottom 24.8, ground_scan_id 50). */
+static inline void alego_default_params(alego_params* p, int n_scan, int horizon_scan) {
+  const double kPi = 3.14159265358979323846;
+  if (n_scan <= 0) n_scan = 16;
+  p->n_scan = n_scan;
+  if (horizon_scan <= 0) {
+    p->ang_res_x = 0.09;
+    p->horizon_scan = (int32_t)(360.0 / p->ang_res_x + 0.5);
+  } else {
+    p->horizon_scan = horizon_scan;
+    p->ang_res_x = 360.0 / (double)horizon_scan;
+  }
+  if (n_scan == 64) {
+    p->ang_res_y = 26.8 / 63.0;
+    p->ang_bottom = 24.8;
+    p->ground_scan_id = 50;
+  } else {
+    p->ang_res_y = 2.0;
+    p->ang_bottom = 15.0;
+    p->ground_scan_id = 10;
+  }
+  p->laser_type = ALEGO_LASER_UNIFORM;
+  p->sensor_mount_ang = 0.0;
+  p->ground_angle_thres = 10.0;
+  p->seg_alpha_x = p->ang_res_x / 180.0 * kPi; /* ANGLE2RAD, utility.h:48 */
+  p->seg_alpha_y = p->ang_res_y / 180.0 * kPi;
+  p->seg_theta = 1.047;
+  p->seg_valid_point_num = 5;
+  p->seg_valid_line_num = 3;
+  p->seg_big_num = 30;
+  p->near_filter = 0;
+  p->near_thres = 1.0;
+  p->occl_col_diff = 10;
+  p->occl_depth = 0.5;
+  p->parallel_ratio = 0.02;
+  p->occl_f32 = 0;
+  p->n_sectors = 6;
+  p->sector_formula = 0;
+  p->edge_thres = 0.1;
+  p->surf_thres = 0.1;
+  p->n_sharp = 2;
+  p->n_less_sharp = 20;
+  p->n_flat = 4;
+  p->suppress_radius = 5;
+  p->suppress_col_diff = 10;
+  p->less_flat_leaf = 0.4f;
+  p->sort_mode = 0;
+  p->nearest_feature_dist = 25.0;
+  p->ring_window = 2;
+  p->huber_delta = 0.1;
+  p->lo_min_corr = 10;
+  p->lo_iters_surf = 5;
+  p->lo_iters_corner = 5;
+  p->lm_leaf_corner = 0.4f;
+  p->lm_leaf_surf = 0.8f;
+  p->lm_leaf_outlier = 1.0f;
+  p->min_keyframe_dist = 1.0;
+  p->recent_keyframe_num = 50;
+  p->lm_every = 2;
+  p->lm_outer_iters = 2;
+  p->lm_max_iters = 20;
+  p->knn_max_dist = 1.0;
+  p->line_ratio = 3.0;
+  p->line_half_len = 0.1;
+  p->plane_tol = 0.2;
+  p->lm_min_corner = 10;
+  p->lm_min_surf = 100;
+  p->lm_min_map_corner = 10;
+}
+
+/* PointXYZI as it crosses the boundary: the first 16 bytes-worth of the PCL
+ * point (x,y,z at 0/4/8, intensity at 16 in PCL's 32-byte layout) packed to 16 B. */
+typedef struct alego_point {
+  float x, y, z, intensity;
+} alego_point;
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ALEGO_PARAMS_H_ */

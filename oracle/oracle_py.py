@@ -1,0 +1,148 @@
+"""ctypes binding of oracle/liboracle.so — TEST INFRASTRUCTURE.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_lib = None
+_DT = {0: np.float32, 1: np.float64, 2: np.int32, 3: np.uint8}
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        path = os.path.join(_HERE, "liboracle.so")
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} missing — build with `make -C oracle`")
+        L = C.CDLL(path)
+        L.oracle_create.restype = C.c_void_p
+        L.oracle_create.argtypes = [C.c_void_p]
+        L.oracle_destroy.argtypes = [C.c_void_p]
+        for f in ("oracle_lo", "oracle_fe", "oracle_lm"):
+            getattr(L, f).restype = C.c_int
+            getattr(L, f).argtypes = [C.c_void_p]
+        L.oracle_ip.restype = C.c_int
+        L.oracle_ip.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.oracle_process_scan.restype = C.c_int
+        L.oracle_process_scan.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        L.oracle_set_lo_params.argtypes = [C.c_void_p, C.c_void_p]
+        L.oracle_set_lm_params.argtypes = [C.c_void_p, C.c_void_p]
+        L.oracle_get.restype = C.c_int
+        L.oracle_get.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.oracle_voxel_grid.restype = C.c_int
+        L.oracle_voxel_grid.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_int]
+        L.oracle_eval_block.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.oracle_solve.restype = C.c_int
+        L.oracle_solve.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_double, C.c_void_p]
+        L.oracle_knn.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.oracle_eig3.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        for f in ("oracle_atan2f_array", "oracle_hypotf_array", "oracle_libm_atan2f_array", "oracle_libm_hypotf_array"):
+            getattr(L, f).argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        _lib = L
+    return _lib
+
+
+class Oracle:
+    """One IP -> LO -> LM chain of the CPU restatement (stateful like the three nodelets)."""
+
+    def __init__(self, params):
+        self._p = params
+        self._h = lib().oracle_create(C.addressof(params))
+
+    def close(self):
+        if self._h:
+            lib().oracle_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    @staticmethod
+    def _pts(pts):
+        a = np.ascontiguousarray(pts, dtype=np.float32)
+        assert a.ndim == 2 and a.shape[1] == 4
+        return a
+
+    def ip(self, pts):
+        a = self._pts(pts)
+        return lib().oracle_ip(self._h, a.ctypes.data, a.shape[0])
+
+    def fe(self):
+        return lib().oracle_fe(self._h)
+
+    def lo(self):
+        return lib().oracle_lo(self._h)
+
+    def lm(self):
+        return lib().oracle_lm(self._h)
+
+    def process_scan(self, pts, stages=7):
+        a = self._pts(pts)
+        return lib().oracle_process_scan(self._h, a.ctypes.data, a.shape[0], stages)
+
+    def set_lo_params(self, p6):
+        a = np.ascontiguousarray(p6, dtype=np.float64)
+        lib().oracle_set_lo_params(self._h, a.ctypes.data)
+
+    def set_lm_params(self, p6):
+        a = np.ascontiguousarray(p6, dtype=np.float64)
+        lib().oracle_set_lm_params(self._h, a.ctypes.data)
+
+    def get(self, name, cloud=None):
+        ptr, cnt, dt = C.c_void_p(), C.c_int(), C.c_int()
+        r = lib().oracle_get(self._h, name.encode(), C.byref(ptr), C.byref(cnt), C.byref(dt))
+        if r != 0:
+            raise KeyError(name)
+        n = cnt.value
+        dtype = np.dtype(_DT[dt.value])
+        if n == 0 or not ptr.value:
+            out = np.zeros(0, dtype=dtype)
+        else:
+            buf = (C.c_char * (n * dtype.itemsize)).from_address(ptr.value)
+            out = np.frombuffer(buf, dtype=dtype, count=n).copy()
+        if cloud is None:
+            cloud = name in _CLOUDS
+        return out.reshape(-1, 4) if cloud else out
+
+
+_CLOUDS = {"seg_cloud", "outlier", "sharp", "less_sharp", "flat", "less_flat", "surf_last", "corner_last",
+           "lm_corner_map_ds", "lm_surf_map_ds", "lm_corner_map", "lm_surf_map", "lm_corner_ds", "lm_surf_ds",
+           "lm_outlier_ds", "lm_surf_total_ds"}
+
+
+def voxel_grid(pts, leaf, sort_mode=0):
+    a = np.ascontiguousarray(pts, dtype=np.float32)
+    out = np.empty_like(a)
+    n = lib().oracle_voxel_grid(a.ctypes.data, a.shape[0], leaf, sort_mode, out.ctypes.data, a.shape[0])
+    return out[:n].copy()
+
+
+def eval_block(btype, geom13, params6):
+    g = np.ascontiguousarray(geom13, dtype=np.float64)
+    p = np.ascontiguousarray(params6, dtype=np.float64)
+    r = np.zeros(1)
+    J = np.zeros(6)
+    lib().oracle_eval_block(btype, g.ctypes.data, p.ctypes.data, r.ctypes.data, J.ctypes.data)
+    return r[0], J
+
+
+def solve(blocks14, params6, max_iter, huber=0.1):
+    b = np.ascontiguousarray(blocks14, dtype=np.float64)
+    p = np.array(params6, dtype=np.float64)
+    costs = np.zeros(2)
+    code = lib().oracle_solve(b.ctypes.data, b.shape[0], p.ctypes.data, max_iter, huber, costs.ctypes.data)
+    return p, dict(iterations=code & 0xFF, termination=(code >> 8) & 0xFF, successful=code >> 16,
+                   initial_cost=costs[0], final_cost=costs[1])
+
+
+def knn(cloud, queries, k):
+    c = np.ascontiguousarray(cloud, dtype=np.float32)
+    q = np.ascontiguousarray(queries, dtype=np.float32)
+    idx = np.empty((q.shape[0], k), dtype=np.int32)
+    dist = np.empty((q.shape[0], k), dtype=np.float32)
+    lib().oracle_knn(c.ctypes.data, c.shape[0], q.ctypes.data, q.shape[0], k, idx.ctypes.data, dist.ctypes.data)
+    return idx, dist
