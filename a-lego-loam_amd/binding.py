@@ -1,0 +1,289 @@
+"""ctypes binding of the C ABI in include/alego_mi355x.h (libalego_mi355x.so).
+
+Host-side mirror of the reference's node interface: `Handle.ip_process` ~ ImageProjection::pcCB,
+`Handle.lo_process` ~ LaserOdometry::mainLoop body, `Handle.lm_process` ~ LaserMapping::mainLoop
+body, `Handle.scan_process` = the three chained on the device.  There is no CPU fallback: loading
+fails loudly if the HIP library is missing and `Handle()` raises if no gfx950 device is visible.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from .params import AlegoParams, AlegoPoint
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_lib = None
+_DT = {0: np.float32, 1: np.float64, 2: np.int32, 3: np.uint8}
+
+# every symbol include/alego_mi355x.h declares
+EXPORTS = [
+    "alego_create", "alego_destroy", "alego_last_error", "alego_device_count", "alego_params_sizeof",
+    "alego_ip_process", "alego_lo_process", "alego_lm_process", "alego_scan_process",
+    "alego_batch_load", "alego_batch_run", "alego_synchronize", "alego_batch_get_pose", "alego_batch_get_counts",
+    "alego_stream", "alego_set_lo_params", "alego_set_lm_params", "alego_debug_get", "alego_debug_atan2f",
+]
+
+FLAG_LO_INIT, FLAG_FEW_SURF, FLAG_FEW_CORNER, FLAG_LM_SKIPPED, FLAG_LM_FEW_FEATURES, FLAG_LM_KEYFRAME = 1, 2, 4, 8, 16, 32
+
+
+class ScanIn(C.Structure):
+    _fields_ = [("pts", C.c_void_p), ("n", C.c_int32), ("stamp", C.c_double)]
+
+
+class SegOut(C.Structure):
+    _fields_ = [("seg", C.c_void_p), ("seg_cap", C.c_int32), ("m", C.c_int32),
+                ("ground", C.c_void_p), ("col", C.c_void_p), ("range", C.c_void_p),
+                ("ring_start", C.c_void_p), ("ring_end", C.c_void_p), ("orientation", C.c_float * 3),
+                ("outlier", C.c_void_p), ("outlier_cap", C.c_int32), ("n_outlier", C.c_int32),
+                ("label_image", C.c_void_p)]
+
+
+class FeatOut(C.Structure):
+    _fields_ = [("sharp", C.c_void_p), ("sharp_cap", C.c_int32), ("n_sharp", C.c_int32),
+                ("less_sharp", C.c_void_p), ("less_sharp_cap", C.c_int32), ("n_less_sharp", C.c_int32),
+                ("flat", C.c_void_p), ("flat_cap", C.c_int32), ("n_flat", C.c_int32),
+                ("less_flat", C.c_void_p), ("less_flat_cap", C.c_int32), ("n_less_flat", C.c_int32),
+                ("point_label", C.c_void_p)]
+
+
+class Pose(C.Structure):
+    _fields_ = [("t", C.c_double * 3), ("q", C.c_double * 4), ("params", C.c_double * 6), ("valid", C.c_int32)]
+
+    def as_dict(self):
+        return dict(t=np.array(self.t[:]), q=np.array(self.q[:]), params=np.array(self.params[:]), valid=int(self.valid))
+
+
+def lib_path():
+    return os.path.join(_HERE, "libalego_mi355x.so")
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        path = lib_path()
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} missing: the HIP extension is not built (run __graft_entry__.build()); "
+                               "there is no CPU fallback")
+        L = C.CDLL(path)
+        L.alego_create.restype = C.c_int
+        L.alego_create.argtypes = [C.POINTER(AlegoParams), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        L.alego_destroy.argtypes = [C.c_void_p]
+        L.alego_last_error.restype = C.c_char_p
+        L.alego_last_error.argtypes = [C.c_void_p]
+        L.alego_device_count.restype = C.c_int
+        L.alego_params_sizeof.restype = C.c_int
+        L.alego_ip_process.restype = C.c_int
+        L.alego_ip_process.argtypes = [C.c_void_p, C.POINTER(ScanIn), C.POINTER(SegOut)]
+        L.alego_lo_process.restype = C.c_int
+        L.alego_lo_process.argtypes = [C.c_void_p, C.POINTER(SegOut), C.POINTER(FeatOut), C.POINTER(Pose)]
+        L.alego_lm_process.restype = C.c_int
+        L.alego_lm_process.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
+                                       C.POINTER(Pose), C.POINTER(Pose)]
+        L.alego_scan_process.restype = C.c_int
+        L.alego_scan_process.argtypes = [C.c_void_p, C.c_int, C.POINTER(ScanIn), C.c_int, C.POINTER(SegOut),
+                                         C.POINTER(FeatOut), C.POINTER(Pose), C.POINTER(Pose)]
+        L.alego_batch_load.restype = C.c_int
+        L.alego_batch_load.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int32]
+        L.alego_batch_run.restype = C.c_int
+        L.alego_batch_run.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.alego_synchronize.restype = C.c_int
+        L.alego_synchronize.argtypes = [C.c_void_p]
+        L.alego_batch_get_pose.restype = C.c_int
+        L.alego_batch_get_pose.argtypes = [C.c_void_p, C.c_int, C.POINTER(Pose), C.POINTER(Pose)]
+        L.alego_batch_get_counts.restype = C.c_int
+        L.alego_batch_get_counts.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        L.alego_stream.restype = C.c_void_p
+        L.alego_stream.argtypes = [C.c_void_p]
+        L.alego_set_lo_params.restype = C.c_int
+        L.alego_set_lo_params.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.alego_set_lm_params.restype = C.c_int
+        L.alego_set_lm_params.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.alego_debug_get.restype = C.c_int
+        L.alego_debug_get.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.alego_debug_atan2f.restype = C.c_int
+        L.alego_debug_atan2f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        if L.alego_params_sizeof() != C.sizeof(AlegoParams):
+            raise RuntimeError("alego_params layout mismatch between params.py and include/alego_params.h")
+        _lib = L
+    return _lib
+
+
+class AlegoError(RuntimeError):
+    pass
+
+
+_CLOUDS = {"seg_cloud", "outlier", "sharp", "less_sharp", "flat", "less_flat"}
+
+
+class Handle:
+    """One alego_handle: `n_slots` independent streams advanced in lock-step on one GPU."""
+
+    def __init__(self, params: AlegoParams, device: int = 0, n_slots: int = 1, ring_len: int = 1):
+        L = lib()
+        self.params = params
+        self.N = params.n_scan * params.horizon_scan
+        self.n_slots, self.ring_len = n_slots, ring_len
+        h = C.c_void_p()
+        rc = L.alego_create(C.byref(params), device, n_slots, ring_len, C.byref(h))
+        if rc != 0:
+            raise AlegoError(f"alego_create failed ({rc}): no gfx950 device / HIP error — there is no CPU fallback")
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().alego_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def _check(self, rc, what):
+        if rc < 0:
+            raise AlegoError(f"{what} failed ({rc}): {lib().alego_last_error(self._h).decode()}")
+        return rc
+
+    # ---- buffers ----
+    def _seg_bufs(self, want_labels):
+        N, NS = self.N, self.params.n_scan
+        b = dict(seg=np.empty((N, 4), np.float32), ground=np.empty(N, np.uint8), col=np.empty(N, np.int32),
+                 range=np.empty(N, np.float32), ring_start=np.empty(NS, np.int32), ring_end=np.empty(NS, np.int32),
+                 outlier=np.empty((N, 4), np.float32), label_image=np.empty(N, np.int32) if want_labels else None)
+        s = SegOut()
+        s.seg, s.seg_cap = b["seg"].ctypes.data, N
+        s.ground, s.col, s.range = b["ground"].ctypes.data, b["col"].ctypes.data, b["range"].ctypes.data
+        s.ring_start, s.ring_end = b["ring_start"].ctypes.data, b["ring_end"].ctypes.data
+        s.outlier, s.outlier_cap = b["outlier"].ctypes.data, N
+        s.label_image = b["label_image"].ctypes.data if want_labels else None
+        return s, b
+
+    @staticmethod
+    def _seg_result(s, b):
+        m, no = s.m, s.n_outlier
+        return dict(seg=b["seg"][:m].copy(), ground=b["ground"][:m].copy(), col=b["col"][:m].copy(), range=b["range"][:m].copy(),
+                    ring_start=b["ring_start"].copy(), ring_end=b["ring_end"].copy(), orientation=np.array(s.orientation[:], np.float32),
+                    outlier=b["outlier"][:no].copy(), label_image=None if b["label_image"] is None else b["label_image"].copy())
+
+    def _feat_bufs(self, want_labels=True):
+        N = self.N
+        caps = (N, N, N, N)
+        b = dict(sharp=np.empty((caps[0], 4), np.float32), less_sharp=np.empty((caps[1], 4), np.float32),
+                 flat=np.empty((caps[2], 4), np.float32), less_flat=np.empty((caps[3], 4), np.float32),
+                 point_label=np.empty(N, np.int32) if want_labels else None)
+        f = FeatOut()
+        f.sharp, f.sharp_cap = b["sharp"].ctypes.data, caps[0]
+        f.less_sharp, f.less_sharp_cap = b["less_sharp"].ctypes.data, caps[1]
+        f.flat, f.flat_cap = b["flat"].ctypes.data, caps[2]
+        f.less_flat, f.less_flat_cap = b["less_flat"].ctypes.data, caps[3]
+        f.point_label = b["point_label"].ctypes.data if want_labels else None
+        return f, b
+
+    @staticmethod
+    def _feat_result(f, b, m=None):
+        return dict(sharp=b["sharp"][:f.n_sharp].copy(), less_sharp=b["less_sharp"][:f.n_less_sharp].copy(),
+                    flat=b["flat"][:f.n_flat].copy(), less_flat=b["less_flat"][:f.n_less_flat].copy(),
+                    point_label=None if b["point_label"] is None else (b["point_label"][:m].copy() if m is not None else b["point_label"].copy()))
+
+    @staticmethod
+    def _scan(pts):
+        a = np.ascontiguousarray(pts, dtype=np.float32)
+        assert a.ndim == 2 and a.shape[1] == 4
+        s = ScanIn()
+        s.pts, s.n, s.stamp = a.ctypes.data, a.shape[0], 0.0
+        return s, a
+
+    # ---- nodelet-shaped entry points ----
+    def ip_process(self, pts, want_labels=True):
+        sin, keep = self._scan(pts)
+        s, b = self._seg_bufs(want_labels)
+        self._check(lib().alego_ip_process(self._h, C.byref(sin), C.byref(s)), "alego_ip_process")
+        return self._seg_result(s, b)
+
+    def lo_process(self, seg):
+        """seg: dict as returned by ip_process (what LO receives on /segmented_cloud + /seg_info)."""
+        m = seg["seg"].shape[0]
+        s = SegOut()
+        arrs = [np.ascontiguousarray(seg["seg"], np.float32), np.ascontiguousarray(seg["ground"], np.uint8),
+                np.ascontiguousarray(seg["col"], np.int32), np.ascontiguousarray(seg["range"], np.float32),
+                np.ascontiguousarray(seg["ring_start"], np.int32), np.ascontiguousarray(seg["ring_end"], np.int32)]
+        s.seg, s.seg_cap, s.m = arrs[0].ctypes.data, m, m
+        s.ground, s.col, s.range = arrs[1].ctypes.data, arrs[2].ctypes.data, arrs[3].ctypes.data
+        s.ring_start, s.ring_end = arrs[4].ctypes.data, arrs[5].ctypes.data
+        f, fb = self._feat_bufs()
+        odom = Pose()
+        flags = self._check(lib().alego_lo_process(self._h, C.byref(s), C.byref(f), C.byref(odom)), "alego_lo_process")
+        return flags, self._feat_result(f, fb, m), odom.as_dict()
+
+    def lm_process(self, corner_last, surf_last, outlier, odom):
+        c = np.ascontiguousarray(corner_last, np.float32)
+        s = np.ascontiguousarray(surf_last, np.float32)
+        o = np.ascontiguousarray(outlier, np.float32)
+        po, pm = Pose(), Pose()
+        po.t[:] = list(odom["t"]); po.q[:] = list(odom["q"]); po.valid = 1
+        flags = self._check(lib().alego_lm_process(self._h, c.ctypes.data, c.shape[0], s.ctypes.data, s.shape[0],
+                                                    o.ctypes.data, o.shape[0], C.byref(po), C.byref(pm)), "alego_lm_process")
+        return flags, pm.as_dict()
+
+    def scan_process(self, pts, stages=7, slot=0, want_outputs=False):
+        sin, keep = self._scan(pts)
+        odom, mp = Pose(), Pose()
+        if want_outputs:
+            s, b = self._seg_bufs(True)
+            f, fb = self._feat_bufs()
+            flags = self._check(lib().alego_scan_process(self._h, slot, C.byref(sin), stages, C.byref(s), C.byref(f),
+                                                          C.byref(odom), C.byref(mp)), "alego_scan_process")
+            return flags, odom.as_dict(), mp.as_dict(), self._seg_result(s, b), self._feat_result(f, fb, s.m)
+        flags = self._check(lib().alego_scan_process(self._h, slot, C.byref(sin), stages, None, None, C.byref(odom), C.byref(mp)),
+                            "alego_scan_process")
+        return flags, odom.as_dict(), mp.as_dict()
+
+    # ---- batch path ----
+    def batch_load(self, slot, ring_pos, pts):
+        a = np.ascontiguousarray(pts, dtype=np.float32)
+        self._check(lib().alego_batch_load(self._h, slot, ring_pos, a.ctypes.data, a.shape[0]), "alego_batch_load")
+
+    def batch_run(self, first_pos, n_scans, stages=7, sync=True):
+        self._check(lib().alego_batch_run(self._h, first_pos, n_scans, stages, 1 if sync else 0), "alego_batch_run")
+
+    def synchronize(self):
+        self._check(lib().alego_synchronize(self._h), "alego_synchronize")
+
+    def batch_get_pose(self, slot=0):
+        odom, mp = Pose(), Pose()
+        flags = self._check(lib().alego_batch_get_pose(self._h, slot, C.byref(odom), C.byref(mp)), "alego_batch_get_pose")
+        return flags, odom.as_dict(), mp.as_dict()
+
+    def batch_get_counts(self, slot=0):
+        out = np.zeros(16, np.int32)
+        self._check(lib().alego_batch_get_counts(self._h, slot, out.ctypes.data, 16), "alego_batch_get_counts")
+        keys = ["P", "M", "O", "Qc", "Fc", "Qs", "Fs", "n_surf_corr", "n_corner_corr", "Kraw_c", "Kraw_s", "Kds_c", "Kds_s", "Lc", "Ls"]
+        return dict(zip(keys, out.tolist()))
+
+    def stream(self):
+        return lib().alego_stream(self._h)
+
+    # ---- test access ----
+    def set_lo_params(self, p6, slot=0):
+        a = np.ascontiguousarray(p6, np.float64)
+        self._check(lib().alego_set_lo_params(self._h, slot, a.ctypes.data), "alego_set_lo_params")
+
+    def set_lm_params(self, p6, slot=0):
+        a = np.ascontiguousarray(p6, np.float64)
+        self._check(lib().alego_set_lm_params(self._h, slot, a.ctypes.data), "alego_set_lm_params")
+
+    def debug_get(self, name, slot=0, cap_bytes=None):
+        cap = cap_bytes or (self.N * 64 + 4096)
+        buf = np.empty(cap, np.uint8)
+        cnt, dt = C.c_int(), C.c_int()
+        self._check(lib().alego_debug_get(self._h, slot, name.encode(), buf.ctypes.data, cap, C.byref(cnt), C.byref(dt)),
+                    f"alego_debug_get({name})")
+        dtype = np.dtype(_DT[dt.value])
+        out = np.frombuffer(buf.tobytes()[:cnt.value * dtype.itemsize], dtype=dtype).copy()
+        return out.reshape(-1, 4) if (name in _CLOUDS or name.startswith("lm_") and name.endswith(("_ds", "_map"))) else out
+
+    def atan2f(self, y, x):
+        y = np.ascontiguousarray(y, np.float32)
+        x = np.ascontiguousarray(x, np.float32)
+        out = np.empty_like(y)
+        self._check(lib().alego_debug_atan2f(self._h, y.ctypes.data, x.ctypes.data, out.ctypes.data, y.size), "alego_debug_atan2f")
+        return out

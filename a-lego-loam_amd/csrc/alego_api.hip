@@ -1,0 +1,408 @@
+// alego_api.hip — host side of the C ABI (include/alego_mi355x.h): HBM allocation, the
+// per-handle HIP stream, kernel sequencing and the nodelet-shaped entry points.
+// No numerics live here and there is no CPU fallback.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/alego_mi355x.h"
+#include "dev_common.h"
+#include "lm_host.h"
+
+void launch_ip(const DevCtx& d, int ring_pos, bool want_labels, hipStream_t st);
+void launch_fe(const DevCtx& d, int cur, hipStream_t st);
+void launch_lo(const DevCtx& d, int cur, hipStream_t st);
+void launch_atan2f_probe(const float* y, const float* x, float* out, int n, int mode, hipStream_t st);
+
+struct alego_handle {
+  alego_params P;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  DevCtx d;
+  std::vector<void*> allocs;
+  std::string err;
+  long scan_counter = 0;  // all slots advance in lock-step; feature double-buffer index = scan_counter & 1
+  LmHost* lm = nullptr;
+};
+
+namespace {
+
+#define HIP_TRY(h, call)                                                                       \
+  do {                                                                                         \
+    hipError_t e_ = (call);                                                                    \
+    if (e_ != hipSuccess) {                                                                    \
+      (h)->err = std::string(#call) + ": " + hipGetErrorString(e_);                            \
+      return ALEGO_ERR_HIP;                                                                    \
+    }                                                                                          \
+  } while (0)
+
+template <class T>
+int dalloc(alego_handle* h, T** p, size_t count, bool zero = true) {
+  void* q = nullptr;
+  size_t bytes = count * sizeof(T);
+  if (bytes == 0) bytes = sizeof(T);
+  hipError_t e = hipMalloc(&q, bytes);
+  if (e != hipSuccess) { h->err = std::string("hipMalloc: ") + hipGetErrorString(e); return ALEGO_ERR_HIP; }
+  h->allocs.push_back(q);
+  if (zero) { e = hipMemset(q, 0, bytes); if (e != hipSuccess) { h->err = "hipMemset failed"; return ALEGO_ERR_HIP; } }
+  *p = (T*)q;
+  return 0;
+}
+
+DevCtx view(const alego_handle* h, int slot0, int n) {
+  DevCtx d = h->d;
+  d.slot0 = slot0;
+  d.n_launch = n;
+  return d;
+}
+
+int check_slot(alego_handle* h, int slot) {
+  if (!h) return ALEGO_ERR_ARG;
+  if (slot < 0 || slot >= h->d.n_slots) { h->err = "slot out of range"; return ALEGO_ERR_ARG; }
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int alego_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+int alego_params_sizeof(void) { return (int)sizeof(alego_params); }
+const char* alego_last_error(const alego_handle* h) { return h ? h->err.c_str() : "null handle"; }
+void* alego_stream(alego_handle* h) { return h ? (void*)h->stream : nullptr; }
+
+int alego_create(const alego_params* params, int device, int n_slots, int ring_len, alego_handle** out) {
+  if (!params || !out) return ALEGO_ERR_ARG;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return ALEGO_ERR_NO_DEVICE;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) return ALEGO_ERR_NO_DEVICE;
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    std::fprintf(stderr, "alego_create: device %d is %s, this library is built for gfx950 only\n", device, prop.gcnArchName);
+    return ALEGO_ERR_NO_DEVICE;
+  }
+  if (n_slots <= 0) n_slots = 1;
+  if (ring_len <= 0) ring_len = 1;
+  if (params->n_scan < 1 || params->n_scan > 64 || params->horizon_scan < 64 || params->horizon_scan > 4096) return ALEGO_ERR_ARG;
+  alego_handle* h = new alego_handle();
+  h->P = *params;
+  h->device = device;
+  if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&h->stream) != hipSuccess) { delete h; return ALEGO_ERR_HIP; }
+  DevCtx& d = h->d;
+  std::memset(&d, 0, sizeof(d));
+  d.P = *params;
+  d.n_slots = n_slots; d.ring_len = ring_len; d.slot0 = 0; d.n_launch = n_slots;
+  d.NS = params->n_scan; d.H = params->horizon_scan; d.N = d.NS * d.H; d.Pcap = d.N;
+  d.cap_sharp = params->n_sharp * params->n_sectors;
+  d.cap_lsharp = params->n_less_sharp * params->n_sectors;
+  d.cap_flat = params->n_flat * params->n_sectors;
+  d.st_stride = d.cap_sharp + d.cap_lsharp + d.cap_flat + d.H;
+  d.sin_ax = std::sin(params->seg_alpha_x); d.cos_ax = std::cos(params->seg_alpha_x);  // imageProjection.cpp:269
+  d.sin_ay = std::sin(params->seg_alpha_y); d.cos_ay = std::cos(params->seg_alpha_y);
+  const size_t B = n_slots, N = d.N, NS = d.NS;
+  int rc = 0;
+  rc |= dalloc(h, &d.in_pts, B * ring_len * d.Pcap, false);
+  rc |= dalloc(h, &d.in_n, B * ring_len);
+  rc |= dalloc(h, &d.owner, B * N); rc |= dalloc(h, &d.range_img, B * N); rc |= dalloc(h, &d.flag_img, B * N);
+  rc |= dalloc(h, &d.parent, B * N); rc |= dalloc(h, &d.cc_size, B * N); rc |= dalloc(h, &d.cc_rows, B * N);
+  rc |= dalloc(h, &d.label_img, B * N); rc |= dalloc(h, &d.cc_label, B * N); rc |= dalloc(h, &d.row_cnt, B * NS * 4);
+  rc |= dalloc(h, &d.scal, B * SC_COUNT);
+  rc |= dalloc(h, &d.seg_pts, B * N); rc |= dalloc(h, &d.seg_ground, B * N); rc |= dalloc(h, &d.seg_col, B * N);
+  rc |= dalloc(h, &d.seg_range, B * N); rc |= dalloc(h, &d.ring_start, B * NS); rc |= dalloc(h, &d.ring_end, B * NS);
+  rc |= dalloc(h, &d.ori, B * 4); rc |= dalloc(h, &d.outlier, B * N);
+  rc |= dalloc(h, &d.cd, B * N); rc |= dalloc(h, &d.picked0, B * N); rc |= dalloc(h, &d.plabel, B * N);
+  rc |= dalloc(h, &d.st_idx, B * NS * d.st_stride); rc |= dalloc(h, &d.st_cnt, B * NS * 8);
+  rc |= dalloc(h, &d.st_lfds, B * NS * d.H);
+  d.fcap[F_SHARP] = d.cap_sharp * d.NS; d.fcap[F_LSHARP] = d.cap_lsharp * d.NS; d.fcap[F_FLAT] = d.cap_flat * d.NS; d.fcap[F_LFLAT] = d.N;
+  for (int k = 0; k < 4; ++k) rc |= dalloc(h, &d.feat[k], B * 2 * d.fcap[k]);
+  for (int k = 0; k < 3; ++k) rc |= dalloc(h, &d.feat_idx[k], B * 2 * d.fcap[k]);
+  rc |= dalloc(h, &d.feat_cnt, B * 2 * 4); rc |= dalloc(h, &d.ring_off, B * 2 * 2 * (NS + 1));
+  d.lo_qcap_surf = d.fcap[F_FLAT]; d.lo_qcap_corner = d.fcap[F_SHARP];
+  rc |= dalloc(h, &d.lo_corr, B * (d.lo_qcap_surf + d.lo_qcap_corner) * 4);
+  rc |= dalloc(h, &d.lo_state, B * LO_STATE_N);
+  rc |= dalloc(h, &d.poses, B * 16);
+  if (rc) { *out = h; int e = ALEGO_ERR_HIP; std::fprintf(stderr, "alego_create: %s\n", h->err.c_str()); alego_destroy(h); *out = nullptr; return e; }
+  // r_w_cur_ = identity, pose quaternions = identity (laserOdometry.cpp:46-47)
+  std::vector<double> st(B * LO_STATE_N, 0.0), po(B * 16, 0.0);
+  for (size_t b = 0; b < B; ++b) {
+    st[b * LO_STATE_N + LS_RW + 0] = st[b * LO_STATE_N + LS_RW + 4] = st[b * LO_STATE_N + LS_RW + 8] = 1.0;
+    po[b * 16 + 3] = 1.0; po[b * 16 + 10] = 1.0;
+  }
+  hipMemcpy(d.lo_state, st.data(), st.size() * sizeof(double), hipMemcpyHostToDevice);
+  hipMemcpy(d.poses, po.data(), po.size() * sizeof(double), hipMemcpyHostToDevice);
+  h->lm = lm_host_create(h->P, d, n_slots, h->stream, &h->err);
+  if (!h->lm) { std::fprintf(stderr, "alego_create: %s\n", h->err.c_str()); alego_destroy(h); return ALEGO_ERR_HIP; }
+  *out = h;
+  return ALEGO_OK;
+}
+
+void alego_destroy(alego_handle* h) {
+  if (!h) return;
+  hipSetDevice(h->device);
+  if (h->stream) hipStreamSynchronize(h->stream);
+  if (h->lm) lm_host_destroy(h->lm);
+  for (void* p : h->allocs) hipFree(p);
+  if (h->stream) hipStreamDestroy(h->stream);
+  delete h;
+}
+
+int alego_synchronize(alego_handle* h) {
+  if (!h) return ALEGO_ERR_ARG;
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+int alego_batch_load(alego_handle* h, int slot, int ring_pos, const alego_point* pts, int32_t n) {
+  if (int r = check_slot(h, slot)) return r;
+  if (ring_pos < 0 || ring_pos >= h->d.ring_len || n < 0) { h->err = "ring_pos/n out of range"; return ALEGO_ERR_ARG; }
+  if (n > h->d.Pcap) { h->err = "scan larger than n_scan*horizon_scan"; return ALEGO_ERR_CAPACITY; }
+  hipSetDevice(h->device);
+  float4* dst = h->d.in_pts + ((size_t)slot * h->d.ring_len + ring_pos) * h->d.Pcap;
+  HIP_TRY(h, hipMemcpyAsync(dst, pts, (size_t)n * sizeof(alego_point), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(h->d.in_n + slot * h->d.ring_len + ring_pos, &n, sizeof(int), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+// enqueue IP -> FE -> LO -> LM for slots [slot0, slot0+n) on ring position `pos`
+static int enqueue_scan(alego_handle* h, int slot0, int n, int pos, int stages, bool want_labels) {
+  const DevCtx d = view(h, slot0, n);
+  const int cur = (int)(h->scan_counter & 1);
+  if (stages & 1) launch_ip(d, pos, want_labels, h->stream);
+  if (stages & 2) { launch_fe(d, cur, h->stream); launch_lo(d, cur, h->stream); }
+  if ((stages & 4) && (stages & 2)) { if (int r = lm_host_enqueue(h->lm, d, cur, &h->err)) return r; }
+  ++h->scan_counter;
+  HIP_TRY(h, hipGetLastError());
+  return 0;
+}
+
+int alego_batch_run(alego_handle* h, int first_pos, int n_scans, int stages, int sync) {
+  if (!h) return ALEGO_ERR_ARG;
+  hipSetDevice(h->device);
+  for (int s = 0; s < n_scans; ++s) {
+    const int pos = ((first_pos + s) % h->d.ring_len + h->d.ring_len) % h->d.ring_len;
+    if (int r = enqueue_scan(h, 0, h->d.n_slots, pos, stages, false)) return r;
+  }
+  if (sync) HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+static int fetch_pose(alego_handle* h, int slot, alego_pose* odom, alego_pose* map_pose) {
+  double po[16], st[LO_STATE_N];
+  int sc[SC_COUNT];
+  HIP_TRY(h, hipMemcpyAsync(po, h->d.poses + (size_t)slot * 16, sizeof(po), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(st, h->d.lo_state + (size_t)slot * LO_STATE_N, sizeof(st), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(sc, h->d.scal + (size_t)slot * SC_COUNT, sizeof(sc), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  if (odom) {
+    for (int i = 0; i < 3; ++i) odom->t[i] = po[i];
+    for (int i = 0; i < 4; ++i) odom->q[i] = po[3 + i];
+    for (int i = 0; i < 6; ++i) odom->params[i] = st[LS_PARAMS + i];
+    odom->valid = sc[SC_ODOM_VALID];
+  }
+  if (map_pose) {
+    for (int i = 0; i < 3; ++i) map_pose->t[i] = po[7 + i];
+    for (int i = 0; i < 4; ++i) map_pose->q[i] = po[10 + i];
+    lm_host_get_params(h->lm, slot, map_pose->params);
+    map_pose->valid = sc[SC_ODOM_VALID];
+  }
+  return sc[SC_LO_FLAGS] | (sc[SC_LM_FLAGS]);
+}
+
+int alego_batch_get_pose(alego_handle* h, int slot, alego_pose* odom, alego_pose* map_pose) {
+  if (int r = check_slot(h, slot)) return r;
+  hipSetDevice(h->device);
+  return fetch_pose(h, slot, odom, map_pose);
+}
+
+int alego_batch_get_counts(alego_handle* h, int slot, int32_t* out, int cap) {
+  if (int r = check_slot(h, slot)) return r;
+  hipSetDevice(h->device);
+  int sc[SC_COUNT], fc[8];
+  HIP_TRY(h, hipMemcpyAsync(sc, h->d.scal + (size_t)slot * SC_COUNT, sizeof(sc), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(fc, h->d.feat_cnt + (size_t)slot * 8, sizeof(fc), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  const int cur = (int)((h->scan_counter + 1) & 1);  // buffer written by the last processed scan
+  int v[16] = {sc[SC_PVALID], sc[SC_M], sc[SC_NOUT], fc[cur * 4 + 0], fc[cur * 4 + 1], fc[cur * 4 + 2], fc[cur * 4 + 3],
+               sc[SC_LO_NSURF], sc[SC_LO_NCORNER], 0, 0, 0, 0, 0, 0, 0};
+  lm_host_get_counts(h->lm, slot, v + 9);
+  for (int i = 0; i < cap && i < 16; ++i) out[i] = v[i];
+  return 0;
+}
+
+static int download_seg(alego_handle* h, int slot, alego_seg_out* out) {
+  const DevCtx& d = h->d;
+  int sc[SC_COUNT];
+  HIP_TRY(h, hipMemcpyAsync(sc, d.scal + (size_t)slot * SC_COUNT, sizeof(sc), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  const int M = sc[SC_M], NO = sc[SC_NOUT];
+  out->m = M; out->n_outlier = NO;
+  if (M > out->seg_cap || NO > out->outlier_cap) { h->err = "seg/outlier capacity too small"; return ALEGO_ERR_CAPACITY; }
+  const size_t base = (size_t)slot * d.N;
+  if (out->seg) HIP_TRY(h, hipMemcpyAsync(out->seg, d.seg_pts + base, (size_t)M * 16, hipMemcpyDeviceToHost, h->stream));
+  if (out->ground) HIP_TRY(h, hipMemcpyAsync(out->ground, d.seg_ground + base, (size_t)M, hipMemcpyDeviceToHost, h->stream));
+  if (out->col) HIP_TRY(h, hipMemcpyAsync(out->col, d.seg_col + base, (size_t)M * 4, hipMemcpyDeviceToHost, h->stream));
+  if (out->range) HIP_TRY(h, hipMemcpyAsync(out->range, d.seg_range + base, (size_t)M * 4, hipMemcpyDeviceToHost, h->stream));
+  if (out->ring_start) HIP_TRY(h, hipMemcpyAsync(out->ring_start, d.ring_start + (size_t)slot * d.NS, d.NS * 4, hipMemcpyDeviceToHost, h->stream));
+  if (out->ring_end) HIP_TRY(h, hipMemcpyAsync(out->ring_end, d.ring_end + (size_t)slot * d.NS, d.NS * 4, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(out->orientation, d.ori + (size_t)slot * 4, 12, hipMemcpyDeviceToHost, h->stream));
+  if (out->outlier) HIP_TRY(h, hipMemcpyAsync(out->outlier, d.outlier + base, (size_t)NO * 16, hipMemcpyDeviceToHost, h->stream));
+  if (out->label_image) HIP_TRY(h, hipMemcpyAsync(out->label_image, d.label_img + base, (size_t)d.N * 4, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+static int download_feat(alego_handle* h, int slot, int cur, alego_feat_out* f) {
+  const DevCtx& d = h->d;
+  int fc[4], M;
+  HIP_TRY(h, hipMemcpyAsync(fc, d.feat_cnt + ((size_t)slot * 2 + cur) * 4, sizeof(fc), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(&M, d.scal + (size_t)slot * SC_COUNT + SC_M, 4, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  f->n_sharp = fc[0]; f->n_less_sharp = fc[1]; f->n_flat = fc[2]; f->n_less_flat = fc[3];
+  if (fc[0] > f->sharp_cap || fc[1] > f->less_sharp_cap || fc[2] > f->flat_cap || fc[3] > f->less_flat_cap) { h->err = "feature capacity too small"; return ALEGO_ERR_CAPACITY; }
+  alego_point* dst[4] = {f->sharp, f->less_sharp, f->flat, f->less_flat};
+  for (int k = 0; k < 4; ++k)
+    if (dst[k]) HIP_TRY(h, hipMemcpyAsync(dst[k], d.feat[k] + ((size_t)slot * 2 + cur) * d.fcap[k], (size_t)fc[k] * 16, hipMemcpyDeviceToHost, h->stream));
+  if (f->point_label) HIP_TRY(h, hipMemcpyAsync(f->point_label, d.plabel + (size_t)slot * d.N, (size_t)M * 4, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+int alego_ip_process(alego_handle* h, const alego_scan_in* in, alego_seg_out* out) {
+  if (!h || !in || !out) return ALEGO_ERR_ARG;
+  hipSetDevice(h->device);
+  if (int r = alego_batch_load(h, 0, 0, in->pts, in->n)) return r;
+  const DevCtx d = view(h, 0, 1);
+  launch_ip(d, 0, out->label_image != nullptr, h->stream);
+  HIP_TRY(h, hipGetLastError());
+  return download_seg(h, 0, out);
+}
+
+int alego_lo_process(alego_handle* h, const alego_seg_out* in, alego_feat_out* feat, alego_pose* odom) {
+  if (!h || !in) return ALEGO_ERR_ARG;
+  hipSetDevice(h->device);
+  const DevCtx& d = h->d;
+  if (in->m > d.N) { h->err = "segmented cloud larger than n_scan*horizon_scan"; return ALEGO_ERR_CAPACITY; }
+  const size_t M = in->m;
+  HIP_TRY(h, hipMemcpyAsync(d.seg_pts, in->seg, M * 16, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(d.seg_ground, in->ground, M, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(d.seg_col, in->col, M * 4, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(d.seg_range, in->range, M * 4, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(d.ring_start, in->ring_start, d.NS * 4, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(d.ring_end, in->ring_end, d.NS * 4, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(d.scal + SC_M, &in->m, 4, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  const int cur = (int)(h->scan_counter & 1);
+  if (int r = enqueue_scan(h, 0, 1, 0, 2, false)) return r;
+  if (feat) { if (int r = download_feat(h, 0, cur, feat)) return r; }
+  return fetch_pose(h, 0, odom, nullptr) & 7;
+}
+
+int alego_lm_process(alego_handle* h, const alego_point* corner_last, int32_t n_corner, const alego_point* surf_last,
+                     int32_t n_surf, const alego_point* outlier, int32_t n_outlier, const alego_pose* odom, alego_pose* map_pose) {
+  if (!h || !odom) return ALEGO_ERR_ARG;
+  hipSetDevice(h->device);
+  return lm_host_process_host(h->lm, h->d, corner_last, n_corner, surf_last, n_surf, outlier, n_outlier, odom, map_pose, &h->err);
+}
+
+int alego_scan_process(alego_handle* h, int slot, const alego_scan_in* in, int stages, alego_seg_out* seg,
+                       alego_feat_out* feat, alego_pose* odom, alego_pose* map_pose) {
+  if (int r = check_slot(h, slot)) return r;
+  if (!in) return ALEGO_ERR_ARG;
+  hipSetDevice(h->device);
+  if (int r = alego_batch_load(h, slot, 0, in->pts, in->n)) return r;
+  const int cur = (int)(h->scan_counter & 1);
+  if (int r = enqueue_scan(h, slot, 1, 0, stages, seg && seg->label_image)) return r;
+  if (seg) { if (int r = download_seg(h, slot, seg)) return r; }
+  if (feat && (stages & 2)) { if (int r = download_feat(h, slot, cur, feat)) return r; }
+  return fetch_pose(h, slot, odom, map_pose);
+}
+
+int alego_set_lo_params(alego_handle* h, int slot, const double* p6) {
+  if (int r = check_slot(h, slot)) return r;
+  hipSetDevice(h->device);
+  HIP_TRY(h, hipMemcpyAsync(h->d.lo_state + (size_t)slot * LO_STATE_N + LS_PARAMS, p6, 48, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return 0;
+}
+int alego_set_lm_params(alego_handle* h, int slot, const double* p6) {
+  if (int r = check_slot(h, slot)) return r;
+  hipSetDevice(h->device);
+  return lm_host_set_params(h->lm, slot, p6, &h->err);
+}
+
+int alego_debug_atan2f(alego_handle* h, const float* y, const float* x, float* out, int n) {
+  if (!h) return ALEGO_ERR_ARG;
+  hipSetDevice(h->device);
+  float *dy, *dx, *dout;
+  HIP_TRY(h, hipMalloc((void**)&dy, n * 4)); HIP_TRY(h, hipMalloc((void**)&dx, n * 4)); HIP_TRY(h, hipMalloc((void**)&dout, n * 4));
+  HIP_TRY(h, hipMemcpy(dy, y, n * 4, hipMemcpyHostToDevice)); HIP_TRY(h, hipMemcpy(dx, x, n * 4, hipMemcpyHostToDevice));
+  launch_atan2f_probe(dy, dx, dout, n, 0, h->stream);
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  HIP_TRY(h, hipMemcpy(out, dout, n * 4, hipMemcpyDeviceToHost));
+  hipFree(dy); hipFree(dx); hipFree(dout);
+  return 0;
+}
+
+int alego_debug_get(alego_handle* h, int slot, const char* name, void* out, int cap_bytes, int* count, int* dtype) {
+  if (int r = check_slot(h, slot)) return r;
+  hipSetDevice(h->device);
+  const DevCtx& d = h->d;
+  int sc[SC_COUNT];
+  HIP_TRY(h, hipMemcpyAsync(sc, d.scal + (size_t)slot * SC_COUNT, sizeof(sc), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  const std::string s(name);
+  const size_t base = (size_t)slot * d.N;
+  const int M = sc[SC_M];
+  const int cur = (int)((h->scan_counter + 1) & 1);  // buffer written by the last processed scan
+  int fc[8];
+  HIP_TRY(h, hipMemcpy(fc, d.feat_cnt + (size_t)slot * 8, sizeof(fc), hipMemcpyDeviceToHost));
+  const void* src = nullptr;
+  size_t n = 0;
+  int dt = 0, esz = 4;
+  auto set = [&](const void* p, size_t cnt, int t) { src = p; n = cnt; dt = t; esz = t == 1 ? 8 : t == 3 ? 1 : 4; };
+  if (s == "range_img") set(d.range_img + base, d.N, 0);
+  else if (s == "label_img") set(d.label_img + base, d.N, 2);
+  else if (s == "flag_img") set(d.flag_img + base, d.N, 3);
+  else if (s == "owner") set(d.owner + base, d.N, 2);
+  else if (s == "parent") set(d.parent + base, d.N, 2);
+  else if (s == "seg_cloud") set(d.seg_pts + base, (size_t)M * 4, 0);
+  else if (s == "outlier") set(d.outlier + base, (size_t)sc[SC_NOUT] * 4, 0);
+  else if (s == "seg_ground") set(d.seg_ground + base, M, 3);
+  else if (s == "seg_col") set(d.seg_col + base, M, 2);
+  else if (s == "seg_range") set(d.seg_range + base, M, 0);
+  else if (s == "ring_start") set(d.ring_start + (size_t)slot * d.NS, d.NS, 2);
+  else if (s == "ring_end") set(d.ring_end + (size_t)slot * d.NS, d.NS, 2);
+  else if (s == "orientation") set(d.ori + (size_t)slot * 4, 3, 0);
+  else if (s == "scal") set(d.scal + (size_t)slot * SC_COUNT, SC_COUNT, 2);
+  else if (s == "curv_d") set(d.cd + base, M, 0);
+  else if (s == "picked_occl") set(d.picked0 + base, M, 3);
+  else if (s == "point_label") set(d.plabel + base, M, 2);
+  else if (s == "sharp") set(d.feat[0] + ((size_t)slot * 2 + cur) * d.fcap[0], (size_t)fc[cur * 4 + 0] * 4, 0);
+  else if (s == "less_sharp") set(d.feat[1] + ((size_t)slot * 2 + cur) * d.fcap[1], (size_t)fc[cur * 4 + 1] * 4, 0);
+  else if (s == "flat") set(d.feat[2] + ((size_t)slot * 2 + cur) * d.fcap[2], (size_t)fc[cur * 4 + 2] * 4, 0);
+  else if (s == "less_flat") set(d.feat[3] + ((size_t)slot * 2 + cur) * d.fcap[3], (size_t)fc[cur * 4 + 3] * 4, 0);
+  else if (s == "sharp_idx") set(d.feat_idx[0] + ((size_t)slot * 2 + cur) * d.fcap[0], fc[cur * 4 + 0], 2);
+  else if (s == "less_sharp_idx") set(d.feat_idx[1] + ((size_t)slot * 2 + cur) * d.fcap[1], fc[cur * 4 + 1], 2);
+  else if (s == "flat_idx") set(d.feat_idx[2] + ((size_t)slot * 2 + cur) * d.fcap[2], fc[cur * 4 + 2], 2);
+  else if (s == "lo_surf_corr") set(d.lo_corr + (size_t)slot * (d.lo_qcap_surf + d.lo_qcap_corner) * 4, (size_t)fc[cur * 4 + 2] * 4, 2);
+  else if (s == "lo_corner_corr") set(d.lo_corr + ((size_t)slot * (d.lo_qcap_surf + d.lo_qcap_corner) + d.lo_qcap_surf) * 4, (size_t)fc[cur * 4 + 0] * 4, 2);
+  else if (s == "lo_state") set(d.lo_state + (size_t)slot * LO_STATE_N, LO_STATE_N, 1);
+  else if (s == "poses") set(d.poses + (size_t)slot * 16, 16, 1);
+  else return lm_host_debug_get(h->lm, slot, name, out, cap_bytes, count, dtype, &h->err);
+  if ((size_t)cap_bytes < n * esz) { h->err = "debug_get: buffer too small"; return ALEGO_ERR_CAPACITY; }
+  if (n) HIP_TRY(h, hipMemcpy(out, src, n * esz, hipMemcpyDeviceToHost));
+  *count = (int)n; *dtype = dt;
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,200 @@
+// dev_common.h — device-side view of one handle's HBM-resident state.
+//
+// Every per-scan array is laid out [slot][capacity] (slot = independent stream),
+// so one launch with blockIdx.y = slot advances all streams together.
+#ifndef ALEGO_DEV_COMMON_H_
+#define ALEGO_DEV_COMMON_H_
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/alego_params.h"
+
+// per-slot integer scalars (DevCtx::scal, stride SC_COUNT)
+enum {
+  SC_FIRST = 0,   // smallest index of a valid input point (orientation, imageProjection.cpp:62)
+  SC_LAST,        // largest index of a valid input point
+  SC_PVALID,      // valid input points
+  SC_M,           // segmented cloud size
+  SC_NOUT,        // outlier cloud size
+  SC_NFEAS,       // feasible segments (label_cnt_-1)
+  SC_LO_INIT,     // system_initialized_ (laserOdometry.cpp:36)
+  SC_LO_NSURF,    // surf correspondences of the last scan
+  SC_LO_NCORNER,  // corner correspondences
+  SC_LO_FLAGS,    // ALEGO_FLAG_* of the last LO step
+  SC_LO_ITERS,    // packed solver summaries (surf: it | succ<<8 | term<<16 ; corner <<... in next)
+  SC_LO_ITERS2,
+  SC_CUR,         // feature double-buffer index written by the last FE (0/1)
+  SC_ODOM_VALID,
+  SC_LM_FRAME,    // LaserMapping frame_cnt (laserMapping.cpp:111)
+  SC_LM_FLAGS,
+  SC_COUNT = 32
+};
+
+// feature cloud kinds
+enum { F_SHARP = 0, F_LSHARP = 1, F_FLAT = 2, F_LFLAT = 3 };
+
+struct DevCtx {
+  alego_params P;
+  int n_slots, ring_len;
+  int slot0, n_launch;  // slots [slot0, slot0+n_launch) are advanced by a launch (blockIdx.y + slot0)
+  int N, H, NS;   // cells, columns, rings
+  int Pcap;       // input points capacity per scan (= N)
+  int cap_sharp, cap_lsharp, cap_flat;  // per-ring staging capacities: n_sharp*n_sectors, ...
+  double sin_ax, cos_ax, sin_ay, cos_ay;  // sin/cos of seg_alpha_x / seg_alpha_y (host libm)
+  // ---- input ring ----
+  float4* in_pts;  // [slot][ring][Pcap]
+  int* in_n;       // [slot][ring]
+  // ---- image projection ----
+  int* owner;           // [slot][N] winning input index per cell (last writer = max index), -1 empty
+  float* range_img;     // [slot][N] f32 range, -1 empty
+  uint8_t* flag_img;    // [slot][N] bit0 ground, bit1 active (filled, non-ground), bit2 edge->right, bit3 edge->down
+  int* parent;          // [slot][N] union-find parent (root = min linear index of the component)
+  int* cc_size;         // [slot][N] per-root size, later per-root label
+  unsigned long long* cc_rows;  // [slot][N] per-root row bitmask
+  int* label_img;       // [slot][N] label_mat_
+  int* cc_label;        // [slot][N] per-root label_cnt_ number (0 = infeasible)
+  int* row_cnt;         // [slot][NS][4] per-row kept / outlier / feasible-root counts
+  int* scal;            // [slot][SC_COUNT]
+  float4* seg_pts;      // [slot][N]
+  uint8_t* seg_ground;  // [slot][N]
+  int* seg_col;         // [slot][N]
+  float* seg_range;     // [slot][N]
+  int* ring_start;      // [slot][NS]
+  int* ring_end;        // [slot][NS]
+  float* ori;           // [slot][4]
+  float4* outlier;      // [slot][N]
+  // ---- feature extraction ----
+  float* cd;            // [slot][N] f32 11-tap sum (curvature = (double)cd^2)
+  uint8_t* picked0;     // [slot][N] cloud_neighbor_picked_ after occlusion marking
+  int* plabel;          // [slot][N] cloud_label_
+  int* st_idx;          // [slot][NS][st_stride] per-ring staging: sharp | less_sharp | flat | less_flat_scan indices
+  int* st_cnt;          // [slot][NS][8]  counts: sharp, less_sharp, flat, less_flat_scan, less_flat voxels
+  float4* st_lfds;      // [slot][NS][H] per-ring voxel-filtered less_flat
+  int st_stride;        // cap_sharp + cap_lsharp + cap_flat + H
+  // ---- feature clouds, double-buffered by scan parity ----
+  float4* feat[4];      // [slot][2][fcap[k]]
+  int* feat_idx[3];     // [slot][2][fcap[k]] indices into the segmented cloud (sharp, less_sharp, flat)
+  int fcap[4];
+  int* feat_cnt;        // [slot][2][4]
+  int* ring_off;        // [slot][2][2][NS+1] ring offsets of less_sharp ([..][0]) and less_flat ([..][1])
+  // ---- laser odometry ----
+  int* lo_corr;         // [slot][qcap][4]  surf rows then corner rows: (query, closest, idx2, idx3) ; closest<0 = none
+  int lo_qcap_surf, lo_qcap_corner;
+  double* lo_state;     // [slot][LO_STATE_N]
+  // ---- outputs ----
+  double* poses;        // [slot][16]: odom t(3) q(4), map t(3) q(4), pad
+};
+
+enum {
+  LS_PARAMS = 0,        // params_[6]
+  LS_TW = 6,            // t_w_cur_[3]
+  LS_RW = 9,            // r_w_cur_[9] row-major
+  LS_PARAMS_SURF = 18,  // params_ after the surf solve (debug)
+  LS_COSTS = 24,        // initial/final cost of both solves
+  LO_STATE_N = 32
+};
+
+#define DEV_INLINE __device__ __forceinline__
+
+DEV_INLINE int32_t d_f2i(float f) { return __float_as_int(f); }
+DEV_INLINE float d_i2f(int32_t i) { return __int_as_float(i); }
+
+// ---------------------------------------------------------------------------
+// atan2f / atanf: the fdlibm algorithm glibc 2.35 uses for std::atan2(float,float)
+// (what imageProjection.cpp:79,87 resolves to), written for the device with plain
+// IEEE f32 + - * / only.  Compiled with -ffp-contract=off.  Algorithm and
+// constants: Sun fdlibm e_atan2f.c / s_atanf.c, "Copyright (C) 1993 by Sun
+// Microsystems, Inc. All rights reserved. ... Permission to use, copy, modify,
+// and distribute this software is freely granted, provided that this notice is
+// preserved."
+// ---------------------------------------------------------------------------
+DEV_INLINE float d_atanf(float x) {
+  const float hi0 = 4.6364760399e-01f, hi1 = 7.8539812565e-01f, hi2 = 9.8279368877e-01f, hi3 = 1.5707962513e+00f;
+  const float lo0 = 5.0121582440e-09f, lo1 = 3.7748947079e-08f, lo2 = 3.4473217170e-08f, lo3 = 7.5497894159e-08f;
+  const float aT0 = 3.3333334327e-01f, aT1 = -2.0000000298e-01f, aT2 = 1.4285714924e-01f, aT3 = -1.1111110449e-01f,
+              aT4 = 9.0908870101e-02f, aT5 = -7.6918758452e-02f, aT6 = 6.6610731184e-02f, aT7 = -5.8335702866e-02f,
+              aT8 = 4.9768779427e-02f, aT9 = -3.6531571299e-02f, aT10 = 1.6285819933e-02f;
+  int32_t hx = d_f2i(x), ix = hx & 0x7fffffff;
+  float ahi = 0.f, alo = 0.f;
+  int id;
+  if (ix >= 0x4c800000) {
+    if (ix > 0x7f800000) return x + x;
+    return hx > 0 ? hi3 + lo3 : -hi3 - lo3;
+  }
+  if (ix < 0x3ee00000) {
+    if (ix < 0x31000000) return x;
+    id = -1;
+  } else {
+    x = fabsf(x);
+    if (ix < 0x3f980000) {
+      if (ix < 0x3f300000) { id = 0; ahi = hi0; alo = lo0; x = (2.0f * x - 1.0f) / (2.0f + x); }
+      else { id = 1; ahi = hi1; alo = lo1; x = (x - 1.0f) / (x + 1.0f); }
+    } else {
+      if (ix < 0x401c0000) { id = 2; ahi = hi2; alo = lo2; x = (x - 1.5f) / (1.0f + 1.5f * x); }
+      else { id = 3; ahi = hi3; alo = lo3; x = -1.0f / x; }
+    }
+  }
+  float z = x * x, w = z * z;
+  float s1 = z * (aT0 + w * (aT2 + w * (aT4 + w * (aT6 + w * (aT8 + w * aT10)))));
+  float s2 = w * (aT1 + w * (aT3 + w * (aT5 + w * (aT7 + w * aT9))));
+  if (id < 0) return x - x * (s1 + s2);
+  z = ahi - ((x * (s1 + s2) - alo) - x);
+  return hx < 0 ? -z : z;
+}
+
+DEV_INLINE float d_atan2f(float y, float x) {
+  const float tiny = 1.0e-30f, pi_o_4 = 7.8539818525e-01f, pi_o_2 = 1.5707963705e+00f,
+              pi = 3.1415927410e+00f, pi_lo = -8.7422776573e-08f;
+  int32_t hx = d_f2i(x), ix = hx & 0x7fffffff, hy = d_f2i(y), iy = hy & 0x7fffffff;
+  if (ix > 0x7f800000 || iy > 0x7f800000) return x + y;
+  if (hx == 0x3f800000) return d_atanf(y);
+  int32_t m = ((hy >> 31) & 1) | ((hx >> 30) & 2);
+  if (iy == 0) { return m == 0 || m == 1 ? y : (m == 2 ? pi + tiny : -pi - tiny); }
+  if (ix == 0) return hy < 0 ? -pi_o_2 - tiny : pi_o_2 + tiny;
+  if (ix == 0x7f800000) {
+    if (iy == 0x7f800000) return m == 0 ? pi_o_4 + tiny : m == 1 ? -pi_o_4 - tiny : m == 2 ? 3.0f * pi_o_4 + tiny : -3.0f * pi_o_4 - tiny;
+    return m == 0 ? 0.0f : m == 1 ? -0.0f : m == 2 ? pi + tiny : -pi - tiny;
+  }
+  if (iy == 0x7f800000) return hy < 0 ? -pi_o_2 - tiny : pi_o_2 + tiny;
+  int32_t k = (iy - ix) >> 23;
+  float z;
+  if (k > 60) z = pi_o_2 + 0.5f * pi_lo;
+  else if (hx < 0 && k < -60) z = 0.0f;
+  else z = d_atanf(fabsf(y / x));
+  if (m == 0) return z;
+  if (m == 1) return d_i2f(d_f2i(z) ^ (int32_t)0x80000000);
+  if (m == 2) return pi - (z - pi_lo);
+  return (z - pi_lo) - pi;
+}
+
+// glibc 2.35 hypotf: evaluated in double, rounded once
+DEV_INLINE float d_hypotf(float x, float y) { return (float)sqrt((double)x * (double)x + (double)y * (double)y); }
+
+// ---------------------------------------------------------------------------
+// wavefront (64 lanes) helpers
+// ---------------------------------------------------------------------------
+DEV_INLINE unsigned long long wave_max_u64(unsigned long long v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    unsigned long long t = __shfl_xor(v, o, 64);
+    v = t > v ? t : v;
+  }
+  return v;
+}
+DEV_INLINE unsigned long long wave_min_u64(unsigned long long v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    unsigned long long t = __shfl_xor(v, o, 64);
+    v = t < v ? t : v;
+  }
+  return v;
+}
+DEV_INLINE double wave_sum_f64(double v) {  // fixed butterfly order -> deterministic
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+DEV_INLINE int lane_id() { return threadIdx.x & 63; }
+
+#endif

@@ -1,0 +1,303 @@
+// dev_cost.h — the four analytic-Jacobian cost functors of include/alego/utility.h:122-349
+// and the small Eigen-equivalent rotation helpers, for the device.
+#ifndef ALEGO_DEV_COST_H_
+#define ALEGO_DEV_COST_H_
+
+#include "dev_common.h"
+
+enum { BLK_SURF = 0, BLK_CORNER = 1, BLK_EDGE = 2, BLK_PLANE = 3 };
+
+struct DQuat { double w, x, y, z; };
+
+DEV_INLINE DQuat dq_mul(const DQuat& a, const DQuat& b) {
+  DQuat r;
+  r.w = a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z;
+  r.x = a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y;
+  r.y = a.w * b.y + a.y * b.w + a.z * b.x - a.x * b.z;
+  r.z = a.w * b.z + a.z * b.w + a.x * b.y - a.y * b.x;
+  return r;
+}
+// AngleAxisd(yaw,Z) * AngleAxisd(pitch,Y) * AngleAxisd(roll,X)  (utility.h:128, laserOdometry.cpp:731)
+DEV_INLINE DQuat dq_zyx(double yaw, double pitch, double roll) {
+  const double hz = 0.5 * yaw, hy = 0.5 * pitch, hx = 0.5 * roll;
+  DQuat qz{cos(hz), 0, 0, sin(hz)}, qy{cos(hy), 0, sin(hy), 0}, qx{cos(hx), sin(hx), 0, 0};
+  return dq_mul(dq_mul(qz, qy), qx);
+}
+DEV_INLINE void dq_rotate(const DQuat& q, const double v[3], double out[3]) {
+  const double u0 = 2 * (q.y * v[2] - q.z * v[1]), u1 = 2 * (q.z * v[0] - q.x * v[2]), u2 = 2 * (q.x * v[1] - q.y * v[0]);
+  out[0] = v[0] + q.w * u0 + (q.y * u2 - q.z * u1);
+  out[1] = v[1] + q.w * u1 + (q.z * u0 - q.x * u2);
+  out[2] = v[2] + q.w * u2 + (q.x * u1 - q.y * u0);
+}
+DEV_INLINE void dq_to_mat(const DQuat& q, double R[9]) {
+  const double tx = 2 * q.x, ty = 2 * q.y, tz = 2 * q.z;
+  const double twx = tx * q.w, twy = ty * q.w, twz = tz * q.w;
+  const double txx = tx * q.x, txy = ty * q.x, txz = tz * q.x, tyy = ty * q.y, tyz = tz * q.y, tzz = tz * q.z;
+  R[0] = 1 - (tyy + tzz); R[1] = txy - twz; R[2] = txz + twy;
+  R[3] = txy + twz; R[4] = 1 - (txx + tzz); R[5] = tyz - twx;
+  R[6] = txz - twy; R[7] = tyz + twx; R[8] = 1 - (txx + tyy);
+}
+DEV_INLINE DQuat dq_from_mat(const double m[9]) {
+  DQuat q;
+  double t = m[0] + m[4] + m[8];
+  if (t > 0) {
+    t = sqrt(t + 1.0); q.w = 0.5 * t; t = 0.5 / t;
+    q.x = (m[7] - m[5]) * t; q.y = (m[2] - m[6]) * t; q.z = (m[3] - m[1]) * t;
+  } else {
+    int i = 0;
+    if (m[4] > m[0]) i = 1;
+    if (m[8] > m[i * 3 + i]) i = 2;
+    const int j = (i + 1) % 3, k = (j + 1) % 3;
+    t = sqrt(m[i * 3 + i] - m[j * 3 + j] - m[k * 3 + k] + 1.0);
+    double v[3];
+    v[i] = 0.5 * t; t = 0.5 / t;
+    q.w = (m[k * 3 + j] - m[j * 3 + k]) * t;
+    v[j] = (m[j * 3 + i] + m[i * 3 + j]) * t;
+    v[k] = (m[k * 3 + i] + m[i * 3 + k]) * t;
+    q.x = v[0]; q.y = v[1]; q.z = v[2];
+  }
+  return q;
+}
+DEV_INLINE DQuat dq_inverse(const DQuat& q) {
+  const double n2 = q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z;
+  return DQuat{q.w / n2, -q.x / n2, -q.y / n2, -q.z / n2};
+}
+
+// Pose-dependent terms shared by every residual of one evaluation.
+struct PoseTerms {
+  DQuat q;
+  double t[3];
+  double sr, cr, sp, cp, sy, cy;
+};
+DEV_INLINE PoseTerms pose_terms(const double* p) {
+  PoseTerms T;
+  T.q = dq_zyx(p[5], p[4], p[3]);
+  T.t[0] = p[0]; T.t[1] = p[1]; T.t[2] = p[2];
+  T.sr = sin(p[3]); T.cr = cos(p[3]); T.sp = sin(p[4]); T.cp = cos(p[4]); T.sy = sin(p[5]); T.cy = cos(p[5]);
+  return T;
+}
+
+// residual + 1x6 Jacobian (uncorrected).  a = lpj | plane normal, b = lpl, c = lpm, dd = negative_OA_dot_norm.
+DEV_INLINE void eval_block(int type, const double cp_[3], const double a[3], const double b[3], const double c[3], double dd,
+                           const PoseTerms& T, double* res, double J[6]) {
+  double lp[3];
+  dq_rotate(T.q, cp_, lp);
+  lp[0] += T.t[0]; lp[1] += T.t[1]; lp[2] += T.t[2];
+  const double X = cp_[0], Y = cp_[1], Z = cp_[2];
+  const double sr = T.sr, cr = T.cr, sp = T.sp, cp = T.cp, sy = T.sy, cy = T.cy;
+  if (type == BLK_SURF) {  // utility.h:185-235
+    double ca = (a[1] - b[1]) * (a[2] - c[2]) - (a[2] - b[2]) * (a[1] - c[1]);
+    double cb = (a[2] - b[2]) * (a[0] - c[0]) - (a[0] - b[0]) * (a[2] - c[2]);
+    double cc = (a[0] - b[0]) * (a[1] - c[1]) - (a[1] - b[1]) * (a[0] - c[0]);
+    ca *= ca; cb *= cb; cc *= cc;
+    const double ex = lp[0] - a[0], ey = lp[1] - a[1], ez = lp[2] - a[2];
+    const double m = sqrt(ex * ex * ca + ey * ey * cb + ez * ez * cc);
+    const double k = sqrt(ca + cb + cc);
+    *res = m / k;
+    const double tmp = m * k;
+    J[0] = 0.; J[1] = 0.; J[2] = ((ez * cc) / tmp) / k; J[3] = 0.; J[4] = 0.; J[5] = 0.;
+    return;
+  }
+  // shared derivative table utility.h:148-158 (dy_dp keeps the reference's cr*sr*cp term)
+  const double dx_dr = (cy * sp * cr + sr * sy) * Y + (sy * cr - cy * sr * sp) * Z;
+  const double dy_dr = (-cy * sr + sy * sp * cr) * Y + (-sr * sy * sp - cy * cr) * Z;
+  const double dz_dr = cp * cr * Y - cp * sr * Z;
+  const double dx_dp = -cy * sp * X + cy * cp * sr * Y + cy * cr * cp * Z;
+  const double dy_dp = -sp * sy * X + sy * cp * sr * Y + cr * sr * cp * Z;
+  const double dz_dp = -cp * X - sp * sr * Y - sp * cr * Z;
+  const double dx_dy = -sy * cp * X - (sy * sp * sr + cr * cy) * Y + (cy * sr - sy * cr * sp) * Z;
+  const double dy_dy = cp * cy * X + (-sy * cr + cy * sp * sr) * Y + (cy * cr * sp + sy * sr) * Z;
+  const double dz_dy = 0.;
+  if (type == BLK_PLANE) {  // utility.h:307-343
+    *res = (a[0] * lp[0] + a[1] * lp[1] + a[2] * lp[2]) + dd;
+    J[0] = a[0]; J[1] = a[1]; J[2] = a[2];
+    J[3] = a[0] * dx_dr + a[1] * dy_dr + a[2] * dz_dr;
+    J[4] = a[0] * dx_dp + a[1] * dy_dp + a[2] * dz_dp;
+    J[5] = a[0] * dx_dy + a[1] * dy_dy + a[2] * dz_dy;
+    return;
+  }
+  // BLK_CORNER utility.h:126-174 / BLK_EDGE utility.h:246-294
+  const double e0 = a[0] - b[0], e1 = a[1] - b[1], e2 = a[2] - b[2];
+  const double k = sqrt(e0 * e0 + e1 * e1 + e2 * e2);
+  const double ca = (lp[1] - a[1]) * (lp[2] - b[2]) - (lp[2] - a[2]) * (lp[1] - b[1]);
+  const double cb = (lp[2] - a[2]) * (lp[0] - b[0]) - (lp[0] - a[0]) * (lp[2] - b[2]);
+  const double cc = (lp[0] - a[0]) * (lp[1] - b[1]) - (lp[1] - a[1]) * (lp[0] - b[0]);
+  const double m = sqrt(ca * ca + cb * cb + cc * cc);
+  *res = m / k;
+  const double dm_dx = (cb * (b[2] - a[2]) + cc * (a[1] - b[1])) / m;
+  const double dm_dy = (ca * (a[2] - b[2]) - cc * (a[0] - b[0])) / m;
+  const double dm_dz = (-ca * (a[1] - b[1]) + cb * (a[0] - b[0])) / m;
+  if (type == BLK_CORNER) {
+    J[0] = dm_dx / k; J[1] = dm_dy / k; J[2] = 0.; J[3] = 0.; J[4] = 0.;
+    J[5] = (dm_dx * dx_dy + dm_dy * dy_dy + dm_dz * dz_dy) / k;
+  } else {
+    J[0] = dm_dx / k; J[1] = dm_dy / k; J[2] = dm_dz / k;
+    J[3] = (dm_dx * dx_dr + dm_dy * dy_dr + dm_dz * dz_dr) / k;
+    J[4] = (dm_dx * dx_dp + dm_dy * dy_dp + dm_dz * dz_dp) / k;
+    J[5] = (dm_dx * dx_dy + dm_dy * dy_dy + dm_dz * dz_dy) / k;
+  }
+}
+
+// ResidualBlock::Evaluate with HuberLoss(a) + Corrector (rho'' <= 0): accumulates the
+// upper triangle of J^T J (21), J^T r (6) and the cost (1) into acc[28].
+DEV_INLINE void accumulate_block(double r, const double J[6], double huber_a, double acc[28]) {
+  const double s = r * r, b2 = huber_a * huber_a;
+  double rho0, rho1;
+  if (s > b2) { const double rr = sqrt(s); rho0 = 2.0 * huber_a * rr - b2; rho1 = fmax(2.2250738585072014e-308, huber_a / rr); }
+  else { rho0 = s; rho1 = 1.0; }
+  const double sq = sqrt(rho1);
+  double Jc[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) Jc[k] = J[k] * sq;
+  const double rc = r * sq;
+  int t = 0;
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int j = i; j < 6; ++j) acc[t++] += Jc[i] * Jc[j];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) acc[21 + k] += Jc[k] * rc;
+  acc[27] += 0.5 * rho0;
+}
+
+// ---------------------------------------------------------------------------
+// Trust-region Levenberg-Marquardt control (Ceres TrustRegionMinimizer +
+// LevenbergMarquardtStrategy defaults) driven by one thread; the
+// residual evaluations are done by the whole workgroup between its steps.
+// The DENSE_QR solve of [J; D] y = [r; 0] is replaced by the equivalent normal
+// equations (J^T J + D^2) y = J^T r with a 6x6 Cholesky factorisation.
+// ---------------------------------------------------------------------------
+struct LmState {
+  double x[6], cand[6], scale[6], x_cost, x_norm, gmax, radius, dec, mcc;
+  double H[21], g[6];   // unscaled J^T J (upper) and J^T r at x
+  int iter, max_iter, num_invalid, step_successful, successful, termination;
+  double initial_cost;
+};
+enum { LM_STOP = 0, LM_EVAL = 1, LM_AGAIN = 2 };
+
+DEV_INLINE int tri(int i, int j) { return i <= j ? i * 6 - i * (i - 1) / 2 + (j - i) : j * 6 - j * (j - 1) / 2 + (i - j); }
+
+DEV_INLINE void lm_load_eval(LmState& S, const double* acc) {
+#pragma unroll
+  for (int k = 0; k < 21; ++k) S.H[k] = acc[k];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) S.g[k] = acc[21 + k];
+  double gm = 0;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) gm = fmax(gm, fabs(S.x[k] - (S.x[k] - S.g[k])));
+  S.gmax = gm;
+}
+
+DEV_INLINE void lm_begin(LmState& S, const double* x0, const double* acc, int max_iter) {
+  double xn = 0;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) { S.x[k] = x0[k]; xn += x0[k] * x0[k]; }
+  S.x_norm = sqrt(xn);
+  S.x_cost = acc[27]; S.initial_cost = acc[27];
+  lm_load_eval(S, acc);
+#pragma unroll
+  for (int k = 0; k < 6; ++k) S.scale[k] = 1.0 / (1.0 + sqrt(S.H[tri(k, k)]));  // jacobi scaling, iteration 0 only
+  S.radius = 1e4; S.dec = 2.0; S.iter = 0; S.max_iter = max_iter; S.num_invalid = 0;
+  S.step_successful = 1; S.successful = 0; S.termination = 0;
+  if (!isfinite(S.x_cost)) S.termination = 4;
+}
+
+// decide whether to stop, and if not compute the next candidate into S.cand
+DEV_INLINE int lm_propose(LmState& S) {
+  if (S.termination == 4) return LM_STOP;
+  if (S.iter >= S.max_iter) { S.termination = 0; return LM_STOP; }
+  if (S.step_successful && S.gmax <= 1e-10) { S.termination = 1; return LM_STOP; }
+  if (S.radius <= 1e-32) { S.termination = 5; return LM_STOP; }
+  ++S.iter;
+  double A[6][6], gs[6], y[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    gs[i] = S.g[i] * S.scale[i];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) A[i][j] = S.H[tri(i, j)] * S.scale[i] * S.scale[j];
+  }
+  double Hs[6][6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int j = 0; j < 6; ++j) Hs[i][j] = A[i][j];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) A[i][i] += fmin(fmax(Hs[i][i], 1e-6), 1e32) / S.radius;
+  // Cholesky A = L L^T
+  bool ok = true;
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    double s = A[j][j];
+    for (int k = 0; k < j; ++k) s -= A[j][k] * A[j][k];
+    if (!(s > 0)) { ok = false; s = 1; }
+    const double l = sqrt(s);
+    A[j][j] = l;
+    for (int i = j + 1; i < 6; ++i) {
+      double t = A[i][j];
+      for (int k = 0; k < j; ++k) t -= A[i][k] * A[j][k];
+      A[i][j] = t / l;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) { double t = gs[i]; for (int k = 0; k < i; ++k) t -= A[i][k] * y[k]; y[i] = t / A[i][i]; }
+#pragma unroll
+  for (int i = 5; i >= 0; --i) { double t = y[i]; for (int k = i + 1; k < 6; ++k) t -= A[k][i] * y[k]; y[i] = t / A[i][i]; }
+  double step[6], mcc = 0;
+  bool finite = ok;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) { step[i] = -y[i]; finite = finite && isfinite(step[i]); }
+  if (finite) {
+    double lin = 0, quad = 0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      lin += step[i] * gs[i];
+      double t = 0;
+#pragma unroll
+      for (int j = 0; j < 6; ++j) t += Hs[i][j] * step[j];
+      quad += step[i] * t;
+    }
+    mcc = -lin - 0.5 * quad;
+  }
+  if (!finite || !(mcc > 0.0)) {  // HandleInvalidStep
+    if (++S.num_invalid >= 5) { S.termination = 4; return LM_STOP; }
+    S.radius /= S.dec; S.dec *= 2.0; S.step_successful = 0;
+    return LM_AGAIN;
+  }
+  S.num_invalid = 0;
+  S.mcc = mcc;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) S.cand[i] = S.x[i] + step[i] * S.scale[i];
+  return LM_EVAL;
+}
+
+// consume the evaluation at S.cand; returns LM_STOP on convergence
+DEV_INLINE int lm_consume(LmState& S, const double* acc) {
+  double cand_cost = acc[27];
+  if (!isfinite(cand_cost)) cand_cost = 1.7976931348623157e308;
+  double sn = 0;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) sn += (S.x[k] - S.cand[k]) * (S.x[k] - S.cand[k]);
+  if (sqrt(sn) <= 1e-8 * (S.x_norm + 1e-8)) { S.termination = 2; return LM_STOP; }
+  const double cost_change = S.x_cost - cand_cost;
+  if (fabs(cost_change) <= 1e-6 * S.x_cost) { S.termination = 3; return LM_STOP; }
+  const double rd = cost_change / S.mcc;
+  if (rd > 1e-3) {
+    double xn = 0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { S.x[k] = S.cand[k]; xn += S.x[k] * S.x[k]; }
+    S.x_norm = sqrt(xn);
+    S.x_cost = cand_cost;
+    lm_load_eval(S, acc);
+    S.step_successful = 1; ++S.successful;
+    const double t = 2.0 * rd - 1.0;
+    S.radius = S.radius / fmax(1.0 / 3.0, 1.0 - t * t * t);
+    S.radius = fmin(1e16, S.radius);
+    S.dec = 2.0;
+  } else {
+    S.step_successful = 0;
+    S.radius /= S.dec; S.dec *= 2.0;
+  }
+  return LM_AGAIN;
+}
+
+#endif

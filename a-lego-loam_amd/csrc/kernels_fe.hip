@@ -1,0 +1,366 @@
+// kernels_fe.hip — feature extraction on gfx950 (replaces src/laserOdometry.cpp:122-293).
+//
+//   fe_curv    a7,a8: 11-tap f32 curvature sum through an LDS window + occlusion / parallel-beam
+//              marking written as a gather (no atomics)                         (:122-159)
+//   fe_pick    a9: one wavefront per ring; the reference's "sort, then scan descending/ascending"
+//              is evaluated as repeated wave-wide arg-max / arg-min over the not-yet-picked
+//              candidates of the sector (identical result for the total order (curvature, index));
+//              +-5 neighbour suppression by ballot                              (:172-286)
+//   fe_voxel   a10: per-ring pcl::VoxelGrid(0.4): LDS bitonic sort of (voxel id, position),
+//              centroid in sorted (= original) order                           (:288-293)
+//   fe_gather  ring-ascending concatenation into the four feature clouds       (:199-205,:245,:293)
+#include "dev_common.h"
+
+#define FE_BLOCK 256
+#define FE_HALO 6
+#define FE_MAXH 4096  // largest horizon_scan supported by the per-ring LDS staging
+
+__global__ void __launch_bounds__(FE_BLOCK) fe_curv(DevCtx d) {
+  const int slot = blockIdx.y + d.slot0;
+  const int M = d.scal[slot * SC_COUNT + SC_M];
+  const int t0 = blockIdx.x * FE_BLOCK;
+  if (t0 >= M) return;
+  const size_t base = (size_t)slot * d.N;
+  const float* rng = d.seg_range + base;
+  const int* colv = d.seg_col + base;
+  const alego_params& P = d.P;
+  __shared__ float s_r[FE_BLOCK + 2 * FE_HALO];
+  __shared__ int s_c[FE_BLOCK + 2 * FE_HALO];
+  __shared__ uint8_t s_f[FE_BLOCK + 2 * FE_HALO];
+  for (int j = threadIdx.x; j < FE_BLOCK + 2 * FE_HALO; j += FE_BLOCK) {
+    const int i = t0 - FE_HALO + j;
+    const bool in = i >= 0 && i < M;
+    s_r[j] = in ? rng[i] : 0.f;
+    s_c[j] = in ? colv[i] : 0;
+  }
+  __syncthreads();
+  // per-point conditions of markOccludedPoints for i = t0-5 .. t0+FE_BLOCK+4
+  for (int j = threadIdx.x + 1; j < FE_BLOCK + 2 * FE_HALO - 1; j += FE_BLOCK) {
+    const int i = t0 - FE_HALO + j;
+    uint8_t f = 0;
+    if (i >= 5 && i < M - 5) {
+      const float r0 = s_r[j], r1 = s_r[j + 1], rm = s_r[j - 1];
+      int cdiff = s_c[j] - s_c[j + 1];
+      cdiff = cdiff < 0 ? -cdiff : cdiff;
+      bool c1, c2;
+      double diff1, diff2;
+      if (P.occl_f32) {  // LO.cpp:203-204
+        c1 = (double)(r0 - r1) > P.occl_depth; c2 = (double)(r1 - r0) > P.occl_depth;
+        diff1 = (double)fabsf(rm - r0); diff2 = (double)fabsf(r1 - r0);
+      } else {           // laserOdometry.cpp:134-135
+        const double d1 = (double)r0, d2 = (double)r1;
+        c1 = d1 - d2 > P.occl_depth; c2 = d2 - d1 > P.occl_depth;
+        diff1 = fabs((double)rm - d1); diff2 = fabs(d2 - d1);
+      }
+      const bool near = cdiff < P.occl_col_diff;
+      const bool A = near && c1;            // marks i-5..i and skips the rest (:142-144)
+      const bool B = near && !c1 && c2;     // marks i+1..i+5 (:148)
+      const bool C = !A && diff1 > P.parallel_ratio * (double)r0 && diff2 > P.parallel_ratio * (double)r0;  // (:154-157)
+      f = (uint8_t)((A ? 1 : 0) | (B ? 2 : 0) | (C ? 4 : 0));
+    }
+    s_f[j] = f;
+  }
+  __syncthreads();
+  const int i = t0 + threadIdx.x;
+  if (i >= M) return;
+  const int j = threadIdx.x + FE_HALO;
+  float cdv = 0.f;
+  if (i >= 5 && i < M - 5) {
+    // strictly left-to-right f32 sum (:124); built with -ffp-contract=off
+    cdv = s_r[j - 5] + s_r[j - 4] + s_r[j - 3] + s_r[j - 2] + s_r[j - 1] - s_r[j] * 10 + s_r[j + 1] + s_r[j + 2] + s_r[j + 3] + s_r[j + 4] + s_r[j + 5];
+  }
+  uint8_t pk = (s_f[j] & 4) ? 1 : 0;
+#pragma unroll
+  for (int l = 0; l <= 5; ++l) pk |= (s_f[j + l] & 1);       // A(i'), i' in [i, i+5]
+#pragma unroll
+  for (int l = 1; l <= 5; ++l) pk |= (s_f[j - l] & 2) >> 1;  // B(i'), i' in [i-5, i-1]
+  d.cd[base + i] = cdv;
+  d.picked0[base + i] = pk;
+}
+
+// one wavefront per (ring, slot)
+__global__ void __launch_bounds__(64) fe_pick(DevCtx d) {
+  const int slot = blockIdx.y + d.slot0, ring = blockIdx.x, lane = threadIdx.x;
+  const size_t base = (size_t)slot * d.N;
+  const alego_params& P = d.P;
+  const int S = d.ring_start[slot * d.NS + ring], E = d.ring_end[slot * d.NS + ring];
+  const int rf = S - 5, rl = E + 5;  // first / last point of this ring in the segmented cloud
+  const int cnt = rl - rf + 1;
+  __shared__ uint32_t s_key[FE_MAXH];  // |cd| bit pattern: curvature order == unsigned order
+  __shared__ uint8_t s_flag[FE_MAXH];  // bit0 picked, bit1 ground
+  __shared__ int8_t s_label[FE_MAXH];
+  const int* colv = d.seg_col + base;
+  for (int k = lane; k < cnt; k += 64) {
+    s_key[k] = (uint32_t)d_f2i(fabsf(d.cd[base + rf + k]));
+    s_flag[k] = (uint8_t)((d.picked0[base + rf + k] & 1) | (d.seg_ground[base + rf + k] ? 2 : 0));
+    s_label[k] = 0;
+  }
+  __syncthreads();
+  int* st = d.st_idx + ((size_t)slot * d.NS + ring) * d.st_stride;
+  int* st_sharp = st, *st_lsharp = st + d.cap_sharp, *st_flat = st_lsharp + d.cap_lsharp, *st_lfs = st_flat + d.cap_flat;
+  int n_sharp = 0, n_ls = 0, n_flat = 0, n_lfs = 0;
+  const int NSEC = P.n_sectors, SR = P.suppress_radius;
+  for (int j = 0; j < NSEC; ++j) {
+    int sp, ep;
+    if (P.sector_formula == 0) { sp = (S * (NSEC - j) + E * j) / NSEC; ep = (S * (NSEC - 1 - j) + E * (j + 1)) / NSEC - 1; }
+    else { const int diff = E - S; sp = S + j * diff / NSEC; ep = S + (j + 1) * diff / NSEC - 1; }
+    if (sp >= ep) continue;
+    // ---- sharp / less-sharp: descending curvature (:189-236) ----
+    int picked_num = 0;
+    while (true) {
+      unsigned long long best = 0ull;
+      for (int k = sp + lane; k <= ep; k += 64) {
+        const int loc = k - rf;
+        if ((s_flag[loc] & 3) == 0) {
+          const uint32_t kb = s_key[loc];
+          const double ad = (double)d_i2f((int32_t)kb);
+          if (ad * ad > P.edge_thres) {
+            const unsigned long long c = ((unsigned long long)kb << 32) | (uint32_t)k;
+            best = c > best ? c : best;
+          }
+        }
+      }
+      best = wave_max_u64(best);
+      if (best == 0ull) break;
+      const int idx = (int)(uint32_t)best;
+      ++picked_num;
+      int lab = 0;
+      if (picked_num <= P.n_sharp) lab = 2; else if (picked_num <= P.n_less_sharp) lab = 1;
+      if (lane == 0) {
+        s_flag[idx - rf] |= 1;
+        if (lab) s_label[idx - rf] = (int8_t)lab;
+        if (lab == 2) st_sharp[n_sharp] = idx;
+        if (lab) st_lsharp[n_ls] = idx;
+      }
+      if (lab == 2) ++n_sharp;
+      if (lab) ++n_ls;
+      if (lab) {  // suppression (:211-234); the 21st pick breaks before it (:207-210)
+        bool bad = false;
+        int tgt = -1;
+        if (lane < SR) { const int a = colv[idx + lane + 1], b = colv[idx + lane]; const int cdf = a - b; bad = (cdf < 0 ? -cdf : cdf) > P.suppress_col_diff; tgt = idx + lane + 1; }
+        else if (lane >= 32 && lane < 32 + SR) { const int l = lane - 32; const int a = colv[idx - l - 1], b = colv[idx - l]; const int cdf = a - b; bad = (cdf < 0 ? -cdf : cdf) > P.suppress_col_diff; tgt = idx - l - 1; }
+        const unsigned long long mb = __ballot(bad);
+        const unsigned lo = (unsigned)(mb & 0xffffffffull), hi = (unsigned)(mb >> 32);
+        const int first_f = lo ? __ffs((int)lo) - 1 : 64, first_b = hi ? __ffs((int)hi) - 1 : 64;
+        if (lane < SR && lane < first_f) s_flag[tgt - rf] |= 1;
+        if (lane >= 32 && lane < 32 + SR && lane - 32 < first_b) s_flag[tgt - rf] |= 1;
+      }
+      __syncthreads();
+      if (!lab) break;
+    }
+    // ---- flat: ascending curvature, ground only (:238-277) ----
+    picked_num = 0;
+    while (true) {
+      unsigned long long best = ~0ull;
+      for (int k = sp + lane; k <= ep; k += 64) {
+        const int loc = k - rf;
+        if ((s_flag[loc] & 3) == 2) {
+          const uint32_t kb = s_key[loc];
+          const double ad = (double)d_i2f((int32_t)kb);
+          if (ad * ad < P.surf_thres) {
+            const unsigned long long c = ((unsigned long long)kb << 32) | (uint32_t)k;
+            best = c < best ? c : best;
+          }
+        }
+      }
+      best = wave_min_u64(best);
+      if (best == ~0ull) break;
+      const int idx = (int)(uint32_t)best;
+      ++picked_num;
+      if (lane == 0) { s_flag[idx - rf] |= 1; s_label[idx - rf] = -1; st_flat[n_flat] = idx; }
+      ++n_flat;
+      const bool stop = picked_num >= P.n_flat;
+      if (!stop) {
+        bool bad = false;
+        int tgt = -1;
+        if (lane < SR) { const int a = colv[idx + lane + 1], b = colv[idx + lane]; const int cdf = a - b; bad = (cdf < 0 ? -cdf : cdf) > P.suppress_col_diff; tgt = idx + lane + 1; }
+        else if (lane >= 32 && lane < 32 + SR) { const int l = lane - 32; const int a = colv[idx - l - 1], b = colv[idx - l]; const int cdf = a - b; bad = (cdf < 0 ? -cdf : cdf) > P.suppress_col_diff; tgt = idx - l - 1; }
+        const unsigned long long mb = __ballot(bad);
+        const unsigned lo = (unsigned)(mb & 0xffffffffull), hi = (unsigned)(mb >> 32);
+        const int first_f = lo ? __ffs((int)lo) - 1 : 64, first_b = hi ? __ffs((int)hi) - 1 : 64;
+        if (lane < SR && lane < first_f) s_flag[tgt - rf] |= 1;
+        if (lane >= 32 && lane < 32 + SR && lane - 32 < first_b) s_flag[tgt - rf] |= 1;
+      }
+      __syncthreads();
+      if (stop) break;
+    }
+    // ---- less-flat candidates in position order (:279-285) ----
+    for (int k0 = sp; k0 <= ep; k0 += 64) {
+      const int k = k0 + lane;
+      const bool take = k <= ep && s_label[k - rf] <= 0;
+      const unsigned long long m = __ballot(take);
+      if (take) st_lfs[n_lfs + (int)__popcll(m & ((1ull << lane) - 1ull))] = k;
+      n_lfs += (int)__popcll(m);
+    }
+  }
+  for (int k = lane; k < cnt; k += 64) d.plabel[base + rf + k] = (int)s_label[k];
+  if (lane == 0) {
+    int* c = d.st_cnt + ((size_t)slot * d.NS + ring) * 8;
+    c[0] = n_sharp; c[1] = n_ls; c[2] = n_flat; c[3] = n_lfs;
+  }
+}
+
+// one block per (ring, slot): pcl::VoxelGrid on the ring's less_flat_scan
+__global__ void __launch_bounds__(FE_BLOCK) fe_voxel(DevCtx d) {
+  const int slot = blockIdx.y + d.slot0, ring = blockIdx.x, tid = threadIdx.x;
+  const size_t base = (size_t)slot * d.N;
+  int* cnts = d.st_cnt + ((size_t)slot * d.NS + ring) * 8;
+  const int n = cnts[3];
+  const int* lfs = d.st_idx + ((size_t)slot * d.NS + ring) * d.st_stride + d.cap_sharp + d.cap_lsharp + d.cap_flat;
+  float4* out = d.st_lfds + ((size_t)slot * d.NS + ring) * d.H;
+  const float4* seg = d.seg_pts + base;
+  __shared__ unsigned long long s_keys[FE_MAXH];
+  __shared__ float s_red[6][FE_BLOCK / 64];
+  __shared__ int s_scan[FE_BLOCK / 64];
+  __shared__ int s_total;
+  if (n == 0) { if (tid == 0) cnts[4] = 0; return; }
+  const float inv = 1.0f / d.P.less_flat_leaf;
+  // getMinMax3D
+  float mn[3] = {3.402823466e+38f, 3.402823466e+38f, 3.402823466e+38f}, mx[3] = {-3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f};
+  for (int i = tid; i < n; i += FE_BLOCK) {
+    const float4 p = seg[lfs[i]];
+    mn[0] = fminf(mn[0], p.x); mn[1] = fminf(mn[1], p.y); mn[2] = fminf(mn[2], p.z);
+    mx[0] = fmaxf(mx[0], p.x); mx[1] = fmaxf(mx[1], p.y); mx[2] = fmaxf(mx[2], p.z);
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { mn[a] = fminf(mn[a], __shfl_xor(mn[a], o, 64)); mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], o, 64)); }
+    if ((tid & 63) == 0) { s_red[a][tid >> 6] = mn[a]; s_red[3 + a][tid >> 6] = mx[a]; }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    mn[a] = s_red[a][0]; mx[a] = s_red[3 + a][0];
+#pragma unroll
+    for (int w = 1; w < FE_BLOCK / 64; ++w) { mn[a] = fminf(mn[a], s_red[a][w]); mx[a] = fmaxf(mx[a], s_red[3 + a][w]); }
+  }
+  const long long dx = (long long)((mx[0] - mn[0]) * inv) + 1, dy = (long long)((mx[1] - mn[1]) * inv) + 1, dz = (long long)((mx[2] - mn[2]) * inv) + 1;
+  if (dx * dy * dz > 2147483647LL) {  // "leaf size too small": the input is returned unchanged
+    for (int i = tid; i < n; i += FE_BLOCK) out[i] = seg[lfs[i]];
+    if (tid == 0) cnts[4] = n;
+    return;
+  }
+  int minb[3], divb[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    minb[a] = (int)floorf(mn[a] * inv);
+    divb[a] = (int)floorf(mx[a] * inv) - minb[a] + 1;
+  }
+  const int mul1 = divb[0], mul2 = divb[0] * divb[1];
+  int np2 = 64;
+  while (np2 < n) np2 <<= 1;
+  for (int i = tid; i < np2; i += FE_BLOCK) {
+    unsigned long long key = ~0ull;
+    if (i < n) {
+      const float4 p = seg[lfs[i]];
+      const int i0 = (int)(floorf(p.x * inv) - (float)minb[0]);
+      const int i1 = (int)(floorf(p.y * inv) - (float)minb[1]);
+      const int i2 = (int)(floorf(p.z * inv) - (float)minb[2]);
+      key = ((unsigned long long)(unsigned)(i0 + i1 * mul1 + i2 * mul2) << 32) | (unsigned)i;
+    }
+    s_keys[i] = key;
+  }
+  __syncthreads();
+  // bitonic sort, ascending (voxel id, position) == stable sort by voxel id
+  for (int k = 2; k <= np2; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = tid; i < np2; i += FE_BLOCK) {
+        const int ixj = i ^ j;
+        if (ixj > i) {
+          const unsigned long long a = s_keys[i], b = s_keys[ixj];
+          const bool up = (i & k) == 0;
+          if ((a > b) == up) { s_keys[i] = b; s_keys[ixj] = a; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  // voxel heads -> output rank; the head thread accumulates its run in sorted order
+  int run = 0;
+  for (int c0 = 0; c0 < n; c0 += FE_BLOCK) {
+    const int i = c0 + tid;
+    bool head = false;
+    if (i < n) head = (i == 0) || ((s_keys[i] >> 32) != (s_keys[i - 1] >> 32));
+    const unsigned long long m = __ballot(head);
+    if ((tid & 63) == 0) s_scan[tid >> 6] = (int)__popcll(m);
+    __syncthreads();
+    int woff = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < FE_BLOCK / 64; ++w) { if (w < (tid >> 6)) woff += s_scan[w]; tot += s_scan[w]; }
+    if (head) {
+      const int rank = run + woff + (int)__popcll(m & ((1ull << (tid & 63)) - 1ull));
+      const unsigned vid = (unsigned)(s_keys[i] >> 32);
+      float sx = 0.f, sy = 0.f, sz = 0.f, si = 0.f;
+      int c = 0;
+      for (int li = i; li < n && (unsigned)(s_keys[li] >> 32) == vid; ++li) {
+        const float4 p = seg[lfs[(unsigned)s_keys[li]]];
+        sx += p.x; sy += p.y; sz += p.z; si += p.w;
+        ++c;
+      }
+      const float fn = (float)c;
+      out[rank] = make_float4(sx / fn, sy / fn, sz / fn, si / fn);
+    }
+    run += tot;
+    __syncthreads();
+  }
+  if (tid == 0) cnts[4] = run;
+}
+
+// ring-ascending concatenation.  grid (NS, slots)
+__global__ void __launch_bounds__(FE_BLOCK) fe_gather(DevCtx d, int cur) {
+  const int slot = blockIdx.y + d.slot0, ring = blockIdx.x, tid = threadIdx.x;
+  const size_t base = (size_t)slot * d.N;
+  __shared__ int s_off[4], s_tot[4];
+  const int* allc = d.st_cnt + (size_t)slot * d.NS * 8;
+  if (tid < 64) {
+    const int r = tid;
+    int c[4], p[4];
+    c[0] = r < d.NS ? allc[r * 8 + 0] : 0; c[1] = r < d.NS ? allc[r * 8 + 1] : 0;
+    c[2] = r < d.NS ? allc[r * 8 + 2] : 0; c[3] = r < d.NS ? allc[r * 8 + 4] : 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      p[k] = r < ring ? c[k] : 0;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) { p[k] += __shfl_xor(p[k], o, 64); c[k] += __shfl_xor(c[k], o, 64); }
+    }
+    if (tid == 0) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { s_off[k] = p[k]; s_tot[k] = c[k]; }
+    }
+  }
+  __syncthreads();
+  const int* st = d.st_idx + ((size_t)slot * d.NS + ring) * d.st_stride;
+  const int* stk[3] = {st, st + d.cap_sharp, st + d.cap_sharp + d.cap_lsharp};
+  const int* myc = allc + ring * 8;
+  const float4* seg = d.seg_pts + base;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    float4* dst = d.feat[k] + ((size_t)slot * 2 + cur) * d.fcap[k] + s_off[k];
+    int* dsti = d.feat_idx[k] + ((size_t)slot * 2 + cur) * d.fcap[k] + s_off[k];
+    for (int i = tid; i < myc[k]; i += FE_BLOCK) { const int idx = stk[k][i]; dst[i] = seg[idx]; dsti[i] = idx; }
+  }
+  {
+    float4* dst = d.feat[F_LFLAT] + ((size_t)slot * 2 + cur) * d.fcap[F_LFLAT] + s_off[3];
+    const float4* src = d.st_lfds + ((size_t)slot * d.NS + ring) * d.H;
+    for (int i = tid; i < myc[4]; i += FE_BLOCK) dst[i] = src[i];
+  }
+  if (tid == 0) {
+    int* ro = d.ring_off + (((size_t)slot * 2 + cur) * 2) * (d.NS + 1);
+    ro[ring] = s_off[1];
+    ro[(d.NS + 1) + ring] = s_off[3];
+    if (ring == d.NS - 1) {
+      ro[d.NS] = s_tot[1];
+      ro[(d.NS + 1) + d.NS] = s_tot[3];
+      int* fc = d.feat_cnt + ((size_t)slot * 2 + cur) * 4;
+      fc[0] = s_tot[0]; fc[1] = s_tot[1]; fc[2] = s_tot[2]; fc[3] = s_tot[3];
+    }
+  }
+}
+
+void launch_fe(const DevCtx& d, int cur, hipStream_t st) {
+  hipLaunchKernelGGL(fe_curv, dim3((d.N + FE_BLOCK - 1) / FE_BLOCK, d.n_launch), dim3(FE_BLOCK), 0, st, d);
+  hipLaunchKernelGGL(fe_pick, dim3(d.NS, d.n_launch), dim3(64), 0, st, d);
+  hipLaunchKernelGGL(fe_voxel, dim3(d.NS, d.n_launch), dim3(FE_BLOCK), 0, st, d);
+  hipLaunchKernelGGL(fe_gather, dim3(d.NS, d.n_launch), dim3(FE_BLOCK), 0, st, d, cur);
+}

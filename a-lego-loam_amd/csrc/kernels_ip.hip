@@ -1,0 +1,403 @@
+// kernels_ip.hip — ImageProjection on gfx950 (replaces src/imageProjection.cpp:49-316).
+//
+//   ip_reset      owner image / per-slot scalars
+//   ip_project    a1-a3: NaN/near filter, row/col from the shared fdlibm atan2f, last-writer-wins
+//                 scatter resolved by atomicMax on the input index          (:58-59,:76-104)
+//   ip_image      a2,a3,a4: orientation, range image gather, per-column ground test (:62-72,:107-143)
+//   cc_edges      a5: 4-neighbour edge predicate atan2(d2 sin a, d1 - d2 cos a) > theta (:255-270)
+//   cc_link       a5: lock-free union-find, root = minimum linear index == BFS discovery order (:147-156)
+//   cc_stats      a5: per-component size and row mask -> feasibility (:282-301)
+//   ip_rowcount / ip_compact  a6: per-row ballot compaction with the +5/-6 ring convention (:158-191)
+//   ip_labels     label_mat_ numbering 1,2,.. in discovery order / 999999 / -1 (:303-314)
+//
+// All kernels are launched with blockIdx.y = slot (independent stream).
+// HBM-bound: one scan moves 16 B/point in and 25 B/segmented point out; the images
+// in between (owner, range, flags, parent: 13 B/cell) stay L2-resident.
+#include "dev_common.h"
+
+#define IP_BLOCK 256
+
+__global__ void __launch_bounds__(IP_BLOCK) ip_reset(DevCtx d) {
+  const int slot = blockIdx.y + d.slot0;
+  const int v = blockIdx.x * IP_BLOCK + threadIdx.x;
+  if (v < d.N) d.owner[(size_t)slot * d.N + v] = -1;
+  if (v == 0) {
+    int* sc = d.scal + slot * SC_COUNT;
+    sc[SC_FIRST] = 0x7fffffff; sc[SC_LAST] = -1; sc[SC_PVALID] = 0;
+  }
+}
+
+__global__ void __launch_bounds__(IP_BLOCK) ip_project(DevCtx d, int ring_pos) {
+  const int slot = blockIdx.y + d.slot0;
+  const int i = blockIdx.x * IP_BLOCK + threadIdx.x;
+  const int n = d.in_n[slot * d.ring_len + ring_pos];
+  const alego_params& P = d.P;
+  bool valid = false;
+  if (i < n) {
+    const float4 p = d.in_pts[((size_t)slot * d.ring_len + ring_pos) * d.Pcap + i];
+    valid = isfinite(p.x) && isfinite(p.y) && isfinite(p.z);
+    if (valid && P.near_filter) {
+      const float th = (float)P.near_thres;
+      if (p.x * p.x + p.y * p.y + p.z * p.z < th * th) valid = false;  // IP.cpp:91
+    }
+    if (valid) {
+      // imageProjection.cpp:79-80 (IP.cpp:142-172 for the RFANS table)
+      const double vertical_ang = ((double)d_atan2f(p.z, d_hypotf(p.x, p.y)) * 180.0) / M_PI;
+      int row;
+      if (P.laser_type == ALEGO_LASER_UNIFORM) row = (int)((vertical_ang + P.ang_bottom) / P.ang_res_y + 0.5);
+      else if (vertical_ang > 4.5) row = (int)(13 + (vertical_ang - 5.) / 3 + 0.5);
+      else if (vertical_ang > 0.5) row = (int)(11 + (vertical_ang - 1.0) / 2 + 0.5);
+      else if (vertical_ang > -7.) row = (int)(10.5 + vertical_ang);
+      else if (vertical_ang > -8.5) row = 3;
+      else if (vertical_ang > -10.5) row = 2;
+      else if (vertical_ang > -13.5) row = 1;
+      else row = 0;
+      // :87-97
+      const double horizon_ang = (((double)(-d_atan2f(p.y, p.x)) + 2 * M_PI) * 180.0) / M_PI;
+      int col = (int)(horizon_ang / P.ang_res_x);
+      if (col >= d.H) col -= d.H;
+      if (row >= 0 && row < d.NS && col >= 0 && col < d.H)
+        atomicMax(&d.owner[(size_t)slot * d.N + col + row * d.H], i);  // later points overwrite earlier ones (:102-103)
+    }
+  }
+  // first / last valid point for the orientation block (:62-63): one atomic per wavefront
+  int vmin = valid ? i : 0x7fffffff, vmax = valid ? i : -1;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    vmin = min(vmin, __shfl_xor(vmin, o, 64));
+    vmax = max(vmax, __shfl_xor(vmax, o, 64));
+  }
+  const unsigned long long vb = __ballot(valid);
+  if (lane_id() == 0 && vb) {
+    int* sc = d.scal + slot * SC_COUNT;
+    atomicMin(&sc[SC_FIRST], vmin);
+    atomicMax(&sc[SC_LAST], vmax);
+    atomicAdd(&sc[SC_PVALID], (int)__popcll(vb));
+  }
+}
+
+// one thread per column; rows walked bottom-up carrying the lower cell in registers
+__global__ void __launch_bounds__(128) ip_image(DevCtx d, int ring_pos) {
+  const int slot = blockIdx.y + d.slot0;
+  const int col = blockIdx.x * 128 + threadIdx.x;
+  const alego_params& P = d.P;
+  const float4* pts = d.in_pts + ((size_t)slot * d.ring_len + ring_pos) * d.Pcap;
+  if (col == 0) {  // orientation, :62-72
+    const int* sc = d.scal + slot * SC_COUNT;
+    float* ori = d.ori + slot * 4;
+    if (sc[SC_LAST] >= 0) {
+      const float4 p0 = pts[sc[SC_FIRST]], p1 = pts[sc[SC_LAST]];
+      float so = -d_atan2f(p0.y, p0.x);
+      float eo = (float)((double)(-d_atan2f(p1.y, p1.x)) + 2 * M_PI);
+      if ((double)(eo - so) > 3 * M_PI) eo = (float)((double)eo - 2 * M_PI);
+      else if ((double)(eo - so) < M_PI) eo = (float)((double)eo + 2 * M_PI);
+      ori[0] = so; ori[1] = eo; ori[2] = eo - so;
+    }
+  }
+  if (col >= d.H) return;
+  const int* owner = d.owner + (size_t)slot * d.N;
+  float* rimg = d.range_img + (size_t)slot * d.N;
+  uint8_t* fimg = d.flag_img + (size_t)slot * d.N;
+  unsigned long long filled = 0, ground = 0;
+  float lx = 0, ly = 0, lz = 0;
+  bool lower_ok = false;
+  for (int row = 0; row < d.NS; ++row) {
+    const int o = owner[row * d.H + col];
+    float r = -1.0f;
+    bool ok = o >= 0;
+    float x = 0, y = 0, z = 0;
+    if (ok) {
+      const float4 p = pts[o];
+      x = p.x; y = p.y; z = p.z;
+      r = sqrtf(x * x + y * y + z * z);  // :99
+      filled |= 1ull << row;
+    }
+    rimg[row * d.H + col] = r;
+    if (row >= 1 && row - 1 < P.ground_scan_id && ok && lower_ok) {  // :111-131, pair (row-1,row)
+      const double dx = (double)(x - lx), dy = (double)(y - ly), dz = (double)(z - lz);
+      const double angle = (atan2(dz, hypot(dx, dy)) * 180.0) / M_PI;
+      if (fabs(angle - P.sensor_mount_ang) < P.ground_angle_thres) ground |= 3ull << (row - 1);
+    }
+    lx = x; ly = y; lz = z; lower_ok = ok;
+  }
+  for (int row = 0; row < d.NS; ++row) {
+    const bool g = (ground >> row) & 1, f = (filled >> row) & 1;
+    fimg[row * d.H + col] = (uint8_t)((g ? 1 : 0) | ((f && !g) ? 2 : 0));
+  }
+}
+
+DEV_INLINE int ld_agent(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+DEV_INLINE void st_agent(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__global__ void __launch_bounds__(IP_BLOCK) cc_edges(DevCtx d) {
+  const int slot = blockIdx.y + d.slot0;
+  const int v = blockIdx.x * IP_BLOCK + threadIdx.x;
+  if (v >= d.N) return;
+  const size_t base = (size_t)slot * d.N;
+  const float* rimg = d.range_img + base;
+  uint8_t* fimg = d.flag_img + base;
+  const uint8_t f = fimg[v];
+  const bool active = f & 2;
+  uint8_t e = 0;
+  if (active) {
+    const int row = v / d.H, col = v - row * d.H;
+    const double rv = (double)rimg[v];
+    const int cr = (col + 1 == d.H) ? 0 : col + 1;
+    const int u = row * d.H + cr;
+    if ((fimg[u] & 2) && d.H > 1) {  // same row, seg_alpha_x (:258-261)
+      const double ru = (double)rimg[u];
+      const double d1 = fmax(rv, ru), d2 = fmin(rv, ru);
+      if (atan2(d2 * d.sin_ax, d1 - d2 * d.cos_ax) > d.P.seg_theta) e |= 4;
+    }
+    if (row + 1 < d.NS) {
+      const int w = v + d.H;
+      if (fimg[w] & 2) {  // same column, seg_alpha_y (:262-265)
+        const double rw = (double)rimg[w];
+        const double d1 = fmax(rv, rw), d2 = fmin(rv, rw);
+        if (atan2(d2 * d.sin_ay, d1 - d2 * d.cos_ay) > d.P.seg_theta) e |= 8;
+      }
+    }
+  }
+  // NOTE: bits 2/3 of a neighbour are never read by this kernel (only bit 1), so the in-place update is race-free
+  fimg[v] = (uint8_t)((f & 3) | e);
+  d.parent[base + v] = active ? v : -1;
+  d.cc_size[base + v] = 0;
+  d.cc_rows[base + v] = 0ull;
+  d.cc_label[base + v] = 0;
+}
+
+// ECL-CC style find with intermediate pointer jumping; parents only ever decrease.
+DEV_INLINE int cc_find(int* parent, int v) {
+  int curr = ld_agent(parent + v);
+  if (curr != v) {
+    int prev = v, next;
+    while (curr > (next = ld_agent(parent + curr))) {
+      st_agent(parent + prev, next);
+      prev = curr;
+      curr = next;
+    }
+  }
+  return curr;
+}
+// read-only find (no pointer jumping): used once linking is complete, so that the
+// final roots written by cc_stats cannot be overwritten by another thread's path halving
+DEV_INLINE int cc_find_ro(const int* parent, int v) {
+  int curr = ld_agent(parent + v), next;
+  while (curr > (next = ld_agent(parent + curr))) curr = next;
+  return curr;
+}
+DEV_INLINE void cc_union(int* parent, int a, int b) {
+  int ra = cc_find(parent, a), rb = cc_find(parent, b);
+  bool repeat;
+  do {
+    repeat = false;
+    if (ra != rb) {
+      int ret;
+      if (ra < rb) { if ((ret = atomicCAS(parent + rb, rb, ra)) != rb) { rb = ret; repeat = true; } }
+      else { if ((ret = atomicCAS(parent + ra, ra, rb)) != ra) { ra = ret; repeat = true; } }
+    }
+  } while (repeat);
+}
+
+__global__ void __launch_bounds__(IP_BLOCK) cc_link(DevCtx d) {
+  const int slot = blockIdx.y + d.slot0;
+  const int v = blockIdx.x * IP_BLOCK + threadIdx.x;
+  if (v >= d.N) return;
+  const size_t base = (size_t)slot * d.N;
+  const uint8_t f = d.flag_img[base + v];
+  int* parent = d.parent + base;
+  if (f & 4) {
+    const int row = v / d.H, col = v - row * d.H;
+    cc_union(parent, v, row * d.H + ((col + 1 == d.H) ? 0 : col + 1));
+  }
+  if (f & 8) cc_union(parent, v, v + d.H);
+}
+
+__global__ void __launch_bounds__(IP_BLOCK) cc_stats(DevCtx d) {
+  const int slot = blockIdx.y + d.slot0;
+  const int v = blockIdx.x * IP_BLOCK + threadIdx.x;
+  const size_t base = (size_t)slot * d.N;
+  int* parent = d.parent + base;
+  bool active = false;
+  int root = -1, row = 0;
+  if (v < d.N) {
+    active = d.flag_img[base + v] & 2;
+    if (active) {
+      root = cc_find_ro(parent, v);
+      // cc_link has completed (kernel boundary), so `root` is final; concurrent readers see either
+      // the old ancestor or the root, both valid
+      st_agent(parent + v, root);
+      row = v / d.H;
+    }
+  }
+  // wavefront aggregation: one atomic pair per distinct root in the wave
+  unsigned long long todo = __ballot(active);
+  const int lane = lane_id();
+  while (todo) {
+    const int leader = __ffsll((long long)todo) - 1;
+    const int lroot = __shfl(root, leader, 64);
+    const bool same = active && root == lroot;
+    const unsigned long long m = __ballot(same);
+    unsigned long long rb = same ? (1ull << row) : 0ull;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) rb |= __shfl_xor(rb, o, 64);
+    if (lane == leader) {
+      atomicAdd(&d.cc_size[base + lroot], (int)__popcll(m));
+      atomicOr(&d.cc_rows[base + lroot], rb);
+    }
+    todo &= ~m;
+  }
+}
+
+DEV_INLINE bool cc_feasible(const DevCtx& d, size_t base, int root) {
+  const int sz = d.cc_size[base + root];
+  if (sz >= d.P.seg_big_num) return true;
+  if (sz >= d.P.seg_valid_point_num) return __popcll(d.cc_rows[base + root]) >= d.P.seg_valid_line_num;
+  return false;
+}
+
+// classification of a cell for the compaction sweep (:164-188): 1 keep, 2 outlier, 0 drop
+DEV_INLINE int ip_classify(const DevCtx& d, size_t base, int v, int row, int col, bool* is_feas_root) {
+  const uint8_t f = d.flag_img[base + v];
+  *is_feas_root = false;
+  if (f & 1) return (col % 5 == 0 || col <= 4 || col >= d.H - 5) ? 1 : 0;
+  if (f & 2) {
+    const int root = d.parent[base + v];
+    const bool feas = cc_feasible(d, base, root);
+    *is_feas_root = feas && root == v;
+    if (feas) return 1;
+    return (row > d.P.ground_scan_id && col % 5 == 0) ? 2 : 0;
+  }
+  return 0;
+}
+
+// per-row counts: kept cells, outliers, feasible roots.  grid (NS, slots)
+__global__ void __launch_bounds__(IP_BLOCK) ip_rowcount(DevCtx d) {
+  const int slot = blockIdx.y + d.slot0, row = blockIdx.x;
+  const size_t base = (size_t)slot * d.N;
+  int nk = 0, no = 0, nf = 0;
+  for (int col = threadIdx.x; col < d.H; col += IP_BLOCK) {
+    bool fr;
+    const int c = ip_classify(d, base, row * d.H + col, row, col, &fr);
+    nk += c == 1; no += c == 2; nf += fr;
+  }
+  __shared__ int s[3][IP_BLOCK / 64];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { nk += __shfl_xor(nk, o, 64); no += __shfl_xor(no, o, 64); nf += __shfl_xor(nf, o, 64); }
+  if (lane_id() == 0) { s[0][threadIdx.x >> 6] = nk; s[1][threadIdx.x >> 6] = no; s[2][threadIdx.x >> 6] = nf; }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    int t = 0;
+    for (int w = 0; w < IP_BLOCK / 64; ++w) t += s[threadIdx.x][w];
+    d.row_cnt[((size_t)slot * d.NS + row) * 4 + threadIdx.x] = t;
+  }
+}
+
+// per-row ordered compaction.  grid (NS, slots)
+__global__ void __launch_bounds__(IP_BLOCK) ip_compact(DevCtx d, int ring_pos) {
+  const int slot = blockIdx.y + d.slot0, row = blockIdx.x;
+  const size_t base = (size_t)slot * d.N;
+  const float4* pts = d.in_pts + ((size_t)slot * d.ring_len + ring_pos) * d.Pcap;
+  __shared__ int s_off[3];
+  __shared__ int s_wave[3][IP_BLOCK / 64];
+  // exclusive prefix over rows (NS <= 64 rows, recomputed by every block)
+  if (threadIdx.x < 64) {
+    const int* rc = d.row_cnt + (size_t)slot * d.NS * 4;
+    const int r = threadIdx.x;
+    int k = r < d.NS ? rc[r * 4 + 0] : 0, o = r < d.NS ? rc[r * 4 + 1] : 0, f = r < d.NS ? rc[r * 4 + 2] : 0;
+    int pk = (r < row) ? k : 0, po = (r < row) ? o : 0, pf = (r < row) ? f : 0;
+    int tk = k, to = o, tf = f;
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) {
+      pk += __shfl_xor(pk, s, 64); po += __shfl_xor(po, s, 64); pf += __shfl_xor(pf, s, 64);
+      tk += __shfl_xor(tk, s, 64); to += __shfl_xor(to, s, 64); tf += __shfl_xor(tf, s, 64);
+    }
+    if (threadIdx.x == 0) {
+      s_off[0] = pk; s_off[1] = po; s_off[2] = pf;
+      const int mykeep = rc[row * 4 + 0];
+      d.ring_start[slot * d.NS + row] = pk + 5;                // :161
+      d.ring_end[slot * d.NS + row] = pk + mykeep - 1 - 5;     // :190
+      if (row == 0) {
+        int* sc = d.scal + slot * SC_COUNT;
+        sc[SC_M] = tk; sc[SC_NOUT] = to; sc[SC_NFEAS] = tf;
+      }
+    }
+  }
+  __syncthreads();
+  int run_k = s_off[0], run_o = s_off[1], run_f = s_off[2];
+  const int lane = lane_id(), wave = threadIdx.x >> 6;
+  for (int c0 = 0; c0 < d.H; c0 += IP_BLOCK) {
+    const int col = c0 + threadIdx.x;
+    int c = 0;
+    bool fr = false;
+    const int v = row * d.H + col;
+    if (col < d.H) c = ip_classify(d, base, v, row, col, &fr);
+    const unsigned long long bk = __ballot(c == 1), bo = __ballot(c == 2), bf = __ballot(fr);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    if (lane == 0) { s_wave[0][wave] = (int)__popcll(bk); s_wave[1][wave] = (int)__popcll(bo); s_wave[2][wave] = (int)__popcll(bf); }
+    __syncthreads();
+    int wk = 0, wo = 0, wf = 0, tk = 0, to = 0, tf = 0;
+#pragma unroll
+    for (int w = 0; w < IP_BLOCK / 64; ++w) {
+      const int a = s_wave[0][w], b = s_wave[1][w], e = s_wave[2][w];
+      if (w < wave) { wk += a; wo += b; wf += e; }
+      tk += a; to += b; tf += e;
+    }
+    if (c == 1 || c == 2) {
+      const int o = d.owner[base + v];
+      float4 p = pts[o];
+      p.w = (float)(row + col / 10000.0);  // :101
+      if (c == 1) {
+        const int line = run_k + wk + (int)__popcll(bk & below);
+        d.seg_pts[base + line] = p;
+        d.seg_ground[base + line] = d.flag_img[base + v] & 1;
+        d.seg_col[base + line] = col;
+        d.seg_range[base + line] = d.range_img[base + v];
+      } else {
+        d.outlier[base + run_o + wo + (int)__popcll(bo & below)] = p;
+      }
+    }
+    if (fr) d.cc_label[base + v] = run_f + wf + (int)__popcll(bf & below) + 1;  // label_cnt_ numbering (:303-306)
+    run_k += tk; run_o += to; run_f += tf;
+    __syncthreads();
+  }
+}
+
+// label_mat_: -1 ground/empty, 999999 infeasible, else the discovery-order counter
+__global__ void __launch_bounds__(IP_BLOCK) ip_labels(DevCtx d) {
+  const int slot = blockIdx.y + d.slot0;
+  const int v = blockIdx.x * IP_BLOCK + threadIdx.x;
+  if (v >= d.N) return;
+  const size_t base = (size_t)slot * d.N;
+  const uint8_t f = d.flag_img[base + v];
+  int lab = -1;
+  if (f & 2) {
+    const int root = d.parent[base + v];
+    const int l = d.cc_label[base + root];
+    lab = l > 0 ? l : 999999;
+  }
+  d.label_img[base + v] = lab;
+}
+
+__global__ void atan2f_probe(const float* y, const float* x, float* out, int n, int mode) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = mode == 0 ? d_atan2f(y[i], x[i]) : d_hypotf(x[i], y[i]);
+}
+
+// ---- host-side launchers -------------------------------------------------------
+void launch_ip(const DevCtx& d, int ring_pos, bool want_labels, hipStream_t st) {
+  const dim3 gN((d.N + IP_BLOCK - 1) / IP_BLOCK, d.n_launch), gP((d.Pcap + IP_BLOCK - 1) / IP_BLOCK, d.n_launch);
+  hipLaunchKernelGGL(ip_reset, gN, dim3(IP_BLOCK), 0, st, d);
+  hipLaunchKernelGGL(ip_project, gP, dim3(IP_BLOCK), 0, st, d, ring_pos);
+  hipLaunchKernelGGL(ip_image, dim3((d.H + 127) / 128, d.n_launch), dim3(128), 0, st, d, ring_pos);
+  hipLaunchKernelGGL(cc_edges, gN, dim3(IP_BLOCK), 0, st, d);
+  hipLaunchKernelGGL(cc_link, gN, dim3(IP_BLOCK), 0, st, d);
+  hipLaunchKernelGGL(cc_stats, gN, dim3(IP_BLOCK), 0, st, d);
+  hipLaunchKernelGGL(ip_rowcount, dim3(d.NS, d.n_launch), dim3(IP_BLOCK), 0, st, d);
+  hipLaunchKernelGGL(ip_compact, dim3(d.NS, d.n_launch), dim3(IP_BLOCK), 0, st, d, ring_pos);
+  if (want_labels) hipLaunchKernelGGL(ip_labels, gN, dim3(IP_BLOCK), 0, st, d);
+}
+
+void launch_atan2f_probe(const float* y, const float* x, float* out, int n, int mode, hipStream_t st) {
+  hipLaunchKernelGGL(atan2f_probe, dim3((n + 255) / 256), dim3(256), 0, st, y, x, out, n, mode);
+}

@@ -1,0 +1,253 @@
+// kernels_lo.hip — scan-to-scan LaserOdometry on gfx950 (replaces src/laserOdometry.cpp:328-534).
+//
+//   lo_assoc   a11-a14: one wavefront per query feature: transformToStart, exact f32 1-NN over the
+//              previous scan's feature cloud (replaces pcl::KdTreeFLANN), then the +-2-ring walks
+//              evaluated as a wave-wide lexicographic arg-min over the contiguous ring interval
+//   lo_solve   a15-a17: one workgroup per stream runs a whole ceres::Solve (trust-region LM, Huber
+//              corrector, Jacobi scaling) on-chip: residual/Jacobian evaluation in fp64, wavefront
+//              shuffle + LDS reduction of the 21+6+1 normal-equation scalars in a fixed order, 6x6
+//              Cholesky by one lane, step acceptance, and (second call) the pose integration
+#include "dev_cost.h"
+
+#define LO_BLOCK 256
+
+DEV_INLINE void transform_to_start(const double* p, const float4& pi, float out[3]) {  // laserOdometry.cpp:728-740
+  const DQuat q = dq_zyx(p[5], p[4], p[3]);
+  double R[9];
+  dq_to_mat(q, R);
+  const double x = pi.x, y = pi.y, z = pi.z;
+  out[0] = (float)(R[0] * x + R[1] * y + R[2] * z + p[0]);
+  out[1] = (float)(R[3] * x + R[4] * y + R[5] * z + p[1]);
+  out[2] = (float)(R[6] * x + R[7] * y + R[8] * z + p[2]);
+}
+
+struct WalkBest { double dist; int rank; int idx; };
+DEV_INLINE void walk_consider(WalkBest& b, double dist, int rank, int idx) {
+  if (dist < b.dist || (dist == b.dist && rank < b.rank)) { b.dist = dist; b.rank = rank; b.idx = idx; }
+}
+DEV_INLINE WalkBest walk_reduce(WalkBest b) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const double od = __shfl_xor(b.dist, o, 64);
+    const int orank = __shfl_xor(b.rank, o, 64), oi = __shfl_xor(b.idx, o, 64);
+    if (od < b.dist || (od == b.dist && orank < b.rank)) { b.dist = od; b.rank = orank; b.idx = oi; }
+  }
+  return b;
+}
+
+// kind 0: flat -> surf_last (less_flat of the previous scan); kind 1: sharp -> corner_last (less_sharp)
+__global__ void __launch_bounds__(LO_BLOCK) lo_assoc(DevCtx d, int cur, int kind) {
+  const int slot = blockIdx.y + d.slot0;
+  const int* sc = d.scal + slot * SC_COUNT;
+  if (!sc[SC_LO_INIT]) return;
+  const int q = blockIdx.x * (LO_BLOCK / 64) + (threadIdx.x >> 6);
+  const int lane = lane_id();
+  const int last = cur ^ 1;
+  const int qk = kind == 0 ? F_FLAT : F_SHARP, tk = kind == 0 ? F_LFLAT : F_LSHARP;
+  const int nq = d.feat_cnt[((size_t)slot * 2 + cur) * 4 + qk];
+  if (q >= nq) return;
+  const int nt = d.feat_cnt[((size_t)slot * 2 + last) * 4 + tk];
+  const float4* tg = d.feat[tk] + ((size_t)slot * 2 + last) * d.fcap[tk];
+  const int* roff = d.ring_off + (((size_t)slot * 2 + last) * 2 + (kind == 0 ? 1 : 0)) * (d.NS + 1);
+  const double* params = d.lo_state + (size_t)slot * LO_STATE_N + LS_PARAMS;
+  const float4 pq = d.feat[qk][((size_t)slot * 2 + cur) * d.fcap[qk] + q];
+  float sel[3];
+  transform_to_start(params, pq, sel);
+  // exact 1-NN, flann::L2_Simple<float>; ties -> lowest index
+  unsigned long long best = ~0ull;
+  for (int t = lane; t < nt; t += 64) {
+    const float4 a = tg[t];
+    float r = 0.f, df;
+    df = a.x - sel[0]; r += df * df;
+    df = a.y - sel[1]; r += df * df;
+    df = a.z - sel[2]; r += df * df;
+    const unsigned long long c = ((unsigned long long)(uint32_t)d_f2i(r) << 32) | (uint32_t)t;
+    best = c < best ? c : best;
+  }
+  best = wave_min_u64(best);
+  int closest = -1, idx2 = -1, idx3 = -1;
+  const double nfd = d.P.nearest_feature_dist;
+  if (nt > 0 && (double)d_i2f((int32_t)(best >> 32)) < nfd) {
+    closest = (int)(uint32_t)best;
+    const int cr = (int)tg[closest].w;  // int(intensity) = ring (:347,:436)
+    const int W = d.P.ring_window;
+    const int rlo = max(cr - W, 0), rhi = min(cr + W, d.NS - 1);
+    const int lo = roff[rlo], hi = roff[rhi + 1];           // the walks stay inside [lo, hi)
+    const int same_lo = roff[cr], same_hi = roff[cr + 1];
+    WalkBest b2{nfd, 0x7fffffff, -1}, b3{nfd, 0x7fffffff, -1};
+    for (int k = lo + lane; k < hi; k += 64) {
+      if (k == closest) continue;
+      const float4 a = tg[k];
+      const double ex = (double)(a.x - sel[0]), ey = (double)(a.y - sel[1]), ez = (double)(a.z - sel[2]);
+      const double pd = ex * ex + ey * ey + ez * ez;  // pow(f32 diff, 2) summed in double (:354)
+      // visiting order of the reference: closest+1, closest+2, ... then closest-1, closest-2, ...
+      const int rank = k > closest ? k - closest - 1 : (hi - closest - 1) + (closest - 1 - k);
+      const bool same = k >= same_lo && k < same_hi;
+      if (!(pd < nfd)) continue;
+      if (kind == 0) { if (same) walk_consider(b2, pd, rank, k); else walk_consider(b3, pd, rank, k); }
+      else if (!same) walk_consider(b2, pd, rank, k);  // strictly above going up / strictly below going down (:446,:462)
+    }
+    b2 = walk_reduce(b2);
+    idx2 = b2.idx;
+    if (kind == 0) { b3 = walk_reduce(b3); idx3 = b3.idx; }
+  }
+  if (lane == 0) {
+    int* row = d.lo_corr + ((size_t)slot * (d.lo_qcap_surf + d.lo_qcap_corner) + (kind == 0 ? 0 : d.lo_qcap_surf) + q) * 4;
+    const bool ok = kind == 0 ? (idx2 >= 0 && idx3 >= 0) : (idx2 >= 0);
+    row[0] = q; row[1] = ok ? closest : -1; row[2] = idx2; row[3] = idx3;
+  }
+}
+
+// Block-wide deterministic reduction of acc[28]: wave butterfly, then waves summed in order.
+DEV_INLINE void block_reduce28(double acc[28], double (*s_part)[28], double* s_out) {
+#pragma unroll
+  for (int k = 0; k < 28; ++k) acc[k] = wave_sum_f64(acc[k]);
+  const int wave = threadIdx.x >> 6;
+  if (lane_id() == 0) {
+#pragma unroll
+    for (int k = 0; k < 28; ++k) s_part[wave][k] = acc[k];
+  }
+  __syncthreads();
+  if (threadIdx.x < 28) {
+    double t = 0;
+    for (int w = 0; w < LO_BLOCK / 64; ++w) t += s_part[w][threadIdx.x];
+    s_out[threadIdx.x] = t;
+  }
+  __syncthreads();
+}
+
+// evaluate every valid correspondence row of [row0, row0+n) at pose p
+DEV_INLINE void lo_eval_rows(const DevCtx& d, int slot, int cur, int kind, int n, const PoseTerms& T, double acc[28]) {
+  const int last = cur ^ 1;
+  const int qk = kind == 0 ? F_FLAT : F_SHARP, tk = kind == 0 ? F_LFLAT : F_LSHARP;
+  const float4* qpts = d.feat[qk] + ((size_t)slot * 2 + cur) * d.fcap[qk];
+  const float4* tg = d.feat[tk] + ((size_t)slot * 2 + last) * d.fcap[tk];
+  const int* rows = d.lo_corr + ((size_t)slot * (d.lo_qcap_surf + d.lo_qcap_corner) + (kind == 0 ? 0 : d.lo_qcap_surf)) * 4;
+  for (int i = threadIdx.x; i < n; i += LO_BLOCK) {
+    const int4 r = *reinterpret_cast<const int4*>(rows + (size_t)i * 4);
+    if (r.y < 0) continue;
+    const float4 pc = qpts[r.x], pa = tg[r.y], pb = tg[r.z];
+    const double cp[3] = {pc.x, pc.y, pc.z}, a[3] = {pa.x, pa.y, pa.z}, b[3] = {pb.x, pb.y, pb.z};
+    double c[3] = {0, 0, 0};
+    if (kind == 0) { const float4 pm = tg[r.w]; c[0] = pm.x; c[1] = pm.y; c[2] = pm.z; }
+    double res, J[6];
+    eval_block(kind == 0 ? BLK_SURF : BLK_CORNER, cp, a, b, c, 0.0, T, &res, J);
+    accumulate_block(res, J, d.P.huber_delta, acc);
+  }
+}
+
+// phase 0: ceres::Solve #1 on the surf blocks (:410-421); phase 1: Solve #2 on surf + corner
+// blocks (:484-495) followed by the pose integration (:504-508).
+__global__ void __launch_bounds__(LO_BLOCK) lo_solve(DevCtx d, int cur, int phase) {
+  const int slot = blockIdx.x + d.slot0;
+  int* sc = d.scal + slot * SC_COUNT;
+  double* st = d.lo_state + (size_t)slot * LO_STATE_N;
+  __shared__ double s_part[LO_BLOCK / 64][28];
+  __shared__ double s_out[28];
+  __shared__ LmState S;
+  __shared__ int s_action, s_cnt[LO_BLOCK / 64];
+  if (!sc[SC_LO_INIT]) {  // :316-324
+    if (phase == 1 && threadIdx.x == 0) { sc[SC_LO_INIT] = 1; sc[SC_ODOM_VALID] = 0; sc[SC_LO_FLAGS] = 1; sc[SC_LO_NSURF] = 0; sc[SC_LO_NCORNER] = 0; }
+    return;
+  }
+  const int nq_s = d.feat_cnt[((size_t)slot * 2 + cur) * 4 + F_FLAT];
+  const int nq_c = d.feat_cnt[((size_t)slot * 2 + cur) * 4 + F_SHARP];
+  // count the correspondences of the kind associated just before this call
+  {
+    const int n = phase == 0 ? nq_s : nq_c;
+    const int* rows = d.lo_corr + ((size_t)slot * (d.lo_qcap_surf + d.lo_qcap_corner) + (phase == 0 ? 0 : d.lo_qcap_surf)) * 4;
+    int c = 0;
+    for (int i = threadIdx.x; i < n; i += LO_BLOCK) c += rows[(size_t)i * 4 + 1] >= 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    if (lane_id() == 0) s_cnt[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int t = 0;
+      for (int w = 0; w < LO_BLOCK / 64; ++w) t += s_cnt[w];
+      s_cnt[0] = t;
+      sc[phase == 0 ? SC_LO_NSURF : SC_LO_NCORNER] = t;
+      if (phase == 0) sc[SC_LO_FLAGS] = 0;
+      if (t < d.P.lo_min_corr) sc[SC_LO_FLAGS] |= (phase == 0 ? 2 : 4);
+    }
+    __syncthreads();
+  }
+  const bool do_solve = s_cnt[0] >= d.P.lo_min_corr;
+  if (do_solve) {
+    double acc[28];
+    auto evaluate = [&](const double* x) {
+#pragma unroll
+      for (int k = 0; k < 28; ++k) acc[k] = 0;
+      const PoseTerms T = pose_terms(x);
+      lo_eval_rows(d, slot, cur, 0, nq_s, T, acc);
+      if (phase == 1) lo_eval_rows(d, slot, cur, 1, nq_c, T, acc);
+      block_reduce28(acc, s_part, s_out);
+    };
+    double x0[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) x0[k] = st[LS_PARAMS + k];
+    evaluate(x0);
+    if (threadIdx.x == 0) lm_begin(S, x0, s_out, phase == 0 ? d.P.lo_iters_surf : d.P.lo_iters_corner);
+    __syncthreads();
+    while (true) {
+      if (threadIdx.x == 0) s_action = lm_propose(S);
+      __syncthreads();
+      const int act = s_action;
+      if (act == LM_STOP) break;
+      if (act == LM_EVAL) {
+        double xc[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) xc[k] = S.cand[k];
+        evaluate(xc);
+        if (threadIdx.x == 0) s_action = lm_consume(S, s_out);
+        __syncthreads();
+        if (s_action == LM_STOP) break;
+      }
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) st[LS_PARAMS + k] = S.x[k];
+      st[LS_COSTS + phase * 2] = S.initial_cost; st[LS_COSTS + phase * 2 + 1] = S.x_cost;
+      sc[phase == 0 ? SC_LO_ITERS : SC_LO_ITERS2] = S.iter | (S.successful << 8) | (S.termination << 16);
+    }
+  } else if (threadIdx.x == 0) {
+    sc[phase == 0 ? SC_LO_ITERS : SC_LO_ITERS2] = 0;
+  }
+  if (threadIdx.x == 0) {
+    if (phase == 0) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) st[LS_PARAMS_SURF + k] = st[LS_PARAMS + k];
+    } else {
+      // pose integration :504-508 (roll/pitch ignored)
+      const double p0 = st[LS_PARAMS + 0], p1 = st[LS_PARAMS + 1], p2 = st[LS_PARAMS + 2], yaw = st[LS_PARAMS + 5];
+      const double c = cos(yaw), s = sin(yaw);
+      const double rl[9] = {c, -s, 0, s, c, 0, 0, 0, 1};
+      double rw[9], nt[3], nr[9];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) rw[k] = st[LS_RW + k];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) nt[i] = st[LS_TW + i] + (rw[i * 3 + 0] * p0 + rw[i * 3 + 1] * p1 + rw[i * 3 + 2] * p2);
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) nr[i * 3 + j] = rw[i * 3 + 0] * rl[j] + rw[i * 3 + 1] * rl[3 + j] + rw[i * 3 + 2] * rl[6 + j];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) st[LS_TW + i] = nt[i];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) st[LS_RW + k] = nr[k];
+      const DQuat q = dq_from_mat(nr);
+      double* po = d.poses + (size_t)slot * 16;
+      po[0] = nt[0]; po[1] = nt[1]; po[2] = nt[2]; po[3] = q.w; po[4] = q.x; po[5] = q.y; po[6] = q.z;
+      sc[SC_ODOM_VALID] = 1;
+    }
+  }
+}
+
+void launch_lo(const DevCtx& d, int cur, hipStream_t st) {
+  const int wpb = LO_BLOCK / 64;
+  hipLaunchKernelGGL(lo_assoc, dim3((d.lo_qcap_surf + wpb - 1) / wpb, d.n_launch), dim3(LO_BLOCK), 0, st, d, cur, 0);
+  hipLaunchKernelGGL(lo_solve, dim3(d.n_launch), dim3(LO_BLOCK), 0, st, d, cur, 0);
+  hipLaunchKernelGGL(lo_assoc, dim3((d.lo_qcap_corner + wpb - 1) / wpb, d.n_launch), dim3(LO_BLOCK), 0, st, d, cur, 1);
+  hipLaunchKernelGGL(lo_solve, dim3(d.n_launch), dim3(LO_BLOCK), 0, st, d, cur, 1);
+}

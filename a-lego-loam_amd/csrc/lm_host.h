@@ -1,0 +1,23 @@
+// lm_host.h — LaserMapping scan-to-map registration: host sequencing + HBM state.
+#ifndef ALEGO_LM_HOST_H_
+#define ALEGO_LM_HOST_H_
+#include <hip/hip_runtime.h>
+
+#include <string>
+
+#include "../../include/alego_mi355x.h"
+#include "dev_common.h"
+
+struct LmHost;
+LmHost* lm_host_create(const alego_params& P, const DevCtx& d, int n_slots, hipStream_t st, std::string* err);
+void lm_host_destroy(LmHost* lm);
+// LaserMapping for the scan just processed by LO, for the slots of view `d`
+int lm_host_enqueue(LmHost* lm, const DevCtx& d, int cur, std::string* err);
+int lm_host_process_host(LmHost* lm, const DevCtx& d, const alego_point* corner_last, int n_corner, const alego_point* surf_last,
+                         int n_surf, const alego_point* outlier, int n_outlier, const alego_pose* odom, alego_pose* map_pose,
+                         std::string* err);
+void lm_host_get_params(LmHost* lm, int slot, double* p6);
+int lm_host_set_params(LmHost* lm, int slot, const double* p6, std::string* err);
+void lm_host_get_counts(LmHost* lm, int slot, int* out6);
+int lm_host_debug_get(LmHost* lm, int slot, const char* name, void* out, int cap_bytes, int* count, int* dtype, std::string* err);
+#endif

@@ -1,0 +1,150 @@
+/*
+ * alego_mi355x.h — C ABI of the MI355X-native A-LeGO-LOAM hot path.
+ *
+ * The reference has no FFI: its boundary is three ROS nodelets exchanging
+ * messages (nodelet_plugins.xml:1-10).  Each entry point below replaces the
+ * numeric body of one nodelet callback and takes / returns exactly the payload
+ * of the ROS messages that callback consumes / publishes, as plain pointers and
+ * sizes.  A thin adapter keeps plugin names, topics and frames.
+ *
+ *   alego_ip_process   <- ImageProjection::pcCB            src/imageProjection.cpp:49-208
+ *   alego_lo_process   <- LaserOdometry::mainLoop body     src/laserOdometry.cpp:111-553
+ *   alego_lm_process   <- LaserMapping::mainLoop body +    src/laserMapping.cpp:112-123,
+ *                         laserOdomHandler                 154-166
+ *   alego_scan_process <- the three chained in one process (launch/test.launch: one
+ *                         nodelet manager), intermediates stay in HBM
+ *   alego_batch_*      <- bag replay at unbounded rate (README.md:33-37) over many
+ *                         independent streams, inputs resident in HBM, no per-scan
+ *                         host synchronisation
+ *
+ * All functions return 0 on success, >0 for the reference's "skip" conditions
+ * (surfaced as flags, see ALEGO_FLAG_*), <0 for hard errors (ALEGO_ERR_*); nothing
+ * throws across the boundary.  A handle is single-threaded (one caller at a time,
+ * one HIP stream); different handles are independent.  There is no CPU fallback:
+ * alego_create fails with ALEGO_ERR_NO_DEVICE when no gfx950 device is visible.
+ */
+#ifndef ALEGO_MI355X_H_
+#define ALEGO_MI355X_H_
+
+#include <stdint.h>
+
+#include "alego_params.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct alego_handle alego_handle;
+
+enum {
+  ALEGO_OK = 0,
+  ALEGO_ERR_NO_DEVICE = -1, /* no HIP device / not gfx950 */
+  ALEGO_ERR_HIP = -2,       /* a HIP call failed, see alego_last_error */
+  ALEGO_ERR_CAPACITY = -3,  /* caller buffer too small */
+  ALEGO_ERR_ARG = -4
+};
+/* bit flags returned by the *_process calls (reference guards, not errors) */
+enum {
+  ALEGO_FLAG_LO_INIT = 1,        /* first scan: features stored, no odometry   laserOdometry.cpp:316-324 */
+  ALEGO_FLAG_FEW_SURF = 2,       /* < lo_min_corr surf correspondences         laserOdometry.cpp:422-425 */
+  ALEGO_FLAG_FEW_CORNER = 4,     /* < lo_min_corr corner correspondences       laserOdometry.cpp:496-499 */
+  ALEGO_FLAG_LM_SKIPPED = 8,     /* odd mapping frame                          laserMapping.cpp:112 */
+  ALEGO_FLAG_LM_FEW_FEATURES = 16, /* registration guard                       laserMapping.cpp:350-354 */
+  ALEGO_FLAG_LM_KEYFRAME = 32    /* a key frame was saved                      laserMapping.cpp:491-559 */
+};
+
+/* ---- messages ------------------------------------------------------------ */
+/* /lslidar_point_cloud (sensor_msgs/PointCloud2 as PointXYZI) */
+typedef struct alego_scan_in {
+  const alego_point* pts;
+  int32_t n;
+  double stamp;
+} alego_scan_in;
+
+/* /segmented_cloud + /seg_info (msg/cloud_info.msg:1-12) + /outlier.
+ * Caller owns every buffer; capacities are in elements; worst case is
+ * n_scan*horizon_scan for seg/ground/col/range/outlier/label_image. */
+typedef struct alego_seg_out {
+  alego_point* seg;      int32_t seg_cap;  int32_t m;          /* segmented_cloud */
+  uint8_t* ground;       /* segmentedCloudGroundFlag[m] */
+  int32_t* col;          /* segmentedCloudColInd[m]     */
+  float* range;          /* segmentedCloudRange[m]      */
+  int32_t* ring_start;   /* startRingIndex[n_scan]      */
+  int32_t* ring_end;     /* endRingIndex[n_scan]        */
+  float orientation[3];  /* startOrientation, endOrientation, orientationDiff */
+  alego_point* outlier;  int32_t outlier_cap;  int32_t n_outlier;
+  int32_t* label_image;  /* optional (may be NULL): label_mat_ [n_scan][horizon_scan] */
+} alego_seg_out;
+
+/* /corner, /corner_less, /surf, /surf_less (laserOdometry.cpp:299-314); the
+ * less_* clouds are also /corner_last and /surf_last (:531-546). */
+typedef struct alego_feat_out {
+  alego_point* sharp;       int32_t sharp_cap;       int32_t n_sharp;
+  alego_point* less_sharp;  int32_t less_sharp_cap;  int32_t n_less_sharp;
+  alego_point* flat;        int32_t flat_cap;        int32_t n_flat;
+  alego_point* less_flat;   int32_t less_flat_cap;   int32_t n_less_flat;
+  int32_t* point_label;     /* optional (may be NULL): cloud_label_[m] */
+} alego_feat_out;
+
+/* nav_msgs/Odometry pose (/odom/lidar, /odom_aft_mapped) + the 6-vector the solver works on */
+typedef struct alego_pose {
+  double t[3];
+  double q[4];      /* w, x, y, z */
+  double params[6]; /* LO: last relative transform; LM: absolute map pose (x,y,z,roll,pitch,yaw) */
+  int32_t valid;
+} alego_pose;
+
+/* ---- lifecycle ------------------------------------------------------------ */
+/* n_slots independent streams share one handle (batch path); the single-scan
+ * entry points use slot 0.  ring_len = scans kept resident per slot for the
+ * batch path (0 -> 1). */
+int alego_create(const alego_params* params, int device, int n_slots, int ring_len, alego_handle** out);
+void alego_destroy(alego_handle* h);
+const char* alego_last_error(const alego_handle* h);
+int alego_device_count(void);
+/* size of alego_params this library was built with (binding sanity check) */
+int alego_params_sizeof(void);
+
+/* ---- nodelet-equivalent single-scan entry points (host buffers, slot 0) --- */
+int alego_ip_process(alego_handle* h, const alego_scan_in* in, alego_seg_out* out);
+/* `in` is the IP output as received on /segmented_cloud + /seg_info; `odom` is /odom/lidar */
+int alego_lo_process(alego_handle* h, const alego_seg_out* in, alego_feat_out* feat, alego_pose* odom);
+/* inputs: /corner_last, /surf_last, /outlier, /odom/lidar; output: /odom_aft_mapped and params_ */
+int alego_lm_process(alego_handle* h, const alego_point* corner_last, int32_t n_corner,
+                     const alego_point* surf_last, int32_t n_surf, const alego_point* outlier,
+                     int32_t n_outlier, const alego_pose* odom, alego_pose* map_pose);
+/* IP -> LO -> LM for one scan with intermediates kept on the device.  stages: bit0 IP,
+ * bit1 LO, bit2 LM.  seg/feat may be NULL (then nothing but the poses is copied back). */
+int alego_scan_process(alego_handle* h, int slot, const alego_scan_in* in, int stages,
+                       alego_seg_out* seg, alego_feat_out* feat, alego_pose* odom, alego_pose* map_pose);
+
+/* ---- device-resident batch path ------------------------------------------ */
+/* copy one scan into ring position `ring_pos` of `slot` (host -> HBM, outside the timed region) */
+int alego_batch_load(alego_handle* h, int slot, int ring_pos, const alego_point* pts, int32_t n);
+/* advance every slot by n_scans scans (ring positions first_pos, first_pos+1, ... mod ring_len),
+ * all kernels enqueued on the handle's stream; returns without synchronising when sync == 0 */
+int alego_batch_run(alego_handle* h, int first_pos, int n_scans, int stages, int sync);
+int alego_synchronize(alego_handle* h);
+/* poses of the last processed scan of `slot` */
+int alego_batch_get_pose(alego_handle* h, int slot, alego_pose* odom, alego_pose* map_pose);
+/* per-scan device counters of the last processed scan of `slot`:
+ * out[0..] = P (valid input points), M, n_outlier, n_sharp, n_less_sharp, n_flat, n_less_flat,
+ *            n_surf_corr, n_corner_corr, lm: Kraw_corner, Kraw_surf, Kds_corner, Kds_surf, Lc, Ls */
+int alego_batch_get_counts(alego_handle* h, int slot, int32_t* out, int cap);
+/* the HIP stream (hipStream_t) the handle enqueues on, for event timing by the caller */
+void* alego_stream(alego_handle* h);
+
+/* ---- state access for parity tests (teacher forcing) ---------------------- */
+int alego_set_lo_params(alego_handle* h, int slot, const double* p6);
+int alego_set_lm_params(alego_handle* h, int slot, const double* p6);
+/* copy a named device intermediate of `slot` to host; *count = number of scalars written.
+ * dtype: 0 f32, 1 f64, 2 i32, 3 u8.  Names mirror oracle_get(). */
+int alego_debug_get(alego_handle* h, int slot, const char* name, void* out, int cap_bytes,
+                    int* count, int* dtype);
+/* device atan2f / hypotf used by the projection kernel, for the libm-equivalence test */
+int alego_debug_atan2f(alego_handle* h, const float* y, const float* x, float* out, int n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ALEGO_MI355X_H_ */
