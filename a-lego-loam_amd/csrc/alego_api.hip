@@ -5,6 +5,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -14,8 +15,8 @@
 #include "lm_host.h"
 
 void launch_ip(const DevCtx& d, int ring_pos, bool want_labels, hipStream_t st);
-void launch_fe(const DevCtx& d, int cur, hipStream_t st);
-void launch_lo(const DevCtx& d, int cur, hipStream_t st);
+void launch_fe(const DevCtx& d, hipStream_t st);
+void launch_lo(const DevCtx& d, hipStream_t st);
 void launch_atan2f_probe(const float* y, const float* x, float* out, int n, int mode, hipStream_t st);
 
 struct alego_handle {
@@ -25,7 +26,7 @@ struct alego_handle {
   DevCtx d;
   std::vector<void*> allocs;
   std::string err;
-  long scan_counter = 0;  // all slots advance in lock-step; feature double-buffer index = scan_counter & 1
+  std::vector<long> lo_scans;  // LO steps enqueued per slot (the first one only initialises, laserOdometry.cpp:316-324)
   LmHost* lm = nullptr;
 };
 
@@ -96,6 +97,7 @@ int alego_create(const alego_params* params, int device, int n_slots, int ring_l
   alego_handle* h = new alego_handle();
   h->P = *params;
   h->device = device;
+  h->lo_scans.assign(n_slots, 0);
   if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&h->stream) != hipSuccess) { delete h; return ALEGO_ERR_HIP; }
   DevCtx& d = h->d;
   std::memset(&d, 0, sizeof(d));
@@ -137,6 +139,9 @@ int alego_create(const alego_params* params, int device, int n_slots, int ring_l
     st[b * LO_STATE_N + LS_RW + 0] = st[b * LO_STATE_N + LS_RW + 4] = st[b * LO_STATE_N + LS_RW + 8] = 1.0;
     po[b * 16 + 3] = 1.0; po[b * 16 + 10] = 1.0;
   }
+  std::vector<int> sc0(B * SC_COUNT, 0);
+  for (size_t b = 0; b < B; ++b) sc0[b * SC_COUNT + SC_CUR] = 1;  // the first scan writes feature buffer 0
+  hipMemcpy(d.scal, sc0.data(), sc0.size() * sizeof(int), hipMemcpyHostToDevice);
   hipMemcpy(d.lo_state, st.data(), st.size() * sizeof(double), hipMemcpyHostToDevice);
   hipMemcpy(d.poses, po.data(), po.size() * sizeof(double), hipMemcpyHostToDevice);
   h->lm = lm_host_create(h->P, d, n_slots, h->stream, &h->err);
@@ -176,11 +181,16 @@ int alego_batch_load(alego_handle* h, int slot, int ring_pos, const alego_point*
 // enqueue IP -> FE -> LO -> LM for slots [slot0, slot0+n) on ring position `pos`
 static int enqueue_scan(alego_handle* h, int slot0, int n, int pos, int stages, bool want_labels) {
   const DevCtx d = view(h, slot0, n);
-  const int cur = (int)(h->scan_counter & 1);
-  if (stages & 1) launch_ip(d, pos, want_labels, h->stream);
-  if (stages & 2) { launch_fe(d, cur, h->stream); launch_lo(d, cur, h->stream); }
-  if ((stages & 4) && (stages & 2)) { if (int r = lm_host_enqueue(h->lm, d, cur, &h->err)) return r; }
-  ++h->scan_counter;
+  static const bool dbg = getenv("ALEGO_DEBUG_SYNC") != nullptr;
+  auto chk = [&](const char* what) { if (dbg) { hipError_t e = hipStreamSynchronize(h->stream); fprintf(stderr, "[alego dbg] %s: %s\n", what, hipGetErrorString(e)); } };
+  if (stages & 1) { launch_ip(d, pos, want_labels, h->stream); chk("ip"); }
+  if (stages & 2) {
+    launch_fe(d, h->stream); chk("fe");
+    launch_lo(d, h->stream); chk("lo");
+    std::vector<char> odom_valid(n);
+    for (int i = 0; i < n; ++i) odom_valid[i] = h->lo_scans[slot0 + i]++ > 0;
+    if (stages & 4) { if (int r = lm_host_enqueue(h->lm, d, odom_valid, &h->err)) return r; }
+  }
   HIP_TRY(h, hipGetLastError());
   return 0;
 }
@@ -215,7 +225,9 @@ static int fetch_pose(alego_handle* h, int slot, alego_pose* odom, alego_pose* m
     lm_host_get_params(h->lm, slot, map_pose->params);
     map_pose->valid = sc[SC_ODOM_VALID];
   }
-  return sc[SC_LO_FLAGS] | (sc[SC_LM_FLAGS]);
+  const int lmf = lm_host_get_flags(h->lm, slot);
+  if (lmf < 0) { h->err = "LaserMapping device capacity exceeded / launch logic out of sync"; return lmf; }
+  return sc[SC_LO_FLAGS] | lmf;
 }
 
 int alego_batch_get_pose(alego_handle* h, int slot, alego_pose* odom, alego_pose* map_pose) {
@@ -231,7 +243,7 @@ int alego_batch_get_counts(alego_handle* h, int slot, int32_t* out, int cap) {
   HIP_TRY(h, hipMemcpyAsync(sc, h->d.scal + (size_t)slot * SC_COUNT, sizeof(sc), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, hipMemcpyAsync(fc, h->d.feat_cnt + (size_t)slot * 8, sizeof(fc), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
-  const int cur = (int)((h->scan_counter + 1) & 1);  // buffer written by the last processed scan
+  const int cur = sc[SC_CUR];  // buffer written by the last processed scan
   int v[16] = {sc[SC_PVALID], sc[SC_M], sc[SC_NOUT], fc[cur * 4 + 0], fc[cur * 4 + 1], fc[cur * 4 + 2], fc[cur * 4 + 3],
                sc[SC_LO_NSURF], sc[SC_LO_NCORNER], 0, 0, 0, 0, 0, 0, 0};
   lm_host_get_counts(h->lm, slot, v + 9);
@@ -261,9 +273,10 @@ static int download_seg(alego_handle* h, int slot, alego_seg_out* out) {
   return 0;
 }
 
-static int download_feat(alego_handle* h, int slot, int cur, alego_feat_out* f) {
+static int download_feat(alego_handle* h, int slot, alego_feat_out* f) {
   const DevCtx& d = h->d;
-  int fc[4], M;
+  int fc[4], M, cur;
+  HIP_TRY(h, hipMemcpy(&cur, d.scal + (size_t)slot * SC_COUNT + SC_CUR, 4, hipMemcpyDeviceToHost));
   HIP_TRY(h, hipMemcpyAsync(fc, d.feat_cnt + ((size_t)slot * 2 + cur) * 4, sizeof(fc), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, hipMemcpyAsync(&M, d.scal + (size_t)slot * SC_COUNT + SC_M, 4, hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -301,9 +314,8 @@ int alego_lo_process(alego_handle* h, const alego_seg_out* in, alego_feat_out* f
   HIP_TRY(h, hipMemcpyAsync(d.ring_end, in->ring_end, d.NS * 4, hipMemcpyHostToDevice, h->stream));
   HIP_TRY(h, hipMemcpyAsync(d.scal + SC_M, &in->m, 4, hipMemcpyHostToDevice, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
-  const int cur = (int)(h->scan_counter & 1);
   if (int r = enqueue_scan(h, 0, 1, 0, 2, false)) return r;
-  if (feat) { if (int r = download_feat(h, 0, cur, feat)) return r; }
+  if (feat) { if (int r = download_feat(h, 0, feat)) return r; }
   return fetch_pose(h, 0, odom, nullptr) & 7;
 }
 
@@ -320,10 +332,9 @@ int alego_scan_process(alego_handle* h, int slot, const alego_scan_in* in, int s
   if (!in) return ALEGO_ERR_ARG;
   hipSetDevice(h->device);
   if (int r = alego_batch_load(h, slot, 0, in->pts, in->n)) return r;
-  const int cur = (int)(h->scan_counter & 1);
   if (int r = enqueue_scan(h, slot, 1, 0, stages, seg && seg->label_image)) return r;
   if (seg) { if (int r = download_seg(h, slot, seg)) return r; }
-  if (feat && (stages & 2)) { if (int r = download_feat(h, slot, cur, feat)) return r; }
+  if (feat && (stages & 2)) { if (int r = download_feat(h, slot, feat)) return r; }
   return fetch_pose(h, slot, odom, map_pose);
 }
 
@@ -363,7 +374,7 @@ int alego_debug_get(alego_handle* h, int slot, const char* name, void* out, int 
   const std::string s(name);
   const size_t base = (size_t)slot * d.N;
   const int M = sc[SC_M];
-  const int cur = (int)((h->scan_counter + 1) & 1);  // buffer written by the last processed scan
+  const int cur = sc[SC_CUR];  // buffer written by the last processed scan
   int fc[8];
   HIP_TRY(h, hipMemcpy(fc, d.feat_cnt + (size_t)slot * 8, sizeof(fc), hipMemcpyDeviceToHost));
   const void* src = nullptr;

@@ -24,7 +24,8 @@ enum {
   SC_LO_FLAGS,    // ALEGO_FLAG_* of the last LO step
   SC_LO_ITERS,    // packed solver summaries (surf: it | succ<<8 | term<<16 ; corner <<... in next)
   SC_LO_ITERS2,
-  SC_CUR,         // feature double-buffer index written by the last FE (0/1)
+  SC_CUR,         // feature double-buffer index holding the features of the last COMPLETED LO step;
+                  // FE/LO of the scan in flight write/read buffer SC_CUR^1, lo_solve(phase 1) flips it
   SC_ODOM_VALID,
   SC_LM_FRAME,    // LaserMapping frame_cnt (laserMapping.cpp:111)
   SC_LM_FLAGS,
@@ -96,6 +97,9 @@ enum {
 };
 
 #define DEV_INLINE __device__ __forceinline__
+
+// buffer written by the scan in flight (valid from fe_gather until lo_solve phase 1 flips SC_CUR)
+DEV_INLINE int cur_in_flight(const DevCtx& d, int slot) { return d.scal[slot * SC_COUNT + SC_CUR] ^ 1; }
 
 DEV_INLINE int32_t d_f2i(float f) { return __float_as_int(f); }
 DEV_INLINE float d_i2f(int32_t i) { return __int_as_float(i); }

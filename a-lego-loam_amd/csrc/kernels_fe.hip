@@ -308,8 +308,9 @@ __global__ void __launch_bounds__(FE_BLOCK) fe_voxel(DevCtx d) {
 }
 
 // ring-ascending concatenation.  grid (NS, slots)
-__global__ void __launch_bounds__(FE_BLOCK) fe_gather(DevCtx d, int cur) {
+__global__ void __launch_bounds__(FE_BLOCK) fe_gather(DevCtx d) {
   const int slot = blockIdx.y + d.slot0, ring = blockIdx.x, tid = threadIdx.x;
+  const int cur = cur_in_flight(d, slot);
   const size_t base = (size_t)slot * d.N;
   __shared__ int s_off[4], s_tot[4];
   const int* allc = d.st_cnt + (size_t)slot * d.NS * 8;
@@ -358,9 +359,9 @@ __global__ void __launch_bounds__(FE_BLOCK) fe_gather(DevCtx d, int cur) {
   }
 }
 
-void launch_fe(const DevCtx& d, int cur, hipStream_t st) {
+void launch_fe(const DevCtx& d, hipStream_t st) {
   hipLaunchKernelGGL(fe_curv, dim3((d.N + FE_BLOCK - 1) / FE_BLOCK, d.n_launch), dim3(FE_BLOCK), 0, st, d);
   hipLaunchKernelGGL(fe_pick, dim3(d.NS, d.n_launch), dim3(64), 0, st, d);
   hipLaunchKernelGGL(fe_voxel, dim3(d.NS, d.n_launch), dim3(FE_BLOCK), 0, st, d);
-  hipLaunchKernelGGL(fe_gather, dim3(d.NS, d.n_launch), dim3(FE_BLOCK), 0, st, d, cur);
+  hipLaunchKernelGGL(fe_gather, dim3(d.NS, d.n_launch), dim3(FE_BLOCK), 0, st, d);
 }

@@ -1,0 +1,617 @@
+// kernels_lm.hip — LaserMapping scan-to-map registration on gfx950
+// (replaces src/laserMapping.cpp:154-166,188-192,194-244,315-559 and laserMapping.h:164-194).
+//
+//   lm_prepare     laserOdomHandler + mainLoop gate + transformAssociateToMap; stages the inputs
+//   lm_concat      a19: concatenation of the <= K most recent key frames (already in the map frame)
+//   (voxel.h)      a19/a20: VoxelGrid of the map (only when the key-frame set changed) and of the scan
+//   lm_total       laser_surf_total_ = laser_surf_ds_ + laser_outlier_ds_ (:337-340)
+//   lm_grid_*      uniform grid (cell >= 1 m) over the down-sampled maps: exact 5-NN for every
+//                  accepted query because acceptance needs d5^2 < 1.0 (:376,:426) — replaces KdTreeFLANN
+//   lm_assoc       a21/a22: 5-NN, 3x3 scatter eigen-decomposition (line) / 5x3 Householder LS (plane)
+//   lm_solve       a23/a24: both ceres::Solve calls of :360-478 in one workgroup per stream
+//   lm_finish / lm_store_kf  saveKeyFramesAndFactor (no-loop-closure pass-through) + transformUpdate
+#include "dev_cost.h"
+#include "lm_ctx.h"
+
+#define LM_BLOCK 256
+#define LM_SOLVE_BLOCK 512
+
+DEV_INLINE double* ldp(const LmCtx& L, int slot) { return L.ld + (size_t)slot * LD_COUNT; }
+DEV_INLINE int* lip(const LmCtx& L, int slot) { return L.li + (size_t)slot * LI_COUNT; }
+DEV_INLINE DQuat ldq(const double* p) { return DQuat{p[0], p[1], p[2], p[3]}; }
+DEV_INLINE void stq(double* p, const DQuat& q) { p[0] = q.w; p[1] = q.x; p[2] = q.y; p[3] = q.z; }
+
+// grid (8, 3, slots).  stage: copy /corner_last, /surf_last, /outlier of this scan into the LM inputs.
+__global__ void __launch_bounds__(LM_BLOCK) lm_prepare(DevCtx d, LmCtx L, int stage, int run_hint) {
+  const int slot = blockIdx.z + d.slot0, kind = blockIdx.y;
+  const int cur = d.scal[slot * SC_COUNT + SC_CUR];  // LO has completed: features of this scan
+  int* li = lip(L, slot);
+  const int* sc = d.scal + slot * SC_COUNT;
+  if (stage) {
+    // (written with unconditional loads + selects: a 3-way if/else chain here was lowered by hipcc 7.2 into
+    //  a scalar switch that left the count pointer of the last arm undefined)
+    const size_t fb = (size_t)slot * 2 + cur;
+    const int n_c = d.feat_cnt[fb * 4 + F_LSHARP], n_s = d.feat_cnt[fb * 4 + F_LFLAT], n_o = sc[SC_NOUT];
+    const float4* src_c = d.feat[F_LSHARP] + fb * d.fcap[F_LSHARP];
+    const float4* src_s = d.feat[F_LFLAT] + fb * d.fcap[F_LFLAT];
+    const float4* src_o = d.outlier + (size_t)slot * d.N;
+    const float4* src = kind == 0 ? src_c : (kind == 1 ? src_s : src_o);
+    float4* dst = kind == 0 ? L.in_corner + (size_t)slot * L.in_cap_c : (kind == 1 ? L.in_surf + (size_t)slot * L.in_cap_s : L.in_outl + (size_t)slot * L.in_cap_o);
+    const int cap = kind == 0 ? L.in_cap_c : (kind == 1 ? L.in_cap_s : L.in_cap_o);
+    int n = kind == 0 ? n_c : (kind == 1 ? n_s : n_o);
+    if (n > cap) { n = cap; if (threadIdx.x == 0 && blockIdx.x == 0) li[LI_OVERFLOW] = 1; }
+    for (int i = blockIdx.x * LM_BLOCK + threadIdx.x; i < n; i += gridDim.x * LM_BLOCK) dst[i] = src[i];
+    if (blockIdx.x == 0 && threadIdx.x == 0) li[LI_NIN_C + kind] = n;
+  }
+  if (blockIdx.x != 0 || kind != 0 || threadIdx.x != 0) return;
+  double* ld = ldp(L, slot);
+  double* po = d.poses + (size_t)slot * 16;
+  li[LI_RUN] = 0; li[LI_REBUILD] = 0; li[LI_KF_ADDED] = 0; li[LI_OPTIMIZED] = 0; li[LI_FLAGS] = 0;
+  if (!sc[SC_ODOM_VALID]) return;  // no /odom/lidar on the initialising scan -> no mapping frame
+  // laserOdomHandler :154-166
+  for (int k = 0; k < 3; ++k) ld[LD_T_O2L + k] = po[k];
+  for (int k = 0; k < 4; ++k) ld[LD_Q_O2L + k] = po[3 + k];
+  const DQuat qm2o = ldq(ld + LD_Q_M2O), qo2l = ldq(ld + LD_Q_O2L);
+  double r[3];
+  dq_rotate(qm2o, ld + LD_T_O2L, r);
+  for (int k = 0; k < 3; ++k) ld[LD_T_M2L + k] = r[k] + ld[LD_T_M2O + k];
+  stq(ld + LD_Q_M2L, dq_mul(qm2o, qo2l));
+  for (int k = 0; k < 3; ++k) po[7 + k] = ld[LD_T_M2L + k];   // /odom_aft_mapped
+  for (int k = 0; k < 4; ++k) po[10 + k] = ld[LD_Q_M2L + k];
+  // mainLoop gate :107-127
+  const int run = (li[LI_FRAME] % d.P.lm_every) == 0;
+  li[LI_FRAME] += 1;
+  li[LI_RUN] = run;
+  if (run_hint >= 0 && run != run_hint) li[LI_OVERFLOW] = 2;  // host launch-skipping logic out of sync
+  if (!run) { li[LI_FLAGS] = 8; return; }
+  if (li[LI_NKF] > 0 && li[LI_DIRTY]) { li[LI_REBUILD] = 1; li[LI_DIRTY] = 0; }
+}
+
+// grid (16, K, slots): chronological concatenation of the key-frame ring
+__global__ void __launch_bounds__(LM_BLOCK) lm_concat(DevCtx d, LmCtx L) {
+  const int slot = blockIdx.z + d.slot0, j = blockIdx.y;
+  int* li = lip(L, slot);
+  if (!li[LI_REBUILD]) return;
+  const int nkf = li[LI_NKF], nk = min(nkf, L.K);
+  if (j >= nk) return;
+  const int* kc = L.kf_cnt + (size_t)slot * L.K * 4;
+  int offc = 0, offs = 0;
+  for (int i = 0; i < j; ++i) { const int r = (nkf - nk + i) % L.K; offc += kc[r * 4 + 0]; offs += kc[r * 4 + 1] + kc[r * 4 + 2]; }
+  const int ring = (nkf - nk + j) % L.K;
+  const int nc = kc[ring * 4 + 0], ns = kc[ring * 4 + 1], no = kc[ring * 4 + 2];
+  const float4* sc_ = L.kf_corner + ((size_t)slot * L.K + ring) * L.kf_cap_c;
+  const float4* ss_ = L.kf_surf + ((size_t)slot * L.K + ring) * L.kf_cap_s;
+  const float4* so_ = L.kf_outl + ((size_t)slot * L.K + ring) * L.kf_cap_o;
+  float4* dc = L.map_corner_raw + (size_t)slot * L.map_cap_c + offc;
+  float4* ds = L.map_surf_raw + (size_t)slot * L.map_cap_s + offs;  // surf then outlier per key frame (:241-242)
+  for (int i = blockIdx.x * LM_BLOCK + threadIdx.x; i < nc; i += gridDim.x * LM_BLOCK) dc[i] = sc_[i];
+  for (int i = blockIdx.x * LM_BLOCK + threadIdx.x; i < ns; i += gridDim.x * LM_BLOCK) ds[i] = ss_[i];
+  for (int i = blockIdx.x * LM_BLOCK + threadIdx.x; i < no; i += gridDim.x * LM_BLOCK) ds[ns + i] = so_[i];
+  if (j == nk - 1 && blockIdx.x == 0 && threadIdx.x == 0) { li[LI_KRAW_C] = offc + nc; li[LI_KRAW_S] = offs + ns + no; }
+}
+
+// grid (8, slots)
+__global__ void __launch_bounds__(LM_BLOCK) lm_total(DevCtx d, LmCtx L) {
+  const int slot = blockIdx.y + d.slot0;
+  int* li = lip(L, slot);
+  if (!li[LI_RUN]) return;
+  int ns = li[LI_NCUR_S], no = li[LI_NCUR_O];
+  if (ns + no > L.total_cap) { no = L.total_cap - ns; if (threadIdx.x == 0 && blockIdx.x == 0) li[LI_OVERFLOW] = 1; }
+  const float4* s = L.cur_surf_ds + (size_t)slot * L.kf_cap_s;
+  const float4* o = L.cur_outl_ds + (size_t)slot * L.kf_cap_o;
+  float4* t = L.cur_total + (size_t)slot * L.total_cap;
+  for (int i = blockIdx.x * LM_BLOCK + threadIdx.x; i < ns; i += gridDim.x * LM_BLOCK) t[i] = s[i];
+  for (int i = blockIdx.x * LM_BLOCK + threadIdx.x; i < no; i += gridDim.x * LM_BLOCK) t[ns + i] = o[i];
+  if (blockIdx.x == 0 && threadIdx.x == 0) li[LI_NTOTAL] = ns + no;
+}
+
+DEV_INLINE float vxl_dec(unsigned e) {
+  const unsigned b = (e >> 31) ? (e ^ 0x80000000u) : ~e;
+  return __int_as_float((int)b);
+}
+
+// grid (2, slots): grid geometry from the raw map bounding box, zero the cell counters
+__global__ void __launch_bounds__(LM_BLOCK) lm_grid_setup(DevCtx d, LmCtx L) {
+  const int slot = blockIdx.y + d.slot0, m = blockIdx.x;
+  const int* li = lip(L, slot);
+  if (!li[LI_REBUILD]) return;
+  __shared__ GridGeom s_g;
+  if (threadIdx.x == 0) {
+    const unsigned* bb = L.vox_bbox + ((size_t)slot * 5 + m) * 8;
+    GridGeom g;
+    float mn[3], mx[3];
+    for (int a = 0; a < 3; ++a) { mn[a] = vxl_dec(bb[a]); mx[a] = vxl_dec(~bb[4 + a]); }
+    if (li[LI_KRAW_C + m] <= 0) { for (int a = 0; a < 3; ++a) { mn[a] = 0.f; mx[a] = 0.f; } }
+    float cell = 1.0f;  // >= sqrt(knn_max_dist)
+    const float need = sqrtf((float)d.P.knn_max_dist);
+    while (cell < need) cell *= 2.0f;
+    for (;;) {
+      g.gx = (int)floorf((mx[0] - mn[0]) / cell) + 2; g.gy = (int)floorf((mx[1] - mn[1]) / cell) + 2; g.gz = (int)floorf((mx[2] - mn[2]) / cell) + 2;
+      if ((long long)g.gx * g.gy * g.gz <= (long long)L.gcap) break;
+      cell *= 2.0f;
+    }
+    g.ox = mn[0]; g.oy = mn[1]; g.oz = mn[2]; g.inv = 1.0f / cell; g.ncell = g.gx * g.gy * g.gz;
+    s_g = g;
+    L.grid[(size_t)slot * 2 + m] = g;
+  }
+  __syncthreads();
+  int* cs = L.cell_start + ((size_t)slot * 2 + m) * (L.gcap + 1);
+  for (int c = threadIdx.x; c <= s_g.ncell; c += LM_BLOCK) cs[c] = 0;
+}
+
+DEV_INLINE int grid_cell(const GridGeom& g, float x, float y, float z, int* cx, int* cy, int* cz) {
+  int ix = (int)floorf((x - g.ox) * g.inv), iy = (int)floorf((y - g.oy) * g.inv), iz = (int)floorf((z - g.oz) * g.inv);
+  *cx = ix; *cy = iy; *cz = iz;
+  ix = min(max(ix, 0), g.gx - 1); iy = min(max(iy, 0), g.gy - 1); iz = min(max(iz, 0), g.gz - 1);
+  return ix + g.gx * (iy + g.gy * iz);
+}
+
+// grid (32, 2, slots)
+__global__ void __launch_bounds__(LM_BLOCK) lm_grid_count(DevCtx d, LmCtx L, int fill) {
+  const int slot = blockIdx.z + d.slot0, m = blockIdx.y;
+  const int* li = lip(L, slot);
+  if (!li[LI_REBUILD]) return;
+  const GridGeom g = L.grid[(size_t)slot * 2 + m];
+  const int n = li[LI_KDS_C + m];
+  const float4* pts = (m == 0 ? L.map_corner_ds + (size_t)slot * L.map_cap_c : L.map_surf_ds + (size_t)slot * L.map_cap_s);
+  int* cs = (fill ? L.cell_cur : L.cell_start) + ((size_t)slot * 2 + m) * (L.gcap + 1);
+  int* cp = L.cell_pts + ((size_t)slot * 2 + m) * L.map_cap_s;
+  for (int i = blockIdx.x * LM_BLOCK + threadIdx.x; i < n; i += gridDim.x * LM_BLOCK) {
+    const float4 p = pts[i];
+    int cx, cy, cz;
+    const int c = grid_cell(g, p.x, p.y, p.z, &cx, &cy, &cz);
+    const int pos = atomicAdd(&cs[c], 1);
+    if (fill) cp[pos] = i;
+  }
+}
+
+// grid (2, slots): exclusive scan of the cell counts (in place) + fill cursors
+__global__ void __launch_bounds__(LM_BLOCK) lm_grid_scan(DevCtx d, LmCtx L) {
+  const int slot = blockIdx.y + d.slot0, m = blockIdx.x;
+  const int* li = lip(L, slot);
+  if (!li[LI_REBUILD]) return;
+  const int ncell = L.grid[(size_t)slot * 2 + m].ncell;
+  int* cs = L.cell_start + ((size_t)slot * 2 + m) * (L.gcap + 1);
+  int* cc = L.cell_cur + ((size_t)slot * 2 + m) * (L.gcap + 1);
+  __shared__ int s[LM_BLOCK / 64];
+  __shared__ int s_run;
+  if (threadIdx.x == 0) s_run = 0;
+  __syncthreads();
+  for (int c0 = 0; c0 <= ncell; c0 += LM_BLOCK) {
+    const int c = c0 + threadIdx.x;
+    const int v = c < ncell ? cs[c] : 0;
+    int incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if ((threadIdx.x & 63) >= o) incl += t; }
+    if ((threadIdx.x & 63) == 63) s[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    int woff = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < LM_BLOCK / 64; ++w) { if (w < (int)(threadIdx.x >> 6)) woff += s[w]; tot += s[w]; }
+    const int run = s_run;
+    if (c <= ncell) { const int e = run + woff + incl - v; cs[c] = e; cc[c] = e; }
+    __syncthreads();
+    if (threadIdx.x == 0) s_run = run + tot;
+    __syncthreads();
+  }
+}
+
+// ---- small dense linear algebra in registers ------------------------------------------
+// symmetric 3x3 eigen-decomposition, cyclic Jacobi (same algorithm as the oracle's eig3)
+DEV_INLINE void d_eig3(const double Ain[9], double lam[3], double vmax[3], double* lam_mid) {
+  double A[9], V[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) { A[i] = Ain[i]; V[i] = (i % 4 == 0) ? 1.0 : 0.0; }
+  for (int sweep = 0; sweep < 60; ++sweep) {
+    const double off = A[1] * A[1] + A[2] * A[2] + A[5] * A[5];
+    if (off < 1e-300) break;
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int q = p + 1; q < 3; ++q) {
+        const double apq = A[p * 3 + q];
+        if (apq == 0.0) continue;
+        const double theta = (A[q * 3 + q] - A[p * 3 + p]) / (2.0 * apq);
+        const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+        const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { const double akp = A[k * 3 + p], akq = A[k * 3 + q]; A[k * 3 + p] = c * akp - s * akq; A[k * 3 + q] = s * akp + c * akq; }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { const double apk = A[p * 3 + k], aqk = A[q * 3 + k]; A[p * 3 + k] = c * apk - s * aqk; A[q * 3 + k] = s * apk + c * aqk; }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { const double vkp = V[k * 3 + p], vkq = V[k * 3 + q]; V[k * 3 + p] = c * vkp - s * vkq; V[k * 3 + q] = s * vkp + c * vkq; }
+      }
+  }
+  const double dd[3] = {A[0], A[4], A[8]};
+  int imax = 0, imin = 0;
+  // ascending order with std::sort-like tie handling on indices (first minimum, last maximum not needed: ties are measure-zero)
+  if (dd[1] > dd[imax]) imax = 1;
+  if (dd[2] > dd[imax]) imax = 2;
+  if (dd[1] < dd[imin]) imin = 1;
+  if (dd[2] < dd[imin]) imin = 2;
+  int imid = 3 - imax - imin;
+  if (imax == imin) { imax = 2; imin = 0; imid = 1; }
+  lam[0] = dd[imin]; lam[1] = dd[imid]; lam[2] = dd[imax];
+  *lam_mid = dd[imid];
+  vmax[0] = V[0 * 3 + imax]; vmax[1] = V[1 * 3 + imax]; vmax[2] = V[2 * 3 + imax];
+}
+
+// least squares min ||A x - b|| for a 5x3 system by Householder QR (the oracle's qr_solve specialised)
+DEV_INLINE void d_qr53(double A[3][5], double b[5], double x[3]) {
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    double norm2 = 0;
+    for (int i = k; i < 5; ++i) norm2 += A[k][i] * A[k][i];
+    const double norm = sqrt(norm2);
+    if (norm == 0.0) continue;
+    const double alpha = A[k][k] > 0 ? -norm : norm;
+    double v[5];
+    for (int i = k; i < 5; ++i) v[i] = A[k][i];
+    v[k] -= alpha;
+    double vn2 = 0;
+    for (int i = k; i < 5; ++i) vn2 += v[i] * v[i];
+    if (vn2 == 0.0) continue;
+    for (int j = k; j < 3; ++j) {
+      double dot = 0;
+      for (int i = k; i < 5; ++i) dot += v[i] * A[j][i];
+      const double f = 2.0 * dot / vn2;
+      for (int i = k; i < 5; ++i) A[j][i] -= f * v[i];
+    }
+    double dot = 0;
+    for (int i = k; i < 5; ++i) dot += v[i] * b[i];
+    const double f = 2.0 * dot / vn2;
+    for (int i = k; i < 5; ++i) b[i] -= f * v[i];
+  }
+  for (int k = 2; k >= 0; --k) {
+    double s = b[k];
+    for (int j = k + 1; j < 3; ++j) s -= A[j][k] * x[j];
+    x[k] = s / A[k][k];
+  }
+}
+
+// grid (ceil(qcap/128), 2, slots): one thread per query point
+__global__ void __launch_bounds__(128) lm_assoc(DevCtx d, LmCtx L) {
+  const int slot = blockIdx.z + d.slot0, kind = blockIdx.y;
+  const int* li = lip(L, slot);
+  if (!li[LI_RUN]) return;
+  const alego_params& P = d.P;
+  // registration guard :350
+  if (li[LI_NCUR_C] < P.lm_min_corner || li[LI_NTOTAL] < P.lm_min_surf || li[LI_KDS_C] < P.lm_min_map_corner || li[LI_NKF] == 0) return;
+  const int nq = kind == 0 ? li[LI_NCUR_C] : li[LI_NTOTAL_DS];
+  const int q = blockIdx.x * 128 + threadIdx.x;
+  if (q >= nq) return;
+  const float4* qp = kind == 0 ? L.cur_corner_ds + (size_t)slot * L.kf_cap_c : L.cur_total_ds + (size_t)slot * L.total_cap;
+  const float4* mp = kind == 0 ? L.map_corner_ds + (size_t)slot * L.map_cap_c : L.map_surf_ds + (size_t)slot * L.map_cap_s;
+  const int nmap = li[LI_KDS_C + kind];
+  const GridGeom g = L.grid[(size_t)slot * 2 + kind];
+  const int* cs = L.cell_start + ((size_t)slot * 2 + kind) * (L.gcap + 1);
+  const int* cp = L.cell_pts + ((size_t)slot * 2 + kind) * L.map_cap_s;
+  const double* ld = ldp(L, slot);
+  double* blk = L.blocks + ((size_t)slot * L.qcap + (kind == 0 ? 0 : L.kf_cap_c) + q) * 8;
+  blk[7] = 0.0;
+  const float4 pin = qp[q];
+  // pointAssociateToMap laserMapping.h:187-194 (pose predicted from odometry)
+  const DQuat qm = ldq(ld + LD_Q_M2L);
+  const double vin[3] = {pin.x, pin.y, pin.z};
+  double r[3];
+  dq_rotate(qm, vin, r);
+  const float sx = (float)(r[0] + ld[LD_T_M2L + 0]), sy = (float)(r[1] + ld[LD_T_M2L + 1]), sz = (float)(r[2] + ld[LD_T_M2L + 2]);
+  // exact 5-NN among all points with d^2 < knn_max_dist: they all lie in the 27 surrounding cells
+  float bd[5];
+  int bi[5];
+#pragma unroll
+  for (int k = 0; k < 5; ++k) { bd[k] = 3.402823466e+38f; bi[k] = 0x7fffffff; }
+  int found = 0;
+  if (nmap >= 5) {
+    int cx, cy, cz;
+    grid_cell(g, sx, sy, sz, &cx, &cy, &cz);
+    for (int dz = -1; dz <= 1; ++dz) {
+      const int z = cz + dz;
+      if (z < 0 || z >= g.gz) continue;
+      for (int dy = -1; dy <= 1; ++dy) {
+        const int y = cy + dy;
+        if (y < 0 || y >= g.gy) continue;
+        const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.gx - 1);
+        if (x0 > x1) continue;
+        const int c0 = x0 + g.gx * (y + g.gy * z), c1 = x1 + g.gx * (y + g.gy * z);
+        for (int t = cs[c0]; t < cs[c1 + 1]; ++t) {  // the x-run of cells is contiguous in the cell-sorted list
+          const int idx = cp[t];
+          const float4 a = mp[idx];
+          float dist = 0.f, df;
+          df = sx - a.x; dist += df * df;
+          df = sy - a.y; dist += df * df;
+          df = sz - a.z; dist += df * df;
+          if (dist < bd[4] || (dist == bd[4] && idx < bi[4])) {
+            bd[4] = dist; bi[4] = idx;
+#pragma unroll
+            for (int k = 4; k > 0; --k) {
+              if (bd[k] < bd[k - 1] || (bd[k] == bd[k - 1] && bi[k] < bi[k - 1])) {
+                const float td = bd[k]; bd[k] = bd[k - 1]; bd[k - 1] = td;
+                const int ti = bi[k]; bi[k] = bi[k - 1]; bi[k - 1] = ti;
+              }
+            }
+            ++found;
+          }
+        }
+      }
+    }
+  }
+  if (found < 5 || !((double)bd[4] < P.knn_max_dist)) return;
+  if (kind == 0) {  // :378-411
+    double near[5][3], center[3] = {0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      const float4 m = mp[bi[j]];
+      near[j][0] = m.x; near[j][1] = m.y; near[j][2] = m.z;
+#pragma unroll
+      for (int a = 0; a < 3; ++a) center[a] = center[a] + near[j][a];
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) center[a] = center[a] / 5.0;
+    double cov[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      const double zm[3] = {near[j][0] - center[0], near[j][1] - center[1], near[j][2] - center[2]};
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) cov[a * 3 + b] = cov[a * 3 + b] + zm[a] * zm[b];
+    }
+    double lam[3], v[3], lmid;
+    d_eig3(cov, lam, v, &lmid);
+    if (lam[2] > P.line_ratio * lam[1]) {
+#pragma unroll
+      for (int a = 0; a < 3; ++a) { blk[a] = P.line_half_len * v[a] + center[a]; blk[3 + a] = -P.line_half_len * v[a] + center[a]; }
+      blk[6] = 0.0;
+      blk[7] = 2.0;  // BLK_EDGE
+    }
+  } else {  // :424-460
+    double A[3][5], b[5], nrm[3];
+    float mx[5], my[5], mz[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      const float4 m = mp[bi[j]];
+      mx[j] = m.x; my[j] = m.y; mz[j] = m.z;
+      A[0][j] = m.x; A[1][j] = m.y; A[2][j] = m.z; b[j] = -1.0;
+    }
+    d_qr53(A, b, nrm);
+    const double nn = sqrt(nrm[0] * nrm[0] + nrm[1] * nrm[1] + nrm[2] * nrm[2]);
+    const double dd = 1 / nn;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) nrm[a] /= nn;
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < 5; ++j)
+      if (fabs(nrm[0] * mx[j] + nrm[1] * my[j] + nrm[2] * mz[j] + dd) > P.plane_tol) ok = false;
+    if (ok) {
+      blk[0] = nrm[0]; blk[1] = nrm[1]; blk[2] = nrm[2]; blk[3] = 0; blk[4] = 0; blk[5] = 0;
+      blk[6] = dd;
+      blk[7] = 3.0;  // BLK_PLANE
+    }
+  }
+}
+
+DEV_INLINE void lm_block_reduce28(double acc[28], double (*s_part)[28], double* s_out) {
+#pragma unroll
+  for (int k = 0; k < 28; ++k) acc[k] = wave_sum_f64(acc[k]);
+  const int wave = threadIdx.x >> 6;
+  if (lane_id() == 0) {
+#pragma unroll
+    for (int k = 0; k < 28; ++k) s_part[wave][k] = acc[k];
+  }
+  __syncthreads();
+  if (threadIdx.x < 28) {
+    double t = 0;
+    for (int w = 0; w < LM_SOLVE_BLOCK / 64; ++w) t += s_part[w][threadIdx.x];
+    s_out[threadIdx.x] = t;
+  }
+  __syncthreads();
+}
+
+// grid (slots): scan2MapOptimization's solver part
+__global__ void __launch_bounds__(LM_SOLVE_BLOCK) lm_solve(DevCtx d, LmCtx L) {
+  const int slot = blockIdx.x + d.slot0;
+  int* li = lip(L, slot);
+  if (!li[LI_RUN]) return;
+  const alego_params& P = d.P;
+  double* ld = ldp(L, slot);
+  if (li[LI_NCUR_C] < P.lm_min_corner || li[LI_NTOTAL] < P.lm_min_surf || li[LI_KDS_C] < P.lm_min_map_corner || li[LI_NKF] == 0) {
+    if (threadIdx.x == 0) { li[LI_FLAGS] |= 16; li[LI_NCC] = 0; li[LI_NSC] = 0; li[LI_SUM0] = 0; li[LI_SUM1] = 0; }
+    return;
+  }
+  __shared__ double s_part[LM_SOLVE_BLOCK / 64][28];
+  __shared__ double s_out[28];
+  __shared__ LmState S;
+  __shared__ int s_action, s_cnt[2][LM_SOLVE_BLOCK / 64];
+  const int nqc = li[LI_NCUR_C], nqs = li[LI_NTOTAL_DS];
+  const double* blocks = L.blocks + (size_t)slot * L.qcap * 8;
+  const float4* qc = L.cur_corner_ds + (size_t)slot * L.kf_cap_c;
+  const float4* qs = L.cur_total_ds + (size_t)slot * L.total_cap;
+  {  // correspondence counts (:465)
+    int cc = 0, cs = 0;
+    for (int i = threadIdx.x; i < nqc; i += LM_SOLVE_BLOCK) cc += blocks[(size_t)i * 8 + 7] != 0.0;
+    for (int i = threadIdx.x; i < nqs; i += LM_SOLVE_BLOCK) cs += blocks[(size_t)(L.kf_cap_c + i) * 8 + 7] != 0.0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { cc += __shfl_xor(cc, o, 64); cs += __shfl_xor(cs, o, 64); }
+    if (lane_id() == 0) { s_cnt[0][threadIdx.x >> 6] = cc; s_cnt[1][threadIdx.x >> 6] = cs; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int a = 0, b = 0;
+      for (int w = 0; w < LM_SOLVE_BLOCK / 64; ++w) { a += s_cnt[0][w]; b += s_cnt[1][w]; }
+      li[LI_NCC] = a; li[LI_NSC] = b; li[LI_OPTIMIZED] = 1;
+      s_cnt[0][0] = a + b;
+    }
+    __syncthreads();
+  }
+  const int R = s_cnt[0][0];
+  double acc[28];
+  auto evaluate = [&](const double* x) {
+#pragma unroll
+    for (int k = 0; k < 28; ++k) acc[k] = 0;
+    const PoseTerms T = pose_terms(x);
+    for (int i = threadIdx.x; i < nqc + nqs; i += LM_SOLVE_BLOCK) {
+      const bool is_c = i < nqc;
+      const double* b = blocks + (size_t)(is_c ? i : L.kf_cap_c + (i - nqc)) * 8;
+      const double ty = b[7];
+      if (ty == 0.0) continue;
+      const float4 pc = is_c ? qc[i] : qs[i - nqc];
+      const double cp[3] = {pc.x, pc.y, pc.z}, a3[3] = {b[0], b[1], b[2]}, b3[3] = {b[3], b[4], b[5]}, c3[3] = {0, 0, 0};
+      double res, J[6];
+      eval_block(ty == 2.0 ? BLK_EDGE : BLK_PLANE, cp, a3, b3, c3, b[6], T, &res, J);
+      accumulate_block(res, J, P.huber_delta, acc);
+    }
+    lm_block_reduce28(acc, s_part, s_out);
+  };
+  for (int outer = 0; outer < P.lm_outer_iters; ++outer) {  // :360 — identical correspondences both times
+    if (R == 0) {  // ceres::Solve on an empty problem is a no-op
+      if (threadIdx.x == 0 && outer < 2) {
+        li[LI_SUM0 + outer] = 4 << 16;
+        for (int k = 0; k < 6; ++k) ld[LD_PARAMS_IT + outer * 6 + k] = ld[LD_PARAMS + k];
+      }
+      continue;
+    }
+    double x0[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) x0[k] = ld[LD_PARAMS + k];
+    evaluate(x0);
+    if (threadIdx.x == 0) lm_begin(S, x0, s_out, P.lm_max_iters);
+    __syncthreads();
+    while (true) {
+      if (threadIdx.x == 0) s_action = lm_propose(S);
+      __syncthreads();
+      const int act = s_action;
+      if (act == LM_STOP) break;
+      if (act == LM_EVAL) {
+        double xc[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) xc[k] = S.cand[k];
+        evaluate(xc);
+        if (threadIdx.x == 0) s_action = lm_consume(S, s_out);
+        __syncthreads();
+        if (s_action == LM_STOP) break;
+      }
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) ld[LD_PARAMS + k] = S.x[k];
+      if (outer < 2) {
+        for (int k = 0; k < 6; ++k) ld[LD_PARAMS_IT + outer * 6 + k] = S.x[k];
+        ld[LD_COSTS + outer * 2] = S.initial_cost; ld[LD_COSTS + outer * 2 + 1] = S.x_cost;
+        li[LI_SUM0 + outer] = S.iter | (S.successful << 8) | (S.termination << 16);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// f32 4x4 of transformPointCloud (laserMapping.h:166-173): AngleAxisf(yaw,Z)*AngleAxisf(pitch,Y)*AngleAxisf(roll,X).
+// sin/cos of the half angles are evaluated in double and rounded to f32 (deviation from sinf/cosf).
+DEV_INLINE void keypose_matrix(const float* kp, float m[3][4]) {
+  const float hz = 0.5f * kp[5], hy = 0.5f * kp[4], hx = 0.5f * kp[3];
+  const float qz[4] = {(float)cos((double)hz), 0.f, 0.f, (float)sin((double)hz)};
+  const float qy[4] = {(float)cos((double)hy), 0.f, (float)sin((double)hy), 0.f};
+  const float qx[4] = {(float)cos((double)hx), (float)sin((double)hx), 0.f, 0.f};
+  float t[4], q[4];
+  t[0] = qz[0] * qy[0] - qz[1] * qy[1] - qz[2] * qy[2] - qz[3] * qy[3];
+  t[1] = qz[0] * qy[1] + qz[1] * qy[0] + qz[2] * qy[3] - qz[3] * qy[2];
+  t[2] = qz[0] * qy[2] + qz[2] * qy[0] + qz[3] * qy[1] - qz[1] * qy[3];
+  t[3] = qz[0] * qy[3] + qz[3] * qy[0] + qz[1] * qy[2] - qz[2] * qy[1];
+  q[0] = t[0] * qx[0] - t[1] * qx[1] - t[2] * qx[2] - t[3] * qx[3];
+  q[1] = t[0] * qx[1] + t[1] * qx[0] + t[2] * qx[3] - t[3] * qx[2];
+  q[2] = t[0] * qx[2] + t[2] * qx[0] + t[3] * qx[1] - t[1] * qx[3];
+  q[3] = t[0] * qx[3] + t[3] * qx[0] + t[1] * qx[2] - t[2] * qx[1];
+  const float w = q[0], x = q[1], y = q[2], z = q[3];
+  const float tx = 2 * x, ty = 2 * y, tz = 2 * z;
+  const float twx = tx * w, twy = ty * w, twz = tz * w, txx = tx * x, txy = ty * x, txz = tz * x, tyy = ty * y, tyz = tz * y, tzz = tz * z;
+  m[0][0] = 1 - (tyy + tzz); m[0][1] = txy - twz; m[0][2] = txz + twy; m[0][3] = kp[0];
+  m[1][0] = txy + twz; m[1][1] = 1 - (txx + tzz); m[1][2] = tyz - twx; m[1][3] = kp[1];
+  m[2][0] = txz - twy; m[2][1] = tyz + twx; m[2][2] = 1 - (txx + tyy); m[2][3] = kp[2];
+}
+
+// grid (ceil(slots/64)): saveKeyFramesAndFactor :491-559 (no-loop-closure pass-through) + transformUpdate :481-489
+__global__ void lm_finish(DevCtx d, LmCtx L) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= d.n_launch) return;
+  const int slot = s + d.slot0;
+  int* li = lip(L, slot);
+  if (!li[LI_RUN]) return;
+  double* ld = ldp(L, slot);
+  const int nkf = li[LI_NKF];
+  bool add = true;
+  if (nkf > 0) {
+    const float* pre = L.kf_pose + ((size_t)slot * L.K + (nkf - 1) % L.K) * 8;
+    const double ex = ld[LD_T_M2L + 0] - (double)pre[0], ey = ld[LD_T_M2L + 1] - (double)pre[1], ez = ld[LD_T_M2L + 2] - (double)pre[2];
+    if (ex * ex + ey * ey + ez * ez < d.P.min_keyframe_dist) add = false;  // :501-508
+  }
+  if (add) {
+    double R[9];
+    dq_to_mat(ldq(ld + LD_Q_M2L), R);
+    const double roll = atan2(R[7], R[8]);
+    const double pitch = atan2(-R[6], sqrt(R[7] * R[7] + R[8] * R[8]));
+    const double yaw = atan2(R[3], R[0]);
+    float* kp = L.kf_pose + ((size_t)slot * L.K + nkf % L.K) * 8;
+    kp[0] = (float)ld[LD_T_M2L + 0]; kp[1] = (float)ld[LD_T_M2L + 1]; kp[2] = (float)ld[LD_T_M2L + 2];
+    kp[3] = (float)roll; kp[4] = (float)pitch; kp[5] = (float)yaw;
+    for (int k = 0; k < 6; ++k) ld[LD_PARAMS + k] = (double)kp[k];  // :539-544
+    li[LI_NKF] = nkf + 1; li[LI_DIRTY] = 1; li[LI_KF_ADDED] = 1; li[LI_FLAGS] |= 32;
+  }
+  // transformUpdate
+  const DQuat qm2l = dq_zyx(ld[LD_PARAMS + 5], ld[LD_PARAMS + 4], ld[LD_PARAMS + 3]);
+  stq(ld + LD_Q_M2L, qm2l);
+  for (int k = 0; k < 3; ++k) ld[LD_T_M2L + k] = ld[LD_PARAMS + k];
+  const DQuat qm2o = dq_mul(qm2l, dq_inverse(ldq(ld + LD_Q_O2L)));
+  stq(ld + LD_Q_M2O, qm2o);
+  double r[3];
+  dq_rotate(qm2o, ld + LD_T_O2L, r);
+  for (int k = 0; k < 3; ++k) ld[LD_T_M2O + k] = ld[LD_T_M2L + k] - r[k];
+}
+
+// grid (8, 3, slots): transform the down-sampled scan by the new key pose into the ring (laserMapping.h:164-177)
+__global__ void __launch_bounds__(LM_BLOCK) lm_store_kf(DevCtx d, LmCtx L) {
+  const int slot = blockIdx.z + d.slot0, kind = blockIdx.y;
+  int* li = lip(L, slot);
+  if (!li[LI_KF_ADDED]) return;
+  const int ring = (li[LI_NKF] - 1) % L.K;
+  const float* kp = L.kf_pose + ((size_t)slot * L.K + ring) * 8;
+  float m[3][4];
+  keypose_matrix(kp, m);
+  const float4* src = kind == 0 ? L.cur_corner_ds + (size_t)slot * L.kf_cap_c : (kind == 1 ? L.cur_surf_ds + (size_t)slot * L.kf_cap_s : L.cur_outl_ds + (size_t)slot * L.kf_cap_o);
+  float4* dst = kind == 0 ? L.kf_corner + ((size_t)slot * L.K + ring) * L.kf_cap_c
+                          : (kind == 1 ? L.kf_surf + ((size_t)slot * L.K + ring) * L.kf_cap_s : L.kf_outl + ((size_t)slot * L.K + ring) * L.kf_cap_o);
+  const int n_c = li[LI_NCUR_C], n_s = li[LI_NCUR_S], n_o = li[LI_NCUR_O];
+  const int n = kind == 0 ? n_c : (kind == 1 ? n_s : n_o);
+  for (int i = blockIdx.x * LM_BLOCK + threadIdx.x; i < n; i += gridDim.x * LM_BLOCK) {
+    const float4 p = src[i];
+    float4 o;
+    o.x = m[0][0] * p.x + m[0][1] * p.y + m[0][2] * p.z + m[0][3];
+    o.y = m[1][0] * p.x + m[1][1] * p.y + m[1][2] * p.z + m[1][3];
+    o.z = m[2][0] * p.x + m[2][1] * p.y + m[2][2] * p.z + m[2][3];
+    o.w = p.w;
+    dst[i] = o;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) L.kf_cnt[((size_t)slot * L.K + ring) * 4 + kind] = n;
+}
+
+// ---- launchers ---------------------------------------------------------------------
+void launch_lm_prepare(const DevCtx& d, const LmCtx& L, int stage, int run_hint, hipStream_t st) {
+  hipLaunchKernelGGL(lm_prepare, dim3(8, 3, d.n_launch), dim3(LM_BLOCK), 0, st, d, L, stage, run_hint);
+}
+void launch_lm_concat(const DevCtx& d, const LmCtx& L, hipStream_t st) {
+  hipLaunchKernelGGL(lm_concat, dim3(16, L.K, d.n_launch), dim3(LM_BLOCK), 0, st, d, L);
+}
+void launch_lm_total_and_grid_setup(const DevCtx& d, const LmCtx& L, hipStream_t st) {
+  hipLaunchKernelGGL(lm_total, dim3(8, d.n_launch), dim3(LM_BLOCK), 0, st, d, L);
+  hipLaunchKernelGGL(lm_grid_setup, dim3(2, d.n_launch), dim3(LM_BLOCK), 0, st, d, L);
+}
+void launch_lm_grid(const DevCtx& d, const LmCtx& L, hipStream_t st) {
+  hipLaunchKernelGGL(lm_grid_count, dim3(32, 2, d.n_launch), dim3(LM_BLOCK), 0, st, d, L, 0);
+  hipLaunchKernelGGL(lm_grid_scan, dim3(2, d.n_launch), dim3(LM_BLOCK), 0, st, d, L);
+  hipLaunchKernelGGL(lm_grid_count, dim3(32, 2, d.n_launch), dim3(LM_BLOCK), 0, st, d, L, 1);
+}
+void launch_lm_register(const DevCtx& d, const LmCtx& L, hipStream_t st) {
+  hipLaunchKernelGGL(lm_assoc, dim3((L.qcap + 127) / 128, 2, d.n_launch), dim3(128), 0, st, d, L);
+  hipLaunchKernelGGL(lm_solve, dim3(d.n_launch), dim3(LM_SOLVE_BLOCK), 0, st, d, L);
+  hipLaunchKernelGGL(lm_finish, dim3((d.n_launch + 63) / 64), dim3(64), 0, st, d, L);
+  hipLaunchKernelGGL(lm_store_kf, dim3(8, 3, d.n_launch), dim3(LM_BLOCK), 0, st, d, L);
+}

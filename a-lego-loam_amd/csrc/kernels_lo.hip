@@ -36,8 +36,9 @@ DEV_INLINE WalkBest walk_reduce(WalkBest b) {
 }
 
 // kind 0: flat -> surf_last (less_flat of the previous scan); kind 1: sharp -> corner_last (less_sharp)
-__global__ void __launch_bounds__(LO_BLOCK) lo_assoc(DevCtx d, int cur, int kind) {
+__global__ void __launch_bounds__(LO_BLOCK) lo_assoc(DevCtx d, int kind) {
   const int slot = blockIdx.y + d.slot0;
+  const int cur = cur_in_flight(d, slot);
   const int* sc = d.scal + slot * SC_COUNT;
   if (!sc[SC_LO_INIT]) return;
   const int q = blockIdx.x * (LO_BLOCK / 64) + (threadIdx.x >> 6);
@@ -138,8 +139,9 @@ DEV_INLINE void lo_eval_rows(const DevCtx& d, int slot, int cur, int kind, int n
 
 // phase 0: ceres::Solve #1 on the surf blocks (:410-421); phase 1: Solve #2 on surf + corner
 // blocks (:484-495) followed by the pose integration (:504-508).
-__global__ void __launch_bounds__(LO_BLOCK) lo_solve(DevCtx d, int cur, int phase) {
+__global__ void __launch_bounds__(LO_BLOCK) lo_solve(DevCtx d, int phase) {
   const int slot = blockIdx.x + d.slot0;
+  const int cur = cur_in_flight(d, slot);
   int* sc = d.scal + slot * SC_COUNT;
   double* st = d.lo_state + (size_t)slot * LO_STATE_N;
   __shared__ double s_part[LO_BLOCK / 64][28];
@@ -147,7 +149,7 @@ __global__ void __launch_bounds__(LO_BLOCK) lo_solve(DevCtx d, int cur, int phas
   __shared__ LmState S;
   __shared__ int s_action, s_cnt[LO_BLOCK / 64];
   if (!sc[SC_LO_INIT]) {  // :316-324
-    if (phase == 1 && threadIdx.x == 0) { sc[SC_LO_INIT] = 1; sc[SC_ODOM_VALID] = 0; sc[SC_LO_FLAGS] = 1; sc[SC_LO_NSURF] = 0; sc[SC_LO_NCORNER] = 0; }
+    if (phase == 1 && threadIdx.x == 0) { sc[SC_LO_INIT] = 1; sc[SC_ODOM_VALID] = 0; sc[SC_LO_FLAGS] = 1; sc[SC_LO_NSURF] = 0; sc[SC_LO_NCORNER] = 0; sc[SC_CUR] = cur; }
     return;
   }
   const int nq_s = d.feat_cnt[((size_t)slot * 2 + cur) * 4 + F_FLAT];
@@ -240,14 +242,15 @@ __global__ void __launch_bounds__(LO_BLOCK) lo_solve(DevCtx d, int cur, int phas
       double* po = d.poses + (size_t)slot * 16;
       po[0] = nt[0]; po[1] = nt[1]; po[2] = nt[2]; po[3] = q.w; po[4] = q.x; po[5] = q.y; po[6] = q.z;
       sc[SC_ODOM_VALID] = 1;
+      sc[SC_CUR] = cur;  // surf_last_ / corner_last_ <- this scan's features (:531-534)
     }
   }
 }
 
-void launch_lo(const DevCtx& d, int cur, hipStream_t st) {
+void launch_lo(const DevCtx& d, hipStream_t st) {
   const int wpb = LO_BLOCK / 64;
-  hipLaunchKernelGGL(lo_assoc, dim3((d.lo_qcap_surf + wpb - 1) / wpb, d.n_launch), dim3(LO_BLOCK), 0, st, d, cur, 0);
-  hipLaunchKernelGGL(lo_solve, dim3(d.n_launch), dim3(LO_BLOCK), 0, st, d, cur, 0);
-  hipLaunchKernelGGL(lo_assoc, dim3((d.lo_qcap_corner + wpb - 1) / wpb, d.n_launch), dim3(LO_BLOCK), 0, st, d, cur, 1);
-  hipLaunchKernelGGL(lo_solve, dim3(d.n_launch), dim3(LO_BLOCK), 0, st, d, cur, 1);
+  hipLaunchKernelGGL(lo_assoc, dim3((d.lo_qcap_surf + wpb - 1) / wpb, d.n_launch), dim3(LO_BLOCK), 0, st, d, 0);
+  hipLaunchKernelGGL(lo_solve, dim3(d.n_launch), dim3(LO_BLOCK), 0, st, d, 0);
+  hipLaunchKernelGGL(lo_assoc, dim3((d.lo_qcap_corner + wpb - 1) / wpb, d.n_launch), dim3(LO_BLOCK), 0, st, d, 1);
+  hipLaunchKernelGGL(lo_solve, dim3(d.n_launch), dim3(LO_BLOCK), 0, st, d, 1);
 }

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <string>
+#include <vector>
 
 #include "../../include/alego_mi355x.h"
 #include "dev_common.h"
@@ -12,7 +13,8 @@ struct LmHost;
 LmHost* lm_host_create(const alego_params& P, const DevCtx& d, int n_slots, hipStream_t st, std::string* err);
 void lm_host_destroy(LmHost* lm);
 // LaserMapping for the scan just processed by LO, for the slots of view `d`
-int lm_host_enqueue(LmHost* lm, const DevCtx& d, int cur, std::string* err);
+int lm_host_enqueue(LmHost* lm, const DevCtx& d, const std::vector<char>& odom_valid, std::string* err);
+int lm_host_get_flags(LmHost* lm, int slot);
 int lm_host_process_host(LmHost* lm, const DevCtx& d, const alego_point* corner_last, int n_corner, const alego_point* surf_last,
                          int n_surf, const alego_point* outlier, int n_outlier, const alego_pose* odom, alego_pose* map_pose,
                          std::string* err);

@@ -1,24 +1,234 @@
-// lm_host.hip — placeholder until the LaserMapping kernels land: /odom_aft_mapped = /odom/lidar.
+// lm_host.hip — LaserMapping: HBM allocation and kernel sequencing (no numerics here).
 #include "lm_host.h"
 
-struct LmHost { int n_slots; hipStream_t st; };
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
 
-__global__ void lm_passthrough(DevCtx d) {
-  const int slot = blockIdx.x * blockDim.x + threadIdx.x;
-  if (slot >= d.n_launch) return;
-  double* po = d.poses + (size_t)(slot + d.slot0) * 16;
-  for (int k = 0; k < 7; ++k) po[7 + k] = po[k];
+#include "lm_ctx.h"
+#include "voxel.h"
+
+void launch_lm_prepare(const DevCtx& d, const LmCtx& L, int stage, int run_hint, hipStream_t st);
+void launch_lm_concat(const DevCtx& d, const LmCtx& L, hipStream_t st);
+void launch_lm_total_and_grid_setup(const DevCtx& d, const LmCtx& L, hipStream_t st);
+void launch_lm_grid(const DevCtx& d, const LmCtx& L, hipStream_t st);
+void launch_lm_register(const DevCtx& d, const LmCtx& L, hipStream_t st);
+
+struct LmHost {
+  alego_params P;
+  int n_slots;
+  hipStream_t st;
+  LmCtx L;
+  VoxCtx v1, v2;  // round 1: map corner, map surf, scan corner, scan surf, scan outlier; round 2: scan surf_total
+  std::vector<void*> allocs;
+  std::vector<long> frames;  // host mirror of frame_cnt per slot: only used to skip launches
+};
+
+namespace {
+template <class T>
+bool A(LmHost* lm, T** p, size_t count, std::string* err) {
+  void* q = nullptr;
+  size_t bytes = count * sizeof(T);
+  if (bytes == 0) bytes = 16;
+  hipError_t e = hipMalloc(&q, bytes);
+  if (e == hipSuccess) e = hipMemset(q, 0, bytes);
+  if (e != hipSuccess) { *err = std::string("lm hipMalloc: ") + hipGetErrorString(e); return false; }
+  lm->allocs.push_back(q);
+  *p = (T*)q;
+  return true;
+}
+}  // namespace
+
+LmHost* lm_host_create(const alego_params& P, const DevCtx& d, int n_slots, hipStream_t st, std::string* err) {
+  LmHost* lm = new LmHost();
+  lm->P = P; lm->n_slots = n_slots; lm->st = st; lm->frames.assign(n_slots, 0);
+  std::memset(&lm->v1, 0, sizeof(VoxCtx)); std::memset(&lm->v2, 0, sizeof(VoxCtx));
+  LmCtx& L = lm->L;
+  std::memset(&L, 0, sizeof(L));
+  L.K = P.recent_keyframe_num > 0 ? P.recent_keyframe_num : 1;
+  L.in_cap_c = d.fcap[F_LSHARP]; L.in_cap_s = d.N; L.in_cap_o = d.N;
+  L.kf_cap_c = d.fcap[F_LSHARP]; L.kf_cap_s = d.N / 2; L.kf_cap_o = d.N / 4;
+  L.total_cap = L.kf_cap_s + L.kf_cap_o;
+  L.map_cap_c = L.K * L.kf_cap_c; L.map_cap_s = L.K * L.total_cap;
+  L.gcap = n_slots <= 64 ? (1 << 20) : (1 << 18);
+  L.qcap = L.kf_cap_c + L.total_cap;
+  const size_t B = n_slots;
+  bool ok = true;
+  ok = ok && A(lm, &L.li, B * LI_COUNT, err) && A(lm, &L.ld, B * LD_COUNT, err);
+  ok = ok && A(lm, &L.in_corner, B * L.in_cap_c, err) && A(lm, &L.in_surf, B * L.in_cap_s, err) && A(lm, &L.in_outl, B * L.in_cap_o, err);
+  ok = ok && A(lm, &L.kf_corner, B * L.K * L.kf_cap_c, err) && A(lm, &L.kf_surf, B * L.K * L.kf_cap_s, err) && A(lm, &L.kf_outl, B * L.K * L.kf_cap_o, err);
+  ok = ok && A(lm, &L.kf_cnt, B * L.K * 4, err) && A(lm, &L.kf_pose, B * L.K * 8, err);
+  ok = ok && A(lm, &L.map_corner_raw, B * L.map_cap_c, err) && A(lm, &L.map_surf_raw, B * L.map_cap_s, err);
+  ok = ok && A(lm, &L.map_corner_ds, B * L.map_cap_c, err) && A(lm, &L.map_surf_ds, B * L.map_cap_s, err);
+  ok = ok && A(lm, &L.cur_corner_ds, B * L.kf_cap_c, err) && A(lm, &L.cur_surf_ds, B * L.kf_cap_s, err) && A(lm, &L.cur_outl_ds, B * L.kf_cap_o, err);
+  ok = ok && A(lm, &L.cur_total, B * L.total_cap, err) && A(lm, &L.cur_total_ds, B * L.total_cap, err);
+  ok = ok && A(lm, &L.grid, B * 2, err) && A(lm, &L.cell_start, B * 2 * ((size_t)L.gcap + 1), err) && A(lm, &L.cell_cur, B * 2 * ((size_t)L.gcap + 1), err);
+  ok = ok && A(lm, &L.cell_pts, B * 2 * L.map_cap_s, err);
+  ok = ok && A(lm, &L.blocks, B * L.qcap * 8, err);
+  if (!ok) { lm_host_destroy(lm); return nullptr; }
+  // identity quaternions (laserMapping.cpp:56-61)
+  std::vector<double> ld(B * LD_COUNT, 0.0);
+  for (size_t b = 0; b < B; ++b) { ld[b * LD_COUNT + LD_Q_M2O] = 1.0; ld[b * LD_COUNT + LD_Q_O2L] = 1.0; ld[b * LD_COUNT + LD_Q_M2L] = 1.0; }
+  (void)hipMemcpy(L.ld, ld.data(), ld.size() * sizeof(double), hipMemcpyHostToDevice);
+  // VoxelGrid job tables (laserMapping.cpp:37-39,316-319,329-342)
+  std::vector<VoxJob> j1, j2;
+  for (size_t b = 0; b < B; ++b) {
+    int* li = L.li + b * LI_COUNT;
+    j1.push_back(VoxJob{L.map_corner_raw + b * L.map_cap_c, li + LI_KRAW_C, L.map_corner_ds + b * L.map_cap_c, li + LI_KDS_C, li + LI_REBUILD, P.lm_leaf_corner, L.map_cap_c, 0});
+    j1.push_back(VoxJob{L.map_surf_raw + b * L.map_cap_s, li + LI_KRAW_S, L.map_surf_ds + b * L.map_cap_s, li + LI_KDS_S, li + LI_REBUILD, P.lm_leaf_surf, L.map_cap_s, 0});
+    j1.push_back(VoxJob{L.in_corner + b * L.in_cap_c, li + LI_NIN_C, L.cur_corner_ds + b * L.kf_cap_c, li + LI_NCUR_C, li + LI_RUN, P.lm_leaf_corner, L.kf_cap_c, 0});
+    j1.push_back(VoxJob{L.in_surf + b * L.in_cap_s, li + LI_NIN_S, L.cur_surf_ds + b * L.kf_cap_s, li + LI_NCUR_S, li + LI_RUN, P.lm_leaf_surf, L.in_cap_s, 0});
+    j1.push_back(VoxJob{L.in_outl + b * L.in_cap_o, li + LI_NIN_O, L.cur_outl_ds + b * L.kf_cap_o, li + LI_NCUR_O, li + LI_RUN, P.lm_leaf_outlier, L.in_cap_o, 0});
+    j2.push_back(VoxJob{L.cur_total + b * L.total_cap, li + LI_NTOTAL, L.cur_total_ds + b * L.total_cap, li + LI_NTOTAL_DS, li + LI_RUN, P.lm_leaf_surf, L.total_cap, 0});
+  }
+  if (vox_create(&lm->v1, j1.data(), (int)j1.size(), err) || vox_create(&lm->v2, j2.data(), (int)j2.size(), err)) { lm_host_destroy(lm); return nullptr; }
+  L.vox_bbox = lm->v1.bbox;
+  return lm;
 }
 
-LmHost* lm_host_create(const alego_params&, const DevCtx&, int n_slots, hipStream_t st, std::string*) { return new LmHost{n_slots, st}; }
-void lm_host_destroy(LmHost* lm) { delete lm; }
-int lm_host_enqueue(LmHost* lm, const DevCtx& d, int, std::string*) {
-  hipLaunchKernelGGL(lm_passthrough, dim3((d.n_launch + 63) / 64), dim3(64), 0, lm->st, d);
+void lm_host_destroy(LmHost* lm) {
+  if (!lm) return;
+  vox_destroy(&lm->v1); vox_destroy(&lm->v2);
+  for (void* p : lm->allocs) (void)hipFree(p);
+  delete lm;
+}
+
+static bool dbg_sync(LmHost* lm, const char* what, std::string* err) {
+  static const bool on = getenv("ALEGO_DEBUG_SYNC") != nullptr;
+  if (!on) return true;
+  hipError_t e = hipStreamSynchronize(lm->st);
+  if (e == hipSuccess) e = hipGetLastError();
+  fprintf(stderr, "[alego dbg] %s: %s\n", what, hipGetErrorString(e));
+  if (e != hipSuccess) { *err = std::string(what) + ": " + hipGetErrorString(e); return false; }
+  return true;
+}
+
+// odom_valid[s - slot0]: whether slot s has an /odom/lidar message for this scan (false on its first scan)
+static int lm_sequence(LmHost* lm, const DevCtx& d, int stage, const std::vector<char>& odom_valid, std::string* err) {
+  const LmCtx& L = lm->L;
+  int n_run = 0, n_norun = 0;
+  for (int i = 0; i < d.n_launch; ++i) {
+    long& f = lm->frames[d.slot0 + i];
+    const bool run = odom_valid[i] && (f % lm->P.lm_every) == 0;
+    if (odom_valid[i]) ++f;
+    run ? ++n_run : ++n_norun;
+  }
+  const int hint = n_run == 0 ? 0 : (n_norun == 0 ? 1 : -1);  // -1: slots out of phase, no launch skipping
+  launch_lm_prepare(d, L, stage, hint, lm->st);
+  if (!dbg_sync(lm, "lm_prepare", err)) return ALEGO_ERR_HIP;
+  if (n_run == 0) return 0;
+  launch_lm_concat(d, L, lm->st);
+  if (!dbg_sync(lm, "lm_concat", err)) return ALEGO_ERR_HIP;
+  if (int r = vox_run(lm->v1, lm->st, err)) return r;
+  if (!dbg_sync(lm, "vox round 1", err)) return ALEGO_ERR_HIP;
+  launch_lm_total_and_grid_setup(d, L, lm->st);
+  if (!dbg_sync(lm, "lm_total/grid_setup", err)) return ALEGO_ERR_HIP;
+  if (int r = vox_run(lm->v2, lm->st, err)) return r;
+  if (!dbg_sync(lm, "vox round 2", err)) return ALEGO_ERR_HIP;
+  launch_lm_grid(d, L, lm->st);
+  if (!dbg_sync(lm, "lm_grid", err)) return ALEGO_ERR_HIP;
+  launch_lm_register(d, L, lm->st);
+  if (!dbg_sync(lm, "lm_register", err)) return ALEGO_ERR_HIP;
   return 0;
 }
-int lm_host_process_host(LmHost*, const DevCtx&, const alego_point*, int, const alego_point*, int, const alego_point*, int,
-                         const alego_pose*, alego_pose*, std::string* err) { *err = "alego_lm_process: not implemented yet"; return ALEGO_ERR_ARG; }
-void lm_host_get_params(LmHost*, int, double* p6) { for (int i = 0; i < 6; ++i) p6[i] = 0; }
-int lm_host_set_params(LmHost*, int, const double*, std::string*) { return 0; }
-void lm_host_get_counts(LmHost*, int, int* o) { for (int i = 0; i < 6; ++i) o[i] = 0; }
-int lm_host_debug_get(LmHost*, int, const char* name, void*, int, int*, int*, std::string* err) { *err = std::string("debug_get: unknown name ") + name; return ALEGO_ERR_ARG; }
+
+// NOTE: the VoxelGrid rounds always cover every slot of the handle; slots outside the launch view
+// have LI_RUN == 0 from their own last prepare only if they were prepared in this call, so the
+// single-slot entry points clear the run flags of the other slots first.
+static void clear_run_flags_outside(LmHost* lm, const DevCtx& d) {
+  if (d.n_launch == lm->n_slots) return;
+  for (int s = 0; s < lm->n_slots; ++s) {
+    if (s >= d.slot0 && s < d.slot0 + d.n_launch) continue;
+    (void)hipMemsetAsync(lm->L.li + (size_t)s * LI_COUNT + LI_RUN, 0, 2 * sizeof(int), lm->st);  // LI_RUN, LI_REBUILD
+  }
+}
+
+int lm_host_enqueue(LmHost* lm, const DevCtx& d, const std::vector<char>& odom_valid, std::string* err) {
+  clear_run_flags_outside(lm, d);
+  return lm_sequence(lm, d, 1, odom_valid, err);
+}
+
+int lm_host_process_host(LmHost* lm, const DevCtx& dfull, const alego_point* corner_last, int n_corner, const alego_point* surf_last,
+                         int n_surf, const alego_point* outlier, int n_outlier, const alego_pose* odom, alego_pose* map_pose,
+                         std::string* err) {
+  const LmCtx& L = lm->L;
+  if (n_corner > L.in_cap_c || n_surf > L.in_cap_s || n_outlier > L.in_cap_o) { *err = "alego_lm_process: input cloud exceeds capacity"; return ALEGO_ERR_CAPACITY; }
+  DevCtx d = dfull;
+  d.slot0 = 0; d.n_launch = 1;
+  hipStream_t st = lm->st;
+  (void)hipMemcpyAsync(L.in_corner, corner_last, (size_t)n_corner * 16, hipMemcpyHostToDevice, st);
+  (void)hipMemcpyAsync(L.in_surf, surf_last, (size_t)n_surf * 16, hipMemcpyHostToDevice, st);
+  (void)hipMemcpyAsync(L.in_outl, outlier, (size_t)n_outlier * 16, hipMemcpyHostToDevice, st);
+  const int nin[3] = {n_corner, n_surf, n_outlier};
+  (void)hipMemcpyAsync(L.li + LI_NIN_C, nin, sizeof(nin), hipMemcpyHostToDevice, st);
+  double po[7] = {odom->t[0], odom->t[1], odom->t[2], odom->q[0], odom->q[1], odom->q[2], odom->q[3]};
+  (void)hipMemcpyAsync(d.poses, po, sizeof(po), hipMemcpyHostToDevice, st);
+  const int one = 1;
+  (void)hipMemcpyAsync(d.scal + SC_ODOM_VALID, &one, sizeof(int), hipMemcpyHostToDevice, st);
+  if (hipStreamSynchronize(st) != hipSuccess) { *err = "alego_lm_process: upload failed"; return ALEGO_ERR_HIP; }
+  clear_run_flags_outside(lm, d);
+  if (int r = lm_sequence(lm, d, 0, std::vector<char>(1, 1), err)) return r;
+  double out[16], ld[LD_COUNT];
+  int li[LI_COUNT];
+  (void)hipMemcpyAsync(out, d.poses, sizeof(out), hipMemcpyDeviceToHost, st);
+  (void)hipMemcpyAsync(ld, L.ld, sizeof(ld), hipMemcpyDeviceToHost, st);
+  (void)hipMemcpyAsync(li, L.li, sizeof(li), hipMemcpyDeviceToHost, st);
+  if (hipStreamSynchronize(st) != hipSuccess) { *err = "alego_lm_process: kernels failed"; return ALEGO_ERR_HIP; }
+  if (li[LI_OVERFLOW]) { *err = "alego_lm_process: device capacity exceeded"; return ALEGO_ERR_CAPACITY; }
+  if (map_pose) {
+    for (int i = 0; i < 3; ++i) map_pose->t[i] = out[7 + i];
+    for (int i = 0; i < 4; ++i) map_pose->q[i] = out[10 + i];
+    for (int i = 0; i < 6; ++i) map_pose->params[i] = ld[LD_PARAMS + i];
+    map_pose->valid = 1;
+  }
+  return li[LI_FLAGS];
+}
+
+void lm_host_get_params(LmHost* lm, int slot, double* p6) {
+  (void)hipMemcpy(p6, lm->L.ld + (size_t)slot * LD_COUNT + LD_PARAMS, 48, hipMemcpyDeviceToHost);
+}
+int lm_host_set_params(LmHost* lm, int slot, const double* p6, std::string* err) {
+  if (hipMemcpy(lm->L.ld + (size_t)slot * LD_COUNT + LD_PARAMS, p6, 48, hipMemcpyHostToDevice) != hipSuccess) { *err = "set_lm_params failed"; return ALEGO_ERR_HIP; }
+  return 0;
+}
+int lm_host_get_flags(LmHost* lm, int slot) {
+  int li[LI_COUNT];
+  (void)hipMemcpy(li, lm->L.li + (size_t)slot * LI_COUNT, sizeof(li), hipMemcpyDeviceToHost);
+  if (li[LI_OVERFLOW]) return ALEGO_ERR_CAPACITY;
+  return li[LI_FLAGS];
+}
+void lm_host_get_counts(LmHost* lm, int slot, int* o) {
+  int li[LI_COUNT];
+  (void)hipMemcpy(li, lm->L.li + (size_t)slot * LI_COUNT, sizeof(li), hipMemcpyDeviceToHost);
+  o[0] = li[LI_KRAW_C]; o[1] = li[LI_KRAW_S]; o[2] = li[LI_KDS_C]; o[3] = li[LI_KDS_S]; o[4] = li[LI_NCUR_C]; o[5] = li[LI_NTOTAL_DS];
+}
+
+int lm_host_debug_get(LmHost* lm, int slot, const char* name, void* out, int cap_bytes, int* count, int* dtype, std::string* err) {
+  const LmCtx& L = lm->L;
+  int li[LI_COUNT];
+  (void)hipMemcpy(li, L.li + (size_t)slot * LI_COUNT, sizeof(li), hipMemcpyDeviceToHost);
+  const std::string s(name);
+  const void* src = nullptr;
+  size_t n = 0;
+  int dt = 0, esz = 4;
+  auto set = [&](const void* p, size_t cnt, int t) { src = p; n = cnt; dt = t; esz = t == 1 ? 8 : t == 3 ? 1 : 4; };
+  const size_t b = slot;
+  if (s == "lm_info") set(L.li + b * LI_COUNT, LI_COUNT, 2);
+  else if (s == "lm_state") set(L.ld + b * LD_COUNT, LD_COUNT, 1);
+  else if (s == "lm_corner_map") set(L.map_corner_raw + b * L.map_cap_c, (size_t)li[LI_KRAW_C] * 4, 0);
+  else if (s == "lm_surf_map") set(L.map_surf_raw + b * L.map_cap_s, (size_t)li[LI_KRAW_S] * 4, 0);
+  else if (s == "lm_corner_map_ds") set(L.map_corner_ds + b * L.map_cap_c, (size_t)li[LI_KDS_C] * 4, 0);
+  else if (s == "lm_surf_map_ds") set(L.map_surf_ds + b * L.map_cap_s, (size_t)li[LI_KDS_S] * 4, 0);
+  else if (s == "lm_corner_ds") set(L.cur_corner_ds + b * L.kf_cap_c, (size_t)li[LI_NCUR_C] * 4, 0);
+  else if (s == "lm_surf_ds") set(L.cur_surf_ds + b * L.kf_cap_s, (size_t)li[LI_NCUR_S] * 4, 0);
+  else if (s == "lm_outlier_ds") set(L.cur_outl_ds + b * L.kf_cap_o, (size_t)li[LI_NCUR_O] * 4, 0);
+  else if (s == "lm_surf_total_ds") set(L.cur_total_ds + b * L.total_cap, (size_t)li[LI_NTOTAL_DS] * 4, 0);
+  else if (s == "lm_blocks") set(L.blocks + b * L.qcap * 8, (size_t)L.qcap * 8, 1);
+  else if (s == "lm_keyposes") set(L.kf_pose + b * L.K * 8, (size_t)L.K * 8, 0);
+  else { *err = std::string("debug_get: unknown name ") + name; return ALEGO_ERR_ARG; }
+  if ((size_t)cap_bytes < n * esz) { *err = "debug_get: buffer too small"; return ALEGO_ERR_CAPACITY; }
+  if (n && hipMemcpy(out, src, n * esz, hipMemcpyDeviceToHost) != hipSuccess) { *err = "debug_get: copy failed"; return ALEGO_ERR_HIP; }
+  *count = (int)n; *dtype = dt;
+  return 0;
+}

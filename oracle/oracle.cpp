@@ -1013,9 +1013,11 @@ struct LaserMapping {
 
   // transformPointCloud, laserMapping.h:164-177 (f32 4x4, pcl::transformPointCloud PCL 1.8 dense path)
   static void transform_cloud(const std::vector<Pt>& in, const KeyPose& kp, std::vector<Pt>& out) {
+    // Eigen evaluates sinf/cosf here; both this oracle and the HIP path evaluate in double and round
+    // once (DESIGN.md "deviations"): device and host libm then agree except w.p. ~2^-29 per call.
     auto qaxis = [](float angle, int axis, float q[4]) {
-      float ha = 0.5f * angle, s = std::sin(ha);
-      q[0] = std::cos(ha); q[1] = q[2] = q[3] = 0.f; q[1 + axis] = s;
+      float ha = 0.5f * angle, s = (float)std::sin((double)ha);
+      q[0] = (float)std::cos((double)ha); q[1] = q[2] = q[3] = 0.f; q[1 + axis] = s;
     };
     auto qmul = [](const float a[4], const float b[4], float o[4]) {
       o[0] = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];

@@ -169,3 +169,90 @@ def test_batch_slots_independent(params_a):
         assert_bit_equal(odomb["q"], odom1["q"], f"slot {s} odometry rotation")
         h1.close()
     hb.close()
+
+
+def _lm_compare(h, o, k, tag):
+    oi = o.get("lm_info")
+    gi = h.debug_get("lm_info")
+    ran, optimized, kf = bool(oi[0]), bool(oi[1]), bool(oi[2])
+    assert bool(gi[2]) == ran, f"{tag}: mapping body ran {gi[2]} vs {ran}"
+    if not ran:
+        return
+    assert bool(gi[10]) == kf, f"{tag}: key frame added {gi[10]} vs {kf}"
+    assert gi[0] == oi[11], f"{tag}: key frame count {gi[0]} vs {oi[11]}"
+    for name in ("lm_corner_ds", "lm_surf_ds", "lm_outlier_ds", "lm_surf_total_ds"):
+        assert_bit_equal(h.debug_get(name), o.get(name), f"{tag} {name}")
+    assert_bit_equal(h.debug_get("lm_corner_map_ds"), o.get("lm_corner_map_ds"), f"{tag} corner map (voxel-filtered)")
+    assert_bit_equal(h.debug_get("lm_surf_map_ds"), o.get("lm_surf_map_ds"), f"{tag} surf map (voxel-filtered)")
+    assert bool(gi[11]) == optimized, f"{tag}: optimisation ran {gi[11]} vs {optimized}"
+    if optimized:
+        assert (gi[6], gi[7]) == (oi[3], oi[4]), f"{tag}: correspondences {gi[6]},{gi[7]} vs {oi[3]},{oi[4]}"
+        blocks = h.debug_get("lm_blocks").reshape(-1, 8)
+        ncur = gi[19]
+        qc = np.nonzero(blocks[:ncur, 7] != 0)[0]
+        assert_bit_equal(qc.astype(np.int32), o.get("lm_corner_corr_q"), f"{tag} accepted corner queries")
+        kf_cap_c = 120 * h.params.n_scan
+        qs = np.nonzero(blocks[kf_cap_c:kf_cap_c + gi[23], 7] != 0)[0]
+        assert_bit_equal(qs.astype(np.int32), o.get("lm_surf_corr_q"), f"{tag} accepted surf queries")
+        st = h.debug_get("lm_state")
+        np.testing.assert_allclose(st[27:39], o.get("lm_params_iter"), rtol=0, atol=1e-6, err_msg=f"{tag} params_ after each outer iteration")
+        assert ((gi[8] & 0xFF, (gi[8] >> 8) & 0xFF, gi[8] >> 16), (gi[9] & 0xFF, (gi[9] >> 8) & 0xFF, gi[9] >> 16)) == \
+            (tuple(oi[5:8]), tuple(oi[8:11])), f"{tag} solver summaries {gi[8]:x} {gi[9]:x} vs {oi[5:11]}"
+    np.testing.assert_allclose(h.debug_get("lm_state")[0:6], o.get("lm_params"), rtol=0, atol=1e-6, err_msg=f"{tag} params_")
+
+
+@pytest.mark.parametrize("geom,nscan", [((16, 1800), 36), ((64, 2048), 8)])
+def test_full_loop_teacher_forced(geom, nscan):
+    """IP -> LO -> LM on the device, each scan started from the oracle's LO/LM params_."""
+    p = synth.default_params(*geom)
+    h, o = binding.Handle(p), O.Oracle(p)
+    for k in range(nscan):
+        pts = synth.scan(p, k)
+        h.set_lo_params(o.get("lo_params"))
+        h.set_lm_params(o.get("lm_params"))
+        o.process_scan(pts)
+        flags, odom, mp = h.scan_process(pts, stages=7)
+        if k == 0:
+            continue
+        _lm_compare(h, o, k, f"{geom} scan {k}")
+        want = o.get("map_pose")
+        assert np.abs(mp["t"] - want[:3]).max() < POSE_TOL, (k, mp["t"], want[:3])
+        assert quat_angle(mp["q"], want[3:]) < POSE_TOL
+    assert o.get("lm_info")[11] >= 3 or geom[0] == 64
+    h.close()
+
+
+def test_full_loop_free_running(params_a):
+    p = params_a
+    h, o = binding.Handle(p), O.Oracle(p)
+    worst_t = worst_r = 0.0
+    for k in range(60):
+        pts = synth.scan(p, k)
+        o.process_scan(pts)
+        flags, odom, mp = h.scan_process(pts, stages=7)
+        if k == 0:
+            continue
+        want = o.get("map_pose")
+        worst_t = max(worst_t, np.abs(mp["t"] - want[:3]).max())
+        worst_r = max(worst_r, quat_angle(mp["q"], want[3:]))
+    print(f"free-running IP->LO->LM over 60 scans: max |dt| {worst_t:.3e} m, max angle {worst_r:.3e} rad")
+    assert worst_t < POSE_TOL and worst_r < POSE_TOL
+    h.close()
+
+
+def test_lm_process_host_entry(params_a):
+    """alego_lm_process fed with host clouds (the /corner_last, /surf_last, /outlier, /odom/lidar messages)."""
+    p = params_a
+    h, o = binding.Handle(p), O.Oracle(p)
+    for k in range(8):
+        pts = synth.scan(p, k)
+        o.process_scan(pts)
+        if k == 0:
+            continue
+        od = o.get("odom_pose")
+        h.set_lm_params(o.get("lm_params")) if False else None
+        flags, mp = h.lm_process(o.get("corner_last"), o.get("surf_last"), o.get("outlier"), dict(t=od[:3], q=od[3:]))
+        want = o.get("map_pose")
+        assert np.abs(mp["t"] - want[:3]).max() < POSE_TOL
+        np.testing.assert_allclose(mp["params"], o.get("lm_params"), rtol=0, atol=1e-5)
+    h.close()
