@@ -21,9 +21,10 @@ EXPORTS = [
     "alego_create", "alego_destroy", "alego_last_error", "alego_device_count", "alego_params_sizeof",
     "alego_ip_process", "alego_lo_process", "alego_lm_process", "alego_scan_process",
     "alego_batch_load", "alego_batch_run", "alego_synchronize", "alego_batch_get_pose", "alego_batch_get_counts",
-    "alego_stream", "alego_set_lo_params", "alego_set_lm_params", "alego_debug_get", "alego_debug_atan2f",
+    "alego_stream", "alego_profile_enable", "alego_profile_report", "alego_set_lo_params", "alego_set_lm_params", "alego_debug_get", "alego_debug_atan2f",
 ]
 
+REPLAY_PINGPONG = 0x100
 FLAG_LO_INIT, FLAG_FEW_SURF, FLAG_FEW_CORNER, FLAG_LM_SKIPPED, FLAG_LM_FEW_FEATURES, FLAG_LM_KEYFRAME = 1, 2, 4, 8, 16, 32
 
 
@@ -93,6 +94,10 @@ def lib():
         L.alego_batch_get_pose.argtypes = [C.c_void_p, C.c_int, C.POINTER(Pose), C.POINTER(Pose)]
         L.alego_batch_get_counts.restype = C.c_int
         L.alego_batch_get_counts.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        L.alego_profile_enable.restype = C.c_int
+        L.alego_profile_enable.argtypes = [C.c_void_p, C.c_int]
+        L.alego_profile_report.restype = C.c_int
+        L.alego_profile_report.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
         L.alego_stream.restype = C.c_void_p
         L.alego_stream.argtypes = [C.c_void_p]
         L.alego_set_lo_params.restype = C.c_int
@@ -258,6 +263,18 @@ class Handle:
         self._check(lib().alego_batch_get_counts(self._h, slot, out.ctypes.data, 16), "alego_batch_get_counts")
         keys = ["P", "M", "O", "Qc", "Fc", "Qs", "Fs", "n_surf_corr", "n_corner_corr", "Kraw_c", "Kraw_s", "Kds_c", "Kds_s", "Lc", "Ls"]
         return dict(zip(keys, out.tolist()))
+
+    def profile_enable(self, on=True):
+        self._check(lib().alego_profile_enable(self._h, 1 if on else 0), "alego_profile_enable")
+
+    def profile_report(self):
+        """{kernel name: (total ms, launches)} measured with HIP events on the handle's stream."""
+        names = C.create_string_buffer(8192)
+        tot = np.zeros(256, np.float64)
+        cnt = np.zeros(256, np.int32)
+        n = self._check(lib().alego_profile_report(self._h, names, 8192, tot.ctypes.data, cnt.ctypes.data, 256), "alego_profile_report")
+        ks = names.value.decode().split(";") if n else []
+        return {k: (float(tot[i]), int(cnt[i])) for i, k in enumerate(ks)}
 
     def stream(self):
         return lib().alego_stream(self._h)

@@ -13,6 +13,9 @@
 #include "../../include/alego_mi355x.h"
 #include "dev_common.h"
 #include "lm_host.h"
+#include "prof.h"
+
+thread_local Profiler* g_prof = nullptr;
 
 void launch_ip(const DevCtx& d, int ring_pos, bool want_labels, hipStream_t st);
 void launch_fe(const DevCtx& d, hipStream_t st);
@@ -28,6 +31,7 @@ struct alego_handle {
   std::string err;
   std::vector<long> lo_scans;  // LO steps enqueued per slot (the first one only initialises, laserOdometry.cpp:316-324)
   LmHost* lm = nullptr;
+  Profiler prof;
 };
 
 namespace {
@@ -154,6 +158,7 @@ void alego_destroy(alego_handle* h) {
   if (!h) return;
   hipSetDevice(h->device);
   if (h->stream) hipStreamSynchronize(h->stream);
+  if (g_prof == &h->prof) g_prof = nullptr;
   if (h->lm) lm_host_destroy(h->lm);
   for (void* p : h->allocs) hipFree(p);
   if (h->stream) hipStreamDestroy(h->stream);
@@ -181,6 +186,7 @@ int alego_batch_load(alego_handle* h, int slot, int ring_pos, const alego_point*
 // enqueue IP -> FE -> LO -> LM for slots [slot0, slot0+n) on ring position `pos`
 static int enqueue_scan(alego_handle* h, int slot0, int n, int pos, int stages, bool want_labels) {
   const DevCtx d = view(h, slot0, n);
+  g_prof = &h->prof;
   static const bool dbg = getenv("ALEGO_DEBUG_SYNC") != nullptr;
   auto chk = [&](const char* what) { if (dbg) { hipError_t e = hipStreamSynchronize(h->stream); fprintf(stderr, "[alego dbg] %s: %s\n", what, hipGetErrorString(e)); } };
   if (stages & 1) { launch_ip(d, pos, want_labels, h->stream); chk("ip"); }
@@ -198,9 +204,17 @@ static int enqueue_scan(alego_handle* h, int slot0, int n, int pos, int stages, 
 int alego_batch_run(alego_handle* h, int first_pos, int n_scans, int stages, int sync) {
   if (!h) return ALEGO_ERR_ARG;
   hipSetDevice(h->device);
+  const int R = h->d.ring_len;
   for (int s = 0; s < n_scans; ++s) {
-    const int pos = ((first_pos + s) % h->d.ring_len + h->d.ring_len) % h->d.ring_len;
-    if (int r = enqueue_scan(h, 0, h->d.n_slots, pos, stages, false)) return r;
+    int pos;
+    if ((stages & ALEGO_REPLAY_PINGPONG) && R > 1) {  // 0,1,..,R-1,R-2,..,1,0,1,.. : consecutive scans stay neighbours
+      const int period = 2 * (R - 1);
+      const int t = ((first_pos + s) % period + period) % period;
+      pos = t < R ? t : period - t;
+    } else {
+      pos = ((first_pos + s) % R + R) % R;
+    }
+    if (int r = enqueue_scan(h, 0, h->d.n_slots, pos, stages & 7, false)) return r;
   }
   if (sync) HIP_TRY(h, hipStreamSynchronize(h->stream));
   return 0;
@@ -295,6 +309,7 @@ int alego_ip_process(alego_handle* h, const alego_scan_in* in, alego_seg_out* ou
   hipSetDevice(h->device);
   if (int r = alego_batch_load(h, 0, 0, in->pts, in->n)) return r;
   const DevCtx d = view(h, 0, 1);
+  g_prof = &h->prof;
   launch_ip(d, 0, out->label_image != nullptr, h->stream);
   HIP_TRY(h, hipGetLastError());
   return download_seg(h, 0, out);
@@ -323,6 +338,7 @@ int alego_lm_process(alego_handle* h, const alego_point* corner_last, int32_t n_
                      int32_t n_surf, const alego_point* outlier, int32_t n_outlier, const alego_pose* odom, alego_pose* map_pose) {
   if (!h || !odom) return ALEGO_ERR_ARG;
   hipSetDevice(h->device);
+  g_prof = &h->prof;
   return lm_host_process_host(h->lm, h->d, corner_last, n_corner, surf_last, n_surf, outlier, n_outlier, odom, map_pose, &h->err);
 }
 
@@ -349,6 +365,35 @@ int alego_set_lm_params(alego_handle* h, int slot, const double* p6) {
   if (int r = check_slot(h, slot)) return r;
   hipSetDevice(h->device);
   return lm_host_set_params(h->lm, slot, p6, &h->err);
+}
+
+int alego_profile_enable(alego_handle* h, int on) {
+  if (!h) return ALEGO_ERR_ARG;
+  hipSetDevice(h->device);
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  h->prof.reset();
+  h->prof.on = on != 0;
+  return 0;
+}
+
+int alego_profile_report(alego_handle* h, char* names, int names_cap, double* total_ms, int* launches, int cap) {
+  if (!h) return ALEGO_ERR_ARG;
+  hipSetDevice(h->device);
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  Profiler& P = h->prof;
+  const int nk = (int)P.names.size();
+  std::vector<double> tot(nk, 0.0);
+  std::vector<int> cnt(nk, 0);
+  for (auto& r : P.recs) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) { tot[r.id] += ms; cnt[r.id]++; }
+  }
+  std::string joined;
+  for (int i = 0; i < nk; ++i) { if (i) joined += ";"; joined += P.names[i]; }
+  if ((int)joined.size() + 1 > names_cap || nk > cap) { h->err = "profile_report: buffers too small"; return ALEGO_ERR_CAPACITY; }
+  std::memcpy(names, joined.c_str(), joined.size() + 1);
+  for (int i = 0; i < nk; ++i) { total_ms[i] = tot[i]; launches[i] = cnt[i]; }
+  return nk;
 }
 
 int alego_debug_atan2f(alego_handle* h, const float* y, const float* x, float* out, int n) {

@@ -10,6 +10,7 @@
 //              centroid in sorted (= original) order                           (:288-293)
 //   fe_gather  ring-ascending concatenation into the four feature clouds       (:199-205,:245,:293)
 #include "dev_common.h"
+#include "prof.h"
 
 #define FE_BLOCK 256
 #define FE_HALO 6
@@ -360,8 +361,8 @@ __global__ void __launch_bounds__(FE_BLOCK) fe_gather(DevCtx d) {
 }
 
 void launch_fe(const DevCtx& d, hipStream_t st) {
-  hipLaunchKernelGGL(fe_curv, dim3((d.N + FE_BLOCK - 1) / FE_BLOCK, d.n_launch), dim3(FE_BLOCK), 0, st, d);
-  hipLaunchKernelGGL(fe_pick, dim3(d.NS, d.n_launch), dim3(64), 0, st, d);
-  hipLaunchKernelGGL(fe_voxel, dim3(d.NS, d.n_launch), dim3(FE_BLOCK), 0, st, d);
-  hipLaunchKernelGGL(fe_gather, dim3(d.NS, d.n_launch), dim3(FE_BLOCK), 0, st, d);
+  ALEGO_LAUNCH(fe_curv, dim3((d.N + FE_BLOCK - 1) / FE_BLOCK, d.n_launch), dim3(FE_BLOCK), 0, st, d);
+  ALEGO_LAUNCH(fe_pick, dim3(d.NS, d.n_launch), dim3(64), 0, st, d);
+  ALEGO_LAUNCH(fe_voxel, dim3(d.NS, d.n_launch), dim3(FE_BLOCK), 0, st, d);
+  ALEGO_LAUNCH(fe_gather, dim3(d.NS, d.n_launch), dim3(FE_BLOCK), 0, st, d);
 }

@@ -14,6 +14,7 @@
 // HBM-bound: one scan moves 16 B/point in and 25 B/segmented point out; the images
 // in between (owner, range, flags, parent: 13 B/cell) stay L2-resident.
 #include "dev_common.h"
+#include "prof.h"
 
 #define IP_BLOCK 256
 
@@ -387,17 +388,17 @@ __global__ void atan2f_probe(const float* y, const float* x, float* out, int n, 
 // ---- host-side launchers -------------------------------------------------------
 void launch_ip(const DevCtx& d, int ring_pos, bool want_labels, hipStream_t st) {
   const dim3 gN((d.N + IP_BLOCK - 1) / IP_BLOCK, d.n_launch), gP((d.Pcap + IP_BLOCK - 1) / IP_BLOCK, d.n_launch);
-  hipLaunchKernelGGL(ip_reset, gN, dim3(IP_BLOCK), 0, st, d);
-  hipLaunchKernelGGL(ip_project, gP, dim3(IP_BLOCK), 0, st, d, ring_pos);
-  hipLaunchKernelGGL(ip_image, dim3((d.H + 127) / 128, d.n_launch), dim3(128), 0, st, d, ring_pos);
-  hipLaunchKernelGGL(cc_edges, gN, dim3(IP_BLOCK), 0, st, d);
-  hipLaunchKernelGGL(cc_link, gN, dim3(IP_BLOCK), 0, st, d);
-  hipLaunchKernelGGL(cc_stats, gN, dim3(IP_BLOCK), 0, st, d);
-  hipLaunchKernelGGL(ip_rowcount, dim3(d.NS, d.n_launch), dim3(IP_BLOCK), 0, st, d);
-  hipLaunchKernelGGL(ip_compact, dim3(d.NS, d.n_launch), dim3(IP_BLOCK), 0, st, d, ring_pos);
+  ALEGO_LAUNCH(ip_reset, gN, dim3(IP_BLOCK), 0, st, d);
+  ALEGO_LAUNCH(ip_project, gP, dim3(IP_BLOCK), 0, st, d, ring_pos);
+  ALEGO_LAUNCH(ip_image, dim3((d.H + 127) / 128, d.n_launch), dim3(128), 0, st, d, ring_pos);
+  ALEGO_LAUNCH(cc_edges, gN, dim3(IP_BLOCK), 0, st, d);
+  ALEGO_LAUNCH(cc_link, gN, dim3(IP_BLOCK), 0, st, d);
+  ALEGO_LAUNCH(cc_stats, gN, dim3(IP_BLOCK), 0, st, d);
+  ALEGO_LAUNCH(ip_rowcount, dim3(d.NS, d.n_launch), dim3(IP_BLOCK), 0, st, d);
+  ALEGO_LAUNCH(ip_compact, dim3(d.NS, d.n_launch), dim3(IP_BLOCK), 0, st, d, ring_pos);
   if (want_labels) hipLaunchKernelGGL(ip_labels, gN, dim3(IP_BLOCK), 0, st, d);
 }
 
 void launch_atan2f_probe(const float* y, const float* x, float* out, int n, int mode, hipStream_t st) {
-  hipLaunchKernelGGL(atan2f_probe, dim3((n + 255) / 256), dim3(256), 0, st, y, x, out, n, mode);
+  ALEGO_LAUNCH(atan2f_probe, dim3((n + 255) / 256), dim3(256), 0, st, y, x, out, n, mode);
 }

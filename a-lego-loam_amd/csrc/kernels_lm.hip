@@ -11,6 +11,7 @@
 //   lm_solve       a23/a24: both ceres::Solve calls of :360-478 in one workgroup per stream
 //   lm_finish / lm_store_kf  saveKeyFramesAndFactor (no-loop-closure pass-through) + transformUpdate
 #include "dev_cost.h"
+#include "prof.h"
 #include "lm_ctx.h"
 
 #define LM_BLOCK 256
@@ -595,23 +596,23 @@ __global__ void __launch_bounds__(LM_BLOCK) lm_store_kf(DevCtx d, LmCtx L) {
 
 // ---- launchers ---------------------------------------------------------------------
 void launch_lm_prepare(const DevCtx& d, const LmCtx& L, int stage, int run_hint, hipStream_t st) {
-  hipLaunchKernelGGL(lm_prepare, dim3(8, 3, d.n_launch), dim3(LM_BLOCK), 0, st, d, L, stage, run_hint);
+  ALEGO_LAUNCH(lm_prepare, dim3(8, 3, d.n_launch), dim3(LM_BLOCK), 0, st, d, L, stage, run_hint);
 }
 void launch_lm_concat(const DevCtx& d, const LmCtx& L, hipStream_t st) {
-  hipLaunchKernelGGL(lm_concat, dim3(16, L.K, d.n_launch), dim3(LM_BLOCK), 0, st, d, L);
+  ALEGO_LAUNCH(lm_concat, dim3(16, L.K, d.n_launch), dim3(LM_BLOCK), 0, st, d, L);
 }
 void launch_lm_total_and_grid_setup(const DevCtx& d, const LmCtx& L, hipStream_t st) {
-  hipLaunchKernelGGL(lm_total, dim3(8, d.n_launch), dim3(LM_BLOCK), 0, st, d, L);
-  hipLaunchKernelGGL(lm_grid_setup, dim3(2, d.n_launch), dim3(LM_BLOCK), 0, st, d, L);
+  ALEGO_LAUNCH(lm_total, dim3(8, d.n_launch), dim3(LM_BLOCK), 0, st, d, L);
+  ALEGO_LAUNCH(lm_grid_setup, dim3(2, d.n_launch), dim3(LM_BLOCK), 0, st, d, L);
 }
 void launch_lm_grid(const DevCtx& d, const LmCtx& L, hipStream_t st) {
-  hipLaunchKernelGGL(lm_grid_count, dim3(32, 2, d.n_launch), dim3(LM_BLOCK), 0, st, d, L, 0);
-  hipLaunchKernelGGL(lm_grid_scan, dim3(2, d.n_launch), dim3(LM_BLOCK), 0, st, d, L);
-  hipLaunchKernelGGL(lm_grid_count, dim3(32, 2, d.n_launch), dim3(LM_BLOCK), 0, st, d, L, 1);
+  ALEGO_LAUNCH(lm_grid_count, dim3(32, 2, d.n_launch), dim3(LM_BLOCK), 0, st, d, L, 0);
+  ALEGO_LAUNCH(lm_grid_scan, dim3(2, d.n_launch), dim3(LM_BLOCK), 0, st, d, L);
+  ALEGO_LAUNCH(lm_grid_count, dim3(32, 2, d.n_launch), dim3(LM_BLOCK), 0, st, d, L, 1);
 }
 void launch_lm_register(const DevCtx& d, const LmCtx& L, hipStream_t st) {
-  hipLaunchKernelGGL(lm_assoc, dim3((L.qcap + 127) / 128, 2, d.n_launch), dim3(128), 0, st, d, L);
-  hipLaunchKernelGGL(lm_solve, dim3(d.n_launch), dim3(LM_SOLVE_BLOCK), 0, st, d, L);
-  hipLaunchKernelGGL(lm_finish, dim3((d.n_launch + 63) / 64), dim3(64), 0, st, d, L);
-  hipLaunchKernelGGL(lm_store_kf, dim3(8, 3, d.n_launch), dim3(LM_BLOCK), 0, st, d, L);
+  ALEGO_LAUNCH(lm_assoc, dim3((L.qcap + 127) / 128, 2, d.n_launch), dim3(128), 0, st, d, L);
+  ALEGO_LAUNCH(lm_solve, dim3(d.n_launch), dim3(LM_SOLVE_BLOCK), 0, st, d, L);
+  ALEGO_LAUNCH(lm_finish, dim3((d.n_launch + 63) / 64), dim3(64), 0, st, d, L);
+  ALEGO_LAUNCH(lm_store_kf, dim3(8, 3, d.n_launch), dim3(LM_BLOCK), 0, st, d, L);
 }

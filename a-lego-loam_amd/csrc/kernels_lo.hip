@@ -8,6 +8,7 @@
 //              shuffle + LDS reduction of the 21+6+1 normal-equation scalars in a fixed order, 6x6
 //              Cholesky by one lane, step acceptance, and (second call) the pose integration
 #include "dev_cost.h"
+#include "prof.h"
 
 #define LO_BLOCK 256
 
@@ -249,8 +250,8 @@ __global__ void __launch_bounds__(LO_BLOCK) lo_solve(DevCtx d, int phase) {
 
 void launch_lo(const DevCtx& d, hipStream_t st) {
   const int wpb = LO_BLOCK / 64;
-  hipLaunchKernelGGL(lo_assoc, dim3((d.lo_qcap_surf + wpb - 1) / wpb, d.n_launch), dim3(LO_BLOCK), 0, st, d, 0);
-  hipLaunchKernelGGL(lo_solve, dim3(d.n_launch), dim3(LO_BLOCK), 0, st, d, 0);
-  hipLaunchKernelGGL(lo_assoc, dim3((d.lo_qcap_corner + wpb - 1) / wpb, d.n_launch), dim3(LO_BLOCK), 0, st, d, 1);
-  hipLaunchKernelGGL(lo_solve, dim3(d.n_launch), dim3(LO_BLOCK), 0, st, d, 1);
+  ALEGO_LAUNCH(lo_assoc, dim3((d.lo_qcap_surf + wpb - 1) / wpb, d.n_launch), dim3(LO_BLOCK), 0, st, d, 0);
+  ALEGO_LAUNCH(lo_solve, dim3(d.n_launch), dim3(LO_BLOCK), 0, st, d, 0);
+  ALEGO_LAUNCH(lo_assoc, dim3((d.lo_qcap_corner + wpb - 1) / wpb, d.n_launch), dim3(LO_BLOCK), 0, st, d, 1);
+  ALEGO_LAUNCH(lo_solve, dim3(d.n_launch), dim3(LO_BLOCK), 0, st, d, 1);
 }

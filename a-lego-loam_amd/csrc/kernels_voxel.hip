@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "voxel.h"
+#include "prof.h"
 
 #define VB 256
 
@@ -215,17 +216,21 @@ void vox_destroy(VoxCtx* V) {
 
 int vox_run(const VoxCtx& V, hipStream_t st, std::string* err) {
   if (V.njobs == 0) return 0;
-  (void)hipMemsetAsync(V.bbox, 0xFF, (size_t)V.njobs * 8 * 4, st);
+  { ProfScope ms_("memset_bbox", st); (void)hipMemsetAsync(V.bbox, 0xFF, (size_t)V.njobs * 8 * 4, st); }
   int nb = (V.max_cap + VB - 1) / VB;
   if (nb > V.gx) nb = V.gx;  // grid-stride inside the kernels: bounded block count per job
-  hipLaunchKernelGGL(vox_bbox, dim3(nb, V.njobs), dim3(VB), 0, st, V);
-  hipLaunchKernelGGL(vox_keys, dim3(nb, V.njobs), dim3(VB), 0, st, V);
+  ALEGO_LAUNCH(vox_bbox, dim3(nb, V.njobs), dim3(VB), 0, st, V);
+  ALEGO_LAUNCH(vox_keys, dim3(nb, V.njobs), dim3(VB), 0, st, V);
   size_t bytes = V.sort_tmp_bytes;
-  hipError_t e = rocprim::segmented_radix_sort_pairs(V.sort_tmp, bytes, V.keys_a, V.keys_b, V.vals_a, V.vals_b, V.total, (unsigned)V.njobs,
-                                                     V.seg_begin, V.seg_end, 0, 32, st);
+  hipError_t e;
+  {
+    ProfScope sort_scope_("rocprim_segmented_radix_sort", st);
+    e = rocprim::segmented_radix_sort_pairs(V.sort_tmp, bytes, V.keys_a, V.keys_b, V.vals_a, V.vals_b, V.total, (unsigned)V.njobs,
+                                            V.seg_begin, V.seg_end, 0, 32, st);
+  }
   if (e != hipSuccess) { *err = std::string("segmented_radix_sort_pairs: ") + hipGetErrorString(e); return -2; }
-  hipLaunchKernelGGL(vox_heads, dim3(nb, V.njobs), dim3(VB), 0, st, V);
-  hipLaunchKernelGGL(vox_scan, dim3(V.njobs), dim3(VB), 0, st, V);
-  hipLaunchKernelGGL(vox_centroid, dim3(nb, V.njobs), dim3(VB), 0, st, V);
+  ALEGO_LAUNCH(vox_heads, dim3(nb, V.njobs), dim3(VB), 0, st, V);
+  ALEGO_LAUNCH(vox_scan, dim3(V.njobs), dim3(VB), 0, st, V);
+  ALEGO_LAUNCH(vox_centroid, dim3(nb, V.njobs), dim3(VB), 0, st, V);
   return 0;
 }

@@ -1,0 +1,51 @@
+// prof.h — optional per-kernel HIP-event timing (bench.py's roofline leg).  Off by default:
+// the timed region of the benchmark runs without events.
+#ifndef ALEGO_PROF_H_
+#define ALEGO_PROF_H_
+#include <hip/hip_runtime.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+struct Profiler {
+  bool on = false;
+  struct Rec { int id; hipEvent_t a, b; };
+  std::vector<Rec> recs;
+  std::vector<std::string> names;
+  std::map<std::string, int> ids;
+  std::vector<hipEvent_t> pool;
+  size_t pool_next = 0;
+  hipEvent_t get() {
+    if (pool_next == pool.size()) { hipEvent_t e; (void)hipEventCreate(&e); pool.push_back(e); }
+    return pool[pool_next++];
+  }
+  int id_of(const char* name) {
+    auto it = ids.find(name);
+    if (it != ids.end()) return it->second;
+    const int id = (int)names.size();
+    names.push_back(name); ids[name] = id;
+    return id;
+  }
+  void begin(const char* name, hipStream_t st) { Rec r{id_of(name), get(), get()}; (void)hipEventRecord(r.a, st); recs.push_back(r); }
+  void end(hipStream_t st) { (void)hipEventRecord(recs.back().b, st); }
+  void reset() { recs.clear(); pool_next = 0; }
+  ~Profiler() { for (auto e : pool) (void)hipEventDestroy(e); }
+};
+
+extern thread_local Profiler* g_prof;  // set by the API while it enqueues work for a handle
+
+struct ProfScope {
+  hipStream_t st; bool on;
+  ProfScope(const char* name, hipStream_t s) : st(s), on(g_prof && g_prof->on) { if (on) g_prof->begin(name, st); }
+  ~ProfScope() { if (on) g_prof->end(st); }
+};
+
+// launch `kernel` bracketed by events when profiling is on
+#define ALEGO_LAUNCH(kernel, grid, block, shmem, stream, ...)                 \
+  do {                                                                        \
+    ProfScope prof_scope_(#kernel, stream);                                   \
+    hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);      \
+  } while (0)
+
+#endif

@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""bench.py — scans/sec of the full IP -> LO -> LM loop on 16x1800 synthetic LiDAR streams.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" advances every resident stream of this rank by one scan (ImageProjection, feature
+extraction + LaserOdometry, LaserMapping on every 2nd scan), all inputs already in HBM.
+One process per GPU; streams are independent (the path shards across streams with no
+data-path collective), so N GPUs run N x `--streams` streams: weak scaling.  Rank 0 prints one JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+from alego_loader import load_package  # noqa: E402
+
+load_package()
+from alego_amd import binding, synth  # noqa: E402
+from alego_amd import dist as D  # noqa: E402
+
+HBM_PEAK = 8.0e12  # B/s, MI355X spec (MI355X_MICROARCH.md)
+
+
+def algorithmic_bytes(c, NS):
+    """SURVEY.md §8(d) compulsory HBM bytes of one scan, from the device counters of that scan."""
+    b_ip = 16 * c["P"] + 25 * c["M"] + 16 * c["O"] + 8 * NS + 12
+    b_fe = 9 * c["M"] + 16 * (c["Qc"] + c["Fc"] + c["Qs"] + c["Fs"])
+    b_lo = 16 * (c["Fc"] + c["Fs"] + c["Qc"] + c["Qs"]) + 104
+    kraw, kds = c["Kraw_c"] + c["Kraw_s"], c["Kds_c"] + c["Kds_s"]
+    b_lm = 16 * kraw + 32 * kds + 16 * (c["Lc"] + c["Ls"]) + 104
+    return dict(B_IP=b_ip, B_FE=b_fe, B_LO=b_lo, B_LM=b_lm, B_scan=b_ip + b_fe + b_lo + b_lm / 2)
+
+
+def kernel_bytes(name, c, NS, H):
+    """Algorithmic (compulsory) HBM bytes one launch of `name` moves for ONE stream.
+    Arrays a kernel only re-reads from a producer in the same stage are charged to it as well, so the
+    per-kernel figures sum to more than B_scan; intermediates never count twice inside one kernel."""
+    N, P, M = NS * H, c["P"], c["M"]
+    feats = c["Qc"] + c["Fc"] + c["Qs"] + c["Fs"]
+    kraw, kds = c["Kraw_c"] + c["Kraw_s"], c["Kds_c"] + c["Kds_s"]
+    L = c["Lc"] + c["Ls"]
+    t = {
+        "ip_reset": 4 * N, "ip_project": 16 * P + 4 * P, "ip_image": 4 * N + 16 * P + 5 * N,
+        "cc_edges": 5 * N + 17 * N, "cc_link": N + 8 * N, "cc_stats": 5 * N + 4 * N,
+        "ip_rowcount": 5 * N, "ip_compact": 9 * N + 16 * M + 25 * M + 16 * c["O"], "ip_labels": 9 * N,
+        "fe_curv": 8 * M + 5 * M, "fe_pick": 14 * M + 4 * M + 4 * (feats + M), "fe_voxel": 20 * M + 16 * c["Fs"],
+        "fe_gather": 20 * (c["Qc"] + c["Fc"] + c["Qs"]) + 32 * c["Fs"],
+        "lo_assoc": 16 * (c["Fc"] + c["Fs"] + c["Qc"] + c["Qs"]) + 16 * (c["Qc"] + c["Qs"]),
+        "lo_solve": 16 * (c["Qc"] + c["Qs"]) + 64 * (c["Qc"] + c["Qs"]) + 104,
+        "lm_prepare": 32 * (c["Fc"] + c["Fs"] + c["O"]), "lm_concat": 32 * kraw, "lm_total": 32 * c["Ls"],
+        "vox_bbox": 16 * (kraw + c["Fc"] + c["Fs"]), "vox_keys": 24 * (kraw + c["Fc"] + c["Fs"]),
+        "rocprim_segmented_radix_sort": 16 * (kraw + c["Fc"] + c["Fs"]) * 4, "vox_heads": 4 * (kraw + c["Fc"] + c["Fs"]),
+        "vox_centroid": 24 * (kraw + c["Fc"] + c["Fs"]) + 16 * (kds + L),
+        "lm_grid_count": 20 * kds, "lm_assoc": 16 * L + 27 * 16 * 8 * L + 64 * L, "lm_solve": 80 * L + 104,
+        "lm_store_kf": 32 * L,
+    }
+    return t.get(name)
+
+
+def gen_scans(p, n_streams, ring, rank):
+    ids = D.stream_ids(rank, n_streams)
+    jobs = [(s, k) for s in range(n_streams) for k in range(ring)]
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
+        out = list(ex.map(lambda sk: synth.scan(p, sk[1], stream=ids[sk[0]]), jobs))
+    return {sk: a for sk, a in zip(jobs, out)}
+
+
+def cpu_baseline(p, seconds=12.0, prime=560, max_scans=1400):
+    """The oracle (CPU restatement, 1 thread) on stream 0: primed with `prime` scans so that the 50-key-frame
+    local map is full, then timed for ~`seconds` s of scans."""
+    from oracle import oracle_py
+    o = oracle_py.Oracle(p)
+    t_all = time.perf_counter()
+    for k in range(prime):
+        o.process_scan(synth.scan(p, k))
+    pre = [synth.scan(p, k) for k in range(prime, max_scans)]
+    n, t0 = 0, time.perf_counter()
+    stage = np.zeros(3)
+    for pts in pre:
+        o.process_scan(pts)
+        stage += o.get("timing_ms")[:3]
+        n += 1
+        if time.perf_counter() - t0 > seconds:
+            break
+    dt = time.perf_counter() - t0
+    info = o.get("lm_info")
+    return dict(value=n / dt, unit="scans/s", cores=1, kind="port",
+                sample=f"oracle IP->LO->LM, stream 0, scans {prime}..{prime + n - 1} after priming {prime} scans "
+                       f"({int(info[11])} key frames); {dt:.1f} s timed, {time.perf_counter() - t_all:.1f} s total",
+                ms_per_scan=dict(ip=stage[0] / n, lo=stage[1] / n, lm=stage[2] / n),
+                host_cores=os.cpu_count())
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--streams", type=int, default=64, help="independent streams resident per GPU")
+    ap.add_argument("--ring", type=int, default=48, help="scans kept in HBM per stream (replayed back and forth)")
+    ap.add_argument("--prime", type=int, default=560, help="untimed scans per stream to fill the 50-key-frame local map")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-profile", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank, local, world = D.env()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the product path")
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        dist = D.init("nccl", torch.device("cuda", local))  # RCCL: only the barrier + max-over-ranks use it
+
+    p = synth.default_params(16, 1800)
+    B, R = args.streams, args.ring
+    h = binding.Handle(p, device=local, n_slots=B, ring_len=R)
+    scans = gen_scans(p, B, R, rank)
+    for (s, k), a in scans.items():
+        h.batch_load(s, k, a)
+    del scans
+    stages = 7 | binding.REPLAY_PINGPONG
+    step = 0
+    h.batch_run(step, args.prime, stages); step += args.prime          # state priming (untimed, like loading a map)
+    h.batch_run(step, args.warmup, stages); step += args.warmup        # W warmup steps
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    h.batch_run(step, args.steps, stages, sync=False)                   # exactly K timed steps
+    h.synchronize()
+    fence()
+    dt = time.perf_counter() - t0
+    step += args.steps
+    dt = D.max_over_ranks(dt, dist, device="cuda")
+    counts = h.batch_get_counts(0)
+    flags, odom, mp = h.batch_get_pose(0)
+
+    roof, kern, single = None, None, None
+    if rank == 0 and not args.no_profile:
+        # per-kernel durations with HIP events on the handle's stream, over another K steps
+        h.profile_enable(True)
+        h.batch_run(step, args.steps, stages); step += args.steps
+        rep = h.profile_report()
+        h.profile_enable(False)
+        tot = sum(v[0] for v in rep.values())
+        kern = {k: dict(ms_total=round(v[0], 3), launches=v[1], avg_us=round(1e3 * v[0] / max(v[1], 1), 2),
+                        share=round(v[0] / tot, 4)) for k, v in sorted(rep.items(), key=lambda kv: -kv[1][0])}
+        dom = next(iter(kern))
+        kb = kernel_bytes(dom, counts, p.n_scan, p.horizon_scan)
+        if kb is not None:
+            ach = kb * B / (kern[dom]["avg_us"] * 1e-6)
+            roof = dict(bound="hbm", kernel=dom, achieved=round(ach / 1e9, 3), peak=HBM_PEAK / 1e9, unit="GB/s",
+                        frac=round(ach / HBM_PEAK, 6), traffic=None,
+                        algorithmic_bytes_per_launch=int(kb * B), avg_launch_us=kern[dom]["avg_us"])
+    value = D.aggregate_scans_per_s(world, B, args.steps, dt)
+    out = {
+        "metric": "scans/sec (16x1800 LiDAR) full IP->LO->LM loop", "value": round(value, 1), "unit": "scans/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32/f64", "data": "synthetic",
+        "config": {"workload": "16x1800 S0/T0 bag-equivalent replay, IP->LO->LM with 50-key-frame local map, "
+                               f"{B} independent streams per GPU advanced in lock-step (one scan per stream per step)",
+                   "streams_per_gpu": B, "ring_scans": R, "primed_scans": args.prime, "parallelism": f"streams x{world}"},
+    }
+    if rank == 0:
+        ab = algorithmic_bytes(counts, p.n_scan)
+        out["pipeline_roofline"] = dict(B_scan=int(ab["B_scan"]), achieved_GBps=round(value / world * ab["B_scan"] / 1e9, 3),
+                                        frac_of_hbm_peak=round(value / world * ab["B_scan"] / HBM_PEAK, 6), **{k: int(v) for k, v in ab.items() if k != "B_scan"})
+        out["counts"] = counts
+        if roof is not None:
+            out["roofline"] = roof
+        if kern is not None:
+            out["kernels"] = kern
+        if world == 1 and not args.no_cpu:
+            # single-stream latency-bound figure (configs[2] as written) next to the batched one
+            h1 = binding.Handle(p, device=local, n_slots=1, ring_len=R)
+            for k in range(R):
+                h1.batch_load(0, k, synth.scan(p, k))
+            h1.batch_run(0, args.prime, stages)
+            t1 = time.perf_counter()
+            h1.batch_run(args.prime, args.steps, stages)
+            out["single_stream_scans_per_s"] = round(args.steps / (time.perf_counter() - t1), 1)
+            h1.close()
+            out["cpu_baseline"] = cpu_baseline(p)
+        print(json.dumps(out), flush=True)
+    h.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -125,6 +125,9 @@ int alego_batch_load(alego_handle* h, int slot, int ring_pos, const alego_point*
  * all kernels enqueued on the handle's stream; returns without synchronising when sync == 0 */
 int alego_batch_run(alego_handle* h, int first_pos, int n_scans, int stages, int sync);
 int alego_synchronize(alego_handle* h);
+/* OR into `stages` of alego_batch_run: replay the resident ring back and forth (0..R-1,R-2..0,1..)
+ * instead of wrapping, so that consecutive scans of a stream are always trajectory neighbours */
+#define ALEGO_REPLAY_PINGPONG 0x100
 /* poses of the last processed scan of `slot` */
 int alego_batch_get_pose(alego_handle* h, int slot, alego_pose* odom, alego_pose* map_pose);
 /* per-scan device counters of the last processed scan of `slot`:
@@ -133,6 +136,13 @@ int alego_batch_get_pose(alego_handle* h, int slot, alego_pose* odom, alego_pose
 int alego_batch_get_counts(alego_handle* h, int slot, int32_t* out, int cap);
 /* the HIP stream (hipStream_t) the handle enqueues on, for event timing by the caller */
 void* alego_stream(alego_handle* h);
+
+/* ---- per-kernel timing (bench.py's roofline leg) --------------------------- */
+/* When enabled every kernel launch of this handle is bracketed by hipEventRecord on the handle's
+ * stream.  Off by default; the benchmark's timed region runs with it off. */
+int alego_profile_enable(alego_handle* h, int on);
+/* names: ';'-separated kernel names; total_ms / launches per kernel.  Returns the kernel count. */
+int alego_profile_report(alego_handle* h, char* names, int names_cap, double* total_ms, int* launches, int cap);
 
 /* ---- state access for parity tests (teacher forcing) ---------------------- */
 int alego_set_lo_params(alego_handle* h, int slot, const double* p6);
