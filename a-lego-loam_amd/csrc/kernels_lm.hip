@@ -446,10 +446,20 @@ __global__ void __launch_bounds__(LM_SOLVE_BLOCK) lm_solve(DevCtx d, LmCtx L) {
   }
   const int R = s_cnt[0][0];
   double acc[28];
+#ifdef ALEGO_TIMING
+  long long tm[5] = {0, 0, 0, 0, 0};
+#define TM(k, expr) { const long long c_ = clock64(); expr; tm[k] += clock64() - c_; }
+#else
+#define TM(k, expr) { expr; }
+#endif
   auto evaluate = [&](const double* x) {
 #pragma unroll
     for (int k = 0; k < 28; ++k) acc[k] = 0;
-    const PoseTerms T = pose_terms(x);
+    PoseTerms T;
+    TM(0, T = pose_terms(x));
+#ifdef ALEGO_TIMING
+    const long long c1_ = clock64();
+#endif
     for (int i = threadIdx.x; i < nqc + nqs; i += LM_SOLVE_BLOCK) {
       const bool is_c = i < nqc;
       const double* b = blocks + (size_t)(is_c ? i : L.kf_cap_c + (i - nqc)) * 8;
@@ -461,7 +471,10 @@ __global__ void __launch_bounds__(LM_SOLVE_BLOCK) lm_solve(DevCtx d, LmCtx L) {
       eval_block(ty == 2.0 ? BLK_EDGE : BLK_PLANE, cp, a3, b3, c3, b[6], T, &res, J);
       accumulate_block(res, J, P.huber_delta, acc);
     }
-    lm_block_reduce28(acc, s_part, s_out);
+#ifdef ALEGO_TIMING
+    tm[1] += clock64() - c1_;
+#endif
+    TM(2, lm_block_reduce28(acc, s_part, s_out));
   };
   for (int outer = 0; outer < P.lm_outer_iters; ++outer) {  // :360 — identical correspondences both times
     if (R == 0) {  // ceres::Solve on an empty problem is a no-op
@@ -478,8 +491,7 @@ __global__ void __launch_bounds__(LM_SOLVE_BLOCK) lm_solve(DevCtx d, LmCtx L) {
     if (threadIdx.x == 0) lm_begin(S, x0, s_out, P.lm_max_iters);
     __syncthreads();
     while (true) {
-      if (threadIdx.x == 0) s_action = lm_propose(S);
-      __syncthreads();
+      TM(3, if (threadIdx.x == 0) s_action = lm_propose(S); __syncthreads());
       const int act = s_action;
       if (act == LM_STOP) break;
       if (act == LM_EVAL) {
@@ -487,13 +499,15 @@ __global__ void __launch_bounds__(LM_SOLVE_BLOCK) lm_solve(DevCtx d, LmCtx L) {
 #pragma unroll
         for (int k = 0; k < 6; ++k) xc[k] = S.cand[k];
         evaluate(xc);
-        if (threadIdx.x == 0) s_action = lm_consume(S, s_out);
-        __syncthreads();
+        TM(4, if (threadIdx.x == 0) s_action = lm_consume(S, s_out); __syncthreads());
         if (s_action == LM_STOP) break;
       }
       __syncthreads();
     }
     if (threadIdx.x == 0) {
+#ifdef ALEGO_TIMING
+      for (int k = 0; k < 5; ++k) ld[43 + k] = (outer == 0 ? 0.0 : ld[43 + k]) + (double)tm[k];
+#endif
 #pragma unroll
       for (int k = 0; k < 6; ++k) ld[LD_PARAMS + k] = S.x[k];
       if (outer < 2) {

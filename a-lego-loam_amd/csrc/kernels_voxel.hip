@@ -1,10 +1,24 @@
 // kernels_voxel.hip — batched pcl::VoxelGrid<PointXYZI>::applyFilter (see voxel.h).
-// Replaces the VoxelGrid calls of laserMapping.cpp:316-319 (map, every mapping frame in the
-// reference; here only when the key-frame set changed) and :329-342 (current scan).
+// Replaces the VoxelGrid calls of laserMapping.cpp:316-319 (map; the reference redoes it every mapping
+// frame, here only when the key-frame set changed) and :329-342 (current scan).
+//
+// Round 1 first used rocprim::segmented_radix_sort_pairs for the (voxel id, position) sort; a 45-75 k point
+// map segment is sorted there by ONE workgroup (~1.2 ms, tools/micro/segsort_bench.hip).  This version is a
+// two-level bucket sort written for the job: voxel ids are bounded by the grid size, so
+//   vox_keys      key = voxel id; bucket = key >> shift (<= 4096 buckets/job); bucket histogram (atomics)
+//   vox_bscan     exclusive scan of the bucket histogram (one workgroup per job)
+//   vox_bscatter  (key << 32 | position) into its bucket (atomic cursor: order inside a bucket is arbitrary)
+//   vox_bsort     one wavefront per bucket: rank-by-counting sort of the bucket (registers for <= 64
+//                 elements, LDS above), counts the voxels of the bucket
+//   vox_vscan     exclusive scan of the per-bucket voxel counts -> output ranks (ascending voxel id)
+//   vox_bcentroid one wavefront per bucket: voxel heads; the head lane accumulates its run in sorted
+//                 (= original) order in f32 and divides by the count (pcl::CentroidPoint)
+// Jobs differ by three orders of magnitude in size (a 45-75 k point map vs a 50 point outlier cloud) and most
+// of the time the big ones are disabled, so the point- and bucket-parallel kernels run on a fixed pool of
+// workgroups that walk a device-built work list (vox_plan: job -> number of 1024-point / 16-bucket items).
 #include <cstring>
 
 #include <hip/hip_runtime.h>
-#include <rocprim/rocprim.hpp>
 
 #include <vector>
 
@@ -12,6 +26,8 @@
 #include "prof.h"
 
 #define VB 256
+
+typedef unsigned long long u64;
 
 __device__ __forceinline__ unsigned vx_enc(float f) {
   const unsigned b = (unsigned)__float_as_int(f);
@@ -23,159 +39,325 @@ __device__ __forceinline__ float vx_dec(unsigned e) {
 }
 __device__ __forceinline__ bool vx_enabled(const VoxJob& J) { return J.enable == nullptr || *J.enable != 0; }
 
-__global__ void __launch_bounds__(VB) vox_bbox(VoxCtx V) {
-  const VoxJob J = V.jobs[blockIdx.y];
-  if (!vx_enabled(J)) return;
-  const int n = min(*J.n_in, J.cap);
-  if ((int)blockIdx.x * VB >= n) return;
-  float mn[3] = {3.402823466e+38f, 3.402823466e+38f, 3.402823466e+38f}, mx[3] = {-3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f};
-  for (int i = blockIdx.x * VB + threadIdx.x; i < n; i += gridDim.x * VB) {
-    const float4 p = J.in[i];
-    mn[0] = fminf(mn[0], p.x); mn[1] = fminf(mn[1], p.y); mn[2] = fminf(mn[2], p.z);
-    mx[0] = fmaxf(mx[0], p.x); mx[1] = fmaxf(mx[1], p.y); mx[2] = fmaxf(mx[2], p.z);
-  }
-  __shared__ float s[6][VB / 64];
-#pragma unroll
-  for (int a = 0; a < 3; ++a) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { mn[a] = fminf(mn[a], __shfl_xor(mn[a], o, 64)); mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], o, 64)); }
-    if ((threadIdx.x & 63) == 0) { s[a][threadIdx.x >> 6] = mn[a]; s[3 + a][threadIdx.x >> 6] = mx[a]; }
-  }
-  __syncthreads();
-  if (threadIdx.x < 6) {
-    const int a = threadIdx.x;
-    float v = s[a][0];
-    for (int w = 1; w < VB / 64; ++w) v = a < 3 ? fminf(v, s[a][w]) : fmaxf(v, s[a][w]);
-    unsigned* bb = V.bbox + blockIdx.y * 8;
-    if (a < 3) atomicMin(&bb[a], vx_enc(v)); else atomicMin(&bb[4 + a - 3], ~vx_enc(v));
-  }
-}
+#define VX_POOL 1024           // workgroups of the point / bucket parallel kernels
+#define VX_PT_ITEM 1024        // points per work item
+#define VX_BK_ITEM 16          // buckets per work item
 
-__global__ void __launch_bounds__(VB) vox_keys(VoxCtx V) {
-  const int job = blockIdx.y;
-  const VoxJob J = V.jobs[job];
-  if (!vx_enabled(J)) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) { V.seg_begin[job] = J.off; V.seg_end[job] = J.off; }
-    return;
-  }
-  const int n = min(*J.n_in, J.cap);
-  const float inv = 1.0f / J.leaf;
-  const unsigned* bb = V.bbox + job * 8;
-  int minb[3] = {0, 0, 0}, mul1 = 1, mul2 = 1, pass = 0;
-  if (n > 0) {
-    float mn[3], mx[3];
-#pragma unroll
-    for (int a = 0; a < 3; ++a) { mn[a] = vx_dec(bb[a]); mx[a] = vx_dec(~bb[4 + a]); }
-    const long long dx = (long long)((mx[0] - mn[0]) * inv) + 1, dy = (long long)((mx[1] - mn[1]) * inv) + 1, dz = (long long)((mx[2] - mn[2]) * inv) + 1;
-    pass = (dx * dy * dz > 2147483647LL) ? 1 : 0;  // PCL: "leaf size too small" -> output = input
-    int divb[3];
-#pragma unroll
-    for (int a = 0; a < 3; ++a) { minb[a] = (int)floorf(mn[a] * inv); divb[a] = (int)floorf(mx[a] * inv) - minb[a] + 1; }
-    mul1 = divb[0]; mul2 = divb[0] * divb[1];
-  }
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    int* g = V.geom + job * 8;
-    g[0] = minb[0]; g[1] = minb[1]; g[2] = minb[2]; g[3] = mul1; g[4] = mul2; g[5] = n; g[6] = pass;
-    V.seg_begin[job] = J.off; V.seg_end[job] = J.off + n;
-  }
-  for (int i = blockIdx.x * VB + threadIdx.x; i < n; i += gridDim.x * VB) {
-    unsigned key;
-    if (pass) key = (unsigned)i;
-    else {
-      const float4 p = J.in[i];
-      const int i0 = (int)(floorf(p.x * inv) - (float)minb[0]);
-      const int i1 = (int)(floorf(p.y * inv) - (float)minb[1]);
-      const int i2 = (int)(floorf(p.z * inv) - (float)minb[2]);
-      key = (unsigned)(i0 + i1 * mul1 + i2 * mul2);
-    }
-    V.keys_a[J.off + i] = key;
-    V.vals_a[J.off + i] = i;
-  }
-}
-
-__global__ void __launch_bounds__(VB) vox_heads(VoxCtx V) {
-  const int job = blockIdx.y;
-  const VoxJob J = V.jobs[job];
-  if (!vx_enabled(J)) return;
-  const int n = V.geom[job * 8 + 5];
-  const unsigned* keys = V.keys_b + J.off;
-  __shared__ int s[VB / 64];
-  for (int b = blockIdx.x; b * VB < n; b += gridDim.x) {
-    const int i = b * VB + threadIdx.x;
-    const bool head = i < n && (i == 0 || keys[i] != keys[i - 1]);
-    const unsigned long long m = __ballot(head);
-    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = (int)__popcll(m);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      int t = 0;
-      for (int w = 0; w < VB / 64; ++w) t += s[w];
-      V.blk_cnt[job * V.blk_stride + b] = t;
-    }
-    __syncthreads();
-  }
-}
-
-__global__ void __launch_bounds__(VB) vox_scan(VoxCtx V) {
-  const int job = blockIdx.x;
-  const VoxJob J = V.jobs[job];
-  if (!vx_enabled(J)) return;
-  const int n = V.geom[job * 8 + 5];
-  const int nblk = (n + VB - 1) / VB;
-  int* bc = V.blk_cnt + job * V.blk_stride;
+// one workgroup: exclusive scan over jobs of their item counts.  which 0: ceil(n/VX_PT_ITEM) from the job
+// inputs; which 1: ceil(nb/VX_BK_ITEM) from the geometry written by vox_keys.
+__global__ void __launch_bounds__(VB) vox_plan(VoxCtx V, int which) {
   __shared__ int s[VB / 64];
   __shared__ int s_run;
+  int* off = which == 0 ? V.pt_items : V.bk_items;
   if (threadIdx.x == 0) s_run = 0;
   __syncthreads();
-  for (int b0 = 0; b0 < nblk; b0 += VB) {
-    const int b = b0 + threadIdx.x;
-    const int v = b < nblk ? bc[b] : 0;
-    int incl = v;  // inclusive scan within the wave
+  for (int j0 = 0; j0 < V.njobs; j0 += VB) {
+    const int j = j0 + threadIdx.x;
+    int v = 0;
+    if (j < V.njobs) {
+      const VoxJob J = V.jobs[j];
+      if (vx_enabled(J)) {
+        if (which == 0) { const int n = min(*J.n_in, J.cap); v = (n + VX_PT_ITEM - 1) / VX_PT_ITEM; }
+        else v = (V.geom[j * VX_GEOM + 8] + VX_BK_ITEM - 1) / VX_BK_ITEM;
+      }
+    }
+    int incl = v;
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if ((threadIdx.x & 63) >= o) incl += t; }
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if ((int)(threadIdx.x & 63) >= o) incl += t; }
     if ((threadIdx.x & 63) == 63) s[threadIdx.x >> 6] = incl;
     __syncthreads();
     int woff = 0, tot = 0;
 #pragma unroll
-    for (int w = 0; w < VB / 64; ++w) { if (w < (threadIdx.x >> 6)) woff += s[w]; tot += s[w]; }
+    for (int w = 0; w < VB / 64; ++w) { if (w < (int)(threadIdx.x >> 6)) woff += s[w]; tot += s[w]; }
     const int run = s_run;
-    if (b < nblk) bc[b] = run + woff + incl - v;
+    if (j < V.njobs) off[j] = run + woff + incl - v;
     __syncthreads();
     if (threadIdx.x == 0) s_run = run + tot;
     __syncthreads();
   }
-  if (threadIdx.x == 0) *J.n_out = s_run;
+  if (threadIdx.x == 0) off[V.njobs] = s_run;
 }
 
-__global__ void __launch_bounds__(VB) vox_centroid(VoxCtx V) {
-  const int job = blockIdx.y;
-  const VoxJob J = V.jobs[job];
-  if (!vx_enabled(J)) return;
-  const int n = V.geom[job * 8 + 5];
-  const unsigned* keys = V.keys_b + J.off;
-  const int* vals = V.vals_b + J.off;
-  __shared__ int s[VB / 64];
-  for (int b = blockIdx.x; b * VB < n; b += gridDim.x) {
-    const int i = b * VB + threadIdx.x;
-    const bool head = i < n && (i == 0 || keys[i] != keys[i - 1]);
-    const unsigned long long m = __ballot(head);
-    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = (int)__popcll(m);
-    __syncthreads();
-    if (head) {
-      int woff = 0;
-      for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) woff += s[w];
-      const int rank = V.blk_cnt[job * V.blk_stride + b] + woff + (int)__popcll(m & ((1ull << (threadIdx.x & 63)) - 1ull));
-      const unsigned vid = keys[i];
-      float sx = 0.f, sy = 0.f, sz = 0.f, si = 0.f;  // pcl::CentroidPoint: f32 accumulators
-      int c = 0;
-      for (int li = i; li < n && keys[li] == vid; ++li) {
-        const float4 p = J.in[vals[li]];
-        sx += p.x; sy += p.y; sz += p.z; si += p.w;
-        ++c;
-      }
-      const float fn = (float)c;
-      if (rank < J.cap) J.out[rank] = make_float4(sx / fn, sy / fn, sz / fn, si / fn);
+// work item -> (job, chunk): largest job with off[job] <= item (jobs without items are skipped by the search)
+__device__ __forceinline__ int vx_item_job(const int* off, int njobs, int item, int* chunk) {
+  int lo = 0, hi = njobs;  // invariant: off[lo] <= item < off[hi]
+  while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (off[mid] <= item) lo = mid; else hi = mid; }
+  *chunk = item - off[lo];
+  return lo;
+}
+
+__global__ void __launch_bounds__(VB) vox_bbox(VoxCtx V) {
+  __shared__ float s[6][VB / 64];
+  const int total = V.pt_items[V.njobs];
+  for (int item = blockIdx.x; item < total; item += gridDim.x) {
+    int chunk;
+    const int job = vx_item_job(V.pt_items, V.njobs, item, &chunk);
+    const VoxJob J = V.jobs[job];
+    const int n = min(*J.n_in, J.cap);
+    float mn[3] = {3.402823466e+38f, 3.402823466e+38f, 3.402823466e+38f}, mx[3] = {-3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f};
+    for (int i = chunk * VX_PT_ITEM + threadIdx.x; i < min(n, (chunk + 1) * VX_PT_ITEM); i += VB) {
+      const float4 p = J.in[i];
+      mn[0] = fminf(mn[0], p.x); mn[1] = fminf(mn[1], p.y); mn[2] = fminf(mn[2], p.z);
+      mx[0] = fmaxf(mx[0], p.x); mx[1] = fmaxf(mx[1], p.y); mx[2] = fmaxf(mx[2], p.z);
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) { mn[a] = fminf(mn[a], __shfl_xor(mn[a], o, 64)); mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], o, 64)); }
+      if ((threadIdx.x & 63) == 0) { s[a][threadIdx.x >> 6] = mn[a]; s[3 + a][threadIdx.x >> 6] = mx[a]; }
     }
     __syncthreads();
+    if (threadIdx.x < 6) {
+      const int a = threadIdx.x;
+      float v = s[a][0];
+      for (int w = 1; w < VB / 64; ++w) v = a < 3 ? fminf(v, s[a][w]) : fmaxf(v, s[a][w]);
+      unsigned* bb = V.bbox + job * 8;
+      if (a < 3) atomicMin(&bb[a], vx_enc(v)); else atomicMin(&bb[4 + a - 3], ~vx_enc(v));
+    }
+    __syncthreads();
+  }
+}
+
+// one thread per job: voxel-grid geometry and bucket layout from the bounding box
+__global__ void __launch_bounds__(VB) vox_geom(VoxCtx V) {
+  const int job = blockIdx.x * VB + threadIdx.x;
+  if (job >= V.njobs) return;
+  const VoxJob J = V.jobs[job];
+  int* g = V.geom + job * VX_GEOM;
+  if (!vx_enabled(J)) { g[5] = 0; g[8] = 0; return; }
+  const int n = min(*J.n_in, J.cap);
+  const float inv = 1.0f / J.leaf;
+  const unsigned* bb = V.bbox + job * 8;
+  int minb[3] = {0, 0, 0}, mul1 = 1, mul2 = 1, pass = 0;
+  unsigned T = 1;
+  if (n > 0) {
+    float mn[3], mx[3];
+    for (int a = 0; a < 3; ++a) { mn[a] = vx_dec(bb[a]); mx[a] = vx_dec(~bb[4 + a]); }
+    const long long dx = (long long)((mx[0] - mn[0]) * inv) + 1, dy = (long long)((mx[1] - mn[1]) * inv) + 1, dz = (long long)((mx[2] - mn[2]) * inv) + 1;
+    pass = (dx * dy * dz > 2147483647LL) ? 1 : 0;  // PCL: "leaf size too small" -> output = input
+    int divb[3];
+    for (int a = 0; a < 3; ++a) { minb[a] = (int)floorf(mn[a] * inv); divb[a] = (int)floorf(mx[a] * inv) - minb[a] + 1; }
+    mul1 = divb[0]; mul2 = divb[0] * divb[1];
+    T = pass ? (unsigned)n : (unsigned)divb[0] * (unsigned)divb[1] * (unsigned)divb[2];
+    if (T == 0) T = 1;
+  }
+  // bucket = key >> shift, about 2 points per bucket (less skew), at most J.nbcap buckets
+  int target = 64;
+  while (target < J.nbcap && target * 2 < n) target <<= 1;
+  int shift = 0;
+  while (((T - 1) >> shift) >= (unsigned)target) ++shift;
+  g[0] = minb[0]; g[1] = minb[1]; g[2] = minb[2]; g[3] = mul1; g[4] = mul2; g[5] = n; g[6] = pass; g[7] = shift;
+  g[8] = n > 0 ? (int)((T - 1) >> shift) + 1 : 0;
+}
+
+__global__ void __launch_bounds__(VB) vox_keys(VoxCtx V) {
+  const int total = V.pt_items[V.njobs];
+  for (int item = blockIdx.x; item < total; item += gridDim.x) {
+    int chunk;
+    const int job = vx_item_job(V.pt_items, V.njobs, item, &chunk);
+    const VoxJob J = V.jobs[job];
+    const int* g = V.geom + job * VX_GEOM;
+    const int n = g[5], pass = g[6], shift = g[7], nb = g[8];
+    const int m0 = g[0], m1 = g[1], m2 = g[2], mul1 = g[3], mul2 = g[4];
+    const float inv = 1.0f / J.leaf;
+    int* bcnt = V.bcnt + J.boff0;
+    for (int i = chunk * VX_PT_ITEM + threadIdx.x; i < min(n, (chunk + 1) * VX_PT_ITEM); i += VB) {
+      unsigned key;
+      if (pass) key = (unsigned)i;
+      else {
+        const float4 p = J.in[i];
+        const int i0 = (int)(floorf(p.x * inv) - (float)m0);
+        const int i1 = (int)(floorf(p.y * inv) - (float)m1);
+        const int i2 = (int)(floorf(p.z * inv) - (float)m2);
+        key = (unsigned)(i0 + i1 * mul1 + i2 * mul2);
+      }
+      V.keys[J.off + i] = key;
+      atomicAdd(&bcnt[min(key >> shift, (unsigned)(nb - 1))], 1);
+    }
+  }
+}
+
+// exclusive scan of cnt[0..nb) by one workgroup; writes `off` and optionally a copy `cur`, the total to *total
+__device__ void vx_block_scan(const int* cnt, int* off, int* cur, int nb, int* total) {
+  __shared__ int s[VB / 64];
+  __shared__ int s_run;
+  if (threadIdx.x == 0) s_run = 0;
+  __syncthreads();
+  for (int b0 = 0; b0 < nb; b0 += VB) {
+    const int b = b0 + threadIdx.x;
+    const int v = b < nb ? cnt[b] : 0;
+    int incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if ((int)(threadIdx.x & 63) >= o) incl += t; }
+    if ((threadIdx.x & 63) == 63) s[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    int woff = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < VB / 64; ++w) { if (w < (int)(threadIdx.x >> 6)) woff += s[w]; tot += s[w]; }
+    const int run = s_run;
+    if (b < nb) { const int e = run + woff + incl - v; off[b] = e; if (cur) cur[b] = e; }
+    __syncthreads();
+    if (threadIdx.x == 0) s_run = run + tot;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0 && total) *total = s_run;
+}
+
+__global__ void __launch_bounds__(VB) vox_bscan(VoxCtx V) {
+  const int job = blockIdx.x;
+  const VoxJob J = V.jobs[job];
+  if (!vx_enabled(J)) return;
+  const int nb = V.geom[job * VX_GEOM + 8];
+  vx_block_scan(V.bcnt + J.boff0, V.boff + J.boff0, V.bcur + J.boff0, nb, nullptr);
+}
+
+__global__ void __launch_bounds__(VB) vox_bscatter(VoxCtx V) {
+  const int total = V.pt_items[V.njobs];
+  for (int item = blockIdx.x; item < total; item += gridDim.x) {
+    int chunk;
+    const int job = vx_item_job(V.pt_items, V.njobs, item, &chunk);
+    const VoxJob J = V.jobs[job];
+    const int* g = V.geom + job * VX_GEOM;
+    const int n = g[5], shift = g[7], nb = g[8];
+    int* bcur = V.bcur + J.boff0;
+    for (int i = chunk * VX_PT_ITEM + threadIdx.x; i < min(n, (chunk + 1) * VX_PT_ITEM); i += VB) {
+      const unsigned key = V.keys[J.off + i];
+      const int pos = atomicAdd(&bcur[min(key >> shift, (unsigned)(nb - 1))], 1);
+      V.pairs_a[J.off + pos] = ((u64)key << 32) | (unsigned)i;
+    }
+  }
+}
+
+__device__ __forceinline__ u64 vx_readlane64(u64 v, int lane) {
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, lane);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), lane);
+  return ((u64)hi << 32) | lo;
+}
+
+// sort every bucket ascending by (voxel id, position) and count its voxels: rank by counting.
+// Buckets of <= 64 elements: one wavefront each, in registers.  Larger buckets: the whole workgroup
+// cooperates through LDS (every element's rank is independent), or straight from memory beyond VX_BLOCK_LDS.
+#define VX_BLOCK_LDS 4096
+__global__ void __launch_bounds__(VB) vox_bsort(VoxCtx V) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __shared__ u64 s_buf[VX_BLOCK_LDS];
+  __shared__ int s_heads;
+  const int total = V.bk_items[V.njobs];
+  for (int item = blockIdx.x; item < total; item += gridDim.x) {
+    int chunk;
+    const int job = vx_item_job(V.bk_items, V.njobs, item, &chunk);
+    const VoxJob J = V.jobs[job];
+    const int nb = V.geom[job * VX_GEOM + 8];
+    const int* bcnt = V.bcnt + J.boff0;
+    const int* boff = V.boff + J.boff0;
+    int* bvox = V.bvox + J.boff0;
+    const int b_end = min(nb, (chunk + 1) * VX_BK_ITEM);
+    for (int b = chunk * VX_BK_ITEM + wave; b < b_end; b += VB / 64) {
+      const int m = bcnt[b];
+      if (m > 64) continue;
+      const u64* src = V.pairs_a + J.off + boff[b];
+      u64* dst = V.pairs_b + J.off + boff[b];
+      const u64 e = lane < m ? src[lane] : ~0ull;
+      int rank = 0;
+      bool head = lane < m;  // head of a voxel: no element with the same voxel id and a smaller position
+      for (int j = 0; j < m; ++j) {
+        const u64 o = vx_readlane64(e, j);
+        rank += o < e;   // keys are unique (position in the low word)
+        if ((o >> 32) == (e >> 32) && o < e) head = false;
+      }
+      if (lane < m) dst[rank] = e;
+      const int heads = (int)__popcll(__ballot(head));
+      if (lane == 0) bvox[b] = heads;
+    }
+    for (int b = chunk * VX_BK_ITEM; b < b_end; ++b) {
+      const int m = bcnt[b];
+      if (m <= 64) continue;
+      const u64* src = V.pairs_a + J.off + boff[b];
+      u64* dst = V.pairs_b + J.off + boff[b];
+      const bool in_lds = m <= VX_BLOCK_LDS;
+      __syncthreads();
+      if (threadIdx.x == 0) s_heads = 0;
+      if (in_lds) for (int t = threadIdx.x; t < m; t += VB) s_buf[t] = src[t];
+      __syncthreads();
+      int heads = 0;
+      for (int t = threadIdx.x; t < m; t += VB) {
+        const u64 e = in_lds ? s_buf[t] : src[t];
+        int rank = 0;
+        bool head = true;
+        if (in_lds) { for (int j = 0; j < m; ++j) { const u64 o = s_buf[j]; rank += o < e; if ((o >> 32) == (e >> 32) && o < e) head = false; } }
+        else { for (int j = 0; j < m; ++j) { const u64 o = src[j]; rank += o < e; if ((o >> 32) == (e >> 32) && o < e) head = false; } }
+        dst[rank] = e;
+        heads += head;
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) heads += __shfl_xor(heads, o, 64);
+      if (lane == 0 && heads) atomicAdd(&s_heads, heads);
+      __syncthreads();
+      if (threadIdx.x == 0) bvox[b] = s_heads;
+    }
+    __syncthreads();
+  }
+}
+
+__global__ void __launch_bounds__(VB) vox_vscan(VoxCtx V) {
+  const int job = blockIdx.x;
+  const VoxJob J = V.jobs[job];
+  if (!vx_enabled(J)) return;
+  const int nb = V.geom[job * VX_GEOM + 8];
+  vx_block_scan(V.bvox + J.boff0, V.voff + J.boff0, nullptr, nb, J.n_out);
+}
+
+// one wavefront per bucket: the points of the bucket are gathered in sorted order into LDS 64 at a time
+// (parallel loads), then lane 0 walks them: f32 sums in sorted (= original) order, one output per voxel.
+__global__ void __launch_bounds__(VB) vox_bcentroid(VoxCtx V) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __shared__ float4 s_pt[VB / 64][64];
+  __shared__ unsigned s_vid[VB / 64][64];
+  const int total = V.bk_items[V.njobs];
+  for (int item = blockIdx.x; item < total; item += gridDim.x) {
+    int chunk;
+    const int job = vx_item_job(V.bk_items, V.njobs, item, &chunk);
+    const VoxJob J = V.jobs[job];
+    const int nb = V.geom[job * VX_GEOM + 8];
+    int* bcnt = V.bcnt + J.boff0;
+    const int* boff = V.boff + J.boff0;
+    const int* voff = V.voff + J.boff0;
+    for (int b = chunk * VX_BK_ITEM + wave; b < min(nb, (chunk + 1) * VX_BK_ITEM); b += VB / 64) {
+      const int m = bcnt[b];
+      if (m == 0) continue;
+      const u64* srt = V.pairs_b + J.off + boff[b];
+      int rank = voff[b];
+      float sx = 0.f, sy = 0.f, sz = 0.f, si = 0.f;  // pcl::CentroidPoint: f32 accumulators (lane 0)
+      int c = 0;
+      unsigned cur = 0;
+      for (int t0 = 0; t0 < m; t0 += 64) {
+        const int t = t0 + lane;
+        if (t < m) { const u64 e = srt[t]; s_vid[wave][lane] = (unsigned)(e >> 32); s_pt[wave][lane] = J.in[(unsigned)e]; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (lane == 0) {
+          const int cnt = min(64, m - t0);
+          for (int k = 0; k < cnt; ++k) {
+            const unsigned vid = s_vid[wave][k];
+            if (c > 0 && vid != cur) {
+              const float fn = (float)c;
+              if (rank < J.cap) J.out[rank] = make_float4(sx / fn, sy / fn, sz / fn, si / fn);
+              ++rank; sx = sy = sz = si = 0.f; c = 0;
+            }
+            const float4 p = s_pt[wave][k];
+            sx += p.x; sy += p.y; sz += p.z; si += p.w;
+            ++c; cur = vid;
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+      if (lane == 0) {
+        const float fn = (float)c;
+        if (rank < J.cap) J.out[rank] = make_float4(sx / fn, sy / fn, sz / fn, si / fn);
+        bcnt[b] = 0;  // keep the histogram zeroed between rounds
+      }
+    }
   }
 }
 
@@ -183,54 +365,53 @@ __global__ void __launch_bounds__(VB) vox_centroid(VoxCtx V) {
 int vox_create(VoxCtx* V, const VoxJob* jobs, int njobs, std::string* err) {
   std::memset(V, 0, sizeof(*V));
   std::vector<VoxJob> h(jobs, jobs + njobs);
-  unsigned total = 0;
+  size_t total = 0;
   int max_cap = 0;
-  for (auto& j : h) { j.off = (int)total; total += (unsigned)j.cap; max_cap = j.cap > max_cap ? j.cap : max_cap; }
-  V->njobs = njobs; V->max_cap = max_cap; V->total = total; V->gx = 32;
-  V->blk_stride = (max_cap + VB - 1) / VB + 1;
+  size_t nbtot = 0;
+  for (auto& j : h) {
+    j.off = (int)total; total += (size_t)j.cap; max_cap = j.cap > max_cap ? j.cap : max_cap;
+    int nbc = 64;
+    while (nbc < 65536 && nbc * 2 < j.cap) nbc <<= 1;   // ~2 points per bucket at capacity, 64 .. 65536 buckets
+    j.nbcap = nbc; j.boff0 = (int)nbtot; nbtot += (size_t)nbc;
+  }
+  if (total > 0x7fffffffull) { *err = "vox_create: scratch exceeds 2^31 elements"; return -3; }
+  V->njobs = njobs; V->max_cap = max_cap; V->total = (unsigned)total;
+  V->gx = 2048 / (njobs > 0 ? njobs : 1);
+  if (V->gx < 4) V->gx = 4;
+  if (V->gx > 64) V->gx = 64;
   hipError_t e = hipSuccess;
-  auto A = [&](void** p, size_t bytes) { if (e == hipSuccess) e = hipMalloc(p, bytes ? bytes : 16); };
+  auto A = [&](void** p, size_t bytes) { if (e == hipSuccess) { e = hipMalloc(p, bytes ? bytes : 16); if (e == hipSuccess) e = hipMemset(*p, 0, bytes ? bytes : 16); } };
   A((void**)&V->jobs, sizeof(VoxJob) * njobs);
-  A((void**)&V->bbox, (size_t)njobs * 8 * 4); A((void**)&V->geom, (size_t)njobs * 8 * 4);
-  A((void**)&V->keys_a, (size_t)total * 4); A((void**)&V->keys_b, (size_t)total * 4);
-  A((void**)&V->vals_a, (size_t)total * 4); A((void**)&V->vals_b, (size_t)total * 4);
-  A((void**)&V->seg_begin, (size_t)njobs * 4); A((void**)&V->seg_end, (size_t)njobs * 4);
-  A((void**)&V->blk_cnt, (size_t)njobs * V->blk_stride * 4);
+  A((void**)&V->bbox, (size_t)njobs * 8 * 4); A((void**)&V->geom, (size_t)njobs * VX_GEOM * 4);
+  A((void**)&V->keys, total * 4); A((void**)&V->pairs_a, total * 8); A((void**)&V->pairs_b, total * 8);
+  A((void**)&V->bcnt, nbtot * 4); A((void**)&V->boff, nbtot * 4); A((void**)&V->bcur, nbtot * 4);
+  A((void**)&V->bvox, nbtot * 4); A((void**)&V->voff, nbtot * 4);
+  A((void**)&V->pt_items, (size_t)(njobs + 1) * 4); A((void**)&V->bk_items, (size_t)(njobs + 1) * 4);
   if (e == hipSuccess) e = hipMemcpy(V->jobs, h.data(), sizeof(VoxJob) * njobs, hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = hipMemset(V->geom, 0, (size_t)njobs * 8 * 4);
-  size_t bytes = 0;
-  if (e == hipSuccess)
-    e = rocprim::segmented_radix_sort_pairs(nullptr, bytes, V->keys_a, V->keys_b, V->vals_a, V->vals_b, total, (unsigned)njobs,
-                                            V->seg_begin, V->seg_end, 0, 32, (hipStream_t)0);
-  V->sort_tmp_bytes = bytes;
-  A(&V->sort_tmp, bytes);
   if (e != hipSuccess) { *err = std::string("vox_create: ") + hipGetErrorString(e); return -2; }
   return 0;
 }
 
 void vox_destroy(VoxCtx* V) {
-  void* ps[] = {V->jobs, V->bbox, V->geom, V->keys_a, V->keys_b, V->vals_a, V->vals_b, V->seg_begin, V->seg_end, V->blk_cnt, V->sort_tmp};
+  void* ps[] = {V->jobs, V->bbox, V->geom, V->keys, V->pairs_a, V->pairs_b, V->bcnt, V->boff, V->bcur, V->bvox, V->voff, V->pt_items, V->bk_items};
   for (void* p : ps) if (p) (void)hipFree(p);
   std::memset(V, 0, sizeof(*V));
 }
 
 int vox_run(const VoxCtx& V, hipStream_t st, std::string* err) {
+  (void)err;
   if (V.njobs == 0) return 0;
   { ProfScope ms_("memset_bbox", st); (void)hipMemsetAsync(V.bbox, 0xFF, (size_t)V.njobs * 8 * 4, st); }
-  int nb = (V.max_cap + VB - 1) / VB;
-  if (nb > V.gx) nb = V.gx;  // grid-stride inside the kernels: bounded block count per job
-  ALEGO_LAUNCH(vox_bbox, dim3(nb, V.njobs), dim3(VB), 0, st, V);
-  ALEGO_LAUNCH(vox_keys, dim3(nb, V.njobs), dim3(VB), 0, st, V);
-  size_t bytes = V.sort_tmp_bytes;
-  hipError_t e;
-  {
-    ProfScope sort_scope_("rocprim_segmented_radix_sort", st);
-    e = rocprim::segmented_radix_sort_pairs(V.sort_tmp, bytes, V.keys_a, V.keys_b, V.vals_a, V.vals_b, V.total, (unsigned)V.njobs,
-                                            V.seg_begin, V.seg_end, 0, 32, st);
-  }
-  if (e != hipSuccess) { *err = std::string("segmented_radix_sort_pairs: ") + hipGetErrorString(e); return -2; }
-  ALEGO_LAUNCH(vox_heads, dim3(nb, V.njobs), dim3(VB), 0, st, V);
-  ALEGO_LAUNCH(vox_scan, dim3(V.njobs), dim3(VB), 0, st, V);
-  ALEGO_LAUNCH(vox_centroid, dim3(nb, V.njobs), dim3(VB), 0, st, V);
+  const dim3 pool(VX_POOL), blk(VB), jobs1((V.njobs + VB - 1) / VB), perjob(V.njobs);
+  ALEGO_LAUNCH(vox_plan, dim3(1), blk, 0, st, V, 0);
+  ALEGO_LAUNCH(vox_bbox, pool, blk, 0, st, V);
+  ALEGO_LAUNCH(vox_geom, jobs1, blk, 0, st, V);
+  ALEGO_LAUNCH(vox_keys, pool, blk, 0, st, V);
+  ALEGO_LAUNCH(vox_bscan, perjob, blk, 0, st, V);
+  ALEGO_LAUNCH(vox_plan, dim3(1), blk, 0, st, V, 1);
+  ALEGO_LAUNCH(vox_bscatter, pool, blk, 0, st, V);
+  ALEGO_LAUNCH(vox_bsort, pool, blk, 0, st, V);
+  ALEGO_LAUNCH(vox_vscan, perjob, blk, 0, st, V);
+  ALEGO_LAUNCH(vox_bcentroid, pool, blk, 0, st, V);
   return 0;
 }

@@ -3,10 +3,10 @@
 // A "job" is one VoxelGrid::filter call (one cloud, one leaf size).  All jobs of a round
 // are processed by the same launches (blockIdx.y = job):
 //   vox_bbox      getMinMax3D (ordered-int atomics)
-//   vox_keys      voxel index per point (f32 floor arithmetic exactly as PCL), value = position
-//   rocprim::segmented_radix_sort_pairs (stable: equal voxel ids keep the input order)
-//   vox_heads / vox_scan / vox_centroid   one output point per voxel in ascending voxel id,
-//                 f32 sums accumulated in sorted (= original) order, divided by the count
+//   vox_keys      voxel index per point (f32 floor arithmetic exactly as PCL) + bucket histogram
+//   vox_bscan / vox_bscatter / vox_bsort   two-level bucket sort of (voxel id, position)
+//   vox_vscan / vox_bcentroid   one output point per voxel in ascending voxel id, f32 sums accumulated
+//                 in sorted (= original) order, divided by the count
 #ifndef ALEGO_VOXEL_H_
 #define ALEGO_VOXEL_H_
 #include <hip/hip_runtime.h>
@@ -21,21 +21,21 @@ struct VoxJob {
   const int* enable;    // device flag (nullptr = always); a disabled job keeps its previous output
   float leaf;
   int cap;              // capacity of in / out (points)
-  int off;              // offset of this job's region in the key / value scratch arrays
+  int off;              // offset of this job's region in the key / pair scratch arrays
+  int nbcap, boff0;     // bucket capacity (power of two) and offset of this job's region in the bucket arrays
 };
+
+#define VX_GEOM 16   // ints of per-job geometry: 0-2 min_b, 3 mul1, 4 mul2, 5 n, 6 passthrough, 7 bucket shift, 8 bucket count
 
 struct VoxCtx {
   VoxJob* jobs;         // device array [njobs]
   int njobs, max_cap, gx;  // gx = blocks per job (kernels grid-stride over chunks)
   unsigned* bbox;       // [job][8] ordered-int encoded min xyz (0..2) and ~max xyz (4..6)
-  int* geom;            // [job][8] min_b xyz, mul1, mul2, n, passthrough
-  unsigned *keys_a, *keys_b;
-  int *vals_a, *vals_b;
-  int *seg_begin, *seg_end;  // [njobs]
-  int* blk_cnt;         // [job][blk_stride]
-  int blk_stride;
-  void* sort_tmp;
-  size_t sort_tmp_bytes;
+  int* geom;            // [job][VX_GEOM]
+  unsigned* keys;       // voxel id per input point
+  unsigned long long *pairs_a, *pairs_b;  // (voxel id << 32 | position): bucketed, then sorted
+  int *bcnt, *boff, *bcur, *bvox, *voff;  // per-job regions: bucket histogram / offsets / cursors / voxel counts / output ranks
+  int *pt_items, *bk_items;  // [njobs+1] exclusive scans of the per-job work-item counts (points / buckets)
   unsigned total;       // total scratch elements
 };
 

@@ -1,0 +1,15 @@
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from alego_loader import load_package; load_package()
+from alego_amd import binding, synth
+p = synth.default_params(16, 1800)
+h = binding.Handle(p, n_slots=1, ring_len=48)
+for k in range(48):
+    h.batch_load(0, k, synth.scan(p, k))
+st = 7 | binding.REPLAY_PINGPONG
+h.batch_run(0, 561, st)
+for i in range(4):
+    h.batch_run(561 + i, 1, st)
+    li = h.debug_get("lm_info"); ld = h.debug_get("lm_state")
+    print("run", li[2], "sum", hex(li[8]), hex(li[9]), "cycles pose/eval/reduce/propose/consume", ld[43:48].astype(np.int64))
