@@ -41,7 +41,9 @@ __device__ __forceinline__ bool vx_enabled(const VoxJob& J) { return J.enable ==
 
 #define VX_POOL 1024           // workgroups of the point / bucket parallel kernels
 #define VX_PT_ITEM 1024        // points per work item
-#define VX_BK_ITEM 16          // buckets per work item
+#define VX_BK_ITEM 64          // buckets per work item (= one wavefront; bsort / bcentroid run 64-thread workgroups)
+#define VX_BPOOL 4096          // single-wave workgroups of the bucket kernels
+#define VX_TINY 8              // buckets up to this size are handled by a single thread
 
 // one workgroup: exclusive scan over jobs of their item counts.  which 0: ceil(n/VX_PT_ITEM) from the job
 // inputs; which 1: ceil(nb/VX_BK_ITEM) from the geometry written by vox_keys.
@@ -141,9 +143,9 @@ __global__ void __launch_bounds__(VB) vox_geom(VoxCtx V) {
     T = pass ? (unsigned)n : (unsigned)divb[0] * (unsigned)divb[1] * (unsigned)divb[2];
     if (T == 0) T = 1;
   }
-  // bucket = key >> shift, about 2 points per bucket (less skew), at most J.nbcap buckets
+  // bucket = key >> shift, about 1 point per bucket (few multi-voxel buckets), at most J.nbcap buckets
   int target = 64;
-  while (target < J.nbcap && target * 2 < n) target <<= 1;
+  while (target < J.nbcap && target < n) target <<= 1;
   int shift = 0;
   while (((T - 1) >> shift) >= (unsigned)target) ++shift;
   g[0] = minb[0]; g[1] = minb[1]; g[2] = minb[2]; g[3] = mul1; g[4] = mul2; g[5] = n; g[6] = pass; g[7] = shift;
@@ -234,14 +236,15 @@ __device__ __forceinline__ u64 vx_readlane64(u64 v, int lane) {
   return ((u64)hi << 32) | lo;
 }
 
-// sort every bucket ascending by (voxel id, position) and count its voxels: rank by counting.
-// Buckets of <= 64 elements: one wavefront each, in registers.  Larger buckets: the whole workgroup
-// cooperates through LDS (every element's rank is independent), or straight from memory beyond VX_BLOCK_LDS.
-#define VX_BLOCK_LDS 4096
-__global__ void __launch_bounds__(VB) vox_bsort(VoxCtx V) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  __shared__ u64 s_buf[VX_BLOCK_LDS];
-  __shared__ int s_heads;
+// sort every bucket ascending by (voxel id, position) and count its voxels: rank by counting
+// (keys are unique: the position is in the low word).  One wavefront per item of 64 buckets:
+//   m <= VX_TINY : one lane per bucket (the 64 buckets of the item in parallel)
+//   m <= 64      : the wavefront takes the bucket, elements in registers, ranks via v_readlane
+//   larger       : the wavefront through LDS (straight from memory beyond VX_WAVE_LDS elements)
+#define VX_WAVE_LDS 4096
+__global__ void __launch_bounds__(64) vox_bsort(VoxCtx V) {
+  const int lane = threadIdx.x;
+  __shared__ u64 s_buf[VX_WAVE_LDS];
   const int total = V.bk_items[V.njobs];
   for (int item = blockIdx.x; item < total; item += gridDim.x) {
     int chunk;
@@ -251,51 +254,71 @@ __global__ void __launch_bounds__(VB) vox_bsort(VoxCtx V) {
     const int* bcnt = V.bcnt + J.boff0;
     const int* boff = V.boff + J.boff0;
     int* bvox = V.bvox + J.boff0;
-    const int b_end = min(nb, (chunk + 1) * VX_BK_ITEM);
-    for (int b = chunk * VX_BK_ITEM + wave; b < b_end; b += VB / 64) {
-      const int m = bcnt[b];
-      if (m > 64) continue;
+    // buckets are spatially ordered and dense regions cluster: lane l of item c takes bucket l*nitems + c
+    const int nitems = (nb + VX_BK_ITEM - 1) / VX_BK_ITEM;
+    const int b = lane * nitems + chunk;
+    const int m = b < nb ? bcnt[b] : 0;
+    if (m > 0 && m <= VX_TINY) {
       const u64* src = V.pairs_a + J.off + boff[b];
       u64* dst = V.pairs_b + J.off + boff[b];
-      const u64 e = lane < m ? src[lane] : ~0ull;
-      int rank = 0;
-      bool head = lane < m;  // head of a voxel: no element with the same voxel id and a smaller position
-      for (int j = 0; j < m; ++j) {
-        const u64 o = vx_readlane64(e, j);
-        rank += o < e;   // keys are unique (position in the low word)
-        if ((o >> 32) == (e >> 32) && o < e) head = false;
-      }
-      if (lane < m) dst[rank] = e;
-      const int heads = (int)__popcll(__ballot(head));
-      if (lane == 0) bvox[b] = heads;
-    }
-    for (int b = chunk * VX_BK_ITEM; b < b_end; ++b) {
-      const int m = bcnt[b];
-      if (m <= 64) continue;
-      const u64* src = V.pairs_a + J.off + boff[b];
-      u64* dst = V.pairs_b + J.off + boff[b];
-      const bool in_lds = m <= VX_BLOCK_LDS;
-      __syncthreads();
-      if (threadIdx.x == 0) s_heads = 0;
-      if (in_lds) for (int t = threadIdx.x; t < m; t += VB) s_buf[t] = src[t];
-      __syncthreads();
-      int heads = 0;
-      for (int t = threadIdx.x; t < m; t += VB) {
-        const u64 e = in_lds ? s_buf[t] : src[t];
-        int rank = 0;
-        bool head = true;
-        if (in_lds) { for (int j = 0; j < m; ++j) { const u64 o = s_buf[j]; rank += o < e; if ((o >> 32) == (e >> 32) && o < e) head = false; } }
-        else { for (int j = 0; j < m; ++j) { const u64 o = src[j]; rank += o < e; if ((o >> 32) == (e >> 32) && o < e) head = false; } }
-        dst[rank] = e;
-        heads += head;
-      }
+      u64 e[VX_TINY];
 #pragma unroll
-      for (int o = 32; o > 0; o >>= 1) heads += __shfl_xor(heads, o, 64);
-      if (lane == 0 && heads) atomicAdd(&s_heads, heads);
-      __syncthreads();
-      if (threadIdx.x == 0) bvox[b] = s_heads;
+      for (int i = 0; i < VX_TINY; ++i) e[i] = i < m ? src[i] : ~0ull;  // all loads in flight together
+      int heads = 0;
+#pragma unroll
+      for (int i = 0; i < VX_TINY; ++i) {
+        if (i < m) {
+          int rank = 0;
+          bool head = true;
+#pragma unroll
+          for (int j = 0; j < VX_TINY; ++j) { rank += e[j] < e[i]; if ((e[j] >> 32) == (e[i] >> 32) && e[j] < e[i]) head = false; }
+          dst[rank] = e[i];
+          heads += head;
+        }
+      }
+      bvox[b] = heads;
+    } else if (m == 0 && b < nb) {
+      bvox[b] = 0;
     }
-    __syncthreads();
+    u64 bigger = __ballot(m > VX_TINY);
+    while (bigger) {
+      const int src_lane = __ffsll((long long)bigger) - 1;
+      bigger &= bigger - 1;
+      const int bb = __shfl(b, src_lane, 64), mm = __shfl(m, src_lane, 64);
+      const u64* src = V.pairs_a + J.off + boff[bb];
+      u64* dst = V.pairs_b + J.off + boff[bb];
+      int heads;
+      if (mm <= 64) {
+        const u64 e = lane < mm ? src[lane] : ~0ull;
+        int rank = 0;
+        bool head = lane < mm;  // head of a voxel: no element with the same voxel id and a smaller position
+        for (int j = 0; j < mm; ++j) {
+          const u64 o = vx_readlane64(e, j);
+          rank += o < e;
+          if ((o >> 32) == (e >> 32) && o < e) head = false;
+        }
+        if (lane < mm) dst[rank] = e;
+        heads = (int)__popcll(__ballot(head));
+      } else {
+        const bool in_lds = mm <= VX_WAVE_LDS;
+        __syncthreads();
+        if (in_lds) for (int t = lane; t < mm; t += 64) s_buf[t] = src[t];
+        __syncthreads();
+        heads = 0;
+        for (int t = lane; t < mm; t += 64) {
+          const u64 e = in_lds ? s_buf[t] : src[t];
+          int rank = 0;
+          bool head = true;
+          if (in_lds) { for (int j = 0; j < mm; ++j) { const u64 o = s_buf[j]; rank += o < e; if ((o >> 32) == (e >> 32) && o < e) head = false; } }
+          else { for (int j = 0; j < mm; ++j) { const u64 o = src[j]; rank += o < e; if ((o >> 32) == (e >> 32) && o < e) head = false; } }
+          dst[rank] = e;
+          heads += head;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) heads += __shfl_xor(heads, o, 64);
+      }
+      if (lane == 0) bvox[bb] = heads;
+    }
   }
 }
 
@@ -307,12 +330,13 @@ __global__ void __launch_bounds__(VB) vox_vscan(VoxCtx V) {
   vx_block_scan(V.bvox + J.boff0, V.voff + J.boff0, nullptr, nb, J.n_out);
 }
 
-// one wavefront per bucket: the points of the bucket are gathered in sorted order into LDS 64 at a time
-// (parallel loads), then lane 0 walks them: f32 sums in sorted (= original) order, one output per voxel.
-__global__ void __launch_bounds__(VB) vox_bcentroid(VoxCtx V) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  __shared__ float4 s_pt[VB / 64][64];
-  __shared__ unsigned s_vid[VB / 64][64];
+// Centroids: f32 sums in sorted (= original) order, one output per voxel in ascending voxel id
+// (pcl::CentroidPoint).  Tiny buckets: one lane walks its bucket.  Larger buckets: the wavefront gathers the
+// points 64 at a time (parallel loads, one point per lane) and accumulates them in lock-step through
+// v_readlane broadcasts — the additions stay strictly sequential, only the loads are parallel.
+__device__ __forceinline__ float vx_bcast(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+__global__ void __launch_bounds__(64) vox_bcentroid(VoxCtx V) {
+  const int lane = threadIdx.x;
   const int total = V.bk_items[V.njobs];
   for (int item = blockIdx.x; item < total; item += gridDim.x) {
     int chunk;
@@ -322,40 +346,70 @@ __global__ void __launch_bounds__(VB) vox_bcentroid(VoxCtx V) {
     int* bcnt = V.bcnt + J.boff0;
     const int* boff = V.boff + J.boff0;
     const int* voff = V.voff + J.boff0;
-    for (int b = chunk * VX_BK_ITEM + wave; b < min(nb, (chunk + 1) * VX_BK_ITEM); b += VB / 64) {
-      const int m = bcnt[b];
-      if (m == 0) continue;
+    // buckets are spatially ordered and dense regions cluster: lane l of item c takes bucket l*nitems + c
+    const int nitems = (nb + VX_BK_ITEM - 1) / VX_BK_ITEM;
+    const int b = lane * nitems + chunk;
+    const int m = b < nb ? bcnt[b] : 0;
+    if (m > 0 && m <= VX_TINY) {
       const u64* srt = V.pairs_b + J.off + boff[b];
       int rank = voff[b];
-      float sx = 0.f, sy = 0.f, sz = 0.f, si = 0.f;  // pcl::CentroidPoint: f32 accumulators (lane 0)
+      u64 e[VX_TINY];
+      float4 pt[VX_TINY];
+#pragma unroll
+      for (int k = 0; k < VX_TINY; ++k) e[k] = k < m ? srt[k] : 0ull;
+#pragma unroll
+      for (int k = 0; k < VX_TINY; ++k) pt[k] = k < m ? J.in[(unsigned)e[k]] : make_float4(0.f, 0.f, 0.f, 0.f);  // gathers in flight together
+      float sx = 0.f, sy = 0.f, sz = 0.f, si = 0.f;
       int c = 0;
       unsigned cur = 0;
-      for (int t0 = 0; t0 < m; t0 += 64) {
-        const int t = t0 + lane;
-        if (t < m) { const u64 e = srt[t]; s_vid[wave][lane] = (unsigned)(e >> 32); s_pt[wave][lane] = J.in[(unsigned)e]; }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (lane == 0) {
-          const int cnt = min(64, m - t0);
-          for (int k = 0; k < cnt; ++k) {
-            const unsigned vid = s_vid[wave][k];
-            if (c > 0 && vid != cur) {
-              const float fn = (float)c;
-              if (rank < J.cap) J.out[rank] = make_float4(sx / fn, sy / fn, sz / fn, si / fn);
-              ++rank; sx = sy = sz = si = 0.f; c = 0;
-            }
-            const float4 p = s_pt[wave][k];
-            sx += p.x; sy += p.y; sz += p.z; si += p.w;
-            ++c; cur = vid;
+#pragma unroll
+      for (int k = 0; k < VX_TINY; ++k) {
+        if (k < m) {
+          const unsigned vid = (unsigned)(e[k] >> 32);
+          if (c > 0 && vid != cur) {
+            const float fn = (float)c;
+            if (rank < J.cap) J.out[rank] = make_float4(sx / fn, sy / fn, sz / fn, si / fn);
+            ++rank; sx = sy = sz = si = 0.f; c = 0;
           }
+          sx += pt[k].x; sy += pt[k].y; sz += pt[k].z; si += pt[k].w;
+          ++c; cur = vid;
         }
-        __builtin_amdgcn_wave_barrier();
       }
+      const float fn = (float)c;
+      if (rank < J.cap) J.out[rank] = make_float4(sx / fn, sy / fn, sz / fn, si / fn);
+      bcnt[b] = 0;  // keep the histogram zeroed between rounds
+    }
+    u64 bigger = __ballot(m > VX_TINY);
+    while (bigger) {
+      const int src_lane = __ffsll((long long)bigger) - 1;
+      bigger &= bigger - 1;
+      const int bb = __shfl(b, src_lane, 64), mm = __shfl(m, src_lane, 64);
+      const u64* srt = V.pairs_b + J.off + boff[bb];
+      int rank = voff[bb];
+      float sx = 0.f, sy = 0.f, sz = 0.f, si = 0.f;  // wave-uniform accumulators
+      int c = 0;
+      unsigned cur = 0;
+      for (int t0 = 0; t0 < mm; t0 += 64) {
+        const int t = t0 + lane;
+        float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+        unsigned myvid = 0;
+        if (t < mm) { const u64 e = srt[t]; myvid = (unsigned)(e >> 32); p = J.in[(unsigned)e]; }
+        const int cnt = min(64, mm - t0);
+        for (int k = 0; k < cnt; ++k) {
+          const unsigned vid = (unsigned)__builtin_amdgcn_readlane((int)myvid, k);
+          if (c > 0 && vid != cur) {
+            const float fn = (float)c;
+            if (lane == 0 && rank < J.cap) J.out[rank] = make_float4(sx / fn, sy / fn, sz / fn, si / fn);
+            ++rank; sx = sy = sz = si = 0.f; c = 0;
+          }
+          sx += vx_bcast(p.x, k); sy += vx_bcast(p.y, k); sz += vx_bcast(p.z, k); si += vx_bcast(p.w, k);
+          ++c; cur = vid;
+        }
+      }
+      const float fn = (float)c;
       if (lane == 0) {
-        const float fn = (float)c;
         if (rank < J.cap) J.out[rank] = make_float4(sx / fn, sy / fn, sz / fn, si / fn);
-        bcnt[b] = 0;  // keep the histogram zeroed between rounds
+        bcnt[bb] = 0;
       }
     }
   }
@@ -371,7 +425,7 @@ int vox_create(VoxCtx* V, const VoxJob* jobs, int njobs, std::string* err) {
   for (auto& j : h) {
     j.off = (int)total; total += (size_t)j.cap; max_cap = j.cap > max_cap ? j.cap : max_cap;
     int nbc = 64;
-    while (nbc < 65536 && nbc * 2 < j.cap) nbc <<= 1;   // ~2 points per bucket at capacity, 64 .. 65536 buckets
+    while (nbc < 65536 && nbc < j.cap) nbc <<= 1;   // ~1 point per bucket at capacity, 64 .. 65536 buckets
     j.nbcap = nbc; j.boff0 = (int)nbtot; nbtot += (size_t)nbc;
   }
   if (total > 0x7fffffffull) { *err = "vox_create: scratch exceeds 2^31 elements"; return -3; }
@@ -410,8 +464,8 @@ int vox_run(const VoxCtx& V, hipStream_t st, std::string* err) {
   ALEGO_LAUNCH(vox_bscan, perjob, blk, 0, st, V);
   ALEGO_LAUNCH(vox_plan, dim3(1), blk, 0, st, V, 1);
   ALEGO_LAUNCH(vox_bscatter, pool, blk, 0, st, V);
-  ALEGO_LAUNCH(vox_bsort, pool, blk, 0, st, V);
+  ALEGO_LAUNCH(vox_bsort, dim3(VX_BPOOL), dim3(64), 0, st, V);
   ALEGO_LAUNCH(vox_vscan, perjob, blk, 0, st, V);
-  ALEGO_LAUNCH(vox_bcentroid, pool, blk, 0, st, V);
+  ALEGO_LAUNCH(vox_bcentroid, dim3(VX_BPOOL), dim3(64), 0, st, V);
   return 0;
 }

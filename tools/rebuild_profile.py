@@ -18,5 +18,5 @@ for i in range(30):
     rep = h.profile_report(); h.profile_enable(False)
     li = h.debug_get("lm_info")
     if li[3] or dt > 2e-3:
-        top = sorted(rep.items(), key=lambda kv: -kv[1][0])[:8]
-        print(f"step {step} {dt*1e6:.0f}us REBUILD={li[3]} Kraw={li[12]},{li[13]} Kds={li[14]},{li[15]}:", [(k, round(v[0]*1e3)) for k, v in top])
+        top = [kv for kv in sorted(rep.items(), key=lambda kv: -kv[1][0]) if kv[0].startswith(('vox', 'lm_', 'memset'))]
+        print(f"step {step} {dt*1e6:.0f}us REBUILD={li[3]} Kraw={li[12]},{li[13]} Kds={li[14]},{li[15]}:", [(k, round(v[0]*1e3), v[1]) for k, v in top])
