@@ -21,6 +21,7 @@ void launch_ip(const DevCtx& d, int ring_pos, bool want_labels, hipStream_t st);
 void launch_fe(const DevCtx& d, hipStream_t st);
 void launch_lo(const DevCtx& d, hipStream_t st);
 void launch_atan2f_probe(const float* y, const float* x, float* out, int n, int mode, hipStream_t st);
+int ip_configure(const DevCtx& d);
 
 struct alego_handle {
   alego_params P;
@@ -148,6 +149,7 @@ int alego_create(const alego_params* params, int device, int n_slots, int ring_l
   hipMemcpy(d.scal, sc0.data(), sc0.size() * sizeof(int), hipMemcpyHostToDevice);
   hipMemcpy(d.lo_state, st.data(), st.size() * sizeof(double), hipMemcpyHostToDevice);
   hipMemcpy(d.poses, po.data(), po.size() * sizeof(double), hipMemcpyHostToDevice);
+  if (ip_configure(d) != 0) { h->err = "hipFuncSetAttribute failed"; std::fprintf(stderr, "alego_create: %s\n", h->err.c_str()); alego_destroy(h); return ALEGO_ERR_HIP; }
   h->lm = lm_host_create(h->P, d, n_slots, h->stream, &h->err);
   if (!h->lm) { std::fprintf(stderr, "alego_create: %s\n", h->err.c_str()); alego_destroy(h); return ALEGO_ERR_HIP; }
   *out = h;

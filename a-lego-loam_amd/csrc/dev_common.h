@@ -201,4 +201,20 @@ DEV_INLINE double wave_sum_f64(double v) {  // fixed butterfly order -> determin
 }
 DEV_INLINE int lane_id() { return threadIdx.x & 63; }
 
+// Wave-wide max / min of a u32 returned as a uniform value: four DPP steps inside each 16-lane row
+// (quad_perm xor1, xor2, row_half_mirror, row_mirror — valid because max/min are idempotent), then the four
+// row results through v_readlane.  ~12 instructions instead of 6 dependent ds_bpermute round trips.
+DEV_INLINE uint32_t wave_max_u32(uint32_t v) {
+  int x = (int)v, t;
+  t = __builtin_amdgcn_update_dpp(x, x, 0xB1, 0xF, 0xF, false); x = (uint32_t)t > (uint32_t)x ? t : x;   // quad_perm [1,0,3,2]
+  t = __builtin_amdgcn_update_dpp(x, x, 0x4E, 0xF, 0xF, false); x = (uint32_t)t > (uint32_t)x ? t : x;   // quad_perm [2,3,0,1]
+  t = __builtin_amdgcn_update_dpp(x, x, 0x141, 0xF, 0xF, false); x = (uint32_t)t > (uint32_t)x ? t : x;  // row_half_mirror
+  t = __builtin_amdgcn_update_dpp(x, x, 0x140, 0xF, 0xF, false); x = (uint32_t)t > (uint32_t)x ? t : x;  // row_mirror
+  const uint32_t a = (uint32_t)__builtin_amdgcn_readlane(x, 0), b = (uint32_t)__builtin_amdgcn_readlane(x, 16);
+  const uint32_t c = (uint32_t)__builtin_amdgcn_readlane(x, 32), e = (uint32_t)__builtin_amdgcn_readlane(x, 48);
+  const uint32_t ab = a > b ? a : b, ce = c > e ? c : e;
+  return ab > ce ? ab : ce;
+}
+DEV_INLINE uint32_t wave_min_u32(uint32_t v) { return ~wave_max_u32(~v); }
+
 #endif

@@ -15,6 +15,7 @@
 #define FE_BLOCK 256
 #define FE_HALO 6
 #define FE_MAXH 4096  // largest horizon_scan supported by the per-ring LDS staging
+#define FE_T 12       // sector elements per lane kept in registers: sectors up to 768 points (4096 / 6 = 683)
 
 __global__ void __launch_bounds__(FE_BLOCK) fe_curv(DevCtx d) {
   const int slot = blockIdx.y + d.slot0;
@@ -79,7 +80,9 @@ __global__ void __launch_bounds__(FE_BLOCK) fe_curv(DevCtx d) {
   d.picked0[base + i] = pk;
 }
 
-// one wavefront per (ring, slot)
+// one wavefront per (ring, slot).  Dynamic LDS: 8 bytes per ring point (key u32, column u16, flags u8, label i8),
+// so a 16x1800 sensor keeps 10+ rings resident per CU.
+// flag bits: 0 picked, 1 ground, 2 curvature > edge_thres, 3 curvature < surf_thres
 __global__ void __launch_bounds__(64) fe_pick(DevCtx d) {
   const int slot = blockIdx.y + d.slot0, ring = blockIdx.x, lane = threadIdx.x;
   const size_t base = (size_t)slot * d.N;
@@ -87,13 +90,19 @@ __global__ void __launch_bounds__(64) fe_pick(DevCtx d) {
   const int S = d.ring_start[slot * d.NS + ring], E = d.ring_end[slot * d.NS + ring];
   const int rf = S - 5, rl = E + 5;  // first / last point of this ring in the segmented cloud
   const int cnt = rl - rf + 1;
-  __shared__ uint32_t s_key[FE_MAXH];  // |cd| bit pattern: curvature order == unsigned order
-  __shared__ uint8_t s_flag[FE_MAXH];  // bit0 picked, bit1 ground
-  __shared__ int8_t s_label[FE_MAXH];
-  const int* colv = d.seg_col + base;
+  extern __shared__ __attribute__((aligned(16))) unsigned char fe_smem[];
+  uint32_t* s_key = reinterpret_cast<uint32_t*>(fe_smem);                 // |cd| bit pattern: curvature order == unsigned order
+  uint16_t* s_col = reinterpret_cast<uint16_t*>(fe_smem + 4 * (size_t)d.H);
+  uint8_t* s_flag = fe_smem + 6 * (size_t)d.H;
+  int8_t* s_label = reinterpret_cast<int8_t*>(fe_smem + 7 * (size_t)d.H);
   for (int k = lane; k < cnt; k += 64) {
-    s_key[k] = (uint32_t)d_f2i(fabsf(d.cd[base + rf + k]));
-    s_flag[k] = (uint8_t)((d.picked0[base + rf + k] & 1) | (d.seg_ground[base + rf + k] ? 2 : 0));
+    const float a = fabsf(d.cd[base + rf + k]);
+    const double ad = (double)a;
+    const double curv = ad * ad;  // (double)diff_range * diff_range, exact (:125)
+    s_key[k] = (uint32_t)d_f2i(a);
+    s_col[k] = (uint16_t)d.seg_col[base + rf + k];
+    s_flag[k] = (uint8_t)((d.picked0[base + rf + k] & 1) | (d.seg_ground[base + rf + k] ? 2 : 0) |
+                          (curv > P.edge_thres ? 4 : 0) | (curv < P.surf_thres ? 8 : 0));
     s_label[k] = 0;
   }
   __syncthreads();
@@ -106,94 +115,95 @@ __global__ void __launch_bounds__(64) fe_pick(DevCtx d) {
     if (P.sector_formula == 0) { sp = (S * (NSEC - j) + E * j) / NSEC; ep = (S * (NSEC - 1 - j) + E * (j + 1)) / NSEC - 1; }
     else { const int diff = E - S; sp = S + j * diff / NSEC; ep = S + (j + 1) * diff / NSEC - 1; }
     if (sp >= ep) continue;
-    // ---- sharp / less-sharp: descending curvature (:189-236) ----
+    const int lsp = sp - rf, lep = ep - rf;
+    // Lane l owns the sector elements lsp + l + 64 t; their keys and candidate bits live in registers for the
+    // whole sector, so an iteration of the greedy pick touches LDS only for the +-SR column test.
+    uint32_t key[FE_T];
+    uint32_t sharp_m = 0, flat_m = 0;
+#pragma unroll
+    for (int t = 0; t < FE_T; ++t) {
+      const int c = lsp + lane + 64 * t;
+      key[t] = 0;
+      if (c <= lep) {
+        const uint8_t f = s_flag[c];
+        key[t] = s_key[c];
+        if ((f & 7) == 4) sharp_m |= 1u << t;    // not picked, not ground, curvature > edge_thres
+        if ((f & 11) == 10) flat_m |= 1u << t;   // not picked, ground, curvature < surf_thres
+      }
+    }
+    // marks local index c and its +-SR neighbours picked (:211-234: stop at the first column jump), in LDS for
+    // the later sectors and in the owners' candidate masks for this one
+    auto mark = [&](int c, bool spread) {
+      int nf = 0, nbk = 0;
+      if (spread) {
+        bool bad = false;
+        if (lane < SR) { const int cdf = (int)s_col[c + lane + 1] - (int)s_col[c + lane]; bad = (cdf < 0 ? -cdf : cdf) > P.suppress_col_diff; }
+        else if (lane >= 32 && lane < 32 + SR) { const int l = lane - 32; const int cdf = (int)s_col[c - l - 1] - (int)s_col[c - l]; bad = (cdf < 0 ? -cdf : cdf) > P.suppress_col_diff; }
+        const unsigned long long mb = __ballot(bad);
+        const unsigned lo = (unsigned)(mb & 0xffffffffull), hi = (unsigned)(mb >> 32);
+        nf = lo ? min(SR, __ffs((int)lo) - 1) : SR;
+        nbk = hi ? min(SR, __ffs((int)hi) - 1) : SR;
+      }
+      const int first = c - nbk, last = c + nf;
+      if (lane <= last - first) s_flag[first + lane] |= 1;
+      // the (single) owned element inside [first, last]
+      const int off = ((lane - (first - lsp)) % 64 + 64) % 64;
+      const int ct = first + off;
+      if (ct <= last && ct >= lsp && ct <= lep) { const uint32_t bit = 1u << ((ct - lsp - lane) / 64); sharp_m &= ~bit; flat_m &= ~bit; }
+    };
+    // ---- sharp / less-sharp: descending curvature, ties -> larger index (:189-236) ----
     int picked_num = 0;
     while (true) {
-      unsigned long long best = 0ull;
-      for (int k = sp + lane; k <= ep; k += 64) {
-        const int loc = k - rf;
-        if ((s_flag[loc] & 3) == 0) {
-          const uint32_t kb = s_key[loc];
-          const double ad = (double)d_i2f((int32_t)kb);
-          if (ad * ad > P.edge_thres) {
-            const unsigned long long c = ((unsigned long long)kb << 32) | (uint32_t)k;
-            best = c > best ? c : best;
-          }
-        }
-      }
-      best = wave_max_u64(best);
-      if (best == 0ull) break;
-      const int idx = (int)(uint32_t)best;
+      uint32_t bk = 0;
+      int bt = 0;
+#pragma unroll
+      for (int t = 0; t < FE_T; ++t) if (((sharp_m >> t) & 1) && key[t] >= bk) { bk = key[t]; bt = t; }
+      const uint32_t kmax = wave_max_u32(bk);
+      if (kmax == 0) break;
+      const uint32_t cand = (sharp_m && bk == kmax) ? (uint32_t)(lsp + lane + 64 * bt) : 0u;
+      const int c = (int)wave_max_u32(cand);
       ++picked_num;
       int lab = 0;
       if (picked_num <= P.n_sharp) lab = 2; else if (picked_num <= P.n_less_sharp) lab = 1;
       if (lane == 0) {
-        s_flag[idx - rf] |= 1;
-        if (lab) s_label[idx - rf] = (int8_t)lab;
-        if (lab == 2) st_sharp[n_sharp] = idx;
-        if (lab) st_lsharp[n_ls] = idx;
+        if (lab) s_label[c] = (int8_t)lab;
+        if (lab == 2) st_sharp[n_sharp] = c + rf;
+        if (lab) st_lsharp[n_ls] = c + rf;
       }
       if (lab == 2) ++n_sharp;
       if (lab) ++n_ls;
-      if (lab) {  // suppression (:211-234); the 21st pick breaks before it (:207-210)
-        bool bad = false;
-        int tgt = -1;
-        if (lane < SR) { const int a = colv[idx + lane + 1], b = colv[idx + lane]; const int cdf = a - b; bad = (cdf < 0 ? -cdf : cdf) > P.suppress_col_diff; tgt = idx + lane + 1; }
-        else if (lane >= 32 && lane < 32 + SR) { const int l = lane - 32; const int a = colv[idx - l - 1], b = colv[idx - l]; const int cdf = a - b; bad = (cdf < 0 ? -cdf : cdf) > P.suppress_col_diff; tgt = idx - l - 1; }
-        const unsigned long long mb = __ballot(bad);
-        const unsigned lo = (unsigned)(mb & 0xffffffffull), hi = (unsigned)(mb >> 32);
-        const int first_f = lo ? __ffs((int)lo) - 1 : 64, first_b = hi ? __ffs((int)hi) - 1 : 64;
-        if (lane < SR && lane < first_f) s_flag[tgt - rf] |= 1;
-        if (lane >= 32 && lane < 32 + SR && lane - 32 < first_b) s_flag[tgt - rf] |= 1;
-      }
-      __syncthreads();
+      mark(c, lab != 0);  // the 21st pick is marked but breaks before the suppression (:207-210)
       if (!lab) break;
     }
-    // ---- flat: ascending curvature, ground only (:238-277) ----
+    // ---- flat: ascending curvature, ground only, ties -> smaller index (:238-277) ----
     picked_num = 0;
     while (true) {
-      unsigned long long best = ~0ull;
-      for (int k = sp + lane; k <= ep; k += 64) {
-        const int loc = k - rf;
-        if ((s_flag[loc] & 3) == 2) {
-          const uint32_t kb = s_key[loc];
-          const double ad = (double)d_i2f((int32_t)kb);
-          if (ad * ad < P.surf_thres) {
-            const unsigned long long c = ((unsigned long long)kb << 32) | (uint32_t)k;
-            best = c < best ? c : best;
-          }
-        }
-      }
-      best = wave_min_u64(best);
-      if (best == ~0ull) break;
-      const int idx = (int)(uint32_t)best;
+      uint32_t bk = 0xFFFFFFFFu;
+      int bt = 0;
+#pragma unroll
+      for (int t = 0; t < FE_T; ++t) if (((flat_m >> t) & 1) && key[t] < bk) { bk = key[t]; bt = t; }
+      const uint32_t kmin = wave_min_u32(bk);
+      if (kmin == 0xFFFFFFFFu) break;
+      const uint32_t cand = (flat_m && bk == kmin) ? (uint32_t)(lsp + lane + 64 * bt) : 0xFFFFFFFFu;
+      const int c = (int)wave_min_u32(cand);
       ++picked_num;
-      if (lane == 0) { s_flag[idx - rf] |= 1; s_label[idx - rf] = -1; st_flat[n_flat] = idx; }
+      if (lane == 0) { s_label[c] = -1; st_flat[n_flat] = c + rf; }
       ++n_flat;
       const bool stop = picked_num >= P.n_flat;
-      if (!stop) {
-        bool bad = false;
-        int tgt = -1;
-        if (lane < SR) { const int a = colv[idx + lane + 1], b = colv[idx + lane]; const int cdf = a - b; bad = (cdf < 0 ? -cdf : cdf) > P.suppress_col_diff; tgt = idx + lane + 1; }
-        else if (lane >= 32 && lane < 32 + SR) { const int l = lane - 32; const int a = colv[idx - l - 1], b = colv[idx - l]; const int cdf = a - b; bad = (cdf < 0 ? -cdf : cdf) > P.suppress_col_diff; tgt = idx - l - 1; }
-        const unsigned long long mb = __ballot(bad);
-        const unsigned lo = (unsigned)(mb & 0xffffffffull), hi = (unsigned)(mb >> 32);
-        const int first_f = lo ? __ffs((int)lo) - 1 : 64, first_b = hi ? __ffs((int)hi) - 1 : 64;
-        if (lane < SR && lane < first_f) s_flag[tgt - rf] |= 1;
-        if (lane >= 32 && lane < 32 + SR && lane - 32 < first_b) s_flag[tgt - rf] |= 1;
-      }
-      __syncthreads();
+      mark(c, !stop);  // the n_flat-th pick breaks before the suppression (:248-251)
       if (stop) break;
     }
+    __syncthreads();
     // ---- less-flat candidates in position order (:279-285) ----
-    for (int k0 = sp; k0 <= ep; k0 += 64) {
-      const int k = k0 + lane;
-      const bool take = k <= ep && s_label[k - rf] <= 0;
+    for (int c0 = lsp; c0 <= lep; c0 += 64) {
+      const int c = c0 + lane;
+      const bool take = c <= lep && s_label[c] <= 0;
       const unsigned long long m = __ballot(take);
-      if (take) st_lfs[n_lfs + (int)__popcll(m & ((1ull << lane) - 1ull))] = k;
+      if (take) st_lfs[n_lfs + (int)__popcll(m & ((1ull << lane) - 1ull))] = c + rf;
       n_lfs += (int)__popcll(m);
     }
   }
+  __syncthreads();
   for (int k = lane; k < cnt; k += 64) d.plabel[base + rf + k] = (int)s_label[k];
   if (lane == 0) {
     int* c = d.st_cnt + ((size_t)slot * d.NS + ring) * 8;
@@ -362,7 +372,7 @@ __global__ void __launch_bounds__(FE_BLOCK) fe_gather(DevCtx d) {
 
 void launch_fe(const DevCtx& d, hipStream_t st) {
   ALEGO_LAUNCH(fe_curv, dim3((d.N + FE_BLOCK - 1) / FE_BLOCK, d.n_launch), dim3(FE_BLOCK), 0, st, d);
-  ALEGO_LAUNCH(fe_pick, dim3(d.NS, d.n_launch), dim3(64), 0, st, d);
+  ALEGO_LAUNCH(fe_pick, dim3(d.NS, d.n_launch), dim3(64), (size_t)8 * d.H, st, d);
   ALEGO_LAUNCH(fe_voxel, dim3(d.NS, d.n_launch), dim3(FE_BLOCK), 0, st, d);
   ALEGO_LAUNCH(fe_gather, dim3(d.NS, d.n_launch), dim3(FE_BLOCK), 0, st, d);
 }
