@@ -211,7 +211,11 @@ __global__ void __launch_bounds__(64) fe_pick(DevCtx d) {
   }
 }
 
-// one block per (ring, slot): pcl::VoxelGrid on the ring's less_flat_scan
+// one block per (ring, slot): pcl::VoxelGrid on the ring's less_flat_scan.
+// Consecutive points of a ring mostly fall into the same 0.4 m voxel, so the (voxel id, position) sort is done on
+// RUNS of equal consecutive voxel ids (a few hundred per ring instead of ~1000 points): rank-by-counting of the
+// runs in LDS, then the first run of every voxel accumulates all runs of that voxel in order — the same f32
+// summation order as a stable sort of the points.  Dynamic LDS: 14 B per ring point.
 __global__ void __launch_bounds__(FE_BLOCK) fe_voxel(DevCtx d) {
   const int slot = blockIdx.y + d.slot0, ring = blockIdx.x, tid = threadIdx.x;
   const size_t base = (size_t)slot * d.N;
@@ -220,10 +224,14 @@ __global__ void __launch_bounds__(FE_BLOCK) fe_voxel(DevCtx d) {
   const int* lfs = d.st_idx + ((size_t)slot * d.NS + ring) * d.st_stride + d.cap_sharp + d.cap_lsharp + d.cap_flat;
   float4* out = d.st_lfds + ((size_t)slot * d.NS + ring) * d.H;
   const float4* seg = d.seg_pts + base;
-  __shared__ unsigned long long s_keys[FE_MAXH];
+  extern __shared__ __attribute__((aligned(16))) unsigned char fv_smem[];
+  uint32_t* s_key = reinterpret_cast<uint32_t*>(fv_smem);                       // voxel id per point      [H]
+  uint32_t* s_rvid = reinterpret_cast<uint32_t*>(fv_smem + 4 * (size_t)d.H);    // voxel id per run        [H]
+  uint16_t* s_rstart = reinterpret_cast<uint16_t*>(fv_smem + 8 * (size_t)d.H);  // first point of the run  [H]
+  uint16_t* s_rlen = reinterpret_cast<uint16_t*>(fv_smem + 10 * (size_t)d.H);   // points in the run       [H]
+  uint16_t* s_order = reinterpret_cast<uint16_t*>(fv_smem + 12 * (size_t)d.H);  // runs sorted by (voxel id, run) [H]
   __shared__ float s_red[6][FE_BLOCK / 64];
   __shared__ int s_scan[FE_BLOCK / 64];
-  __shared__ int s_total;
   if (n == 0) { if (tid == 0) cnts[4] = 0; return; }
   const float inv = 1.0f / d.P.less_flat_leaf;
   // getMinMax3D
@@ -259,40 +267,19 @@ __global__ void __launch_bounds__(FE_BLOCK) fe_voxel(DevCtx d) {
     divb[a] = (int)floorf(mx[a] * inv) - minb[a] + 1;
   }
   const int mul1 = divb[0], mul2 = divb[0] * divb[1];
-  int np2 = 64;
-  while (np2 < n) np2 <<= 1;
-  for (int i = tid; i < np2; i += FE_BLOCK) {
-    unsigned long long key = ~0ull;
-    if (i < n) {
-      const float4 p = seg[lfs[i]];
-      const int i0 = (int)(floorf(p.x * inv) - (float)minb[0]);
-      const int i1 = (int)(floorf(p.y * inv) - (float)minb[1]);
-      const int i2 = (int)(floorf(p.z * inv) - (float)minb[2]);
-      key = ((unsigned long long)(unsigned)(i0 + i1 * mul1 + i2 * mul2) << 32) | (unsigned)i;
-    }
-    s_keys[i] = key;
+  for (int i = tid; i < n; i += FE_BLOCK) {
+    const float4 p = seg[lfs[i]];
+    const int i0 = (int)(floorf(p.x * inv) - (float)minb[0]);
+    const int i1 = (int)(floorf(p.y * inv) - (float)minb[1]);
+    const int i2 = (int)(floorf(p.z * inv) - (float)minb[2]);
+    s_key[i] = (uint32_t)(i0 + i1 * mul1 + i2 * mul2);
   }
   __syncthreads();
-  // bitonic sort, ascending (voxel id, position) == stable sort by voxel id
-  for (int k = 2; k <= np2; k <<= 1) {
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int i = tid; i < np2; i += FE_BLOCK) {
-        const int ixj = i ^ j;
-        if (ixj > i) {
-          const unsigned long long a = s_keys[i], b = s_keys[ixj];
-          const bool up = (i & k) == 0;
-          if ((a > b) == up) { s_keys[i] = b; s_keys[ixj] = a; }
-        }
-      }
-      __syncthreads();
-    }
-  }
-  // voxel heads -> output rank; the head thread accumulates its run in sorted order
-  int run = 0;
+  // runs of consecutive equal voxel ids
+  int nruns = 0;
   for (int c0 = 0; c0 < n; c0 += FE_BLOCK) {
     const int i = c0 + tid;
-    bool head = false;
-    if (i < n) head = (i == 0) || ((s_keys[i] >> 32) != (s_keys[i - 1] >> 32));
+    const bool head = i < n && (i == 0 || s_key[i] != s_key[i - 1]);
     const unsigned long long m = __ballot(head);
     if ((tid & 63) == 0) s_scan[tid >> 6] = (int)__popcll(m);
     __syncthreads();
@@ -300,22 +287,53 @@ __global__ void __launch_bounds__(FE_BLOCK) fe_voxel(DevCtx d) {
 #pragma unroll
     for (int w = 0; w < FE_BLOCK / 64; ++w) { if (w < (tid >> 6)) woff += s_scan[w]; tot += s_scan[w]; }
     if (head) {
-      const int rank = run + woff + (int)__popcll(m & ((1ull << (tid & 63)) - 1ull));
-      const unsigned vid = (unsigned)(s_keys[i] >> 32);
+      const int r = nruns + woff + (int)__popcll(m & ((1ull << (tid & 63)) - 1ull));
+      s_rvid[r] = s_key[i];
+      s_rstart[r] = (uint16_t)i;
+    }
+    nruns += tot;
+    __syncthreads();
+  }
+  for (int r = tid; r < nruns; r += FE_BLOCK) s_rlen[r] = (uint16_t)((r + 1 < nruns ? (int)s_rstart[r + 1] : n) - (int)s_rstart[r]);
+  // rank the runs by (voxel id, run index): LDS broadcast reads, no barriers inside
+  for (int r = tid; r < nruns; r += FE_BLOCK) {
+    const uint32_t v = s_rvid[r];
+    int rank = 0;
+    for (int q = 0; q < nruns; ++q) { const uint32_t u = s_rvid[q]; rank += (u < v) || (u == v && q < r); }
+    s_order[rank] = (uint16_t)r;
+  }
+  __syncthreads();
+  // first run of every voxel -> output rank; it accumulates all runs of the voxel in order
+  int nvox = 0;
+  for (int c0 = 0; c0 < nruns; c0 += FE_BLOCK) {
+    const int j = c0 + tid;
+    const bool head = j < nruns && (j == 0 || s_rvid[s_order[j]] != s_rvid[s_order[j - 1]]);
+    const unsigned long long m = __ballot(head);
+    if ((tid & 63) == 0) s_scan[tid >> 6] = (int)__popcll(m);
+    __syncthreads();
+    int woff = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < FE_BLOCK / 64; ++w) { if (w < (tid >> 6)) woff += s_scan[w]; tot += s_scan[w]; }
+    if (head) {
+      const int rank = nvox + woff + (int)__popcll(m & ((1ull << (tid & 63)) - 1ull));
+      const uint32_t vid = s_rvid[s_order[j]];
       float sx = 0.f, sy = 0.f, sz = 0.f, si = 0.f;
       int c = 0;
-      for (int li = i; li < n && (unsigned)(s_keys[li] >> 32) == vid; ++li) {
-        const float4 p = seg[lfs[(unsigned)s_keys[li]]];
-        sx += p.x; sy += p.y; sz += p.z; si += p.w;
-        ++c;
+      for (int jj = j; jj < nruns && s_rvid[s_order[jj]] == vid; ++jj) {
+        const int r = s_order[jj], i0 = s_rstart[r], len = s_rlen[r];
+        for (int i = i0; i < i0 + len; ++i) {
+          const float4 p = seg[lfs[i]];
+          sx += p.x; sy += p.y; sz += p.z; si += p.w;
+          ++c;
+        }
       }
       const float fn = (float)c;
       out[rank] = make_float4(sx / fn, sy / fn, sz / fn, si / fn);
     }
-    run += tot;
+    nvox += tot;
     __syncthreads();
   }
-  if (tid == 0) cnts[4] = run;
+  if (tid == 0) cnts[4] = nvox;
 }
 
 // ring-ascending concatenation.  grid (NS, slots)
@@ -373,6 +391,6 @@ __global__ void __launch_bounds__(FE_BLOCK) fe_gather(DevCtx d) {
 void launch_fe(const DevCtx& d, hipStream_t st) {
   ALEGO_LAUNCH(fe_curv, dim3((d.N + FE_BLOCK - 1) / FE_BLOCK, d.n_launch), dim3(FE_BLOCK), 0, st, d);
   ALEGO_LAUNCH(fe_pick, dim3(d.NS, d.n_launch), dim3(64), (size_t)8 * d.H, st, d);
-  ALEGO_LAUNCH(fe_voxel, dim3(d.NS, d.n_launch), dim3(FE_BLOCK), 0, st, d);
+  ALEGO_LAUNCH(fe_voxel, dim3(d.NS, d.n_launch), dim3(FE_BLOCK), (size_t)14 * d.H, st, d);
   ALEGO_LAUNCH(fe_gather, dim3(d.NS, d.n_launch), dim3(FE_BLOCK), 0, st, d);
 }
