@@ -39,6 +39,7 @@ __device__ __forceinline__ float vx_dec(unsigned e) {
 }
 __device__ __forceinline__ bool vx_enabled(const VoxJob& J) { return J.enable == nullptr || *J.enable != 0; }
 
+#define VX_SMALL_MAX_ 8192     // jobs up to this many points are done by vox_small in one launch
 #define VX_POOL 1024           // workgroups of the point / bucket parallel kernels
 #define VX_PT_ITEM 1024        // points per work item
 #define VX_BK_ITEM 64          // buckets per work item (= one wavefront; bsort / bcentroid run 64-thread workgroups)
@@ -59,7 +60,7 @@ __global__ void __launch_bounds__(VB) vox_plan(VoxCtx V, int which) {
     if (j < V.njobs) {
       const VoxJob J = V.jobs[j];
       if (vx_enabled(J)) {
-        if (which == 0) { const int n = min(*J.n_in, J.cap); v = (n + VX_PT_ITEM - 1) / VX_PT_ITEM; }
+        if (which == 0) { const int n = min(*J.n_in, J.cap); v = n > VX_SMALL_MAX_ ? (n + VX_PT_ITEM - 1) / VX_PT_ITEM : 0; }
         else v = (V.geom[j * VX_GEOM + 8] + VX_BK_ITEM - 1) / VX_BK_ITEM;
       }
     }
@@ -126,8 +127,10 @@ __global__ void __launch_bounds__(VB) vox_geom(VoxCtx V) {
   if (job >= V.njobs) return;
   const VoxJob J = V.jobs[job];
   int* g = V.geom + job * VX_GEOM;
-  if (!vx_enabled(J)) { g[5] = 0; g[8] = 0; return; }
+  if (!vx_enabled(J)) { g[5] = 0; g[8] = 0; g[9] = 1; return; }
   const int n = min(*J.n_in, J.cap);
+  if (n <= VX_SMALL_MAX_) { g[5] = 0; g[8] = 0; g[9] = 1; return; }  // done by vox_small
+  g[9] = 0;
   const float inv = 1.0f / J.leaf;
   const unsigned* bb = V.bbox + job * 8;
   int minb[3] = {0, 0, 0}, mul1 = 1, mul2 = 1, pass = 0;
@@ -208,7 +211,7 @@ __device__ void vx_block_scan(const int* cnt, int* off, int* cur, int nb, int* t
 __global__ void __launch_bounds__(VB) vox_bscan(VoxCtx V) {
   const int job = blockIdx.x;
   const VoxJob J = V.jobs[job];
-  if (!vx_enabled(J)) return;
+  if (!vx_enabled(J) || V.geom[job * VX_GEOM + 9]) return;
   const int nb = V.geom[job * VX_GEOM + 8];
   vx_block_scan(V.bcnt + J.boff0, V.boff + J.boff0, V.bcur + J.boff0, nb, nullptr);
 }
@@ -241,7 +244,7 @@ __device__ __forceinline__ u64 vx_readlane64(u64 v, int lane) {
 //   m <= VX_TINY : one lane per bucket (the 64 buckets of the item in parallel)
 //   m <= 64      : the wavefront takes the bucket, elements in registers, ranks via v_readlane
 //   larger       : the wavefront through LDS (straight from memory beyond VX_WAVE_LDS elements)
-#define VX_WAVE_LDS 4096
+#define VX_WAVE_LDS 1024   // 8 KB of LDS per single-wave workgroup keeps ~20 of them resident per CU
 __global__ void __launch_bounds__(64) vox_bsort(VoxCtx V) {
   const int lane = threadIdx.x;
   __shared__ u64 s_buf[VX_WAVE_LDS];
@@ -325,7 +328,7 @@ __global__ void __launch_bounds__(64) vox_bsort(VoxCtx V) {
 __global__ void __launch_bounds__(VB) vox_vscan(VoxCtx V) {
   const int job = blockIdx.x;
   const VoxJob J = V.jobs[job];
-  if (!vx_enabled(J)) return;
+  if (!vx_enabled(J) || V.geom[job * VX_GEOM + 9]) return;
   const int nb = V.geom[job * VX_GEOM + 8];
   vx_block_scan(V.bvox + J.boff0, V.voff + J.boff0, nullptr, nb, J.n_out);
 }
@@ -415,9 +418,211 @@ __global__ void __launch_bounds__(64) vox_bcentroid(VoxCtx V) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Small jobs (n <= VX_SMALL_MAX points: the VoxelGrid calls on the current scan, laserMapping.cpp:329-342) run the
+// whole filter in ONE launch, one workgroup per job, with every intermediate in LDS: bounding box, voxel ids,
+// bucket histogram (LDS atomics), scan, scatter, per-bucket rank sort, voxel ranks, centroids.  The multi-kernel
+// path above is left for the map (45-75 k points).  LDS: 4 B key + 2 B index per point, 6 B per bucket.
+#define VX_SMALL_MAX 8192
+#define VX_SMALL_NB 4096
+#define VX_SB 512
+__device__ __forceinline__ bool vx_less(const unsigned* key, unsigned a, unsigned b) { return key[a] < key[b] || (key[a] == key[b] && a < b); }
+
+__global__ void __launch_bounds__(VX_SB) vox_small(VoxCtx V) {
+  const int job = blockIdx.x;
+  const VoxJob J = V.jobs[job];
+  if (!vx_enabled(J)) return;
+  const int n = min(*J.n_in, J.cap);
+  if (n > VX_SMALL_MAX) return;  // left to the multi-kernel path (vox_geom reads the same condition)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  extern __shared__ __attribute__((aligned(16))) unsigned char vs_smem[];
+  unsigned* s_key = reinterpret_cast<unsigned*>(vs_smem);                                             // [VX_SMALL_MAX]
+  int* s_cnt = reinterpret_cast<int*>(vs_smem + 4 * VX_SMALL_MAX);                                    // [VX_SMALL_NB] histogram -> starts -> ends
+  unsigned short* s_idx = reinterpret_cast<unsigned short*>(vs_smem + 4 * VX_SMALL_MAX + 4 * VX_SMALL_NB);          // [VX_SMALL_MAX]
+  unsigned short* s_vox = reinterpret_cast<unsigned short*>(vs_smem + 6 * VX_SMALL_MAX + 4 * VX_SMALL_NB);          // [VX_SMALL_NB]
+  __shared__ float s_red[6][VX_SB / 64];
+  __shared__ int s_scan[VX_SB / 64];
+  __shared__ int s_run;
+  if (n == 0) { if (tid == 0) *J.n_out = 0; return; }
+  const float inv = 1.0f / J.leaf;
+  // getMinMax3D
+  float mn[3] = {3.402823466e+38f, 3.402823466e+38f, 3.402823466e+38f}, mx[3] = {-3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f};
+  for (int i = tid; i < n; i += VX_SB) {
+    const float4 p = J.in[i];
+    mn[0] = fminf(mn[0], p.x); mn[1] = fminf(mn[1], p.y); mn[2] = fminf(mn[2], p.z);
+    mx[0] = fmaxf(mx[0], p.x); mx[1] = fmaxf(mx[1], p.y); mx[2] = fmaxf(mx[2], p.z);
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { mn[a] = fminf(mn[a], __shfl_xor(mn[a], o, 64)); mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], o, 64)); }
+    if (lane == 0) { s_red[a][wave] = mn[a]; s_red[3 + a][wave] = mx[a]; }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    mn[a] = s_red[a][0]; mx[a] = s_red[3 + a][0];
+#pragma unroll
+    for (int w = 1; w < VX_SB / 64; ++w) { mn[a] = fminf(mn[a], s_red[a][w]); mx[a] = fmaxf(mx[a], s_red[3 + a][w]); }
+  }
+  const long long dx = (long long)((mx[0] - mn[0]) * inv) + 1, dy = (long long)((mx[1] - mn[1]) * inv) + 1, dz = (long long)((mx[2] - mn[2]) * inv) + 1;
+  if (dx * dy * dz > 2147483647LL) {  // PCL: "leaf size too small" -> output = input
+    for (int i = tid; i < n; i += VX_SB) J.out[i] = J.in[i];
+    if (tid == 0) *J.n_out = n;
+    return;
+  }
+  int minb[3], divb[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) { minb[a] = (int)floorf(mn[a] * inv); divb[a] = (int)floorf(mx[a] * inv) - minb[a] + 1; }
+  const int mul1 = divb[0], mul2 = divb[0] * divb[1];
+  unsigned T = (unsigned)divb[0] * (unsigned)divb[1] * (unsigned)divb[2];
+  if (T == 0) T = 1;
+  int target = 64;
+  while (target < VX_SMALL_NB && target < n) target <<= 1;
+  int shift = 0;
+  while (((T - 1) >> shift) >= (unsigned)target) ++shift;
+  const int nb = (int)((T - 1) >> shift) + 1;
+  for (int b = tid; b < nb; b += VX_SB) s_cnt[b] = 0;
+  __syncthreads();
+  for (int i = tid; i < n; i += VX_SB) {
+    const float4 p = J.in[i];
+    const int i0 = (int)(floorf(p.x * inv) - (float)minb[0]);
+    const int i1 = (int)(floorf(p.y * inv) - (float)minb[1]);
+    const int i2 = (int)(floorf(p.z * inv) - (float)minb[2]);
+    const unsigned key = (unsigned)(i0 + i1 * mul1 + i2 * mul2);
+    s_key[i] = key;
+    atomicAdd(&s_cnt[min(key >> shift, (unsigned)(nb - 1))], 1);
+  }
+  __syncthreads();
+  // exclusive scan of the histogram in place
+  auto block_scan = [&](auto get, auto put, int cnt) -> int {
+    if (tid == 0) s_run = 0;
+    __syncthreads();
+    for (int b0 = 0; b0 < cnt; b0 += VX_SB) {
+      const int b = b0 + tid;
+      const int v = b < cnt ? get(b) : 0;
+      int incl = v;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+      if (lane == 63) s_scan[wave] = incl;
+      __syncthreads();
+      int woff = 0, tot = 0;
+#pragma unroll
+      for (int w = 0; w < VX_SB / 64; ++w) { if (w < wave) woff += s_scan[w]; tot += s_scan[w]; }
+      const int run = s_run;
+      if (b < cnt) put(b, run + woff + incl - v);
+      __syncthreads();
+      if (tid == 0) s_run = run + tot;
+      __syncthreads();
+    }
+    return s_run;
+  };
+  block_scan([&](int b) { return s_cnt[b]; }, [&](int b, int v) { s_cnt[b] = v; }, nb);
+  // scatter: s_cnt[b] turns from bucket start into bucket end
+  for (int i = tid; i < n; i += VX_SB) {
+    const int pos = atomicAdd(&s_cnt[min(s_key[i] >> shift, (unsigned)(nb - 1))], 1);
+    s_idx[pos] = (unsigned short)i;
+  }
+  __syncthreads();
+  // per-bucket rank sort by (voxel id, position) + voxel count.  thread per bucket; buckets > VX_TINY by the wave
+  for (int b0 = 0; b0 < nb; b0 += VX_SB) {
+    const int b = b0 + tid;
+    const int bs = b < nb ? (b == 0 ? 0 : s_cnt[b - 1]) : 0;
+    const int m = b < nb ? s_cnt[b] - bs : 0;
+    if (m > 0 && m <= VX_TINY) {
+      unsigned short e[VX_TINY];
+#pragma unroll
+      for (int i = 0; i < VX_TINY; ++i) e[i] = i < m ? s_idx[bs + i] : (unsigned short)0;
+      int heads = 0;
+#pragma unroll
+      for (int i = 0; i < VX_TINY; ++i) {
+        if (i < m) {
+          int rank = 0;
+          bool head = true;
+#pragma unroll
+          for (int j = 0; j < VX_TINY; ++j) if (j < m && j != i) { const bool lt = vx_less(s_key, e[j], e[i]); rank += lt; if (lt && s_key[e[j]] == s_key[e[i]]) head = false; }
+          s_idx[bs + rank] = e[i];
+          heads += head;
+        }
+      }
+      s_vox[b] = (unsigned short)heads;
+    } else if (b < nb && m == 0) {
+      s_vox[b] = 0;
+    }
+    unsigned long long bigger = __ballot(m > VX_TINY);
+    while (bigger) {
+      const int src_lane = __ffsll((long long)bigger) - 1;
+      bigger &= bigger - 1;
+      const int bb = __shfl(b, src_lane, 64), mm = __shfl(m, src_lane, 64), bbs = __shfl(bs, src_lane, 64);
+      int heads = 0;
+      // ranks first (all reads), then the writes: in place is safe because the wave runs in lock-step
+      unsigned short mine[8];  // up to 512 elements per bucket through registers; beyond: serial fallback below
+      int myrank[8];
+      if (mm <= 512) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int t = lane + 64 * q;
+          mine[q] = 0; myrank[q] = -1;
+          if (t < mm) {
+            const unsigned short e = s_idx[bbs + t];
+            int rank = 0;
+            bool head = true;
+            for (int j = 0; j < mm; ++j) { const unsigned short o = s_idx[bbs + j]; if (o != e) { const bool lt = vx_less(s_key, o, e); rank += lt; if (lt && s_key[o] == s_key[e]) head = false; } }
+            mine[q] = e; myrank[q] = rank; heads += head;
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int q = 0; q < 8; ++q) if (myrank[q] >= 0) s_idx[bbs + myrank[q]] = mine[q];
+      } else if (lane == 0) {
+        // very large bucket (never seen on scan clouds): insertion sort by one lane
+        for (int i = 1; i < mm; ++i) {
+          const unsigned short e = s_idx[bbs + i];
+          int j = i - 1;
+          while (j >= 0 && vx_less(s_key, e, s_idx[bbs + j])) { s_idx[bbs + j + 1] = s_idx[bbs + j]; --j; }
+          s_idx[bbs + j + 1] = e;
+        }
+        for (int i = 0; i < mm; ++i) heads += (i == 0 || s_key[s_idx[bbs + i]] != s_key[s_idx[bbs + i - 1]]);
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) heads += __shfl_xor(heads, o, 64);
+      if (lane == 0) s_vox[bb] = (unsigned short)heads;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+  }
+  __syncthreads();
+  const int nvox = block_scan([&](int b) { return (int)s_vox[b]; }, [&](int b, int v) { s_vox[b] = (unsigned short)v; }, nb);
+  // centroids: one thread per bucket walks its sorted points; f32 sums in sorted (= original) order
+  for (int b = tid; b < nb; b += VX_SB) {
+    const int bs = b == 0 ? 0 : s_cnt[b - 1], m = s_cnt[b] - bs;
+    if (m == 0) continue;
+    int rank = s_vox[b];
+    float sx = 0.f, sy = 0.f, sz = 0.f, si = 0.f;
+    int c = 0;
+    unsigned cur = 0;
+    for (int k = 0; k < m; ++k) {
+      const unsigned short e = s_idx[bs + k];
+      const unsigned vid = s_key[e];
+      if (c > 0 && vid != cur) {
+        const float fn = (float)c;
+        if (rank < J.cap) J.out[rank] = make_float4(sx / fn, sy / fn, sz / fn, si / fn);
+        ++rank; sx = sy = sz = si = 0.f; c = 0;
+      }
+      const float4 p = J.in[e];
+      sx += p.x; sy += p.y; sz += p.z; si += p.w;
+      ++c; cur = vid;
+    }
+    const float fn = (float)c;
+    if (rank < J.cap) J.out[rank] = make_float4(sx / fn, sy / fn, sz / fn, si / fn);
+  }
+  if (tid == 0) *J.n_out = nvox;
+}
+
 // ---- host ------------------------------------------------------------------------
+#define VX_SMALL_LDS (6 * VX_SMALL_MAX + 6 * VX_SMALL_NB)
 int vox_create(VoxCtx* V, const VoxJob* jobs, int njobs, std::string* err) {
   std::memset(V, 0, sizeof(*V));
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(vox_small), hipFuncAttributeMaxDynamicSharedMemorySize, VX_SMALL_LDS) != hipSuccess) { *err = "vox_create: hipFuncSetAttribute"; return -2; }
   std::vector<VoxJob> h(jobs, jobs + njobs);
   size_t total = 0;
   int max_cap = 0;
@@ -457,6 +662,7 @@ int vox_run(const VoxCtx& V, hipStream_t st, std::string* err) {
   if (V.njobs == 0) return 0;
   { ProfScope ms_("memset_bbox", st); (void)hipMemsetAsync(V.bbox, 0xFF, (size_t)V.njobs * 8 * 4, st); }
   const dim3 pool(VX_POOL), blk(VB), jobs1((V.njobs + VB - 1) / VB), perjob(V.njobs);
+  ALEGO_LAUNCH(vox_small, perjob, dim3(VX_SB), (size_t)VX_SMALL_LDS, st, V);
   ALEGO_LAUNCH(vox_plan, dim3(1), blk, 0, st, V, 0);
   ALEGO_LAUNCH(vox_bbox, pool, blk, 0, st, V);
   ALEGO_LAUNCH(vox_geom, jobs1, blk, 0, st, V);
