@@ -22,6 +22,8 @@ void launch_fe(const DevCtx& d, hipStream_t st);
 void launch_lo(const DevCtx& d, hipStream_t st);
 void launch_atan2f_probe(const float* y, const float* x, float* out, int n, int mode, hipStream_t st);
 int ip_configure(const DevCtx& d);
+int lo_configure();
+int lm_configure();
 
 struct alego_handle {
   alego_params P;
@@ -149,7 +151,7 @@ int alego_create(const alego_params* params, int device, int n_slots, int ring_l
   hipMemcpy(d.scal, sc0.data(), sc0.size() * sizeof(int), hipMemcpyHostToDevice);
   hipMemcpy(d.lo_state, st.data(), st.size() * sizeof(double), hipMemcpyHostToDevice);
   hipMemcpy(d.poses, po.data(), po.size() * sizeof(double), hipMemcpyHostToDevice);
-  if (ip_configure(d) != 0) { h->err = "hipFuncSetAttribute failed"; std::fprintf(stderr, "alego_create: %s\n", h->err.c_str()); alego_destroy(h); return ALEGO_ERR_HIP; }
+  if (ip_configure(d) != 0 || lo_configure() != 0 || lm_configure() != 0) { h->err = "hipFuncSetAttribute failed"; std::fprintf(stderr, "alego_create: %s\n", h->err.c_str()); alego_destroy(h); return ALEGO_ERR_HIP; }
   h->lm = lm_host_create(h->P, d, n_slots, h->stream, &h->err);
   if (!h->lm) { std::fprintf(stderr, "alego_create: %s\n", h->err.c_str()); alego_destroy(h); return ALEGO_ERR_HIP; }
   *out = h;

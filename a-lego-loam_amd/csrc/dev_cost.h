@@ -145,7 +145,7 @@ DEV_INLINE void accumulate_block(double r, const double J[6], double huber_a, do
   double rho0, rho1;
   if (s > b2) { const double rr = sqrt(s); rho0 = 2.0 * huber_a * rr - b2; rho1 = fmax(2.2250738585072014e-308, huber_a / rr); }
   else { rho0 = s; rho1 = 1.0; }
-  const double sq = sqrt(rho1);
+  const double sq = s > b2 ? sqrt(rho1) : 1.0;  // inliers: rho' = 1, no correction
   double Jc[6];
 #pragma unroll
   for (int k = 0; k < 6; ++k) Jc[k] = J[k] * sq;
@@ -158,6 +158,33 @@ DEV_INLINE void accumulate_block(double r, const double J[6], double huber_a, do
 #pragma unroll
   for (int k = 0; k < 6; ++k) acc[21 + k] += Jc[k] * rc;
   acc[27] += 0.5 * rho0;
+}
+
+// Deterministic workgroup reduction of the 28 normal-equation scalars through LDS: every thread stores its
+// partials k-major (conflict-free), NSEG = T/32 threads per scalar add 32 strided entries each, then one thread
+// per scalar adds the NSEG segment sums in order.  ~40 dependent adds instead of 28 x 6 cross-lane shuffles.
+template <int T>
+DEV_INLINE void block_reduce28_lds(const double acc[28], double* s_acc /*[28*T]*/, double* s_seg /*[28*(T/32)]*/, double* s_out /*[28]*/) {
+  constexpr int NSEG = T / 32;
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int k = 0; k < 28; ++k) s_acc[k * T + tid] = acc[k];
+  __syncthreads();
+  if (tid < 28 * NSEG) {
+    const int k = tid / NSEG, seg = tid - k * NSEG;
+    double t = 0;
+#pragma unroll 8
+    for (int j = 0; j < 32; ++j) t += s_acc[k * T + j * NSEG + seg];
+    s_seg[k * NSEG + seg] = t;
+  }
+  __syncthreads();
+  if (tid < 28) {
+    double t = 0;
+#pragma unroll
+    for (int sgm = 0; sgm < NSEG; ++sgm) t += s_seg[tid * NSEG + sgm];
+    s_out[tid] = t;
+  }
+  __syncthreads();
 }
 
 // ---------------------------------------------------------------------------
@@ -209,12 +236,16 @@ DEV_INLINE int lm_propose(LmState& S) {
   if (S.step_successful && S.gmax <= 1e-10) { S.termination = 1; return LM_STOP; }
   if (S.radius <= 1e-32) { S.termination = 5; return LM_STOP; }
   ++S.iter;
-  double A[6][6], gs[6], y[6];
+  double A[6][6], gs[6], y[6], Hl[21], sc[6], gl[6];
+#pragma unroll
+  for (int k = 0; k < 21; ++k) Hl[k] = S.H[k];  // LDS -> registers once
+#pragma unroll
+  for (int k = 0; k < 6; ++k) { sc[k] = S.scale[k]; gl[k] = S.g[k]; }
 #pragma unroll
   for (int i = 0; i < 6; ++i) {
-    gs[i] = S.g[i] * S.scale[i];
+    gs[i] = gl[i] * sc[i];
 #pragma unroll
-    for (int j = 0; j < 6; ++j) A[i][j] = S.H[tri(i, j)] * S.scale[i] * S.scale[j];
+    for (int j = 0; j < 6; ++j) A[i][j] = Hl[tri(i, j)] * sc[i] * sc[j];
   }
   double Hs[6][6];
 #pragma unroll
@@ -266,7 +297,7 @@ DEV_INLINE int lm_propose(LmState& S) {
   S.num_invalid = 0;
   S.mcc = mcc;
 #pragma unroll
-  for (int i = 0; i < 6; ++i) S.cand[i] = S.x[i] + step[i] * S.scale[i];
+  for (int i = 0; i < 6; ++i) S.cand[i] = S.x[i] + step[i] * sc[i];
   return LM_EVAL;
 }
 

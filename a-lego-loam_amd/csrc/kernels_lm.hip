@@ -392,23 +392,6 @@ __global__ void __launch_bounds__(128) lm_assoc(DevCtx d, LmCtx L) {
   }
 }
 
-DEV_INLINE void lm_block_reduce28(double acc[28], double (*s_part)[28], double* s_out) {
-#pragma unroll
-  for (int k = 0; k < 28; ++k) acc[k] = wave_sum_f64(acc[k]);
-  const int wave = threadIdx.x >> 6;
-  if (lane_id() == 0) {
-#pragma unroll
-    for (int k = 0; k < 28; ++k) s_part[wave][k] = acc[k];
-  }
-  __syncthreads();
-  if (threadIdx.x < 28) {
-    double t = 0;
-    for (int w = 0; w < LM_SOLVE_BLOCK / 64; ++w) t += s_part[w][threadIdx.x];
-    s_out[threadIdx.x] = t;
-  }
-  __syncthreads();
-}
-
 // grid (slots): scan2MapOptimization's solver part
 __global__ void __launch_bounds__(LM_SOLVE_BLOCK) lm_solve(DevCtx d, LmCtx L) {
   const int slot = blockIdx.x + d.slot0;
@@ -420,7 +403,9 @@ __global__ void __launch_bounds__(LM_SOLVE_BLOCK) lm_solve(DevCtx d, LmCtx L) {
     if (threadIdx.x == 0) { li[LI_FLAGS] |= 16; li[LI_NCC] = 0; li[LI_NSC] = 0; li[LI_SUM0] = 0; li[LI_SUM1] = 0; }
     return;
   }
-  __shared__ double s_part[LM_SOLVE_BLOCK / 64][28];
+  extern __shared__ __attribute__((aligned(16))) unsigned char lm_smem[];
+  double* s_acc = reinterpret_cast<double*>(lm_smem);                // [28][LM_SOLVE_BLOCK]
+  double* s_seg = s_acc + 28 * LM_SOLVE_BLOCK;                        // [28][LM_SOLVE_BLOCK/32]
   __shared__ double s_out[28];
   __shared__ LmState S;
   __shared__ int s_action, s_cnt[2][LM_SOLVE_BLOCK / 64];
@@ -474,7 +459,7 @@ __global__ void __launch_bounds__(LM_SOLVE_BLOCK) lm_solve(DevCtx d, LmCtx L) {
 #ifdef ALEGO_TIMING
     tm[1] += clock64() - c1_;
 #endif
-    TM(2, lm_block_reduce28(acc, s_part, s_out));
+    TM(2, block_reduce28_lds<LM_SOLVE_BLOCK>(acc, s_acc, s_seg, s_out));
   };
   for (int outer = 0; outer < P.lm_outer_iters; ++outer) {  // :360 — identical correspondences both times
     if (R == 0) {  // ceres::Solve on an empty problem is a no-op
@@ -608,6 +593,11 @@ __global__ void __launch_bounds__(LM_BLOCK) lm_store_kf(DevCtx d, LmCtx L) {
   if (blockIdx.x == 0 && threadIdx.x == 0) L.kf_cnt[((size_t)slot * L.K + ring) * 4 + kind] = n;
 }
 
+#define LM_SOLVE_LDS ((size_t)(28 * LM_SOLVE_BLOCK + 28 * (LM_SOLVE_BLOCK / 32)) * sizeof(double))
+int lm_configure() {
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(lm_solve), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LM_SOLVE_LDS) == hipSuccess ? 0 : -1;
+}
+
 // ---- launchers ---------------------------------------------------------------------
 void launch_lm_prepare(const DevCtx& d, const LmCtx& L, int stage, int run_hint, hipStream_t st) {
   ALEGO_LAUNCH(lm_prepare, dim3(8, 3, d.n_launch), dim3(LM_BLOCK), 0, st, d, L, stage, run_hint);
@@ -626,7 +616,7 @@ void launch_lm_grid(const DevCtx& d, const LmCtx& L, hipStream_t st) {
 }
 void launch_lm_register(const DevCtx& d, const LmCtx& L, hipStream_t st) {
   ALEGO_LAUNCH(lm_assoc, dim3((L.qcap + 127) / 128, 2, d.n_launch), dim3(128), 0, st, d, L);
-  ALEGO_LAUNCH(lm_solve, dim3(d.n_launch), dim3(LM_SOLVE_BLOCK), 0, st, d, L);
+  ALEGO_LAUNCH(lm_solve, dim3(d.n_launch), dim3(LM_SOLVE_BLOCK), LM_SOLVE_LDS, st, d, L);
   ALEGO_LAUNCH(lm_finish, dim3((d.n_launch + 63) / 64), dim3(64), 0, st, d, L);
   ALEGO_LAUNCH(lm_store_kf, dim3(8, 3, d.n_launch), dim3(LM_BLOCK), 0, st, d, L);
 }

@@ -100,24 +100,6 @@ __global__ void __launch_bounds__(LO_BLOCK) lo_assoc(DevCtx d, int kind) {
   }
 }
 
-// Block-wide deterministic reduction of acc[28]: wave butterfly, then waves summed in order.
-DEV_INLINE void block_reduce28(double acc[28], double (*s_part)[28], double* s_out) {
-#pragma unroll
-  for (int k = 0; k < 28; ++k) acc[k] = wave_sum_f64(acc[k]);
-  const int wave = threadIdx.x >> 6;
-  if (lane_id() == 0) {
-#pragma unroll
-    for (int k = 0; k < 28; ++k) s_part[wave][k] = acc[k];
-  }
-  __syncthreads();
-  if (threadIdx.x < 28) {
-    double t = 0;
-    for (int w = 0; w < LO_BLOCK / 64; ++w) t += s_part[w][threadIdx.x];
-    s_out[threadIdx.x] = t;
-  }
-  __syncthreads();
-}
-
 // evaluate every valid correspondence row of [row0, row0+n) at pose p
 DEV_INLINE void lo_eval_rows(const DevCtx& d, int slot, int cur, int kind, int n, const PoseTerms& T, double acc[28]) {
   const int last = cur ^ 1;
@@ -145,7 +127,9 @@ __global__ void __launch_bounds__(LO_BLOCK) lo_solve(DevCtx d, int phase) {
   const int cur = cur_in_flight(d, slot);
   int* sc = d.scal + slot * SC_COUNT;
   double* st = d.lo_state + (size_t)slot * LO_STATE_N;
-  __shared__ double s_part[LO_BLOCK / 64][28];
+  extern __shared__ __attribute__((aligned(16))) unsigned char lo_smem[];
+  double* s_acc = reinterpret_cast<double*>(lo_smem);                // [28][LO_BLOCK]
+  double* s_seg = s_acc + 28 * LO_BLOCK;                              // [28][LO_BLOCK/32]
   __shared__ double s_out[28];
   __shared__ LmState S;
   __shared__ int s_action, s_cnt[LO_BLOCK / 64];
@@ -184,7 +168,7 @@ __global__ void __launch_bounds__(LO_BLOCK) lo_solve(DevCtx d, int phase) {
       const PoseTerms T = pose_terms(x);
       lo_eval_rows(d, slot, cur, 0, nq_s, T, acc);
       if (phase == 1) lo_eval_rows(d, slot, cur, 1, nq_c, T, acc);
-      block_reduce28(acc, s_part, s_out);
+      block_reduce28_lds<LO_BLOCK>(acc, s_acc, s_seg, s_out);
     };
     double x0[6];
 #pragma unroll
@@ -248,10 +232,15 @@ __global__ void __launch_bounds__(LO_BLOCK) lo_solve(DevCtx d, int phase) {
   }
 }
 
+#define LO_SOLVE_LDS ((size_t)(28 * LO_BLOCK + 28 * (LO_BLOCK / 32)) * sizeof(double))
+int lo_configure() {
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(lo_solve), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LO_SOLVE_LDS) == hipSuccess ? 0 : -1;
+}
+
 void launch_lo(const DevCtx& d, hipStream_t st) {
   const int wpb = LO_BLOCK / 64;
   ALEGO_LAUNCH(lo_assoc, dim3((d.lo_qcap_surf + wpb - 1) / wpb, d.n_launch), dim3(LO_BLOCK), 0, st, d, 0);
-  ALEGO_LAUNCH(lo_solve, dim3(d.n_launch), dim3(LO_BLOCK), 0, st, d, 0);
+  ALEGO_LAUNCH(lo_solve, dim3(d.n_launch), dim3(LO_BLOCK), LO_SOLVE_LDS, st, d, 0);
   ALEGO_LAUNCH(lo_assoc, dim3((d.lo_qcap_corner + wpb - 1) / wpb, d.n_launch), dim3(LO_BLOCK), 0, st, d, 1);
-  ALEGO_LAUNCH(lo_solve, dim3(d.n_launch), dim3(LO_BLOCK), 0, st, d, 1);
+  ALEGO_LAUNCH(lo_solve, dim3(d.n_launch), dim3(LO_BLOCK), LO_SOLVE_LDS, st, d, 1);
 }
