@@ -178,22 +178,6 @@ DEV_INLINE float d_hypotf(float x, float y) { return (float)sqrt((double)x * (do
 // ---------------------------------------------------------------------------
 // wavefront (64 lanes) helpers
 // ---------------------------------------------------------------------------
-DEV_INLINE unsigned long long wave_max_u64(unsigned long long v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    unsigned long long t = __shfl_xor(v, o, 64);
-    v = t > v ? t : v;
-  }
-  return v;
-}
-DEV_INLINE unsigned long long wave_min_u64(unsigned long long v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    unsigned long long t = __shfl_xor(v, o, 64);
-    v = t < v ? t : v;
-  }
-  return v;
-}
 DEV_INLINE double wave_sum_f64(double v) {  // fixed butterfly order -> deterministic
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -216,5 +200,16 @@ DEV_INLINE uint32_t wave_max_u32(uint32_t v) {
   return ab > ce ? ab : ce;
 }
 DEV_INLINE uint32_t wave_min_u32(uint32_t v) { return ~wave_max_u32(~v); }
+// u64 versions: high word first, then the low word among the lanes that hold the winning high word
+DEV_INLINE unsigned long long wave_max_u64(unsigned long long v) {
+  const uint32_t hi = wave_max_u32((uint32_t)(v >> 32));
+  const uint32_t lo = wave_max_u32((uint32_t)(v >> 32) == hi ? (uint32_t)v : 0u);
+  return ((unsigned long long)hi << 32) | lo;
+}
+DEV_INLINE unsigned long long wave_min_u64(unsigned long long v) {
+  const uint32_t hi = wave_min_u32((uint32_t)(v >> 32));
+  const uint32_t lo = wave_min_u32((uint32_t)(v >> 32) == hi ? (uint32_t)v : 0xFFFFFFFFu);
+  return ((unsigned long long)hi << 32) | lo;
+}
 
 #endif

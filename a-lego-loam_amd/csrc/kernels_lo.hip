@@ -26,77 +26,105 @@ struct WalkBest { double dist; int rank; int idx; };
 DEV_INLINE void walk_consider(WalkBest& b, double dist, int rank, int idx) {
   if (dist < b.dist || (dist == b.dist && rank < b.rank)) { b.dist = dist; b.rank = rank; b.idx = idx; }
 }
+// lexicographic (distance, visiting rank) arg-min over the wavefront: non-negative doubles order like their bit
+// patterns, so this is a u64 min, then a u32 min of the rank among the lanes that hold the winning distance
 DEV_INLINE WalkBest walk_reduce(WalkBest b) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const double od = __shfl_xor(b.dist, o, 64);
-    const int orank = __shfl_xor(b.rank, o, 64), oi = __shfl_xor(b.idx, o, 64);
-    if (od < b.dist || (od == b.dist && orank < b.rank)) { b.dist = od; b.rank = orank; b.idx = oi; }
-  }
-  return b;
+  const unsigned long long bits = (unsigned long long)__double_as_longlong(b.dist);
+  const unsigned long long mn = wave_min_u64(bits);
+  const uint32_t rk = wave_min_u32(bits == mn ? (uint32_t)b.rank : 0xFFFFFFFFu);
+  const uint32_t ix = wave_min_u32((bits == mn && (uint32_t)b.rank == rk) ? (uint32_t)b.idx : 0xFFFFFFFFu);
+  WalkBest r;
+  r.dist = __longlong_as_double((long long)mn); r.rank = (int)rk; r.idx = (int)ix;  // idx -1 (0xFFFFFFFF) = none
+  return r;
 }
 
-// kind 0: flat -> surf_last (less_flat of the previous scan); kind 1: sharp -> corner_last (less_sharp)
+// kind 0: flat -> surf_last (less_flat of the previous scan); kind 1: sharp -> corner_last (less_sharp).
+// A workgroup takes LO_QPB queries of one stream (LO_QPW per wavefront).  The 1-NN pass streams the target cloud
+// through LDS in tiles shared by all queries of the workgroup (each target is read from HBM/L2 once per 16
+// queries instead of once per query, and each LDS read serves LO_QPW queries); the +-2-ring walk then reads the
+// few hundred candidates of the ring interval directly.
+#define LO_QPW 4
+#define LO_QPB (LO_QPW * LO_BLOCK / 64)
+#define LO_TILE 2048
 __global__ void __launch_bounds__(LO_BLOCK) lo_assoc(DevCtx d, int kind) {
   const int slot = blockIdx.y + d.slot0;
   const int cur = cur_in_flight(d, slot);
   const int* sc = d.scal + slot * SC_COUNT;
   if (!sc[SC_LO_INIT]) return;
-  const int q = blockIdx.x * (LO_BLOCK / 64) + (threadIdx.x >> 6);
-  const int lane = lane_id();
+  const int lane = lane_id(), wave = threadIdx.x >> 6;
   const int last = cur ^ 1;
   const int qk = kind == 0 ? F_FLAT : F_SHARP, tk = kind == 0 ? F_LFLAT : F_LSHARP;
   const int nq = d.feat_cnt[((size_t)slot * 2 + cur) * 4 + qk];
-  if (q >= nq) return;
+  if ((int)blockIdx.x * LO_QPB >= nq) return;
   const int nt = d.feat_cnt[((size_t)slot * 2 + last) * 4 + tk];
   const float4* tg = d.feat[tk] + ((size_t)slot * 2 + last) * d.fcap[tk];
   const int* roff = d.ring_off + (((size_t)slot * 2 + last) * 2 + (kind == 0 ? 1 : 0)) * (d.NS + 1);
   const double* params = d.lo_state + (size_t)slot * LO_STATE_N + LS_PARAMS;
-  const float4 pq = d.feat[qk][((size_t)slot * 2 + cur) * d.fcap[qk] + q];
-  float sel[3];
-  transform_to_start(params, pq, sel);
+  __shared__ float4 s_t[LO_TILE];
+  const int q0 = blockIdx.x * LO_QPB + wave * LO_QPW;
+  float sel[LO_QPW][3];
+  unsigned long long best[LO_QPW];
+#pragma unroll
+  for (int j = 0; j < LO_QPW; ++j) {
+    best[j] = ~0ull;
+    sel[j][0] = sel[j][1] = sel[j][2] = 0.f;
+    if (q0 + j < nq) transform_to_start(params, d.feat[qk][((size_t)slot * 2 + cur) * d.fcap[qk] + q0 + j], sel[j]);
+  }
   // exact 1-NN, flann::L2_Simple<float>; ties -> lowest index
-  unsigned long long best = ~0ull;
-  for (int t = lane; t < nt; t += 64) {
-    const float4 a = tg[t];
-    float r = 0.f, df;
-    df = a.x - sel[0]; r += df * df;
-    df = a.y - sel[1]; r += df * df;
-    df = a.z - sel[2]; r += df * df;
-    const unsigned long long c = ((unsigned long long)(uint32_t)d_f2i(r) << 32) | (uint32_t)t;
-    best = c < best ? c : best;
-  }
-  best = wave_min_u64(best);
-  int closest = -1, idx2 = -1, idx3 = -1;
-  const double nfd = d.P.nearest_feature_dist;
-  if (nt > 0 && (double)d_i2f((int32_t)(best >> 32)) < nfd) {
-    closest = (int)(uint32_t)best;
-    const int cr = (int)tg[closest].w;  // int(intensity) = ring (:347,:436)
-    const int W = d.P.ring_window;
-    const int rlo = max(cr - W, 0), rhi = min(cr + W, d.NS - 1);
-    const int lo = roff[rlo], hi = roff[rhi + 1];           // the walks stay inside [lo, hi)
-    const int same_lo = roff[cr], same_hi = roff[cr + 1];
-    WalkBest b2{nfd, 0x7fffffff, -1}, b3{nfd, 0x7fffffff, -1};
-    for (int k = lo + lane; k < hi; k += 64) {
-      if (k == closest) continue;
-      const float4 a = tg[k];
-      const double ex = (double)(a.x - sel[0]), ey = (double)(a.y - sel[1]), ez = (double)(a.z - sel[2]);
-      const double pd = ex * ex + ey * ey + ez * ez;  // pow(f32 diff, 2) summed in double (:354)
-      // visiting order of the reference: closest+1, closest+2, ... then closest-1, closest-2, ...
-      const int rank = k > closest ? k - closest - 1 : (hi - closest - 1) + (closest - 1 - k);
-      const bool same = k >= same_lo && k < same_hi;
-      if (!(pd < nfd)) continue;
-      if (kind == 0) { if (same) walk_consider(b2, pd, rank, k); else walk_consider(b3, pd, rank, k); }
-      else if (!same) walk_consider(b2, pd, rank, k);  // strictly above going up / strictly below going down (:446,:462)
+  for (int t0 = 0; t0 < nt; t0 += LO_TILE) {
+    const int cnt = min(LO_TILE, nt - t0);
+    __syncthreads();
+    for (int i = threadIdx.x; i < cnt; i += LO_BLOCK) s_t[i] = tg[t0 + i];
+    __syncthreads();
+    for (int t = lane; t < cnt; t += 64) {
+      const float4 a = s_t[t];
+#pragma unroll
+      for (int j = 0; j < LO_QPW; ++j) {
+        float r = 0.f, df;
+        df = a.x - sel[j][0]; r += df * df;
+        df = a.y - sel[j][1]; r += df * df;
+        df = a.z - sel[j][2]; r += df * df;
+        const unsigned long long c = ((unsigned long long)(uint32_t)d_f2i(r) << 32) | (uint32_t)(t0 + t);
+        best[j] = c < best[j] ? c : best[j];
+      }
     }
-    b2 = walk_reduce(b2);
-    idx2 = b2.idx;
-    if (kind == 0) { b3 = walk_reduce(b3); idx3 = b3.idx; }
   }
-  if (lane == 0) {
-    int* row = d.lo_corr + ((size_t)slot * (d.lo_qcap_surf + d.lo_qcap_corner) + (kind == 0 ? 0 : d.lo_qcap_surf) + q) * 4;
-    const bool ok = kind == 0 ? (idx2 >= 0 && idx3 >= 0) : (idx2 >= 0);
-    row[0] = q; row[1] = ok ? closest : -1; row[2] = idx2; row[3] = idx3;
+  const double nfd = d.P.nearest_feature_dist;
+#pragma unroll
+  for (int j = 0; j < LO_QPW; ++j) {
+    const int q = q0 + j;
+    if (q >= nq) break;
+    const unsigned long long bj = wave_min_u64(best[j]);
+    int closest = -1, idx2 = -1, idx3 = -1;
+    if (nt > 0 && (double)d_i2f((int32_t)(bj >> 32)) < nfd) {
+      closest = (int)(uint32_t)bj;
+      const int cr = (int)tg[closest].w;  // int(intensity) = ring (:347,:436)
+      const int W = d.P.ring_window;
+      const int rlo = max(cr - W, 0), rhi = min(cr + W, d.NS - 1);
+      const int lo = roff[rlo], hi = roff[rhi + 1];           // the walks stay inside [lo, hi)
+      const int same_lo = roff[cr], same_hi = roff[cr + 1];
+      WalkBest b2{nfd, 0x7fffffff, -1}, b3{nfd, 0x7fffffff, -1};
+      for (int k = lo + lane; k < hi; k += 64) {
+        if (k == closest) continue;
+        const float4 a = tg[k];
+        const double ex = (double)(a.x - sel[j][0]), ey = (double)(a.y - sel[j][1]), ez = (double)(a.z - sel[j][2]);
+        const double pd = ex * ex + ey * ey + ez * ez;  // pow(f32 diff, 2) summed in double (:354)
+        // visiting order of the reference: closest+1, closest+2, ... then closest-1, closest-2, ...
+        const int rank = k > closest ? k - closest - 1 : (hi - closest - 1) + (closest - 1 - k);
+        const bool same = k >= same_lo && k < same_hi;
+        if (!(pd < nfd)) continue;
+        if (kind == 0) { if (same) walk_consider(b2, pd, rank, k); else walk_consider(b3, pd, rank, k); }
+        else if (!same) walk_consider(b2, pd, rank, k);  // strictly above going up / strictly below going down (:446,:462)
+      }
+      b2 = walk_reduce(b2);
+      idx2 = b2.idx;
+      if (kind == 0) { b3 = walk_reduce(b3); idx3 = b3.idx; }
+    }
+    if (lane == 0) {
+      int* row = d.lo_corr + ((size_t)slot * (d.lo_qcap_surf + d.lo_qcap_corner) + (kind == 0 ? 0 : d.lo_qcap_surf) + q) * 4;
+      const bool ok = kind == 0 ? (idx2 >= 0 && idx3 >= 0) : (idx2 >= 0);
+      row[0] = q; row[1] = ok ? closest : -1; row[2] = idx2; row[3] = idx3;
+    }
   }
 }
 
@@ -238,9 +266,8 @@ int lo_configure() {
 }
 
 void launch_lo(const DevCtx& d, hipStream_t st) {
-  const int wpb = LO_BLOCK / 64;
-  ALEGO_LAUNCH(lo_assoc, dim3((d.lo_qcap_surf + wpb - 1) / wpb, d.n_launch), dim3(LO_BLOCK), 0, st, d, 0);
+  ALEGO_LAUNCH(lo_assoc, dim3((d.lo_qcap_surf + LO_QPB - 1) / LO_QPB, d.n_launch), dim3(LO_BLOCK), 0, st, d, 0);
   ALEGO_LAUNCH(lo_solve, dim3(d.n_launch), dim3(LO_BLOCK), LO_SOLVE_LDS, st, d, 0);
-  ALEGO_LAUNCH(lo_assoc, dim3((d.lo_qcap_corner + wpb - 1) / wpb, d.n_launch), dim3(LO_BLOCK), 0, st, d, 1);
+  ALEGO_LAUNCH(lo_assoc, dim3((d.lo_qcap_corner + LO_QPB - 1) / LO_QPB, d.n_launch), dim3(LO_BLOCK), 0, st, d, 1);
   ALEGO_LAUNCH(lo_solve, dim3(d.n_launch), dim3(LO_BLOCK), LO_SOLVE_LDS, st, d, 1);
 }
