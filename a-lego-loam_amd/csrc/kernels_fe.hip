@@ -15,7 +15,8 @@
 #define FE_BLOCK 256
 #define FE_HALO 6
 #define FE_MAXH 4096  // largest horizon_scan supported by the per-ring LDS staging
-#define FE_T 12       // sector elements per lane kept in registers: sectors up to 768 points (4096 / 6 = 683)
+// fe_pick<FE_T>: sector elements per lane kept in registers (sector length <= 64*FE_T): 6 covers 16x1800
+// (<= 300 points per sector), 12 covers horizon_scan 4096 (683)
 
 __global__ void __launch_bounds__(FE_BLOCK) fe_curv(DevCtx d) {
   const int slot = blockIdx.y + d.slot0;
@@ -83,6 +84,7 @@ __global__ void __launch_bounds__(FE_BLOCK) fe_curv(DevCtx d) {
 // one wavefront per (ring, slot).  Dynamic LDS: 8 bytes per ring point (key u32, column u16, flags u8, label i8),
 // so a 16x1800 sensor keeps 10+ rings resident per CU.
 // flag bits: 0 picked, 1 ground, 2 curvature > edge_thres, 3 curvature < surf_thres
+template <int FE_T>
 __global__ void __launch_bounds__(64) fe_pick(DevCtx d) {
   const int slot = blockIdx.y + d.slot0, ring = blockIdx.x, lane = threadIdx.x;
   const size_t base = (size_t)slot * d.N;
@@ -390,7 +392,10 @@ __global__ void __launch_bounds__(FE_BLOCK) fe_gather(DevCtx d) {
 
 void launch_fe(const DevCtx& d, hipStream_t st) {
   ALEGO_LAUNCH(fe_curv, dim3((d.N + FE_BLOCK - 1) / FE_BLOCK, d.n_launch), dim3(FE_BLOCK), 0, st, d);
-  ALEGO_LAUNCH(fe_pick, dim3(d.NS, d.n_launch), dim3(64), (size_t)8 * d.H, st, d);
+  // the longest sector holds at most ceil(H / n_sectors) + 1 points
+  const int sector_max = (d.H + d.P.n_sectors - 1) / (d.P.n_sectors > 0 ? d.P.n_sectors : 1) + 2;
+  if (sector_max <= 64 * 6) { ALEGO_LAUNCH(fe_pick<6>, dim3(d.NS, d.n_launch), dim3(64), (size_t)8 * d.H, st, d); }
+  else { ALEGO_LAUNCH(fe_pick<12>, dim3(d.NS, d.n_launch), dim3(64), (size_t)8 * d.H, st, d); }
   ALEGO_LAUNCH(fe_voxel, dim3(d.NS, d.n_launch), dim3(FE_BLOCK), (size_t)14 * d.H, st, d);
   ALEGO_LAUNCH(fe_gather, dim3(d.NS, d.n_launch), dim3(FE_BLOCK), 0, st, d);
 }

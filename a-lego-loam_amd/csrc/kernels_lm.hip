@@ -156,13 +156,13 @@ __global__ void __launch_bounds__(LM_BLOCK) lm_grid_count(DevCtx d, LmCtx L, int
   const int n = li[LI_KDS_C + m];
   const float4* pts = (m == 0 ? L.map_corner_ds + (size_t)slot * L.map_cap_c : L.map_surf_ds + (size_t)slot * L.map_cap_s);
   int* cs = (fill ? L.cell_cur : L.cell_start) + ((size_t)slot * 2 + m) * (L.gcap + 1);
-  int* cp = L.cell_pts + ((size_t)slot * 2 + m) * L.map_cap_s;
+  float4* cp = L.cell_pts + ((size_t)slot * 2 + m) * L.map_cap_s;
   for (int i = blockIdx.x * LM_BLOCK + threadIdx.x; i < n; i += gridDim.x * LM_BLOCK) {
     const float4 p = pts[i];
     int cx, cy, cz;
     const int c = grid_cell(g, p.x, p.y, p.z, &cx, &cy, &cz);
     const int pos = atomicAdd(&cs[c], 1);
-    if (fill) cp[pos] = i;
+    if (fill) cp[pos] = make_float4(p.x, p.y, p.z, __int_as_float(i));  // cell-sorted copy: one contiguous read per cell run
   }
 }
 
@@ -286,7 +286,7 @@ __global__ void __launch_bounds__(128) lm_assoc(DevCtx d, LmCtx L) {
   const int nmap = li[LI_KDS_C + kind];
   const GridGeom g = L.grid[(size_t)slot * 2 + kind];
   const int* cs = L.cell_start + ((size_t)slot * 2 + kind) * (L.gcap + 1);
-  const int* cp = L.cell_pts + ((size_t)slot * 2 + kind) * L.map_cap_s;
+  const float4* cp = L.cell_pts + ((size_t)slot * 2 + kind) * L.map_cap_s;
   const double* ld = ldp(L, slot);
   double* blk = L.blocks + ((size_t)slot * L.qcap + (kind == 0 ? 0 : L.kf_cap_c) + q) * 8;
   blk[7] = 0.0;
@@ -316,8 +316,8 @@ __global__ void __launch_bounds__(128) lm_assoc(DevCtx d, LmCtx L) {
         if (x0 > x1) continue;
         const int c0 = x0 + g.gx * (y + g.gy * z), c1 = x1 + g.gx * (y + g.gy * z);
         for (int t = cs[c0]; t < cs[c1 + 1]; ++t) {  // the x-run of cells is contiguous in the cell-sorted list
-          const int idx = cp[t];
-          const float4 a = mp[idx];
+          const float4 a = cp[t];
+          const int idx = __float_as_int(a.w);
           float dist = 0.f, df;
           df = sx - a.x; dist += df * df;
           df = sy - a.y; dist += df * df;

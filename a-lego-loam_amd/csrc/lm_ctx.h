@@ -56,7 +56,7 @@ struct LmCtx {
   // uniform grid over the down-sampled maps (index 0 corner, 1 surf)
   GridGeom* grid;                                 // [slot][2]
   int *cell_start, *cell_cur;                     // [slot][2][gcap+1]
-  int* cell_pts;                                  // [slot][2][map_cap_s]
+  float4* cell_pts;                               // [slot][2][map_cap_s] map points in cell order (w = index in the ds map)
   const unsigned* vox_bbox;                       // VoxCtx::bbox of round 1 (jobs slot*5 + {0,1} are the maps)
   // residual blocks
   double* blocks;                                 // [slot][qcap][8]: a/normal (3), b (3), d, type (0 = none)

@@ -45,7 +45,7 @@ struct ProfScope {
 #define ALEGO_LAUNCH(kernel, grid, block, shmem, stream, ...)                 \
   do {                                                                        \
     ProfScope prof_scope_(#kernel, stream);                                   \
-    hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);      \
+    hipLaunchKernelGGL((kernel), grid, block, shmem, stream, __VA_ARGS__);    \
   } while (0)
 
 #endif
