@@ -286,10 +286,39 @@ __global__ void __launch_bounds__(CC_LDS_THREADS) cc_lds(DevCtx d) {
     if (f & 8) ccl_union(parent, v, v + H);
   }
   __syncthreads();
-  for (int v = threadIdx.x; v < N; v += CC_LDS_THREADS) {
-    int r = -1;
-    if (fi[v] & 2) { r = parent[v]; int nx; while (r > (nx = parent[r])) r = nx; }
-    d.parent[base + v] = r;
+  // roots into registers, then the LDS array is reused for the per-root statistics of :282-301
+  // (low 16 bits = size < 65536, high 16 bits = row mask: needs n_scan <= 16, otherwise cc_stats does it)
+  constexpr int PER = (CC_LDS_MAXN + CC_LDS_THREADS - 1) / CC_LDS_THREADS;
+  int rt[PER];
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    const int v = threadIdx.x + k * CC_LDS_THREADS;
+    rt[k] = -1;
+    if (v < N && (fi[v] & 2)) { int r = parent[v], nx; while (r > (nx = parent[r])) r = nx; rt[k] = r; }
+  }
+  __syncthreads();
+  const bool stats = d.NS <= 16;
+  if (stats) {
+#pragma unroll
+    for (int k = 0; k < PER; ++k) { const int v = threadIdx.x + k * CC_LDS_THREADS; if (v < N) parent[v] = 0; }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      const int v = threadIdx.x + k * CC_LDS_THREADS;
+      if (rt[k] >= 0) {  // LDS atomics resolve same-address lanes in hardware; no wave aggregation needed here
+        atomicAdd(&parent[rt[k]], 1);
+        atomicOr((unsigned*)&parent[rt[k]], 1u << (16 + v / H));
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    const int v = threadIdx.x + k * CC_LDS_THREADS;
+    if (v < N) {
+      d.parent[base + v] = rt[k];
+      if (stats && rt[k] == v) { const unsigned w = (unsigned)parent[v]; d.cc_size[base + v] = (int)(w & 0xFFFFu); d.cc_rows[base + v] = (unsigned long long)(w >> 16); }
+    }
   }
 }
 
@@ -477,7 +506,7 @@ void launch_ip(const DevCtx& d, int ring_pos, bool want_labels, hipStream_t st) 
     ALEGO_LAUNCH(cc_runs, dim3((d.H + 127) / 128, d.n_launch), dim3(128), 0, st, d);
     ALEGO_LAUNCH(cc_link, gN, dim3(IP_BLOCK), 0, st, d);
   }
-  ALEGO_LAUNCH(cc_stats, gN, dim3(IP_BLOCK), 0, st, d);
+  if (!(d.N <= CC_LDS_MAXN && d.NS <= 16)) ALEGO_LAUNCH(cc_stats, gN, dim3(IP_BLOCK), 0, st, d);  // cc_lds already produced the statistics
   ALEGO_LAUNCH(ip_rowcount, dim3(d.NS, d.n_launch), dim3(IP_BLOCK), 0, st, d);
   ALEGO_LAUNCH(ip_compact, dim3(d.NS, d.n_launch), dim3(IP_BLOCK), 0, st, d, ring_pos);
   if (want_labels) hipLaunchKernelGGL(ip_labels, gN, dim3(IP_BLOCK), 0, st, d);
