@@ -270,8 +270,26 @@ DEV_INLINE void d_qr53(double A[3][5], double b[5], double x[3]) {
   }
 }
 
-// grid (ceil(qcap/128), 2, slots): one thread per query point
-__global__ void __launch_bounds__(128) lm_assoc(DevCtx d, LmCtx L) {
+// 16-lane row minimum of a u64 (high word, then low word among the winners): every lane of the row gets it
+DEV_INLINE uint32_t row_max_u32(uint32_t v) {
+  int x = (int)v, t;
+  t = __builtin_amdgcn_update_dpp(x, x, 0xB1, 0xF, 0xF, false); x = (uint32_t)t > (uint32_t)x ? t : x;
+  t = __builtin_amdgcn_update_dpp(x, x, 0x4E, 0xF, 0xF, false); x = (uint32_t)t > (uint32_t)x ? t : x;
+  t = __builtin_amdgcn_update_dpp(x, x, 0x141, 0xF, 0xF, false); x = (uint32_t)t > (uint32_t)x ? t : x;
+  t = __builtin_amdgcn_update_dpp(x, x, 0x140, 0xF, 0xF, false); x = (uint32_t)t > (uint32_t)x ? t : x;
+  return (uint32_t)x;
+}
+DEV_INLINE unsigned long long row_min_u64(unsigned long long v) {
+  const uint32_t hi = ~row_max_u32(~(uint32_t)(v >> 32));
+  const uint32_t lo = ~row_max_u32(~((uint32_t)(v >> 32) == hi ? (uint32_t)v : 0xFFFFFFFFu));
+  return ((unsigned long long)hi << 32) | lo;
+}
+
+// grid (LM_ASSOC_GX, 2, slots): 16 lanes (one DPP row) per query, 8 queries per 128-thread workgroup, grid-stride
+// over the queries.  The 16 lanes split the candidates of the 27 surrounding cells, keep a private top-5 each and
+// merge them with five row-wide arg-min rounds; lane 0 of the row then fits the line / plane.
+#define LM_ASSOC_GX 64
+__global__ void __launch_bounds__(128) lm_knn(DevCtx d, LmCtx L) {
   const int slot = blockIdx.z + d.slot0, kind = blockIdx.y;
   const int* li = lip(L, slot);
   if (!li[LI_RUN]) return;
@@ -279,8 +297,6 @@ __global__ void __launch_bounds__(128) lm_assoc(DevCtx d, LmCtx L) {
   // registration guard :350
   if (li[LI_NCUR_C] < P.lm_min_corner || li[LI_NTOTAL] < P.lm_min_surf || li[LI_KDS_C] < P.lm_min_map_corner || li[LI_NKF] == 0) return;
   const int nq = kind == 0 ? li[LI_NCUR_C] : li[LI_NTOTAL_DS];
-  const int q = blockIdx.x * 128 + threadIdx.x;
-  if (q >= nq) return;
   const float4* qp = kind == 0 ? L.cur_corner_ds + (size_t)slot * L.kf_cap_c : L.cur_total_ds + (size_t)slot * L.total_cap;
   const float4* mp = kind == 0 ? L.map_corner_ds + (size_t)slot * L.map_cap_c : L.map_surf_ds + (size_t)slot * L.map_cap_s;
   const int nmap = li[LI_KDS_C + kind];
@@ -288,11 +304,11 @@ __global__ void __launch_bounds__(128) lm_assoc(DevCtx d, LmCtx L) {
   const int* cs = L.cell_start + ((size_t)slot * 2 + kind) * (L.gcap + 1);
   const float4* cp = L.cell_pts + ((size_t)slot * 2 + kind) * L.map_cap_s;
   const double* ld = ldp(L, slot);
-  double* blk = L.blocks + ((size_t)slot * L.qcap + (kind == 0 ? 0 : L.kf_cap_c) + q) * 8;
-  blk[7] = 0.0;
+  const DQuat qm = ldq(ld + LD_Q_M2L);
+  const int sub = threadIdx.x & 15;
+  for (int q = blockIdx.x * 8 + (threadIdx.x >> 4); q < nq; q += gridDim.x * 8) {
   const float4 pin = qp[q];
   // pointAssociateToMap laserMapping.h:187-194 (pose predicted from odometry)
-  const DQuat qm = ldq(ld + LD_Q_M2L);
   const double vin[3] = {pin.x, pin.y, pin.z};
   double r[3];
   dq_rotate(qm, vin, r);
@@ -302,7 +318,6 @@ __global__ void __launch_bounds__(128) lm_assoc(DevCtx d, LmCtx L) {
   int bi[5];
 #pragma unroll
   for (int k = 0; k < 5; ++k) { bd[k] = 3.402823466e+38f; bi[k] = 0x7fffffff; }
-  int found = 0;
   if (nmap >= 5) {
     int cx, cy, cz;
     grid_cell(g, sx, sy, sz, &cx, &cy, &cz);
@@ -315,7 +330,8 @@ __global__ void __launch_bounds__(128) lm_assoc(DevCtx d, LmCtx L) {
         const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.gx - 1);
         if (x0 > x1) continue;
         const int c0 = x0 + g.gx * (y + g.gy * z), c1 = x1 + g.gx * (y + g.gy * z);
-        for (int t = cs[c0]; t < cs[c1 + 1]; ++t) {  // the x-run of cells is contiguous in the cell-sorted list
+        const int tend = cs[c1 + 1];
+        for (int t = cs[c0] + sub; t < tend; t += 16) {  // the x-run of cells is contiguous in the cell-sorted copy
           const float4 a = cp[t];
           const int idx = __float_as_int(a.w);
           float dist = 0.f, df;
@@ -331,13 +347,58 @@ __global__ void __launch_bounds__(128) lm_assoc(DevCtx d, LmCtx L) {
                 const int ti = bi[k]; bi[k] = bi[k - 1]; bi[k - 1] = ti;
               }
             }
-            ++found;
           }
         }
       }
     }
   }
-  if (found < 5 || !((double)bd[4] < P.knn_max_dist)) return;
+  // merge the 16 private lists: five rounds of "smallest head of the row"
+  {
+    float rd[5];
+    int ri[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      const unsigned long long head = ((unsigned long long)(uint32_t)d_f2i(bd[0]) << 32) | (uint32_t)bi[0];
+      const unsigned long long m = row_min_u64(head);
+      rd[k] = d_i2f((int32_t)(m >> 32)); ri[k] = (int)(uint32_t)m;
+      if (head == m && bi[0] != 0x7fffffff) {  // the winner pops its head
+        bd[0] = bd[1]; bd[1] = bd[2]; bd[2] = bd[3]; bd[3] = bd[4]; bd[4] = 3.402823466e+38f;
+        bi[0] = bi[1]; bi[1] = bi[2]; bi[2] = bi[3]; bi[3] = bi[4]; bi[4] = 0x7fffffff;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 5; ++k) { bd[k] = rd[k]; bi[k] = ri[k]; }
+  }
+  // neighbour indices (ascending distance) for lm_fit; idx[0] < 0 = rejected (:376,:426)
+  if (sub == 0) {
+    int* kn = L.knn + ((size_t)slot * L.qcap + (kind == 0 ? 0 : L.kf_cap_c) + q) * 5;
+    const bool ok = bi[4] != 0x7fffffff && (double)bd[4] < P.knn_max_dist;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) kn[k] = ok ? bi[k] : -1;
+  }
+  }
+}
+
+// grid (ceil(qcap/128), 2, slots): one thread per query: 3x3 scatter eigen-decomposition (line) or 5x3 Householder
+// least squares (plane) on the five neighbours found by lm_knn
+__global__ void __launch_bounds__(128) lm_fit(DevCtx d, LmCtx L) {
+  const int slot = blockIdx.z + d.slot0, kind = blockIdx.y;
+  const int* li = lip(L, slot);
+  if (!li[LI_RUN]) return;
+  const alego_params& P = d.P;
+  if (li[LI_NCUR_C] < P.lm_min_corner || li[LI_NTOTAL] < P.lm_min_surf || li[LI_KDS_C] < P.lm_min_map_corner || li[LI_NKF] == 0) return;
+  const int nq = kind == 0 ? li[LI_NCUR_C] : li[LI_NTOTAL_DS];
+  const int q = blockIdx.x * 128 + threadIdx.x;
+  if (q >= nq) return;
+  const float4* mp = kind == 0 ? L.map_corner_ds + (size_t)slot * L.map_cap_c : L.map_surf_ds + (size_t)slot * L.map_cap_s;
+  const int* kn = L.knn + ((size_t)slot * L.qcap + (kind == 0 ? 0 : L.kf_cap_c) + q) * 5;
+  double* blk = L.blocks + ((size_t)slot * L.qcap + (kind == 0 ? 0 : L.kf_cap_c) + q) * 8;
+  int bi[5];
+#pragma unroll
+  for (int k = 0; k < 5; ++k) bi[k] = kn[k];
+  blk[7] = 0.0;
+  do {
+    if (bi[0] < 0) break;
   if (kind == 0) {  // :378-411
     double near[5][3], center[3] = {0, 0, 0};
 #pragma unroll
@@ -390,6 +451,7 @@ __global__ void __launch_bounds__(128) lm_assoc(DevCtx d, LmCtx L) {
       blk[7] = 3.0;  // BLK_PLANE
     }
   }
+  } while (false);
 }
 
 // grid (slots): scan2MapOptimization's solver part
@@ -615,7 +677,8 @@ void launch_lm_grid(const DevCtx& d, const LmCtx& L, hipStream_t st) {
   ALEGO_LAUNCH(lm_grid_count, dim3(32, 2, d.n_launch), dim3(LM_BLOCK), 0, st, d, L, 1);
 }
 void launch_lm_register(const DevCtx& d, const LmCtx& L, hipStream_t st) {
-  ALEGO_LAUNCH(lm_assoc, dim3((L.qcap + 127) / 128, 2, d.n_launch), dim3(128), 0, st, d, L);
+  ALEGO_LAUNCH(lm_knn, dim3(LM_ASSOC_GX, 2, d.n_launch), dim3(128), 0, st, d, L);
+  ALEGO_LAUNCH(lm_fit, dim3((L.qcap + 127) / 128, 2, d.n_launch), dim3(128), 0, st, d, L);
   ALEGO_LAUNCH(lm_solve, dim3(d.n_launch), dim3(LM_SOLVE_BLOCK), LM_SOLVE_LDS, st, d, L);
   ALEGO_LAUNCH(lm_finish, dim3((d.n_launch + 63) / 64), dim3(64), 0, st, d, L);
   ALEGO_LAUNCH(lm_store_kf, dim3(8, 3, d.n_launch), dim3(LM_BLOCK), 0, st, d, L);

@@ -103,9 +103,9 @@ def cpu_baseline(p, seconds=12.0, prime=560, max_scans=1400):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--streams", type=int, default=64, help="independent streams resident per GPU")
+    ap.add_argument("--streams", type=int, default=256, help="independent streams resident per GPU")
     ap.add_argument("--ring", type=int, default=48, help="scans kept in HBM per stream (replayed back and forth)")
     ap.add_argument("--prime", type=int, default=560, help="untimed scans per stream to fill the 50-key-frame local map")
     ap.add_argument("--no-cpu", action="store_true")
