@@ -21,7 +21,7 @@ EXPORTS = [
     "alego_create", "alego_destroy", "alego_last_error", "alego_device_count", "alego_params_sizeof",
     "alego_ip_process", "alego_lo_process", "alego_lm_process", "alego_scan_process",
     "alego_batch_load", "alego_batch_run", "alego_synchronize", "alego_batch_get_pose", "alego_batch_get_counts",
-    "alego_stream", "alego_profile_enable", "alego_profile_report", "alego_set_lo_params", "alego_set_lm_params", "alego_debug_get", "alego_debug_atan2f",
+    "alego_stream", "alego_profile_enable", "alego_profile_report", "alego_set_lo_params", "alego_set_lm_params", "alego_debug_get", "alego_debug_voxel", "alego_debug_atan2f",
 ]
 
 REPLAY_PINGPONG = 0x100
@@ -106,6 +106,8 @@ def lib():
         L.alego_set_lm_params.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.alego_debug_get.restype = C.c_int
         L.alego_debug_get.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.alego_debug_voxel.restype = C.c_int
+        L.alego_debug_voxel.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_int]
         L.alego_debug_atan2f.restype = C.c_int
         L.alego_debug_atan2f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         if L.alego_params_sizeof() != C.sizeof(AlegoParams):
@@ -297,6 +299,13 @@ class Handle:
         dtype = np.dtype(_DT[dt.value])
         out = np.frombuffer(buf.tobytes()[:cnt.value * dtype.itemsize], dtype=dtype).copy()
         return out.reshape(-1, 4) if (name in _CLOUDS or name.startswith("lm_") and name.endswith(("_ds", "_map"))) else out
+
+    def voxel_grid(self, pts, leaf):
+        """The device VoxelGrid on a host cloud (debug entry; both the LDS path and the bucket-sort path)."""
+        a = np.ascontiguousarray(pts, np.float32)
+        out = np.empty((max(a.shape[0], 1), 4), np.float32)
+        n = self._check(lib().alego_debug_voxel(self._h, a.ctypes.data, a.shape[0], leaf, out.ctypes.data, out.shape[0]), "alego_debug_voxel")
+        return out[:n].copy()
 
     def atan2f(self, y, x):
         y = np.ascontiguousarray(y, np.float32)

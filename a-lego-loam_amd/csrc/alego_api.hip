@@ -14,6 +14,7 @@
 #include "dev_common.h"
 #include "lm_host.h"
 #include "prof.h"
+#include "voxel.h"
 
 thread_local Profiler* g_prof = nullptr;
 
@@ -398,6 +399,31 @@ int alego_profile_report(alego_handle* h, char* names, int names_cap, double* to
   std::memcpy(names, joined.c_str(), joined.size() + 1);
   for (int i = 0; i < nk; ++i) { total_ms[i] = tot[i]; launches[i] = cnt[i]; }
   return nk;
+}
+
+int alego_debug_voxel(alego_handle* h, const alego_point* pts, int n, float leaf, alego_point* out, int cap) {
+  if (!h || n < 0) return ALEGO_ERR_ARG;
+  hipSetDevice(h->device);
+  g_prof = &h->prof;
+  float4 *din = nullptr, *dout = nullptr;
+  int* cnt = nullptr;
+  const int c = n > 0 ? n : 1;
+  HIP_TRY(h, hipMalloc((void**)&din, (size_t)c * 16)); HIP_TRY(h, hipMalloc((void**)&dout, (size_t)c * 16)); HIP_TRY(h, hipMalloc((void**)&cnt, 8));
+  const int hc[2] = {n, 0};
+  HIP_TRY(h, hipMemcpy(cnt, hc, 8, hipMemcpyHostToDevice));
+  if (n) HIP_TRY(h, hipMemcpy(din, pts, (size_t)n * 16, hipMemcpyHostToDevice));
+  VoxJob job{din, cnt, dout, cnt + 1, nullptr, leaf, c, 0, 0, 0};
+  VoxCtx V;
+  if (vox_create(&V, &job, 1, &h->err)) return ALEGO_ERR_HIP;
+  int rc = vox_run(V, h->stream, &h->err);
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  int nout = 0;
+  HIP_TRY(h, hipMemcpy(&nout, cnt + 1, 4, hipMemcpyDeviceToHost));
+  if (rc == 0 && nout > cap) { h->err = "debug_voxel: output capacity"; rc = ALEGO_ERR_CAPACITY; }
+  if (rc == 0 && nout) HIP_TRY(h, hipMemcpy(out, dout, (size_t)nout * 16, hipMemcpyDeviceToHost));
+  vox_destroy(&V);
+  hipFree(din); hipFree(dout); hipFree(cnt);
+  return rc ? rc : nout;
 }
 
 int alego_debug_atan2f(alego_handle* h, const float* y, const float* x, float* out, int n) {

@@ -151,6 +151,9 @@ int alego_set_lm_params(alego_handle* h, int slot, const double* p6);
  * dtype: 0 f32, 1 f64, 2 i32, 3 u8.  Names mirror oracle_get(). */
 int alego_debug_get(alego_handle* h, int slot, const char* name, void* out, int cap_bytes,
                     int* count, int* dtype);
+/* the device pcl::VoxelGrid replacement on a host cloud (both the one-launch LDS path for <= 8192 points and the
+ * multi-kernel bucket-sort path), for direct parity tests against the oracle; returns the output count */
+int alego_debug_voxel(alego_handle* h, const alego_point* pts, int n, float leaf, alego_point* out, int cap);
 /* device atan2f / hypotf used by the projection kernel, for the libm-equivalence test */
 int alego_debug_atan2f(alego_handle* h, const float* y, const float* x, float* out, int n);
 

@@ -256,3 +256,83 @@ def test_lm_process_host_entry(params_a):
         assert np.abs(mp["t"] - want[:3]).max() < POSE_TOL
         np.testing.assert_allclose(mp["params"], o.get("lm_params"), rtol=0, atol=1e-5)
     h.close()
+
+
+@pytest.mark.parametrize("n,leaf,kind", [(0, 0.4, "gauss"), (1, 0.4, "gauss"), (37, 0.4, "gauss"), (3000, 0.4, "gauss"), (8192, 0.8, "gauss"),
+                                         (8193, 0.8, "gauss"), (60000, 0.4, "gauss"), (60000, 0.8, "dense"), (120000, 0.8, "wall"),
+                                         (5000, 0.001, "gauss"), (20000, 50.0, "gauss")])
+def test_device_voxel_grid_bit_exact(params_a, n, leaf, kind):
+    """Both device VoxelGrid paths (one-launch LDS path up to 8192 points, bucket-sort path above) against the
+    oracle's restatement of pcl::VoxelGrid: small, large, skewed (thousands of points in one voxel), leaf too small
+    (PCL returns the input) and leaf larger than the cloud (a single voxel)."""
+    h = binding.Handle(params_a)
+    rng = np.random.default_rng(n + int(leaf * 1000))
+    if kind == "gauss":
+        pts = (rng.standard_normal((n, 4)) * [6, 6, 1.5, 1]).astype(np.float32)
+    elif kind == "dense":  # most points in a handful of voxels
+        pts = (rng.standard_normal((n, 4)) * [0.5, 0.5, 0.2, 1]).astype(np.float32)
+        pts[: n // 10] *= np.float32(20)
+    else:  # a planar wall revisited many times (map-like duplicates)
+        base = (rng.random((n // 40, 4)) * [30, 0.05, 5, 1]).astype(np.float32)
+        pts = (np.repeat(base, 40, axis=0) + rng.standard_normal((n // 40 * 40, 4)).astype(np.float32) * np.float32(0.01))
+    assert_bit_equal(h.voxel_grid(pts, leaf), O.voxel_grid(pts, leaf), f"device voxel grid n={n} leaf={leaf} {kind}")
+    h.close()
+
+
+def test_full_loop_reference_geometry_16x4000():
+    """Reference geometry 16 x 4000 (utility.h:50-55): global-memory union-find path, fe_pick<12>."""
+    p = synth.default_params(16, 0)
+    h, o = binding.Handle(p), O.Oracle(p)
+    for k in range(8):
+        pts = synth.scan(p, k)
+        h.set_lo_params(o.get("lo_params"))
+        h.set_lm_params(o.get("lm_params"))
+        o.process_scan(pts)
+        flags, odom, mp, seg, feat = h.scan_process(pts, stages=7, want_outputs=True)
+        assert_bit_equal(seg["label_image"], o.get("label_img"), f"16x4000 scan {k} labels")
+        assert_bit_equal(feat["less_flat"], o.get("less_flat"), f"16x4000 scan {k} less_flat")
+        if k == 0:
+            continue
+        _lm_compare(h, o, k, f"16x4000 scan {k}")
+        want = o.get("map_pose")
+        assert np.abs(mp["t"] - want[:3]).max() < POSE_TOL and quat_angle(mp["q"], want[3:]) < POSE_TOL
+    h.close()
+
+
+def test_batch_full_loop_equals_single_stream(params_a):
+    """Slots advanced in lock-step through IP -> LO -> LM (batch path) give bit-identical poses to one-slot handles."""
+    p = params_a
+    nslot, nscan = 3, 30
+    hb = binding.Handle(p, n_slots=nslot, ring_len=nscan)
+    for s in range(nslot):
+        for k in range(nscan):
+            hb.batch_load(s, k, synth.scan(p, k, stream=s))
+    hb.batch_run(0, nscan, stages=7)
+    for s in range(nslot):
+        h1 = binding.Handle(p)
+        for k in range(nscan):
+            _, odom1, mp1 = h1.scan_process(synth.scan(p, k, stream=s), stages=7)
+        _, odomb, mpb = hb.batch_get_pose(s)
+        assert_bit_equal(mpb["t"], mp1["t"], f"slot {s} map translation")
+        assert_bit_equal(mpb["q"], mp1["q"], f"slot {s} map rotation")
+        assert_bit_equal(mpb["params"], mp1["params"], f"slot {s} LM params_")
+        h1.close()
+    hb.close()
+
+
+def test_degenerate_scans_do_not_break_the_loop(params_a):
+    """Empty and tiny scans take the reference's guard paths (few correspondences, few features) on both sides."""
+    p = params_a
+    h, o = binding.Handle(p), O.Oracle(p)
+    seq = [synth.scan(p, 0), synth.scan(p, 1), synth.scan(p, 2)[:0], synth.scan(p, 3)[:500], synth.scan(p, 4), synth.scan(p, 5)]
+    for k, pts in enumerate(seq):
+        o.process_scan(pts)
+        flags, odom, mp = h.scan_process(pts, stages=7)
+        if k == 0:
+            continue
+        info = o.get("lo_solve_info")
+        assert bool(flags & binding.FLAG_FEW_SURF) == (info[6] < p.lo_min_corr), (k, flags, info)
+        assert bool(flags & binding.FLAG_FEW_CORNER) == (info[7] < p.lo_min_corr), (k, flags, info)
+        want = o.get("map_pose")
+        assert np.abs(mp["t"] - want[:3]).max() < POSE_TOL, (k, mp["t"], want[:3])
+    h.close()
