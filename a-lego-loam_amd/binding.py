@@ -263,7 +263,7 @@ class Handle:
     def batch_get_counts(self, slot=0):
         out = np.zeros(16, np.int32)
         self._check(lib().alego_batch_get_counts(self._h, slot, out.ctypes.data, 16), "alego_batch_get_counts")
-        keys = ["P", "M", "O", "Qc", "Fc", "Qs", "Fs", "n_surf_corr", "n_corner_corr", "Kraw_c", "Kraw_s", "Kds_c", "Kds_s", "Lc", "Ls"]
+        keys = ["P", "M", "O", "Qc", "Fc", "Qs", "Fs", "n_surf_corr", "n_corner_corr", "Kraw_c", "Kraw_s", "Kds_c", "Kds_s", "Lc", "Ls", "n_rebuild"]
         return dict(zip(keys, out.tolist()))
 
     def profile_enable(self, on=True):

@@ -264,7 +264,7 @@ int alego_batch_get_counts(alego_handle* h, int slot, int32_t* out, int cap) {
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   const int cur = sc[SC_CUR];  // buffer written by the last processed scan
   int v[16] = {sc[SC_PVALID], sc[SC_M], sc[SC_NOUT], fc[cur * 4 + 0], fc[cur * 4 + 1], fc[cur * 4 + 2], fc[cur * 4 + 3],
-               sc[SC_LO_NSURF], sc[SC_LO_NCORNER], 0, 0, 0, 0, 0, 0, 0};
+               sc[SC_LO_NSURF], sc[SC_LO_NCORNER], 0, 0, 0, 0, 0, 0, 0};  // v[15] = map rebuilds so far
   lm_host_get_counts(h->lm, slot, v + 9);
   for (int i = 0; i < cap && i < 16; ++i) out[i] = v[i];
   return 0;

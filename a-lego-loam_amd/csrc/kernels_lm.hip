@@ -65,7 +65,7 @@ __global__ void __launch_bounds__(LM_BLOCK) lm_prepare(DevCtx d, LmCtx L, int st
   li[LI_RUN] = run;
   if (run_hint >= 0 && run != run_hint) li[LI_OVERFLOW] = 2;  // host launch-skipping logic out of sync
   if (!run) { li[LI_FLAGS] = 8; return; }
-  if (li[LI_NKF] > 0 && li[LI_DIRTY]) { li[LI_REBUILD] = 1; li[LI_DIRTY] = 0; }
+  if (li[LI_NKF] > 0 && li[LI_DIRTY]) { li[LI_REBUILD] = 1; li[LI_DIRTY] = 0; li[LI_NREBUILD] += 1; }
 }
 
 // grid (16, K, slots): chronological concatenation of the key-frame ring

@@ -17,6 +17,7 @@ enum {
   LI_NIN_C, LI_NIN_S, LI_NIN_O,          // staged inputs (/corner_last, /surf_last, /outlier)
   LI_NCUR_C, LI_NCUR_S, LI_NCUR_O,       // laser_corner_ds_, laser_surf_ds_, laser_outlier_ds_
   LI_NTOTAL, LI_NTOTAL_DS,               // laser_surf_total_, laser_surf_total_ds_
+  LI_NREBUILD,     // map rebuilds so far (bench: expected work of the map VoxelGrid kernels)
   LI_OVERFLOW,     // a capacity was exceeded (clouds truncated): reported as an error by the host
   LI_COUNT = 32
 };

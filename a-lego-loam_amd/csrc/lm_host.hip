@@ -198,10 +198,10 @@ int lm_host_get_flags(LmHost* lm, int slot) {
   if (li[LI_OVERFLOW]) return ALEGO_ERR_CAPACITY;
   return li[LI_FLAGS];
 }
-void lm_host_get_counts(LmHost* lm, int slot, int* o) {
+void lm_host_get_counts(LmHost* lm, int slot, int* o) {  // o[7]
   int li[LI_COUNT];
   (void)hipMemcpy(li, lm->L.li + (size_t)slot * LI_COUNT, sizeof(li), hipMemcpyDeviceToHost);
-  o[0] = li[LI_KRAW_C]; o[1] = li[LI_KRAW_S]; o[2] = li[LI_KDS_C]; o[3] = li[LI_KDS_S]; o[4] = li[LI_NCUR_C]; o[5] = li[LI_NTOTAL_DS];
+  o[0] = li[LI_KRAW_C]; o[1] = li[LI_KRAW_S]; o[2] = li[LI_KDS_C]; o[3] = li[LI_KDS_S]; o[4] = li[LI_NCUR_C]; o[5] = li[LI_NTOTAL_DS]; o[6] = li[LI_NREBUILD];
 }
 
 int lm_host_debug_get(LmHost* lm, int slot, const char* name, void* out, int cap_bytes, int* count, int* dtype, std::string* err) {

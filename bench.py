@@ -40,30 +40,45 @@ def algorithmic_bytes(c, NS):
     return dict(B_IP=b_ip, B_FE=b_fe, B_LO=b_lo, B_LM=b_lm, B_scan=b_ip + b_fe + b_lo + b_lm / 2)
 
 
-def kernel_bytes(name, c, NS, H):
-    """Algorithmic (compulsory) HBM bytes one launch of `name` moves for ONE stream (DESIGN.md §kernels).
-    Arrays a kernel only re-reads from a producer in the same stage are charged to it as well, so the
-    per-kernel figures sum to more than B_scan; intermediates never count twice inside one kernel."""
+def kernel_bytes(name, c, NS, H, rebuilds_per_launch=0.0):
+    """Algorithmic (compulsory) HBM bytes one launch of `name` moves for ONE stream (DESIGN.md §4).
+    Arrays a kernel only re-reads from a producer in the same stage are charged to it as well, so the per-kernel
+    figures sum to more than B_scan.  The map VoxelGrid kernels only work for the streams whose key-frame set
+    changed: their bytes are scaled by the measured rebuilds per launch."""
+    name = name.split("<")[0]
     N, P, M = NS * H, c["P"], c["M"]
     feats = c["Qc"] + c["Fc"] + c["Qs"] + c["Fs"]
     kraw, kds = c["Kraw_c"] + c["Kraw_s"], c["Kds_c"] + c["Kds_s"]
     L = c["Lc"] + c["Ls"]
+    scan_pts = c["Fc"] + c["Fs"] + c["O"] + c["Ls"]  # points of the four current-scan VoxelGrid jobs
+    rb = rebuilds_per_launch
     t = {
         "ip_reset": 4 * N, "ip_project": 16 * P + 4 * P, "ip_image": 4 * N + 16 * P + 5 * N,
-        "cc_edges": 5 * N + 17 * N, "cc_link": N + 8 * N, "cc_stats": 5 * N + 4 * N,
+        "cc_edges": 5 * N + 17 * N, "cc_lds": N + 4 * N + 12 * N, "cc_runs": 5 * N, "cc_link": N + 8 * N, "cc_stats": 5 * N + 4 * N,
         "ip_rowcount": 5 * N, "ip_compact": 9 * N + 16 * M + 25 * M + 16 * c["O"], "ip_labels": 9 * N,
         "fe_curv": 8 * M + 5 * M, "fe_pick": 14 * M + 4 * M + 4 * (feats + M), "fe_voxel": 20 * M + 16 * c["Fs"],
         "fe_gather": 20 * (c["Qc"] + c["Fc"] + c["Qs"]) + 32 * c["Fs"],
-        "lo_assoc": 16 * (c["Fc"] + c["Fs"] + c["Qc"] + c["Qs"]) + 16 * (c["Qc"] + c["Qs"]),
+        "lo_assoc": 16 * (c["Fc"] + c["Fs"] + c["Qc"] + c["Qs"]) / 2 + 16 * (c["Qc"] + c["Qs"]) / 2,
         "lo_solve": 16 * (c["Qc"] + c["Qs"]) + 64 * (c["Qc"] + c["Qs"]) + 104,
-        "lm_prepare": 32 * (c["Fc"] + c["Fs"] + c["O"]), "lm_concat": 32 * kraw, "lm_total": 32 * c["Ls"],
-        "vox_bbox": 16 * (kraw + c["Fc"] + c["Fs"]), "vox_keys": 24 * (kraw + c["Fc"] + c["Fs"]),
-        "rocprim_segmented_radix_sort": 16 * (kraw + c["Fc"] + c["Fs"]) * 4, "vox_heads": 4 * (kraw + c["Fc"] + c["Fs"]),
-        "vox_centroid": 24 * (kraw + c["Fc"] + c["Fs"]) + 16 * (kds + L),
-        "lm_grid_count": 20 * kds, "lm_assoc": 16 * L + 27 * 16 * 8 * L + 64 * L, "lm_solve": 80 * L + 104,
-        "lm_store_kf": 32 * L,
+        "lm_prepare": 32 * (c["Fc"] + c["Fs"] + c["O"]), "lm_concat": 32 * kraw * rb, "lm_total": 32 * c["Ls"],
+        "vox_small": 16 * scan_pts / 2 + 16 * L / 2,
+        "vox_bbox": 16 * kraw * rb, "vox_keys": 20 * kraw * rb, "vox_bscatter": 12 * kraw * rb, "vox_bsort": 16 * kraw * rb,
+        "vox_bcentroid": (24 * kraw + 16 * kds) * rb, "vox_bscan": 0, "vox_vscan": 0,
+        "lm_grid_count": 20 * kds * rb, "lm_knn": 16 * L + 16 * kds + 20 * L, "lm_fit": 20 * L + 5 * 16 * L + 64 * L,
+        "lm_solve": 80 * L + 104, "lm_store_kf": 32 * L,
     }
     return t.get(name)
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/r01_pmc_traffic.json, 256 streams)."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)["kernels"]
+        return d.get(kernel.split("<")[0], {}).get("hbm_bytes_per_launch")
+    except (OSError, ValueError, KeyError):
+        return None
 
 
 def gen_scans(p, n_streams, ring, rank):
@@ -149,6 +164,7 @@ def main():
     dt = D.max_over_ranks(dt, dist, device="cuda")
     counts = h.batch_get_counts(0)
     flags, odom, mp = h.batch_get_pose(0)
+    rebuilds0 = sum(h.batch_get_counts(s)["n_rebuild"] for s in range(B))
 
     roof, kern, single = None, None, None
     if rank == 0 and not args.no_profile:
@@ -161,12 +177,16 @@ def main():
         kern = {k: dict(ms_total=round(v[0], 3), launches=v[1], avg_us=round(1e3 * v[0] / max(v[1], 1), 2),
                         share=round(v[0] / tot, 4)) for k, v in sorted(rep.items(), key=lambda kv: -kv[1][0])}
         dom = next(iter(kern))
-        kb = kernel_bytes(dom, counts, p.n_scan, p.horizon_scan)
+        rebuilds = sum(h.batch_get_counts(s)["n_rebuild"] for s in range(B)) - rebuilds0
+        rb = rebuilds / max(kern[dom]["launches"], 1) / B  # per launch and stream
+        kb = kernel_bytes(dom, counts, p.n_scan, p.horizon_scan, rb)
         if kb is not None:
             ach = kb * B / (kern[dom]["avg_us"] * 1e-6)
+            tr = pmc_traffic(dom) if B == 256 else None
             roof = dict(bound="hbm", kernel=dom, achieved=round(ach / 1e9, 3), peak=HBM_PEAK / 1e9, unit="GB/s",
-                        frac=round(ach / HBM_PEAK, 6), traffic=None,
-                        algorithmic_bytes_per_launch=int(kb * B), avg_launch_us=kern[dom]["avg_us"])
+                        frac=round(ach / HBM_PEAK, 6), traffic=tr,
+                        algorithmic_bytes_per_launch=int(kb * B), avg_launch_us=kern[dom]["avg_us"],
+                        map_rebuilds_per_launch=round(rebuilds / max(kern[dom]["launches"], 1), 2))
     value = D.aggregate_scans_per_s(world, B, args.steps, dt)
     out = {
         "metric": "scans/sec (16x1800 LiDAR) full IP->LO->LM loop", "value": round(value, 1), "unit": "scans/s",

@@ -132,7 +132,8 @@ int alego_synchronize(alego_handle* h);
 int alego_batch_get_pose(alego_handle* h, int slot, alego_pose* odom, alego_pose* map_pose);
 /* per-scan device counters of the last processed scan of `slot`:
  * out[0..] = P (valid input points), M, n_outlier, n_sharp, n_less_sharp, n_flat, n_less_flat,
- *            n_surf_corr, n_corner_corr, lm: Kraw_corner, Kraw_surf, Kds_corner, Kds_surf, Lc, Ls */
+ *            n_surf_corr, n_corner_corr, lm: Kraw_corner, Kraw_surf, Kds_corner, Kds_surf, Lc, Ls,
+ *            map rebuilds so far */
 int alego_batch_get_counts(alego_handle* h, int slot, int32_t* out, int cap);
 /* the HIP stream (hipStream_t) the handle enqueues on, for event timing by the caller */
 void* alego_stream(alego_handle* h);
