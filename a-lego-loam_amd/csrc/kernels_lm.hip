@@ -507,16 +507,33 @@ __global__ void __launch_bounds__(LM_SOLVE_BLOCK) lm_solve(DevCtx d, LmCtx L) {
 #ifdef ALEGO_TIMING
     const long long c1_ = clock64();
 #endif
-    for (int i = threadIdx.x; i < nqc + nqs; i += LM_SOLVE_BLOCK) {
+    // software-pipelined: the (unconditional) loads of row i+1 are issued before row i is evaluated
+    struct Row { double4 lo, hi; float4 pc; };
+    auto load_row = [&](int i) {
+      Row r;
       const bool is_c = i < nqc;
-      const double* b = blocks + (size_t)(is_c ? i : L.kf_cap_c + (i - nqc)) * 8;
-      const double ty = b[7];
-      if (ty == 0.0) continue;
-      const float4 pc = is_c ? qc[i] : qs[i - nqc];
-      const double cp[3] = {pc.x, pc.y, pc.z}, a3[3] = {b[0], b[1], b[2]}, b3[3] = {b[3], b[4], b[5]}, c3[3] = {0, 0, 0};
-      double res, J[6];
-      eval_block(ty == 2.0 ? BLK_EDGE : BLK_PLANE, cp, a3, b3, c3, b[6], T, &res, J);
-      accumulate_block(res, J, P.huber_delta, acc);
+      const double4* b = reinterpret_cast<const double4*>(blocks + (size_t)(is_c ? i : L.kf_cap_c + (i - nqc)) * 8);
+      r.lo = b[0]; r.hi = b[1];
+      r.pc = is_c ? qc[i] : qs[i - nqc];
+      return r;
+    };
+    const int nrows = nqc + nqs;
+    int i = threadIdx.x;
+    Row cur;
+    if (i < nrows) cur = load_row(i);
+    while (i < nrows) {
+      const int inext = i + LM_SOLVE_BLOCK;
+      Row nxt = cur;
+      if (inext < nrows) nxt = load_row(inext);
+      const double ty = cur.hi.w;
+      if (ty != 0.0) {
+        const double cp[3] = {cur.pc.x, cur.pc.y, cur.pc.z}, a3[3] = {cur.lo.x, cur.lo.y, cur.lo.z}, b3[3] = {cur.lo.w, cur.hi.x, cur.hi.y}, c3[3] = {0, 0, 0};
+        double res, J[6];
+        eval_block(ty == 2.0 ? BLK_EDGE : BLK_PLANE, cp, a3, b3, c3, cur.hi.z, T, &res, J);
+        accumulate_block(res, J, P.huber_delta, acc);
+      }
+      cur = nxt;
+      i = inext;
     }
 #ifdef ALEGO_TIMING
     tm[1] += clock64() - c1_;
