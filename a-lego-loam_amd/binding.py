@@ -21,7 +21,7 @@ EXPORTS = [
     "alego_create", "alego_destroy", "alego_last_error", "alego_device_count", "alego_params_sizeof",
     "alego_ip_process", "alego_lo_process", "alego_lm_process", "alego_scan_process",
     "alego_batch_load", "alego_batch_run", "alego_synchronize", "alego_batch_get_pose", "alego_batch_get_counts",
-    "alego_stream", "alego_profile_enable", "alego_profile_report", "alego_set_lo_params", "alego_set_lm_params", "alego_debug_get", "alego_debug_voxel", "alego_debug_atan2f",
+    "alego_stream", "alego_stream_groups", "alego_profile_enable", "alego_profile_report", "alego_set_lo_params", "alego_set_lm_params", "alego_debug_get", "alego_debug_voxel", "alego_debug_atan2f",
 ]
 
 REPLAY_PINGPONG = 0x100
@@ -100,6 +100,8 @@ def lib():
         L.alego_profile_report.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
         L.alego_stream.restype = C.c_void_p
         L.alego_stream.argtypes = [C.c_void_p]
+        L.alego_stream_groups.restype = C.c_int
+        L.alego_stream_groups.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
         L.alego_set_lo_params.restype = C.c_int
         L.alego_set_lo_params.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.alego_set_lm_params.restype = C.c_int
@@ -280,6 +282,12 @@ class Handle:
 
     def stream(self):
         return lib().alego_stream(self._h)
+
+    def stream_groups(self):
+        """(number of HIP stream groups, slots covered by one kernel launch)"""
+        per = C.c_int(0)
+        g = lib().alego_stream_groups(self._h, C.byref(per))
+        return g, per.value
 
     # ---- test access ----
     def set_lo_params(self, p6, slot=0):

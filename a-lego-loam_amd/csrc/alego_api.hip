@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -29,7 +30,11 @@ int lm_configure();
 struct alego_handle {
   alego_params P;
   int device = 0;
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;       // = streams[0]
+  // Slots are split into contiguous groups of `gsize`; each group has its own HIP stream (and its own VoxelGrid scratch in
+  // LmHost), so the latency-bound kernels of one group overlap with the kernels of the others.  Slots never interact.
+  std::vector<hipStream_t> streams;
+  int gsize = 1;
   DevCtx d;
   std::vector<void*> allocs;
   std::string err;
@@ -69,6 +74,13 @@ DevCtx view(const alego_handle* h, int slot0, int n) {
   return d;
 }
 
+hipStream_t stream_of(const alego_handle* h, int slot) { return h->streams[slot / h->gsize]; }
+hipError_t sync_all(const alego_handle* h) {
+  hipError_t r = hipSuccess;
+  for (hipStream_t s : h->streams) { hipError_t e = hipStreamSynchronize(s); if (e != hipSuccess) r = e; }
+  return r;
+}
+
 int check_slot(alego_handle* h, int slot) {
   if (!h) return ALEGO_ERR_ARG;
   if (slot < 0 || slot >= h->d.n_slots) { h->err = "slot out of range"; return ALEGO_ERR_ARG; }
@@ -87,6 +99,11 @@ int alego_device_count(void) {
 int alego_params_sizeof(void) { return (int)sizeof(alego_params); }
 const char* alego_last_error(const alego_handle* h) { return h ? h->err.c_str() : "null handle"; }
 void* alego_stream(alego_handle* h) { return h ? (void*)h->stream : nullptr; }
+int alego_stream_groups(const alego_handle* h, int* slots_per_group) {
+  if (!h) return ALEGO_ERR_ARG;
+  if (slots_per_group) *slots_per_group = h->gsize;
+  return (int)h->streams.size();
+}
 
 int alego_create(const alego_params* params, int device, int n_slots, int ring_len, alego_handle** out) {
   if (!params || !out) return ALEGO_ERR_ARG;
@@ -106,7 +123,24 @@ int alego_create(const alego_params* params, int device, int n_slots, int ring_l
   h->P = *params;
   h->device = device;
   h->lo_scans.assign(n_slots, 0);
-  if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&h->stream) != hipSuccess) { delete h; return ALEGO_ERR_HIP; }
+  if (hipSetDevice(device) != hipSuccess) { delete h; return ALEGO_ERR_HIP; }
+  {
+    // stream groups: ALEGO_STREAM_GROUPS overrides; default one group per 64 slots, at most 4 (the HIP runtime's hardware queues)
+    int G = n_slots / 64;
+    if (const char* e = getenv("ALEGO_STREAM_GROUPS")) G = atoi(e);
+    if (G > 8) G = 8;
+    if (G > n_slots) G = n_slots;
+    if (G < 1) G = 1;
+    if (!getenv("ALEGO_STREAM_GROUPS") && G > 4) G = 4;
+    h->gsize = (n_slots + G - 1) / G;
+    G = (n_slots + h->gsize - 1) / h->gsize;
+    for (int g = 0; g < G; ++g) {
+      hipStream_t s = nullptr;
+      if (hipStreamCreate(&s) != hipSuccess) { for (hipStream_t t : h->streams) hipStreamDestroy(t); delete h; return ALEGO_ERR_HIP; }
+      h->streams.push_back(s);
+    }
+    h->stream = h->streams[0];
+  }
   DevCtx& d = h->d;
   std::memset(&d, 0, sizeof(d));
   d.P = *params;
@@ -153,7 +187,7 @@ int alego_create(const alego_params* params, int device, int n_slots, int ring_l
   hipMemcpy(d.lo_state, st.data(), st.size() * sizeof(double), hipMemcpyHostToDevice);
   hipMemcpy(d.poses, po.data(), po.size() * sizeof(double), hipMemcpyHostToDevice);
   if (ip_configure(d) != 0 || lo_configure() != 0 || lm_configure() != 0) { h->err = "hipFuncSetAttribute failed"; std::fprintf(stderr, "alego_create: %s\n", h->err.c_str()); alego_destroy(h); return ALEGO_ERR_HIP; }
-  h->lm = lm_host_create(h->P, d, n_slots, h->stream, &h->err);
+  h->lm = lm_host_create(h->P, d, n_slots, h->gsize, h->streams, &h->err);
   if (!h->lm) { std::fprintf(stderr, "alego_create: %s\n", h->err.c_str()); alego_destroy(h); return ALEGO_ERR_HIP; }
   *out = h;
   return ALEGO_OK;
@@ -162,17 +196,17 @@ int alego_create(const alego_params* params, int device, int n_slots, int ring_l
 void alego_destroy(alego_handle* h) {
   if (!h) return;
   hipSetDevice(h->device);
-  if (h->stream) hipStreamSynchronize(h->stream);
+  (void)sync_all(h);
   if (g_prof == &h->prof) g_prof = nullptr;
   if (h->lm) lm_host_destroy(h->lm);
   for (void* p : h->allocs) hipFree(p);
-  if (h->stream) hipStreamDestroy(h->stream);
+  for (hipStream_t s : h->streams) hipStreamDestroy(s);
   delete h;
 }
 
 int alego_synchronize(alego_handle* h) {
   if (!h) return ALEGO_ERR_ARG;
-  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  HIP_TRY(h, sync_all(h));
   return 0;
 }
 
@@ -182,22 +216,23 @@ int alego_batch_load(alego_handle* h, int slot, int ring_pos, const alego_point*
   if (n > h->d.Pcap) { h->err = "scan larger than n_scan*horizon_scan"; return ALEGO_ERR_CAPACITY; }
   hipSetDevice(h->device);
   float4* dst = h->d.in_pts + ((size_t)slot * h->d.ring_len + ring_pos) * h->d.Pcap;
-  HIP_TRY(h, hipMemcpyAsync(dst, pts, (size_t)n * sizeof(alego_point), hipMemcpyHostToDevice, h->stream));
-  HIP_TRY(h, hipMemcpyAsync(h->d.in_n + slot * h->d.ring_len + ring_pos, &n, sizeof(int), hipMemcpyHostToDevice, h->stream));
-  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  HIP_TRY(h, hipMemcpyAsync(dst, pts, (size_t)n * sizeof(alego_point), hipMemcpyHostToDevice, stream_of(h, slot)));
+  HIP_TRY(h, hipMemcpyAsync(h->d.in_n + slot * h->d.ring_len + ring_pos, &n, sizeof(int), hipMemcpyHostToDevice, stream_of(h, slot)));
+  HIP_TRY(h, hipStreamSynchronize(stream_of(h, slot)));
   return 0;
 }
 
 // enqueue IP -> FE -> LO -> LM for slots [slot0, slot0+n) on ring position `pos`
 static int enqueue_scan(alego_handle* h, int slot0, int n, int pos, int stages, bool want_labels) {
   const DevCtx d = view(h, slot0, n);
+  hipStream_t S = stream_of(h, slot0);  // [slot0, slot0+n) lies inside one stream group
   g_prof = &h->prof;
   static const bool dbg = getenv("ALEGO_DEBUG_SYNC") != nullptr;
-  auto chk = [&](const char* what) { if (dbg) { hipError_t e = hipStreamSynchronize(h->stream); fprintf(stderr, "[alego dbg] %s: %s\n", what, hipGetErrorString(e)); } };
-  if (stages & 1) { launch_ip(d, pos, want_labels, h->stream); chk("ip"); }
+  auto chk = [&](const char* what) { if (dbg) { hipError_t e = hipStreamSynchronize(S); fprintf(stderr, "[alego dbg] %s: %s\n", what, hipGetErrorString(e)); } };
+  if (stages & 1) { launch_ip(d, pos, want_labels, S); chk("ip"); }
   if (stages & 2) {
-    launch_fe(d, h->stream); chk("fe");
-    launch_lo(d, h->stream); chk("lo");
+    launch_fe(d, S); chk("fe");
+    launch_lo(d, S); chk("lo");
     std::vector<char> odom_valid(n);
     for (int i = 0; i < n; ++i) odom_valid[i] = h->lo_scans[slot0 + i]++ > 0;
     if (stages & 4) { if (int r = lm_host_enqueue(h->lm, d, odom_valid, &h->err)) return r; }
@@ -219,19 +254,20 @@ int alego_batch_run(alego_handle* h, int first_pos, int n_scans, int stages, int
     } else {
       pos = ((first_pos + s) % R + R) % R;
     }
-    if (int r = enqueue_scan(h, 0, h->d.n_slots, pos, stages & 7, false)) return r;
+    for (int s0 = 0; s0 < h->d.n_slots; s0 += h->gsize)
+      if (int r = enqueue_scan(h, s0, std::min(h->gsize, h->d.n_slots - s0), pos, stages & 7, false)) return r;
   }
-  if (sync) HIP_TRY(h, hipStreamSynchronize(h->stream));
+  if (sync) HIP_TRY(h, sync_all(h));
   return 0;
 }
 
 static int fetch_pose(alego_handle* h, int slot, alego_pose* odom, alego_pose* map_pose) {
   double po[16], st[LO_STATE_N];
   int sc[SC_COUNT];
-  HIP_TRY(h, hipMemcpyAsync(po, h->d.poses + (size_t)slot * 16, sizeof(po), hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(h, hipMemcpyAsync(st, h->d.lo_state + (size_t)slot * LO_STATE_N, sizeof(st), hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(h, hipMemcpyAsync(sc, h->d.scal + (size_t)slot * SC_COUNT, sizeof(sc), hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  HIP_TRY(h, hipMemcpyAsync(po, h->d.poses + (size_t)slot * 16, sizeof(po), hipMemcpyDeviceToHost, stream_of(h, slot)));
+  HIP_TRY(h, hipMemcpyAsync(st, h->d.lo_state + (size_t)slot * LO_STATE_N, sizeof(st), hipMemcpyDeviceToHost, stream_of(h, slot)));
+  HIP_TRY(h, hipMemcpyAsync(sc, h->d.scal + (size_t)slot * SC_COUNT, sizeof(sc), hipMemcpyDeviceToHost, stream_of(h, slot)));
+  HIP_TRY(h, hipStreamSynchronize(stream_of(h, slot)));
   if (odom) {
     for (int i = 0; i < 3; ++i) odom->t[i] = po[i];
     for (int i = 0; i < 4; ++i) odom->q[i] = po[3 + i];
@@ -259,9 +295,9 @@ int alego_batch_get_counts(alego_handle* h, int slot, int32_t* out, int cap) {
   if (int r = check_slot(h, slot)) return r;
   hipSetDevice(h->device);
   int sc[SC_COUNT], fc[8];
-  HIP_TRY(h, hipMemcpyAsync(sc, h->d.scal + (size_t)slot * SC_COUNT, sizeof(sc), hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(h, hipMemcpyAsync(fc, h->d.feat_cnt + (size_t)slot * 8, sizeof(fc), hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  HIP_TRY(h, hipMemcpyAsync(sc, h->d.scal + (size_t)slot * SC_COUNT, sizeof(sc), hipMemcpyDeviceToHost, stream_of(h, slot)));
+  HIP_TRY(h, hipMemcpyAsync(fc, h->d.feat_cnt + (size_t)slot * 8, sizeof(fc), hipMemcpyDeviceToHost, stream_of(h, slot)));
+  HIP_TRY(h, hipStreamSynchronize(stream_of(h, slot)));
   const int cur = sc[SC_CUR];  // buffer written by the last processed scan
   int v[16] = {sc[SC_PVALID], sc[SC_M], sc[SC_NOUT], fc[cur * 4 + 0], fc[cur * 4 + 1], fc[cur * 4 + 2], fc[cur * 4 + 3],
                sc[SC_LO_NSURF], sc[SC_LO_NCORNER], 0, 0, 0, 0, 0, 0, 0};  // v[15] = map rebuilds so far
@@ -273,22 +309,22 @@ int alego_batch_get_counts(alego_handle* h, int slot, int32_t* out, int cap) {
 static int download_seg(alego_handle* h, int slot, alego_seg_out* out) {
   const DevCtx& d = h->d;
   int sc[SC_COUNT];
-  HIP_TRY(h, hipMemcpyAsync(sc, d.scal + (size_t)slot * SC_COUNT, sizeof(sc), hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  HIP_TRY(h, hipMemcpyAsync(sc, d.scal + (size_t)slot * SC_COUNT, sizeof(sc), hipMemcpyDeviceToHost, stream_of(h, slot)));
+  HIP_TRY(h, hipStreamSynchronize(stream_of(h, slot)));
   const int M = sc[SC_M], NO = sc[SC_NOUT];
   out->m = M; out->n_outlier = NO;
   if (M > out->seg_cap || NO > out->outlier_cap) { h->err = "seg/outlier capacity too small"; return ALEGO_ERR_CAPACITY; }
   const size_t base = (size_t)slot * d.N;
-  if (out->seg) HIP_TRY(h, hipMemcpyAsync(out->seg, d.seg_pts + base, (size_t)M * 16, hipMemcpyDeviceToHost, h->stream));
-  if (out->ground) HIP_TRY(h, hipMemcpyAsync(out->ground, d.seg_ground + base, (size_t)M, hipMemcpyDeviceToHost, h->stream));
-  if (out->col) HIP_TRY(h, hipMemcpyAsync(out->col, d.seg_col + base, (size_t)M * 4, hipMemcpyDeviceToHost, h->stream));
-  if (out->range) HIP_TRY(h, hipMemcpyAsync(out->range, d.seg_range + base, (size_t)M * 4, hipMemcpyDeviceToHost, h->stream));
-  if (out->ring_start) HIP_TRY(h, hipMemcpyAsync(out->ring_start, d.ring_start + (size_t)slot * d.NS, d.NS * 4, hipMemcpyDeviceToHost, h->stream));
-  if (out->ring_end) HIP_TRY(h, hipMemcpyAsync(out->ring_end, d.ring_end + (size_t)slot * d.NS, d.NS * 4, hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(h, hipMemcpyAsync(out->orientation, d.ori + (size_t)slot * 4, 12, hipMemcpyDeviceToHost, h->stream));
-  if (out->outlier) HIP_TRY(h, hipMemcpyAsync(out->outlier, d.outlier + base, (size_t)NO * 16, hipMemcpyDeviceToHost, h->stream));
-  if (out->label_image) HIP_TRY(h, hipMemcpyAsync(out->label_image, d.label_img + base, (size_t)d.N * 4, hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  if (out->seg) HIP_TRY(h, hipMemcpyAsync(out->seg, d.seg_pts + base, (size_t)M * 16, hipMemcpyDeviceToHost, stream_of(h, slot)));
+  if (out->ground) HIP_TRY(h, hipMemcpyAsync(out->ground, d.seg_ground + base, (size_t)M, hipMemcpyDeviceToHost, stream_of(h, slot)));
+  if (out->col) HIP_TRY(h, hipMemcpyAsync(out->col, d.seg_col + base, (size_t)M * 4, hipMemcpyDeviceToHost, stream_of(h, slot)));
+  if (out->range) HIP_TRY(h, hipMemcpyAsync(out->range, d.seg_range + base, (size_t)M * 4, hipMemcpyDeviceToHost, stream_of(h, slot)));
+  if (out->ring_start) HIP_TRY(h, hipMemcpyAsync(out->ring_start, d.ring_start + (size_t)slot * d.NS, d.NS * 4, hipMemcpyDeviceToHost, stream_of(h, slot)));
+  if (out->ring_end) HIP_TRY(h, hipMemcpyAsync(out->ring_end, d.ring_end + (size_t)slot * d.NS, d.NS * 4, hipMemcpyDeviceToHost, stream_of(h, slot)));
+  HIP_TRY(h, hipMemcpyAsync(out->orientation, d.ori + (size_t)slot * 4, 12, hipMemcpyDeviceToHost, stream_of(h, slot)));
+  if (out->outlier) HIP_TRY(h, hipMemcpyAsync(out->outlier, d.outlier + base, (size_t)NO * 16, hipMemcpyDeviceToHost, stream_of(h, slot)));
+  if (out->label_image) HIP_TRY(h, hipMemcpyAsync(out->label_image, d.label_img + base, (size_t)d.N * 4, hipMemcpyDeviceToHost, stream_of(h, slot)));
+  HIP_TRY(h, hipStreamSynchronize(stream_of(h, slot)));
   return 0;
 }
 
@@ -296,16 +332,16 @@ static int download_feat(alego_handle* h, int slot, alego_feat_out* f) {
   const DevCtx& d = h->d;
   int fc[4], M, cur;
   HIP_TRY(h, hipMemcpy(&cur, d.scal + (size_t)slot * SC_COUNT + SC_CUR, 4, hipMemcpyDeviceToHost));
-  HIP_TRY(h, hipMemcpyAsync(fc, d.feat_cnt + ((size_t)slot * 2 + cur) * 4, sizeof(fc), hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(h, hipMemcpyAsync(&M, d.scal + (size_t)slot * SC_COUNT + SC_M, 4, hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  HIP_TRY(h, hipMemcpyAsync(fc, d.feat_cnt + ((size_t)slot * 2 + cur) * 4, sizeof(fc), hipMemcpyDeviceToHost, stream_of(h, slot)));
+  HIP_TRY(h, hipMemcpyAsync(&M, d.scal + (size_t)slot * SC_COUNT + SC_M, 4, hipMemcpyDeviceToHost, stream_of(h, slot)));
+  HIP_TRY(h, hipStreamSynchronize(stream_of(h, slot)));
   f->n_sharp = fc[0]; f->n_less_sharp = fc[1]; f->n_flat = fc[2]; f->n_less_flat = fc[3];
   if (fc[0] > f->sharp_cap || fc[1] > f->less_sharp_cap || fc[2] > f->flat_cap || fc[3] > f->less_flat_cap) { h->err = "feature capacity too small"; return ALEGO_ERR_CAPACITY; }
   alego_point* dst[4] = {f->sharp, f->less_sharp, f->flat, f->less_flat};
   for (int k = 0; k < 4; ++k)
-    if (dst[k]) HIP_TRY(h, hipMemcpyAsync(dst[k], d.feat[k] + ((size_t)slot * 2 + cur) * d.fcap[k], (size_t)fc[k] * 16, hipMemcpyDeviceToHost, h->stream));
-  if (f->point_label) HIP_TRY(h, hipMemcpyAsync(f->point_label, d.plabel + (size_t)slot * d.N, (size_t)M * 4, hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (dst[k]) HIP_TRY(h, hipMemcpyAsync(dst[k], d.feat[k] + ((size_t)slot * 2 + cur) * d.fcap[k], (size_t)fc[k] * 16, hipMemcpyDeviceToHost, stream_of(h, slot)));
+  if (f->point_label) HIP_TRY(h, hipMemcpyAsync(f->point_label, d.plabel + (size_t)slot * d.N, (size_t)M * 4, hipMemcpyDeviceToHost, stream_of(h, slot)));
+  HIP_TRY(h, hipStreamSynchronize(stream_of(h, slot)));
   return 0;
 }
 
@@ -362,8 +398,8 @@ int alego_scan_process(alego_handle* h, int slot, const alego_scan_in* in, int s
 int alego_set_lo_params(alego_handle* h, int slot, const double* p6) {
   if (int r = check_slot(h, slot)) return r;
   hipSetDevice(h->device);
-  HIP_TRY(h, hipMemcpyAsync(h->d.lo_state + (size_t)slot * LO_STATE_N + LS_PARAMS, p6, 48, hipMemcpyHostToDevice, h->stream));
-  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  HIP_TRY(h, hipMemcpyAsync(h->d.lo_state + (size_t)slot * LO_STATE_N + LS_PARAMS, p6, 48, hipMemcpyHostToDevice, stream_of(h, slot)));
+  HIP_TRY(h, hipStreamSynchronize(stream_of(h, slot)));
   return 0;
 }
 int alego_set_lm_params(alego_handle* h, int slot, const double* p6) {
@@ -375,7 +411,7 @@ int alego_set_lm_params(alego_handle* h, int slot, const double* p6) {
 int alego_profile_enable(alego_handle* h, int on) {
   if (!h) return ALEGO_ERR_ARG;
   hipSetDevice(h->device);
-  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  HIP_TRY(h, sync_all(h));
   h->prof.reset();
   h->prof.on = on != 0;
   return 0;
@@ -384,7 +420,7 @@ int alego_profile_enable(alego_handle* h, int on) {
 int alego_profile_report(alego_handle* h, char* names, int names_cap, double* total_ms, int* launches, int cap) {
   if (!h) return ALEGO_ERR_ARG;
   hipSetDevice(h->device);
-  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  HIP_TRY(h, sync_all(h));
   Profiler& P = h->prof;
   const int nk = (int)P.names.size();
   std::vector<double> tot(nk, 0.0);
@@ -444,8 +480,8 @@ int alego_debug_get(alego_handle* h, int slot, const char* name, void* out, int 
   hipSetDevice(h->device);
   const DevCtx& d = h->d;
   int sc[SC_COUNT];
-  HIP_TRY(h, hipMemcpyAsync(sc, d.scal + (size_t)slot * SC_COUNT, sizeof(sc), hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  HIP_TRY(h, hipMemcpyAsync(sc, d.scal + (size_t)slot * SC_COUNT, sizeof(sc), hipMemcpyDeviceToHost, stream_of(h, slot)));
+  HIP_TRY(h, hipStreamSynchronize(stream_of(h, slot)));
   const std::string s(name);
   const size_t base = (size_t)slot * d.N;
   const int M = sc[SC_M];

@@ -118,7 +118,7 @@ __global__ void __launch_bounds__(LM_BLOCK) lm_grid_setup(DevCtx d, LmCtx L) {
   if (!li[LI_REBUILD]) return;
   __shared__ GridGeom s_g;
   if (threadIdx.x == 0) {
-    const unsigned* bb = L.vox_bbox + ((size_t)slot * 5 + m) * 8;
+    const unsigned* bb = L.vox_bbox + ((size_t)(slot - L.vox_slot0) * 5 + m) * 8;
     GridGeom g;
     float mn[3], mx[3];
     for (int a = 0; a < 3; ++a) { mn[a] = vxl_dec(bb[a]); mx[a] = vxl_dec(~bb[4 + a]); }

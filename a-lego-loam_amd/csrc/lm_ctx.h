@@ -58,7 +58,8 @@ struct LmCtx {
   GridGeom* grid;                                 // [slot][2]
   int *cell_start, *cell_cur;                     // [slot][2][gcap+1]
   float4* cell_pts;                               // [slot][2][map_cap_s] map points in cell order (w = index in the ds map)
-  const unsigned* vox_bbox;                       // VoxCtx::bbox of round 1 (jobs slot*5 + {0,1} are the maps)
+  const unsigned* vox_bbox;                       // VoxCtx::bbox of round 1 of this stream group (jobs (slot-vox_slot0)*5 + {0,1} are the maps)
+  int vox_slot0;                                  // first slot of the stream group
   int* knn;                                       // [slot][qcap][5] neighbour indices of every query (lm_knn -> lm_fit)
   // residual blocks
   double* blocks;                                 // [slot][qcap][8]: a/normal (3), b (3), d, type (0 = none)

@@ -10,7 +10,7 @@
 #include "dev_common.h"
 
 struct LmHost;
-LmHost* lm_host_create(const alego_params& P, const DevCtx& d, int n_slots, hipStream_t st, std::string* err);
+LmHost* lm_host_create(const alego_params& P, const DevCtx& d, int n_slots, int gsize, const std::vector<hipStream_t>& streams, std::string* err);
 void lm_host_destroy(LmHost* lm);
 // LaserMapping for the scan just processed by LO, for the slots of view `d`
 int lm_host_enqueue(LmHost* lm, const DevCtx& d, const std::vector<char>& odom_valid, std::string* err);

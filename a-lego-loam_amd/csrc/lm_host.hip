@@ -3,6 +3,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <vector>
 
@@ -18,9 +19,11 @@ void launch_lm_register(const DevCtx& d, const LmCtx& L, hipStream_t st);
 struct LmHost {
   alego_params P;
   int n_slots;
-  hipStream_t st;
+  int gsize;                   // slots per stream group
+  std::vector<hipStream_t> st; // one HIP stream per group
   LmCtx L;
-  VoxCtx v1, v2;  // round 1: map corner, map surf, scan corner, scan surf, scan outlier; round 2: scan surf_total
+  // per group — round 1: map corner, map surf, scan corner, scan surf, scan outlier; round 2: scan surf_total
+  std::vector<VoxCtx> v1, v2;
   std::vector<void*> allocs;
   std::vector<long> frames;  // host mirror of frame_cnt per slot: only used to skip launches
 };
@@ -40,10 +43,11 @@ bool A(LmHost* lm, T** p, size_t count, std::string* err) {
 }
 }  // namespace
 
-LmHost* lm_host_create(const alego_params& P, const DevCtx& d, int n_slots, hipStream_t st, std::string* err) {
+LmHost* lm_host_create(const alego_params& P, const DevCtx& d, int n_slots, int gsize, const std::vector<hipStream_t>& st, std::string* err) {
   LmHost* lm = new LmHost();
-  lm->P = P; lm->n_slots = n_slots; lm->st = st; lm->frames.assign(n_slots, 0);
-  std::memset(&lm->v1, 0, sizeof(VoxCtx)); std::memset(&lm->v2, 0, sizeof(VoxCtx));
+  lm->P = P; lm->n_slots = n_slots; lm->gsize = gsize; lm->st = st; lm->frames.assign(n_slots, 0);
+  VoxCtx vz; std::memset(&vz, 0, sizeof(VoxCtx));
+  lm->v1.assign(st.size(), vz); lm->v2.assign(st.size(), vz);
   LmCtx& L = lm->L;
   std::memset(&L, 0, sizeof(L));
   L.K = P.recent_keyframe_num > 0 ? P.recent_keyframe_num : 1;
@@ -72,8 +76,9 @@ LmHost* lm_host_create(const alego_params& P, const DevCtx& d, int n_slots, hipS
   for (size_t b = 0; b < B; ++b) { ld[b * LD_COUNT + LD_Q_M2O] = 1.0; ld[b * LD_COUNT + LD_Q_O2L] = 1.0; ld[b * LD_COUNT + LD_Q_M2L] = 1.0; }
   (void)hipMemcpy(L.ld, ld.data(), ld.size() * sizeof(double), hipMemcpyHostToDevice);
   // VoxelGrid job tables (laserMapping.cpp:37-39,316-319,329-342)
+  for (size_t g = 0; g < st.size(); ++g) {
   std::vector<VoxJob> j1, j2;
-  for (size_t b = 0; b < B; ++b) {
+  for (size_t b = g * gsize; b < B && b < (g + 1) * (size_t)gsize; ++b) {
     int* li = L.li + b * LI_COUNT;
     j1.push_back(VoxJob{L.map_corner_raw + b * L.map_cap_c, li + LI_KRAW_C, L.map_corner_ds + b * L.map_cap_c, li + LI_KDS_C, li + LI_REBUILD, P.lm_leaf_corner, L.map_cap_c, 0, 0, 0});
     j1.push_back(VoxJob{L.map_surf_raw + b * L.map_cap_s, li + LI_KRAW_S, L.map_surf_ds + b * L.map_cap_s, li + LI_KDS_S, li + LI_REBUILD, P.lm_leaf_surf, L.map_cap_s, 0, 0, 0});
@@ -82,22 +87,23 @@ LmHost* lm_host_create(const alego_params& P, const DevCtx& d, int n_slots, hipS
     j1.push_back(VoxJob{L.in_outl + b * L.in_cap_o, li + LI_NIN_O, L.cur_outl_ds + b * L.kf_cap_o, li + LI_NCUR_O, li + LI_RUN, P.lm_leaf_outlier, L.in_cap_o, 0, 0, 0});
     j2.push_back(VoxJob{L.cur_total + b * L.total_cap, li + LI_NTOTAL, L.cur_total_ds + b * L.total_cap, li + LI_NTOTAL_DS, li + LI_RUN, P.lm_leaf_surf, L.total_cap, 0, 0, 0});
   }
-  if (vox_create(&lm->v1, j1.data(), (int)j1.size(), err) || vox_create(&lm->v2, j2.data(), (int)j2.size(), err)) { lm_host_destroy(lm); return nullptr; }
-  L.vox_bbox = lm->v1.bbox;
+  if (vox_create(&lm->v1[g], j1.data(), (int)j1.size(), err) || vox_create(&lm->v2[g], j2.data(), (int)j2.size(), err)) { lm_host_destroy(lm); return nullptr; }
+  }
   return lm;
 }
 
 void lm_host_destroy(LmHost* lm) {
   if (!lm) return;
-  vox_destroy(&lm->v1); vox_destroy(&lm->v2);
+  for (auto& v : lm->v1) vox_destroy(&v);
+  for (auto& v : lm->v2) vox_destroy(&v);
   for (void* p : lm->allocs) (void)hipFree(p);
   delete lm;
 }
 
-static bool dbg_sync(LmHost* lm, const char* what, std::string* err) {
+static bool dbg_sync(hipStream_t st, const char* what, std::string* err) {
   static const bool on = getenv("ALEGO_DEBUG_SYNC") != nullptr;
   if (!on) return true;
-  hipError_t e = hipStreamSynchronize(lm->st);
+  hipError_t e = hipStreamSynchronize(st);
   if (e == hipSuccess) e = hipGetLastError();
   fprintf(stderr, "[alego dbg] %s: %s\n", what, hipGetErrorString(e));
   if (e != hipSuccess) { *err = std::string(what) + ": " + hipGetErrorString(e); return false; }
@@ -106,7 +112,11 @@ static bool dbg_sync(LmHost* lm, const char* what, std::string* err) {
 
 // odom_valid[s - slot0]: whether slot s has an /odom/lidar message for this scan (false on its first scan)
 static int lm_sequence(LmHost* lm, const DevCtx& d, int stage, const std::vector<char>& odom_valid, std::string* err) {
-  const LmCtx& L = lm->L;
+  // the slots of one launch view always belong to one stream group
+  const int g = d.slot0 / lm->gsize;
+  hipStream_t st = lm->st[g];
+  LmCtx L = lm->L;
+  L.vox_bbox = lm->v1[g].bbox; L.vox_slot0 = g * lm->gsize;
   int n_run = 0, n_norun = 0;
   for (int i = 0; i < d.n_launch; ++i) {
     long& f = lm->frames[d.slot0 + i];
@@ -115,32 +125,34 @@ static int lm_sequence(LmHost* lm, const DevCtx& d, int stage, const std::vector
     run ? ++n_run : ++n_norun;
   }
   const int hint = n_run == 0 ? 0 : (n_norun == 0 ? 1 : -1);  // -1: slots out of phase, no launch skipping
-  launch_lm_prepare(d, L, stage, hint, lm->st);
-  if (!dbg_sync(lm, "lm_prepare", err)) return ALEGO_ERR_HIP;
+  launch_lm_prepare(d, L, stage, hint, st);
+  if (!dbg_sync(st, "lm_prepare", err)) return ALEGO_ERR_HIP;
   if (n_run == 0) return 0;
-  launch_lm_concat(d, L, lm->st);
-  if (!dbg_sync(lm, "lm_concat", err)) return ALEGO_ERR_HIP;
-  if (int r = vox_run(lm->v1, lm->st, err)) return r;
-  if (!dbg_sync(lm, "vox round 1", err)) return ALEGO_ERR_HIP;
-  launch_lm_total_and_grid_setup(d, L, lm->st);
-  if (!dbg_sync(lm, "lm_total/grid_setup", err)) return ALEGO_ERR_HIP;
-  if (int r = vox_run(lm->v2, lm->st, err)) return r;
-  if (!dbg_sync(lm, "vox round 2", err)) return ALEGO_ERR_HIP;
-  launch_lm_grid(d, L, lm->st);
-  if (!dbg_sync(lm, "lm_grid", err)) return ALEGO_ERR_HIP;
-  launch_lm_register(d, L, lm->st);
-  if (!dbg_sync(lm, "lm_register", err)) return ALEGO_ERR_HIP;
+  launch_lm_concat(d, L, st);
+  if (!dbg_sync(st, "lm_concat", err)) return ALEGO_ERR_HIP;
+  if (int r = vox_run(lm->v1[g], st, err)) return r;
+  if (!dbg_sync(st, "vox round 1", err)) return ALEGO_ERR_HIP;
+  launch_lm_total_and_grid_setup(d, L, st);
+  if (!dbg_sync(st, "lm_total/grid_setup", err)) return ALEGO_ERR_HIP;
+  if (int r = vox_run(lm->v2[g], st, err)) return r;
+  if (!dbg_sync(st, "vox round 2", err)) return ALEGO_ERR_HIP;
+  launch_lm_grid(d, L, st);
+  if (!dbg_sync(st, "lm_grid", err)) return ALEGO_ERR_HIP;
+  launch_lm_register(d, L, st);
+  if (!dbg_sync(st, "lm_register", err)) return ALEGO_ERR_HIP;
   return 0;
 }
 
-// NOTE: the VoxelGrid rounds always cover every slot of the handle; slots outside the launch view
+// NOTE: the VoxelGrid rounds always cover every slot of the stream group; slots outside the launch view
 // have LI_RUN == 0 from their own last prepare only if they were prepared in this call, so the
-// single-slot entry points clear the run flags of the other slots first.
+// single-slot entry points clear the run flags of the other slots of the group first.
 static void clear_run_flags_outside(LmHost* lm, const DevCtx& d) {
-  if (d.n_launch == lm->n_slots) return;
-  for (int s = 0; s < lm->n_slots; ++s) {
+  const int g = d.slot0 / lm->gsize;
+  const int lo = g * lm->gsize, hi = std::min(lm->n_slots, lo + lm->gsize);
+  if (d.slot0 == lo && d.slot0 + d.n_launch == hi) return;
+  for (int s = lo; s < hi; ++s) {
     if (s >= d.slot0 && s < d.slot0 + d.n_launch) continue;
-    (void)hipMemsetAsync(lm->L.li + (size_t)s * LI_COUNT + LI_RUN, 0, 2 * sizeof(int), lm->st);  // LI_RUN, LI_REBUILD
+    (void)hipMemsetAsync(lm->L.li + (size_t)s * LI_COUNT + LI_RUN, 0, 2 * sizeof(int), lm->st[g]);  // LI_RUN, LI_REBUILD
   }
 }
 
@@ -156,7 +168,7 @@ int lm_host_process_host(LmHost* lm, const DevCtx& dfull, const alego_point* cor
   if (n_corner > L.in_cap_c || n_surf > L.in_cap_s || n_outlier > L.in_cap_o) { *err = "alego_lm_process: input cloud exceeds capacity"; return ALEGO_ERR_CAPACITY; }
   DevCtx d = dfull;
   d.slot0 = 0; d.n_launch = 1;
-  hipStream_t st = lm->st;
+  hipStream_t st = lm->st[0];
   (void)hipMemcpyAsync(L.in_corner, corner_last, (size_t)n_corner * 16, hipMemcpyHostToDevice, st);
   (void)hipMemcpyAsync(L.in_surf, surf_last, (size_t)n_surf * 16, hipMemcpyHostToDevice, st);
   (void)hipMemcpyAsync(L.in_outl, outlier, (size_t)n_outlier * 16, hipMemcpyHostToDevice, st);

@@ -19,8 +19,8 @@
  *
  * All functions return 0 on success, >0 for the reference's "skip" conditions
  * (surfaced as flags, see ALEGO_FLAG_*), <0 for hard errors (ALEGO_ERR_*); nothing
- * throws across the boundary.  A handle is single-threaded (one caller at a time,
- * one HIP stream); different handles are independent.  There is no CPU fallback:
+ * throws across the boundary.  A handle is single-threaded (one caller at a time;
+ * it owns its HIP streams); different handles are independent.  There is no CPU fallback:
  * alego_create fails with ALEGO_ERR_NO_DEVICE when no gfx950 device is visible.
  */
 #ifndef ALEGO_MI355X_H_
@@ -135,8 +135,12 @@ int alego_batch_get_pose(alego_handle* h, int slot, alego_pose* odom, alego_pose
  *            n_surf_corr, n_corner_corr, lm: Kraw_corner, Kraw_surf, Kds_corner, Kds_surf, Lc, Ls,
  *            map rebuilds so far */
 int alego_batch_get_counts(alego_handle* h, int slot, int32_t* out, int cap);
-/* the HIP stream (hipStream_t) the handle enqueues on, for event timing by the caller */
+/* the HIP stream (hipStream_t) the handle enqueues slot 0 on, for event timing by the caller */
 void* alego_stream(alego_handle* h);
+/* The slots of a handle are split into contiguous groups, each enqueued on its own HIP stream so that the kernels of
+ * different groups overlap (slots never interact).  Returns the number of groups; *slots_per_group (may be NULL) =
+ * slots one kernel launch covers.  Default: one group per 64 slots, at most 4; ALEGO_STREAM_GROUPS=<n> overrides. */
+int alego_stream_groups(const alego_handle* h, int* slots_per_group);
 
 /* ---- per-kernel timing (bench.py's roofline leg) --------------------------- */
 /* When enabled every kernel launch of this handle is bracketed by hipEventRecord on the handle's

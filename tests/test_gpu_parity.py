@@ -299,11 +299,15 @@ def test_full_loop_reference_geometry_16x4000():
     h.close()
 
 
-def test_batch_full_loop_equals_single_stream(params_a):
-    """Slots advanced in lock-step through IP -> LO -> LM (batch path) give bit-identical poses to one-slot handles."""
+@pytest.mark.parametrize("nslot,groups", [(3, 1), (5, 3)])
+def test_batch_full_loop_equals_single_stream(params_a, nslot, groups, monkeypatch):
+    """Slots advanced through IP -> LO -> LM (batch path) give bit-identical poses to one-slot handles, also when the
+    slots are split over several HIP streams (groups of 2+2+1 slots running concurrently)."""
     p = params_a
-    nslot, nscan = 3, 30
+    nscan = 30
+    monkeypatch.setenv("ALEGO_STREAM_GROUPS", str(groups))
     hb = binding.Handle(p, n_slots=nslot, ring_len=nscan)
+    monkeypatch.delenv("ALEGO_STREAM_GROUPS")
     for s in range(nslot):
         for k in range(nscan):
             hb.batch_load(s, k, synth.scan(p, k, stream=s))
