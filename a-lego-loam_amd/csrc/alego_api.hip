@@ -448,7 +448,7 @@ int alego_debug_voxel(alego_handle* h, const alego_point* pts, int n, float leaf
   const int hc[2] = {n, 0};
   HIP_TRY(h, hipMemcpy(cnt, hc, 8, hipMemcpyHostToDevice));
   if (n) HIP_TRY(h, hipMemcpy(din, pts, (size_t)n * 16, hipMemcpyHostToDevice));
-  VoxJob job{din, cnt, dout, cnt + 1, nullptr, leaf, c, 0, 0, 0};
+  VoxJob job{din, cnt, dout, cnt + 1, nullptr, leaf, c, 0};
   VoxCtx V;
   if (vox_create(&V, &job, 1, &h->err)) return ALEGO_ERR_HIP;
   int rc = vox_run(V, h->stream, &h->err);

@@ -80,12 +80,12 @@ LmHost* lm_host_create(const alego_params& P, const DevCtx& d, int n_slots, int 
   std::vector<VoxJob> j1, j2;
   for (size_t b = g * gsize; b < B && b < (g + 1) * (size_t)gsize; ++b) {
     int* li = L.li + b * LI_COUNT;
-    j1.push_back(VoxJob{L.map_corner_raw + b * L.map_cap_c, li + LI_KRAW_C, L.map_corner_ds + b * L.map_cap_c, li + LI_KDS_C, li + LI_REBUILD, P.lm_leaf_corner, L.map_cap_c, 0, 0, 0});
-    j1.push_back(VoxJob{L.map_surf_raw + b * L.map_cap_s, li + LI_KRAW_S, L.map_surf_ds + b * L.map_cap_s, li + LI_KDS_S, li + LI_REBUILD, P.lm_leaf_surf, L.map_cap_s, 0, 0, 0});
-    j1.push_back(VoxJob{L.in_corner + b * L.in_cap_c, li + LI_NIN_C, L.cur_corner_ds + b * L.kf_cap_c, li + LI_NCUR_C, li + LI_RUN, P.lm_leaf_corner, L.kf_cap_c, 0, 0, 0});
-    j1.push_back(VoxJob{L.in_surf + b * L.in_cap_s, li + LI_NIN_S, L.cur_surf_ds + b * L.kf_cap_s, li + LI_NCUR_S, li + LI_RUN, P.lm_leaf_surf, L.in_cap_s, 0, 0, 0});
-    j1.push_back(VoxJob{L.in_outl + b * L.in_cap_o, li + LI_NIN_O, L.cur_outl_ds + b * L.kf_cap_o, li + LI_NCUR_O, li + LI_RUN, P.lm_leaf_outlier, L.in_cap_o, 0, 0, 0});
-    j2.push_back(VoxJob{L.cur_total + b * L.total_cap, li + LI_NTOTAL, L.cur_total_ds + b * L.total_cap, li + LI_NTOTAL_DS, li + LI_RUN, P.lm_leaf_surf, L.total_cap, 0, 0, 0});
+    j1.push_back(VoxJob{L.map_corner_raw + b * L.map_cap_c, li + LI_KRAW_C, L.map_corner_ds + b * L.map_cap_c, li + LI_KDS_C, li + LI_REBUILD, P.lm_leaf_corner, L.map_cap_c, 0});
+    j1.push_back(VoxJob{L.map_surf_raw + b * L.map_cap_s, li + LI_KRAW_S, L.map_surf_ds + b * L.map_cap_s, li + LI_KDS_S, li + LI_REBUILD, P.lm_leaf_surf, L.map_cap_s, 0});
+    j1.push_back(VoxJob{L.in_corner + b * L.in_cap_c, li + LI_NIN_C, L.cur_corner_ds + b * L.kf_cap_c, li + LI_NCUR_C, li + LI_RUN, P.lm_leaf_corner, L.kf_cap_c, 0});
+    j1.push_back(VoxJob{L.in_surf + b * L.in_cap_s, li + LI_NIN_S, L.cur_surf_ds + b * L.kf_cap_s, li + LI_NCUR_S, li + LI_RUN, P.lm_leaf_surf, L.in_cap_s, 0});
+    j1.push_back(VoxJob{L.in_outl + b * L.in_cap_o, li + LI_NIN_O, L.cur_outl_ds + b * L.kf_cap_o, li + LI_NCUR_O, li + LI_RUN, P.lm_leaf_outlier, L.in_cap_o, 0});
+    j2.push_back(VoxJob{L.cur_total + b * L.total_cap, li + LI_NTOTAL, L.cur_total_ds + b * L.total_cap, li + LI_NTOTAL_DS, li + LI_RUN, P.lm_leaf_surf, L.total_cap, 0});
   }
   if (vox_create(&lm->v1[g], j1.data(), (int)j1.size(), err) || vox_create(&lm->v2[g], j2.data(), (int)j2.size(), err)) { lm_host_destroy(lm); return nullptr; }
   }
