@@ -68,7 +68,7 @@ __global__ void __launch_bounds__(LM_BLOCK) lm_prepare(DevCtx d, LmCtx L, int st
   if (li[LI_NKF] > 0 && li[LI_DIRTY]) { li[LI_REBUILD] = 1; li[LI_DIRTY] = 0; li[LI_NREBUILD] += 1; }
 }
 
-// grid (16, K, slots): chronological concatenation of the key-frame ring
+// grid (2, K, slots): chronological concatenation of the key-frame ring
 __global__ void __launch_bounds__(LM_BLOCK) lm_concat(DevCtx d, LmCtx L) {
   const int slot = blockIdx.z + d.slot0, j = blockIdx.y;
   int* li = lip(L, slot);
@@ -147,7 +147,7 @@ DEV_INLINE int grid_cell(const GridGeom& g, float x, float y, float z, int* cx, 
   return ix + g.gx * (iy + g.gy * iz);
 }
 
-// grid (32, 2, slots)
+// grid (8, 2, slots)
 __global__ void __launch_bounds__(LM_BLOCK) lm_grid_count(DevCtx d, LmCtx L, int fill) {
   const int slot = blockIdx.z + d.slot0, m = blockIdx.y;
   const int* li = lip(L, slot);
@@ -381,6 +381,7 @@ __global__ void __launch_bounds__(128) lm_knn(DevCtx d, LmCtx L) {
 
 // grid (ceil(qcap/128), 2, slots): one thread per query: 3x3 scatter eigen-decomposition (line) or 5x3 Householder
 // least squares (plane) on the five neighbours found by lm_knn
+#define LM_FIT_GX 20   // x 128 threads: the 1-2 k queries of a kind in one sweep; larger clouds grid-stride
 __global__ void __launch_bounds__(128) lm_fit(DevCtx d, LmCtx L) {
   const int slot = blockIdx.z + d.slot0, kind = blockIdx.y;
   const int* li = lip(L, slot);
@@ -388,9 +389,8 @@ __global__ void __launch_bounds__(128) lm_fit(DevCtx d, LmCtx L) {
   const alego_params& P = d.P;
   if (li[LI_NCUR_C] < P.lm_min_corner || li[LI_NTOTAL] < P.lm_min_surf || li[LI_KDS_C] < P.lm_min_map_corner || li[LI_NKF] == 0) return;
   const int nq = kind == 0 ? li[LI_NCUR_C] : li[LI_NTOTAL_DS];
-  const int q = blockIdx.x * 128 + threadIdx.x;
-  if (q >= nq) return;
   const float4* mp = kind == 0 ? L.map_corner_ds + (size_t)slot * L.map_cap_c : L.map_surf_ds + (size_t)slot * L.map_cap_s;
+  for (int q = blockIdx.x * 128 + threadIdx.x; q < nq; q += gridDim.x * 128) {
   const int* kn = L.knn + ((size_t)slot * L.qcap + (kind == 0 ? 0 : L.kf_cap_c) + q) * 5;
   double* blk = L.blocks + ((size_t)slot * L.qcap + (kind == 0 ? 0 : L.kf_cap_c) + q) * 8;
   int bi[5];
@@ -452,6 +452,7 @@ __global__ void __launch_bounds__(128) lm_fit(DevCtx d, LmCtx L) {
     }
   }
   } while (false);
+  }
 }
 
 // grid (slots): scan2MapOptimization's solver part
@@ -682,20 +683,20 @@ void launch_lm_prepare(const DevCtx& d, const LmCtx& L, int stage, int run_hint,
   ALEGO_LAUNCH(lm_prepare, dim3(8, 3, d.n_launch), dim3(LM_BLOCK), 0, st, d, L, stage, run_hint);
 }
 void launch_lm_concat(const DevCtx& d, const LmCtx& L, hipStream_t st) {
-  ALEGO_LAUNCH(lm_concat, dim3(16, L.K, d.n_launch), dim3(LM_BLOCK), 0, st, d, L);
+  ALEGO_LAUNCH(lm_concat, dim3(2, L.K, d.n_launch), dim3(LM_BLOCK), 0, st, d, L);
 }
 void launch_lm_total_and_grid_setup(const DevCtx& d, const LmCtx& L, hipStream_t st) {
   ALEGO_LAUNCH(lm_total, dim3(8, d.n_launch), dim3(LM_BLOCK), 0, st, d, L);
   ALEGO_LAUNCH(lm_grid_setup, dim3(2, d.n_launch), dim3(LM_BLOCK), 0, st, d, L);
 }
 void launch_lm_grid(const DevCtx& d, const LmCtx& L, hipStream_t st) {
-  ALEGO_LAUNCH(lm_grid_count, dim3(32, 2, d.n_launch), dim3(LM_BLOCK), 0, st, d, L, 0);
+  ALEGO_LAUNCH(lm_grid_count, dim3(8, 2, d.n_launch), dim3(LM_BLOCK), 0, st, d, L, 0);
   ALEGO_LAUNCH(lm_grid_scan, dim3(2, d.n_launch), dim3(LM_BLOCK), 0, st, d, L);
-  ALEGO_LAUNCH(lm_grid_count, dim3(32, 2, d.n_launch), dim3(LM_BLOCK), 0, st, d, L, 1);
+  ALEGO_LAUNCH(lm_grid_count, dim3(8, 2, d.n_launch), dim3(LM_BLOCK), 0, st, d, L, 1);
 }
 void launch_lm_register(const DevCtx& d, const LmCtx& L, hipStream_t st) {
   ALEGO_LAUNCH(lm_knn, dim3(LM_ASSOC_GX, 2, d.n_launch), dim3(128), 0, st, d, L);
-  ALEGO_LAUNCH(lm_fit, dim3((L.qcap + 127) / 128, 2, d.n_launch), dim3(128), 0, st, d, L);
+  ALEGO_LAUNCH(lm_fit, dim3(LM_FIT_GX, 2, d.n_launch), dim3(128), 0, st, d, L);
   ALEGO_LAUNCH(lm_solve, dim3(d.n_launch), dim3(LM_SOLVE_BLOCK), LM_SOLVE_LDS, st, d, L);
   ALEGO_LAUNCH(lm_finish, dim3((d.n_launch + 63) / 64), dim3(64), 0, st, d, L);
   ALEGO_LAUNCH(lm_store_kf, dim3(8, 3, d.n_launch), dim3(LM_BLOCK), 0, st, d, L);
