@@ -218,6 +218,7 @@ __global__ void __launch_bounds__(64) fe_pick(DevCtx d) {
 // RUNS of equal consecutive voxel ids (a few hundred per ring instead of ~1000 points): rank-by-counting of the
 // runs in LDS, then the first run of every voxel accumulates all runs of that voxel in order — the same f32
 // summation order as a stable sort of the points.  Dynamic LDS: 14 B per ring point.
+#define FV_NB 1024
 __global__ void __launch_bounds__(FE_BLOCK) fe_voxel(DevCtx d) {
   const int slot = blockIdx.y + d.slot0, ring = blockIdx.x, tid = threadIdx.x;
   const size_t base = (size_t)slot * d.N;
@@ -234,6 +235,7 @@ __global__ void __launch_bounds__(FE_BLOCK) fe_voxel(DevCtx d) {
   uint16_t* s_order = reinterpret_cast<uint16_t*>(fv_smem + 12 * (size_t)d.H);  // runs sorted by (voxel id, run) [H]
   __shared__ float s_red[6][FE_BLOCK / 64];
   __shared__ int s_scan[FE_BLOCK / 64];
+  __shared__ int s_boff[FV_NB + 1], s_bcur[FV_NB + 1];
   if (n == 0) { if (tid == 0) cnts[4] = 0; return; }
   const float inv = 1.0f / d.P.less_flat_leaf;
   // getMinMax3D
@@ -297,12 +299,53 @@ __global__ void __launch_bounds__(FE_BLOCK) fe_voxel(DevCtx d) {
     __syncthreads();
   }
   for (int r = tid; r < nruns; r += FE_BLOCK) s_rlen[r] = (uint16_t)((r + 1 < nruns ? (int)s_rstart[r + 1] : n) - (int)s_rstart[r]);
-  // rank the runs by (voxel id, run index): LDS broadcast reads, no barriers inside
-  for (int r = tid; r < nruns; r += FE_BLOCK) {
-    const uint32_t v = s_rvid[r];
-    int rank = 0;
-    for (int q = 0; q < nruns; ++q) { const uint32_t u = s_rvid[q]; rank += (u < v) || (u == v && q < r); }
-    s_order[rank] = (uint16_t)r;
+  // Order the runs by (voxel id, run index).  Voxel ids are bounded by the grid size T, so the runs are first dealt
+  // into <= FV_NB buckets that are monotone in the voxel id (LDS atomics; arbitrary order inside a bucket), then
+  // every run ranks itself among the one or two runs of its bucket — instead of against all runs of the ring.
+  {
+    unsigned T = (unsigned)divb[0] * (unsigned)divb[1] * (unsigned)divb[2];
+    if (T == 0) T = 1;
+    int shift = 0;
+    while (((T - 1) >> shift) >= (unsigned)FV_NB) ++shift;
+    const int nb = (int)((T - 1) >> shift) + 1;
+    uint16_t* s_tmp = reinterpret_cast<uint16_t*>(s_key);  // the per-point voxel ids are dead once the runs exist
+    for (int b = tid; b <= nb; b += FE_BLOCK) s_boff[b] = 0;
+    __syncthreads();
+    for (int r = tid; r < nruns; r += FE_BLOCK) atomicAdd(&s_boff[min((int)(s_rvid[r] >> shift), nb - 1) + 1], 1);
+    __syncthreads();
+    // inclusive scan of s_boff[1..nb] (FV_NB / FE_BLOCK consecutive entries per thread) -> bucket b = [s_boff[b], s_boff[b+1])
+    {
+      constexpr int PER = FV_NB / FE_BLOCK;
+      int v[PER], sum = 0;
+#pragma unroll
+      for (int k = 0; k < PER; ++k) { const int b = tid * PER + k; v[k] = b < nb ? s_boff[b + 1] : 0; sum += v[k]; }
+      int incl = sum;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if ((tid & 63) >= o) incl += t; }
+      if ((tid & 63) == 63) s_scan[tid >> 6] = incl;
+      __syncthreads();
+      int run = incl - sum;
+#pragma unroll
+      for (int w = 0; w < FE_BLOCK / 64; ++w) if (w < (tid >> 6)) run += s_scan[w];
+#pragma unroll
+      for (int k = 0; k < PER; ++k) { const int b = tid * PER + k; run += v[k]; if (b < nb) { s_boff[b + 1] = run; s_bcur[b + 1] = run; } }
+      if (tid == 0) s_bcur[0] = 0;
+    }
+    __syncthreads();
+    for (int r = tid; r < nruns; r += FE_BLOCK) {
+      const int b = min((int)(s_rvid[r] >> shift), nb - 1);
+      s_tmp[atomicAdd(&s_bcur[b], 1)] = (uint16_t)r;  // s_bcur[b] starts at s_boff[b] (written one slot up, read one down)
+    }
+    __syncthreads();
+    for (int t = tid; t < nruns; t += FE_BLOCK) {
+      const int r = s_tmp[t];
+      const uint32_t v = s_rvid[r];
+      const int b = min((int)(v >> shift), nb - 1);
+      const int bs = s_boff[b], be = s_boff[b + 1];
+      int rank = bs;
+      for (int q = bs; q < be; ++q) { const int o = s_tmp[q]; const uint32_t u = s_rvid[o]; rank += (u < v) || (u == v && o < r); }
+      s_order[rank] = (uint16_t)r;
+    }
   }
   __syncthreads();
   // first run of every voxel -> output rank; it accumulates all runs of the voxel in order
