@@ -172,6 +172,8 @@ int alego_create(const alego_params* params, int device, int n_slots, int ring_l
   rc |= dalloc(h, &d.feat_cnt, B * 2 * 4); rc |= dalloc(h, &d.ring_off, B * 2 * 2 * (NS + 1));
   d.lo_qcap_surf = d.fcap[F_FLAT]; d.lo_qcap_corner = d.fcap[F_SHARP];
   rc |= dalloc(h, &d.lo_corr, B * (d.lo_qcap_surf + d.lo_qcap_corner) * 4);
+  d.lo_box_cap = (d.N + LO_CH - 1) / LO_CH;
+  rc |= dalloc(h, &d.lo_box, B * 2 * 2 * d.lo_box_cap * 2);
   rc |= dalloc(h, &d.lo_state, B * LO_STATE_N);
   rc |= dalloc(h, &d.poses, B * 16);
   if (rc) { *out = h; int e = ALEGO_ERR_HIP; std::fprintf(stderr, "alego_create: %s\n", h->err.c_str()); alego_destroy(h); *out = nullptr; return e; }

@@ -82,6 +82,8 @@ struct DevCtx {
   // ---- laser odometry ----
   int* lo_corr;         // [slot][qcap][4]  surf rows then corner rows: (query, closest, idx2, idx3) ; closest<0 = none
   int lo_qcap_surf, lo_qcap_corner;
+  float4* lo_box;       // [slot][2 buffers][2 kinds][lo_box_cap][2]: min / max corner of every LO_CH consecutive targets
+  int lo_box_cap;       //   (kind 0: less_flat, 1: less_sharp), written by fe_boxes next to the feature clouds
   double* lo_state;     // [slot][LO_STATE_N]
   // ---- outputs ----
   double* poses;        // [slot][16]: odom t(3) q(4), map t(3) q(4), pad
@@ -97,6 +99,8 @@ enum {
 };
 
 #define DEV_INLINE __device__ __forceinline__
+
+#define LO_CH 32  // targets per bounding box of the LaserOdometry 1-NN / ring-walk pruning
 
 // buffer written by the scan in flight (valid from fe_gather until lo_solve phase 1 flips SC_CUR)
 DEV_INLINE int cur_in_flight(const DevCtx& d, int slot) { return d.scal[slot * SC_COUNT + SC_CUR] ^ 1; }

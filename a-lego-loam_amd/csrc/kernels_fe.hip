@@ -9,6 +9,7 @@
 //   fe_voxel   a10: per-ring pcl::VoxelGrid(0.4): LDS bitonic sort of (voxel id, position),
 //              centroid in sorted (= original) order                           (:288-293)
 //   fe_gather  ring-ascending concatenation into the four feature clouds       (:199-205,:245,:293)
+//   fe_boxes   bounding boxes of 32 consecutive less_flat / less_sharp points for the next scan's LaserOdometry
 #include "dev_common.h"
 #include "prof.h"
 
@@ -433,6 +434,33 @@ __global__ void __launch_bounds__(FE_BLOCK) fe_gather(DevCtx d) {
   }
 }
 
+// Bounding boxes of every LO_CH consecutive points of the less_flat / less_sharp clouds: next scan's LaserOdometry
+// prunes its exact nearest-neighbour searches with them (kernels_lo.hip).  Consecutive points are neighbours on a
+// ring, so the boxes are small.  grid (24, 2, slots), 256 threads = 8 boxes of 32 lanes, grid-stride.
+__global__ void __launch_bounds__(FE_BLOCK) fe_boxes(DevCtx d) {
+  const int slot = blockIdx.z + d.slot0, kind = blockIdx.y;
+  const int cur = cur_in_flight(d, slot);
+  const int tk = kind == 0 ? F_LFLAT : F_LSHARP;
+  const int nt = d.feat_cnt[((size_t)slot * 2 + cur) * 4 + tk];
+  const float4* tg = d.feat[tk] + ((size_t)slot * 2 + cur) * d.fcap[tk];
+  float4* bx = d.lo_box + (((size_t)slot * 2 + cur) * 2 + kind) * d.lo_box_cap * 2;
+  // whole workgroups stride over the boxes, so every lane of a 32-lane group stays in the loop together
+  for (int c0 = blockIdx.x * (FE_BLOCK / LO_CH); c0 * LO_CH < nt; c0 += gridDim.x * (FE_BLOCK / LO_CH)) {
+    const int c = c0 + threadIdx.x / LO_CH;
+    const int t = c * LO_CH + (threadIdx.x % LO_CH);
+    float mn[3] = {3.402823466e+38f, 3.402823466e+38f, 3.402823466e+38f}, mx[3] = {-3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f};
+    if (t < nt) { const float4 p = tg[t]; mn[0] = mx[0] = p.x; mn[1] = mx[1] = p.y; mn[2] = mx[2] = p.z; }
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int o = LO_CH / 2; o > 0; o >>= 1) { mn[a] = fminf(mn[a], __shfl_xor(mn[a], o, 64)); mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], o, 64)); }
+    if ((threadIdx.x % LO_CH) == 0 && c * LO_CH < nt) {
+      bx[2 * c] = make_float4(mn[0], mn[1], mn[2], 0.f);
+      bx[2 * c + 1] = make_float4(mx[0], mx[1], mx[2], 0.f);
+    }
+  }
+}
+
 void launch_fe(const DevCtx& d, hipStream_t st) {
   ALEGO_LAUNCH(fe_curv, dim3((d.N + FE_BLOCK - 1) / FE_BLOCK, d.n_launch), dim3(FE_BLOCK), 0, st, d);
   // the longest sector holds at most ceil(H / n_sectors) + 1 points
@@ -441,4 +469,5 @@ void launch_fe(const DevCtx& d, hipStream_t st) {
   else { ALEGO_LAUNCH(fe_pick<12>, dim3(d.NS, d.n_launch), dim3(64), (size_t)8 * d.H, st, d); }
   ALEGO_LAUNCH(fe_voxel, dim3(d.NS, d.n_launch), dim3(FE_BLOCK), (size_t)14 * d.H, st, d);
   ALEGO_LAUNCH(fe_gather, dim3(d.NS, d.n_launch), dim3(FE_BLOCK), 0, st, d);
+  ALEGO_LAUNCH(fe_boxes, dim3(24, 2, d.n_launch), dim3(FE_BLOCK), 0, st, d);  // 24 x 8 boxes = 6144 targets per sweep
 }

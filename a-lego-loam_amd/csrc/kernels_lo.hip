@@ -2,7 +2,8 @@
 //
 //   lo_assoc   a11-a14: one wavefront per query feature: transformToStart, exact f32 1-NN over the
 //              previous scan's feature cloud (replaces pcl::KdTreeFLANN), then the +-2-ring walks
-//              evaluated as a wave-wide lexicographic arg-min over the contiguous ring interval
+//              evaluated as a lexicographic arg-min over the ring interval; both pruned with the
+//              bounding boxes of 32 consecutive targets
 //   lo_solve   a15-a17: one workgroup per stream runs a whole ceres::Solve (trust-region LM, Huber
 //              corrector, Jacobi scaling) on-chip: residual/Jacobian evaluation in fp64, wavefront
 //              shuffle + LDS reduction of the 21+6+1 normal-equation scalars in a fixed order, 6x6
@@ -39,86 +40,176 @@ DEV_INLINE WalkBest walk_reduce(WalkBest b) {
 }
 
 // kind 0: flat -> surf_last (less_flat of the previous scan); kind 1: sharp -> corner_last (less_sharp).
-// A workgroup takes LO_QPB queries of one stream (LO_QPW per wavefront).  The 1-NN pass streams the target cloud
-// through LDS in tiles shared by all queries of the workgroup (each target is read from HBM/L2 once per 16
-// queries instead of once per query, and each LDS read serves LO_QPW queries); the +-2-ring walk then reads the
-// few hundred candidates of the ring interval directly.
+// A workgroup takes LO_QPB queries of one stream, a wavefront LO_QPW of them one after the other.
+//
+// Both searches of a query are exact and pruned with the bounding boxes of LO_CH consecutive targets (fe_boxes):
+// a box is skipped when its lower bound exceeds the best distance found so far.  The lower bound is evaluated with
+// the same operations, in the same order and precision as the distance itself (clamped per-axis difference, squares,
+// left-to-right sum), and IEEE rounding is monotone, so bound <= distance of every point of the box: no candidate
+// that could win or tie is ever skipped.
+//   1-NN      (flann::L2_Simple<float>, ties -> lowest index): seed = the box with the smallest bound and its
+//             neighbour, then every box whose bound <= seed distance; half a wavefront per box
+//   ring walk (:344-373,:433-475): the reference walks up and down from the closest point inside +-2.5 rings and keeps
+//             the minimum of the double-precision distance per class, first visited on ties; here a lexicographic
+//             (distance, visiting rank) arg-min over the surviving boxes of the ring interval
 #define LO_QPW 4
 #define LO_QPB (LO_QPW * LO_BLOCK / 64)
-#define LO_TILE 2048
 __global__ void __launch_bounds__(LO_BLOCK) lo_assoc(DevCtx d, int kind) {
   const int slot = blockIdx.y + d.slot0;
   const int cur = cur_in_flight(d, slot);
   const int* sc = d.scal + slot * SC_COUNT;
   if (!sc[SC_LO_INIT]) return;
   const int lane = lane_id(), wave = threadIdx.x >> 6;
+  const int half = lane >> 5, l32 = lane & 31;
   const int last = cur ^ 1;
   const int qk = kind == 0 ? F_FLAT : F_SHARP, tk = kind == 0 ? F_LFLAT : F_LSHARP;
   const int nq = d.feat_cnt[((size_t)slot * 2 + cur) * 4 + qk];
   if ((int)blockIdx.x * LO_QPB >= nq) return;
   const int nt = d.feat_cnt[((size_t)slot * 2 + last) * 4 + tk];
   const float4* tg = d.feat[tk] + ((size_t)slot * 2 + last) * d.fcap[tk];
+  const float4* bx = d.lo_box + (((size_t)slot * 2 + last) * 2 + kind) * d.lo_box_cap * 2;
+  const int nch = (nt + LO_CH - 1) / LO_CH;
   const int* roff = d.ring_off + (((size_t)slot * 2 + last) * 2 + (kind == 0 ? 1 : 0)) * (d.NS + 1);
   const double* params = d.lo_state + (size_t)slot * LO_STATE_N + LS_PARAMS;
-  __shared__ float4 s_t[LO_TILE];
-  const int q0 = blockIdx.x * LO_QPB + wave * LO_QPW;
-  float sel[LO_QPW][3];
-  unsigned long long best[LO_QPW];
-#pragma unroll
-  for (int j = 0; j < LO_QPW; ++j) {
-    best[j] = ~0ull;
-    sel[j][0] = sel[j][1] = sel[j][2] = 0.f;
-    if (q0 + j < nq) transform_to_start(params, d.feat[qk][((size_t)slot * 2 + cur) * d.fcap[qk] + q0 + j], sel[j]);
+  __shared__ float s_sel[LO_QPB][4];
+  if (threadIdx.x < LO_QPB) {  // transformToStart once per query (fp64 quaternion), shared through LDS
+    const int q = blockIdx.x * LO_QPB + threadIdx.x;
+    float o[3] = {0.f, 0.f, 0.f};
+    if (q < nq) transform_to_start(params, d.feat[qk][((size_t)slot * 2 + cur) * d.fcap[qk] + q], o);
+    s_sel[threadIdx.x][0] = o[0]; s_sel[threadIdx.x][1] = o[1]; s_sel[threadIdx.x][2] = o[2];
   }
-  // exact 1-NN, flann::L2_Simple<float>; ties -> lowest index
-  for (int t0 = 0; t0 < nt; t0 += LO_TILE) {
-    const int cnt = min(LO_TILE, nt - t0);
-    __syncthreads();
-    for (int i = threadIdx.x; i < cnt; i += LO_BLOCK) s_t[i] = tg[t0 + i];
-    __syncthreads();
-    for (int t = lane; t < cnt; t += 64) {
-      const float4 a = s_t[t];
-#pragma unroll
-      for (int j = 0; j < LO_QPW; ++j) {
-        float r = 0.f, df;
-        df = a.x - sel[j][0]; r += df * df;
-        df = a.y - sel[j][1]; r += df * df;
-        df = a.z - sel[j][2]; r += df * df;
-        const unsigned long long c = ((unsigned long long)(uint32_t)d_f2i(r) << 32) | (uint32_t)(t0 + t);
-        best[j] = c < best[j] ? c : best[j];
-      }
-    }
-  }
+  __syncthreads();
   const double nfd = d.P.nearest_feature_dist;
-#pragma unroll
+  const float INF = __int_as_float(0x7f800000);
   for (int j = 0; j < LO_QPW; ++j) {
-    const int q = q0 + j;
+    const int qi = wave * LO_QPW + j, q = blockIdx.x * LO_QPB + qi;
     if (q >= nq) break;
-    const unsigned long long bj = wave_min_u64(best[j]);
+    const float sx = s_sel[qi][0], sy = s_sel[qi][1], sz = s_sel[qi][2];
     int closest = -1, idx2 = -1, idx3 = -1;
-    if (nt > 0 && (double)d_i2f((int32_t)(bj >> 32)) < nfd) {
-      closest = (int)(uint32_t)bj;
-      const int cr = (int)tg[closest].w;  // int(intensity) = ring (:347,:436)
-      const int W = d.P.ring_window;
-      const int rlo = max(cr - W, 0), rhi = min(cr + W, d.NS - 1);
-      const int lo = roff[rlo], hi = roff[rhi + 1];           // the walks stay inside [lo, hi)
-      const int same_lo = roff[cr], same_hi = roff[cr + 1];
-      WalkBest b2{nfd, 0x7fffffff, -1}, b3{nfd, 0x7fffffff, -1};
-      for (int k = lo + lane; k < hi; k += 64) {
-        if (k == closest) continue;
-        const float4 a = tg[k];
-        const double ex = (double)(a.x - sel[j][0]), ey = (double)(a.y - sel[j][1]), ez = (double)(a.z - sel[j][2]);
-        const double pd = ex * ex + ey * ey + ez * ez;  // pow(f32 diff, 2) summed in double (:354)
-        // visiting order of the reference: closest+1, closest+2, ... then closest-1, closest-2, ...
-        const int rank = k > closest ? k - closest - 1 : (hi - closest - 1) + (closest - 1 - k);
-        const bool same = k >= same_lo && k < same_hi;
-        if (!(pd < nfd)) continue;
-        if (kind == 0) { if (same) walk_consider(b2, pd, rank, k); else walk_consider(b3, pd, rank, k); }
-        else if (!same) walk_consider(b2, pd, rank, k);  // strictly above going up / strictly below going down (:446,:462)
+    if (nt > 0) {
+      // per-axis clamped differences to box c (0 inside the box); the box of a lane beyond nch is infinitely far
+      auto box_diff = [&](int c, float& dx, float& dy, float& dz) {
+        const float4 lo = bx[2 * c], hi = bx[2 * c + 1];
+        dx = fmaxf(fmaxf(lo.x - sx, sx - hi.x), 0.f);
+        dy = fmaxf(fmaxf(lo.y - sy, sy - hi.y), 0.f);
+        dz = fmaxf(fmaxf(lo.z - sz, sz - hi.z), 0.f);
+      };
+      auto lb_f32 = [&](int c) -> float {
+        if (c >= nch) return INF;
+        float dx, dy, dz;
+        box_diff(c, dx, dy, dz);
+        float r = 0.f;
+        r += dx * dx; r += dy * dy; r += dz * dz;
+        return r;
+      };
+      // this lane's target of box c (l32-th point), folded into its running (distance, index) minimum
+      auto nn_eval = [&](int c, unsigned long long best) -> unsigned long long {
+        const int t = c * LO_CH + l32;
+        if (c >= 0 && t < nt) {
+          const float4 a = tg[t];
+          float r = 0.f, df;
+          df = a.x - sx; r += df * df;
+          df = a.y - sy; r += df * df;
+          df = a.z - sz; r += df * df;
+          const unsigned long long k = ((unsigned long long)(uint32_t)d_f2i(r) << 32) | (uint32_t)t;
+          best = k < best ? k : best;
+        }
+        return best;
+      };
+      unsigned long long m1 = ~0ull;
+      for (int c = lane; c < nch; c += 64) {
+        const unsigned long long k = ((unsigned long long)(uint32_t)d_f2i(lb_f32(c)) << 32) | (uint32_t)c;
+        m1 = k < m1 ? k : m1;
       }
-      b2 = walk_reduce(b2);
-      idx2 = b2.idx;
-      if (kind == 0) { b3 = walk_reduce(b3); idx3 = b3.idx; }
+      const int cs = (int)(uint32_t)wave_min_u64(m1);   // box with the smallest bound: nt > 0, so it exists
+      unsigned long long best = nn_eval(half == 0 ? cs : (cs ^ 1), ~0ull);
+      const float bound = d_i2f((int32_t)(wave_min_u64(best) >> 32));
+      for (int c0 = 0; c0 < nch; c0 += 64) {
+        const int c = c0 + lane;
+        unsigned long long surv = __ballot(lb_f32(c) <= bound && (c >> 1) != (cs >> 1));
+        while (surv) {
+          const int a = __ffsll((long long)surv) - 1;
+          surv &= surv - 1;
+          int b = -1;
+          if (surv) { b = __ffsll((long long)surv) - 1; surv &= surv - 1; }
+          best = nn_eval(half == 0 ? c0 + a : (b >= 0 ? c0 + b : -1), best);
+        }
+      }
+      const unsigned long long bj = wave_min_u64(best);
+      if ((double)d_i2f((int32_t)(bj >> 32)) < nfd) {
+        closest = (int)(uint32_t)bj;
+        const int cr = (int)tg[closest].w;  // int(intensity) = ring (:347,:436)
+        const int W = d.P.ring_window;
+        const int rlo = max(cr - W, 0), rhi = min(cr + W, d.NS - 1);
+        const int lo = roff[rlo], hi = roff[rhi + 1];           // the walks stay inside [lo, hi)
+        const int same_lo = roff[cr], same_hi = roff[cr + 1];
+        WalkBest b2{nfd, 0x7fffffff, -1}, b3{nfd, 0x7fffffff, -1};
+        auto walk_eval = [&](int c) {
+          const int k = c * LO_CH + l32;
+          if (c < 0 || k < lo || k >= hi || k == closest) return;
+          const float4 a = tg[k];
+          const double ex = (double)(a.x - sx), ey = (double)(a.y - sy), ez = (double)(a.z - sz);
+          const double pd = ex * ex + ey * ey + ez * ez;  // pow(f32 diff, 2) summed in double (:354)
+          if (!(pd < nfd)) return;
+          // visiting order of the reference: closest+1, closest+2, ... then closest-1, closest-2, ...
+          const int rank = k > closest ? k - closest - 1 : (hi - closest - 1) + (closest - 1 - k);
+          const bool same = k >= same_lo && k < same_hi;
+          if (kind == 0) { if (same) walk_consider(b2, pd, rank, k); else walk_consider(b3, pd, rank, k); }
+          else if (!same) walk_consider(b2, pd, rank, k);  // strictly above going up / strictly below going down (:446,:462)
+        };
+        // class S: same ring (surf only); class O: the other rings of the window.  A box may overlap both.
+        const int cw0 = lo / LO_CH, cw1 = (hi - 1) / LO_CH;
+        auto box_class = [&](int c, bool& inS, bool& inO) {
+          const int k0 = max(c * LO_CH, lo), k1 = min(c * LO_CH + LO_CH, hi);   // [k0, k1) inside the window
+          inS = kind == 0 && k0 < same_hi && k1 > same_lo;
+          inO = k0 < same_lo || k1 > same_hi;
+        };
+        auto lb_f64 = [&](int c) -> double {
+          float dx, dy, dz;
+          box_diff(c, dx, dy, dz);
+          const double ex = (double)dx, ey = (double)dy, ez = (double)dz;
+          return ex * ex + ey * ey + ez * ez;
+        };
+        if (hi > lo) {
+          // seeds: the box of the closest point (its ring neighbours) and the other-ring box with the smallest bound
+          unsigned long long mo = ~0ull;
+          for (int c = cw0 + lane; c <= cw1; c += 64) {
+            bool inS, inO;
+            box_class(c, inS, inO);
+            if (inO) {
+              const unsigned long long k = ((unsigned long long)__double_as_longlong(lb_f64(c)) & 0xFFFFFFFF00000000ull) | (uint32_t)c;
+              mo = k < mo ? k : mo;   // ordered by the high word of the bound: any box is a valid seed
+            }
+          }
+          mo = wave_min_u64(mo);
+          const int cseedS = closest / LO_CH, cseedO = mo == ~0ull ? -1 : (int)(uint32_t)mo;
+          walk_eval(half == 0 ? cseedS : cseedO);
+          // class bounds after the seeds (an upper bound of the final minimum; nfd when nothing was found)
+          const double boundS = __longlong_as_double((long long)wave_min_u64((unsigned long long)__double_as_longlong(kind == 0 ? b2.dist : nfd)));
+          const double boundO = __longlong_as_double((long long)wave_min_u64((unsigned long long)__double_as_longlong(kind == 0 ? b3.dist : b2.dist)));
+          for (int c0 = cw0; c0 <= cw1; c0 += 64) {
+            const int c = c0 + lane;
+            bool take = false;
+            if (c <= cw1 && c != cseedS && c != cseedO) {
+              bool inS, inO;
+              box_class(c, inS, inO);
+              const double lb = lb_f64(c);
+              take = (inS && lb <= boundS) || (inO && lb <= boundO);
+            }
+            unsigned long long surv = __ballot(take);
+            while (surv) {
+              const int a = __ffsll((long long)surv) - 1;
+              surv &= surv - 1;
+              int b = -1;
+              if (surv) { b = __ffsll((long long)surv) - 1; surv &= surv - 1; }
+              walk_eval(half == 0 ? c0 + a : (b >= 0 ? c0 + b : -1));
+            }
+          }
+        }
+        b2 = walk_reduce(b2);
+        idx2 = b2.idx;
+        if (kind == 0) { b3 = walk_reduce(b3); idx3 = b3.idx; }
+      }
     }
     if (lane == 0) {
       int* row = d.lo_corr + ((size_t)slot * (d.lo_qcap_surf + d.lo_qcap_corner) + (kind == 0 ? 0 : d.lo_qcap_surf) + q) * 4;
