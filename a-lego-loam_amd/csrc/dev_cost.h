@@ -160,21 +160,36 @@ DEV_INLINE void accumulate_block(double r, const double J[6], double huber_a, do
   acc[27] += 0.5 * rho0;
 }
 
-// Deterministic workgroup reduction of the 28 normal-equation scalars through LDS: every thread stores its
-// partials k-major (conflict-free), NSEG = T/32 threads per scalar add 32 strided entries each, then one thread
-// per scalar adds the NSEG segment sums in order.  ~40 dependent adds instead of 28 x 6 cross-lane shuffles.
+// Deterministic workgroup reduction of the 28 normal-equation scalars.  Each quad of lanes first adds its four
+// partials with two DPP quad_perm steps (no LDS), one lane per quad stores the sums k-major (conflict-free),
+// NSEG = T/128 threads per scalar add 32 strided entries each, then one thread per scalar adds the NSEG segment
+// sums in order.  The quad step keeps the LDS footprint at 28 x T/4 doubles (28 KB for 512 threads): these solver
+// workgroups live for hundreds of microseconds, and their LDS is what keeps other streams' workgroups off the CU.
+DEV_INLINE double quad_xor_add(double v, const int ctrl_is_xor2) {
+  const long long b = __double_as_longlong(v);
+  int lo = (int)(unsigned)(unsigned long long)b, hi = (int)(unsigned)((unsigned long long)b >> 32);
+  int plo, phi;
+  if (ctrl_is_xor2) { plo = __builtin_amdgcn_update_dpp(lo, lo, 0x4E, 0xF, 0xF, false); phi = __builtin_amdgcn_update_dpp(hi, hi, 0x4E, 0xF, 0xF, false); }
+  else { plo = __builtin_amdgcn_update_dpp(lo, lo, 0xB1, 0xF, 0xF, false); phi = __builtin_amdgcn_update_dpp(hi, hi, 0xB1, 0xF, 0xF, false); }
+  const double o = __longlong_as_double((long long)(((unsigned long long)(unsigned)phi << 32) | (unsigned)plo));
+  return v + o;
+}
 template <int T>
-DEV_INLINE void block_reduce28_lds(const double acc[28], double* s_acc /*[28*T]*/, double* s_seg /*[28*(T/32)]*/, double* s_out /*[28]*/) {
-  constexpr int NSEG = T / 32;
+DEV_INLINE void block_reduce28_lds(const double acc[28], double* s_acc /*[28*T/4]*/, double* s_seg /*[28*(T/128)]*/, double* s_out /*[28]*/) {
+  constexpr int Q = T / 4, NSEG = Q / 32;
   const int tid = threadIdx.x;
 #pragma unroll
-  for (int k = 0; k < 28; ++k) s_acc[k * T + tid] = acc[k];
+  for (int k = 0; k < 28; ++k) {
+    double v = quad_xor_add(acc[k], 0);   // lane ^ 1: both lanes of a pair hold a + b (commutative: identical bits)
+    v = quad_xor_add(v, 1);               // lane ^ 2: all four lanes hold (a + b) + (c + d)
+    if ((tid & 3) == 0) s_acc[k * Q + (tid >> 2)] = v;
+  }
   __syncthreads();
   if (tid < 28 * NSEG) {
     const int k = tid / NSEG, seg = tid - k * NSEG;
     double t = 0;
 #pragma unroll 8
-    for (int j = 0; j < 32; ++j) t += s_acc[k * T + j * NSEG + seg];
+    for (int j = 0; j < 32; ++j) t += s_acc[k * Q + j * NSEG + seg];
     s_seg[k * NSEG + seg] = t;
   }
   __syncthreads();

@@ -10,6 +10,7 @@
 //              centroid in sorted (= original) order                           (:288-293)
 //   fe_gather  ring-ascending concatenation into the four feature clouds       (:199-205,:245,:293)
 //   fe_boxes   bounding boxes of 32 consecutive less_flat / less_sharp points for the next scan's LaserOdometry
+#include <cstdlib>
 #include "dev_common.h"
 #include "prof.h"
 
@@ -82,8 +83,8 @@ __global__ void __launch_bounds__(FE_BLOCK) fe_curv(DevCtx d) {
   d.picked0[base + i] = pk;
 }
 
-// one wavefront per (ring, slot).  Dynamic LDS: 8 bytes per ring point (key u32, column u16, flags u8, label i8),
-// so a 16x1800 sensor keeps 10+ rings resident per CU.
+// one wavefront per (ring, slot).  Dynamic LDS: 4 bytes per ring point (column u16, flags u8, label i8); the
+// kernel's duration under load is set by how many rings fit a CU next to the other streams' workgroups.
 // flag bits: 0 picked, 1 ground, 2 curvature > edge_thres, 3 curvature < surf_thres
 template <int FE_T>
 __global__ void __launch_bounds__(64) fe_pick(DevCtx d) {
@@ -94,15 +95,14 @@ __global__ void __launch_bounds__(64) fe_pick(DevCtx d) {
   const int rf = S - 5, rl = E + 5;  // first / last point of this ring in the segmented cloud
   const int cnt = rl - rf + 1;
   extern __shared__ __attribute__((aligned(16))) unsigned char fe_smem[];
-  uint32_t* s_key = reinterpret_cast<uint32_t*>(fe_smem);                 // |cd| bit pattern: curvature order == unsigned order
-  uint16_t* s_col = reinterpret_cast<uint16_t*>(fe_smem + 4 * (size_t)d.H);
-  uint8_t* s_flag = fe_smem + 6 * (size_t)d.H;
-  int8_t* s_label = reinterpret_cast<int8_t*>(fe_smem + 7 * (size_t)d.H);
+  uint16_t* s_col = reinterpret_cast<uint16_t*>(fe_smem);
+  uint8_t* s_flag = fe_smem + 2 * (size_t)d.H;
+  int8_t* s_label = reinterpret_cast<int8_t*>(fe_smem + 3 * (size_t)d.H);
+  const float* cdv = d.cd + base + rf;  // |cd| bit pattern = sort key: curvature order == unsigned order
   for (int k = lane; k < cnt; k += 64) {
     const float a = fabsf(d.cd[base + rf + k]);
     const double ad = (double)a;
     const double curv = ad * ad;  // (double)diff_range * diff_range, exact (:125)
-    s_key[k] = (uint32_t)d_f2i(a);
     s_col[k] = (uint16_t)d.seg_col[base + rf + k];
     s_flag[k] = (uint8_t)((d.picked0[base + rf + k] & 1) | (d.seg_ground[base + rf + k] ? 2 : 0) |
                           (curv > P.edge_thres ? 4 : 0) | (curv < P.surf_thres ? 8 : 0));
@@ -129,7 +129,7 @@ __global__ void __launch_bounds__(64) fe_pick(DevCtx d) {
       key[t] = 0;
       if (c <= lep) {
         const uint8_t f = s_flag[c];
-        key[t] = s_key[c];
+        key[t] = (uint32_t)d_f2i(fabsf(cdv[c]));  // straight from HBM/L2: the LDS footprint decides how many rings fit a CU
         if ((f & 7) == 4) sharp_m |= 1u << t;    // not picked, not ground, curvature > edge_thres
         if ((f & 11) == 10) flat_m |= 1u << t;   // not picked, ground, curvature < surf_thres
       }
@@ -465,8 +465,9 @@ void launch_fe(const DevCtx& d, hipStream_t st) {
   ALEGO_LAUNCH(fe_curv, dim3((d.N + FE_BLOCK - 1) / FE_BLOCK, d.n_launch), dim3(FE_BLOCK), 0, st, d);
   // the longest sector holds at most ceil(H / n_sectors) + 1 points
   const int sector_max = (d.H + d.P.n_sectors - 1) / (d.P.n_sectors > 0 ? d.P.n_sectors : 1) + 2;
-  if (sector_max <= 64 * 6) { ALEGO_LAUNCH(fe_pick<6>, dim3(d.NS, d.n_launch), dim3(64), (size_t)8 * d.H, st, d); }
-  else { ALEGO_LAUNCH(fe_pick<12>, dim3(d.NS, d.n_launch), dim3(64), (size_t)8 * d.H, st, d); }
+  static const int extra = getenv("ALEGO_DBG_EXTRA_LDS") ? atoi(getenv("ALEGO_DBG_EXTRA_LDS")) : 0;
+  if (sector_max <= 64 * 6) { ALEGO_LAUNCH(fe_pick<6>, dim3(d.NS, d.n_launch), dim3(64), (size_t)4 * d.H + extra, st, d); }
+  else { ALEGO_LAUNCH(fe_pick<12>, dim3(d.NS, d.n_launch), dim3(64), (size_t)4 * d.H, st, d); }
   ALEGO_LAUNCH(fe_voxel, dim3(d.NS, d.n_launch), dim3(FE_BLOCK), (size_t)14 * d.H, st, d);
   ALEGO_LAUNCH(fe_gather, dim3(d.NS, d.n_launch), dim3(FE_BLOCK), 0, st, d);
   ALEGO_LAUNCH(fe_boxes, dim3(24, 2, d.n_launch), dim3(FE_BLOCK), 0, st, d);  // 24 x 8 boxes = 6144 targets per sweep

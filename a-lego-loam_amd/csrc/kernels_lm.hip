@@ -468,7 +468,7 @@ __global__ void __launch_bounds__(LM_SOLVE_BLOCK) lm_solve(DevCtx d, LmCtx L) {
   }
   extern __shared__ __attribute__((aligned(16))) unsigned char lm_smem[];
   double* s_acc = reinterpret_cast<double*>(lm_smem);                // [28][LM_SOLVE_BLOCK]
-  double* s_seg = s_acc + 28 * LM_SOLVE_BLOCK;                        // [28][LM_SOLVE_BLOCK/32]
+  double* s_seg = s_acc + 28 * (LM_SOLVE_BLOCK / 4);                  // [28][LM_SOLVE_BLOCK/128]
   __shared__ double s_out[28];
   __shared__ LmState S;
   __shared__ int s_action, s_cnt[2][LM_SOLVE_BLOCK / 64];
@@ -673,7 +673,7 @@ __global__ void __launch_bounds__(LM_BLOCK) lm_store_kf(DevCtx d, LmCtx L) {
   if (blockIdx.x == 0 && threadIdx.x == 0) L.kf_cnt[((size_t)slot * L.K + ring) * 4 + kind] = n;
 }
 
-#define LM_SOLVE_LDS ((size_t)(28 * LM_SOLVE_BLOCK + 28 * (LM_SOLVE_BLOCK / 32)) * sizeof(double))
+#define LM_SOLVE_LDS ((size_t)(28 * (LM_SOLVE_BLOCK / 4) + 28 * (LM_SOLVE_BLOCK / 128)) * sizeof(double))
 int lm_configure() {
   return hipFuncSetAttribute(reinterpret_cast<const void*>(lm_solve), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LM_SOLVE_LDS) == hipSuccess ? 0 : -1;
 }

@@ -248,7 +248,7 @@ __global__ void __launch_bounds__(LO_BLOCK) lo_solve(DevCtx d, int phase) {
   double* st = d.lo_state + (size_t)slot * LO_STATE_N;
   extern __shared__ __attribute__((aligned(16))) unsigned char lo_smem[];
   double* s_acc = reinterpret_cast<double*>(lo_smem);                // [28][LO_BLOCK]
-  double* s_seg = s_acc + 28 * LO_BLOCK;                              // [28][LO_BLOCK/32]
+  double* s_seg = s_acc + 28 * (LO_BLOCK / 4);                        // [28][LO_BLOCK/128]
   __shared__ double s_out[28];
   __shared__ LmState S;
   __shared__ int s_action, s_cnt[LO_BLOCK / 64];
@@ -351,7 +351,7 @@ __global__ void __launch_bounds__(LO_BLOCK) lo_solve(DevCtx d, int phase) {
   }
 }
 
-#define LO_SOLVE_LDS ((size_t)(28 * LO_BLOCK + 28 * (LO_BLOCK / 32)) * sizeof(double))
+#define LO_SOLVE_LDS ((size_t)(28 * (LO_BLOCK / 4) + 28 * (LO_BLOCK / 128)) * sizeof(double))
 int lo_configure() {
   return hipFuncSetAttribute(reinterpret_cast<const void*>(lo_solve), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LO_SOLVE_LDS) == hipSuccess ? 0 : -1;
 }
