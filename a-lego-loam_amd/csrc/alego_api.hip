@@ -181,6 +181,7 @@ int alego_create(const alego_params* params, int device, int n_slots, int ring_l
   std::vector<double> st(B * LO_STATE_N, 0.0), po(B * 16, 0.0);
   for (size_t b = 0; b < B; ++b) {
     st[b * LO_STATE_N + LS_RW + 0] = st[b * LO_STATE_N + LS_RW + 4] = st[b * LO_STATE_N + LS_RW + 8] = 1.0;
+    for (int k = 0; k < 6; ++k) st[b * LO_STATE_N + LS_ROT_P + k] = std::nan("");  // no cached rotation yet
     po[b * 16 + 3] = 1.0; po[b * 16 + 10] = 1.0;
   }
   std::vector<int> sc0(B * SC_COUNT, 0);

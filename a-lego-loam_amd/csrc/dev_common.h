@@ -95,7 +95,9 @@ enum {
   LS_RW = 9,            // r_w_cur_[9] row-major
   LS_PARAMS_SURF = 18,  // params_ after the surf solve (debug)
   LS_COSTS = 24,        // initial/final cost of both solves
-  LO_STATE_N = 32
+  LS_ROT = 32,          // rotation matrix of params_ (row-major), cached for transformToStart ...
+  LS_ROT_P = 41,        // ... and the params_ it was computed from (recomputed by lo_assoc when they differ)
+  LO_STATE_N = 48
 };
 
 #define DEV_INLINE __device__ __forceinline__
@@ -213,6 +215,22 @@ DEV_INLINE unsigned long long wave_max_u64(unsigned long long v) {
 DEV_INLINE unsigned long long wave_min_u64(unsigned long long v) {
   const uint32_t hi = wave_min_u32((uint32_t)(v >> 32));
   const uint32_t lo = wave_min_u32((uint32_t)(v >> 32) == hi ? (uint32_t)v : 0xFFFFFFFFu);
+  return ((unsigned long long)hi << 32) | lo;
+}
+
+// 16-lane (one DPP row) versions: every lane of the row gets the result; no cross-row traffic at all
+DEV_INLINE uint32_t row16_max_u32(uint32_t v) {
+  int x = (int)v, t;
+  t = __builtin_amdgcn_update_dpp(x, x, 0xB1, 0xF, 0xF, false); x = (uint32_t)t > (uint32_t)x ? t : x;
+  t = __builtin_amdgcn_update_dpp(x, x, 0x4E, 0xF, 0xF, false); x = (uint32_t)t > (uint32_t)x ? t : x;
+  t = __builtin_amdgcn_update_dpp(x, x, 0x141, 0xF, 0xF, false); x = (uint32_t)t > (uint32_t)x ? t : x;
+  t = __builtin_amdgcn_update_dpp(x, x, 0x140, 0xF, 0xF, false); x = (uint32_t)t > (uint32_t)x ? t : x;
+  return (uint32_t)x;
+}
+DEV_INLINE uint32_t row16_min_u32(uint32_t v) { return ~row16_max_u32(~v); }
+DEV_INLINE unsigned long long row16_min_u64(unsigned long long v) {
+  const uint32_t hi = row16_min_u32((uint32_t)(v >> 32));
+  const uint32_t lo = row16_min_u32((uint32_t)(v >> 32) == hi ? (uint32_t)v : 0xFFFFFFFFu);
   return ((unsigned long long)hi << 32) | lo;
 }
 

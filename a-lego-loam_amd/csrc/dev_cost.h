@@ -77,6 +77,27 @@ DEV_INLINE PoseTerms pose_terms(const double* p) {
   return T;
 }
 
+// The same terms computed cooperatively by a workgroup: six lanes take one angle each (the three half angles of the
+// quaternion, the three full angles of the Jacobian terms), everybody assembles the result from LDS.  Evaluating the
+// nine sin/cos pairs in every thread cost ~2000 fp64 instructions per wavefront and solver evaluation — most of what
+// lo_solve / lm_solve issued.  Same sin()/cos() calls on the same arguments: bit-identical to pose_terms().
+// Ends with a barrier; the caller must pass another barrier before the next call (block_reduce28_lds does).
+DEV_INLINE PoseTerms pose_terms_coop(const double* p, double* s_trig /*[12] LDS*/) {
+  const int tid = threadIdx.x;
+  if (tid < 6) {
+    const double a = tid == 0 ? 0.5 * p[5] : tid == 1 ? 0.5 * p[4] : tid == 2 ? 0.5 * p[3] : tid == 3 ? p[3] : tid == 4 ? p[4] : p[5];
+    s_trig[2 * tid] = cos(a);
+    s_trig[2 * tid + 1] = sin(a);
+  }
+  __syncthreads();
+  PoseTerms T;
+  const DQuat qz{s_trig[0], 0, 0, s_trig[1]}, qy{s_trig[2], 0, s_trig[3], 0}, qx{s_trig[4], s_trig[5], 0, 0};
+  T.q = dq_mul(dq_mul(qz, qy), qx);
+  T.t[0] = p[0]; T.t[1] = p[1]; T.t[2] = p[2];
+  T.cr = s_trig[6]; T.sr = s_trig[7]; T.cp = s_trig[8]; T.sp = s_trig[9]; T.cy = s_trig[10]; T.sy = s_trig[11];
+  return T;
+}
+
 // residual + 1x6 Jacobian (uncorrected).  a = lpj | plane normal, b = lpl, c = lpm, dd = negative_OA_dot_norm.
 DEV_INLINE void eval_block(int type, const double cp_[3], const double a[3], const double b[3], const double c[3], double dd,
                            const PoseTerms& T, double* res, double J[6]) {

@@ -270,13 +270,17 @@ DEV_INLINE void d_qr53(double A[3][5], double b[5], double x[3]) {
   }
 }
 
-// 16-lane row minimum of a u64 (high word, then low word among the winners): every lane of the row gets it
+// minimum of a u64 over a group of LM_KNN_LANES consecutive lanes (high word, then low word among the winners): every
+// lane of the group gets it.  DPP quad_perm xor 1, xor 2, row_half_mirror cover 8 lanes; row_mirror extends to 16.
+#ifndef LM_KNN_LANES
+#define LM_KNN_LANES 4   // measured at 1024 streams: 16 lanes 1008 us, 8: 689, 4: 581, 2: 662, 1: 1176
+#endif
 DEV_INLINE uint32_t row_max_u32(uint32_t v) {
   int x = (int)v, t;
-  t = __builtin_amdgcn_update_dpp(x, x, 0xB1, 0xF, 0xF, false); x = (uint32_t)t > (uint32_t)x ? t : x;
-  t = __builtin_amdgcn_update_dpp(x, x, 0x4E, 0xF, 0xF, false); x = (uint32_t)t > (uint32_t)x ? t : x;
-  t = __builtin_amdgcn_update_dpp(x, x, 0x141, 0xF, 0xF, false); x = (uint32_t)t > (uint32_t)x ? t : x;
-  t = __builtin_amdgcn_update_dpp(x, x, 0x140, 0xF, 0xF, false); x = (uint32_t)t > (uint32_t)x ? t : x;
+  if (LM_KNN_LANES >= 2) { t = __builtin_amdgcn_update_dpp(x, x, 0xB1, 0xF, 0xF, false); x = (uint32_t)t > (uint32_t)x ? t : x; }
+  if (LM_KNN_LANES >= 4) { t = __builtin_amdgcn_update_dpp(x, x, 0x4E, 0xF, 0xF, false); x = (uint32_t)t > (uint32_t)x ? t : x; }
+  if (LM_KNN_LANES >= 8) { t = __builtin_amdgcn_update_dpp(x, x, 0x141, 0xF, 0xF, false); x = (uint32_t)t > (uint32_t)x ? t : x; }
+  if (LM_KNN_LANES == 16) { t = __builtin_amdgcn_update_dpp(x, x, 0x140, 0xF, 0xF, false); x = (uint32_t)t > (uint32_t)x ? t : x; }
   return (uint32_t)x;
 }
 DEV_INLINE unsigned long long row_min_u64(unsigned long long v) {
@@ -285,9 +289,10 @@ DEV_INLINE unsigned long long row_min_u64(unsigned long long v) {
   return ((unsigned long long)hi << 32) | lo;
 }
 
-// grid (LM_ASSOC_GX, 2, slots): 16 lanes (one DPP row) per query, 8 queries per 128-thread workgroup, grid-stride
-// over the queries.  The 16 lanes split the candidates of the 27 surrounding cells, keep a private top-5 each and
-// merge them with five row-wide arg-min rounds; lane 0 of the row then fits the line / plane.
+// grid (LM_ASSOC_GX, 2, slots): LM_KNN_LANES lanes per query, 128-thread workgroups, grid-stride over the queries.
+// The lanes of a group split the candidates of the 27 surrounding cells, keep a private top-5 each and merge them
+// with five group-wide arg-min rounds.  The kernel is instruction-issue bound: with 4 lanes per query the per-query
+// fixed work (pose transform, cell addressing, merge) is shared by 16 queries per wavefront.
 #define LM_ASSOC_GX 64
 __global__ void __launch_bounds__(128) lm_knn(DevCtx d, LmCtx L) {
   const int slot = blockIdx.z + d.slot0, kind = blockIdx.y;
@@ -305,8 +310,12 @@ __global__ void __launch_bounds__(128) lm_knn(DevCtx d, LmCtx L) {
   const float4* cp = L.cell_pts + ((size_t)slot * 2 + kind) * L.map_cap_s;
   const double* ld = ldp(L, slot);
   const DQuat qm = ldq(ld + LD_Q_M2L);
-  const int sub = threadIdx.x & 15;
-  for (int q = blockIdx.x * 8 + (threadIdx.x >> 4); q < nq; q += gridDim.x * 8) {
+  constexpr int QPB = 128 / LM_KNN_LANES;
+  const int sub = threadIdx.x & (LM_KNN_LANES - 1);
+  // every lane of a wavefront runs the same number of iterations (DPP reads neighbours' registers): clamp, don't exit
+  const int nq_round = (nq + QPB - 1) / QPB * QPB;
+  for (int qq = blockIdx.x * QPB + threadIdx.x / LM_KNN_LANES; qq < nq_round; qq += gridDim.x * QPB) {
+  const int q = min(qq, nq - 1);
   const float4 pin = qp[q];
   // pointAssociateToMap laserMapping.h:187-194 (pose predicted from odometry)
   const double vin[3] = {pin.x, pin.y, pin.z};
@@ -331,7 +340,7 @@ __global__ void __launch_bounds__(128) lm_knn(DevCtx d, LmCtx L) {
         if (x0 > x1) continue;
         const int c0 = x0 + g.gx * (y + g.gy * z), c1 = x1 + g.gx * (y + g.gy * z);
         const int tend = cs[c1 + 1];
-        for (int t = cs[c0] + sub; t < tend; t += 16) {  // the x-run of cells is contiguous in the cell-sorted copy
+        for (int t = cs[c0] + sub; t < tend; t += LM_KNN_LANES) {  // the x-run of cells is contiguous in the cell-sorted copy
           const float4 a = cp[t];
           const int idx = __float_as_int(a.w);
           float dist = 0.f, df;
@@ -370,7 +379,7 @@ __global__ void __launch_bounds__(128) lm_knn(DevCtx d, LmCtx L) {
     for (int k = 0; k < 5; ++k) { bd[k] = rd[k]; bi[k] = ri[k]; }
   }
   // neighbour indices (ascending distance) for lm_fit; idx[0] < 0 = rejected (:376,:426)
-  if (sub == 0) {
+  if (sub == 0 && qq < nq) {
     int* kn = L.knn + ((size_t)slot * L.qcap + (kind == 0 ? 0 : L.kf_cap_c) + q) * 5;
     const bool ok = bi[4] != 0x7fffffff && (double)bd[4] < P.knn_max_dist;
 #pragma unroll
@@ -469,7 +478,7 @@ __global__ void __launch_bounds__(LM_SOLVE_BLOCK) lm_solve(DevCtx d, LmCtx L) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lm_smem[];
   double* s_acc = reinterpret_cast<double*>(lm_smem);                // [28][LM_SOLVE_BLOCK]
   double* s_seg = s_acc + 28 * (LM_SOLVE_BLOCK / 4);                  // [28][LM_SOLVE_BLOCK/128]
-  __shared__ double s_out[28];
+  __shared__ double s_out[28], s_trig[12];
   __shared__ LmState S;
   __shared__ int s_action, s_cnt[2][LM_SOLVE_BLOCK / 64];
   const int nqc = li[LI_NCUR_C], nqs = li[LI_NTOTAL_DS];
@@ -504,7 +513,7 @@ __global__ void __launch_bounds__(LM_SOLVE_BLOCK) lm_solve(DevCtx d, LmCtx L) {
 #pragma unroll
     for (int k = 0; k < 28; ++k) acc[k] = 0;
     PoseTerms T;
-    TM(0, T = pose_terms(x));
+    TM(0, T = pose_terms_coop(x, s_trig));
 #ifdef ALEGO_TIMING
     const long long c1_ = clock64();
 #endif

@@ -1,6 +1,6 @@
 // kernels_lo.hip — scan-to-scan LaserOdometry on gfx950 (replaces src/laserOdometry.cpp:328-534).
 //
-//   lo_assoc   a11-a14: one wavefront per query feature: transformToStart, exact f32 1-NN over the
+//   lo_assoc   a11-a14: 16 lanes per query feature: transformToStart, exact f32 1-NN over the
 //              previous scan's feature cloud (replaces pcl::KdTreeFLANN), then the +-2-ring walks
 //              evaluated as a lexicographic arg-min over the ring interval; both pruned with the
 //              bounding boxes of 32 consecutive targets
@@ -13,10 +13,21 @@
 
 #define LO_BLOCK 256
 
-DEV_INLINE void transform_to_start(const double* p, const float4& pi, float out[3]) {  // laserOdometry.cpp:728-740
+// transformToStart (laserOdometry.cpp:728-740) = R(params_) * p + t.  R depends on the pose only, not on the point:
+// lo_solve caches it next to the pose (three fp64 sin/cos pairs are a thousand instructions), lo_assoc applies it.
+DEV_INLINE void pose_rotation(const double* p, double R[9]) {
   const DQuat q = dq_zyx(p[5], p[4], p[3]);
-  double R[9];
   dq_to_mat(q, R);
+}
+DEV_INLINE void store_pose_rotation(double* st) {
+  double R[9];
+  pose_rotation(st + LS_PARAMS, R);
+#pragma unroll
+  for (int k = 0; k < 9; ++k) st[LS_ROT + k] = R[k];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) st[LS_ROT_P + k] = st[LS_PARAMS + k];
+}
+DEV_INLINE void transform_to_start(const double* R, const double* p, const float4& pi, float out[3]) {
   const double x = pi.x, y = pi.y, z = pi.z;
   out[0] = (float)(R[0] * x + R[1] * y + R[2] * z + p[0]);
   out[1] = (float)(R[3] * x + R[4] * y + R[5] * z + p[1]);
@@ -40,7 +51,8 @@ DEV_INLINE WalkBest walk_reduce(WalkBest b) {
 }
 
 // kind 0: flat -> surf_last (less_flat of the previous scan); kind 1: sharp -> corner_last (less_sharp).
-// A workgroup takes LO_QPB queries of one stream, a wavefront LO_QPW of them one after the other.
+// One DPP row (16 lanes) per query, four queries per wavefront in lock-step, LO_QPB per workgroup: the kernel is
+// instruction-issue bound, and every reduction below is four row-local DPP steps shared by the four queries.
 //
 // Both searches of a query are exact and pruned with the bounding boxes of LO_CH consecutive targets (fe_boxes):
 // a box is skipped when its lower bound exceeds the best distance found so far.  The lower bound is evaluated with
@@ -48,19 +60,31 @@ DEV_INLINE WalkBest walk_reduce(WalkBest b) {
 // left-to-right sum), and IEEE rounding is monotone, so bound <= distance of every point of the box: no candidate
 // that could win or tie is ever skipped.
 //   1-NN      (flann::L2_Simple<float>, ties -> lowest index): seed = the box with the smallest bound and its
-//             neighbour, then every box whose bound <= seed distance; half a wavefront per box
+//             neighbour, then every box whose bound <= seed distance
 //   ring walk (:344-373,:433-475): the reference walks up and down from the closest point inside +-2.5 rings and keeps
 //             the minimum of the double-precision distance per class, first visited on ties; here a lexicographic
 //             (distance, visiting rank) arg-min over the surviving boxes of the ring interval
-#define LO_QPW 4
-#define LO_QPB (LO_QPW * LO_BLOCK / 64)
+#define LO_QPB (LO_BLOCK / 16)
+#define LO_BOX_LDS 512   // boxes (of LO_CH targets) staged in LDS: 16 KB
+DEV_INLINE WalkBest walk_reduce_row(WalkBest b) {
+  const unsigned long long bits = (unsigned long long)__double_as_longlong(b.dist);
+  const unsigned long long mn = row16_min_u64(bits);
+  const uint32_t rk = row16_min_u32(bits == mn ? (uint32_t)b.rank : 0xFFFFFFFFu);
+  const uint32_t ix = row16_min_u32((bits == mn && (uint32_t)b.rank == rk) ? (uint32_t)b.idx : 0xFFFFFFFFu);
+  WalkBest r;
+  r.dist = __longlong_as_double((long long)mn); r.rank = (int)rk; r.idx = (int)ix;  // idx -1 (0xFFFFFFFF) = none
+  return r;
+}
+// the 16 bits of a wave-wide ballot that belong to this lane's row
+DEV_INLINE uint32_t row_bits(unsigned long long ballot, int lane) { return (uint32_t)(ballot >> (lane & 48)) & 0xFFFFu; }
+
 __global__ void __launch_bounds__(LO_BLOCK) lo_assoc(DevCtx d, int kind) {
+  static_assert(LO_CH == 32, "a box is evaluated as two targets per lane of a 16-lane row");
   const int slot = blockIdx.y + d.slot0;
   const int cur = cur_in_flight(d, slot);
   const int* sc = d.scal + slot * SC_COUNT;
   if (!sc[SC_LO_INIT]) return;
-  const int lane = lane_id(), wave = threadIdx.x >> 6;
-  const int half = lane >> 5, l32 = lane & 31;
+  const int lane = lane_id(), l16 = lane & 15;
   const int last = cur ^ 1;
   const int qk = kind == 0 ? F_FLAT : F_SHARP, tk = kind == 0 ? F_LFLAT : F_LSHARP;
   const int nq = d.feat_cnt[((size_t)slot * 2 + cur) * 4 + qk];
@@ -70,152 +94,180 @@ __global__ void __launch_bounds__(LO_BLOCK) lo_assoc(DevCtx d, int kind) {
   const float4* bx = d.lo_box + (((size_t)slot * 2 + last) * 2 + kind) * d.lo_box_cap * 2;
   const int nch = (nt + LO_CH - 1) / LO_CH;
   const int* roff = d.ring_off + (((size_t)slot * 2 + last) * 2 + (kind == 0 ? 1 : 0)) * (d.NS + 1);
-  const double* params = d.lo_state + (size_t)slot * LO_STATE_N + LS_PARAMS;
+  const double* st = d.lo_state + (size_t)slot * LO_STATE_N;
   __shared__ float s_sel[LO_QPB][4];
-  if (threadIdx.x < LO_QPB) {  // transformToStart once per query (fp64 quaternion), shared through LDS
-    const int q = blockIdx.x * LO_QPB + threadIdx.x;
-    float o[3] = {0.f, 0.f, 0.f};
-    if (q < nq) transform_to_start(params, d.feat[qk][((size_t)slot * 2 + cur) * d.fcap[qk] + q], o);
+  __shared__ double s_pose[12];
+  __shared__ float4 s_box[2 * LO_BOX_LDS];   // the boxes are read by every query of the workgroup: LDS when they fit
+  __shared__ int s_roff[65];
+  const bool box_lds = nch <= LO_BOX_LDS;
+  if (box_lds) for (int i = threadIdx.x; i < 2 * nch; i += LO_BLOCK) s_box[i] = bx[i];
+  for (int i = threadIdx.x; i <= d.NS; i += LO_BLOCK) s_roff[i] = roff[i];
+  if (threadIdx.x == 0) {
+    bool same = true;   // NaN (nothing cached yet) or a pose written by alego_set_lo_params compares unequal
+#pragma unroll
+    for (int k = 0; k < 6; ++k) same = same && st[LS_ROT_P + k] == st[LS_PARAMS + k];
+    double R[9];
+    if (same) {
+#pragma unroll
+      for (int k = 0; k < 9; ++k) R[k] = st[LS_ROT + k];
+    } else {
+      pose_rotation(st + LS_PARAMS, R);
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) s_pose[k] = R[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) s_pose[9 + k] = st[LS_PARAMS + k];
+  }
+  __syncthreads();
+  if (threadIdx.x < LO_QPB) {  // transformToStart once per query, shared through LDS
+    const int q = min((int)(blockIdx.x * LO_QPB + threadIdx.x), nq - 1);
+    float o[3];
+    transform_to_start(s_pose, s_pose + 9, d.feat[qk][((size_t)slot * 2 + cur) * d.fcap[qk] + q], o);
     s_sel[threadIdx.x][0] = o[0]; s_sel[threadIdx.x][1] = o[1]; s_sel[threadIdx.x][2] = o[2];
   }
   __syncthreads();
   const double nfd = d.P.nearest_feature_dist;
   const float INF = __int_as_float(0x7f800000);
-  for (int j = 0; j < LO_QPW; ++j) {
-    const int qi = wave * LO_QPW + j, q = blockIdx.x * LO_QPB + qi;
-    if (q >= nq) break;
-    const float sx = s_sel[qi][0], sy = s_sel[qi][1], sz = s_sel[qi][2];
-    int closest = -1, idx2 = -1, idx3 = -1;
-    if (nt > 0) {
-      // per-axis clamped differences to box c (0 inside the box); the box of a lane beyond nch is infinitely far
-      auto box_diff = [&](int c, float& dx, float& dy, float& dz) {
-        const float4 lo = bx[2 * c], hi = bx[2 * c + 1];
-        dx = fmaxf(fmaxf(lo.x - sx, sx - hi.x), 0.f);
-        dy = fmaxf(fmaxf(lo.y - sy, sy - hi.y), 0.f);
-        dz = fmaxf(fmaxf(lo.z - sz, sz - hi.z), 0.f);
-      };
-      auto lb_f32 = [&](int c) -> float {
-        if (c >= nch) return INF;
-        float dx, dy, dz;
-        box_diff(c, dx, dy, dz);
-        float r = 0.f;
-        r += dx * dx; r += dy * dy; r += dz * dz;
-        return r;
-      };
-      // this lane's target of box c (l32-th point), folded into its running (distance, index) minimum
-      auto nn_eval = [&](int c, unsigned long long best) -> unsigned long long {
-        const int t = c * LO_CH + l32;
-        if (c >= 0 && t < nt) {
-          const float4 a = tg[t];
-          float r = 0.f, df;
-          df = a.x - sx; r += df * df;
-          df = a.y - sy; r += df * df;
-          df = a.z - sz; r += df * df;
-          const unsigned long long k = ((unsigned long long)(uint32_t)d_f2i(r) << 32) | (uint32_t)t;
-          best = k < best ? k : best;
-        }
-        return best;
-      };
-      unsigned long long m1 = ~0ull;
-      for (int c = lane; c < nch; c += 64) {
-        const unsigned long long k = ((unsigned long long)(uint32_t)d_f2i(lb_f32(c)) << 32) | (uint32_t)c;
-        m1 = k < m1 ? k : m1;
-      }
-      const int cs = (int)(uint32_t)wave_min_u64(m1);   // box with the smallest bound: nt > 0, so it exists
-      unsigned long long best = nn_eval(half == 0 ? cs : (cs ^ 1), ~0ull);
-      const float bound = d_i2f((int32_t)(wave_min_u64(best) >> 32));
-      for (int c0 = 0; c0 < nch; c0 += 64) {
-        const int c = c0 + lane;
-        unsigned long long surv = __ballot(lb_f32(c) <= bound && (c >> 1) != (cs >> 1));
-        while (surv) {
-          const int a = __ffsll((long long)surv) - 1;
-          surv &= surv - 1;
-          int b = -1;
-          if (surv) { b = __ffsll((long long)surv) - 1; surv &= surv - 1; }
-          best = nn_eval(half == 0 ? c0 + a : (b >= 0 ? c0 + b : -1), best);
-        }
-      }
-      const unsigned long long bj = wave_min_u64(best);
-      if ((double)d_i2f((int32_t)(bj >> 32)) < nfd) {
-        closest = (int)(uint32_t)bj;
-        const int cr = (int)tg[closest].w;  // int(intensity) = ring (:347,:436)
-        const int W = d.P.ring_window;
-        const int rlo = max(cr - W, 0), rhi = min(cr + W, d.NS - 1);
-        const int lo = roff[rlo], hi = roff[rhi + 1];           // the walks stay inside [lo, hi)
-        const int same_lo = roff[cr], same_hi = roff[cr + 1];
-        WalkBest b2{nfd, 0x7fffffff, -1}, b3{nfd, 0x7fffffff, -1};
-        auto walk_eval = [&](int c) {
-          const int k = c * LO_CH + l32;
-          if (c < 0 || k < lo || k >= hi || k == closest) return;
-          const float4 a = tg[k];
-          const double ex = (double)(a.x - sx), ey = (double)(a.y - sy), ez = (double)(a.z - sz);
-          const double pd = ex * ex + ey * ey + ez * ez;  // pow(f32 diff, 2) summed in double (:354)
-          if (!(pd < nfd)) return;
-          // visiting order of the reference: closest+1, closest+2, ... then closest-1, closest-2, ...
-          const int rank = k > closest ? k - closest - 1 : (hi - closest - 1) + (closest - 1 - k);
-          const bool same = k >= same_lo && k < same_hi;
-          if (kind == 0) { if (same) walk_consider(b2, pd, rank, k); else walk_consider(b3, pd, rank, k); }
-          else if (!same) walk_consider(b2, pd, rank, k);  // strictly above going up / strictly below going down (:446,:462)
-        };
-        // class S: same ring (surf only); class O: the other rings of the window.  A box may overlap both.
-        const int cw0 = lo / LO_CH, cw1 = (hi - 1) / LO_CH;
-        auto box_class = [&](int c, bool& inS, bool& inO) {
-          const int k0 = max(c * LO_CH, lo), k1 = min(c * LO_CH + LO_CH, hi);   // [k0, k1) inside the window
-          inS = kind == 0 && k0 < same_hi && k1 > same_lo;
-          inO = k0 < same_lo || k1 > same_hi;
-        };
-        auto lb_f64 = [&](int c) -> double {
-          float dx, dy, dz;
-          box_diff(c, dx, dy, dz);
-          const double ex = (double)dx, ey = (double)dy, ez = (double)dz;
-          return ex * ex + ey * ey + ez * ez;
-        };
-        if (hi > lo) {
-          // seeds: the box of the closest point (its ring neighbours) and the other-ring box with the smallest bound
-          unsigned long long mo = ~0ull;
-          for (int c = cw0 + lane; c <= cw1; c += 64) {
-            bool inS, inO;
-            box_class(c, inS, inO);
-            if (inO) {
-              const unsigned long long k = ((unsigned long long)__double_as_longlong(lb_f64(c)) & 0xFFFFFFFF00000000ull) | (uint32_t)c;
-              mo = k < mo ? k : mo;   // ordered by the high word of the bound: any box is a valid seed
-            }
-          }
-          mo = wave_min_u64(mo);
-          const int cseedS = closest / LO_CH, cseedO = mo == ~0ull ? -1 : (int)(uint32_t)mo;
-          walk_eval(half == 0 ? cseedS : cseedO);
-          // class bounds after the seeds (an upper bound of the final minimum; nfd when nothing was found)
-          const double boundS = __longlong_as_double((long long)wave_min_u64((unsigned long long)__double_as_longlong(kind == 0 ? b2.dist : nfd)));
-          const double boundO = __longlong_as_double((long long)wave_min_u64((unsigned long long)__double_as_longlong(kind == 0 ? b3.dist : b2.dist)));
-          for (int c0 = cw0; c0 <= cw1; c0 += 64) {
-            const int c = c0 + lane;
-            bool take = false;
-            if (c <= cw1 && c != cseedS && c != cseedO) {
-              bool inS, inO;
-              box_class(c, inS, inO);
-              const double lb = lb_f64(c);
-              take = (inS && lb <= boundS) || (inO && lb <= boundO);
-            }
-            unsigned long long surv = __ballot(take);
-            while (surv) {
-              const int a = __ffsll((long long)surv) - 1;
-              surv &= surv - 1;
-              int b = -1;
-              if (surv) { b = __ffsll((long long)surv) - 1; surv &= surv - 1; }
-              walk_eval(half == 0 ? c0 + a : (b >= 0 ? c0 + b : -1));
-            }
-          }
-        }
-        b2 = walk_reduce(b2);
-        idx2 = b2.idx;
-        if (kind == 0) { b3 = walk_reduce(b3); idx3 = b3.idx; }
+  // rows beyond the last query redo the last one (the rows of a wavefront run in lock-step) and do not store
+  const int qi = threadIdx.x >> 4, q = blockIdx.x * LO_QPB + qi;
+  const bool store = q < nq;
+  const float sx = s_sel[qi][0], sy = s_sel[qi][1], sz = s_sel[qi][2];
+  int closest = -1, idx2 = -1, idx3 = -1;
+  if (nt > 0) {
+    // per-axis clamped differences to box c (0 inside the box)
+    auto box_diff = [&](int c, float& dx, float& dy, float& dz) {
+      float4 lo, hi;
+      if (box_lds) { lo = s_box[2 * c]; hi = s_box[2 * c + 1]; } else { lo = bx[2 * c]; hi = bx[2 * c + 1]; }
+      dx = fmaxf(fmaxf(lo.x - sx, sx - hi.x), 0.f);
+      dy = fmaxf(fmaxf(lo.y - sy, sy - hi.y), 0.f);
+      dz = fmaxf(fmaxf(lo.z - sz, sz - hi.z), 0.f);
+    };
+    auto lb_f32 = [&](int c) -> float {
+      if (c >= nch) return INF;
+      float dx, dy, dz;
+      box_diff(c, dx, dy, dz);
+      float r = 0.f;
+      r += dx * dx; r += dy * dy; r += dz * dz;
+      return r;
+    };
+    // this lane's two targets of box c folded into its running (distance, index) minimum; c < 0: nothing
+    auto nn_eval = [&](int c, unsigned long long best) -> unsigned long long {
+      const int t0 = c * LO_CH + l16, t1 = t0 + 16;
+      const bool v0 = c >= 0 && t0 < nt, v1 = c >= 0 && t1 < nt;
+      const float4 a0 = tg[v0 ? t0 : 0], a1 = tg[v1 ? t1 : 0];   // both loads in flight
+      float r0 = 0.f, r1 = 0.f, df;
+      df = a0.x - sx; r0 += df * df; df = a0.y - sy; r0 += df * df; df = a0.z - sz; r0 += df * df;
+      df = a1.x - sx; r1 += df * df; df = a1.y - sy; r1 += df * df; df = a1.z - sz; r1 += df * df;
+      const unsigned long long k0 = ((unsigned long long)(uint32_t)d_f2i(r0) << 32) | (uint32_t)t0;
+      const unsigned long long k1 = ((unsigned long long)(uint32_t)d_f2i(r1) << 32) | (uint32_t)t1;
+      if (v0) best = k0 < best ? k0 : best;
+      if (v1) best = k1 < best ? k1 : best;
+      return best;
+    };
+    unsigned long long m1 = ~0ull;
+    for (int c = l16; c < nch; c += 16) {
+      const unsigned long long k = ((unsigned long long)(uint32_t)d_f2i(lb_f32(c)) << 32) | (uint32_t)c;
+      m1 = k < m1 ? k : m1;
+    }
+    const int cs = (int)(uint32_t)row16_min_u64(m1);   // box with the smallest bound: nt > 0, so it exists
+    unsigned long long best = nn_eval(cs, ~0ull);
+    best = nn_eval((cs ^ 1) < nch ? (cs ^ 1) : -1, best);
+    const float bound = d_i2f((int32_t)(row16_min_u64(best) >> 32));
+    for (int c0 = 0; c0 < nch; c0 += 16) {
+      const int c = c0 + l16;
+      uint32_t surv = row_bits(__ballot(lb_f32(c) <= bound && (c >> 1) != (cs >> 1)), lane);
+      while (__ballot(surv != 0)) {
+        const int a = surv ? __ffs((int)surv) - 1 : -1;
+        surv &= surv - 1;   // 0 stays 0
+        best = nn_eval(a >= 0 ? c0 + a : -1, best);
       }
     }
-    if (lane == 0) {
-      int* row = d.lo_corr + ((size_t)slot * (d.lo_qcap_surf + d.lo_qcap_corner) + (kind == 0 ? 0 : d.lo_qcap_surf) + q) * 4;
-      const bool ok = kind == 0 ? (idx2 >= 0 && idx3 >= 0) : (idx2 >= 0);
-      row[0] = q; row[1] = ok ? closest : -1; row[2] = idx2; row[3] = idx3;
+    const unsigned long long bj = row16_min_u64(best);
+    const bool found = (double)d_i2f((int32_t)(bj >> 32)) < nfd;
+    if (found) closest = (int)(uint32_t)bj;
+    // ---- ring walk; rows without a closest point walk an empty window
+    const int cref = found ? closest : 0;
+    const int cr = (int)tg[cref].w;  // int(intensity) = ring (:347,:436)
+    const int W = d.P.ring_window;
+    const int rlo = min(max(cr - W, 0), d.NS - 1), rhi = min(max(cr + W, 0), d.NS - 1), crc = min(max(cr, 0), d.NS - 1);
+    const int lo = found ? s_roff[rlo] : 0, hi = found ? s_roff[rhi + 1] : 0;           // the walks stay inside [lo, hi)
+    const int same_lo = s_roff[crc], same_hi = s_roff[crc + 1];
+    WalkBest b2{nfd, 0x7fffffff, -1}, b3{nfd, 0x7fffffff, -1};
+    auto walk_one = [&](int k, bool valid, const float4& a) {
+      if (!valid || k < lo || k >= hi || k == closest) return;
+      const double ex = (double)(a.x - sx), ey = (double)(a.y - sy), ez = (double)(a.z - sz);
+      const double pd = ex * ex + ey * ey + ez * ez;  // pow(f32 diff, 2) summed in double (:354)
+      if (!(pd < nfd)) return;
+      // visiting order of the reference: closest+1, closest+2, ... then closest-1, closest-2, ...
+      const int rank = k > closest ? k - closest - 1 : (hi - closest - 1) + (closest - 1 - k);
+      const bool same = k >= same_lo && k < same_hi;
+      if (kind == 0) { if (same) walk_consider(b2, pd, rank, k); else walk_consider(b3, pd, rank, k); }
+      else if (!same) walk_consider(b2, pd, rank, k);  // strictly above going up / strictly below going down (:446,:462)
+    };
+    auto walk_eval = [&](int c) {
+      const int k0 = c * LO_CH + l16, k1 = k0 + 16;
+      const bool v0 = c >= 0 && k0 < nt, v1 = c >= 0 && k1 < nt;
+      const float4 a0 = tg[v0 ? k0 : 0], a1 = tg[v1 ? k1 : 0];
+      walk_one(k0, v0, a0);
+      walk_one(k1, v1, a1);
+    };
+    // class S: same ring (surf only); class O: the other rings of the window.  A box may overlap both.
+    const int cw0 = lo / LO_CH, cw1 = hi > lo ? (hi - 1) / LO_CH : -1;   // empty window: no box
+    auto box_class = [&](int c, bool& inS, bool& inO) {
+      const int k0 = max(c * LO_CH, lo), k1 = min(c * LO_CH + LO_CH, hi);   // [k0, k1) inside the window
+      inS = kind == 0 && k0 < same_hi && k1 > same_lo;
+      inO = k0 < same_lo || k1 > same_hi;
+    };
+    auto lb_f64 = [&](int c) -> double {
+      float dx, dy, dz;
+      box_diff(c, dx, dy, dz);
+      const double ex = (double)dx, ey = (double)dy, ez = (double)dz;
+      return ex * ex + ey * ey + ez * ez;
+    };
+    // seeds: the box of the closest point (its ring neighbours) and the other-ring box with the smallest bound
+    unsigned long long mo = ~0ull;
+    for (int it = 0; __ballot(cw0 + it * 16 <= cw1); ++it) {
+      const int c = cw0 + it * 16 + l16;
+      if (c <= cw1) {
+        bool inS, inO;
+        box_class(c, inS, inO);
+        if (inO) {
+          const unsigned long long k = ((unsigned long long)__double_as_longlong(lb_f64(c)) & 0xFFFFFFFF00000000ull) | (uint32_t)c;
+          mo = k < mo ? k : mo;   // ordered by the high word of the bound: any box is a valid seed
+        }
+      }
     }
+    mo = row16_min_u64(mo);
+    const int cseedS = cw1 >= 0 ? closest / LO_CH : -1, cseedO = mo == ~0ull ? -1 : (int)(uint32_t)mo;
+    walk_eval(cseedS);
+    walk_eval(cseedO != cseedS ? cseedO : -1);
+    // class bounds after the seeds (an upper bound of the final minimum; nfd when nothing was found)
+    const double boundS = __longlong_as_double((long long)row16_min_u64((unsigned long long)__double_as_longlong(kind == 0 ? b2.dist : nfd)));
+    const double boundO = __longlong_as_double((long long)row16_min_u64((unsigned long long)__double_as_longlong(kind == 0 ? b3.dist : b2.dist)));
+    for (int it = 0; __ballot(cw0 + it * 16 <= cw1); ++it) {
+      const int c0 = cw0 + it * 16, c = c0 + l16;
+      bool take = false;
+      if (c <= cw1 && c != cseedS && c != cseedO) {
+        bool inS, inO;
+        box_class(c, inS, inO);
+        const double lb = lb_f64(c);
+        take = (inS && lb <= boundS) || (inO && lb <= boundO);
+      }
+      uint32_t surv = row_bits(__ballot(take), lane);
+      while (__ballot(surv != 0)) {
+        const int a = surv ? __ffs((int)surv) - 1 : -1;
+        surv &= surv - 1;
+        walk_eval(a >= 0 ? c0 + a : -1);
+      }
+    }
+    b2 = walk_reduce_row(b2);
+    idx2 = b2.idx;
+    if (kind == 0) { b3 = walk_reduce_row(b3); idx3 = b3.idx; }
+  }
+  if (l16 == 0 && store) {
+    int* row = d.lo_corr + ((size_t)slot * (d.lo_qcap_surf + d.lo_qcap_corner) + (kind == 0 ? 0 : d.lo_qcap_surf) + q) * 4;
+    const bool ok = kind == 0 ? (idx2 >= 0 && idx3 >= 0) : (idx2 >= 0);
+    row[0] = q; row[1] = ok ? closest : -1; row[2] = idx2; row[3] = idx3;
   }
 }
 
@@ -249,7 +301,7 @@ __global__ void __launch_bounds__(LO_BLOCK) lo_solve(DevCtx d, int phase) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lo_smem[];
   double* s_acc = reinterpret_cast<double*>(lo_smem);                // [28][LO_BLOCK]
   double* s_seg = s_acc + 28 * (LO_BLOCK / 4);                        // [28][LO_BLOCK/128]
-  __shared__ double s_out[28];
+  __shared__ double s_out[28], s_trig[12];
   __shared__ LmState S;
   __shared__ int s_action, s_cnt[LO_BLOCK / 64];
   if (!sc[SC_LO_INIT]) {  // :316-324
@@ -284,7 +336,7 @@ __global__ void __launch_bounds__(LO_BLOCK) lo_solve(DevCtx d, int phase) {
     auto evaluate = [&](const double* x) {
 #pragma unroll
       for (int k = 0; k < 28; ++k) acc[k] = 0;
-      const PoseTerms T = pose_terms(x);
+      const PoseTerms T = pose_terms_coop(x, s_trig);
       lo_eval_rows(d, slot, cur, 0, nq_s, T, acc);
       if (phase == 1) lo_eval_rows(d, slot, cur, 1, nq_c, T, acc);
       block_reduce28_lds<LO_BLOCK>(acc, s_acc, s_seg, s_out);
@@ -314,6 +366,7 @@ __global__ void __launch_bounds__(LO_BLOCK) lo_solve(DevCtx d, int phase) {
     if (threadIdx.x == 0) {
 #pragma unroll
       for (int k = 0; k < 6; ++k) st[LS_PARAMS + k] = S.x[k];
+      store_pose_rotation(st);   // for the next lo_assoc (corner association / next scan)
       st[LS_COSTS + phase * 2] = S.initial_cost; st[LS_COSTS + phase * 2 + 1] = S.x_cost;
       sc[phase == 0 ? SC_LO_ITERS : SC_LO_ITERS2] = S.iter | (S.successful << 8) | (S.termination << 16);
     }
