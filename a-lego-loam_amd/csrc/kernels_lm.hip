@@ -47,7 +47,7 @@ __global__ void __launch_bounds__(LM_BLOCK) lm_prepare(DevCtx d, LmCtx L, int st
   if (blockIdx.x != 0 || kind != 0 || threadIdx.x != 0) return;
   double* ld = ldp(L, slot);
   double* po = d.poses + (size_t)slot * 16;
-  li[LI_RUN] = 0; li[LI_REBUILD] = 0; li[LI_KF_ADDED] = 0; li[LI_OPTIMIZED] = 0; li[LI_FLAGS] = 0;
+  li[LI_RUN] = 0; li[LI_KF_ADDED] = 0; li[LI_OPTIMIZED] = 0; li[LI_FLAGS] = 0;   // LI_REBUILD belongs to the map sequence
   if (!sc[SC_ODOM_VALID]) return;  // no /odom/lidar on the initialising scan -> no mapping frame
   // laserOdomHandler :154-166
   for (int k = 0; k < 3; ++k) ld[LD_T_O2L + k] = po[k];
@@ -65,7 +65,24 @@ __global__ void __launch_bounds__(LM_BLOCK) lm_prepare(DevCtx d, LmCtx L, int st
   li[LI_RUN] = run;
   if (run_hint >= 0 && run != run_hint) li[LI_OVERFLOW] = 2;  // host launch-skipping logic out of sync
   if (!run) { li[LI_FLAGS] = 8; return; }
-  if (li[LI_NKF] > 0 && li[LI_DIRTY]) { li[LI_REBUILD] = 1; li[LI_DIRTY] = 0; li[LI_NREBUILD] += 1; }
+}
+
+// Map sequence = lm_map_begin, lm_concat, VoxelGrid of the two maps, lm_grid_*, lm_map_end.  The local map only
+// changes when a key frame is saved, so the sequence is either run at the start of a mapping frame (single-scan entry
+// points) or right after lm_store_kf of the previous mapping frame on the group's side stream (batch path), where it
+// overlaps the ImageProjection / LaserOdometry kernels of the following scans.  Same kernels, same data, same result.
+__global__ void lm_map_begin(DevCtx d, LmCtx L) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= d.n_launch) return;
+  int* li = lip(L, s + d.slot0);
+  const int rb = li[LI_NKF] > 0 && li[LI_DIRTY];
+  li[LI_REBUILD] = rb;
+  if (rb) { li[LI_DIRTY] = 0; li[LI_NREBUILD] += 1; }
+}
+__global__ void lm_map_end(DevCtx d, LmCtx L) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= d.n_launch) return;
+  lip(L, s + d.slot0)[LI_REBUILD] = 0;
 }
 
 // grid (2, K, slots): chronological concatenation of the key-frame ring
@@ -118,7 +135,7 @@ __global__ void __launch_bounds__(LM_BLOCK) lm_grid_setup(DevCtx d, LmCtx L) {
   if (!li[LI_REBUILD]) return;
   __shared__ GridGeom s_g;
   if (threadIdx.x == 0) {
-    const unsigned* bb = L.vox_bbox + ((size_t)(slot - L.vox_slot0) * 5 + m) * 8;
+    const unsigned* bb = L.vox_bbox + ((size_t)(slot - L.vox_slot0) * 2 + m) * 8;
     GridGeom g;
     float mn[3], mx[3];
     for (int a = 0; a < 3; ++a) { mn[a] = vxl_dec(bb[a]); mx[a] = vxl_dec(~bb[4 + a]); }
@@ -694,11 +711,17 @@ void launch_lm_prepare(const DevCtx& d, const LmCtx& L, int stage, int run_hint,
 void launch_lm_concat(const DevCtx& d, const LmCtx& L, hipStream_t st) {
   ALEGO_LAUNCH(lm_concat, dim3(2, L.K, d.n_launch), dim3(LM_BLOCK), 0, st, d, L);
 }
-void launch_lm_total_and_grid_setup(const DevCtx& d, const LmCtx& L, hipStream_t st) {
+void launch_lm_total(const DevCtx& d, const LmCtx& L, hipStream_t st) {
   ALEGO_LAUNCH(lm_total, dim3(8, d.n_launch), dim3(LM_BLOCK), 0, st, d, L);
-  ALEGO_LAUNCH(lm_grid_setup, dim3(2, d.n_launch), dim3(LM_BLOCK), 0, st, d, L);
+}
+void launch_lm_map_begin(const DevCtx& d, const LmCtx& L, hipStream_t st) {
+  ALEGO_LAUNCH(lm_map_begin, dim3((d.n_launch + 63) / 64), dim3(64), 0, st, d, L);
+}
+void launch_lm_map_end(const DevCtx& d, const LmCtx& L, hipStream_t st) {
+  ALEGO_LAUNCH(lm_map_end, dim3((d.n_launch + 63) / 64), dim3(64), 0, st, d, L);
 }
 void launch_lm_grid(const DevCtx& d, const LmCtx& L, hipStream_t st) {
+  ALEGO_LAUNCH(lm_grid_setup, dim3(2, d.n_launch), dim3(LM_BLOCK), 0, st, d, L);
   ALEGO_LAUNCH(lm_grid_count, dim3(8, 2, d.n_launch), dim3(LM_BLOCK), 0, st, d, L, 0);
   ALEGO_LAUNCH(lm_grid_scan, dim3(2, d.n_launch), dim3(LM_BLOCK), 0, st, d, L);
   ALEGO_LAUNCH(lm_grid_count, dim3(8, 2, d.n_launch), dim3(LM_BLOCK), 0, st, d, L, 1);

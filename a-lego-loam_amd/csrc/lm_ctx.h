@@ -58,7 +58,7 @@ struct LmCtx {
   GridGeom* grid;                                 // [slot][2]
   int *cell_start, *cell_cur;                     // [slot][2][gcap+1]
   float4* cell_pts;                               // [slot][2][map_cap_s] map points in cell order (w = index in the ds map)
-  const unsigned* vox_bbox;                       // VoxCtx::bbox of round 1 of this stream group (jobs (slot-vox_slot0)*5 + {0,1} are the maps)
+  const unsigned* vox_bbox;                       // VoxCtx::bbox of round 1 of this stream group (the map VoxelGrid context: jobs (slot-vox_slot0)*2 + {0,1})
   int vox_slot0;                                  // first slot of the stream group
   int* knn;                                       // [slot][qcap][5] neighbour indices of every query (lm_knn -> lm_fit)
   // residual blocks

@@ -12,7 +12,9 @@
 
 void launch_lm_prepare(const DevCtx& d, const LmCtx& L, int stage, int run_hint, hipStream_t st);
 void launch_lm_concat(const DevCtx& d, const LmCtx& L, hipStream_t st);
-void launch_lm_total_and_grid_setup(const DevCtx& d, const LmCtx& L, hipStream_t st);
+void launch_lm_total(const DevCtx& d, const LmCtx& L, hipStream_t st);
+void launch_lm_map_begin(const DevCtx& d, const LmCtx& L, hipStream_t st);
+void launch_lm_map_end(const DevCtx& d, const LmCtx& L, hipStream_t st);
 void launch_lm_grid(const DevCtx& d, const LmCtx& L, hipStream_t st);
 void launch_lm_register(const DevCtx& d, const LmCtx& L, hipStream_t st);
 
@@ -22,8 +24,14 @@ struct LmHost {
   int gsize;                   // slots per stream group
   std::vector<hipStream_t> st; // one HIP stream per group
   LmCtx L;
-  // per group — round 1: map corner, map surf, scan corner, scan surf, scan outlier; round 2: scan surf_total
-  std::vector<VoxCtx> v1, v2;
+  // per group — vm: map corner, map surf; v1: scan corner, scan surf, scan outlier; v2: scan surf_total
+  std::vector<VoxCtx> vm, v1, v2;
+  // batch path: the map sequence of a group runs on its side stream, ordered by events against the main stream
+  std::vector<hipStream_t> side;
+  std::vector<hipEvent_t> ev_main, ev_side;
+  std::vector<char> side_pending;
+  bool eager_enabled = false;
+  std::vector<char> map_current;   // the last mapping frame of the group was followed by an eager map sequence
   std::vector<void*> allocs;
   std::vector<long> frames;  // host mirror of frame_cnt per slot: only used to skip launches
 };
@@ -47,7 +55,16 @@ LmHost* lm_host_create(const alego_params& P, const DevCtx& d, int n_slots, int 
   LmHost* lm = new LmHost();
   lm->P = P; lm->n_slots = n_slots; lm->gsize = gsize; lm->st = st; lm->frames.assign(n_slots, 0);
   VoxCtx vz; std::memset(&vz, 0, sizeof(VoxCtx));
-  lm->v1.assign(st.size(), vz); lm->v2.assign(st.size(), vz);
+  lm->vm.assign(st.size(), vz); lm->v1.assign(st.size(), vz); lm->v2.assign(st.size(), vz);
+  lm->side.assign(st.size(), nullptr); lm->ev_main.assign(st.size(), nullptr); lm->ev_side.assign(st.size(), nullptr);
+  lm->side_pending.assign(st.size(), 0); lm->map_current.assign(st.size(), 0);
+  // Measured (512 streams): with the HIP runtime's 4 hardware queues, 4 main + 4 side streams multiplex and lose
+  // (148 k scans/s vs 186 k), 2 + 2 ties (184 k); more queues (GPU_MAX_HW_QUEUES=8) lose as well.  Off by default.
+  lm->eager_enabled = getenv("ALEGO_EAGER_MAP") != nullptr && atoi(getenv("ALEGO_EAGER_MAP")) != 0;
+  for (size_t g = 0; lm->eager_enabled && g < st.size(); ++g) {
+    if (hipStreamCreate(&lm->side[g]) != hipSuccess || hipEventCreateWithFlags(&lm->ev_main[g], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&lm->ev_side[g], hipEventDisableTiming) != hipSuccess) { *err = "lm_host_create: side stream"; lm_host_destroy(lm); return nullptr; }
+  }
   LmCtx& L = lm->L;
   std::memset(&L, 0, sizeof(L));
   L.K = P.recent_keyframe_num > 0 ? P.recent_keyframe_num : 1;
@@ -77,23 +94,27 @@ LmHost* lm_host_create(const alego_params& P, const DevCtx& d, int n_slots, int 
   (void)hipMemcpy(L.ld, ld.data(), ld.size() * sizeof(double), hipMemcpyHostToDevice);
   // VoxelGrid job tables (laserMapping.cpp:37-39,316-319,329-342)
   for (size_t g = 0; g < st.size(); ++g) {
-  std::vector<VoxJob> j1, j2;
+  std::vector<VoxJob> jm, j1, j2;
   for (size_t b = g * gsize; b < B && b < (g + 1) * (size_t)gsize; ++b) {
     int* li = L.li + b * LI_COUNT;
-    j1.push_back(VoxJob{L.map_corner_raw + b * L.map_cap_c, li + LI_KRAW_C, L.map_corner_ds + b * L.map_cap_c, li + LI_KDS_C, li + LI_REBUILD, P.lm_leaf_corner, L.map_cap_c, 0});
-    j1.push_back(VoxJob{L.map_surf_raw + b * L.map_cap_s, li + LI_KRAW_S, L.map_surf_ds + b * L.map_cap_s, li + LI_KDS_S, li + LI_REBUILD, P.lm_leaf_surf, L.map_cap_s, 0});
+    jm.push_back(VoxJob{L.map_corner_raw + b * L.map_cap_c, li + LI_KRAW_C, L.map_corner_ds + b * L.map_cap_c, li + LI_KDS_C, li + LI_REBUILD, P.lm_leaf_corner, L.map_cap_c, 0});
+    jm.push_back(VoxJob{L.map_surf_raw + b * L.map_cap_s, li + LI_KRAW_S, L.map_surf_ds + b * L.map_cap_s, li + LI_KDS_S, li + LI_REBUILD, P.lm_leaf_surf, L.map_cap_s, 0});
     j1.push_back(VoxJob{L.in_corner + b * L.in_cap_c, li + LI_NIN_C, L.cur_corner_ds + b * L.kf_cap_c, li + LI_NCUR_C, li + LI_RUN, P.lm_leaf_corner, L.kf_cap_c, 0});
     j1.push_back(VoxJob{L.in_surf + b * L.in_cap_s, li + LI_NIN_S, L.cur_surf_ds + b * L.kf_cap_s, li + LI_NCUR_S, li + LI_RUN, P.lm_leaf_surf, L.in_cap_s, 0});
     j1.push_back(VoxJob{L.in_outl + b * L.in_cap_o, li + LI_NIN_O, L.cur_outl_ds + b * L.kf_cap_o, li + LI_NCUR_O, li + LI_RUN, P.lm_leaf_outlier, L.in_cap_o, 0});
     j2.push_back(VoxJob{L.cur_total + b * L.total_cap, li + LI_NTOTAL, L.cur_total_ds + b * L.total_cap, li + LI_NTOTAL_DS, li + LI_RUN, P.lm_leaf_surf, L.total_cap, 0});
   }
-  if (vox_create(&lm->v1[g], j1.data(), (int)j1.size(), err) || vox_create(&lm->v2[g], j2.data(), (int)j2.size(), err)) { lm_host_destroy(lm); return nullptr; }
+  if (vox_create(&lm->vm[g], jm.data(), (int)jm.size(), err) || vox_create(&lm->v1[g], j1.data(), (int)j1.size(), err) || vox_create(&lm->v2[g], j2.data(), (int)j2.size(), err)) { lm_host_destroy(lm); return nullptr; }
   }
   return lm;
 }
 
 void lm_host_destroy(LmHost* lm) {
   if (!lm) return;
+  for (hipStream_t q : lm->side) if (q) { (void)hipStreamSynchronize(q); (void)hipStreamDestroy(q); }
+  for (hipEvent_t e : lm->ev_main) if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : lm->ev_side) if (e) (void)hipEventDestroy(e);
+  for (auto& v : lm->vm) vox_destroy(&v);
   for (auto& v : lm->v1) vox_destroy(&v);
   for (auto& v : lm->v2) vox_destroy(&v);
   for (void* p : lm->allocs) (void)hipFree(p);
@@ -110,13 +131,28 @@ static bool dbg_sync(hipStream_t st, const char* what, std::string* err) {
   return true;
 }
 
-// odom_valid[s - slot0]: whether slot s has an /odom/lidar message for this scan (false on its first scan)
-static int lm_sequence(LmHost* lm, const DevCtx& d, int stage, const std::vector<char>& odom_valid, std::string* err) {
+// lm_map_begin .. lm_map_end on stream `st` (see kernels_lm.hip)
+static int map_sequence(LmHost* lm, const DevCtx& d, const LmCtx& L, int g, hipStream_t st, std::string* err) {
+  launch_lm_map_begin(d, L, st);
+  launch_lm_concat(d, L, st);
+  if (!dbg_sync(st, "lm_concat", err)) return ALEGO_ERR_HIP;
+  if (int r = vox_run(lm->vm[g], st, err)) return r;
+  if (!dbg_sync(st, "vox map", err)) return ALEGO_ERR_HIP;
+  launch_lm_grid(d, L, st);
+  launch_lm_map_end(d, L, st);
+  if (!dbg_sync(st, "lm_grid", err)) return ALEGO_ERR_HIP;
+  return 0;
+}
+
+// odom_valid[s - slot0]: whether slot s has an /odom/lidar message for this scan (false on its first scan).
+// eager: run the map sequence for the NEXT mapping frame on the side stream right after this one (batch path).
+static int lm_sequence(LmHost* lm, const DevCtx& d, int stage, const std::vector<char>& odom_valid, bool eager, std::string* err) {
+  eager = eager && lm->eager_enabled;
   // the slots of one launch view always belong to one stream group
   const int g = d.slot0 / lm->gsize;
   hipStream_t st = lm->st[g];
   LmCtx L = lm->L;
-  L.vox_bbox = lm->v1[g].bbox; L.vox_slot0 = g * lm->gsize;
+  L.vox_bbox = lm->vm[g].bbox; L.vox_slot0 = g * lm->gsize;
   int n_run = 0, n_norun = 0;
   for (int i = 0; i < d.n_launch; ++i) {
     long& f = lm->frames[d.slot0 + i];
@@ -128,18 +164,26 @@ static int lm_sequence(LmHost* lm, const DevCtx& d, int stage, const std::vector
   launch_lm_prepare(d, L, stage, hint, st);
   if (!dbg_sync(st, "lm_prepare", err)) return ALEGO_ERR_HIP;
   if (n_run == 0) return 0;
-  launch_lm_concat(d, L, st);
-  if (!dbg_sync(st, "lm_concat", err)) return ALEGO_ERR_HIP;
   if (int r = vox_run(lm->v1[g], st, err)) return r;
-  if (!dbg_sync(st, "vox round 1", err)) return ALEGO_ERR_HIP;
-  launch_lm_total_and_grid_setup(d, L, st);
-  if (!dbg_sync(st, "lm_total/grid_setup", err)) return ALEGO_ERR_HIP;
+  if (!dbg_sync(st, "vox scan", err)) return ALEGO_ERR_HIP;
+  launch_lm_total(d, L, st);
   if (int r = vox_run(lm->v2[g], st, err)) return r;
-  if (!dbg_sync(st, "vox round 2", err)) return ALEGO_ERR_HIP;
-  launch_lm_grid(d, L, st);
-  if (!dbg_sync(st, "lm_grid", err)) return ALEGO_ERR_HIP;
+  if (!dbg_sync(st, "vox total", err)) return ALEGO_ERR_HIP;
+  // the map: wait for a map sequence still running on the side stream, then (a no-op when the key-frame set did not
+  // change since) bring it up to date
+  if (lm->side_pending[g]) { (void)hipStreamWaitEvent(st, lm->ev_side[g], 0); lm->side_pending[g] = 0; }
+  if (!lm->map_current[g]) { if (int r = map_sequence(lm, d, L, g, st, err)) return r; }
   launch_lm_register(d, L, st);
   if (!dbg_sync(st, "lm_register", err)) return ALEGO_ERR_HIP;
+  if (eager) {
+    (void)hipEventRecord(lm->ev_main[g], st);
+    (void)hipStreamWaitEvent(lm->side[g], lm->ev_main[g], 0);
+    if (int r = map_sequence(lm, d, L, g, lm->side[g], err)) return r;
+    (void)hipEventRecord(lm->ev_side[g], lm->side[g]);
+    lm->side_pending[g] = 1;
+  }
+  // only a whole-group eager frame leaves every map of the group up to date
+  lm->map_current[g] = eager && d.slot0 == g * lm->gsize && d.slot0 + d.n_launch == std::min(lm->n_slots, (g + 1) * lm->gsize);
   return 0;
 }
 
@@ -152,13 +196,18 @@ static void clear_run_flags_outside(LmHost* lm, const DevCtx& d) {
   if (d.slot0 == lo && d.slot0 + d.n_launch == hi) return;
   for (int s = lo; s < hi; ++s) {
     if (s >= d.slot0 && s < d.slot0 + d.n_launch) continue;
-    (void)hipMemsetAsync(lm->L.li + (size_t)s * LI_COUNT + LI_RUN, 0, 2 * sizeof(int), lm->st[g]);  // LI_RUN, LI_REBUILD
+    (void)hipMemsetAsync(lm->L.li + (size_t)s * LI_COUNT + LI_RUN, 0, sizeof(int), lm->st[g]);  // LI_REBUILD is always 0 between map sequences
   }
 }
 
-int lm_host_enqueue(LmHost* lm, const DevCtx& d, const std::vector<char>& odom_valid, std::string* err) {
+int lm_host_enqueue(LmHost* lm, const DevCtx& d, const std::vector<char>& odom_valid, bool eager_map, std::string* err) {
   clear_run_flags_outside(lm, d);
-  return lm_sequence(lm, d, 1, odom_valid, err);
+  return lm_sequence(lm, d, 1, odom_valid, eager_map, err);
+}
+hipError_t lm_host_sync(LmHost* lm) {
+  hipError_t r = hipSuccess;
+  for (hipStream_t q : lm->side) { if (!q) continue; hipError_t e = hipStreamSynchronize(q); if (e != hipSuccess) r = e; }
+  return r;
 }
 
 int lm_host_process_host(LmHost* lm, const DevCtx& dfull, const alego_point* corner_last, int n_corner, const alego_point* surf_last,
@@ -180,7 +229,7 @@ int lm_host_process_host(LmHost* lm, const DevCtx& dfull, const alego_point* cor
   (void)hipMemcpyAsync(d.scal + SC_ODOM_VALID, &one, sizeof(int), hipMemcpyHostToDevice, st);
   if (hipStreamSynchronize(st) != hipSuccess) { *err = "alego_lm_process: upload failed"; return ALEGO_ERR_HIP; }
   clear_run_flags_outside(lm, d);
-  if (int r = lm_sequence(lm, d, 0, std::vector<char>(1, 1), err)) return r;
+  if (int r = lm_sequence(lm, d, 0, std::vector<char>(1, 1), false, err)) return r;
   double out[16], ld[LD_COUNT];
   int li[LI_COUNT];
   (void)hipMemcpyAsync(out, d.poses, sizeof(out), hipMemcpyDeviceToHost, st);
