@@ -271,7 +271,7 @@ DEV_INLINE void ccl_union(int* parent, int a, int b) {
     }
   } while (repeat);
 }
-__global__ void __launch_bounds__(CC_LDS_THREADS) cc_lds(DevCtx d) {
+__global__ void __launch_bounds__(CC_LDS_THREADS) cc_lds(DevCtx d, int ring_pos) {
   const int slot = blockIdx.x + d.slot0;
   const size_t base = (size_t)slot * d.N;
   extern __shared__ __attribute__((aligned(16))) unsigned char cc_smem[];
@@ -319,6 +319,99 @@ __global__ void __launch_bounds__(CC_LDS_THREADS) cc_lds(DevCtx d) {
       d.parent[base + v] = rt[k];
       if (stats && rt[k] == v) { const unsigned w = (unsigned)parent[v]; d.cc_size[base + v] = (int)(w & 0xFFFFu); d.cc_rows[base + v] = (unsigned long long)(w >> 16); }
     }
+  }
+  if (!stats) return;  // ip_rowcount / ip_compact follow (launch_ip)
+  // ---- fused a6: ordered compaction of the whole image (replaces ip_rowcount + ip_compact for this geometry).
+  // Chunk k = cells [1024 k, 1024 k + 1024) in row-major order, one cell per thread: per-(chunk, wavefront) counts of
+  // kept cells / outliers / feasible roots, one exclusive scan over the (chunk, wavefront) table, then every cell
+  // knows its output line.  Classification as ip_classify, with the component statistics still in LDS.
+  constexpr int NW = CC_LDS_THREADS / 64;
+  __shared__ int s_cnt[3][PER * NW];
+  __shared__ int s_wtot[3][NW];
+  const int lane = lane_id(), wave = threadIdx.x >> 6;
+  const alego_params& P = d.P;
+  unsigned long long keep_m = 0, outl_m = 0, root_m = 0;
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    const int v = threadIdx.x + k * CC_LDS_THREADS;
+    int c = 0;
+    bool fr = false;
+    if (v < N) {
+      const uint8_t f = fi[v];
+      const int row = v / H, col = v - row * H;
+      if (f & 1) c = (col % 5 == 0 || col <= 4 || col >= H - 5) ? 1 : 0;
+      else if (f & 2) {
+        const unsigned w = (unsigned)parent[rt[k]];
+        const int sz = (int)(w & 0xFFFFu);
+        const bool feas = sz >= P.seg_big_num || (sz >= P.seg_valid_point_num && __popc(w >> 16) >= P.seg_valid_line_num);
+        fr = feas && rt[k] == v;
+        c = feas ? 1 : ((row > P.ground_scan_id && col % 5 == 0) ? 2 : 0);
+      }
+    }
+    if (c == 1) keep_m |= 1ull << k;
+    if (c == 2) outl_m |= 1ull << k;
+    if (fr) root_m |= 1ull << k;
+    const unsigned long long bk = __ballot(c == 1), bo = __ballot(c == 2), bf = __ballot(fr);
+    if (lane == 0) { s_cnt[0][k * NW + wave] = (int)__popcll(bk); s_cnt[1][k * NW + wave] = (int)__popcll(bo); s_cnt[2][k * NW + wave] = (int)__popcll(bf); }
+  }
+  __syncthreads();
+  {  // exclusive scan of the three count tables (PER * NW <= 1024 entries: one per thread)
+    const int e = threadIdx.x;
+    int v3[3], in3[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      v3[a] = e < PER * NW ? s_cnt[a][e] : 0;
+      int incl = v3[a];
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+      in3[a] = incl;
+      if (lane == 63) s_wtot[a][wave] = incl;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      int woff = 0;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) if (w < wave) woff += s_wtot[a][w];
+      if (e < PER * NW) s_cnt[a][e] = woff + in3[a] - v3[a];
+    }
+    if (threadIdx.x == 0) {
+      int t3[3] = {0, 0, 0};
+#pragma unroll
+      for (int a = 0; a < 3; ++a) for (int w = 0; w < NW; ++w) t3[a] += s_wtot[a][w];
+      int* sc = d.scal + slot * SC_COUNT;
+      sc[SC_M] = t3[0]; sc[SC_NOUT] = t3[1]; sc[SC_NFEAS] = t3[2];
+      d.ring_end[slot * d.NS + d.NS - 1] = t3[0] - 1 - 5;   // :190 for the last row
+    }
+  }
+  __syncthreads();
+  const float4* pts = d.in_pts + ((size_t)slot * d.ring_len + ring_pos) * d.Pcap;
+  const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll 4
+  for (int k = 0; k < PER; ++k) {
+    const int v = threadIdx.x + k * CC_LDS_THREADS;
+    const bool kp = (keep_m >> k) & 1ull, ol = (outl_m >> k) & 1ull, fr = (root_m >> k) & 1ull;
+    const unsigned long long bk = __ballot(kp), bo = __ballot(ol), bf = __ballot(fr);
+    if (v >= N) continue;
+    const int row = v / H, col = v - row * H;
+    const int line = s_cnt[0][k * NW + wave] + (int)__popcll(bk & below);   // kept cells before this one
+    if (col == 0) {   // ring convention of :161,:190
+      d.ring_start[slot * d.NS + row] = line + 5;
+      if (row > 0) d.ring_end[slot * d.NS + row - 1] = line - 1 - 5;
+    }
+    if (kp || ol) {
+      float4 p = pts[d.owner[base + v]];
+      p.w = (float)(row + col / 10000.0);  // :101
+      if (kp) {
+        d.seg_pts[base + line] = p;
+        d.seg_ground[base + line] = fi[v] & 1;
+        d.seg_col[base + line] = col;
+        d.seg_range[base + line] = d.range_img[base + v];
+      } else {
+        d.outlier[base + s_cnt[1][k * NW + wave] + (int)__popcll(bo & below)] = p;
+      }
+    }
+    if (fr) d.cc_label[base + v] = s_cnt[2][k * NW + wave] + (int)__popcll(bf & below) + 1;  // label_cnt_ numbering (:303-306)
   }
 }
 
@@ -501,14 +594,16 @@ void launch_ip(const DevCtx& d, int ring_pos, bool want_labels, hipStream_t st) 
   ALEGO_LAUNCH(ip_image, dim3((d.H + 127) / 128, d.n_launch), dim3(128), 0, st, d, ring_pos);
   ALEGO_LAUNCH(cc_edges, gN, dim3(IP_BLOCK), 0, st, d);
   if (d.N <= CC_LDS_MAXN) {
-    ALEGO_LAUNCH(cc_lds, dim3(d.n_launch), dim3(CC_LDS_THREADS), (size_t)4 * d.N, st, d);
+    ALEGO_LAUNCH(cc_lds, dim3(d.n_launch), dim3(CC_LDS_THREADS), (size_t)4 * d.N, st, d, ring_pos);
   } else {
     ALEGO_LAUNCH(cc_runs, dim3((d.H + 127) / 128, d.n_launch), dim3(128), 0, st, d);
     ALEGO_LAUNCH(cc_link, gN, dim3(IP_BLOCK), 0, st, d);
   }
-  if (!(d.N <= CC_LDS_MAXN && d.NS <= 16)) ALEGO_LAUNCH(cc_stats, gN, dim3(IP_BLOCK), 0, st, d);  // cc_lds already produced the statistics
-  ALEGO_LAUNCH(ip_rowcount, dim3(d.NS, d.n_launch), dim3(IP_BLOCK), 0, st, d);
-  ALEGO_LAUNCH(ip_compact, dim3(d.NS, d.n_launch), dim3(IP_BLOCK), 0, st, d, ring_pos);
+  if (!(d.N <= CC_LDS_MAXN && d.NS <= 16)) {  // otherwise cc_lds already produced the statistics and the compaction
+    ALEGO_LAUNCH(cc_stats, gN, dim3(IP_BLOCK), 0, st, d);
+    ALEGO_LAUNCH(ip_rowcount, dim3(d.NS, d.n_launch), dim3(IP_BLOCK), 0, st, d);
+    ALEGO_LAUNCH(ip_compact, dim3(d.NS, d.n_launch), dim3(IP_BLOCK), 0, st, d, ring_pos);
+  }
   if (want_labels) hipLaunchKernelGGL(ip_labels, gN, dim3(IP_BLOCK), 0, st, d);
 }
 
