@@ -78,7 +78,6 @@ hipStream_t stream_of(const alego_handle* h, int slot) { return h->streams[slot 
 hipError_t sync_all(const alego_handle* h) {
   hipError_t r = hipSuccess;
   for (hipStream_t s : h->streams) { hipError_t e = hipStreamSynchronize(s); if (e != hipSuccess) r = e; }
-  if (h->lm) { hipError_t e = lm_host_sync(h->lm); if (e != hipSuccess) r = e; }
   return r;
 }
 
@@ -227,7 +226,7 @@ int alego_batch_load(alego_handle* h, int slot, int ring_pos, const alego_point*
 }
 
 // enqueue IP -> FE -> LO -> LM for slots [slot0, slot0+n) on ring position `pos`
-static int enqueue_scan(alego_handle* h, int slot0, int n, int pos, int stages, bool want_labels, bool eager_map = false) {
+static int enqueue_scan(alego_handle* h, int slot0, int n, int pos, int stages, bool want_labels) {
   const DevCtx d = view(h, slot0, n);
   hipStream_t S = stream_of(h, slot0);  // [slot0, slot0+n) lies inside one stream group
   g_prof = &h->prof;
@@ -239,7 +238,7 @@ static int enqueue_scan(alego_handle* h, int slot0, int n, int pos, int stages, 
     launch_lo(d, S); chk("lo");
     std::vector<char> odom_valid(n);
     for (int i = 0; i < n; ++i) odom_valid[i] = h->lo_scans[slot0 + i]++ > 0;
-    if (stages & 4) { if (int r = lm_host_enqueue(h->lm, d, odom_valid, eager_map, &h->err)) return r; }
+    if (stages & 4) { if (int r = lm_host_enqueue(h->lm, d, odom_valid, &h->err)) return r; }
   }
   HIP_TRY(h, hipGetLastError());
   return 0;
@@ -259,7 +258,7 @@ int alego_batch_run(alego_handle* h, int first_pos, int n_scans, int stages, int
       pos = ((first_pos + s) % R + R) % R;
     }
     for (int s0 = 0; s0 < h->d.n_slots; s0 += h->gsize)
-      if (int r = enqueue_scan(h, s0, std::min(h->gsize, h->d.n_slots - s0), pos, stages & 7, false, true)) return r;
+      if (int r = enqueue_scan(h, s0, std::min(h->gsize, h->d.n_slots - s0), pos, stages & 7, false)) return r;
   }
   if (sync) HIP_TRY(h, sync_all(h));
   return 0;

@@ -67,17 +67,40 @@ __global__ void __launch_bounds__(LM_BLOCK) lm_prepare(DevCtx d, LmCtx L, int st
   if (!run) { li[LI_FLAGS] = 8; return; }
 }
 
-// Map sequence = lm_map_begin, lm_concat, VoxelGrid of the two maps, lm_grid_*, lm_map_end.  The local map only
-// changes when a key frame is saved, so the sequence is either run at the start of a mapping frame (single-scan entry
-// points) or right after lm_store_kf of the previous mapping frame on the group's side stream (batch path), where it
-// overlaps the ImageProjection / LaserOdometry kernels of the following scans.  Same kernels, same data, same result.
+// Map sequence = lm_map_begin, lm_concat, VoxelGrid of the two maps, lm_grid_*, lm_map_end, at the start of every
+// mapping frame.  lm_map_begin replays the deque bookkeeping of extractSurroundingKeyFrames (laserMapping.cpp:206-238)
+// on the list of frame ids and decides whether the local map changed (the reference re-assembles and re-filters the
+// identical map on every mapping frame; here only when its content changes):
+//   deque not full yet  -> the newest min(n, K) key frames; content changes when a key frame was saved
+//   deque full          -> if latest_frame_id_ != n-1: pop front, push frame n-1.  latest_frame_id_ starts at -1, so the
+//                          first mapping frame after the deque filled up pushes frame K-1 a second time (and drops
+//                          frame 0) although no key frame was saved: the duplicate stays in the window for K-1 further
+//                          key frames and doubles that frame's weight in the voxel centroids.  Reproduced as is.
 __global__ void lm_map_begin(DevCtx d, LmCtx L) {
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= d.n_launch) return;
-  int* li = lip(L, s + d.slot0);
-  const int rb = li[LI_NKF] > 0 && li[LI_DIRTY];
-  li[LI_REBUILD] = rb;
-  if (rb) { li[LI_DIRTY] = 0; li[LI_NREBUILD] += 1; }
+  const int slot = s + d.slot0;
+  int* li = lip(L, slot);
+  li[LI_REBUILD] = 0;
+  if (!li[LI_RUN]) return;
+  const int nkf = li[LI_NKF];
+  if (nkf == 0) return;   // :196-199
+  int* rec = L.rec + (size_t)slot * L.K;
+  const int cnt = li[LI_REC_CNT];
+  bool changed = false;
+  if (cnt < L.K) {
+    const int nk = min(nkf, L.K);
+    changed = li[LI_DIRTY] != 0;
+    for (int j = 0; j < nk; ++j) rec[j] = nkf - nk + j;
+    li[LI_REC_CNT] = nk;
+  } else if (li[LI_LATEST] != nkf - 1) {
+    for (int j = 0; j + 1 < L.K; ++j) rec[j] = rec[j + 1];
+    rec[L.K - 1] = nkf - 1;
+    li[LI_LATEST] = nkf - 1;
+    changed = true;
+  }
+  li[LI_DIRTY] = 0;
+  if (changed) { li[LI_REBUILD] = 1; li[LI_NREBUILD] += 1; }
 }
 __global__ void lm_map_end(DevCtx d, LmCtx L) {
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
@@ -90,12 +113,13 @@ __global__ void __launch_bounds__(LM_BLOCK) lm_concat(DevCtx d, LmCtx L) {
   const int slot = blockIdx.z + d.slot0, j = blockIdx.y;
   int* li = lip(L, slot);
   if (!li[LI_REBUILD]) return;
-  const int nkf = li[LI_NKF], nk = min(nkf, L.K);
+  const int nk = li[LI_REC_CNT];
   if (j >= nk) return;
   const int* kc = L.kf_cnt + (size_t)slot * L.K * 4;
+  const int* rec = L.rec + (size_t)slot * L.K;   // frame f lives in ring slot f % K (a full deque only holds the last K frames)
   int offc = 0, offs = 0;
-  for (int i = 0; i < j; ++i) { const int r = (nkf - nk + i) % L.K; offc += kc[r * 4 + 0]; offs += kc[r * 4 + 1] + kc[r * 4 + 2]; }
-  const int ring = (nkf - nk + j) % L.K;
+  for (int i = 0; i < j; ++i) { const int r = rec[i] % L.K; offc += kc[r * 4 + 0]; offs += kc[r * 4 + 1] + kc[r * 4 + 2]; }
+  const int ring = rec[j] % L.K;
   const int nc = kc[ring * 4 + 0], ns = kc[ring * 4 + 1], no = kc[ring * 4 + 2];
   const float4* sc_ = L.kf_corner + ((size_t)slot * L.K + ring) * L.kf_cap_c;
   const float4* ss_ = L.kf_surf + ((size_t)slot * L.K + ring) * L.kf_cap_s;

@@ -19,6 +19,8 @@ enum {
   LI_NTOTAL, LI_NTOTAL_DS,               // laser_surf_total_, laser_surf_total_ds_
   LI_NREBUILD,     // map rebuilds so far (bench: expected work of the map VoxelGrid kernels)
   LI_OVERFLOW,     // a capacity was exceeded (clouds truncated): reported as an error by the host
+  LI_REC_CNT,      // recent_*_keyframes_.size() (laserMapping.cpp:208)
+  LI_LATEST,       // latest_frame_id_ (laserMapping.cpp:226), -1 until the deque has been full once
   LI_COUNT = 32
 };
 enum {
@@ -47,6 +49,7 @@ struct LmCtx {
   float4 *in_corner, *in_surf, *in_outl;          // [slot][in_cap_*]
   // key-frame ring (clouds already transformed into the map frame, laserMapping.cpp:216-218)
   float4 *kf_corner, *kf_surf, *kf_outl;          // [slot][K][kf_cap_*]
+  int* rec;                                       // [slot][K] frame ids held by recent_*_keyframes_, front first
   int* kf_cnt;                                    // [slot][K][4]
   float* kf_pose;                                 // [slot][K][8]  x y z roll pitch yaw (PointXYZIRPYT f32)
   // local map

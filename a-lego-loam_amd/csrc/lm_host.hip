@@ -26,12 +26,6 @@ struct LmHost {
   LmCtx L;
   // per group — vm: map corner, map surf; v1: scan corner, scan surf, scan outlier; v2: scan surf_total
   std::vector<VoxCtx> vm, v1, v2;
-  // batch path: the map sequence of a group runs on its side stream, ordered by events against the main stream
-  std::vector<hipStream_t> side;
-  std::vector<hipEvent_t> ev_main, ev_side;
-  std::vector<char> side_pending;
-  bool eager_enabled = false;
-  std::vector<char> map_current;   // the last mapping frame of the group was followed by an eager map sequence
   std::vector<void*> allocs;
   std::vector<long> frames;  // host mirror of frame_cnt per slot: only used to skip launches
 };
@@ -56,15 +50,6 @@ LmHost* lm_host_create(const alego_params& P, const DevCtx& d, int n_slots, int 
   lm->P = P; lm->n_slots = n_slots; lm->gsize = gsize; lm->st = st; lm->frames.assign(n_slots, 0);
   VoxCtx vz; std::memset(&vz, 0, sizeof(VoxCtx));
   lm->vm.assign(st.size(), vz); lm->v1.assign(st.size(), vz); lm->v2.assign(st.size(), vz);
-  lm->side.assign(st.size(), nullptr); lm->ev_main.assign(st.size(), nullptr); lm->ev_side.assign(st.size(), nullptr);
-  lm->side_pending.assign(st.size(), 0); lm->map_current.assign(st.size(), 0);
-  // Measured (512 streams): with the HIP runtime's 4 hardware queues, 4 main + 4 side streams multiplex and lose
-  // (148 k scans/s vs 186 k), 2 + 2 ties (184 k); more queues (GPU_MAX_HW_QUEUES=8) lose as well.  Off by default.
-  lm->eager_enabled = getenv("ALEGO_EAGER_MAP") != nullptr && atoi(getenv("ALEGO_EAGER_MAP")) != 0;
-  for (size_t g = 0; lm->eager_enabled && g < st.size(); ++g) {
-    if (hipStreamCreate(&lm->side[g]) != hipSuccess || hipEventCreateWithFlags(&lm->ev_main[g], hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&lm->ev_side[g], hipEventDisableTiming) != hipSuccess) { *err = "lm_host_create: side stream"; lm_host_destroy(lm); return nullptr; }
-  }
   LmCtx& L = lm->L;
   std::memset(&L, 0, sizeof(L));
   L.K = P.recent_keyframe_num > 0 ? P.recent_keyframe_num : 1;
@@ -79,6 +64,7 @@ LmHost* lm_host_create(const alego_params& P, const DevCtx& d, int n_slots, int 
   ok = ok && A(lm, &L.li, B * LI_COUNT, err) && A(lm, &L.ld, B * LD_COUNT, err);
   ok = ok && A(lm, &L.in_corner, B * L.in_cap_c, err) && A(lm, &L.in_surf, B * L.in_cap_s, err) && A(lm, &L.in_outl, B * L.in_cap_o, err);
   ok = ok && A(lm, &L.kf_corner, B * L.K * L.kf_cap_c, err) && A(lm, &L.kf_surf, B * L.K * L.kf_cap_s, err) && A(lm, &L.kf_outl, B * L.K * L.kf_cap_o, err);
+  ok = ok && A(lm, &L.rec, B * L.K, err);
   ok = ok && A(lm, &L.kf_cnt, B * L.K * 4, err) && A(lm, &L.kf_pose, B * L.K * 8, err);
   ok = ok && A(lm, &L.map_corner_raw, B * L.map_cap_c, err) && A(lm, &L.map_surf_raw, B * L.map_cap_s, err);
   ok = ok && A(lm, &L.map_corner_ds, B * L.map_cap_c, err) && A(lm, &L.map_surf_ds, B * L.map_cap_s, err);
@@ -92,6 +78,9 @@ LmHost* lm_host_create(const alego_params& P, const DevCtx& d, int n_slots, int 
   std::vector<double> ld(B * LD_COUNT, 0.0);
   for (size_t b = 0; b < B; ++b) { ld[b * LD_COUNT + LD_Q_M2O] = 1.0; ld[b * LD_COUNT + LD_Q_O2L] = 1.0; ld[b * LD_COUNT + LD_Q_M2L] = 1.0; }
   (void)hipMemcpy(L.ld, ld.data(), ld.size() * sizeof(double), hipMemcpyHostToDevice);
+  std::vector<int> li0(B * LI_COUNT, 0);
+  for (size_t b = 0; b < B; ++b) li0[b * LI_COUNT + LI_LATEST] = -1;   // laserMapping.cpp:50
+  (void)hipMemcpy(L.li, li0.data(), li0.size() * sizeof(int), hipMemcpyHostToDevice);
   // VoxelGrid job tables (laserMapping.cpp:37-39,316-319,329-342)
   for (size_t g = 0; g < st.size(); ++g) {
   std::vector<VoxJob> jm, j1, j2;
@@ -111,9 +100,6 @@ LmHost* lm_host_create(const alego_params& P, const DevCtx& d, int n_slots, int 
 
 void lm_host_destroy(LmHost* lm) {
   if (!lm) return;
-  for (hipStream_t q : lm->side) if (q) { (void)hipStreamSynchronize(q); (void)hipStreamDestroy(q); }
-  for (hipEvent_t e : lm->ev_main) if (e) (void)hipEventDestroy(e);
-  for (hipEvent_t e : lm->ev_side) if (e) (void)hipEventDestroy(e);
   for (auto& v : lm->vm) vox_destroy(&v);
   for (auto& v : lm->v1) vox_destroy(&v);
   for (auto& v : lm->v2) vox_destroy(&v);
@@ -144,10 +130,8 @@ static int map_sequence(LmHost* lm, const DevCtx& d, const LmCtx& L, int g, hipS
   return 0;
 }
 
-// odom_valid[s - slot0]: whether slot s has an /odom/lidar message for this scan (false on its first scan).
-// eager: run the map sequence for the NEXT mapping frame on the side stream right after this one (batch path).
-static int lm_sequence(LmHost* lm, const DevCtx& d, int stage, const std::vector<char>& odom_valid, bool eager, std::string* err) {
-  eager = eager && lm->eager_enabled;
+// odom_valid[s - slot0]: whether slot s has an /odom/lidar message for this scan (false on its first scan)
+static int lm_sequence(LmHost* lm, const DevCtx& d, int stage, const std::vector<char>& odom_valid, std::string* err) {
   // the slots of one launch view always belong to one stream group
   const int g = d.slot0 / lm->gsize;
   hipStream_t st = lm->st[g];
@@ -164,26 +148,14 @@ static int lm_sequence(LmHost* lm, const DevCtx& d, int stage, const std::vector
   launch_lm_prepare(d, L, stage, hint, st);
   if (!dbg_sync(st, "lm_prepare", err)) return ALEGO_ERR_HIP;
   if (n_run == 0) return 0;
+  if (int r = map_sequence(lm, d, L, g, st, err)) return r;
   if (int r = vox_run(lm->v1[g], st, err)) return r;
   if (!dbg_sync(st, "vox scan", err)) return ALEGO_ERR_HIP;
   launch_lm_total(d, L, st);
   if (int r = vox_run(lm->v2[g], st, err)) return r;
   if (!dbg_sync(st, "vox total", err)) return ALEGO_ERR_HIP;
-  // the map: wait for a map sequence still running on the side stream, then (a no-op when the key-frame set did not
-  // change since) bring it up to date
-  if (lm->side_pending[g]) { (void)hipStreamWaitEvent(st, lm->ev_side[g], 0); lm->side_pending[g] = 0; }
-  if (!lm->map_current[g]) { if (int r = map_sequence(lm, d, L, g, st, err)) return r; }
   launch_lm_register(d, L, st);
   if (!dbg_sync(st, "lm_register", err)) return ALEGO_ERR_HIP;
-  if (eager) {
-    (void)hipEventRecord(lm->ev_main[g], st);
-    (void)hipStreamWaitEvent(lm->side[g], lm->ev_main[g], 0);
-    if (int r = map_sequence(lm, d, L, g, lm->side[g], err)) return r;
-    (void)hipEventRecord(lm->ev_side[g], lm->side[g]);
-    lm->side_pending[g] = 1;
-  }
-  // only a whole-group eager frame leaves every map of the group up to date
-  lm->map_current[g] = eager && d.slot0 == g * lm->gsize && d.slot0 + d.n_launch == std::min(lm->n_slots, (g + 1) * lm->gsize);
   return 0;
 }
 
@@ -200,14 +172,9 @@ static void clear_run_flags_outside(LmHost* lm, const DevCtx& d) {
   }
 }
 
-int lm_host_enqueue(LmHost* lm, const DevCtx& d, const std::vector<char>& odom_valid, bool eager_map, std::string* err) {
+int lm_host_enqueue(LmHost* lm, const DevCtx& d, const std::vector<char>& odom_valid, std::string* err) {
   clear_run_flags_outside(lm, d);
-  return lm_sequence(lm, d, 1, odom_valid, eager_map, err);
-}
-hipError_t lm_host_sync(LmHost* lm) {
-  hipError_t r = hipSuccess;
-  for (hipStream_t q : lm->side) { if (!q) continue; hipError_t e = hipStreamSynchronize(q); if (e != hipSuccess) r = e; }
-  return r;
+  return lm_sequence(lm, d, 1, odom_valid, err);
 }
 
 int lm_host_process_host(LmHost* lm, const DevCtx& dfull, const alego_point* corner_last, int n_corner, const alego_point* surf_last,
@@ -229,7 +196,7 @@ int lm_host_process_host(LmHost* lm, const DevCtx& dfull, const alego_point* cor
   (void)hipMemcpyAsync(d.scal + SC_ODOM_VALID, &one, sizeof(int), hipMemcpyHostToDevice, st);
   if (hipStreamSynchronize(st) != hipSuccess) { *err = "alego_lm_process: upload failed"; return ALEGO_ERR_HIP; }
   clear_run_flags_outside(lm, d);
-  if (int r = lm_sequence(lm, d, 0, std::vector<char>(1, 1), false, err)) return r;
+  if (int r = lm_sequence(lm, d, 0, std::vector<char>(1, 1), err)) return r;
   double out[16], ld[LD_COUNT];
   int li[LI_COUNT];
   (void)hipMemcpyAsync(out, d.poses, sizeof(out), hipMemcpyDeviceToHost, st);

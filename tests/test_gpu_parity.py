@@ -222,6 +222,29 @@ def test_full_loop_teacher_forced(geom, nscan):
     h.close()
 
 
+def test_recent_keyframe_deque_quirk():
+    """The local-map window past its fill-up: with latest_frame_id_ starting at -1 (laserMapping.cpp:50,227-236) the first
+    mapping frame after the deque filled pushes the newest key frame a second time; the duplicate then slides through the
+    window.  4-key-frame window, a key frame every ~3 scans: fill, duplicate, slide-out, all compared map by map."""
+    p = synth.default_params(16, 1800)
+    p.recent_keyframe_num = 4
+    p.min_keyframe_dist = 0.09
+    h, o = binding.Handle(p), O.Oracle(p)
+    for k in range(70):
+        pts = synth.scan(p, k)
+        h.set_lo_params(o.get("lo_params"))
+        h.set_lm_params(o.get("lm_params"))
+        o.process_scan(pts)
+        flags, odom, mp = h.scan_process(pts, stages=7)
+        if k == 0:
+            continue
+        _lm_compare(h, o, k, f"K=4 scan {k}")
+        want = o.get("map_pose")
+        assert np.abs(mp["t"] - want[:3]).max() < POSE_TOL and quat_angle(mp["q"], want[3:]) < POSE_TOL
+    assert o.get("lm_info")[11] >= 10, "needs more than 2 K key frames"
+    h.close()
+
+
 def test_full_loop_free_running(params_a):
     p = params_a
     h, o = binding.Handle(p), O.Oracle(p)
