@@ -1,0 +1,25 @@
+#!/bin/bash
+# Run on the GPU box (gpurun -- 'bash tools/refresh_profiles.sh'): writes gpurun_out/r01_* ; copy them to profiles/ afterwards.
+#   r01_bench.json                 the default bench.py line (HIP-event kernel table, roofline, cpu_baseline, parity)
+#   r01_bench_under_rocprof.json   the same command under rocprofv3 --kernel-trace --stats (without the CPU legs)
+#   r01_bench_kernel_stats.csv     rocprofv3's per-kernel summary of that run
+#   r01_pmc_traffic.json           HBM bytes per launch from two separate --pmc passes (FETCH_SIZE, WRITE_SIZE)
+set -u
+cd /tmp && export TMPDIR=/tmp
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+mkdir -p gpurun_out
+python bench.py > gpurun_out/r01_bench.json 2> gpurun_out/r01_bench.err
+rm -rf /tmp/prof_stats /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE
+rocprofv3 --kernel-trace --stats -d /tmp/prof_stats -o st --output-format csv -- python bench.py --no-cpu > gpurun_out/r01_bench_under_rocprof.json 2> /tmp/st.log
+find /tmp/prof_stats -name "*kernel_stats.csv" -exec cp {} gpurun_out/r01_bench_kernel_stats.csv \;
+PER=$(python - <<'PY'
+import json
+d = json.loads(open("gpurun_out/r01_bench.json").read().strip().splitlines()[-1])
+print(d["roofline"]["streams_per_launch"])
+PY
+)
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 900 rocprofv3 --pmc $c --kernel-trace -d /tmp/pmc_$c -o p --output-format csv -- python bench.py --steps 8 --warmup 0 --prime 560 --no-cpu --no-profile > /tmp/pmc_$c.log 2>&1
+done
+python tools/pmc_traffic.py /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE "$PER" 16 > gpurun_out/r01_pmc_traffic.json
+ls -la gpurun_out/r01_*

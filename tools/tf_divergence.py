@@ -6,7 +6,8 @@ from alego_loader import load_package; load_package()
 from alego_amd import binding, synth
 from oracle import oracle_py as O
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 560
-p = synth.default_params(16, 1800)
+geom = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (16, 1800)
+p = synth.default_params(*geom)
 h, o = binding.Handle(p), O.Oracle(p)
 for k in range(n):
     pts = synth.scan(p, k)
