@@ -49,8 +49,8 @@ __device__ __forceinline__ bool vx_enabled(const VoxJob& J) { return J.enable ==
 #define VG_ND (1 << VG_DMAX)
 #define VG_U 4                 // independent loads kept in flight per lane in the streaming loops
 
-__device__ __forceinline__ int vg_div(int pos, int seglen, float inv_seglen) {  // floor(pos / seglen), both < 2^24
-  int q = (int)((float)pos * inv_seglen);
+__device__ __forceinline__ int vg_div(int pos, int seglen, double inv_seglen) {  // floor(pos / seglen) for any int32 pair
+  int q = (int)((double)pos * inv_seglen);
   if (q * seglen > pos) --q;
   if ((q + 1) * seglen <= pos) ++q;
   return q;
@@ -119,7 +119,7 @@ __global__ void __launch_bounds__(VG_T) vox_big(VoxCtx V) {
   const unsigned dmask = (unsigned)(nd - 1);
   // every wavefront owns [seg0, seg1): whole rounds of 64 so that lanes are in index order
   const int seglen = ((n + VG_T - 1) / VG_T) * 64;
-  const float inv_seglen = 1.0f / (float)seglen;
+  const double inv_seglen = 1.0 / (double)seglen;
   const int seg0 = min(n, wave * seglen), seg1 = min(n, seg0 + seglen);
   unsigned* keys = V.keys + J.off;
   u64* bufA = V.pairs_a + J.off;
@@ -488,7 +488,6 @@ int vox_create(VoxCtx* V, const VoxJob* jobs, int njobs, std::string* err) {
   for (auto& j : h) {
     j.off = (int)total;
     if (j.cap > VX_SMALL_MAX) total += (size_t)j.cap;  // only jobs that can reach vox_big need sort scratch
-    if (j.cap >= (1 << 24)) { *err = "vox_create: job capacity must be below 2^24 points"; return -3; }
   }
   if (total > 0x7fffffffull) { *err = "vox_create: scratch exceeds 2^31 elements"; return -3; }
   V->njobs = njobs; V->total = (unsigned)total;

@@ -172,6 +172,8 @@ def main():
     ap.add_argument("--streams", type=int, default=512, help="independent streams resident per GPU")
     ap.add_argument("--ring", type=int, default=48, help="scans kept in HBM per stream (replayed back and forth)")
     ap.add_argument("--prime", type=int, default=560, help="untimed scans per stream to fill the 50-key-frame local map")
+    ap.add_argument("--geometry", default="16x1800", help="n_scan x horizon_scan: 16x1800 (BASELINE metric), 16x4000, 64x2048")
+    ap.add_argument("--keyframes", type=int, default=0, help="local-map window (0 = reference default 50; config 5 uses 200)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     args = ap.parse_args()
@@ -185,7 +187,10 @@ def main():
     if world > 1:
         dist = D.init("nccl", torch.device("cuda", local))  # RCCL: only the barrier + max-over-ranks use it
 
-    p = synth.default_params(16, 1800)
+    ns, hs = (int(v) for v in args.geometry.lower().split("x"))
+    p = synth.default_params(ns, hs)
+    if args.keyframes > 0:
+        p.recent_keyframe_num = args.keyframes
     B, R = args.streams, args.ring
     h = binding.Handle(p, device=local, n_slots=B, ring_len=R)
     scans = gen_scans(p, B, R, rank)
@@ -245,10 +250,10 @@ def main():
                         map_rebuilds_per_launch=round(rebuilds / max(kern[dom]["launches"], 1), 2))
     value = D.aggregate_scans_per_s(world, B, args.steps, dt)
     out = {
-        "metric": "scans/sec (16x1800 LiDAR) full IP->LO->LM loop", "value": round(value, 1), "unit": "scans/s",
+        "metric": f"scans/sec ({ns}x{hs} LiDAR) full IP->LO->LM loop", "value": round(value, 1), "unit": "scans/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32/f64", "data": "synthetic",
-        "config": {"workload": "16x1800 S0/T0 bag-equivalent replay, IP->LO->LM with 50-key-frame local map, "
+        "config": {"workload": f"{ns}x{hs} S0/T0 bag-equivalent replay, IP->LO->LM with {p.recent_keyframe_num}-key-frame local map, "
                                f"{B} independent streams per GPU (one scan per stream per step)",
                    "streams_per_gpu": B, "ring_scans": R, "primed_scans": args.prime, "parallelism": f"streams x{world}"},
     }

@@ -2,7 +2,8 @@
 # Run on the GPU box (gpurun -- 'bash tools/refresh_profiles.sh'): writes gpurun_out/r01_* ; copy them to profiles/ afterwards.
 #   r01_bench.json                 the default bench.py line (HIP-event kernel table, roofline, cpu_baseline, parity)
 #   r01_bench_under_rocprof.json   the same command under rocprofv3 --kernel-trace --stats (without the CPU legs)
-#   r01_bench_kernel_stats.csv     rocprofv3's per-kernel summary of that run
+#   r01_bench_kernel_stats.csv     rocprofv3's per-kernel summary of that run (all dispatches, priming included)
+#   r01_bench_kernel_stats_steady.csv  the same trace restricted to the dispatches of bench.py's HIP-event pass, side by side
 #   r01_pmc_traffic.json           HBM bytes per launch from two separate --pmc passes (FETCH_SIZE, WRITE_SIZE)
 set -u
 cd /tmp && export TMPDIR=/tmp
@@ -12,6 +13,7 @@ python bench.py > gpurun_out/r01_bench.json 2> gpurun_out/r01_bench.err
 rm -rf /tmp/prof_stats /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE
 rocprofv3 --kernel-trace --stats -d /tmp/prof_stats -o st --output-format csv -- python bench.py --no-cpu > gpurun_out/r01_bench_under_rocprof.json 2> /tmp/st.log
 find /tmp/prof_stats -name "*kernel_stats.csv" -exec cp {} gpurun_out/r01_bench_kernel_stats.csv \;
+python tools/trace_tail_stats.py /tmp/prof_stats gpurun_out/r01_bench_under_rocprof.json > gpurun_out/r01_bench_kernel_stats_steady.csv
 PER=$(python - <<'PY'
 import json
 d = json.loads(open("gpurun_out/r01_bench.json").read().strip().splitlines()[-1])
