@@ -43,6 +43,8 @@ struct DevCtx {
   int Pcap;       // input points capacity per scan (= N)
   int cap_sharp, cap_lsharp, cap_flat;  // per-ring staging capacities: n_sharp*n_sectors, ...
   double sin_ax, cos_ax, sin_ay, cos_ay;  // sin/cos of seg_alpha_x / seg_alpha_y (host libm)
+  double inv_res_x, inv_res_y;            // 1 / ang_res_x, 1 / ang_res_y (projection shortcut)
+  double tan_theta;                       // tan(seg_theta) for the edge predicate shortcut; NaN disables the shortcut
   // ---- input ring ----
   float4* in_pts;  // [slot][ring][Pcap]
   int* in_n;       // [slot][ring]

@@ -14,6 +14,7 @@
 // All kernels are launched with blockIdx.y = slot (independent stream).
 // HBM-bound: one scan moves 16 B/point in and 25 B/segmented point out; the images
 // in between (owner, range, flags, parent: 13 B/cell) stay L2-resident.
+#include <cstdlib>
 #include "dev_common.h"
 #include "prof.h"
 
@@ -45,19 +46,30 @@ __global__ void __launch_bounds__(IP_BLOCK) ip_project(DevCtx d, int ring_pos) {
     }
     if (valid) {
       // imageProjection.cpp:79-80 (IP.cpp:142-172 for the RFANS table)
-      const double vertical_ang = ((double)d_atan2f(p.z, d_hypotf(p.x, p.y)) * 180.0) / M_PI;
+      // (a * 180.0) / M_PI and x / ang_res are IEEE fp64 divisions in the reference (~35 instructions each here).  The
+      // integer part of the result only depends on the exact quotient when it lies within rounding error of an
+      // integer: multiply by the reciprocals first and redo the reference expression only in that case.
+      const double va = (double)d_atan2f(p.z, d_hypotf(p.x, p.y)) * 180.0;
       int row;
-      if (P.laser_type == ALEGO_LASER_UNIFORM) row = (int)((vertical_ang + P.ang_bottom) / P.ang_res_y + 0.5);
-      else if (vertical_ang > 4.5) row = (int)(13 + (vertical_ang - 5.) / 3 + 0.5);
-      else if (vertical_ang > 0.5) row = (int)(11 + (vertical_ang - 1.0) / 2 + 0.5);
-      else if (vertical_ang > -7.) row = (int)(10.5 + vertical_ang);
-      else if (vertical_ang > -8.5) row = 3;
-      else if (vertical_ang > -10.5) row = 2;
-      else if (vertical_ang > -13.5) row = 1;
-      else row = 0;
+      if (P.laser_type == ALEGO_LASER_UNIFORM) {
+        const double r = (va * (1.0 / M_PI) + P.ang_bottom) * d.inv_res_y + 0.5;
+        row = (int)r;
+        if (fabs(r - rint(r)) < 1e-9 * (1.0 + fabs(r))) row = (int)((va / M_PI + P.ang_bottom) / P.ang_res_y + 0.5);
+      } else {  // RFANS ring table (IP.cpp:142-172)
+        const double vertical_ang = va / M_PI;
+        if (vertical_ang > 4.5) row = (int)(13 + (vertical_ang - 5.) / 3 + 0.5);
+        else if (vertical_ang > 0.5) row = (int)(11 + (vertical_ang - 1.0) / 2 + 0.5);
+        else if (vertical_ang > -7.) row = (int)(10.5 + vertical_ang);
+        else if (vertical_ang > -8.5) row = 3;
+        else if (vertical_ang > -10.5) row = 2;
+        else if (vertical_ang > -13.5) row = 1;
+        else row = 0;
+      }
       // :87-97
-      const double horizon_ang = (((double)(-d_atan2f(p.y, p.x)) + 2 * M_PI) * 180.0) / M_PI;
-      int col = (int)(horizon_ang / P.ang_res_x);
+      const double ha = ((double)(-d_atan2f(p.y, p.x)) + 2 * M_PI) * 180.0;
+      const double cfast = ha * (1.0 / M_PI) * d.inv_res_x;
+      int col = (int)cfast;
+      if (fabs(cfast - rint(cfast)) < 1e-9 * (1.0 + fabs(cfast))) col = (int)((ha / M_PI) / P.ang_res_x);
       if (col >= d.H) col -= d.H;
       if (row >= 0 && row < d.NS && col >= 0 && col < d.H)
         atomicMax(&d.owner[(size_t)slot * d.N + col + row * d.H], i);  // later points overwrite earlier ones (:102-103)
@@ -132,7 +144,18 @@ __global__ void __launch_bounds__(128) ip_image(DevCtx d, int ring_pos) {
 DEV_INLINE int ld_agent(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 DEV_INLINE void st_agent(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-__global__ void __launch_bounds__(IP_BLOCK) cc_edges(DevCtx d) {
+// atan2(y, x) > theta for y > 0, x > 0 (y = d2 sin a, x = d1 - d2 cos a with d1 >= d2 > 0 and 0 < a < pi/2).
+// tan is monotone on (0, pi/2): the comparison is decided by the sign of y - x tan(theta) whenever that difference is
+// far (1e-9 relative) from zero — rounding errors of either form are ~1e-16 — and by the reference expression itself
+// otherwise.  Saves two fp64 atan2 per cell on all but a vanishing fraction of the edges.
+DEV_INLINE bool edge_angle_gt(double y, double x, double theta, double tan_theta) {
+  const double xt = x * tan_theta, m = y - xt;
+  if (fabs(m) > 1e-9 * (y + fabs(xt))) return m > 0.0;
+  return atan2(y, x) > theta;
+}
+
+// init: bit 0 parent (global union-find path), bit 1 component statistics (cc_stats path), bit 2 labels (ip_compact path)
+__global__ void __launch_bounds__(IP_BLOCK) cc_edges(DevCtx d, int init) {
   const int slot = blockIdx.y + d.slot0;
   const int v = blockIdx.x * IP_BLOCK + threadIdx.x;
   if (v >= d.N) return;
@@ -150,23 +173,22 @@ __global__ void __launch_bounds__(IP_BLOCK) cc_edges(DevCtx d) {
     if ((fimg[u] & 2) && d.H > 1) {  // same row, seg_alpha_x (:258-261)
       const double ru = (double)rimg[u];
       const double d1 = fmax(rv, ru), d2 = fmin(rv, ru);
-      if (atan2(d2 * d.sin_ax, d1 - d2 * d.cos_ax) > d.P.seg_theta) e |= 4;
+      if (edge_angle_gt(d2 * d.sin_ax, d1 - d2 * d.cos_ax, d.P.seg_theta, d.tan_theta)) e |= 4;
     }
     if (row + 1 < d.NS) {
       const int w = v + d.H;
       if (fimg[w] & 2) {  // same column, seg_alpha_y (:262-265)
         const double rw = (double)rimg[w];
         const double d1 = fmax(rv, rw), d2 = fmin(rv, rw);
-        if (atan2(d2 * d.sin_ay, d1 - d2 * d.cos_ay) > d.P.seg_theta) e |= 8;
+        if (edge_angle_gt(d2 * d.sin_ay, d1 - d2 * d.cos_ay, d.P.seg_theta, d.tan_theta)) e |= 8;
       }
     }
   }
   // NOTE: bits 2/3 of a neighbour are never read by this kernel (only bit 1), so the in-place update is race-free
   fimg[v] = (uint8_t)((f & 3) | e);
-  d.parent[base + v] = active ? v : -1;
-  d.cc_size[base + v] = 0;
-  d.cc_rows[base + v] = 0ull;
-  d.cc_label[base + v] = 0;
+  if (init & 1) d.parent[base + v] = active ? v : -1;
+  if (init & 2) { d.cc_size[base + v] = 0; d.cc_rows[base + v] = 0ull; }
+  if (init & 4) d.cc_label[base + v] = 0;
 }
 
 // ECL-CC style find with intermediate pointer jumping; parents only ever decrease.
@@ -271,7 +293,7 @@ DEV_INLINE void ccl_union(int* parent, int a, int b) {
     }
   } while (repeat);
 }
-__global__ void __launch_bounds__(CC_LDS_THREADS) cc_lds(DevCtx d, int ring_pos) {
+__global__ void __launch_bounds__(CC_LDS_THREADS) cc_lds(DevCtx d, int ring_pos, int fused) {
   const int slot = blockIdx.x + d.slot0;
   const size_t base = (size_t)slot * d.N;
   extern __shared__ __attribute__((aligned(16))) unsigned char cc_smem[];
@@ -320,7 +342,7 @@ __global__ void __launch_bounds__(CC_LDS_THREADS) cc_lds(DevCtx d, int ring_pos)
       if (stats && rt[k] == v) { const unsigned w = (unsigned)parent[v]; d.cc_size[base + v] = (int)(w & 0xFFFFu); d.cc_rows[base + v] = (unsigned long long)(w >> 16); }
     }
   }
-  if (!stats) return;  // ip_rowcount / ip_compact follow (launch_ip)
+  if (!stats || !fused) return;  // ip_rowcount / ip_compact follow (launch_ip)
   // ---- fused a6: ordered compaction of the whole image (replaces ip_rowcount + ip_compact for this geometry).
   // Chunk k = cells [1024 k, 1024 k + 1024) in row-major order, one cell per thread: per-(chunk, wavefront) counts of
   // kept cells / outliers / feasible roots, one exclusive scan over the (chunk, wavefront) table, then every cell
@@ -411,7 +433,8 @@ __global__ void __launch_bounds__(CC_LDS_THREADS) cc_lds(DevCtx d, int ring_pos)
         d.outlier[base + s_cnt[1][k * NW + wave] + (int)__popcll(bo & below)] = p;
       }
     }
-    if (fr) d.cc_label[base + v] = s_cnt[2][k * NW + wave] + (int)__popcll(bf & below) + 1;  // label_cnt_ numbering (:303-306)
+    // label_cnt_ numbering (:303-306); 0 for the root of an infeasible component (ip_labels turns it into 999999)
+    if (rt[k] == v) d.cc_label[base + v] = fr ? s_cnt[2][k * NW + wave] + (int)__popcll(bf & below) + 1 : 0;
   }
 }
 
@@ -588,19 +611,22 @@ __global__ void atan2f_probe(const float* y, const float* x, float* out, int n, 
 
 // ---- host-side launchers -------------------------------------------------------
 void launch_ip(const DevCtx& d, int ring_pos, bool want_labels, hipStream_t st) {
+  static const bool fuse_env = !(getenv("ALEGO_CC_FUSED") && atoi(getenv("ALEGO_CC_FUSED")) == 0);
+  const bool fused = fuse_env && d.N <= CC_LDS_MAXN && d.NS <= 16;   // cc_lds also does the compaction
   const dim3 gN((d.N + IP_BLOCK - 1) / IP_BLOCK, d.n_launch), gP((d.Pcap + IP_BLOCK - 1) / IP_BLOCK, d.n_launch);
   ALEGO_LAUNCH(ip_reset, gN, dim3(IP_BLOCK), 0, st, d);
   ALEGO_LAUNCH(ip_project, gP, dim3(IP_BLOCK), 0, st, d, ring_pos);
   ALEGO_LAUNCH(ip_image, dim3((d.H + 127) / 128, d.n_launch), dim3(128), 0, st, d, ring_pos);
-  ALEGO_LAUNCH(cc_edges, gN, dim3(IP_BLOCK), 0, st, d);
+  const bool lds_cc = d.N <= CC_LDS_MAXN, lds_stats = lds_cc && d.NS <= 16;
+  ALEGO_LAUNCH(cc_edges, gN, dim3(IP_BLOCK), 0, st, d, (lds_cc ? 0 : 1) | (lds_stats ? 0 : 2) | (fused ? 0 : 4));
   if (d.N <= CC_LDS_MAXN) {
-    ALEGO_LAUNCH(cc_lds, dim3(d.n_launch), dim3(CC_LDS_THREADS), (size_t)4 * d.N, st, d, ring_pos);
+    ALEGO_LAUNCH(cc_lds, dim3(d.n_launch), dim3(CC_LDS_THREADS), (size_t)4 * d.N, st, d, ring_pos, fused ? 1 : 0);
   } else {
     ALEGO_LAUNCH(cc_runs, dim3((d.H + 127) / 128, d.n_launch), dim3(128), 0, st, d);
     ALEGO_LAUNCH(cc_link, gN, dim3(IP_BLOCK), 0, st, d);
   }
-  if (!(d.N <= CC_LDS_MAXN && d.NS <= 16)) {  // otherwise cc_lds already produced the statistics and the compaction
-    ALEGO_LAUNCH(cc_stats, gN, dim3(IP_BLOCK), 0, st, d);
+  if (!(d.N <= CC_LDS_MAXN && d.NS <= 16)) ALEGO_LAUNCH(cc_stats, gN, dim3(IP_BLOCK), 0, st, d);  // otherwise cc_lds produced the statistics
+  if (!fused) {
     ALEGO_LAUNCH(ip_rowcount, dim3(d.NS, d.n_launch), dim3(IP_BLOCK), 0, st, d);
     ALEGO_LAUNCH(ip_compact, dim3(d.NS, d.n_launch), dim3(IP_BLOCK), 0, st, d, ring_pos);
   }
