@@ -152,6 +152,12 @@ int alego_create(const alego_params* params, int device, int n_slots, int ring_l
   d.st_stride = d.cap_sharp + d.cap_lsharp + d.cap_flat + d.H;
   d.sin_ax = std::sin(params->seg_alpha_x); d.cos_ax = std::cos(params->seg_alpha_x);  // imageProjection.cpp:269
   d.sin_ay = std::sin(params->seg_alpha_y); d.cos_ay = std::cos(params->seg_alpha_y);
+  {
+    const double lo = params->sensor_mount_ang - params->ground_angle_thres, hi = params->sensor_mount_ang + params->ground_angle_thres;
+    const bool ok = lo > -89.0 && hi < 89.0 && lo < hi;
+    d.tan_g_lo = ok ? std::tan(lo * M_PI / 180.0) : std::nan("");
+    d.tan_g_hi = ok ? std::tan(hi * M_PI / 180.0) : std::nan("");
+  }
   d.inv_res_x = 1.0 / params->ang_res_x; d.inv_res_y = 1.0 / params->ang_res_y;
   d.tan_theta = (params->seg_theta > 0.0 && params->seg_theta < 1.5) ? std::tan(params->seg_theta) : std::nan("");
   const size_t B = n_slots, N = d.N, NS = d.NS;

@@ -44,6 +44,7 @@ struct DevCtx {
   int cap_sharp, cap_lsharp, cap_flat;  // per-ring staging capacities: n_sharp*n_sectors, ...
   double sin_ax, cos_ax, sin_ay, cos_ay;  // sin/cos of seg_alpha_x / seg_alpha_y (host libm)
   double inv_res_x, inv_res_y;            // 1 / ang_res_x, 1 / ang_res_y (projection shortcut)
+  double tan_g_lo, tan_g_hi;              // tan of (sensor_mount_ang -/+ ground_angle_thres) (ground test shortcut; NaN disables)
   double tan_theta;                       // tan(seg_theta) for the edge predicate shortcut; NaN disables the shortcut
   // ---- input ring ----
   float4* in_pts;  // [slot][ring][Pcap]

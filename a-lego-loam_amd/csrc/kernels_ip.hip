@@ -130,8 +130,18 @@ __global__ void __launch_bounds__(128) ip_image(DevCtx d, int ring_pos) {
     rimg[row * d.H + col] = r;
     if (row >= 1 && row - 1 < P.ground_scan_id && ok && lower_ok) {  // :111-131, pair (row-1,row)
       const double dx = (double)(x - lx), dy = (double)(y - ly), dz = (double)(z - lz);
-      const double angle = (atan2(dz, hypot(dx, dy)) * 180.0) / M_PI;
-      if (fabs(angle - P.sensor_mount_ang) < P.ground_angle_thres) ground |= 3ull << (row - 1);
+      // |deg(atan2(dz, hypot(dx, dy))) - mount| < thres  <=>  tan(lo) h < dz < tan(hi) h; decided by the two signed
+      // margins unless one of them is within 1e-9 (relative) of zero, where the reference expression decides
+      const double hq = sqrt(dx * dx + dy * dy);
+      const double m1 = dz - d.tan_g_lo * hq, m2 = d.tan_g_hi * hq - dz, tol = 1e-9 * (fabs(dz) + hq);
+      bool is_ground;
+      if (m1 > tol && m2 > tol) is_ground = true;
+      else if (m1 < -tol || m2 < -tol) is_ground = false;
+      else {
+        const double angle = (atan2(dz, hypot(dx, dy)) * 180.0) / M_PI;
+        is_ground = fabs(angle - P.sensor_mount_ang) < P.ground_angle_thres;
+      }
+      if (is_ground) ground |= 3ull << (row - 1);
     }
     lx = x; ly = y; lz = z; lower_ok = ok;
   }
