@@ -448,6 +448,272 @@ __global__ void __launch_bounds__(CC_LDS_THREADS) cc_lds(DevCtx d, int ring_pos,
   }
 }
 
+// 16-bit variant for n_scan <= 16 (every such image has < 65536 cells): the parent array takes 2 B/cell (58 KB at 16x1800
+// instead of 115 KB), so that two of these workgroups — or one of them and the other stream groups' workgroups — fit a CU;
+// under load the kernel's duration is decided by that, not by its instruction count.  LDS has no 16-bit atomics: the union's
+// compare-and-swap goes through the aligned 32-bit word (a concurrent change of the other half makes it retry), the
+// path-halving stores are plain 16-bit stores (parents only ever decrease, any ancestor is a valid parent).  Component size
+// and row mask are accumulated one after the other in the same array with 32-bit atomics on packed halves (sizes < 65536
+// cannot carry into the neighbour; OR is bit-local).
+DEV_INLINE int ccl16_find(uint16_t* par, int v) {
+  int curr = par[v];
+  if (curr != v) {
+    int prev = v, next;
+    while (curr > (next = par[curr])) { par[prev] = (uint16_t)next; prev = curr; curr = next; }
+  }
+  return curr;
+}
+// compare-and-swap of entry idx (expect -> val); returns the entry's previous value
+DEV_INLINE int ccl16_cas(uint16_t* par, int idx, int expect, int val) {
+  unsigned* w = reinterpret_cast<unsigned*>(par) + (idx >> 1);
+  const int sh = (idx & 1) * 16;
+  unsigned old = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  while (true) {
+    const int cur = (int)((old >> sh) & 0xFFFFu);
+    if (cur != expect) return cur;
+    const unsigned nw = (old & ~(0xFFFFu << sh)) | ((unsigned)val << sh);
+    const unsigned got = atomicCAS(w, old, nw);
+    if (got == old) return expect;
+    old = got;
+  }
+}
+DEV_INLINE void ccl16_union(uint16_t* par, int a, int b) {
+  int ra = ccl16_find(par, a), rb = ccl16_find(par, b);
+  bool repeat;
+  do {
+    repeat = false;
+    if (ra != rb) {
+      int ret;
+      if (ra < rb) { if ((ret = ccl16_cas(par, rb, rb, ra)) != rb) { rb = ret; repeat = true; } }
+      else { if ((ret = ccl16_cas(par, ra, ra, rb)) != ra) { ra = ret; repeat = true; } }
+    }
+  } while (repeat);
+}
+#ifdef ALEGO_TIMING
+__device__ long long cc_times[16];
+#define CC_TICK(k) do { if (threadIdx.x == 0 && blockIdx.x == 0) cc_times[k] = wall_clock64(); } while (0)
+extern "C" void alego_cc_times(long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(cc_times), sizeof(long long) * 16); }
+#else
+#define CC_TICK(k)
+#endif
+#define CC_T CC_LDS_THREADS   // (512-thread workgroups were measured: 188 k vs 203 k scans/s)
+__global__ void __launch_bounds__(CC_T) cc_lds16(DevCtx d, int ring_pos, int fused) {
+  const int slot = blockIdx.x + d.slot0;
+  const size_t base = (size_t)slot * d.N;
+  extern __shared__ __attribute__((aligned(16))) unsigned char cc_smem[];
+  uint16_t* par = reinterpret_cast<uint16_t*>(cc_smem);
+  unsigned* packed = reinterpret_cast<unsigned*>(cc_smem);   // the same bytes as [ceil(N/2)] words of two 16-bit counters
+  const uint8_t* fi = d.flag_img + base;
+  const int N = d.N, H = d.H, NWORD = (N + 1) / 2;
+  CC_TICK(0);
+  constexpr int PER = (CC_LDS_MAXN + CC_T - 1) / CC_T;
+  // the 4 flag bits of this thread's cells, all loads in flight together, packed 16 cells per register pair
+  unsigned long long flw[(PER + 15) / 16];
+#pragma unroll
+  for (int q = 0; q < (PER + 15) / 16; ++q) flw[q] = 0;
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    const int v = threadIdx.x + k * CC_T;
+    const unsigned f = v < N ? (unsigned)fi[v] & 15u : 0u;
+    flw[k >> 4] |= (unsigned long long)f << ((k & 15) * 4);
+  }
+  auto flag_of = [&](int k) -> unsigned { return (unsigned)(flw[k >> 4] >> ((k & 15) * 4)) & 15u; };
+  for (int v = threadIdx.x; v < N; v += CC_T) par[v] = (uint16_t)v;
+  __syncthreads();
+  CC_TICK(1);
+  for (int k = 0; k < PER; ++k) {
+    const int v = threadIdx.x + k * CC_T;
+    const unsigned f = flag_of(k);
+    if (f & 4) { const int row = v / H, col = v - row * H; ccl16_union(par, v, row * H + (col + 1 == H ? 0 : col + 1)); }
+    if (f & 8) ccl16_union(par, v, v + H);
+  }
+  __syncthreads();
+  CC_TICK(2);
+  int rt[PER];
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    const int v = threadIdx.x + k * CC_T;
+    rt[k] = -1;
+    if (flag_of(k) & 2) { int r = par[v], nx; while (r > (nx = par[r])) r = nx; rt[k] = r; }
+  }
+  __syncthreads();
+  CC_TICK(3);
+  const alego_params& P = d.P;
+  // component sizes (:282-301)
+  for (int i = threadIdx.x; i < NWORD; i += CC_T) packed[i] = 0u;
+  __syncthreads();
+  // The 64 cells of a wavefront round are consecutive in a row and mostly belong to one or two components: a run of
+  // lanes with the same root sends one atomic (its length) instead of one per lane — same-address LDS atomics serialise.
+  const int lane_ = lane_id();
+  unsigned long long head_m = 0;   // bit k: this lane starts a run in round k
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    const int v = threadIdx.x + k * CC_T;
+    const int prev_rt = __shfl_up(rt[k], 1, 64);
+    const bool head = rt[k] >= 0 && (lane_ == 0 || prev_rt != rt[k] || (v % H) == 0);   // a new image row starts a run too
+    const unsigned long long starts = __ballot(lane_ == 0 || prev_rt != rt[k] || (v % H) == 0);  // run starts of any kind
+    if (head) {
+      head_m |= 1ull << k;
+      const unsigned long long after = lane_ == 63 ? 0ull : (starts >> (lane_ + 1));
+      const int len = after ? __ffsll((long long)after) : 64 - lane_;
+      atomicAdd(&packed[rt[k] >> 1], (unsigned)len << ((rt[k] & 1) * 16));
+    }
+  }
+  __syncthreads();
+  unsigned long long big_m = 0, mid_m = 0;
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    const int v = threadIdx.x + k * CC_T;
+    if (rt[k] >= 0) {
+      const int sz = (int)((packed[rt[k] >> 1] >> ((rt[k] & 1) * 16)) & 0xFFFFu);
+      if (sz >= P.seg_big_num) big_m |= 1ull << k;
+      else if (sz >= P.seg_valid_point_num) mid_m |= 1ull << k;
+      if (!(fused & 1) && rt[k] == v) d.cc_size[base + v] = sz;
+    }
+  }
+  __syncthreads();
+  CC_TICK(4);
+  // rows touched by every component
+  for (int i = threadIdx.x; i < NWORD; i += CC_T) packed[i] = 0u;
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    const int v = threadIdx.x + k * CC_T;
+    if ((head_m >> k) & 1ull) atomicOr(&packed[rt[k] >> 1], (1u << (v / H)) << ((rt[k] & 1) * 16));   // a run lies in one row
+  }
+  __syncthreads();
+  unsigned long long feas_m = big_m;
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    const int v = threadIdx.x + k * CC_T;
+    if (rt[k] >= 0) {
+      const unsigned rows = (packed[rt[k] >> 1] >> ((rt[k] & 1) * 16)) & 0xFFFFu;
+      if (((mid_m >> k) & 1ull) && __popc(rows) >= P.seg_valid_line_num) feas_m |= 1ull << k;
+      if (!(fused & 1) && rt[k] == v) d.cc_rows[base + v] = (unsigned long long)rows;
+    }
+    if ((fused & 2) && v < N) d.parent[base + v] = rt[k];   // only ip_classify / ip_labels / debug read it
+  }
+  CC_TICK(5);
+  if (!(fused & 1)) return;  // ip_rowcount / ip_compact follow (launch_ip)
+  // ---- fused a6: ordered compaction of the whole image (replaces ip_rowcount + ip_compact for this geometry).
+  // Chunk k = cells [1024 k, 1024 k + 1024) in row-major order, one cell per thread: per-(chunk, wavefront) counts of
+  // kept cells / outliers / feasible roots, one exclusive scan over the (chunk, wavefront) table, then every cell
+  // knows its output line.  Classification as ip_classify, with the component statistics still in LDS.
+  constexpr int NW = CC_T / 64;
+  __shared__ int s_cnt[3][PER * NW];
+  __shared__ int s_wtot[3][NW];
+  const int lane = lane_id(), wave = threadIdx.x >> 6;
+  unsigned long long keep_m = 0, outl_m = 0, root_m = 0;
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    const int v = threadIdx.x + k * CC_T;
+    int c = 0;
+    bool fr = false;
+    if (v < N) {
+      const unsigned f = flag_of(k);
+      const int row = v / H, col = v - row * H;
+      if (f & 1) c = (col % 5 == 0 || col <= 4 || col >= H - 5) ? 1 : 0;
+      else if (f & 2) {
+        const bool feas = (feas_m >> k) & 1ull;
+        fr = feas && rt[k] == v;
+        c = feas ? 1 : ((row > P.ground_scan_id && col % 5 == 0) ? 2 : 0);
+      }
+    }
+    if (c == 1) keep_m |= 1ull << k;
+    if (c == 2) outl_m |= 1ull << k;
+    if (fr) root_m |= 1ull << k;
+    const unsigned long long bk = __ballot(c == 1), bo = __ballot(c == 2), bf = __ballot(fr);
+    if (lane == 0) { s_cnt[0][k * NW + wave] = (int)__popcll(bk); s_cnt[1][k * NW + wave] = (int)__popcll(bo); s_cnt[2][k * NW + wave] = (int)__popcll(bf); }
+  }
+  __syncthreads();
+  CC_TICK(6);
+  {  // exclusive scan of the three count tables (PER * NW <= 1024 entries: one per thread)
+    const int e = threadIdx.x;
+    int v3[3], in3[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      v3[a] = e < PER * NW ? s_cnt[a][e] : 0;
+      int incl = v3[a];
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+      in3[a] = incl;
+      if (lane == 63) s_wtot[a][wave] = incl;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      int woff = 0;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) if (w < wave) woff += s_wtot[a][w];
+      if (e < PER * NW) s_cnt[a][e] = woff + in3[a] - v3[a];
+    }
+    if (threadIdx.x == 0) {
+      int t3[3] = {0, 0, 0};
+#pragma unroll
+      for (int a = 0; a < 3; ++a) for (int w = 0; w < NW; ++w) t3[a] += s_wtot[a][w];
+      int* sc = d.scal + slot * SC_COUNT;
+      sc[SC_M] = t3[0]; sc[SC_NOUT] = t3[1]; sc[SC_NFEAS] = t3[2];
+      d.ring_end[slot * d.NS + d.NS - 1] = t3[0] - 1 - 5;   // :190 for the last row
+    }
+  }
+  __syncthreads();
+  CC_TICK(7);
+  const float4* pts = d.in_pts + ((size_t)slot * d.ring_len + ring_pos) * d.Pcap;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  // batches of CB cells: owner indices, then the point gathers and ranges, then the stores — the loads of a batch are
+  // independent of each other, so each batch costs two memory latencies instead of two per cell
+  constexpr int CB = 9;
+  static_assert(PER % CB == 0, "cells per thread must be a multiple of the batch");
+  for (int k0 = 0; k0 < PER; k0 += CB) {
+    int own[CB];
+#pragma unroll
+    for (int b = 0; b < CB; ++b) {
+      const int k = k0 + b, v = threadIdx.x + k * CC_T;
+      const bool any = ((keep_m | outl_m) >> k) & 1ull;
+      own[b] = any ? d.owner[base + v] : 0;
+    }
+    float4 pt[CB];
+    float rg[CB];
+#pragma unroll
+    for (int b = 0; b < CB; ++b) {
+      const int k = k0 + b, v = threadIdx.x + k * CC_T;
+      const bool any = ((keep_m | outl_m) >> k) & 1ull;
+      pt[b] = any ? pts[own[b]] : make_float4(0.f, 0.f, 0.f, 0.f);
+      rg[b] = ((keep_m >> k) & 1ull) ? d.range_img[base + v] : 0.f;
+    }
+#pragma unroll
+    for (int b = 0; b < CB; ++b) {
+      const int k = k0 + b, v = threadIdx.x + k * CC_T;
+      const bool kp = (keep_m >> k) & 1ull, ol = (outl_m >> k) & 1ull, fr = (root_m >> k) & 1ull;
+      const unsigned long long bk = __ballot(kp), bo = __ballot(ol), bf = __ballot(fr);
+      if (v >= N) continue;
+      const int row = v / H, col = v - row * H;
+      const int line = s_cnt[0][k * NW + wave] + (int)__popcll(bk & below);   // kept cells before this one
+      if (col == 0) {   // ring convention of :161,:190
+        d.ring_start[slot * d.NS + row] = line + 5;
+        if (row > 0) d.ring_end[slot * d.NS + row - 1] = line - 1 - 5;
+      }
+      if (kp || ol) {
+        float4 p = pt[b];
+        p.w = (float)(row + col / 10000.0);  // :101
+        if (kp) {
+          d.seg_pts[base + line] = p;
+          d.seg_ground[base + line] = (uint8_t)(flag_of(k) & 1);
+          d.seg_col[base + line] = col;
+          d.seg_range[base + line] = rg[b];
+        } else {
+          d.outlier[base + s_cnt[1][k * NW + wave] + (int)__popcll(bo & below)] = p;
+        }
+      }
+      // label_cnt_ numbering (:303-306); 0 for the root of an infeasible component (ip_labels turns it into 999999)
+      if (rt[k] == v) d.cc_label[base + v] = fr ? s_cnt[2][k * NW + wave] + (int)__popcll(bf & below) + 1 : 0;
+    }
+  }
+  __syncthreads();
+  CC_TICK(8);
+}
+
+
 __global__ void __launch_bounds__(IP_BLOCK) cc_stats(DevCtx d) {
   const int slot = blockIdx.y + d.slot0;
   const int v = blockIdx.x * IP_BLOCK + threadIdx.x;
@@ -629,8 +895,13 @@ void launch_ip(const DevCtx& d, int ring_pos, bool want_labels, hipStream_t st) 
   ALEGO_LAUNCH(ip_image, dim3((d.H + 127) / 128, d.n_launch), dim3(128), 0, st, d, ring_pos);
   const bool lds_cc = d.N <= CC_LDS_MAXN, lds_stats = lds_cc && d.NS <= 16;
   ALEGO_LAUNCH(cc_edges, gN, dim3(IP_BLOCK), 0, st, d, (lds_cc ? 0 : 1) | (lds_stats ? 0 : 2) | (fused ? 0 : 4));
-  if (d.N <= CC_LDS_MAXN) {
-    ALEGO_LAUNCH(cc_lds, dim3(d.n_launch), dim3(CC_LDS_THREADS), (size_t)4 * d.N, st, d, ring_pos, fused ? 1 : 0);
+  if (lds_stats) {
+    // bit 0: fused compaction; bit 1: write the root image to HBM (only ip_classify, ip_labels and alego_debug_get read it:
+    // the single-scan entry points keep it, the batch path does not)
+    const int cc_flags = (fused ? 1 : 0) | ((!fused || want_labels || d.n_launch == 1) ? 2 : 0);
+    ALEGO_LAUNCH(cc_lds16, dim3(d.n_launch), dim3(CC_LDS_THREADS), (size_t)4 * ((d.N + 1) / 2), st, d, ring_pos, cc_flags);
+  } else if (lds_cc) {
+    ALEGO_LAUNCH(cc_lds, dim3(d.n_launch), dim3(CC_LDS_THREADS), (size_t)4 * d.N, st, d, ring_pos, 0);
   } else {
     ALEGO_LAUNCH(cc_runs, dim3((d.H + 127) / 128, d.n_launch), dim3(128), 0, st, d);
     ALEGO_LAUNCH(cc_link, gN, dim3(IP_BLOCK), 0, st, d);
@@ -651,6 +922,7 @@ void launch_atan2f_probe(const float* y, const float* x, float* out, int n, int 
 int ip_configure(const DevCtx& d) {
   if (d.N <= CC_LDS_MAXN) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(cc_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * d.N) != hipSuccess) return -1;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(cc_lds16), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * ((d.N + 1) / 2)) != hipSuccess) return -1;
   }
   return 0;
 }
