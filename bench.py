@@ -169,8 +169,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--streams", type=int, default=1024, help="independent streams resident per GPU (≈123 MB of HBM each at 16x1800)")
-    ap.add_argument("--ring", type=int, default=48, help="scans kept in HBM per stream (replayed back and forth)")
+    ap.add_argument("--streams", type=int, default=1536, help="independent streams resident per GPU (≈115 MB of HBM each at 16x1800 with a 24-scan ring)")
+    ap.add_argument("--ring", type=int, default=24, help="scans kept in HBM per stream (replayed back and forth)")
     ap.add_argument("--prime", type=int, default=560, help="untimed scans per stream to fill the 50-key-frame local map")
     ap.add_argument("--geometry", default="16x1800", help="n_scan x horizon_scan: 16x1800 (BASELINE metric), 16x4000, 64x2048")
     ap.add_argument("--keyframes", type=int, default=0, help="local-map window (0 = reference default 50; config 5 uses 200)")
