@@ -4,7 +4,8 @@
 #   r01_bench_under_rocprof.json   the same command under rocprofv3 --kernel-trace --stats (without the CPU legs)
 #   r01_bench_kernel_stats.csv     rocprofv3's per-kernel summary of that run (all dispatches, priming included)
 #   r01_bench_kernel_stats_steady.csv  the same trace restricted to the dispatches of bench.py's HIP-event pass, side by side
-#   r01_pmc_traffic.json           HBM bytes per launch from two separate --pmc passes (FETCH_SIZE, WRITE_SIZE)
+#   r01_pmc_traffic.json           HBM bytes per launch from two separate --pmc passes (FETCH_SIZE, WRITE_SIZE), taken after 700
+#                                  priming scans: around scan 560 every stream fills its 50-key-frame window and rebuilds its map at once
 set -u
 cd /tmp && export TMPDIR=/tmp
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
@@ -21,7 +22,7 @@ print(d["roofline"]["streams_per_launch"])
 PY
 )
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 900 rocprofv3 --pmc $c --kernel-trace -d /tmp/pmc_$c -o p --output-format csv -- python bench.py --steps 8 --warmup 0 --prime 560 --no-cpu --no-profile > /tmp/pmc_$c.log 2>&1
+  timeout 900 rocprofv3 --pmc $c --kernel-trace -d /tmp/pmc_$c -o p --output-format csv -- python bench.py --steps 8 --warmup 0 --prime 700 --no-cpu --no-profile > /tmp/pmc_$c.log 2>&1
 done
 python tools/pmc_traffic.py /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE "$PER" 16 > gpurun_out/r01_pmc_traffic.json
 ls -la gpurun_out/r01_*
