@@ -218,8 +218,9 @@ __global__ void __launch_bounds__(64) fe_pick(DevCtx d) {
 // Consecutive points of a ring mostly fall into the same 0.4 m voxel, so the (voxel id, position) sort is done on
 // RUNS of equal consecutive voxel ids (a few hundred per ring instead of ~1000 points): rank-by-counting of the
 // runs in LDS, then the first run of every voxel accumulates all runs of that voxel in order — the same f32
-// summation order as a stable sort of the points.  Dynamic LDS: 14 B per ring point.
-#define FV_NB 1024
+// summation order as a stable sort of the points.  Dynamic LDS: 10 B per ring point (+ 4 KB of bucket counters): the
+// number of these workgroups that fit a CU decides the kernel's duration.
+#define FV_NB 512
 __global__ void __launch_bounds__(FE_BLOCK) fe_voxel(DevCtx d) {
   const int slot = blockIdx.y + d.slot0, ring = blockIdx.x, tid = threadIdx.x;
   const size_t base = (size_t)slot * d.N;
@@ -230,10 +231,10 @@ __global__ void __launch_bounds__(FE_BLOCK) fe_voxel(DevCtx d) {
   const float4* seg = d.seg_pts + base;
   extern __shared__ __attribute__((aligned(16))) unsigned char fv_smem[];
   uint32_t* s_key = reinterpret_cast<uint32_t*>(fv_smem);                       // voxel id per point      [H]
-  uint32_t* s_rvid = reinterpret_cast<uint32_t*>(fv_smem + 4 * (size_t)d.H);    // voxel id per run        [H]
-  uint16_t* s_rstart = reinterpret_cast<uint16_t*>(fv_smem + 8 * (size_t)d.H);  // first point of the run  [H]
-  uint16_t* s_rlen = reinterpret_cast<uint16_t*>(fv_smem + 10 * (size_t)d.H);   // points in the run       [H]
-  uint16_t* s_order = reinterpret_cast<uint16_t*>(fv_smem + 12 * (size_t)d.H);  // runs sorted by (voxel id, run) [H]
+  uint32_t* s_rvid = s_key;                                                     // voxel id per run, compacted in place (run r <= its first point)
+  uint16_t* s_rstart = reinterpret_cast<uint16_t*>(fv_smem + 4 * (size_t)d.H);  // first point of the run  [H]
+  uint16_t* s_order = reinterpret_cast<uint16_t*>(fv_smem + 6 * (size_t)d.H);   // runs sorted by (voxel id, run) [H]
+  uint16_t* s_tmp = reinterpret_cast<uint16_t*>(fv_smem + 8 * (size_t)d.H);     // runs dealt into buckets [H]
   __shared__ float s_red[6][FE_BLOCK / 64];
   __shared__ int s_scan[FE_BLOCK / 64];
   __shared__ int s_boff[FV_NB + 1], s_bcur[FV_NB + 1];
@@ -284,7 +285,8 @@ __global__ void __launch_bounds__(FE_BLOCK) fe_voxel(DevCtx d) {
   int nruns = 0;
   for (int c0 = 0; c0 < n; c0 += FE_BLOCK) {
     const int i = c0 + tid;
-    const bool head = i < n && (i == 0 || s_key[i] != s_key[i - 1]);
+    const uint32_t mykey = i < n ? s_key[i] : 0u;   // read before the barrier: the run ids are compacted into the same array
+    const bool head = i < n && (i == 0 || mykey != s_key[i - 1]);
     const unsigned long long m = __ballot(head);
     if ((tid & 63) == 0) s_scan[tid >> 6] = (int)__popcll(m);
     __syncthreads();
@@ -293,13 +295,12 @@ __global__ void __launch_bounds__(FE_BLOCK) fe_voxel(DevCtx d) {
     for (int w = 0; w < FE_BLOCK / 64; ++w) { if (w < (tid >> 6)) woff += s_scan[w]; tot += s_scan[w]; }
     if (head) {
       const int r = nruns + woff + (int)__popcll(m & ((1ull << (tid & 63)) - 1ull));
-      s_rvid[r] = s_key[i];
+      s_rvid[r] = mykey;
       s_rstart[r] = (uint16_t)i;
     }
     nruns += tot;
     __syncthreads();
   }
-  for (int r = tid; r < nruns; r += FE_BLOCK) s_rlen[r] = (uint16_t)((r + 1 < nruns ? (int)s_rstart[r + 1] : n) - (int)s_rstart[r]);
   // Order the runs by (voxel id, run index).  Voxel ids are bounded by the grid size T, so the runs are first dealt
   // into <= FV_NB buckets that are monotone in the voxel id (LDS atomics; arbitrary order inside a bucket), then
   // every run ranks itself among the one or two runs of its bucket — instead of against all runs of the ring.
@@ -309,7 +310,6 @@ __global__ void __launch_bounds__(FE_BLOCK) fe_voxel(DevCtx d) {
     int shift = 0;
     while (((T - 1) >> shift) >= (unsigned)FV_NB) ++shift;
     const int nb = (int)((T - 1) >> shift) + 1;
-    uint16_t* s_tmp = reinterpret_cast<uint16_t*>(s_key);  // the per-point voxel ids are dead once the runs exist
     for (int b = tid; b <= nb; b += FE_BLOCK) s_boff[b] = 0;
     __syncthreads();
     for (int r = tid; r < nruns; r += FE_BLOCK) atomicAdd(&s_boff[min((int)(s_rvid[r] >> shift), nb - 1) + 1], 1);
@@ -366,7 +366,7 @@ __global__ void __launch_bounds__(FE_BLOCK) fe_voxel(DevCtx d) {
       float sx = 0.f, sy = 0.f, sz = 0.f, si = 0.f;
       int c = 0;
       for (int jj = j; jj < nruns && s_rvid[s_order[jj]] == vid; ++jj) {
-        const int r = s_order[jj], i0 = s_rstart[r], len = s_rlen[r];
+        const int r = s_order[jj], i0 = s_rstart[r], len = (r + 1 < nruns ? (int)s_rstart[r + 1] : n) - i0;
         for (int i = i0; i < i0 + len; ++i) {
           const float4 p = seg[lfs[i]];
           sx += p.x; sy += p.y; sz += p.z; si += p.w;
@@ -468,7 +468,7 @@ void launch_fe(const DevCtx& d, hipStream_t st) {
   static const int extra = getenv("ALEGO_DBG_EXTRA_LDS") ? atoi(getenv("ALEGO_DBG_EXTRA_LDS")) : 0;
   if (sector_max <= 64 * 6) { ALEGO_LAUNCH(fe_pick<6>, dim3(d.NS, d.n_launch), dim3(64), (size_t)4 * d.H + extra, st, d); }
   else { ALEGO_LAUNCH(fe_pick<12>, dim3(d.NS, d.n_launch), dim3(64), (size_t)4 * d.H, st, d); }
-  ALEGO_LAUNCH(fe_voxel, dim3(d.NS, d.n_launch), dim3(FE_BLOCK), (size_t)14 * d.H, st, d);
+  ALEGO_LAUNCH(fe_voxel, dim3(d.NS, d.n_launch), dim3(FE_BLOCK), (size_t)10 * d.H, st, d);
   ALEGO_LAUNCH(fe_gather, dim3(d.NS, d.n_launch), dim3(FE_BLOCK), 0, st, d);
   ALEGO_LAUNCH(fe_boxes, dim3(24, 2, d.n_launch), dim3(FE_BLOCK), 0, st, d);  // 24 x 8 boxes = 6144 targets per sweep
 }
