@@ -150,7 +150,7 @@ __global__ void __launch_bounds__(64) fe_pick(DevCtx d) {
       const int first = c - nbk, last = c + nf;
       if (lane <= last - first) s_flag[first + lane] |= 1;
       // the (single) owned element inside [first, last]
-      const int off = ((lane - (first - lsp)) % 64 + 64) % 64;
+      const int off = (lane - (first - lsp)) & 63;
       const int ct = first + off;
       if (ct <= last && ct >= lsp && ct <= lep) { const uint32_t bit = 1u << ((ct - lsp - lane) / 64); sharp_m &= ~bit; flat_m &= ~bit; }
     };
@@ -163,8 +163,17 @@ __global__ void __launch_bounds__(64) fe_pick(DevCtx d) {
       for (int t = 0; t < FE_T; ++t) if (((sharp_m >> t) & 1) && key[t] >= bk) { bk = key[t]; bt = t; }
       const uint32_t kmax = wave_max_u32(bk);
       if (kmax == 0) break;
-      const uint32_t cand = (sharp_m && bk == kmax) ? (uint32_t)(lsp + lane + 64 * bt) : 0u;
-      const int c = (int)wave_max_u32(cand);
+      // almost always exactly one lane holds the maximum: its index comes through v_readlane; equal keys in several
+      // lanes (ties -> larger index) take the second reduction
+      const unsigned long long tie = __ballot(sharp_m && bk == kmax);
+      int c;
+      if ((tie & (tie - 1)) == 0) {
+        const int wl = __ffsll((long long)tie) - 1;
+        c = lsp + wl + 64 * __builtin_amdgcn_readlane(bt, wl);
+      } else {
+        const uint32_t cand = (sharp_m && bk == kmax) ? (uint32_t)(lsp + lane + 64 * bt) : 0u;
+        c = (int)wave_max_u32(cand);
+      }
       ++picked_num;
       int lab = 0;
       if (picked_num <= P.n_sharp) lab = 2; else if (picked_num <= P.n_less_sharp) lab = 1;
@@ -187,8 +196,15 @@ __global__ void __launch_bounds__(64) fe_pick(DevCtx d) {
       for (int t = 0; t < FE_T; ++t) if (((flat_m >> t) & 1) && key[t] < bk) { bk = key[t]; bt = t; }
       const uint32_t kmin = wave_min_u32(bk);
       if (kmin == 0xFFFFFFFFu) break;
-      const uint32_t cand = (flat_m && bk == kmin) ? (uint32_t)(lsp + lane + 64 * bt) : 0xFFFFFFFFu;
-      const int c = (int)wave_min_u32(cand);
+      const unsigned long long tie = __ballot(flat_m && bk == kmin);
+      int c;
+      if ((tie & (tie - 1)) == 0) {
+        const int wl = __ffsll((long long)tie) - 1;
+        c = lsp + wl + 64 * __builtin_amdgcn_readlane(bt, wl);
+      } else {
+        const uint32_t cand = (flat_m && bk == kmin) ? (uint32_t)(lsp + lane + 64 * bt) : 0xFFFFFFFFu;
+        c = (int)wave_min_u32(cand);
+      }
       ++picked_num;
       if (lane == 0) { s_label[c] = -1; st_flat[n_flat] = c + rf; }
       ++n_flat;
