@@ -62,12 +62,9 @@ __device__ long long vg_times[16];
 #else
 #define VG_TICK(k)
 #endif
-__global__ void __launch_bounds__(VG_T) vox_big(VoxCtx V) {
-  const int job = blockIdx.x;
+__device__ void vox_big_job(const VoxCtx& V, int job) {
   const VoxJob J = V.jobs[job];
-  if (!vx_enabled(J)) return;
   const int n = min(*J.n_in, J.cap);
-  if (n <= VX_SMALL_MAX) return;  // vox_small
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   __shared__ int s_cnt[2][VG_W][VG_ND];
   __shared__ int s_tot[VG_ND];
@@ -275,6 +272,14 @@ __global__ void __launch_bounds__(VG_T) vox_big(VoxCtx V) {
   __syncthreads();
   VG_TICK(13);
 }
+// persistent workgroups over the list of enabled jobs with more than VX_SMALL_MAX points (vox_plan)
+__global__ void __launch_bounds__(VG_T) vox_big(VoxCtx V) {
+  const int cnt = V.cnt[1];
+  for (int j = blockIdx.x; j < cnt; j += gridDim.x) {
+    vox_big_job(V, V.list_big[j]);
+    __syncthreads();   // LDS of the job just finished is reused by the next one
+  }
+}
 #ifdef ALEGO_TIMING
 extern "C" void alego_vg_times(long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(vg_times), sizeof(long long) * 16); }
 #endif
@@ -287,12 +292,9 @@ extern "C" void alego_vg_times(long long* out) { (void)hipMemcpyFromSymbol(out, 
 #define VX_SB 512
 __device__ __forceinline__ bool vx_less(const unsigned* key, unsigned a, unsigned b) { return key[a] < key[b] || (key[a] == key[b] && a < b); }
 
-__global__ void __launch_bounds__(VX_SB) vox_small(VoxCtx V) {
-  const int job = blockIdx.x;
+__device__ void vox_small_job(const VoxCtx& V, int job) {
   const VoxJob J = V.jobs[job];
-  if (!vx_enabled(J)) return;
   const int n = min(*J.n_in, J.cap);
-  if (n > VX_SMALL_MAX) return;  // vox_big
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   extern __shared__ __attribute__((aligned(16))) unsigned char vs_smem[];
   unsigned* s_key = reinterpret_cast<unsigned*>(vs_smem);                                             // [VX_SMALL_MAX]
@@ -477,6 +479,33 @@ __global__ void __launch_bounds__(VX_SB) vox_small(VoxCtx V) {
   }
   if (tid == 0) *J.n_out = nvox;
 }
+__global__ void __launch_bounds__(VX_SB) vox_small(VoxCtx V) {
+  const int cnt = V.cnt[0];
+  for (int j = blockIdx.x; j < cnt; j += gridDim.x) {
+    vox_small_job(V, V.list_small[j]);
+    __syncthreads();
+  }
+}
+
+// One workgroup sorts the jobs of a round into the two work lists.  Disabled jobs keep their previous output, empty
+// clouds are finished right here.  The lists let vox_small / vox_big run as a few persistent workgroups where little
+// work is expected (a context's launch sizes are fixed by the host), instead of one 72 KB-LDS workgroup per job that
+// only finds out on the CU that it has nothing to do.
+__global__ void __launch_bounds__(256) vox_plan(VoxCtx V) {
+  __shared__ int s_n[2];
+  if (threadIdx.x < 2) s_n[threadIdx.x] = 0;
+  __syncthreads();
+  for (int j = threadIdx.x; j < V.njobs; j += 256) {
+    const VoxJob J = V.jobs[j];
+    if (!vx_enabled(J)) continue;
+    const int n = min(*J.n_in, J.cap);
+    if (n == 0) { *J.n_out = 0; continue; }
+    if (n <= VX_SMALL_MAX) V.list_small[atomicAdd(&s_n[0], 1)] = j;
+    else V.list_big[atomicAdd(&s_n[1], 1)] = j;
+  }
+  __syncthreads();
+  if (threadIdx.x < 2) V.cnt[threadIdx.x] = s_n[threadIdx.x];
+}
 
 // ---- host ------------------------------------------------------------------------
 #define VX_SMALL_LDS (6 * VX_SMALL_MAX + 6 * VX_SMALL_NB)
@@ -496,13 +525,15 @@ int vox_create(VoxCtx* V, const VoxJob* jobs, int njobs, std::string* err) {
   A((void**)&V->jobs, sizeof(VoxJob) * njobs);
   A((void**)&V->bbox, (size_t)njobs * 8 * 4);
   A((void**)&V->keys, total * 4); A((void**)&V->pairs_a, total * 8); A((void**)&V->pairs_b, total * 8);
+  A((void**)&V->list_small, (size_t)njobs * 4); A((void**)&V->list_big, (size_t)njobs * 4); A((void**)&V->cnt, 8);
+  V->grid_small = V->grid_big = njobs;
   if (e == hipSuccess) e = hipMemcpy(V->jobs, h.data(), sizeof(VoxJob) * njobs, hipMemcpyHostToDevice);
   if (e != hipSuccess) { *err = std::string("vox_create: ") + hipGetErrorString(e); return -2; }
   return 0;
 }
 
 void vox_destroy(VoxCtx* V) {
-  void* ps[] = {V->jobs, V->bbox, V->keys, V->pairs_a, V->pairs_b};
+  void* ps[] = {V->jobs, V->bbox, V->keys, V->pairs_a, V->pairs_b, V->list_small, V->list_big, V->cnt};
   for (void* p : ps) if (p) (void)hipFree(p);
   std::memset(V, 0, sizeof(*V));
 }
@@ -510,7 +541,8 @@ void vox_destroy(VoxCtx* V) {
 int vox_run(const VoxCtx& V, hipStream_t st, std::string* err) {
   (void)err;
   if (V.njobs == 0) return 0;
-  ALEGO_LAUNCH(vox_small, dim3(V.njobs), dim3(VX_SB), (size_t)VX_SMALL_LDS, st, V);
-  ALEGO_LAUNCH(vox_big, dim3(V.njobs), dim3(VG_T), 0, st, V);
+  ALEGO_LAUNCH(vox_plan, dim3(1), dim3(256), 0, st, V);
+  ALEGO_LAUNCH(vox_small, dim3(V.grid_small), dim3(VX_SB), (size_t)VX_SMALL_LDS, st, V);
+  ALEGO_LAUNCH(vox_big, dim3(V.grid_big), dim3(VG_T), 0, st, V);
   return 0;
 }

@@ -94,6 +94,11 @@ LmHost* lm_host_create(const alego_params& P, const DevCtx& d, int n_slots, int 
     j2.push_back(VoxJob{L.cur_total + b * L.total_cap, li + LI_NTOTAL, L.cur_total_ds + b * L.total_cap, li + LI_NTOTAL_DS, li + LI_RUN, P.lm_leaf_surf, L.total_cap, 0});
   }
   if (vox_create(&lm->vm[g], jm.data(), (int)jm.size(), err) || vox_create(&lm->v1[g], j1.data(), (int)j1.size(), err) || vox_create(&lm->v2[g], j2.data(), (int)j2.size(), err)) { lm_host_destroy(lm); return nullptr; }
+  // Expected work per context: the maps are rebuilt for ~1 stream in 8 per mapping frame and are only small while a stream
+  // is young; the current-scan clouds practically never exceed 8192 points.  Fewer persistent workgroups there (they loop).
+  const int ns = (int)jm.size() / 2;
+  lm->vm[g].grid_small = std::max(2, ns / 4); lm->vm[g].grid_big = std::max(2, ns / 2);
+  lm->v1[g].grid_big = std::max(1, ns / 16); lm->v2[g].grid_big = std::max(1, ns / 16);
   }
   return lm;
 }

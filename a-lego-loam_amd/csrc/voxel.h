@@ -1,7 +1,7 @@
 // voxel.h — batched pcl::VoxelGrid<PointXYZI> on the device.
 //
 // A "job" is one VoxelGrid::filter call (one cloud, one leaf size); a round processes all jobs of a
-// context with two launches, one workgroup per job (kernels_voxel.hip): vox_small for clouds of up to
+// context with three launches (work lists, then one workgroup per job; kernels_voxel.hip): vox_small for clouds of up to
 // 8192 points (LDS resident), vox_big for the local maps (stable LSD radix sort of (voxel id, position)).
 // Output: one point per voxel in ascending voxel id, f32 sums accumulated in original order, divided by the count.
 #ifndef ALEGO_VOXEL_H_
@@ -27,6 +27,8 @@ struct VoxCtx {
   unsigned* bbox;       // [job][8] ordered-int encoded min xyz (0..2) and ~max xyz (4..6) of the input cloud
   unsigned* keys;       // voxel id per input point; later the list of voxel run starts
   unsigned long long *pairs_a, *pairs_b;  // (voxel id << 32 | position) ping-pong buffers of the radix passes
+  int *list_small, *list_big, *cnt;       // work lists of a round (vox_plan): enabled jobs of <= 8192 / more points; cnt[2]
+  int grid_small, grid_big;               // workgroups launched for each list (default njobs; persistent loop over the list)
   unsigned total;       // total scratch elements
 };
 
