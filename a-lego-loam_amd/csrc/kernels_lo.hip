@@ -8,6 +8,7 @@
 //              corrector, Jacobi scaling) on-chip: residual/Jacobian evaluation in fp64, wavefront
 //              shuffle + LDS reduction of the 21+6+1 normal-equation scalars in a fixed order, 6x6
 //              Cholesky by one lane, step acceptance, and (second call) the pose integration
+#include <algorithm>
 #include "dev_cost.h"
 #include "prof.h"
 
@@ -118,9 +119,11 @@ __global__ void __launch_bounds__(LO_BLOCK) lo_assoc(DevCtx d, int kind) {
 #pragma unroll
     for (int k = 0; k < 3; ++k) s_pose[9 + k] = st[LS_PARAMS + k];
   }
+  // the launch covers the typical query count in one sweep; larger feature sets take further sweeps
+  for (int qb = blockIdx.x; qb * LO_QPB < nq; qb += gridDim.x) {
   __syncthreads();
   if (threadIdx.x < LO_QPB) {  // transformToStart once per query, shared through LDS
-    const int q = min((int)(blockIdx.x * LO_QPB + threadIdx.x), nq - 1);
+    const int q = min((int)(qb * LO_QPB + threadIdx.x), nq - 1);
     float o[3];
     transform_to_start(s_pose, s_pose + 9, d.feat[qk][((size_t)slot * 2 + cur) * d.fcap[qk] + q], o);
     s_sel[threadIdx.x][0] = o[0]; s_sel[threadIdx.x][1] = o[1]; s_sel[threadIdx.x][2] = o[2];
@@ -129,7 +132,7 @@ __global__ void __launch_bounds__(LO_BLOCK) lo_assoc(DevCtx d, int kind) {
   const double nfd = d.P.nearest_feature_dist;
   const float INF = __int_as_float(0x7f800000);
   // rows beyond the last query redo the last one (the rows of a wavefront run in lock-step) and do not store
-  const int qi = threadIdx.x >> 4, q = blockIdx.x * LO_QPB + qi;
+  const int qi = threadIdx.x >> 4, q = qb * LO_QPB + qi;
   const bool store = q < nq;
   const float sx = s_sel[qi][0], sy = s_sel[qi][1], sz = s_sel[qi][2];
   int closest = -1, idx2 = -1, idx3 = -1;
@@ -268,6 +271,7 @@ __global__ void __launch_bounds__(LO_BLOCK) lo_assoc(DevCtx d, int kind) {
     int* row = d.lo_corr + ((size_t)slot * (d.lo_qcap_surf + d.lo_qcap_corner) + (kind == 0 ? 0 : d.lo_qcap_surf) + q) * 4;
     const bool ok = kind == 0 ? (idx2 >= 0 && idx3 >= 0) : (idx2 >= 0);
     row[0] = q; row[1] = ok ? closest : -1; row[2] = idx2; row[3] = idx3;
+  }
   }
 }
 
@@ -410,8 +414,8 @@ int lo_configure() {
 }
 
 void launch_lo(const DevCtx& d, hipStream_t st) {
-  ALEGO_LAUNCH(lo_assoc, dim3((d.lo_qcap_surf + LO_QPB - 1) / LO_QPB, d.n_launch), dim3(LO_BLOCK), 0, st, d, 0);
+  ALEGO_LAUNCH(lo_assoc, dim3(std::min((d.lo_qcap_surf + LO_QPB - 1) / LO_QPB, 8), d.n_launch), dim3(LO_BLOCK), 0, st, d, 0);
   ALEGO_LAUNCH(lo_solve, dim3(d.n_launch), dim3(LO_BLOCK), LO_SOLVE_LDS, st, d, 0);
-  ALEGO_LAUNCH(lo_assoc, dim3((d.lo_qcap_corner + LO_QPB - 1) / LO_QPB, d.n_launch), dim3(LO_BLOCK), 0, st, d, 1);
+  ALEGO_LAUNCH(lo_assoc, dim3(std::min((d.lo_qcap_corner + LO_QPB - 1) / LO_QPB, 12), d.n_launch), dim3(LO_BLOCK), 0, st, d, 1);
   ALEGO_LAUNCH(lo_solve, dim3(d.n_launch), dim3(LO_BLOCK), LO_SOLVE_LDS, st, d, 1);
 }
