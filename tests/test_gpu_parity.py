@@ -327,7 +327,7 @@ def test_batch_full_loop_equals_single_stream(params_a, nslot, groups, monkeypat
     """Slots advanced through IP -> LO -> LM (batch path) give bit-identical poses to one-slot handles, also when the
     slots are split over several HIP streams (groups of 2+2+1 slots running concurrently)."""
     p = params_a
-    nscan = 30
+    nscan = 30 if groups == 1 else 80   # 80 scans: the maps outgrow 8192 points, several of them per persistent vox_big workgroup
     monkeypatch.setenv("ALEGO_STREAM_GROUPS", str(groups))
     hb = binding.Handle(p, n_slots=nslot, ring_len=nscan)
     monkeypatch.delenv("ALEGO_STREAM_GROUPS")
