@@ -28,7 +28,6 @@ __device__ __forceinline__ unsigned vx_enc(float f) {
 }
 __device__ __forceinline__ bool vx_enabled(const VoxJob& J) { return J.enable == nullptr || *J.enable != 0; }
 
-#define VX_TINY 8              // vox_small: buckets up to this size are handled by a single thread
 #define VX_SMALL_MAX 8192      // jobs up to this many points are done by vox_small
 
 // ---------------------------------------------------------------------------------------------------------
@@ -288,8 +287,10 @@ extern "C" void alego_vg_times(long long* out) { (void)hipMemcpyFromSymbol(out, 
 // Small jobs (n <= VX_SMALL_MAX points: the VoxelGrid calls on the current scan, laserMapping.cpp:329-342) run the
 // whole filter with every intermediate in LDS: bounding box, voxel ids, bucket histogram (LDS atomics), scan,
 // scatter, per-bucket rank sort, voxel ranks, centroids.  LDS: 4 B key + 2 B index per point, 6 B per bucket.
-#define VX_SMALL_NB 4096
 #define VX_SB 512
+#define VS_W (VX_SB / 64)
+#define VS_DMAX 9          // radix digit width: 8 x 512 16-bit counters = 8 KB of LDS
+#define VS_ND (1 << VS_DMAX)
 __device__ __forceinline__ bool vx_less(const unsigned* key, unsigned a, unsigned b) { return key[a] < key[b] || (key[a] == key[b] && a < b); }
 
 __device__ void vox_small_job(const VoxCtx& V, int job) {
@@ -297,15 +298,16 @@ __device__ void vox_small_job(const VoxCtx& V, int job) {
   const int n = min(*J.n_in, J.cap);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   extern __shared__ __attribute__((aligned(16))) unsigned char vs_smem[];
-  unsigned* s_key = reinterpret_cast<unsigned*>(vs_smem);                                             // [VX_SMALL_MAX]
-  int* s_cnt = reinterpret_cast<int*>(vs_smem + 4 * VX_SMALL_MAX);                                    // [VX_SMALL_NB] histogram -> starts -> ends
-  unsigned short* s_idx = reinterpret_cast<unsigned short*>(vs_smem + 4 * VX_SMALL_MAX + 4 * VX_SMALL_NB);          // [VX_SMALL_MAX]
-  unsigned short* s_vox = reinterpret_cast<unsigned short*>(vs_smem + 6 * VX_SMALL_MAX + 4 * VX_SMALL_NB);          // [VX_SMALL_NB]
+  unsigned* s_key = reinterpret_cast<unsigned*>(vs_smem);                                              // voxel id per point [VX_SMALL_MAX]
+  unsigned short* s_ia = reinterpret_cast<unsigned short*>(vs_smem + 4 * VX_SMALL_MAX);                // point order, ping  [VX_SMALL_MAX]
+  unsigned short* s_ib = reinterpret_cast<unsigned short*>(vs_smem + 6 * VX_SMALL_MAX);                // point order, pong  [VX_SMALL_MAX]
+  unsigned short* s_cnt = reinterpret_cast<unsigned short*>(vs_smem + 8 * VX_SMALL_MAX);               // [VS_W][VS_ND] digit counters per wavefront
   __shared__ float s_red[6][VX_SB / 64];
   __shared__ int s_scan[VX_SB / 64];
-  __shared__ int s_run;
+  __shared__ int s_tot[VS_ND];
   if (n == 0) { if (tid == 0) *J.n_out = 0; return; }
   const float inv = 1.0f / J.leaf;
+  VG_TICK(0);
   // getMinMax3D
   float mn[3] = {3.402823466e+38f, 3.402823466e+38f, 3.402823466e+38f}, mx[3] = {-3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f};
   for (int i = tid; i < n; i += VX_SB) {
@@ -333,151 +335,125 @@ __device__ void vox_small_job(const VoxCtx& V, int job) {
     if (tid == 0) *J.n_out = n;
     return;
   }
+  VG_TICK(1);
   int minb[3], divb[3];
 #pragma unroll
   for (int a = 0; a < 3; ++a) { minb[a] = (int)floorf(mn[a] * inv); divb[a] = (int)floorf(mx[a] * inv) - minb[a] + 1; }
   const int mul1 = divb[0], mul2 = divb[0] * divb[1];
   unsigned T = (unsigned)divb[0] * (unsigned)divb[1] * (unsigned)divb[2];
   if (T == 0) T = 1;
-  int target = 64;
-  while (target < VX_SMALL_NB && target < n) target <<= 1;
-  int shift = 0;
-  while (((T - 1) >> shift) >= (unsigned)target) ++shift;
-  const int nb = (int)((T - 1) >> shift) + 1;
-  for (int b = tid; b < nb; b += VX_SB) s_cnt[b] = 0;
-  __syncthreads();
+  // ---- voxel ids
   for (int i = tid; i < n; i += VX_SB) {
     const float4 p = J.in[i];
     const int i0 = (int)(floorf(p.x * inv) - (float)minb[0]);
     const int i1 = (int)(floorf(p.y * inv) - (float)minb[1]);
     const int i2 = (int)(floorf(p.z * inv) - (float)minb[2]);
-    const unsigned key = (unsigned)(i0 + i1 * mul1 + i2 * mul2);
-    s_key[i] = key;
-    atomicAdd(&s_cnt[min(key >> shift, (unsigned)(nb - 1))], 1);
+    s_key[i] = (unsigned)(i0 + i1 * mul1 + i2 * mul2);
   }
-  __syncthreads();
-  // exclusive scan of the histogram in place
-  auto block_scan = [&](auto get, auto put, int cnt) -> int {
-    if (tid == 0) s_run = 0;
+  VG_TICK(2);
+  // ---- stable LSD radix sort of the point order by voxel id (as vox_big, but every array in LDS): every wavefront owns a
+  // contiguous segment, counts its digits, and after the digit-major / wave-minor prefix scatters its segment in order; the
+  // rank among equal digits inside a round of 64 comes from D ballots.  The order inside a voxel stays the original one.
+  if (T < 2) T = 2;
+  const int bits = 32 - __clz((int)(T - 1));
+  const int P = (bits + VS_DMAX - 1) / VS_DMAX, D = (bits + P - 1) / P, nd = 1 << D;
+  const unsigned dmask = (unsigned)(nd - 1);
+  const int seglen = ((n + VX_SB - 1) / VX_SB) * 64;
+  const int seg0 = min(n, wave * seglen), seg1 = min(n, seg0 + seglen);
+  unsigned short* my = s_cnt + wave * VS_ND;
+  for (int p = 0; p < P; ++p) {
+    const unsigned short* src = (p & 1) ? s_ia : s_ib;   // pass 0 reads the identity order, writes ia; pass 1 ia -> ib; ...
+    unsigned short* dst = (p & 1) ? s_ib : s_ia;
+    const int sh = p * D;
     __syncthreads();
-    for (int b0 = 0; b0 < cnt; b0 += VX_SB) {
-      const int b = b0 + tid;
-      const int v = b < cnt ? get(b) : 0;
-      int incl = v;
+    for (int q = lane; q < nd; q += 64) my[q] = 0;
+    // two sweeps over the own segment: count, then (after the prefix) scatter
+    for (int sweep = 0; sweep < 2; ++sweep) {
+      if (sweep == 1) {
+        __syncthreads();
+        if (tid < nd) {  // exclusive prefix over the wavefronts of every digit, digit totals
+          int run = 0;
 #pragma unroll
-      for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
-      if (lane == 63) s_scan[wave] = incl;
-      __syncthreads();
-      int woff = 0, tot = 0;
-#pragma unroll
-      for (int w = 0; w < VX_SB / 64; ++w) { if (w < wave) woff += s_scan[w]; tot += s_scan[w]; }
-      const int run = s_run;
-      if (b < cnt) put(b, run + woff + incl - v);
-      __syncthreads();
-      if (tid == 0) s_run = run + tot;
-      __syncthreads();
-    }
-    return s_run;
-  };
-  block_scan([&](int b) { return s_cnt[b]; }, [&](int b, int v) { s_cnt[b] = v; }, nb);
-  // scatter: s_cnt[b] turns from bucket start into bucket end
-  for (int i = tid; i < n; i += VX_SB) {
-    const int pos = atomicAdd(&s_cnt[min(s_key[i] >> shift, (unsigned)(nb - 1))], 1);
-    s_idx[pos] = (unsigned short)i;
-  }
-  __syncthreads();
-  // per-bucket rank sort by (voxel id, position) + voxel count.  thread per bucket; buckets > VX_TINY by the wave
-  for (int b0 = 0; b0 < nb; b0 += VX_SB) {
-    const int b = b0 + tid;
-    const int bs = b < nb ? (b == 0 ? 0 : s_cnt[b - 1]) : 0;
-    const int m = b < nb ? s_cnt[b] - bs : 0;
-    if (m > 0 && m <= VX_TINY) {
-      unsigned short e[VX_TINY];
-#pragma unroll
-      for (int i = 0; i < VX_TINY; ++i) e[i] = i < m ? s_idx[bs + i] : (unsigned short)0;
-      int heads = 0;
-#pragma unroll
-      for (int i = 0; i < VX_TINY; ++i) {
-        if (i < m) {
-          int rank = 0;
-          bool head = true;
-#pragma unroll
-          for (int j = 0; j < VX_TINY; ++j) if (j < m && j != i) { const bool lt = vx_less(s_key, e[j], e[i]); rank += lt; if (lt && s_key[e[j]] == s_key[e[i]]) head = false; }
-          s_idx[bs + rank] = e[i];
-          heads += head;
+          for (int w = 0; w < VS_W; ++w) { const int c = s_cnt[w * VS_ND + tid]; s_cnt[w * VS_ND + tid] = (unsigned short)run; run += c; }
+          s_tot[tid] = run;
         }
+        __syncthreads();
+        if (wave == 0) {  // exclusive scan of the digit totals (VS_ND / 64 per lane)
+          constexpr int PER = VS_ND / 64;
+          int v[PER], sum = 0;
+#pragma unroll
+          for (int k = 0; k < PER; ++k) { const int dgt = lane * PER + k; v[k] = dgt < nd ? s_tot[dgt] : 0; sum += v[k]; }
+          int incl = sum;
+#pragma unroll
+          for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+          int run = incl - sum;
+#pragma unroll
+          for (int k = 0; k < PER; ++k) { const int dgt = lane * PER + k; if (dgt < nd) s_tot[dgt] = run; run += v[k]; }
+        }
+        __syncthreads();
       }
-      s_vox[b] = (unsigned short)heads;
-    } else if (b < nb && m == 0) {
-      s_vox[b] = 0;
-    }
-    unsigned long long bigger = __ballot(m > VX_TINY);
-    while (bigger) {
-      const int src_lane = __ffsll((long long)bigger) - 1;
-      bigger &= bigger - 1;
-      const int bb = __shfl(b, src_lane, 64), mm = __shfl(m, src_lane, 64), bbs = __shfl(bs, src_lane, 64);
-      int heads = 0;
-      // ranks first (all reads), then the writes: in place is safe because the wave runs in lock-step
-      unsigned short mine[8];  // up to 512 elements per bucket through registers; beyond: serial fallback below
-      int myrank[8];
-      if (mm <= 512) {
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          const int t = lane + 64 * q;
-          mine[q] = 0; myrank[q] = -1;
-          if (t < mm) {
-            const unsigned short e = s_idx[bbs + t];
-            int rank = 0;
-            bool head = true;
-            for (int j = 0; j < mm; ++j) { const unsigned short o = s_idx[bbs + j]; if (o != e) { const bool lt = vx_less(s_key, o, e); rank += lt; if (lt && s_key[o] == s_key[e]) head = false; } }
-            mine[q] = e; myrank[q] = rank; heads += head;
-          }
+      for (int r0 = seg0; r0 < seg1; r0 += 64) {
+        const int i = r0 + lane;
+        const bool valid = i < seg1;
+        const unsigned idx = valid ? (p == 0 ? (unsigned)i : (unsigned)src[i]) : 0u;
+        const unsigned dg = valid ? (s_key[idx] >> sh) & dmask : 0u;
+        unsigned long long m = __ballot(valid);
+        for (int bit = 0; bit < D; ++bit) {
+          const bool one = (dg >> bit) & 1u;
+          const unsigned long long bal = __ballot(one);
+          m &= one ? bal : ~bal;
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-        for (int q = 0; q < 8; ++q) if (myrank[q] >= 0) s_idx[bbs + myrank[q]] = mine[q];
-      } else if (lane == 0) {
-        // very large bucket (never seen on scan clouds): insertion sort by one lane
-        for (int i = 1; i < mm; ++i) {
-          const unsigned short e = s_idx[bbs + i];
-          int j = i - 1;
-          while (j >= 0 && vx_less(s_key, e, s_idx[bbs + j])) { s_idx[bbs + j + 1] = s_idx[bbs + j]; --j; }
-          s_idx[bbs + j + 1] = e;
-        }
-        for (int i = 0; i < mm; ++i) heads += (i == 0 || s_key[s_idx[bbs + i]] != s_key[s_idx[bbs + i - 1]]);
+        const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+        if (sweep == 1 && valid) dst[(int)my[dg] + s_tot[dg] + rank] = (unsigned short)idx;
+        // LDS operations of one wavefront execute in order: every lane has read my[dg] before the leaders add
+        if (valid && rank == 0) my[dg] = (unsigned short)(my[dg] + (int)__popcll(m));
       }
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) heads += __shfl_xor(heads, o, 64);
-      if (lane == 0) s_vox[bb] = (unsigned short)heads;
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
   }
   __syncthreads();
-  const int nvox = block_scan([&](int b) { return (int)s_vox[b]; }, [&](int b, int v) { s_vox[b] = (unsigned short)v; }, nb);
-  // centroids: one thread per bucket walks its sorted points; f32 sums in sorted (= original) order
-  for (int b = tid; b < nb; b += VX_SB) {
-    const int bs = b == 0 ? 0 : s_cnt[b - 1], m = s_cnt[b] - bs;
-    if (m == 0) continue;
-    int rank = s_vox[b];
+  const unsigned short* srt = (P & 1) ? s_ia : s_ib;
+  unsigned short* hl = (P & 1) ? s_ib : s_ia;   // the other buffer: list of voxel run starts
+  VG_TICK(3);
+  // ---- voxel heads: count per segment, prefix over the wavefronts, list of run starts
+  int heads = 0;
+  for (int r0 = seg0; r0 < seg1; r0 += 64) {
+    const int i = r0 + lane;
+    const bool head = i < seg1 && (i == 0 || s_key[srt[i]] != s_key[srt[i - 1]]);
+    heads += (int)__popcll(__ballot(head));
+  }
+  if (lane == 0) s_scan[wave] = heads;
+  __syncthreads();
+  int vbase = 0, nvox = 0;
+#pragma unroll
+  for (int w = 0; w < VX_SB / 64; ++w) { const int c = s_scan[w]; if (w < wave) vbase += c; nvox += c; }
+  for (int r0 = seg0; r0 < seg1; r0 += 64) {
+    const int i = r0 + lane;
+    const bool head = i < seg1 && (i == 0 || s_key[srt[i]] != s_key[srt[i - 1]]);
+    const unsigned long long hb = __ballot(head);
+    if (head) hl[vbase + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(hb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)hb, 0u))] = (unsigned short)i;
+    vbase += (int)__popcll(hb);
+  }
+  __syncthreads();
+  VG_TICK(4);
+  VG_TICK(5);
+  VG_TICK(6);
+  // ---- centroids: one thread per voxel, f32 sums in sorted (= original) order, four gathers in flight
+  for (int r = tid; r < nvox; r += VX_SB) {
+    const int a = hl[r], b = r + 1 < nvox ? (int)hl[r + 1] : n;
     float sx = 0.f, sy = 0.f, sz = 0.f, si = 0.f;
-    int c = 0;
-    unsigned cur = 0;
-    for (int k = 0; k < m; ++k) {
-      const unsigned short e = s_idx[bs + k];
-      const unsigned vid = s_key[e];
-      if (c > 0 && vid != cur) {
-        const float fn = (float)c;
-        if (rank < J.cap) J.out[rank] = make_float4(sx / fn, sy / fn, sz / fn, si / fn);
-        ++rank; sx = sy = sz = si = 0.f; c = 0;
-      }
-      const float4 p = J.in[e];
-      sx += p.x; sy += p.y; sz += p.z; si += p.w;
-      ++c; cur = vid;
+    for (int j = a; j < b; j += 4) {
+      float4 pt[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) pt[k] = J.in[srt[min(j + k, b - 1)]];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) if (j + k < b) { sx += pt[k].x; sy += pt[k].y; sz += pt[k].z; si += pt[k].w; }
     }
-    const float fn = (float)c;
-    if (rank < J.cap) J.out[rank] = make_float4(sx / fn, sy / fn, sz / fn, si / fn);
+    const float fn = (float)(b - a);
+    J.out[r] = make_float4(sx / fn, sy / fn, sz / fn, si / fn);
   }
   if (tid == 0) *J.n_out = nvox;
+  __syncthreads();
+  VG_TICK(7);
 }
 __global__ void __launch_bounds__(VX_SB) vox_small(VoxCtx V) {
   const int cnt = V.cnt[0];
@@ -508,7 +484,7 @@ __global__ void __launch_bounds__(256) vox_plan(VoxCtx V) {
 }
 
 // ---- host ------------------------------------------------------------------------
-#define VX_SMALL_LDS (6 * VX_SMALL_MAX + 6 * VX_SMALL_NB)
+#define VX_SMALL_LDS (8 * VX_SMALL_MAX + 2 * VS_W * VS_ND)
 int vox_create(VoxCtx* V, const VoxJob* jobs, int njobs, std::string* err) {
   std::memset(V, 0, sizeof(*V));
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(vox_small), hipFuncAttributeMaxDynamicSharedMemorySize, VX_SMALL_LDS) != hipSuccess) { *err = "vox_create: hipFuncSetAttribute"; return -2; }
