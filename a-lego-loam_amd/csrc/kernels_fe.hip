@@ -83,9 +83,9 @@ __global__ void __launch_bounds__(FE_BLOCK) fe_curv(DevCtx d) {
   d.picked0[base + i] = pk;
 }
 
-// one wavefront per (ring, slot).  Dynamic LDS: 4 bytes per ring point (column u16, flags u8, label i8); the
+// one wavefront per (ring, slot).  Dynamic LDS: 3 bytes per ring point (column u16, flags + label u8); the
 // kernel's duration under load is set by how many rings fit a CU next to the other streams' workgroups.
-// flag bits: 0 picked, 1 ground, 2 curvature > edge_thres, 3 curvature < surf_thres
+// flag bits: 0 picked, 1 ground, 2 curvature > edge_thres, 3 curvature < surf_thres, 4-5 cloud_label_ + 1
 template <int FE_T>
 __global__ void __launch_bounds__(64) fe_pick(DevCtx d) {
   const int slot = blockIdx.y + d.slot0, ring = blockIdx.x, lane = threadIdx.x;
@@ -97,7 +97,6 @@ __global__ void __launch_bounds__(64) fe_pick(DevCtx d) {
   extern __shared__ __attribute__((aligned(16))) unsigned char fe_smem[];
   uint16_t* s_col = reinterpret_cast<uint16_t*>(fe_smem);
   uint8_t* s_flag = fe_smem + 2 * (size_t)d.H;
-  int8_t* s_label = reinterpret_cast<int8_t*>(fe_smem + 3 * (size_t)d.H);
   const float* cdv = d.cd + base + rf;  // |cd| bit pattern = sort key: curvature order == unsigned order
   for (int k = lane; k < cnt; k += 64) {
     const float a = fabsf(d.cd[base + rf + k]);
@@ -105,8 +104,7 @@ __global__ void __launch_bounds__(64) fe_pick(DevCtx d) {
     const double curv = ad * ad;  // (double)diff_range * diff_range, exact (:125)
     s_col[k] = (uint16_t)d.seg_col[base + rf + k];
     s_flag[k] = (uint8_t)((d.picked0[base + rf + k] & 1) | (d.seg_ground[base + rf + k] ? 2 : 0) |
-                          (curv > P.edge_thres ? 4 : 0) | (curv < P.surf_thres ? 8 : 0));
-    s_label[k] = 0;
+                          (curv > P.edge_thres ? 4 : 0) | (curv < P.surf_thres ? 8 : 0) | (1 << 4));  // bits 4-5: label + 1
   }
   __syncthreads();
   int* st = d.st_idx + ((size_t)slot * d.NS + ring) * d.st_stride;
@@ -178,7 +176,7 @@ __global__ void __launch_bounds__(64) fe_pick(DevCtx d) {
       int lab = 0;
       if (picked_num <= P.n_sharp) lab = 2; else if (picked_num <= P.n_less_sharp) lab = 1;
       if (lane == 0) {
-        if (lab) s_label[c] = (int8_t)lab;
+        if (lab) s_flag[c] = (uint8_t)((s_flag[c] & 0xCF) | ((lab + 1) << 4));
         if (lab == 2) st_sharp[n_sharp] = c + rf;
         if (lab) st_lsharp[n_ls] = c + rf;
       }
@@ -206,7 +204,7 @@ __global__ void __launch_bounds__(64) fe_pick(DevCtx d) {
         c = (int)wave_min_u32(cand);
       }
       ++picked_num;
-      if (lane == 0) { s_label[c] = -1; st_flat[n_flat] = c + rf; }
+      if (lane == 0) { s_flag[c] = (uint8_t)(s_flag[c] & 0xCF); st_flat[n_flat] = c + rf; }   // label -1
       ++n_flat;
       const bool stop = picked_num >= P.n_flat;
       mark(c, !stop);  // the n_flat-th pick breaks before the suppression (:248-251)
@@ -216,14 +214,14 @@ __global__ void __launch_bounds__(64) fe_pick(DevCtx d) {
     // ---- less-flat candidates in position order (:279-285) ----
     for (int c0 = lsp; c0 <= lep; c0 += 64) {
       const int c = c0 + lane;
-      const bool take = c <= lep && s_label[c] <= 0;
+      const bool take = c <= lep && ((s_flag[c] >> 4) & 3) <= 1;   // label <= 0
       const unsigned long long m = __ballot(take);
       if (take) st_lfs[n_lfs + (int)__popcll(m & ((1ull << lane) - 1ull))] = c + rf;
       n_lfs += (int)__popcll(m);
     }
   }
   __syncthreads();
-  for (int k = lane; k < cnt; k += 64) d.plabel[base + rf + k] = (int)s_label[k];
+  for (int k = lane; k < cnt; k += 64) d.plabel[base + rf + k] = (int)((s_flag[k] >> 4) & 3) - 1;
   if (lane == 0) {
     int* c = d.st_cnt + ((size_t)slot * d.NS + ring) * 8;
     c[0] = n_sharp; c[1] = n_ls; c[2] = n_flat; c[3] = n_lfs;
@@ -482,8 +480,8 @@ void launch_fe(const DevCtx& d, hipStream_t st) {
   // the longest sector holds at most ceil(H / n_sectors) + 1 points
   const int sector_max = (d.H + d.P.n_sectors - 1) / (d.P.n_sectors > 0 ? d.P.n_sectors : 1) + 2;
   static const int extra = getenv("ALEGO_DBG_EXTRA_LDS") ? atoi(getenv("ALEGO_DBG_EXTRA_LDS")) : 0;
-  if (sector_max <= 64 * 6) { ALEGO_LAUNCH(fe_pick<6>, dim3(d.NS, d.n_launch), dim3(64), (size_t)4 * d.H + extra, st, d); }
-  else { ALEGO_LAUNCH(fe_pick<12>, dim3(d.NS, d.n_launch), dim3(64), (size_t)4 * d.H, st, d); }
+  if (sector_max <= 64 * 6) { ALEGO_LAUNCH(fe_pick<6>, dim3(d.NS, d.n_launch), dim3(64), (size_t)3 * d.H + extra, st, d); }
+  else { ALEGO_LAUNCH(fe_pick<12>, dim3(d.NS, d.n_launch), dim3(64), (size_t)3 * d.H, st, d); }
   ALEGO_LAUNCH(fe_voxel, dim3(d.NS, d.n_launch), dim3(FE_BLOCK), (size_t)10 * d.H, st, d);
   ALEGO_LAUNCH(fe_gather, dim3(d.NS, d.n_launch), dim3(FE_BLOCK), 0, st, d);
   ALEGO_LAUNCH(fe_boxes, dim3(24, 2, d.n_launch), dim3(FE_BLOCK), 0, st, d);  // 24 x 8 boxes = 6144 targets per sweep

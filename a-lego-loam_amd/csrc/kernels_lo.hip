@@ -297,6 +297,15 @@ DEV_INLINE void lo_eval_rows(const DevCtx& d, int slot, int cur, int kind, int n
 
 // phase 0: ceres::Solve #1 on the surf blocks (:410-421); phase 1: Solve #2 on surf + corner
 // blocks (:484-495) followed by the pose integration (:504-508).
+#ifdef ALEGO_TIMING
+__device__ long long lo_times[8];
+extern "C" void alego_lo_times(long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(lo_times), sizeof(long long) * 8); }
+#define LO_T0 const long long t0_ = wall_clock64()
+#define LO_ACC(k) do { if (threadIdx.x == 0 && blockIdx.x == 0) lo_times[k] += wall_clock64() - t0_; } while (0)
+#else
+#define LO_T0
+#define LO_ACC(k)
+#endif
 __global__ void __launch_bounds__(LO_BLOCK) lo_solve(DevCtx d, int phase) {
   const int slot = blockIdx.x + d.slot0;
   const int cur = cur_in_flight(d, slot);
@@ -312,6 +321,10 @@ __global__ void __launch_bounds__(LO_BLOCK) lo_solve(DevCtx d, int phase) {
     if (phase == 1 && threadIdx.x == 0) { sc[SC_LO_INIT] = 1; sc[SC_ODOM_VALID] = 0; sc[SC_LO_FLAGS] = 1; sc[SC_LO_NSURF] = 0; sc[SC_LO_NCORNER] = 0; sc[SC_CUR] = cur; }
     return;
   }
+#ifdef ALEGO_TIMING
+  const long long tk0_ = wall_clock64();
+  if (threadIdx.x == 0 && blockIdx.x == 0) lo_times[7] += 1;
+#endif
   const int nq_s = d.feat_cnt[((size_t)slot * 2 + cur) * 4 + F_FLAT];
   const int nq_c = d.feat_cnt[((size_t)slot * 2 + cur) * 4 + F_SHARP];
   // count the correspondences of the kind associated just before this call
@@ -340,10 +353,11 @@ __global__ void __launch_bounds__(LO_BLOCK) lo_solve(DevCtx d, int phase) {
     auto evaluate = [&](const double* x) {
 #pragma unroll
       for (int k = 0; k < 28; ++k) acc[k] = 0;
-      const PoseTerms T = pose_terms_coop(x, s_trig);
-      lo_eval_rows(d, slot, cur, 0, nq_s, T, acc);
-      if (phase == 1) lo_eval_rows(d, slot, cur, 1, nq_c, T, acc);
-      block_reduce28_lds<LO_BLOCK>(acc, s_acc, s_seg, s_out);
+      PoseTerms T;
+      { LO_T0; T = pose_terms_coop(x, s_trig); LO_ACC(0); }
+      { LO_T0; lo_eval_rows(d, slot, cur, 0, nq_s, T, acc);
+        if (phase == 1) lo_eval_rows(d, slot, cur, 1, nq_c, T, acc); LO_ACC(1); }
+      { LO_T0; block_reduce28_lds<LO_BLOCK>(acc, s_acc, s_seg, s_out); LO_ACC(2); }
     };
     double x0[6];
 #pragma unroll
@@ -352,8 +366,8 @@ __global__ void __launch_bounds__(LO_BLOCK) lo_solve(DevCtx d, int phase) {
     if (threadIdx.x == 0) lm_begin(S, x0, s_out, phase == 0 ? d.P.lo_iters_surf : d.P.lo_iters_corner);
     __syncthreads();
     while (true) {
-      if (threadIdx.x == 0) s_action = lm_propose(S);
-      __syncthreads();
+      { LO_T0; if (threadIdx.x == 0) s_action = lm_propose(S);
+      __syncthreads(); LO_ACC(3); }
       const int act = s_action;
       if (act == LM_STOP) break;
       if (act == LM_EVAL) {
@@ -361,8 +375,8 @@ __global__ void __launch_bounds__(LO_BLOCK) lo_solve(DevCtx d, int phase) {
 #pragma unroll
         for (int k = 0; k < 6; ++k) xc[k] = S.cand[k];
         evaluate(xc);
-        if (threadIdx.x == 0) s_action = lm_consume(S, s_out);
-        __syncthreads();
+        { LO_T0; if (threadIdx.x == 0) s_action = lm_consume(S, s_out);
+        __syncthreads(); LO_ACC(4); }
         if (s_action == LM_STOP) break;
       }
       __syncthreads();
@@ -370,7 +384,7 @@ __global__ void __launch_bounds__(LO_BLOCK) lo_solve(DevCtx d, int phase) {
     if (threadIdx.x == 0) {
 #pragma unroll
       for (int k = 0; k < 6; ++k) st[LS_PARAMS + k] = S.x[k];
-      store_pose_rotation(st);   // for the next lo_assoc (corner association / next scan)
+      { LO_T0; store_pose_rotation(st); LO_ACC(5); }   // for the next lo_assoc (corner association / next scan)
       st[LS_COSTS + phase * 2] = S.initial_cost; st[LS_COSTS + phase * 2 + 1] = S.x_cost;
       sc[phase == 0 ? SC_LO_ITERS : SC_LO_ITERS2] = S.iter | (S.successful << 8) | (S.termination << 16);
     }
@@ -406,6 +420,9 @@ __global__ void __launch_bounds__(LO_BLOCK) lo_solve(DevCtx d, int phase) {
       sc[SC_CUR] = cur;  // surf_last_ / corner_last_ <- this scan's features (:531-534)
     }
   }
+#ifdef ALEGO_TIMING
+  if (threadIdx.x == 0 && blockIdx.x == 0) lo_times[6] += wall_clock64() - tk0_;
+#endif
 }
 
 #define LO_SOLVE_LDS ((size_t)(28 * (LO_BLOCK / 4) + 28 * (LO_BLOCK / 128)) * sizeof(double))
