@@ -518,14 +518,30 @@ __global__ void __launch_bounds__(CC_T) cc_lds16(DevCtx d, int ring_pos, int fus
     flw[k >> 4] |= (unsigned long long)f << ((k & 15) * 4);
   }
   auto flag_of = [&](int k) -> unsigned { return (unsigned)(flw[k >> 4] >> ((k & 15) * 4)) & 15u; };
-  for (int v = threadIdx.x; v < N; v += CC_T) par[v] = (uint16_t)v;
+  // Vertical neighbours (2 deg apart) pass the angle test far more often than horizontal ones (0.2 deg apart: a few cm of
+  // range difference already fail), so the components are mostly column strips.  One thread per column walks its rows
+  // bottom-up and gives every cell the start of its vertical run as parent (as cc_runs does on the global path): no
+  // atomics, and the union-find proper only has to process the right-edges.
+  for (int c = threadIdx.x; c < H; c += CC_T) {
+    unsigned fcol[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) fcol[r] = r < d.NS ? (unsigned)fi[r * H + c] : 0u;   // n_scan <= 16 on this path
+    int start = 0;
+    unsigned prev = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      if (r < d.NS) {
+        if (!(prev & 8)) start = r;   // no down-edge from the row below: a new run begins here
+        par[r * H + c] = (uint16_t)(((fcol[r] & 2) ? start : r) * H + c);
+        prev = fcol[r];
+      }
+    }
+  }
   __syncthreads();
   CC_TICK(1);
   for (int k = 0; k < PER; ++k) {
     const int v = threadIdx.x + k * CC_T;
-    const unsigned f = flag_of(k);
-    if (f & 4) { const int row = v / H, col = v - row * H; ccl16_union(par, v, row * H + (col + 1 == H ? 0 : col + 1)); }
-    if (f & 8) ccl16_union(par, v, v + H);
+    if (flag_of(k) & 4) { const int row = v / H, col = v - row * H; ccl16_union(par, v, row * H + (col + 1 == H ? 0 : col + 1)); }
   }
   __syncthreads();
   CC_TICK(2);
