@@ -183,42 +183,42 @@ DEV_INLINE void accumulate_block(double r, const double J[6], double huber_a, do
 
 // Deterministic workgroup reduction of the 28 normal-equation scalars.  Each quad of lanes first adds its four
 // partials with two DPP quad_perm steps (no LDS), one lane per quad stores the sums k-major (conflict-free),
-// NSEG = T/128 threads per scalar add 32 strided entries each, then one thread per scalar adds the NSEG segment
-// sums in order.  The quad step keeps the LDS footprint at 28 x T/4 doubles (28 KB for 512 threads): these solver
-// workgroups live for hundreds of microseconds, and their LDS is what keeps other streams' workgroups off the CU.
-DEV_INLINE double quad_xor_add(double v, const int ctrl_is_xor2) {
+// then a group of 8 / 16 lanes per scalar finishes (below).  The quad step keeps the LDS footprint at 28 x T/4 doubles
+// (28 KB for 512 threads): these solver workgroups live for hundreds of microseconds, and their LDS is what keeps other
+// streams' workgroups off the CU.  (An earlier version let 4 threads per scalar add 32 entries each and a third stage add
+// the 4 sums: 30 % of lm_solve's time.)
+template <int CTRL>
+DEV_INLINE double dpp_add_f64(double v) {   // v + (v of the lane selected by the DPP control CTRL)
   const long long b = __double_as_longlong(v);
-  int lo = (int)(unsigned)(unsigned long long)b, hi = (int)(unsigned)((unsigned long long)b >> 32);
-  int plo, phi;
-  if (ctrl_is_xor2) { plo = __builtin_amdgcn_update_dpp(lo, lo, 0x4E, 0xF, 0xF, false); phi = __builtin_amdgcn_update_dpp(hi, hi, 0x4E, 0xF, 0xF, false); }
-  else { plo = __builtin_amdgcn_update_dpp(lo, lo, 0xB1, 0xF, 0xF, false); phi = __builtin_amdgcn_update_dpp(hi, hi, 0xB1, 0xF, 0xF, false); }
-  const double o = __longlong_as_double((long long)(((unsigned long long)(unsigned)phi << 32) | (unsigned)plo));
-  return v + o;
+  const int lo = (int)(unsigned)(unsigned long long)b, hi = (int)(unsigned)((unsigned long long)b >> 32);
+  const int plo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false), phi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+  return v + __longlong_as_double((long long)(((unsigned long long)(unsigned)phi << 32) | (unsigned)plo));
 }
+// T threads -> Q = T/4 partials per scalar after the quad step; G = Q/8 lanes per scalar (16 for 512 threads, 8 for 256)
+// add 8 strided partials each and finish with log2(G) DPP steps inside their row: two barriers per reduction.
 template <int T>
-DEV_INLINE void block_reduce28_lds(const double acc[28], double* s_acc /*[28*T/4]*/, double* s_seg /*[28*(T/128)]*/, double* s_out /*[28]*/) {
-  constexpr int Q = T / 4, NSEG = Q / 32;
+DEV_INLINE void block_reduce28_lds(const double acc[28], double* s_acc /*[28*T/4]*/, double* /*unused*/, double* s_out /*[28]*/) {
+  constexpr int Q = T / 4, G = Q / 8;
+  static_assert(G == 8 || G == 16, "256 or 512 threads");
+  static_assert(28 * G <= T, "one lane group per scalar");
   const int tid = threadIdx.x;
 #pragma unroll
   for (int k = 0; k < 28; ++k) {
-    double v = quad_xor_add(acc[k], 0);   // lane ^ 1: both lanes of a pair hold a + b (commutative: identical bits)
-    v = quad_xor_add(v, 1);               // lane ^ 2: all four lanes hold (a + b) + (c + d)
+    double v = dpp_add_f64<0xB1>(acc[k]);   // lane ^ 1: both lanes of a pair hold a + b (commutative: identical bits)
+    v = dpp_add_f64<0x4E>(v);               // lane ^ 2: all four lanes hold (a + b) + (c + d)
     if ((tid & 3) == 0) s_acc[k * Q + (tid >> 2)] = v;
   }
   __syncthreads();
-  if (tid < 28 * NSEG) {
-    const int k = tid / NSEG, seg = tid - k * NSEG;
-    double t = 0;
-#pragma unroll 8
-    for (int j = 0; j < 32; ++j) t += s_acc[k * Q + j * NSEG + seg];
-    s_seg[k * NSEG + seg] = t;
-  }
-  __syncthreads();
-  if (tid < 28) {
+  if (tid < 28 * G) {   // whole lane groups: the DPP steps below never leave a group
+    const int k = tid / G, g = tid - k * G;
     double t = 0;
 #pragma unroll
-    for (int sgm = 0; sgm < NSEG; ++sgm) t += s_seg[tid * NSEG + sgm];
-    s_out[tid] = t;
+    for (int j = 0; j < 8; ++j) t += s_acc[k * Q + j * G + g];
+    t = dpp_add_f64<0xB1>(t);
+    t = dpp_add_f64<0x4E>(t);
+    t = dpp_add_f64<0x141>(t);               // row_half_mirror: the two quads of an 8-lane group
+    if (G == 16) t = dpp_add_f64<0x140>(t);  // row_mirror: the two halves of a row
+    if (g == 0) s_out[k] = t;
   }
   __syncthreads();
 }

@@ -4,8 +4,8 @@ import numpy as np
 from alego_loader import load_package; load_package()
 from alego_amd import binding, synth
 p = synth.default_params(16, 1800)
-h = binding.Handle(p, n_slots=1, ring_len=48)
-for k in range(48):
+h = binding.Handle(p, n_slots=1, ring_len=24)
+for k in range(24):
     h.batch_load(0, k, synth.scan(p, k))
 st = 7 | binding.REPLAY_PINGPONG
 h.batch_run(0, 561, st)
