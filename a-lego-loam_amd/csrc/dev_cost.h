@@ -290,25 +290,27 @@ DEV_INLINE int lm_propose(LmState& S) {
     for (int j = 0; j < 6; ++j) Hs[i][j] = A[i][j];
 #pragma unroll
   for (int i = 0; i < 6; ++i) A[i][i] += fmin(fmax(Hs[i][i], 1e-6), 1e32) / S.radius;
-  // Cholesky A = L L^T
+  // Cholesky A = L L^T; the diagonal is stored inverted: one division per column instead of one per entry (this thread
+  // is the serial part of every solver iteration, and an fp64 division is ~30 instructions)
   bool ok = true;
+  double dinv[6];
 #pragma unroll
   for (int j = 0; j < 6; ++j) {
     double s = A[j][j];
     for (int k = 0; k < j; ++k) s -= A[j][k] * A[j][k];
     if (!(s > 0)) { ok = false; s = 1; }
     const double l = sqrt(s);
-    A[j][j] = l;
+    dinv[j] = 1.0 / l;
     for (int i = j + 1; i < 6; ++i) {
       double t = A[i][j];
       for (int k = 0; k < j; ++k) t -= A[i][k] * A[j][k];
-      A[i][j] = t / l;
+      A[i][j] = t * dinv[j];
     }
   }
 #pragma unroll
-  for (int i = 0; i < 6; ++i) { double t = gs[i]; for (int k = 0; k < i; ++k) t -= A[i][k] * y[k]; y[i] = t / A[i][i]; }
+  for (int i = 0; i < 6; ++i) { double t = gs[i]; for (int k = 0; k < i; ++k) t -= A[i][k] * y[k]; y[i] = t * dinv[i]; }
 #pragma unroll
-  for (int i = 5; i >= 0; --i) { double t = y[i]; for (int k = i + 1; k < 6; ++k) t -= A[k][i] * y[k]; y[i] = t / A[i][i]; }
+  for (int i = 5; i >= 0; --i) { double t = y[i]; for (int k = i + 1; k < 6; ++k) t -= A[k][i] * y[k]; y[i] = t * dinv[i]; }
   double step[6], mcc = 0;
   bool finite = ok;
 #pragma unroll
