@@ -132,6 +132,44 @@ def test_fe_lo_teacher_forced(geom, nscan):
     h.close()
 
 
+def test_fe_lo_standalone_node_variants(params_a):
+    """LO.cpp's variants of the nodelet code: f32 occlusion test (LO.cpp:203-204) and the other sector split (:245-249)."""
+    p = params_a.copy()
+    p.occl_f32, p.sector_formula = 1, 1
+    h, o = binding.Handle(p), O.Oracle(p)
+    for k in range(4):
+        pts = synth.scan(p, k)
+        seg = _ip_compare(h, o, pts, f"variants scan {k}")
+        h.set_lo_params(o.get("lo_params"))
+        o.lo()
+        flags, feat, odom = h.lo_process(seg)
+        _fe_compare(h, o, feat, f"variants scan {k}")
+        if k:
+            np.testing.assert_allclose(odom["params"], o.get("lo_params"), rtol=0, atol=1e-7)
+    h.close()
+
+
+def test_full_loop_on_jittered_scans_with_nan_returns(params_a):
+    """Azimuth jitter moves points next to cell boundaries and drops returns as NaN: the projection shortcuts' exact
+    fallbacks, duplicate cells and ragged rings all the way through LO and LM."""
+    p = params_a
+    h, o = binding.Handle(p), O.Oracle(p)
+    for k in range(24):
+        pts = synth.scan(p, k, flags=3)
+        h.set_lo_params(o.get("lo_params"))
+        h.set_lm_params(o.get("lm_params"))
+        o.process_scan(pts)
+        flags, odom, mp = h.scan_process(pts, stages=7)
+        if k == 0:
+            continue
+        assert_bit_equal(h.debug_get("seg_col"), o.get("seg_col"), f"jitter scan {k} columns")
+        assert_bit_equal(h.debug_get("less_flat"), o.get("less_flat"), f"jitter scan {k} less_flat")
+        _lm_compare(h, o, k, f"jitter scan {k}")
+        want = o.get("map_pose")
+        assert np.abs(mp["t"] - want[:3]).max() < POSE_TOL and quat_angle(mp["q"], want[3:]) < POSE_TOL
+    h.close()
+
+
 def test_lo_free_running(params_a):
     """No teacher forcing: report first index divergence, require pose agreement over 40 scans."""
     p = params_a
