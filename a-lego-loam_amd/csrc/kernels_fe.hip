@@ -234,7 +234,15 @@ __global__ void __launch_bounds__(64) fe_pick(DevCtx d) {
 // runs in LDS, then the first run of every voxel accumulates all runs of that voxel in order — the same f32
 // summation order as a stable sort of the points.  Dynamic LDS: 10 B per ring point (+ 4 KB of bucket counters): the
 // number of these workgroups that fit a CU decides the kernel's duration.
+#ifdef ALEGO_TIMING
+__device__ long long fv_times[12];
+extern "C" void alego_fv_times(long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(fv_times), sizeof(long long) * 12); }
+#define FV_TICK(k) do { if (threadIdx.x == 0 && blockIdx.x == 8 && blockIdx.y == 0) fv_times[k] = wall_clock64(); } while (0)
+#else
+#define FV_TICK(k)
+#endif
 #define FV_NB 512
+#define FV_U 4    // gathers kept in flight per thread
 __global__ void __launch_bounds__(FE_BLOCK) fe_voxel(DevCtx d) {
   const int slot = blockIdx.y + d.slot0, ring = blockIdx.x, tid = threadIdx.x;
   const size_t base = (size_t)slot * d.N;
@@ -254,12 +262,22 @@ __global__ void __launch_bounds__(FE_BLOCK) fe_voxel(DevCtx d) {
   __shared__ int s_boff[FV_NB + 1], s_bcur[FV_NB + 1];
   if (n == 0) { if (tid == 0) cnts[4] = 0; return; }
   const float inv = 1.0f / d.P.less_flat_leaf;
+  FV_TICK(0);
   // getMinMax3D
   float mn[3] = {3.402823466e+38f, 3.402823466e+38f, 3.402823466e+38f}, mx[3] = {-3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f};
-  for (int i = tid; i < n; i += FE_BLOCK) {
-    const float4 p = seg[lfs[i]];
-    mn[0] = fminf(mn[0], p.x); mn[1] = fminf(mn[1], p.y); mn[2] = fminf(mn[2], p.z);
-    mx[0] = fmaxf(mx[0], p.x); mx[1] = fmaxf(mx[1], p.y); mx[2] = fmaxf(mx[2], p.z);
+  // gathers through the index list: FV_U index loads, then FV_U point loads in flight together
+  for (int i0 = tid; i0 < n; i0 += FE_BLOCK * FV_U) {
+    int ix[FV_U];
+    float4 pt[FV_U];
+#pragma unroll
+    for (int u = 0; u < FV_U; ++u) ix[u] = lfs[min(i0 + u * FE_BLOCK, n - 1)];
+#pragma unroll
+    for (int u = 0; u < FV_U; ++u) pt[u] = seg[ix[u]];
+#pragma unroll
+    for (int u = 0; u < FV_U; ++u) {   // (a clamped duplicate of the last point does not change min / max)
+      mn[0] = fminf(mn[0], pt[u].x); mn[1] = fminf(mn[1], pt[u].y); mn[2] = fminf(mn[2], pt[u].z);
+      mx[0] = fmaxf(mx[0], pt[u].x); mx[1] = fmaxf(mx[1], pt[u].y); mx[2] = fmaxf(mx[2], pt[u].z);
+    }
   }
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
@@ -280,6 +298,7 @@ __global__ void __launch_bounds__(FE_BLOCK) fe_voxel(DevCtx d) {
     if (tid == 0) cnts[4] = n;
     return;
   }
+  FV_TICK(1);
   int minb[3], divb[3];
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
@@ -287,14 +306,26 @@ __global__ void __launch_bounds__(FE_BLOCK) fe_voxel(DevCtx d) {
     divb[a] = (int)floorf(mx[a] * inv) - minb[a] + 1;
   }
   const int mul1 = divb[0], mul2 = divb[0] * divb[1];
-  for (int i = tid; i < n; i += FE_BLOCK) {
-    const float4 p = seg[lfs[i]];
-    const int i0 = (int)(floorf(p.x * inv) - (float)minb[0]);
-    const int i1 = (int)(floorf(p.y * inv) - (float)minb[1]);
-    const int i2 = (int)(floorf(p.z * inv) - (float)minb[2]);
-    s_key[i] = (uint32_t)(i0 + i1 * mul1 + i2 * mul2);
+  for (int ib = tid; ib < n; ib += FE_BLOCK * FV_U) {
+    int ix[FV_U];
+    float4 pt[FV_U];
+#pragma unroll
+    for (int u = 0; u < FV_U; ++u) ix[u] = lfs[min(ib + u * FE_BLOCK, n - 1)];
+#pragma unroll
+    for (int u = 0; u < FV_U; ++u) pt[u] = seg[ix[u]];
+#pragma unroll
+    for (int u = 0; u < FV_U; ++u) {
+      const int i = ib + u * FE_BLOCK;
+      if (i < n) {
+        const int i0 = (int)(floorf(pt[u].x * inv) - (float)minb[0]);
+        const int i1 = (int)(floorf(pt[u].y * inv) - (float)minb[1]);
+        const int i2 = (int)(floorf(pt[u].z * inv) - (float)minb[2]);
+        s_key[i] = (uint32_t)(i0 + i1 * mul1 + i2 * mul2);
+      }
+    }
   }
   __syncthreads();
+  FV_TICK(2);
   // runs of consecutive equal voxel ids
   int nruns = 0;
   for (int c0 = 0; c0 < n; c0 += FE_BLOCK) {
@@ -315,6 +346,7 @@ __global__ void __launch_bounds__(FE_BLOCK) fe_voxel(DevCtx d) {
     nruns += tot;
     __syncthreads();
   }
+  FV_TICK(3);
   // Order the runs by (voxel id, run index).  Voxel ids are bounded by the grid size T, so the runs are first dealt
   // into <= FV_NB buckets that are monotone in the voxel id (LDS atomics; arbitrary order inside a bucket), then
   // every run ranks itself among the one or two runs of its bucket — instead of against all runs of the ring.
@@ -363,6 +395,7 @@ __global__ void __launch_bounds__(FE_BLOCK) fe_voxel(DevCtx d) {
     }
   }
   __syncthreads();
+  FV_TICK(4);
   // first run of every voxel -> output rank; it accumulates all runs of the voxel in order
   int nvox = 0;
   for (int c0 = 0; c0 < nruns; c0 += FE_BLOCK) {
@@ -381,10 +414,15 @@ __global__ void __launch_bounds__(FE_BLOCK) fe_voxel(DevCtx d) {
       int c = 0;
       for (int jj = j; jj < nruns && s_rvid[s_order[jj]] == vid; ++jj) {
         const int r = s_order[jj], i0 = s_rstart[r], len = (r + 1 < nruns ? (int)s_rstart[r + 1] : n) - i0;
-        for (int i = i0; i < i0 + len; ++i) {
-          const float4 p = seg[lfs[i]];
-          sx += p.x; sy += p.y; sz += p.z; si += p.w;
-          ++c;
+        for (int i = i0; i < i0 + len; i += 4) {   // four gathers in flight, added strictly in order
+          int ix[4];
+          float4 pt[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) ix[u] = lfs[min(i + u, i0 + len - 1)];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) pt[u] = seg[ix[u]];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) if (i + u < i0 + len) { sx += pt[u].x; sy += pt[u].y; sz += pt[u].z; si += pt[u].w; ++c; }
         }
       }
       const float fn = (float)c;
@@ -394,6 +432,7 @@ __global__ void __launch_bounds__(FE_BLOCK) fe_voxel(DevCtx d) {
     __syncthreads();
   }
   if (tid == 0) cnts[4] = nvox;
+  FV_TICK(5);
 }
 
 // ring-ascending concatenation.  grid (NS, slots)
