@@ -98,6 +98,7 @@ __global__ void __launch_bounds__(64) fe_pick(DevCtx d) {
   uint16_t* s_col = reinterpret_cast<uint16_t*>(fe_smem);
   uint8_t* s_flag = fe_smem + 2 * (size_t)d.H;
   const float* cdv = d.cd + base + rf;  // |cd| bit pattern = sort key: curvature order == unsigned order
+#pragma unroll 4
   for (int k = lane; k < cnt; k += 64) {
     const float a = fabsf(d.cd[base + rf + k]);
     const double ad = (double)a;

@@ -116,13 +116,25 @@ __global__ void __launch_bounds__(128) ip_image(DevCtx d, int ring_pos) {
   unsigned long long filled = 0, ground = 0;
   float lx = 0, ly = 0, lz = 0;
   bool lower_ok = false;
-  for (int row = 0; row < d.NS; ++row) {
-    const int o = owner[row * d.H + col];
+  // rows in batches of IM_U: the owner indices of a batch, then its point gathers, are independent loads
+  constexpr int IM_U = 8;
+  for (int row0 = 0; row0 < d.NS; row0 += IM_U) {
+  int ob[IM_U];
+  float4 pb[IM_U];
+#pragma unroll
+  for (int u = 0; u < IM_U; ++u) ob[u] = row0 + u < d.NS ? owner[(row0 + u) * d.H + col] : -1;
+#pragma unroll
+  for (int u = 0; u < IM_U; ++u) pb[u] = ob[u] >= 0 ? pts[ob[u]] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int u = 0; u < IM_U; ++u) {
+    const int row = row0 + u;
+    if (row >= d.NS) break;
+    const int o = ob[u];
     float r = -1.0f;
     bool ok = o >= 0;
     float x = 0, y = 0, z = 0;
     if (ok) {
-      const float4 p = pts[o];
+      const float4 p = pb[u];
       x = p.x; y = p.y; z = p.z;
       r = sqrtf(x * x + y * y + z * z);  // :99
       filled |= 1ull << row;
@@ -144,6 +156,7 @@ __global__ void __launch_bounds__(128) ip_image(DevCtx d, int ring_pos) {
       if (is_ground) ground |= 3ull << (row - 1);
     }
     lx = x; ly = y; lz = z; lower_ok = ok;
+  }
   }
   for (int row = 0; row < d.NS; ++row) {
     const bool g = (ground >> row) & 1, f = (filled >> row) & 1;
