@@ -371,34 +371,41 @@ __global__ void __launch_bounds__(128) lm_knn(DevCtx d, LmCtx L) {
   if (nmap >= 5) {
     int cx, cy, cz;
     grid_cell(g, sx, sy, sz, &cx, &cy, &cz);
-    for (int dz = -1; dz <= 1; ++dz) {
-      const int z = cz + dz;
-      if (z < 0 || z >= g.gz) continue;
-      for (int dy = -1; dy <= 1; ++dy) {
-        const int y = cy + dy;
-        if (y < 0 || y >= g.gy) continue;
-        const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.gx - 1);
-        if (x0 > x1) continue;
-        const int c0 = x0 + g.gx * (y + g.gy * z), c1 = x1 + g.gx * (y + g.gy * z);
-        const int tend = cs[c1 + 1];
-        for (int t = cs[c0] + sub; t < tend; t += LM_KNN_LANES) {  // the x-run of cells is contiguous in the cell-sorted copy
-          const float4 a = cp[t];
-          const int idx = __float_as_int(a.w);
-          float dist = 0.f, df;
-          df = sx - a.x; dist += df * df;
-          df = sy - a.y; dist += df * df;
-          df = sz - a.z; dist += df * df;
-          if (dist < bd[4] || (dist == bd[4] && idx < bi[4])) {
-            bd[4] = dist; bi[4] = idx;
+    // bounds of the nine x-runs of cells first (18 independent loads), then the candidates two per lane at a time
+    int rs[9], re[9];
 #pragma unroll
-            for (int k = 4; k > 0; --k) {
-              if (bd[k] < bd[k - 1] || (bd[k] == bd[k - 1] && bi[k] < bi[k - 1])) {
-                const float td = bd[k]; bd[k] = bd[k - 1]; bd[k - 1] = td;
-                const int ti = bi[k]; bi[k] = bi[k - 1]; bi[k - 1] = ti;
-              }
-            }
+    for (int r = 0; r < 9; ++r) {
+      const int z = cz + r / 3 - 1, y = cy + r % 3 - 1;
+      const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.gx - 1);
+      const bool in = z >= 0 && z < g.gz && y >= 0 && y < g.gy && x0 <= x1;
+      const int c0 = x0 + g.gx * (y + g.gy * z), c1 = x1 + g.gx * (y + g.gy * z);
+      rs[r] = in ? cs[c0] : 0;
+      re[r] = in ? cs[c1 + 1] : 0;
+    }
+    auto consider = [&](const float4& a) {
+      const int idx = __float_as_int(a.w);
+      float dist = 0.f, df;
+      df = sx - a.x; dist += df * df;
+      df = sy - a.y; dist += df * df;
+      df = sz - a.z; dist += df * df;
+      if (dist < bd[4] || (dist == bd[4] && idx < bi[4])) {
+        bd[4] = dist; bi[4] = idx;
+#pragma unroll
+        for (int k = 4; k > 0; --k) {
+          if (bd[k] < bd[k - 1] || (bd[k] == bd[k - 1] && bi[k] < bi[k - 1])) {
+            const float td = bd[k]; bd[k] = bd[k - 1]; bd[k - 1] = td;
+            const int ti = bi[k]; bi[k] = bi[k - 1]; bi[k - 1] = ti;
           }
         }
+      }
+    };
+#pragma unroll
+    for (int r = 0; r < 9; ++r) {
+      for (int t = rs[r] + sub; t < re[r]; t += 2 * LM_KNN_LANES) {  // an x-run of cells is contiguous in the cell-sorted copy
+        const int t1 = t + LM_KNN_LANES;
+        const float4 a0 = cp[t], a1 = cp[t1 < re[r] ? t1 : t];
+        consider(a0);
+        if (t1 < re[r]) consider(a1);
       }
     }
   }
