@@ -16,6 +16,7 @@
 
 #define FE_BLOCK 256
 #define FE_HALO 6
+#define FE_CW 1024   // points per fe_curv workgroup
 #define FE_MAXH 4096  // largest horizon_scan supported by the per-ring LDS staging
 // fe_pick<FE_T>: sector elements per lane kept in registers (sector length <= 64*FE_T): 6 covers 16x1800
 // (<= 300 points per sector), 12 covers horizon_scan 4096 (683)
@@ -23,16 +24,17 @@
 __global__ void __launch_bounds__(FE_BLOCK) fe_curv(DevCtx d) {
   const int slot = blockIdx.y + d.slot0;
   const int M = d.scal[slot * SC_COUNT + SC_M];
-  const int t0 = blockIdx.x * FE_BLOCK;
+  const int t0 = blockIdx.x * FE_CW;   // FE_CW points per workgroup, FE_CW / FE_BLOCK per thread
   if (t0 >= M) return;
   const size_t base = (size_t)slot * d.N;
   const float* rng = d.seg_range + base;
   const int* colv = d.seg_col + base;
   const alego_params& P = d.P;
-  __shared__ float s_r[FE_BLOCK + 2 * FE_HALO];
-  __shared__ int s_c[FE_BLOCK + 2 * FE_HALO];
-  __shared__ uint8_t s_f[FE_BLOCK + 2 * FE_HALO];
-  for (int j = threadIdx.x; j < FE_BLOCK + 2 * FE_HALO; j += FE_BLOCK) {
+  __shared__ float s_r[FE_CW + 2 * FE_HALO];
+  __shared__ int s_c[FE_CW + 2 * FE_HALO];
+  __shared__ uint8_t s_f[FE_CW + 2 * FE_HALO];
+  #pragma unroll 5
+  for (int j = threadIdx.x; j < FE_CW + 2 * FE_HALO; j += FE_BLOCK) {
     const int i = t0 - FE_HALO + j;
     const bool in = i >= 0 && i < M;
     s_r[j] = in ? rng[i] : 0.f;
@@ -40,7 +42,7 @@ __global__ void __launch_bounds__(FE_BLOCK) fe_curv(DevCtx d) {
   }
   __syncthreads();
   // per-point conditions of markOccludedPoints for i = t0-5 .. t0+FE_BLOCK+4
-  for (int j = threadIdx.x + 1; j < FE_BLOCK + 2 * FE_HALO - 1; j += FE_BLOCK) {
+  for (int j = threadIdx.x + 1; j < FE_CW + 2 * FE_HALO - 1; j += FE_BLOCK) {
     const int i = t0 - FE_HALO + j;
     uint8_t f = 0;
     if (i >= 5 && i < M - 5) {
@@ -66,21 +68,24 @@ __global__ void __launch_bounds__(FE_BLOCK) fe_curv(DevCtx d) {
     s_f[j] = f;
   }
   __syncthreads();
-  const int i = t0 + threadIdx.x;
-  if (i >= M) return;
-  const int j = threadIdx.x + FE_HALO;
-  float cdv = 0.f;
-  if (i >= 5 && i < M - 5) {
-    // strictly left-to-right f32 sum (:124); built with -ffp-contract=off
-    cdv = s_r[j - 5] + s_r[j - 4] + s_r[j - 3] + s_r[j - 2] + s_r[j - 1] - s_r[j] * 10 + s_r[j + 1] + s_r[j + 2] + s_r[j + 3] + s_r[j + 4] + s_r[j + 5];
+#pragma unroll
+  for (int u = 0; u < FE_CW / FE_BLOCK; ++u) {
+    const int i = t0 + u * FE_BLOCK + threadIdx.x;
+    if (i >= M) break;
+    const int j = u * FE_BLOCK + threadIdx.x + FE_HALO;
+    float cdv = 0.f;
+    if (i >= 5 && i < M - 5) {
+      // strictly left-to-right f32 sum (:124); built with -ffp-contract=off
+      cdv = s_r[j - 5] + s_r[j - 4] + s_r[j - 3] + s_r[j - 2] + s_r[j - 1] - s_r[j] * 10 + s_r[j + 1] + s_r[j + 2] + s_r[j + 3] + s_r[j + 4] + s_r[j + 5];
+    }
+    uint8_t pk = (s_f[j] & 4) ? 1 : 0;
+#pragma unroll
+    for (int l = 0; l <= 5; ++l) pk |= (s_f[j + l] & 1);       // A(i'), i' in [i, i+5]
+#pragma unroll
+    for (int l = 1; l <= 5; ++l) pk |= (s_f[j - l] & 2) >> 1;  // B(i'), i' in [i-5, i-1]
+    d.cd[base + i] = cdv;
+    d.picked0[base + i] = pk;
   }
-  uint8_t pk = (s_f[j] & 4) ? 1 : 0;
-#pragma unroll
-  for (int l = 0; l <= 5; ++l) pk |= (s_f[j + l] & 1);       // A(i'), i' in [i, i+5]
-#pragma unroll
-  for (int l = 1; l <= 5; ++l) pk |= (s_f[j - l] & 2) >> 1;  // B(i'), i' in [i-5, i-1]
-  d.cd[base + i] = cdv;
-  d.picked0[base + i] = pk;
 }
 
 // one wavefront per (ring, slot).  Dynamic LDS: 3 bytes per ring point (column u16, flags + label u8); the
@@ -516,7 +521,7 @@ __global__ void __launch_bounds__(FE_BLOCK) fe_boxes(DevCtx d) {
 }
 
 void launch_fe(const DevCtx& d, hipStream_t st) {
-  ALEGO_LAUNCH(fe_curv, dim3((d.N + FE_BLOCK - 1) / FE_BLOCK, d.n_launch), dim3(FE_BLOCK), 0, st, d);
+  ALEGO_LAUNCH(fe_curv, dim3((d.N + FE_CW - 1) / FE_CW, d.n_launch), dim3(FE_BLOCK), 0, st, d);
   // the longest sector holds at most ceil(H / n_sectors) + 1 points
   const int sector_max = (d.H + d.P.n_sectors - 1) / (d.P.n_sectors > 0 ? d.P.n_sectors : 1) + 2;
   static const int extra = getenv("ALEGO_DBG_EXTRA_LDS") ? atoi(getenv("ALEGO_DBG_EXTRA_LDS")) : 0;
