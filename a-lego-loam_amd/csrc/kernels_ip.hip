@@ -19,12 +19,14 @@
 #include "prof.h"
 
 #define IP_BLOCK 256
+#define IP_PW 4   // points / cells per thread in the streaming kernels
 
 __global__ void __launch_bounds__(IP_BLOCK) ip_reset(DevCtx d) {
   const int slot = blockIdx.y + d.slot0;
-  const int v = blockIdx.x * IP_BLOCK + threadIdx.x;
-  if (v < d.N) d.owner[(size_t)slot * d.N + v] = -1;
-  if (v == 0) {
+  const int v0 = blockIdx.x * IP_BLOCK * IP_PW + threadIdx.x;
+#pragma unroll
+  for (int u = 0; u < IP_PW; ++u) { const int v = v0 + u * IP_BLOCK; if (v < d.N) d.owner[(size_t)slot * d.N + v] = -1; }
+  if (v0 == 0) {
     int* sc = d.scal + slot * SC_COUNT;
     sc[SC_FIRST] = 0x7fffffff; sc[SC_LAST] = -1; sc[SC_PVALID] = 0;
 
@@ -33,12 +35,20 @@ __global__ void __launch_bounds__(IP_BLOCK) ip_reset(DevCtx d) {
 
 __global__ void __launch_bounds__(IP_BLOCK) ip_project(DevCtx d, int ring_pos) {
   const int slot = blockIdx.y + d.slot0;
-  const int i = blockIdx.x * IP_BLOCK + threadIdx.x;
+  const int i0 = blockIdx.x * IP_BLOCK * IP_PW + threadIdx.x;   // IP_PW points per thread, their loads in flight together
   const int n = d.in_n[slot * d.ring_len + ring_pos];
   const alego_params& P = d.P;
+  const float4* in = d.in_pts + ((size_t)slot * d.ring_len + ring_pos) * d.Pcap;
+  float4 pin[IP_PW];
+#pragma unroll
+  for (int u = 0; u < IP_PW; ++u) pin[u] = in[min(i0 + u * IP_BLOCK, max(n - 1, 0))];
+  int vmin = 0x7fffffff, vmax = -1, nvalid = 0;
+#pragma unroll
+  for (int u = 0; u < IP_PW; ++u) {
+  const int i = i0 + u * IP_BLOCK;
   bool valid = false;
   if (i < n) {
-    const float4 p = d.in_pts[((size_t)slot * d.ring_len + ring_pos) * d.Pcap + i];
+    const float4 p = pin[u];
     valid = isfinite(p.x) && isfinite(p.y) && isfinite(p.z);
     if (valid && P.near_filter) {
       const float th = (float)P.near_thres;
@@ -75,19 +85,20 @@ __global__ void __launch_bounds__(IP_BLOCK) ip_project(DevCtx d, int ring_pos) {
         atomicMax(&d.owner[(size_t)slot * d.N + col + row * d.H], i);  // later points overwrite earlier ones (:102-103)
     }
   }
+  if (valid) { vmin = min(vmin, i); vmax = max(vmax, i); ++nvalid; }
+  }
   // first / last valid point for the orientation block (:62-63): one atomic per wavefront
-  int vmin = valid ? i : 0x7fffffff, vmax = valid ? i : -1;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     vmin = min(vmin, __shfl_xor(vmin, o, 64));
     vmax = max(vmax, __shfl_xor(vmax, o, 64));
+    nvalid += __shfl_xor(nvalid, o, 64);
   }
-  const unsigned long long vb = __ballot(valid);
-  if (lane_id() == 0 && vb) {
+  if (lane_id() == 0 && nvalid) {
     int* sc = d.scal + slot * SC_COUNT;
     atomicMin(&sc[SC_FIRST], vmin);
     atomicMax(&sc[SC_LAST], vmax);
-    atomicAdd(&sc[SC_PVALID], (int)__popcll(vb));
+    atomicAdd(&sc[SC_PVALID], nvalid);
   }
 }
 
@@ -180,38 +191,50 @@ DEV_INLINE bool edge_angle_gt(double y, double x, double theta, double tan_theta
 // init: bit 0 parent (global union-find path), bit 1 component statistics (cc_stats path), bit 2 labels (ip_compact path)
 __global__ void __launch_bounds__(IP_BLOCK) cc_edges(DevCtx d, int init) {
   const int slot = blockIdx.y + d.slot0;
-  const int v = blockIdx.x * IP_BLOCK + threadIdx.x;
-  if (v >= d.N) return;
   const size_t base = (size_t)slot * d.N;
   const float* rimg = d.range_img + base;
   uint8_t* fimg = d.flag_img + base;
-  const uint8_t f = fimg[v];
-  const bool active = f & 2;
-  uint8_t e = 0;
-  if (active) {
-    const int row = v / d.H, col = v - row * d.H;
-    const double rv = (double)rimg[v];
-    const int cr = (col + 1 == d.H) ? 0 : col + 1;
-    const int u = row * d.H + cr;
-    if ((fimg[u] & 2) && d.H > 1) {  // same row, seg_alpha_x (:258-261)
-      const double ru = (double)rimg[u];
-      const double d1 = fmax(rv, ru), d2 = fmin(rv, ru);
-      if (edge_angle_gt(d2 * d.sin_ax, d1 - d2 * d.cos_ax, d.P.seg_theta, d.tan_theta)) e |= 4;
-    }
-    if (row + 1 < d.NS) {
-      const int w = v + d.H;
-      if (fimg[w] & 2) {  // same column, seg_alpha_y (:262-265)
-        const double rw = (double)rimg[w];
-        const double d1 = fmax(rv, rw), d2 = fmin(rv, rw);
+  // IP_PW cells per thread; the flag and range loads of all of them are issued before the predicates are evaluated
+  int vv[IP_PW], uu[IP_PW];
+  uint8_t f[IP_PW], fu[IP_PW], fw[IP_PW];
+  float rv[IP_PW], ru[IP_PW], rw[IP_PW];
+#pragma unroll
+  for (int q = 0; q < IP_PW; ++q) {
+    const int v = blockIdx.x * IP_BLOCK * IP_PW + q * IP_BLOCK + threadIdx.x;
+    vv[q] = v;
+    const int vc = min(v, d.N - 1);
+    const int row = vc / d.H, col = vc - row * d.H;
+    uu[q] = row * d.H + ((col + 1 == d.H) ? 0 : col + 1);   // right neighbour with column wrap-around (:241-248)
+    const int w = row + 1 < d.NS ? vc + d.H : vc;
+    f[q] = fimg[vc]; fu[q] = fimg[uu[q]]; fw[q] = fimg[w];
+    rv[q] = rimg[vc]; ru[q] = rimg[uu[q]]; rw[q] = rimg[w];
+  }
+#pragma unroll
+  for (int q = 0; q < IP_PW; ++q) {
+    const int v = vv[q];
+    if (v >= d.N) continue;
+    const bool active = f[q] & 2;
+    uint8_t e = 0;
+    if (active) {
+      const int row = v / d.H;
+      const double r0 = (double)rv[q];
+      if ((fu[q] & 2) && d.H > 1) {  // same row, seg_alpha_x (:258-261)
+        const double r1 = (double)ru[q];
+        const double d1 = fmax(r0, r1), d2 = fmin(r0, r1);
+        if (edge_angle_gt(d2 * d.sin_ax, d1 - d2 * d.cos_ax, d.P.seg_theta, d.tan_theta)) e |= 4;
+      }
+      if (row + 1 < d.NS && (fw[q] & 2)) {  // same column, seg_alpha_y (:262-265)
+        const double r1 = (double)rw[q];
+        const double d1 = fmax(r0, r1), d2 = fmin(r0, r1);
         if (edge_angle_gt(d2 * d.sin_ay, d1 - d2 * d.cos_ay, d.P.seg_theta, d.tan_theta)) e |= 8;
       }
     }
+    // NOTE: bits 2/3 of a neighbour are never read by this kernel (only bit 1), so the in-place update is race-free
+    fimg[v] = (uint8_t)((f[q] & 3) | e);
+    if (init & 1) d.parent[base + v] = active ? v : -1;
+    if (init & 2) { d.cc_size[base + v] = 0; d.cc_rows[base + v] = 0ull; }
+    if (init & 4) d.cc_label[base + v] = 0;
   }
-  // NOTE: bits 2/3 of a neighbour are never read by this kernel (only bit 1), so the in-place update is race-free
-  fimg[v] = (uint8_t)((f & 3) | e);
-  if (init & 1) d.parent[base + v] = active ? v : -1;
-  if (init & 2) { d.cc_size[base + v] = 0; d.cc_rows[base + v] = 0ull; }
-  if (init & 4) d.cc_label[base + v] = 0;
 }
 
 // ECL-CC style find with intermediate pointer jumping; parents only ever decrease.
@@ -918,12 +941,13 @@ __global__ void atan2f_probe(const float* y, const float* x, float* out, int n, 
 void launch_ip(const DevCtx& d, int ring_pos, bool want_labels, hipStream_t st) {
   static const bool fuse_env = !(getenv("ALEGO_CC_FUSED") && atoi(getenv("ALEGO_CC_FUSED")) == 0);
   const bool fused = fuse_env && d.N <= CC_LDS_MAXN && d.NS <= 16;   // cc_lds also does the compaction
-  const dim3 gN((d.N + IP_BLOCK - 1) / IP_BLOCK, d.n_launch), gP((d.Pcap + IP_BLOCK - 1) / IP_BLOCK, d.n_launch);
-  ALEGO_LAUNCH(ip_reset, gN, dim3(IP_BLOCK), 0, st, d);
-  ALEGO_LAUNCH(ip_project, gP, dim3(IP_BLOCK), 0, st, d, ring_pos);
+  const dim3 gN((d.N + IP_BLOCK - 1) / IP_BLOCK, d.n_launch);
+  const dim3 gN4((d.N + IP_BLOCK * IP_PW - 1) / (IP_BLOCK * IP_PW), d.n_launch), gP4((d.Pcap + IP_BLOCK * IP_PW - 1) / (IP_BLOCK * IP_PW), d.n_launch);
+  ALEGO_LAUNCH(ip_reset, gN4, dim3(IP_BLOCK), 0, st, d);
+  ALEGO_LAUNCH(ip_project, gP4, dim3(IP_BLOCK), 0, st, d, ring_pos);
   ALEGO_LAUNCH(ip_image, dim3((d.H + 127) / 128, d.n_launch), dim3(128), 0, st, d, ring_pos);
   const bool lds_cc = d.N <= CC_LDS_MAXN, lds_stats = lds_cc && d.NS <= 16;
-  ALEGO_LAUNCH(cc_edges, gN, dim3(IP_BLOCK), 0, st, d, (lds_cc ? 0 : 1) | (lds_stats ? 0 : 2) | (fused ? 0 : 4));
+  ALEGO_LAUNCH(cc_edges, gN4, dim3(IP_BLOCK), 0, st, d, (lds_cc ? 0 : 1) | (lds_stats ? 0 : 2) | (fused ? 0 : 4));
   if (lds_stats) {
     // bit 0: fused compaction; bit 1: write the root image to HBM (only ip_classify, ip_labels and alego_debug_get read it:
     // the single-scan entry points keep it, the batch path does not)
