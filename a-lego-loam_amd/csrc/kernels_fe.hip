@@ -473,7 +473,17 @@ __global__ void __launch_bounds__(FE_BLOCK) fe_gather(DevCtx d) {
   for (int k = 0; k < 3; ++k) {
     float4* dst = d.feat[k] + ((size_t)slot * 2 + cur) * d.fcap[k] + s_off[k];
     int* dsti = d.feat_idx[k] + ((size_t)slot * 2 + cur) * d.fcap[k] + s_off[k];
-    for (int i = tid; i < myc[k]; i += FE_BLOCK) { const int idx = stk[k][i]; dst[i] = seg[idx]; dsti[i] = idx; }
+    const int cnt_k = myc[k];
+    for (int i0 = tid; i0 < cnt_k; i0 += FE_BLOCK * 4) {   // index loads, then point gathers, four in flight
+      int ix[4];
+      float4 pt[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) ix[u] = stk[k][min(i0 + u * FE_BLOCK, cnt_k - 1)];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) pt[u] = seg[ix[u]];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { const int i = i0 + u * FE_BLOCK; if (i < cnt_k) { dst[i] = pt[u]; dsti[i] = ix[u]; } }
+    }
   }
   {
     float4* dst = d.feat[F_LFLAT] + ((size_t)slot * 2 + cur) * d.fcap[F_LFLAT] + s_off[3];
