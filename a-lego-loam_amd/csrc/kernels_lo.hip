@@ -79,6 +79,13 @@ DEV_INLINE WalkBest walk_reduce_row(WalkBest b) {
 // the 16 bits of a wave-wide ballot that belong to this lane's row
 DEV_INLINE uint32_t row_bits(unsigned long long ballot, int lane) { return (uint32_t)(ballot >> (lane & 48)) & 0xFFFFu; }
 
+#ifdef ALEGO_TIMING
+__device__ long long la_times[12];
+extern "C" void alego_la_times(long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(la_times), sizeof(long long) * 12); }
+#define LA_TICK(k) do { if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && kind == 0) la_times[k] = wall_clock64(); } while (0)
+#else
+#define LA_TICK(k)
+#endif
 __global__ void __launch_bounds__(LO_BLOCK) lo_assoc(DevCtx d, int kind) {
   static_assert(LO_CH == 32, "a box is evaluated as two targets per lane of a 16-lane row");
   const int slot = blockIdx.y + d.slot0;
@@ -96,6 +103,7 @@ __global__ void __launch_bounds__(LO_BLOCK) lo_assoc(DevCtx d, int kind) {
   const int nch = (nt + LO_CH - 1) / LO_CH;
   const int* roff = d.ring_off + (((size_t)slot * 2 + last) * 2 + (kind == 0 ? 1 : 0)) * (d.NS + 1);
   const double* st = d.lo_state + (size_t)slot * LO_STATE_N;
+  LA_TICK(0);
   __shared__ float s_sel[LO_QPB][4];
   __shared__ double s_pose[12];
   __shared__ float4 s_box[2 * LO_BOX_LDS];   // the boxes are read by every query of the workgroup: LDS when they fit
@@ -129,6 +137,7 @@ __global__ void __launch_bounds__(LO_BLOCK) lo_assoc(DevCtx d, int kind) {
     s_sel[threadIdx.x][0] = o[0]; s_sel[threadIdx.x][1] = o[1]; s_sel[threadIdx.x][2] = o[2];
   }
   __syncthreads();
+  LA_TICK(1);
   const double nfd = d.P.nearest_feature_dist;
   const float INF = __int_as_float(0x7f800000);
   // rows beyond the last query redo the last one (the rows of a wavefront run in lock-step) and do not store
@@ -153,18 +162,21 @@ __global__ void __launch_bounds__(LO_BLOCK) lo_assoc(DevCtx d, int kind) {
       r += dx * dx; r += dy * dy; r += dz * dz;
       return r;
     };
-    // this lane's two targets of box c folded into its running (distance, index) minimum; c < 0: nothing
-    auto nn_eval = [&](int c, unsigned long long best) -> unsigned long long {
-      const int t0 = c * LO_CH + l16, t1 = t0 + 16;
-      const bool v0 = c >= 0 && t0 < nt, v1 = c >= 0 && t1 < nt;
-      const float4 a0 = tg[v0 ? t0 : 0], a1 = tg[v1 ? t1 : 0];   // both loads in flight
-      float r0 = 0.f, r1 = 0.f, df;
-      df = a0.x - sx; r0 += df * df; df = a0.y - sy; r0 += df * df; df = a0.z - sz; r0 += df * df;
-      df = a1.x - sx; r1 += df * df; df = a1.y - sy; r1 += df * df; df = a1.z - sz; r1 += df * df;
-      const unsigned long long k0 = ((unsigned long long)(uint32_t)d_f2i(r0) << 32) | (uint32_t)t0;
-      const unsigned long long k1 = ((unsigned long long)(uint32_t)d_f2i(r1) << 32) | (uint32_t)t1;
-      if (v0) best = k0 < best ? k0 : best;
-      if (v1) best = k1 < best ? k1 : best;
+    // this lane's two targets of each of the boxes ca, cb (< 0: none) folded into its running (distance, index) minimum;
+    // the four loads are issued together
+    auto nn_eval = [&](int ca, int cb, unsigned long long best) -> unsigned long long {
+      int t[4] = {ca * LO_CH + l16, ca * LO_CH + l16 + 16, cb * LO_CH + l16, cb * LO_CH + l16 + 16};
+      bool v[4] = {ca >= 0 && t[0] < nt, ca >= 0 && t[1] < nt, cb >= 0 && t[2] < nt, cb >= 0 && t[3] < nt};
+      float4 a[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) a[u] = tg[v[u] ? t[u] : 0];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        float r = 0.f, df;
+        df = a[u].x - sx; r += df * df; df = a[u].y - sy; r += df * df; df = a[u].z - sz; r += df * df;
+        const unsigned long long k = ((unsigned long long)(uint32_t)d_f2i(r) << 32) | (uint32_t)t[u];
+        if (v[u]) best = k < best ? k : best;
+      }
       return best;
     };
     unsigned long long m1 = ~0ull;
@@ -172,20 +184,24 @@ __global__ void __launch_bounds__(LO_BLOCK) lo_assoc(DevCtx d, int kind) {
       const unsigned long long k = ((unsigned long long)(uint32_t)d_f2i(lb_f32(c)) << 32) | (uint32_t)c;
       m1 = k < m1 ? k : m1;
     }
-    const int cs = (int)(uint32_t)row16_min_u64(m1);   // box with the smallest bound: nt > 0, so it exists
-    unsigned long long best = nn_eval(cs, ~0ull);
-    best = nn_eval((cs ^ 1) < nch ? (cs ^ 1) : -1, best);
+    const int cs = (int)(uint32_t)row16_min_u64(m1);
+    LA_TICK(2);   // box with the smallest bound: nt > 0, so it exists
+    unsigned long long best = nn_eval(cs, (cs ^ 1) < nch ? (cs ^ 1) : -1, ~0ull);
     const float bound = d_i2f((int32_t)(row16_min_u64(best) >> 32));
+    LA_TICK(3);
     for (int c0 = 0; c0 < nch; c0 += 16) {
       const int c = c0 + l16;
       uint32_t surv = row_bits(__ballot(lb_f32(c) <= bound && (c >> 1) != (cs >> 1)), lane);
-      while (__ballot(surv != 0)) {
+      while (__ballot(surv != 0)) {   // two surviving boxes per turn
         const int a = surv ? __ffs((int)surv) - 1 : -1;
         surv &= surv - 1;   // 0 stays 0
-        best = nn_eval(a >= 0 ? c0 + a : -1, best);
+        const int b = surv ? __ffs((int)surv) - 1 : -1;
+        surv &= surv - 1;
+        best = nn_eval(a >= 0 ? c0 + a : -1, b >= 0 ? c0 + b : -1, best);
       }
     }
     const unsigned long long bj = row16_min_u64(best);
+    LA_TICK(4);
     const bool found = (double)d_i2f((int32_t)(bj >> 32)) < nfd;
     if (found) closest = (int)(uint32_t)bj;
     // ---- ring walk; rows without a closest point walk an empty window
@@ -207,12 +223,14 @@ __global__ void __launch_bounds__(LO_BLOCK) lo_assoc(DevCtx d, int kind) {
       if (kind == 0) { if (same) walk_consider(b2, pd, rank, k); else walk_consider(b3, pd, rank, k); }
       else if (!same) walk_consider(b2, pd, rank, k);  // strictly above going up / strictly below going down (:446,:462)
     };
-    auto walk_eval = [&](int c) {
-      const int k0 = c * LO_CH + l16, k1 = k0 + 16;
-      const bool v0 = c >= 0 && k0 < nt, v1 = c >= 0 && k1 < nt;
-      const float4 a0 = tg[v0 ? k0 : 0], a1 = tg[v1 ? k1 : 0];
-      walk_one(k0, v0, a0);
-      walk_one(k1, v1, a1);
+    auto walk_eval = [&](int ca, int cb) {   // boxes ca, cb (< 0: none): four loads in flight
+      int k[4] = {ca * LO_CH + l16, ca * LO_CH + l16 + 16, cb * LO_CH + l16, cb * LO_CH + l16 + 16};
+      bool v[4] = {ca >= 0 && k[0] < nt, ca >= 0 && k[1] < nt, cb >= 0 && k[2] < nt, cb >= 0 && k[3] < nt};
+      float4 a[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) a[u] = tg[v[u] ? k[u] : 0];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) walk_one(k[u], v[u], a[u]);
     };
     // class S: same ring (surf only); class O: the other rings of the window.  A box may overlap both.
     const int cw0 = lo / LO_CH, cw1 = hi > lo ? (hi - 1) / LO_CH : -1;   // empty window: no box
@@ -241,11 +259,12 @@ __global__ void __launch_bounds__(LO_BLOCK) lo_assoc(DevCtx d, int kind) {
       }
     }
     mo = row16_min_u64(mo);
+    LA_TICK(5);
     const int cseedS = cw1 >= 0 ? closest / LO_CH : -1, cseedO = mo == ~0ull ? -1 : (int)(uint32_t)mo;
-    walk_eval(cseedS);
-    walk_eval(cseedO != cseedS ? cseedO : -1);
+    walk_eval(cseedS, cseedO != cseedS ? cseedO : -1);
     // class bounds after the seeds (an upper bound of the final minimum; nfd when nothing was found)
     const double boundS = __longlong_as_double((long long)row16_min_u64((unsigned long long)__double_as_longlong(kind == 0 ? b2.dist : nfd)));
+    LA_TICK(6);
     const double boundO = __longlong_as_double((long long)row16_min_u64((unsigned long long)__double_as_longlong(kind == 0 ? b3.dist : b2.dist)));
     for (int it = 0; __ballot(cw0 + it * 16 <= cw1); ++it) {
       const int c0 = cw0 + it * 16, c = c0 + l16;
@@ -260,13 +279,17 @@ __global__ void __launch_bounds__(LO_BLOCK) lo_assoc(DevCtx d, int kind) {
       while (__ballot(surv != 0)) {
         const int a = surv ? __ffs((int)surv) - 1 : -1;
         surv &= surv - 1;
-        walk_eval(a >= 0 ? c0 + a : -1);
+        const int b = surv ? __ffs((int)surv) - 1 : -1;
+        surv &= surv - 1;
+        walk_eval(a >= 0 ? c0 + a : -1, b >= 0 ? c0 + b : -1);
       }
     }
+    LA_TICK(7);
     b2 = walk_reduce_row(b2);
     idx2 = b2.idx;
     if (kind == 0) { b3 = walk_reduce_row(b3); idx3 = b3.idx; }
   }
+  LA_TICK(8);
   if (l16 == 0 && store) {
     int* row = d.lo_corr + ((size_t)slot * (d.lo_qcap_surf + d.lo_qcap_corner) + (kind == 0 ? 0 : d.lo_qcap_surf) + q) * 4;
     const bool ok = kind == 0 ? (idx2 >= 0 && idx3 >= 0) : (idx2 >= 0);
