@@ -66,6 +66,9 @@ DEV_INLINE WalkBest walk_reduce(WalkBest b) {
 //             the minimum of the double-precision distance per class, first visited on ties; here a lexicographic
 //             (distance, visiting rank) arg-min over the surviving boxes of the ring interval
 #define LO_QPB (LO_BLOCK / 16)
+#ifndef LO_NB
+#define LO_NB 2       // surviving boxes evaluated per turn (2 x LO_NB loads in flight per lane); 3: same, 4: slower
+#endif
 #define LO_BOX_LDS 512   // boxes (of LO_CH targets) staged in LDS: 16 KB
 DEV_INLINE WalkBest walk_reduce_row(WalkBest b) {
   const unsigned long long bits = (unsigned long long)__double_as_longlong(b.dist);
@@ -164,20 +167,27 @@ __global__ void __launch_bounds__(LO_BLOCK) lo_assoc(DevCtx d, int kind) {
     };
     // this lane's two targets of each of the boxes ca, cb (< 0: none) folded into its running (distance, index) minimum;
     // the four loads are issued together
-    auto nn_eval = [&](int ca, int cb, unsigned long long best) -> unsigned long long {
-      int t[4] = {ca * LO_CH + l16, ca * LO_CH + l16 + 16, cb * LO_CH + l16, cb * LO_CH + l16 + 16};
-      bool v[4] = {ca >= 0 && t[0] < nt, ca >= 0 && t[1] < nt, cb >= 0 && t[2] < nt, cb >= 0 && t[3] < nt};
-      float4 a[4];
+    auto nn_eval = [&](const int (&cb)[LO_NB], unsigned long long best) -> unsigned long long {
+      int t[2 * LO_NB];
+      bool v[2 * LO_NB];
+      float4 a[2 * LO_NB];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) a[u] = tg[v[u] ? t[u] : 0];
+      for (int u = 0; u < 2 * LO_NB; ++u) { t[u] = cb[u >> 1] * LO_CH + l16 + 16 * (u & 1); v[u] = cb[u >> 1] >= 0 && t[u] < nt; }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < 2 * LO_NB; ++u) a[u] = tg[v[u] ? t[u] : 0];
+#pragma unroll
+      for (int u = 0; u < 2 * LO_NB; ++u) {
         float r = 0.f, df;
         df = a[u].x - sx; r += df * df; df = a[u].y - sy; r += df * df; df = a[u].z - sz; r += df * df;
         const unsigned long long k = ((unsigned long long)(uint32_t)d_f2i(r) << 32) | (uint32_t)t[u];
         if (v[u]) best = k < best ? k : best;
       }
       return best;
+    };
+    // the next LO_NB set bits of a row's survivor mask as box indices (-1 when exhausted)
+    auto pop_boxes = [&](uint32_t& surv, int c0, int (&cb)[LO_NB]) {
+#pragma unroll
+      for (int u = 0; u < LO_NB; ++u) { cb[u] = surv ? c0 + __ffs((int)surv) - 1 : -1; surv &= surv - 1; }   // 0 stays 0
     };
     unsigned long long m1 = ~0ull;
     for (int c = l16; c < nch; c += 16) {
@@ -186,18 +196,17 @@ __global__ void __launch_bounds__(LO_BLOCK) lo_assoc(DevCtx d, int kind) {
     }
     const int cs = (int)(uint32_t)row16_min_u64(m1);
     LA_TICK(2);   // box with the smallest bound: nt > 0, so it exists
-    unsigned long long best = nn_eval(cs, (cs ^ 1) < nch ? (cs ^ 1) : -1, ~0ull);
+    unsigned long long best;
+    { int cb[LO_NB]; for (int u = 0; u < LO_NB; ++u) cb[u] = -1; cb[0] = cs; cb[1] = (cs ^ 1) < nch ? (cs ^ 1) : -1; best = nn_eval(cb, ~0ull); }
     const float bound = d_i2f((int32_t)(row16_min_u64(best) >> 32));
     LA_TICK(3);
     for (int c0 = 0; c0 < nch; c0 += 16) {
       const int c = c0 + l16;
       uint32_t surv = row_bits(__ballot(lb_f32(c) <= bound && (c >> 1) != (cs >> 1)), lane);
-      while (__ballot(surv != 0)) {   // two surviving boxes per turn
-        const int a = surv ? __ffs((int)surv) - 1 : -1;
-        surv &= surv - 1;   // 0 stays 0
-        const int b = surv ? __ffs((int)surv) - 1 : -1;
-        surv &= surv - 1;
-        best = nn_eval(a >= 0 ? c0 + a : -1, b >= 0 ? c0 + b : -1, best);
+      while (__ballot(surv != 0)) {   // LO_NB surviving boxes per turn
+        int cb[LO_NB];
+        pop_boxes(surv, c0, cb);
+        best = nn_eval(cb, best);
       }
     }
     const unsigned long long bj = row16_min_u64(best);
@@ -223,14 +232,16 @@ __global__ void __launch_bounds__(LO_BLOCK) lo_assoc(DevCtx d, int kind) {
       if (kind == 0) { if (same) walk_consider(b2, pd, rank, k); else walk_consider(b3, pd, rank, k); }
       else if (!same) walk_consider(b2, pd, rank, k);  // strictly above going up / strictly below going down (:446,:462)
     };
-    auto walk_eval = [&](int ca, int cb) {   // boxes ca, cb (< 0: none): four loads in flight
-      int k[4] = {ca * LO_CH + l16, ca * LO_CH + l16 + 16, cb * LO_CH + l16, cb * LO_CH + l16 + 16};
-      bool v[4] = {ca >= 0 && k[0] < nt, ca >= 0 && k[1] < nt, cb >= 0 && k[2] < nt, cb >= 0 && k[3] < nt};
-      float4 a[4];
+    auto walk_eval = [&](const int (&cb)[LO_NB]) {   // boxes cb[] (< 0: none): all their loads in flight together
+      int k[2 * LO_NB];
+      bool v[2 * LO_NB];
+      float4 a[2 * LO_NB];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) a[u] = tg[v[u] ? k[u] : 0];
+      for (int u = 0; u < 2 * LO_NB; ++u) { k[u] = cb[u >> 1] * LO_CH + l16 + 16 * (u & 1); v[u] = cb[u >> 1] >= 0 && k[u] < nt; }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) walk_one(k[u], v[u], a[u]);
+      for (int u = 0; u < 2 * LO_NB; ++u) a[u] = tg[v[u] ? k[u] : 0];
+#pragma unroll
+      for (int u = 0; u < 2 * LO_NB; ++u) walk_one(k[u], v[u], a[u]);
     };
     // class S: same ring (surf only); class O: the other rings of the window.  A box may overlap both.
     const int cw0 = lo / LO_CH, cw1 = hi > lo ? (hi - 1) / LO_CH : -1;   // empty window: no box
@@ -261,7 +272,7 @@ __global__ void __launch_bounds__(LO_BLOCK) lo_assoc(DevCtx d, int kind) {
     mo = row16_min_u64(mo);
     LA_TICK(5);
     const int cseedS = cw1 >= 0 ? closest / LO_CH : -1, cseedO = mo == ~0ull ? -1 : (int)(uint32_t)mo;
-    walk_eval(cseedS, cseedO != cseedS ? cseedO : -1);
+    { int cb[LO_NB]; for (int u = 0; u < LO_NB; ++u) cb[u] = -1; cb[0] = cseedS; cb[1] = cseedO != cseedS ? cseedO : -1; walk_eval(cb); }
     // class bounds after the seeds (an upper bound of the final minimum; nfd when nothing was found)
     const double boundS = __longlong_as_double((long long)row16_min_u64((unsigned long long)__double_as_longlong(kind == 0 ? b2.dist : nfd)));
     LA_TICK(6);
@@ -277,11 +288,9 @@ __global__ void __launch_bounds__(LO_BLOCK) lo_assoc(DevCtx d, int kind) {
       }
       uint32_t surv = row_bits(__ballot(take), lane);
       while (__ballot(surv != 0)) {
-        const int a = surv ? __ffs((int)surv) - 1 : -1;
-        surv &= surv - 1;
-        const int b = surv ? __ffs((int)surv) - 1 : -1;
-        surv &= surv - 1;
-        walk_eval(a >= 0 ? c0 + a : -1, b >= 0 ? c0 + b : -1);
+        int cb[LO_NB];
+        pop_boxes(surv, c0, cb);
+        walk_eval(cb);
       }
     }
     LA_TICK(7);
