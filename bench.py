@@ -87,12 +87,15 @@ def pmc_traffic(kernel, streams_per_launch):
         return None
 
 
-def gen_scans(p, n_streams, ring, rank):
+def load_streams(h, p, n_streams, ring, rank, chunk=32):
+    """Generate the synthetic scans of every stream and copy them into the handle's HBM ring, a chunk of streams at a
+    time (a whole rank's scans would be 17 GB of host memory at 1536 streams x 24 scans)."""
     ids = D.stream_ids(rank, n_streams)
-    jobs = [(s, k) for s in range(n_streams) for k in range(ring)]
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
-        out = list(ex.map(lambda sk: synth.scan(p, sk[1], stream=ids[sk[0]]), jobs))
-    return {sk: a for sk, a in zip(jobs, out)}
+        for s0 in range(0, n_streams, chunk):
+            jobs = [(s, k) for s in range(s0, min(s0 + chunk, n_streams)) for k in range(ring)]
+            for (s, k), a in zip(jobs, ex.map(lambda sk: synth.scan(p, sk[1], stream=ids[sk[0]]), jobs)):
+                h.batch_load(s, k, a)
 
 
 def quat_angle(q1, q2):
@@ -196,10 +199,7 @@ def main():
         p.recent_keyframe_num = args.keyframes
     B, R = args.streams, args.ring
     h = binding.Handle(p, device=local, n_slots=B, ring_len=R)
-    scans = gen_scans(p, B, R, rank)
-    for (s, k), a in scans.items():
-        h.batch_load(s, k, a)
-    del scans
+    load_streams(h, p, B, R, rank)
     stages = 7 | binding.REPLAY_PINGPONG
     step = 0
     h.batch_run(step, args.prime, stages); step += args.prime          # state priming (untimed, like loading a map)
