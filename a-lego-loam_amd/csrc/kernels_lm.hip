@@ -28,7 +28,7 @@ __global__ void __launch_bounds__(LM_BLOCK) lm_prepare(DevCtx d, LmCtx L, int st
   const int cur = d.scal[slot * SC_COUNT + SC_CUR];  // LO has completed: features of this scan
   int* li = lip(L, slot);
   const int* sc = d.scal + slot * SC_COUNT;
-  if (stage) {
+  if (stage && run_hint != 0) {   // run_hint == 0: the host knows that no slot of this launch maps this scan (odd frame)
     // (written with unconditional loads + selects: a 3-way if/else chain here was lowered by hipcc 7.2 into
     //  a scalar switch that left the count pointer of the last arm undefined)
     const size_t fb = (size_t)slot * 2 + cur;
@@ -737,7 +737,9 @@ int lm_configure() {
 
 // ---- launchers ---------------------------------------------------------------------
 void launch_lm_prepare(const DevCtx& d, const LmCtx& L, int stage, int run_hint, hipStream_t st) {
-  ALEGO_LAUNCH(lm_prepare, dim3(8, 3, d.n_launch), dim3(LM_BLOCK), 0, st, d, L, stage, run_hint);
+  // a frame that is not mapped only needs the odometry hand-over (one thread per slot)
+  const dim3 grid = run_hint == 0 ? dim3(1, 1, d.n_launch) : dim3(8, 3, d.n_launch);
+  ALEGO_LAUNCH(lm_prepare, grid, dim3(run_hint == 0 ? 64 : LM_BLOCK), 0, st, d, L, stage, run_hint);
 }
 void launch_lm_concat(const DevCtx& d, const LmCtx& L, hipStream_t st) {
   ALEGO_LAUNCH(lm_concat, dim3(2, L.K, d.n_launch), dim3(LM_BLOCK), 0, st, d, L);
