@@ -105,7 +105,10 @@ enum {
 
 #define DEV_INLINE __device__ __forceinline__
 
-#define LO_CH 32  // targets per bounding box of the LaserOdometry 1-NN / ring-walk pruning
+#ifndef LO_CH
+#define LO_CH 32
+#endif
+// LO_CH: targets per bounding box of the LaserOdometry 1-NN / ring-walk pruning
 
 // buffer written by the scan in flight (valid from fe_gather until lo_solve phase 1 flips SC_CUR)
 DEV_INLINE int cur_in_flight(const DevCtx& d, int slot) { return d.scal[slot * SC_COUNT + SC_CUR] ^ 1; }

@@ -69,7 +69,7 @@ DEV_INLINE WalkBest walk_reduce(WalkBest b) {
 #ifndef LO_NB
 #define LO_NB 2       // surviving boxes evaluated per turn (2 x LO_NB loads in flight per lane); 3: same, 4: slower
 #endif
-#define LO_BOX_LDS 512   // boxes (of LO_CH targets) staged in LDS: 16 KB
+#define LO_BOX_LDS (16384 / LO_CH)   // boxes (of LO_CH targets) staged in LDS: 512 boxes = 16 KB at 32 targets per box
 DEV_INLINE WalkBest walk_reduce_row(WalkBest b) {
   const unsigned long long bits = (unsigned long long)__double_as_longlong(b.dist);
   const unsigned long long mn = row16_min_u64(bits);
@@ -90,7 +90,8 @@ extern "C" void alego_la_times(long long* out) { (void)hipMemcpyFromSymbol(out, 
 #define LA_TICK(k)
 #endif
 __global__ void __launch_bounds__(LO_BLOCK) lo_assoc(DevCtx d, int kind) {
-  static_assert(LO_CH == 32, "a box is evaluated as two targets per lane of a 16-lane row");
+  static_assert(LO_CH % 16 == 0, "a box is evaluated as LO_CH / 16 targets per lane of a 16-lane row");
+  constexpr int TPL = LO_CH / 16;
   const int slot = blockIdx.y + d.slot0;
   const int cur = cur_in_flight(d, slot);
   const int* sc = d.scal + slot * SC_COUNT;
@@ -168,15 +169,15 @@ __global__ void __launch_bounds__(LO_BLOCK) lo_assoc(DevCtx d, int kind) {
     // this lane's two targets of each of the boxes ca, cb (< 0: none) folded into its running (distance, index) minimum;
     // the four loads are issued together
     auto nn_eval = [&](const int (&cb)[LO_NB], unsigned long long best) -> unsigned long long {
-      int t[2 * LO_NB];
-      bool v[2 * LO_NB];
-      float4 a[2 * LO_NB];
+      int t[TPL * LO_NB];
+      bool v[TPL * LO_NB];
+      float4 a[TPL * LO_NB];
 #pragma unroll
-      for (int u = 0; u < 2 * LO_NB; ++u) { t[u] = cb[u >> 1] * LO_CH + l16 + 16 * (u & 1); v[u] = cb[u >> 1] >= 0 && t[u] < nt; }
+      for (int u = 0; u < TPL * LO_NB; ++u) { t[u] = cb[u / TPL] * LO_CH + l16 + 16 * (u % TPL); v[u] = cb[u / TPL] >= 0 && t[u] < nt; }
 #pragma unroll
-      for (int u = 0; u < 2 * LO_NB; ++u) a[u] = tg[v[u] ? t[u] : 0];
+      for (int u = 0; u < TPL * LO_NB; ++u) a[u] = tg[v[u] ? t[u] : 0];
 #pragma unroll
-      for (int u = 0; u < 2 * LO_NB; ++u) {
+      for (int u = 0; u < TPL * LO_NB; ++u) {
         float r = 0.f, df;
         df = a[u].x - sx; r += df * df; df = a[u].y - sy; r += df * df; df = a[u].z - sz; r += df * df;
         const unsigned long long k = ((unsigned long long)(uint32_t)d_f2i(r) << 32) | (uint32_t)t[u];
@@ -233,15 +234,15 @@ __global__ void __launch_bounds__(LO_BLOCK) lo_assoc(DevCtx d, int kind) {
       else if (!same) walk_consider(b2, pd, rank, k);  // strictly above going up / strictly below going down (:446,:462)
     };
     auto walk_eval = [&](const int (&cb)[LO_NB]) {   // boxes cb[] (< 0: none): all their loads in flight together
-      int k[2 * LO_NB];
-      bool v[2 * LO_NB];
-      float4 a[2 * LO_NB];
+      int k[TPL * LO_NB];
+      bool v[TPL * LO_NB];
+      float4 a[TPL * LO_NB];
 #pragma unroll
-      for (int u = 0; u < 2 * LO_NB; ++u) { k[u] = cb[u >> 1] * LO_CH + l16 + 16 * (u & 1); v[u] = cb[u >> 1] >= 0 && k[u] < nt; }
+      for (int u = 0; u < TPL * LO_NB; ++u) { k[u] = cb[u / TPL] * LO_CH + l16 + 16 * (u % TPL); v[u] = cb[u / TPL] >= 0 && k[u] < nt; }
 #pragma unroll
-      for (int u = 0; u < 2 * LO_NB; ++u) a[u] = tg[v[u] ? k[u] : 0];
+      for (int u = 0; u < TPL * LO_NB; ++u) a[u] = tg[v[u] ? k[u] : 0];
 #pragma unroll
-      for (int u = 0; u < 2 * LO_NB; ++u) walk_one(k[u], v[u], a[u]);
+      for (int u = 0; u < TPL * LO_NB; ++u) walk_one(k[u], v[u], a[u]);
     };
     // class S: same ring (surf only); class O: the other rings of the window.  A box may overlap both.
     const int cw0 = lo / LO_CH, cw1 = hi > lo ? (hi - 1) / LO_CH : -1;   // empty window: no box
