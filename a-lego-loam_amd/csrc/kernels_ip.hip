@@ -645,6 +645,9 @@ __global__ void __launch_bounds__(CC_T) cc_lds16(DevCtx d, int ring_pos, int fus
     }
     if ((fused & 2) && v < N) d.parent[base + v] = rt[k];   // only ip_classify / ip_labels / debug read it
   }
+  unsigned long long self_m = 0;   // bit k: cell k is the root of its component; rt[] is dead from here on (registers)
+#pragma unroll
+  for (int k = 0; k < PER; ++k) if (rt[k] == (int)(threadIdx.x + k * CC_T)) self_m |= 1ull << k;
   CC_TICK(5);
   if (!(fused & 1)) return;  // ip_rowcount / ip_compact follow (launch_ip)
   // ---- fused a6: ordered compaction of the whole image (replaces ip_rowcount + ip_compact for this geometry).
@@ -667,7 +670,7 @@ __global__ void __launch_bounds__(CC_T) cc_lds16(DevCtx d, int ring_pos, int fus
       if (f & 1) c = (col % 5 == 0 || col <= 4 || col >= H - 5) ? 1 : 0;
       else if (f & 2) {
         const bool feas = (feas_m >> k) & 1ull;
-        fr = feas && rt[k] == v;
+        fr = feas && ((self_m >> k) & 1ull);
         c = feas ? 1 : ((row > P.ground_scan_id && col % 5 == 0) ? 2 : 0);
       }
     }
@@ -714,7 +717,7 @@ __global__ void __launch_bounds__(CC_T) cc_lds16(DevCtx d, int ring_pos, int fus
   const unsigned long long below = (1ull << lane) - 1ull;
   // batches of CB cells: owner indices, then the point gathers and ranges, then the stores — the loads of a batch are
   // independent of each other, so each batch costs two memory latencies instead of two per cell
-  constexpr int CB = 9;
+  constexpr int CB = 6;
   static_assert(PER % CB == 0, "cells per thread must be a multiple of the batch");
   for (int k0 = 0; k0 < PER; k0 += CB) {
     int own[CB];
@@ -758,7 +761,7 @@ __global__ void __launch_bounds__(CC_T) cc_lds16(DevCtx d, int ring_pos, int fus
         }
       }
       // label_cnt_ numbering (:303-306); 0 for the root of an infeasible component (ip_labels turns it into 999999)
-      if (rt[k] == v) d.cc_label[base + v] = fr ? s_cnt[2][k * NW + wave] + (int)__popcll(bf & below) + 1 : 0;
+      if ((self_m >> k) & 1ull) d.cc_label[base + v] = fr ? s_cnt[2][k * NW + wave] + (int)__popcll(bf & below) + 1 : 0;
     }
   }
   __syncthreads();
