@@ -230,8 +230,14 @@ __global__ void __launch_bounds__(LO_BLOCK) lo_assoc(DevCtx d, int kind) {
       // visiting order of the reference: closest+1, closest+2, ... then closest-1, closest-2, ...
       const int rank = k > closest ? k - closest - 1 : (hi - closest - 1) + (closest - 1 - k);
       const bool same = k >= same_lo && k < same_hi;
-      if (kind == 0) { if (same) walk_consider(b2, pd, rank, k); else walk_consider(b3, pd, rank, k); }
-      else if (!same) walk_consider(b2, pd, rank, k);  // strictly above going up / strictly below going down (:446,:462)
+      // surf: same ring -> b2, other rings -> b3; corner: other rings -> b2 (strictly above going up / strictly below going
+      // down, :446,:462).  Both updates are evaluated and committed by value: choosing the struct to update at run time
+      // is a select of addresses, which put b2 / b3 into scratch memory.
+      const bool to2 = kind == 0 ? same : !same, to3 = kind == 0 && !same;
+      const bool w2 = to2 && (pd < b2.dist || (pd == b2.dist && rank < b2.rank));
+      const bool w3 = to3 && (pd < b3.dist || (pd == b3.dist && rank < b3.rank));
+      b2.dist = w2 ? pd : b2.dist; b2.rank = w2 ? rank : b2.rank; b2.idx = w2 ? k : b2.idx;
+      b3.dist = w3 ? pd : b3.dist; b3.rank = w3 ? rank : b3.rank; b3.idx = w3 ? k : b3.idx;
     };
     auto walk_eval = [&](const int (&cb)[LO_NB]) {   // boxes cb[] (< 0: none): all their loads in flight together
       int k[TPL * LO_NB];
@@ -275,9 +281,14 @@ __global__ void __launch_bounds__(LO_BLOCK) lo_assoc(DevCtx d, int kind) {
     const int cseedS = cw1 >= 0 ? closest / LO_CH : -1, cseedO = mo == ~0ull ? -1 : (int)(uint32_t)mo;
     { int cb[LO_NB]; for (int u = 0; u < LO_NB; ++u) cb[u] = -1; cb[0] = cseedS; cb[1] = cseedO != cseedS ? cseedO : -1; walk_eval(cb); }
     // class bounds after the seeds (an upper bound of the final minimum; nfd when nothing was found)
-    const double boundS = __longlong_as_double((long long)row16_min_u64((unsigned long long)__double_as_longlong(kind == 0 ? b2.dist : nfd)));
+    // (values, not a conditional on the two structs: `c ? b3.dist : b2.dist` is a select of addresses and sent both structs
+    //  to scratch memory, in the middle of the hot loop)
+    const double seenS = b2.dist, seenO3 = b3.dist;
+    double inS = nfd, inO = seenS;
+    if (kind == 0) { inS = seenS; inO = seenO3; }
+    const double boundS = __longlong_as_double((long long)row16_min_u64((unsigned long long)__double_as_longlong(inS)));
     LA_TICK(6);
-    const double boundO = __longlong_as_double((long long)row16_min_u64((unsigned long long)__double_as_longlong(kind == 0 ? b3.dist : b2.dist)));
+    const double boundO = __longlong_as_double((long long)row16_min_u64((unsigned long long)__double_as_longlong(inO)));
     for (int it = 0; __ballot(cw0 + it * 16 <= cw1); ++it) {
       const int c0 = cw0 + it * 16, c = c0 + l16;
       bool take = false;
