@@ -97,7 +97,11 @@ __device__ void vox_big_job(const VoxCtx& V, int job) {
 #pragma unroll
     for (int w = 1; w < VG_W; ++w) { mn[a] = fminf(mn[a], s_red[a][w]); mx[a] = fmaxf(mx[a], s_red[3 + a][w]); }
   }
-  if (tid < 3) { unsigned* bb = V.bbox + job * 8; bb[tid] = vx_enc(mn[tid]); bb[4 + tid] = ~vx_enc(mx[tid]); }
+  if (tid < 3) {   // (selects, not mn[tid]: a dynamically indexed local array lives in scratch memory)
+    unsigned* bb = V.bbox + job * 8;
+    bb[tid] = vx_enc(tid == 0 ? mn[0] : tid == 1 ? mn[1] : mn[2]);
+    bb[4 + tid] = ~vx_enc(tid == 0 ? mx[0] : tid == 1 ? mx[1] : mx[2]);
+  }
   const long long dx = (long long)((mx[0] - mn[0]) * inv) + 1, dy = (long long)((mx[1] - mn[1]) * inv) + 1, dz = (long long)((mx[2] - mn[2]) * inv) + 1;
   if (dx * dy * dz > 2147483647LL) {  // PCL: "leaf size too small" -> output = input
     for (int i = tid; i < n; i += VG_T) J.out[i] = J.in[i];
@@ -328,7 +332,11 @@ __device__ void vox_small_job(const VoxCtx& V, int job) {
 #pragma unroll
     for (int w = 1; w < VX_SB / 64; ++w) { mn[a] = fminf(mn[a], s_red[a][w]); mx[a] = fmaxf(mx[a], s_red[3 + a][w]); }
   }
-  if (tid < 3) { unsigned* bb = V.bbox + job * 8; bb[tid] = vx_enc(mn[tid]); bb[4 + tid] = ~vx_enc(mx[tid]); }
+  if (tid < 3) {   // (selects, not mn[tid]: a dynamically indexed local array lives in scratch memory)
+    unsigned* bb = V.bbox + job * 8;
+    bb[tid] = vx_enc(tid == 0 ? mn[0] : tid == 1 ? mn[1] : mn[2]);
+    bb[4 + tid] = ~vx_enc(tid == 0 ? mx[0] : tid == 1 ? mx[1] : mx[2]);
+  }
   const long long dx = (long long)((mx[0] - mn[0]) * inv) + 1, dy = (long long)((mx[1] - mn[1]) * inv) + 1, dz = (long long)((mx[2] - mn[2]) * inv) + 1;
   if (dx * dy * dz > 2147483647LL) {  // PCL: "leaf size too small" -> output = input
     for (int i = tid; i < n; i += VX_SB) J.out[i] = J.in[i];
