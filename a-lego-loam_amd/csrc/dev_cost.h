@@ -194,12 +194,12 @@ DEV_INLINE double dpp_add_f64(double v) {   // v + (v of the lane selected by th
   const int plo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false), phi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
   return v + __longlong_as_double((long long)(((unsigned long long)(unsigned)phi << 32) | (unsigned)plo));
 }
-// T threads -> Q = T/4 partials per scalar after the quad step; G = Q/8 lanes per scalar (16 for 512 threads, 8 for 256)
+// T threads -> Q = T/4 partials per scalar after the quad step; G = Q/8 lanes per scalar (16 for 512 threads ... 2 for 64)
 // add 8 strided partials each and finish with log2(G) DPP steps inside their row: two barriers per reduction.
 template <int T>
 DEV_INLINE void block_reduce28_lds(const double acc[28], double* s_acc /*[28*T/4]*/, double* /*unused*/, double* s_out /*[28]*/) {
   constexpr int Q = T / 4, G = Q / 8;
-  static_assert(G == 8 || G == 16, "256 or 512 threads");
+  static_assert(G == 2 || G == 4 || G == 8 || G == 16, "64, 128, 256 or 512 threads");
   static_assert(28 * G <= T, "one lane group per scalar");
   const int tid = threadIdx.x;
 #pragma unroll
@@ -215,8 +215,8 @@ DEV_INLINE void block_reduce28_lds(const double acc[28], double* s_acc /*[28*T/4
 #pragma unroll
     for (int j = 0; j < 8; ++j) t += s_acc[k * Q + j * G + g];
     t = dpp_add_f64<0xB1>(t);
-    t = dpp_add_f64<0x4E>(t);
-    t = dpp_add_f64<0x141>(t);               // row_half_mirror: the two quads of an 8-lane group
+    if (G >= 4) t = dpp_add_f64<0x4E>(t);
+    if (G >= 8) t = dpp_add_f64<0x141>(t);   // row_half_mirror: the two quads of an 8-lane group
     if (G == 16) t = dpp_add_f64<0x140>(t);  // row_mirror: the two halves of a row
     if (g == 0) s_out[k] = t;
   }

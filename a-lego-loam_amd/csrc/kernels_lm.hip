@@ -15,7 +15,9 @@
 #include "lm_ctx.h"
 
 #define LM_BLOCK 256
+#ifndef LM_SOLVE_BLOCK
 #define LM_SOLVE_BLOCK 256
+#endif
 
 DEV_INLINE double* ldp(const LmCtx& L, int slot) { return L.ld + (size_t)slot * LD_COUNT; }
 DEV_INLINE int* lip(const LmCtx& L, int slot) { return L.li + (size_t)slot * LI_COUNT; }

@@ -13,6 +13,9 @@
 #include "prof.h"
 
 #define LO_BLOCK 256
+#ifndef LO_SOLVE_BLOCK
+#define LO_SOLVE_BLOCK 64    // threads of the per-stream solver workgroup (~300 rows): 64 measured 127 us per launch, 128: 133, 256: 199
+#endif
 
 // transformToStart (laserOdometry.cpp:728-740) = R(params_) * p + t.  R depends on the pose only, not on the point:
 // lo_solve caches it next to the pose (three fp64 sin/cos pairs are a thousand instructions), lo_assoc applies it.
@@ -326,7 +329,7 @@ DEV_INLINE void lo_eval_rows(const DevCtx& d, int slot, int cur, int kind, int n
   const float4* qpts = d.feat[qk] + ((size_t)slot * 2 + cur) * d.fcap[qk];
   const float4* tg = d.feat[tk] + ((size_t)slot * 2 + last) * d.fcap[tk];
   const int* rows = d.lo_corr + ((size_t)slot * (d.lo_qcap_surf + d.lo_qcap_corner) + (kind == 0 ? 0 : d.lo_qcap_surf)) * 4;
-  for (int i = threadIdx.x; i < n; i += LO_BLOCK) {
+  for (int i = threadIdx.x; i < n; i += LO_SOLVE_BLOCK) {
     const int4 r = *reinterpret_cast<const int4*>(rows + (size_t)i * 4);
     if (r.y < 0) continue;
     const float4 pc = qpts[r.x], pa = tg[r.y], pb = tg[r.z];
@@ -350,17 +353,17 @@ extern "C" void alego_lo_times(long long* out) { (void)hipMemcpyFromSymbol(out, 
 #define LO_T0
 #define LO_ACC(k)
 #endif
-__global__ void __launch_bounds__(LO_BLOCK) lo_solve(DevCtx d, int phase) {
+__global__ void __launch_bounds__(LO_SOLVE_BLOCK) lo_solve(DevCtx d, int phase) {
   const int slot = blockIdx.x + d.slot0;
   const int cur = cur_in_flight(d, slot);
   int* sc = d.scal + slot * SC_COUNT;
   double* st = d.lo_state + (size_t)slot * LO_STATE_N;
   extern __shared__ __attribute__((aligned(16))) unsigned char lo_smem[];
-  double* s_acc = reinterpret_cast<double*>(lo_smem);                // [28][LO_BLOCK]
-  double* s_seg = s_acc + 28 * (LO_BLOCK / 4);                        // [28][LO_BLOCK/128]
+  double* s_acc = reinterpret_cast<double*>(lo_smem);                // [28][LO_SOLVE_BLOCK]
+  double* s_seg = s_acc + 28 * (LO_SOLVE_BLOCK / 4);                        // [28][LO_SOLVE_BLOCK/128]
   __shared__ double s_out[28], s_trig[12];
   __shared__ LmState S;
-  __shared__ int s_action, s_cnt[LO_BLOCK / 64];
+  __shared__ int s_action, s_cnt[LO_SOLVE_BLOCK / 64];
   if (!sc[SC_LO_INIT]) {  // :316-324
     if (phase == 1 && threadIdx.x == 0) { sc[SC_LO_INIT] = 1; sc[SC_ODOM_VALID] = 0; sc[SC_LO_FLAGS] = 1; sc[SC_LO_NSURF] = 0; sc[SC_LO_NCORNER] = 0; sc[SC_CUR] = cur; }
     return;
@@ -376,14 +379,14 @@ __global__ void __launch_bounds__(LO_BLOCK) lo_solve(DevCtx d, int phase) {
     const int n = phase == 0 ? nq_s : nq_c;
     const int* rows = d.lo_corr + ((size_t)slot * (d.lo_qcap_surf + d.lo_qcap_corner) + (phase == 0 ? 0 : d.lo_qcap_surf)) * 4;
     int c = 0;
-    for (int i = threadIdx.x; i < n; i += LO_BLOCK) c += rows[(size_t)i * 4 + 1] >= 0;
+    for (int i = threadIdx.x; i < n; i += LO_SOLVE_BLOCK) c += rows[(size_t)i * 4 + 1] >= 0;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
     if (lane_id() == 0) s_cnt[threadIdx.x >> 6] = c;
     __syncthreads();
     if (threadIdx.x == 0) {
       int t = 0;
-      for (int w = 0; w < LO_BLOCK / 64; ++w) t += s_cnt[w];
+      for (int w = 0; w < LO_SOLVE_BLOCK / 64; ++w) t += s_cnt[w];
       s_cnt[0] = t;
       sc[phase == 0 ? SC_LO_NSURF : SC_LO_NCORNER] = t;
       if (phase == 0) sc[SC_LO_FLAGS] = 0;
@@ -401,7 +404,7 @@ __global__ void __launch_bounds__(LO_BLOCK) lo_solve(DevCtx d, int phase) {
       { LO_T0; T = pose_terms_coop(x, s_trig); LO_ACC(0); }
       { LO_T0; lo_eval_rows(d, slot, cur, 0, nq_s, T, acc);
         if (phase == 1) lo_eval_rows(d, slot, cur, 1, nq_c, T, acc); LO_ACC(1); }
-      { LO_T0; block_reduce28_lds<LO_BLOCK>(acc, s_acc, s_seg, s_out); LO_ACC(2); }
+      { LO_T0; block_reduce28_lds<LO_SOLVE_BLOCK>(acc, s_acc, s_seg, s_out); LO_ACC(2); }
     };
     double x0[6];
 #pragma unroll
@@ -469,14 +472,14 @@ __global__ void __launch_bounds__(LO_BLOCK) lo_solve(DevCtx d, int phase) {
 #endif
 }
 
-#define LO_SOLVE_LDS ((size_t)(28 * (LO_BLOCK / 4) + 28 * (LO_BLOCK / 128)) * sizeof(double))
+#define LO_SOLVE_LDS ((size_t)(28 * (LO_SOLVE_BLOCK / 4) + 28 * (LO_SOLVE_BLOCK / 128)) * sizeof(double))
 int lo_configure() {
   return hipFuncSetAttribute(reinterpret_cast<const void*>(lo_solve), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LO_SOLVE_LDS) == hipSuccess ? 0 : -1;
 }
 
 void launch_lo(const DevCtx& d, hipStream_t st) {
   ALEGO_LAUNCH(lo_assoc, dim3(std::min((d.lo_qcap_surf + LO_QPB - 1) / LO_QPB, 8), d.n_launch), dim3(LO_BLOCK), 0, st, d, 0);
-  ALEGO_LAUNCH(lo_solve, dim3(d.n_launch), dim3(LO_BLOCK), LO_SOLVE_LDS, st, d, 0);
+  ALEGO_LAUNCH(lo_solve, dim3(d.n_launch), dim3(LO_SOLVE_BLOCK), LO_SOLVE_LDS, st, d, 0);
   ALEGO_LAUNCH(lo_assoc, dim3(std::min((d.lo_qcap_corner + LO_QPB - 1) / LO_QPB, 12), d.n_launch), dim3(LO_BLOCK), 0, st, d, 1);
-  ALEGO_LAUNCH(lo_solve, dim3(d.n_launch), dim3(LO_BLOCK), LO_SOLVE_LDS, st, d, 1);
+  ALEGO_LAUNCH(lo_solve, dim3(d.n_launch), dim3(LO_SOLVE_BLOCK), LO_SOLVE_LDS, st, d, 1);
 }
