@@ -469,27 +469,34 @@ __global__ void __launch_bounds__(FE_BLOCK) fe_gather(DevCtx d) {
   const int* stk[3] = {st, st + d.cap_sharp, st + d.cap_sharp + d.cap_lsharp};
   const int* myc = allc + ring * 8;
   const float4* seg = d.seg_pts + base;
+  // A ring contributes at most a few hundred points per cloud: the first FE_BLOCK entries of the three index lists and
+  // the first 2 FE_BLOCK less_flat points are loaded together (one latency for all the indices, one for all the points);
+  // the loops behind only run for unusually large rings.
+  float4* dstk[3];
+  int* dstik[3];
+  int ixk[3];
+  float4 ptk[3], lf[2];
+  float4* dst_lf = d.feat[F_LFLAT] + ((size_t)slot * 2 + cur) * d.fcap[F_LFLAT] + s_off[3];
+  const float4* src_lf = d.st_lfds + ((size_t)slot * d.NS + ring) * d.H;
+  const int n_lf = myc[4];
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
-    float4* dst = d.feat[k] + ((size_t)slot * 2 + cur) * d.fcap[k] + s_off[k];
-    int* dsti = d.feat_idx[k] + ((size_t)slot * 2 + cur) * d.fcap[k] + s_off[k];
-    const int cnt_k = myc[k];
-    for (int i0 = tid; i0 < cnt_k; i0 += FE_BLOCK * 4) {   // index loads, then point gathers, four in flight
-      int ix[4];
-      float4 pt[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) ix[u] = stk[k][min(i0 + u * FE_BLOCK, cnt_k - 1)];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) pt[u] = seg[ix[u]];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) { const int i = i0 + u * FE_BLOCK; if (i < cnt_k) { dst[i] = pt[u]; dsti[i] = ix[u]; } }
-    }
+    dstk[k] = d.feat[k] + ((size_t)slot * 2 + cur) * d.fcap[k] + s_off[k];
+    dstik[k] = d.feat_idx[k] + ((size_t)slot * 2 + cur) * d.fcap[k] + s_off[k];
+    ixk[k] = tid < myc[k] ? stk[k][tid] : 0;
   }
-  {
-    float4* dst = d.feat[F_LFLAT] + ((size_t)slot * 2 + cur) * d.fcap[F_LFLAT] + s_off[3];
-    const float4* src = d.st_lfds + ((size_t)slot * d.NS + ring) * d.H;
-    for (int i = tid; i < myc[4]; i += FE_BLOCK) dst[i] = src[i];
-  }
+#pragma unroll
+  for (int u = 0; u < 2; ++u) lf[u] = tid + u * FE_BLOCK < n_lf ? src_lf[tid + u * FE_BLOCK] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) ptk[k] = seg[ixk[k]];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) if (tid < myc[k]) { dstk[k][tid] = ptk[k]; dstik[k][tid] = ixk[k]; }
+#pragma unroll
+  for (int u = 0; u < 2; ++u) if (tid + u * FE_BLOCK < n_lf) dst_lf[tid + u * FE_BLOCK] = lf[u];
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+    for (int i = tid + FE_BLOCK; i < myc[k]; i += FE_BLOCK) { const int idx = stk[k][i]; dstk[k][i] = seg[idx]; dstik[k][i] = idx; }
+  for (int i = tid + 2 * FE_BLOCK; i < n_lf; i += FE_BLOCK) dst_lf[i] = src_lf[i];
   if (tid == 0) {
     int* ro = d.ring_off + (((size_t)slot * 2 + cur) * 2) * (d.NS + 1);
     ro[ring] = s_off[1];
