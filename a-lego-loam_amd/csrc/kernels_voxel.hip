@@ -42,7 +42,9 @@ __device__ __forceinline__ bool vx_enabled(const VoxJob& J) { return J.enable ==
 //     digit is accumulated while scattering (the destination index tells the owning wavefront).
 //   4 voxel heads -> output ranks (ascending voxel id), list of run starts
 //   5 one thread per voxel: f32 sums in sorted (= original) order, divided by the count (pcl::CentroidPoint)
+#ifndef VG_T
 #define VG_T 1024
+#endif
 #define VG_W (VG_T / 64)
 #define VG_DMAX 9               // radix digit width: 2 x 16 x 512 counters = 64 KB of LDS
 #define VG_ND (1 << VG_DMAX)
