@@ -541,7 +541,8 @@ void launch_fe(const DevCtx& d, hipStream_t st) {
   ALEGO_LAUNCH(fe_curv, dim3((d.N + FE_CW - 1) / FE_CW, d.n_launch), dim3(FE_BLOCK), 0, st, d);
   // the longest sector holds at most ceil(H / n_sectors) + 1 points
   const int sector_max = (d.H + d.P.n_sectors - 1) / (d.P.n_sectors > 0 ? d.P.n_sectors : 1) + 2;
-  static const int extra = getenv("ALEGO_DBG_EXTRA_LDS") ? atoi(getenv("ALEGO_DBG_EXTRA_LDS")) : 0;
+  // (padding this allocation by 16 KB cost 7 % of the whole pipeline: the LDS footprint decides how many rings share a CU)
+  const int extra = 0;
   if (sector_max <= 64 * 6) { ALEGO_LAUNCH(fe_pick<6>, dim3(d.NS, d.n_launch), dim3(64), (size_t)3 * d.H + extra, st, d); }
   else { ALEGO_LAUNCH(fe_pick<12>, dim3(d.NS, d.n_launch), dim3(64), (size_t)3 * d.H, st, d); }
   ALEGO_LAUNCH(fe_voxel, dim3(d.NS, d.n_launch), dim3(FE_BLOCK), (size_t)10 * d.H, st, d);
