@@ -92,7 +92,8 @@ extern "C" void alego_la_times(long long* out) { (void)hipMemcpyFromSymbol(out, 
 #else
 #define LA_TICK(k)
 #endif
-__global__ void __launch_bounds__(LO_BLOCK) lo_assoc(DevCtx d, int kind) {
+template <int kind>   // compile-time: the corner association has one class of second points, the surf one two
+__global__ void __launch_bounds__(LO_BLOCK) lo_assoc(DevCtx d) {
   static_assert(LO_CH % 16 == 0, "a box is evaluated as LO_CH / 16 targets per lane of a 16-lane row");
   constexpr int TPL = LO_CH / 16;
   const int slot = blockIdx.y + d.slot0;
@@ -478,8 +479,8 @@ int lo_configure() {
 }
 
 void launch_lo(const DevCtx& d, hipStream_t st) {
-  ALEGO_LAUNCH(lo_assoc, dim3(std::min((d.lo_qcap_surf + LO_QPB - 1) / LO_QPB, 8), d.n_launch), dim3(LO_BLOCK), 0, st, d, 0);
+  ALEGO_LAUNCH(lo_assoc<0>, dim3(std::min((d.lo_qcap_surf + LO_QPB - 1) / LO_QPB, 8), d.n_launch), dim3(LO_BLOCK), 0, st, d);
   ALEGO_LAUNCH(lo_solve, dim3(d.n_launch), dim3(LO_SOLVE_BLOCK), LO_SOLVE_LDS, st, d, 0);
-  ALEGO_LAUNCH(lo_assoc, dim3(std::min((d.lo_qcap_corner + LO_QPB - 1) / LO_QPB, 12), d.n_launch), dim3(LO_BLOCK), 0, st, d, 1);
+  ALEGO_LAUNCH(lo_assoc<1>, dim3(std::min((d.lo_qcap_corner + LO_QPB - 1) / LO_QPB, 12), d.n_launch), dim3(LO_BLOCK), 0, st, d);
   ALEGO_LAUNCH(lo_solve, dim3(d.n_launch), dim3(LO_SOLVE_BLOCK), LO_SOLVE_LDS, st, d, 1);
 }
