@@ -158,6 +158,7 @@ int alego_create(const alego_params* params, int device, int n_slots, int ring_l
     d.tan_g_lo = ok ? std::tan(lo * M_PI / 180.0) : std::nan("");
     d.tan_g_hi = ok ? std::tan(hi * M_PI / 180.0) : std::nan("");
   }
+  d.h_magic = (unsigned)((1ull << 32) / (unsigned long long)d.H) + 1u;
   d.inv_res_x = 1.0 / params->ang_res_x; d.inv_res_y = 1.0 / params->ang_res_y;
   d.tan_theta = (params->seg_theta > 0.0 && params->seg_theta < 1.5) ? std::tan(params->seg_theta) : std::nan("");
   const size_t B = n_slots, N = d.N, NS = d.NS;

@@ -44,6 +44,7 @@ struct DevCtx {
   int cap_sharp, cap_lsharp, cap_flat;  // per-ring staging capacities: n_sharp*n_sectors, ...
   double sin_ax, cos_ax, sin_ay, cos_ay;  // sin/cos of seg_alpha_x / seg_alpha_y (host libm)
   double inv_res_x, inv_res_y;            // 1 / ang_res_x, 1 / ang_res_y (projection shortcut)
+  unsigned h_magic;                       // floor(2^32 / H) + 1: cell / H == umulhi(cell, h_magic) for every cell < 2^32 / H
   double tan_g_lo, tan_g_hi;              // tan of (sensor_mount_ang -/+ ground_angle_thres) (ground test shortcut; NaN disables)
   double tan_theta;                       // tan(seg_theta) for the edge predicate shortcut; NaN disables the shortcut
   // ---- input ring ----
@@ -109,6 +110,9 @@ enum {
 #define LO_CH 32
 #endif
 // LO_CH: targets per bounding box of the LaserOdometry 1-NN / ring-walk pruning
+
+// row of a cell index without an integer division (exact for v < 2^32 / H, i.e. for every supported image)
+DEV_INLINE int cell_row(const DevCtx& d, int v) { return (int)__umulhi((unsigned)v, d.h_magic); }
 
 // buffer written by the scan in flight (valid from fe_gather until lo_solve phase 1 flips SC_CUR)
 DEV_INLINE int cur_in_flight(const DevCtx& d, int slot) { return d.scal[slot * SC_COUNT + SC_CUR] ^ 1; }

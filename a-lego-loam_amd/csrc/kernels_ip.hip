@@ -203,7 +203,7 @@ __global__ void __launch_bounds__(IP_BLOCK) cc_edges(DevCtx d, int init) {
     const int v = blockIdx.x * IP_BLOCK * IP_PW + q * IP_BLOCK + threadIdx.x;
     vv[q] = v;
     const int vc = min(v, d.N - 1);
-    const int row = vc / d.H, col = vc - row * d.H;
+    const int row = cell_row(d, vc), col = vc - row * d.H;
     uu[q] = row * d.H + ((col + 1 == d.H) ? 0 : col + 1);   // right neighbour with column wrap-around (:241-248)
     const int w = row + 1 < d.NS ? vc + d.H : vc;
     f[q] = fimg[vc]; fu[q] = fimg[uu[q]]; fw[q] = fimg[w];
@@ -216,7 +216,7 @@ __global__ void __launch_bounds__(IP_BLOCK) cc_edges(DevCtx d, int init) {
     const bool active = f[q] & 2;
     uint8_t e = 0;
     if (active) {
-      const int row = v / d.H;
+      const int row = cell_row(d, v);
       const double r0 = (double)rv[q];
       if ((fu[q] & 2) && d.H > 1) {  // same row, seg_alpha_x (:258-261)
         const double r1 = (double)ru[q];
@@ -577,7 +577,7 @@ __global__ void __launch_bounds__(CC_T) cc_lds16(DevCtx d, int ring_pos, int fus
   CC_TICK(1);
   for (int k = 0; k < PER; ++k) {
     const int v = threadIdx.x + k * CC_T;
-    if (flag_of(k) & 4) { const int row = v / H, col = v - row * H; ccl16_union(par, v, row * H + (col + 1 == H ? 0 : col + 1)); }
+    if (flag_of(k) & 4) { const int row = cell_row(d, v), col = v - row * H; ccl16_union(par, v, row * H + (col + 1 == H ? 0 : col + 1)); }
   }
   __syncthreads();
   CC_TICK(2);
@@ -602,8 +602,8 @@ __global__ void __launch_bounds__(CC_T) cc_lds16(DevCtx d, int ring_pos, int fus
   for (int k = 0; k < PER; ++k) {
     const int v = threadIdx.x + k * CC_T;
     const int prev_rt = __shfl_up(rt[k], 1, 64);
-    const bool head = rt[k] >= 0 && (lane_ == 0 || prev_rt != rt[k] || (v % H) == 0);   // a new image row starts a run too
-    const unsigned long long starts = __ballot(lane_ == 0 || prev_rt != rt[k] || (v % H) == 0);  // run starts of any kind
+    const bool head = rt[k] >= 0 && (lane_ == 0 || prev_rt != rt[k] || (v - cell_row(d, v) * H) == 0);   // a new image row starts a run too
+    const unsigned long long starts = __ballot(lane_ == 0 || prev_rt != rt[k] || (v - cell_row(d, v) * H) == 0);  // run starts of any kind
     if (head) {
       head_m |= 1ull << k;
       const unsigned long long after = lane_ == 63 ? 0ull : (starts >> (lane_ + 1));
@@ -631,7 +631,7 @@ __global__ void __launch_bounds__(CC_T) cc_lds16(DevCtx d, int ring_pos, int fus
 #pragma unroll
   for (int k = 0; k < PER; ++k) {
     const int v = threadIdx.x + k * CC_T;
-    if ((head_m >> k) & 1ull) atomicOr(&packed[rt[k] >> 1], (1u << (v / H)) << ((rt[k] & 1) * 16));   // a run lies in one row
+    if ((head_m >> k) & 1ull) atomicOr(&packed[rt[k] >> 1], (1u << cell_row(d, v)) << ((rt[k] & 1) * 16));   // a run lies in one row
   }
   __syncthreads();
   unsigned long long feas_m = big_m;
@@ -666,7 +666,7 @@ __global__ void __launch_bounds__(CC_T) cc_lds16(DevCtx d, int ring_pos, int fus
     bool fr = false;
     if (v < N) {
       const unsigned f = flag_of(k);
-      const int row = v / H, col = v - row * H;
+      const int row = cell_row(d, v), col = v - row * H;
       if (f & 1) c = (col % 5 == 0 || col <= 4 || col >= H - 5) ? 1 : 0;
       else if (f & 2) {
         const bool feas = (feas_m >> k) & 1ull;
@@ -742,7 +742,7 @@ __global__ void __launch_bounds__(CC_T) cc_lds16(DevCtx d, int ring_pos, int fus
       const bool kp = (keep_m >> k) & 1ull, ol = (outl_m >> k) & 1ull, fr = (root_m >> k) & 1ull;
       const unsigned long long bk = __ballot(kp), bo = __ballot(ol), bf = __ballot(fr);
       if (v >= N) continue;
-      const int row = v / H, col = v - row * H;
+      const int row = cell_row(d, v), col = v - row * H;
       const int line = s_cnt[0][k * NW + wave] + (int)__popcll(bk & below);   // kept cells before this one
       if (col == 0) {   // ring convention of :161,:190
         d.ring_start[slot * d.NS + row] = line + 5;
