@@ -769,6 +769,224 @@ __global__ void __launch_bounds__(CC_T) cc_lds16(DevCtx d, int ring_pos, int fus
 }
 
 
+// Register-light variant of cc_lds16.  cc_lds16 keeps the root of each of a thread's 36 cells in registers and unrolls
+// every pass: 128 VGPRs x 1024 threads is the whole register file of a CU, so a workgroup can only start on an EMPTY CU
+// and nothing runs next to it.  Here the flattened roots stay in the LDS parent array (the statistics get their own
+// array: 116 KB of LDS instead of 58), the passes are plain loops and the per-cell state is a handful of 64-bit masks:
+// other streams' wavefronts share the CU.
+__global__ void __attribute__((amdgpu_waves_per_eu(8, 8))) __launch_bounds__(CC_T) cc_lds16b(DevCtx d, int ring_pos, int fused) {
+  const int slot = blockIdx.x + d.slot0;
+  const size_t base = (size_t)slot * d.N;
+  const int N = d.N, H = d.H, NWORD = (N + 1) / 2;
+  extern __shared__ __attribute__((aligned(16))) unsigned char cc_smem[];
+  uint16_t* par = reinterpret_cast<uint16_t*>(cc_smem);
+  unsigned* packed = reinterpret_cast<unsigned*>(cc_smem + 4 * (size_t)NWORD);   // behind the parent array
+  const uint8_t* fi = d.flag_img + base;
+  constexpr int PER = (CC_LDS_MAXN + CC_T - 1) / CC_T;
+  static_assert(PER <= 48, "three 64-bit words of 4-bit flags");
+  const int lane = lane_id(), wave = threadIdx.x >> 6;
+  unsigned long long f0 = 0, f1 = 0, f2 = 0;   // the 4 flag bits of this thread's cells, 16 cells per word
+#pragma unroll 1
+  for (int w = 0; w < 3; ++w) {   // (one word at a time: 16 loads in flight, not 36 64-bit addresses in registers)
+    unsigned long long acc = 0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int k = w * 16 + q, v = threadIdx.x + k * CC_T;
+      const unsigned long long f = (k < PER && v < N) ? (unsigned long long)(fi[v] & 15u) : 0ull;
+      acc |= f << (q * 4);
+    }
+    if (w == 0) f0 = acc; else if (w == 1) f1 = acc; else f2 = acc;
+  }
+  auto flag_of = [&](int k) -> unsigned { const unsigned long long w = k < 16 ? f0 : (k < 32 ? f1 : f2); return (unsigned)(w >> ((k & 15) * 4)) & 15u; };
+  for (int c = threadIdx.x; c < H; c += CC_T) {   // vertical runs (see cc_lds16)
+    unsigned fcol[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) fcol[r] = r < d.NS ? (unsigned)fi[r * H + c] : 0u;
+    int start = 0;
+    unsigned prev = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      if (r < d.NS) {
+        if (!(prev & 8)) start = r;
+        par[r * H + c] = (uint16_t)(((fcol[r] & 2) ? start : r) * H + c);
+        prev = fcol[r];
+      }
+    }
+  }
+  __syncthreads();
+#pragma unroll 1
+  for (int k = 0; k < PER; ++k) {
+    const int v = threadIdx.x + k * CC_T;
+    if (flag_of(k) & 4) { const int row = cell_row(d, v), col = v - row * H; ccl16_union(par, v, row * H + (col + 1 == H ? 0 : col + 1)); }
+  }
+  __syncthreads();
+  // flatten: par[v] = root.  Concurrent walkers see either the old parent or the root of a cell, both are ancestors.
+#pragma unroll 1
+  for (int k = 0; k < PER; ++k) {
+    const int v = threadIdx.x + k * CC_T;
+    if (flag_of(k) & 2) { int r = par[v], nx; while (r > (nx = par[r])) r = nx; par[v] = (uint16_t)r; }
+  }
+  for (int i = threadIdx.x; i < NWORD; i += CC_T) packed[i] = 0u;
+  __syncthreads();
+  const alego_params& P = d.P;
+  unsigned long long head_m = 0;
+#pragma unroll 1
+  for (int k = 0; k < PER; ++k) {   // component sizes: one atomic per run of equal roots in the wavefront
+    const int v = threadIdx.x + k * CC_T;
+    const int r = (flag_of(k) & 2) ? (int)par[v] : -1;
+    const int prev_r = __shfl_up(r, 1, 64);
+    const bool brk = lane == 0 || prev_r != r || (v - cell_row(d, v) * H) == 0;
+    const unsigned long long starts = __ballot(brk);
+    if (r >= 0 && brk) {
+      head_m |= 1ull << k;
+      const unsigned long long after = lane == 63 ? 0ull : (starts >> (lane + 1));
+      const int len = after ? __ffsll((long long)after) : 64 - lane;
+      atomicAdd(&packed[r >> 1], (unsigned)len << ((r & 1) * 16));
+    }
+  }
+  __syncthreads();
+  unsigned long long big_m = 0, mid_m = 0;
+#pragma unroll 1
+  for (int k = 0; k < PER; ++k) {
+    const int v = threadIdx.x + k * CC_T;
+    if (flag_of(k) & 2) {
+      const int r = par[v];
+      const int sz = (int)((packed[r >> 1] >> ((r & 1) * 16)) & 0xFFFFu);
+      if (sz >= P.seg_big_num) big_m |= 1ull << k;
+      else if (sz >= P.seg_valid_point_num) mid_m |= 1ull << k;
+      if (!(fused & 1) && r == v) d.cc_size[base + v] = sz;
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < NWORD; i += CC_T) packed[i] = 0u;
+  __syncthreads();
+#pragma unroll 1
+  for (int k = 0; k < PER; ++k) {   // rows touched by every component (a run lies in one row)
+    const int v = threadIdx.x + k * CC_T;
+    if ((head_m >> k) & 1ull) { const int r = par[v]; atomicOr(&packed[r >> 1], (1u << cell_row(d, v)) << ((r & 1) * 16)); }
+  }
+  __syncthreads();
+  unsigned long long feas_m = big_m, self_m = 0;
+#pragma unroll 1
+  for (int k = 0; k < PER; ++k) {
+    const int v = threadIdx.x + k * CC_T;
+    int r = -1;
+    if (flag_of(k) & 2) {
+      r = par[v];
+      const unsigned rows = (packed[r >> 1] >> ((r & 1) * 16)) & 0xFFFFu;
+      if (((mid_m >> k) & 1ull) && __popc(rows) >= P.seg_valid_line_num) feas_m |= 1ull << k;
+      if (r == v) self_m |= 1ull << k;
+      if (!(fused & 1) && r == v) d.cc_rows[base + v] = (unsigned long long)rows;
+    }
+    if ((fused & 2) && v < N) d.parent[base + v] = r;
+  }
+  if (!(fused & 1)) return;
+  // ---- ordered compaction (as cc_lds16)
+  constexpr int NW = CC_T / 64;
+  __shared__ int s_cnt[3][PER * NW];
+  __shared__ int s_wtot[3][NW];
+  unsigned long long keep_m = 0, outl_m = 0, root_m = 0;
+#pragma unroll 1
+  for (int k = 0; k < PER; ++k) {
+    const int v = threadIdx.x + k * CC_T;
+    int c = 0;
+    bool fr = false;
+    if (v < N) {
+      const unsigned f = flag_of(k);
+      const int row = cell_row(d, v), col = v - row * H;
+      if (f & 1) c = (col % 5 == 0 || col <= 4 || col >= H - 5) ? 1 : 0;
+      else if (f & 2) {
+        const bool feas = (feas_m >> k) & 1ull;
+        fr = feas && ((self_m >> k) & 1ull);
+        c = feas ? 1 : ((row > P.ground_scan_id && col % 5 == 0) ? 2 : 0);
+      }
+    }
+    if (c == 1) keep_m |= 1ull << k;
+    if (c == 2) outl_m |= 1ull << k;
+    if (fr) root_m |= 1ull << k;
+    const unsigned long long bk = __ballot(c == 1), bo = __ballot(c == 2), bf = __ballot(fr);
+    if (lane == 0) { s_cnt[0][k * NW + wave] = (int)__popcll(bk); s_cnt[1][k * NW + wave] = (int)__popcll(bo); s_cnt[2][k * NW + wave] = (int)__popcll(bf); }
+  }
+  __syncthreads();
+  {
+    const int e = threadIdx.x;
+    int v3[3], in3[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      v3[a] = e < PER * NW ? s_cnt[a][e] : 0;
+      int incl = v3[a];
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+      in3[a] = incl;
+      if (lane == 63) s_wtot[a][wave] = incl;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      int woff = 0;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) if (w < wave) woff += s_wtot[a][w];
+      if (e < PER * NW) s_cnt[a][e] = woff + in3[a] - v3[a];
+    }
+    if (threadIdx.x == 0) {
+      int t3[3] = {0, 0, 0};
+#pragma unroll
+      for (int a = 0; a < 3; ++a) for (int w = 0; w < NW; ++w) t3[a] += s_wtot[a][w];
+      int* sc = d.scal + slot * SC_COUNT;
+      sc[SC_M] = t3[0]; sc[SC_NOUT] = t3[1]; sc[SC_NFEAS] = t3[2];
+      d.ring_end[slot * d.NS + d.NS - 1] = t3[0] - 1 - 5;
+    }
+  }
+  __syncthreads();
+  const float4* pts = d.in_pts + ((size_t)slot * d.ring_len + ring_pos) * d.Pcap;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  constexpr int CB = 3;
+  static_assert(PER % CB == 0, "cells per thread must be a multiple of the batch");
+#pragma unroll 1
+  for (int k0 = 0; k0 < PER; k0 += CB) {
+    int own[CB];
+    float4 pt[CB];
+    float rg[CB];
+#pragma unroll
+    for (int b = 0; b < CB; ++b) {
+      const int k = k0 + b, v = threadIdx.x + k * CC_T;
+      own[b] = (((keep_m | outl_m) >> k) & 1ull) ? d.owner[base + v] : 0;
+    }
+#pragma unroll
+    for (int b = 0; b < CB; ++b) {
+      const int k = k0 + b, v = threadIdx.x + k * CC_T;
+      pt[b] = (((keep_m | outl_m) >> k) & 1ull) ? pts[own[b]] : make_float4(0.f, 0.f, 0.f, 0.f);
+      rg[b] = ((keep_m >> k) & 1ull) ? d.range_img[base + v] : 0.f;
+    }
+#pragma unroll
+    for (int b = 0; b < CB; ++b) {
+      const int k = k0 + b, v = threadIdx.x + k * CC_T;
+      const bool kp = (keep_m >> k) & 1ull, ol = (outl_m >> k) & 1ull, fr = (root_m >> k) & 1ull;
+      const unsigned long long bk = __ballot(kp), bo = __ballot(ol), bf = __ballot(fr);
+      if (v >= N) continue;
+      const int row = cell_row(d, v), col = v - row * H;
+      const int line = s_cnt[0][k * NW + wave] + (int)__popcll(bk & below);
+      if (col == 0) {
+        d.ring_start[slot * d.NS + row] = line + 5;
+        if (row > 0) d.ring_end[slot * d.NS + row - 1] = line - 1 - 5;
+      }
+      if (kp || ol) {
+        float4 p = pt[b];
+        p.w = (float)(row + col / 10000.0);
+        if (kp) {
+          d.seg_pts[base + line] = p;
+          d.seg_ground[base + line] = (uint8_t)(flag_of(k) & 1);
+          d.seg_col[base + line] = col;
+          d.seg_range[base + line] = rg[b];
+        } else {
+          d.outlier[base + s_cnt[1][k * NW + wave] + (int)__popcll(bo & below)] = p;
+        }
+      }
+      if ((self_m >> k) & 1ull) d.cc_label[base + v] = fr ? s_cnt[2][k * NW + wave] + (int)__popcll(bf & below) + 1 : 0;
+    }
+  }
+}
+
 __global__ void __launch_bounds__(IP_BLOCK) cc_stats(DevCtx d) {
   const int slot = blockIdx.y + d.slot0;
   const int v = blockIdx.x * IP_BLOCK + threadIdx.x;
@@ -955,7 +1173,11 @@ void launch_ip(const DevCtx& d, int ring_pos, bool want_labels, hipStream_t st) 
     // bit 0: fused compaction; bit 1: write the root image to HBM (only ip_classify, ip_labels and alego_debug_get read it:
     // the single-scan entry points keep it, the batch path does not)
     const int cc_flags = (fused ? 1 : 0) | ((!fused || want_labels || d.n_launch == 1) ? 2 : 0);
-    ALEGO_LAUNCH(cc_lds16, dim3(d.n_launch), dim3(CC_LDS_THREADS), (size_t)4 * ((d.N + 1) / 2), st, d, ring_pos, cc_flags);
+    // the register-light variant whenever its LDS fits (116 KB at 16x1800); ALEGO_CC_LIGHT=0 selects the register variant
+    static const bool light_env = !(getenv("ALEGO_CC_LIGHT") && atoi(getenv("ALEGO_CC_LIGHT")) == 0);
+    const bool light = light_env && (size_t)8 * ((d.N + 1) / 2) <= 150 * 1024;
+    if (light) { ALEGO_LAUNCH(cc_lds16b, dim3(d.n_launch), dim3(CC_LDS_THREADS), (size_t)8 * ((d.N + 1) / 2), st, d, ring_pos, cc_flags); }
+    else { ALEGO_LAUNCH(cc_lds16, dim3(d.n_launch), dim3(CC_LDS_THREADS), (size_t)4 * ((d.N + 1) / 2), st, d, ring_pos, cc_flags); }
   } else if (lds_cc) {
     ALEGO_LAUNCH(cc_lds, dim3(d.n_launch), dim3(CC_LDS_THREADS), (size_t)4 * d.N, st, d, ring_pos, 0);
   } else {
@@ -979,6 +1201,7 @@ int ip_configure(const DevCtx& d) {
   if (d.N <= CC_LDS_MAXN) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(cc_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * d.N) != hipSuccess) return -1;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(cc_lds16), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * ((d.N + 1) / 2)) != hipSuccess) return -1;
+    if (8 * ((d.N + 1) / 2) <= 150 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(cc_lds16b), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * ((d.N + 1) / 2)) != hipSuccess) return -1;
   }
   return 0;
 }
