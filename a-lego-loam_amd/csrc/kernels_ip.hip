@@ -1160,7 +1160,8 @@ __global__ void atan2f_probe(const float* y, const float* x, float* out, int n, 
 
 // ---- host-side launchers -------------------------------------------------------
 void launch_ip(const DevCtx& d, int ring_pos, bool want_labels, hipStream_t st) {
-  static const bool fuse_env = !(getenv("ALEGO_CC_FUSED") && atoi(getenv("ALEGO_CC_FUSED")) == 0);
+  const char* fe_ = getenv("ALEGO_CC_FUSED");   // (per call: the parity tests switch variants inside one process)
+  const bool fuse_env = !(fe_ && atoi(fe_) == 0);
   const bool fused = fuse_env && d.N <= CC_LDS_MAXN && d.NS <= 16;   // cc_lds also does the compaction
   const dim3 gN((d.N + IP_BLOCK - 1) / IP_BLOCK, d.n_launch);
   const dim3 gN4((d.N + IP_BLOCK * IP_PW - 1) / (IP_BLOCK * IP_PW), d.n_launch), gP4((d.Pcap + IP_BLOCK * IP_PW - 1) / (IP_BLOCK * IP_PW), d.n_launch);
@@ -1174,7 +1175,8 @@ void launch_ip(const DevCtx& d, int ring_pos, bool want_labels, hipStream_t st) 
     // the single-scan entry points keep it, the batch path does not)
     const int cc_flags = (fused ? 1 : 0) | ((!fused || want_labels || d.n_launch == 1) ? 2 : 0);
     // the register-light variant whenever its LDS fits (116 KB at 16x1800); ALEGO_CC_LIGHT=0 selects the register variant
-    static const bool light_env = !(getenv("ALEGO_CC_LIGHT") && atoi(getenv("ALEGO_CC_LIGHT")) == 0);
+    const char* le_ = getenv("ALEGO_CC_LIGHT");
+    const bool light_env = !(le_ && atoi(le_) == 0);
     const bool light = light_env && (size_t)8 * ((d.N + 1) / 2) <= 150 * 1024;
     if (light) { ALEGO_LAUNCH(cc_lds16b, dim3(d.n_launch), dim3(CC_LDS_THREADS), (size_t)8 * ((d.N + 1) / 2), st, d, ring_pos, cc_flags); }
     else { ALEGO_LAUNCH(cc_lds16, dim3(d.n_launch), dim3(CC_LDS_THREADS), (size_t)4 * ((d.N + 1) / 2), st, d, ring_pos, cc_flags); }

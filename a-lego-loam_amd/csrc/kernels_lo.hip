@@ -9,6 +9,7 @@
 //              shuffle + LDS reduction of the 21+6+1 normal-equation scalars in a fixed order, 6x6
 //              Cholesky by one lane, step acceptance, and (second call) the pose integration
 #include <algorithm>
+#include <cstdlib>
 #include "dev_cost.h"
 #include "prof.h"
 
@@ -93,7 +94,7 @@ extern "C" void alego_la_times(long long* out) { (void)hipMemcpyFromSymbol(out, 
 #define LA_TICK(k)
 #endif
 template <int kind>   // compile-time: the corner association has one class of second points, the surf one two
-__global__ void __launch_bounds__(LO_BLOCK) lo_assoc(DevCtx d) {
+__global__ void __launch_bounds__(LO_BLOCK) lo_assoc(DevCtx d, int box_lds_max) {
   static_assert(LO_CH % 16 == 0, "a box is evaluated as LO_CH / 16 targets per lane of a 16-lane row");
   constexpr int TPL = LO_CH / 16;
   const int slot = blockIdx.y + d.slot0;
@@ -116,7 +117,7 @@ __global__ void __launch_bounds__(LO_BLOCK) lo_assoc(DevCtx d) {
   __shared__ double s_pose[12];
   __shared__ float4 s_box[2 * LO_BOX_LDS];   // the boxes are read by every query of the workgroup: LDS when they fit
   __shared__ int s_roff[65];
-  const bool box_lds = nch <= LO_BOX_LDS;
+  const bool box_lds = nch <= box_lds_max;   // (<= LO_BOX_LDS; the parity tests also run with 0 = boxes straight from HBM)
   if (box_lds) for (int i = threadIdx.x; i < 2 * nch; i += LO_BLOCK) s_box[i] = bx[i];
   for (int i = threadIdx.x; i <= d.NS; i += LO_BLOCK) s_roff[i] = roff[i];
   if (threadIdx.x == 0) {
@@ -479,8 +480,10 @@ int lo_configure() {
 }
 
 void launch_lo(const DevCtx& d, hipStream_t st) {
-  ALEGO_LAUNCH(lo_assoc<0>, dim3(std::min((d.lo_qcap_surf + LO_QPB - 1) / LO_QPB, 8), d.n_launch), dim3(LO_BLOCK), 0, st, d);
+  const char* ble = getenv("ALEGO_LO_BOX_LDS");   // (read per call: the parity tests switch it inside one process)
+  const int box_lds_max = ble ? std::min(atoi(ble), (int)LO_BOX_LDS) : (int)LO_BOX_LDS;
+  ALEGO_LAUNCH(lo_assoc<0>, dim3(std::min((d.lo_qcap_surf + LO_QPB - 1) / LO_QPB, 8), d.n_launch), dim3(LO_BLOCK), 0, st, d, box_lds_max);
   ALEGO_LAUNCH(lo_solve, dim3(d.n_launch), dim3(LO_SOLVE_BLOCK), LO_SOLVE_LDS, st, d, 0);
-  ALEGO_LAUNCH(lo_assoc<1>, dim3(std::min((d.lo_qcap_corner + LO_QPB - 1) / LO_QPB, 12), d.n_launch), dim3(LO_BLOCK), 0, st, d);
+  ALEGO_LAUNCH(lo_assoc<1>, dim3(std::min((d.lo_qcap_corner + LO_QPB - 1) / LO_QPB, 12), d.n_launch), dim3(LO_BLOCK), 0, st, d, box_lds_max);
   ALEGO_LAUNCH(lo_solve, dim3(d.n_launch), dim3(LO_SOLVE_BLOCK), LO_SOLVE_LDS, st, d, 1);
 }

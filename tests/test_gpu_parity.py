@@ -31,8 +31,13 @@ def _ip_compare(h, o, pts, tag):
     return seg
 
 
-@pytest.mark.parametrize("geom", [(16, 1800), (16, 4000), (64, 2048)])
-def test_ip_bit_exact(geom):
+@pytest.mark.parametrize("geom,variant", [((16, 1800), None), ((16, 1800), "ALEGO_CC_LIGHT"), ((16, 1800), "ALEGO_CC_FUSED"),
+                                          ((16, 4000), None), ((64, 2048), None)])
+def test_ip_bit_exact(geom, variant, monkeypatch):
+    """ImageProjection bit for bit.  16x1800 runs the fused LDS kernel (cc_lds16b); <variant>=0 selects the register-resident
+    cc_lds16 / the separate ip_rowcount + ip_compact kernels; the larger geometries take the global-memory union-find."""
+    if variant:
+        monkeypatch.setenv(variant, "0")
     p = synth.default_params(*geom)
     h, o = binding.Handle(p), O.Oracle(p)
     for k in (0, 1, 150):
@@ -95,9 +100,12 @@ def _fe_compare(h, o, feat, tag):
         assert_bit_equal(feat[name], o.get(name), f"{tag} {name} cloud")
 
 
-@pytest.mark.parametrize("geom,nscan", [((16, 1800), 6), ((16, 4000), 3), ((64, 2048), 3)])
-def test_fe_lo_teacher_forced(geom, nscan):
-    """Each scan starts from the oracle's params_ (teacher forcing): indices exact, pose 1e-4."""
+@pytest.mark.parametrize("geom,nscan,box_lds", [((16, 1800), 6, None), ((16, 1800), 3, 0), ((16, 4000), 3, None), ((64, 2048), 3, None)])
+def test_fe_lo_teacher_forced(geom, nscan, box_lds, monkeypatch):
+    """Each scan starts from the oracle's params_ (teacher forcing): indices exact, pose 1e-4.  box_lds = 0 makes lo_assoc
+    read its bounding boxes from HBM (the path of feature clouds too large for the LDS staging)."""
+    if box_lds is not None:
+        monkeypatch.setenv("ALEGO_LO_BOX_LDS", str(box_lds))
     p = synth.default_params(*geom)
     h, o = binding.Handle(p), O.Oracle(p)
     for k in range(nscan):
