@@ -533,248 +533,18 @@ extern "C" void alego_cc_times(long long* out) { (void)hipMemcpyFromSymbol(out, 
 #define CC_TICK(k)
 #endif
 #define CC_T CC_LDS_THREADS   // (512-thread workgroups were measured: 188 k vs 203 k scans/s)
-__global__ void __launch_bounds__(CC_T) cc_lds16(DevCtx d, int ring_pos, int fused) {
-  const int slot = blockIdx.x + d.slot0;
-  const size_t base = (size_t)slot * d.N;
-  extern __shared__ __attribute__((aligned(16))) unsigned char cc_smem[];
-  uint16_t* par = reinterpret_cast<uint16_t*>(cc_smem);
-  unsigned* packed = reinterpret_cast<unsigned*>(cc_smem);   // the same bytes as [ceil(N/2)] words of two 16-bit counters
-  const uint8_t* fi = d.flag_img + base;
-  const int N = d.N, H = d.H, NWORD = (N + 1) / 2;
-  CC_TICK(0);
-  constexpr int PER = (CC_LDS_MAXN + CC_T - 1) / CC_T;
-  // the 4 flag bits of this thread's cells, all loads in flight together, packed 16 cells per register pair
-  unsigned long long flw[(PER + 15) / 16];
-#pragma unroll
-  for (int q = 0; q < (PER + 15) / 16; ++q) flw[q] = 0;
-#pragma unroll
-  for (int k = 0; k < PER; ++k) {
-    const int v = threadIdx.x + k * CC_T;
-    const unsigned f = v < N ? (unsigned)fi[v] & 15u : 0u;
-    flw[k >> 4] |= (unsigned long long)f << ((k & 15) * 4);
-  }
-  auto flag_of = [&](int k) -> unsigned { return (unsigned)(flw[k >> 4] >> ((k & 15) * 4)) & 15u; };
-  // Vertical neighbours (2 deg apart) pass the angle test far more often than horizontal ones (0.2 deg apart: a few cm of
-  // range difference already fail), so the components are mostly column strips.  One thread per column walks its rows
-  // bottom-up and gives every cell the start of its vertical run as parent (as cc_runs does on the global path): no
-  // atomics, and the union-find proper only has to process the right-edges.
-  for (int c = threadIdx.x; c < H; c += CC_T) {
-    unsigned fcol[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) fcol[r] = r < d.NS ? (unsigned)fi[r * H + c] : 0u;   // n_scan <= 16 on this path
-    int start = 0;
-    unsigned prev = 0;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      if (r < d.NS) {
-        if (!(prev & 8)) start = r;   // no down-edge from the row below: a new run begins here
-        par[r * H + c] = (uint16_t)(((fcol[r] & 2) ? start : r) * H + c);
-        prev = fcol[r];
-      }
-    }
-  }
-  __syncthreads();
-  CC_TICK(1);
-  for (int k = 0; k < PER; ++k) {
-    const int v = threadIdx.x + k * CC_T;
-    if (flag_of(k) & 4) { const int row = cell_row(d, v), col = v - row * H; ccl16_union(par, v, row * H + (col + 1 == H ? 0 : col + 1)); }
-  }
-  __syncthreads();
-  CC_TICK(2);
-  int rt[PER];
-#pragma unroll
-  for (int k = 0; k < PER; ++k) {
-    const int v = threadIdx.x + k * CC_T;
-    rt[k] = -1;
-    if (flag_of(k) & 2) { int r = par[v], nx; while (r > (nx = par[r])) r = nx; rt[k] = r; }
-  }
-  __syncthreads();
-  CC_TICK(3);
-  const alego_params& P = d.P;
-  // component sizes (:282-301)
-  for (int i = threadIdx.x; i < NWORD; i += CC_T) packed[i] = 0u;
-  __syncthreads();
-  // The 64 cells of a wavefront round are consecutive in a row and mostly belong to one or two components: a run of
-  // lanes with the same root sends one atomic (its length) instead of one per lane — same-address LDS atomics serialise.
-  const int lane_ = lane_id();
-  unsigned long long head_m = 0;   // bit k: this lane starts a run in round k
-#pragma unroll
-  for (int k = 0; k < PER; ++k) {
-    const int v = threadIdx.x + k * CC_T;
-    const int prev_rt = __shfl_up(rt[k], 1, 64);
-    const bool head = rt[k] >= 0 && (lane_ == 0 || prev_rt != rt[k] || (v - cell_row(d, v) * H) == 0);   // a new image row starts a run too
-    const unsigned long long starts = __ballot(lane_ == 0 || prev_rt != rt[k] || (v - cell_row(d, v) * H) == 0);  // run starts of any kind
-    if (head) {
-      head_m |= 1ull << k;
-      const unsigned long long after = lane_ == 63 ? 0ull : (starts >> (lane_ + 1));
-      const int len = after ? __ffsll((long long)after) : 64 - lane_;
-      atomicAdd(&packed[rt[k] >> 1], (unsigned)len << ((rt[k] & 1) * 16));
-    }
-  }
-  __syncthreads();
-  unsigned long long big_m = 0, mid_m = 0;
-#pragma unroll
-  for (int k = 0; k < PER; ++k) {
-    const int v = threadIdx.x + k * CC_T;
-    if (rt[k] >= 0) {
-      const int sz = (int)((packed[rt[k] >> 1] >> ((rt[k] & 1) * 16)) & 0xFFFFu);
-      if (sz >= P.seg_big_num) big_m |= 1ull << k;
-      else if (sz >= P.seg_valid_point_num) mid_m |= 1ull << k;
-      if (!(fused & 1) && rt[k] == v) d.cc_size[base + v] = sz;
-    }
-  }
-  __syncthreads();
-  CC_TICK(4);
-  // rows touched by every component
-  for (int i = threadIdx.x; i < NWORD; i += CC_T) packed[i] = 0u;
-  __syncthreads();
-#pragma unroll
-  for (int k = 0; k < PER; ++k) {
-    const int v = threadIdx.x + k * CC_T;
-    if ((head_m >> k) & 1ull) atomicOr(&packed[rt[k] >> 1], (1u << cell_row(d, v)) << ((rt[k] & 1) * 16));   // a run lies in one row
-  }
-  __syncthreads();
-  unsigned long long feas_m = big_m;
-#pragma unroll
-  for (int k = 0; k < PER; ++k) {
-    const int v = threadIdx.x + k * CC_T;
-    if (rt[k] >= 0) {
-      const unsigned rows = (packed[rt[k] >> 1] >> ((rt[k] & 1) * 16)) & 0xFFFFu;
-      if (((mid_m >> k) & 1ull) && __popc(rows) >= P.seg_valid_line_num) feas_m |= 1ull << k;
-      if (!(fused & 1) && rt[k] == v) d.cc_rows[base + v] = (unsigned long long)rows;
-    }
-    if ((fused & 2) && v < N) d.parent[base + v] = rt[k];   // only ip_classify / ip_labels / debug read it
-  }
-  unsigned long long self_m = 0;   // bit k: cell k is the root of its component; rt[] is dead from here on (registers)
-#pragma unroll
-  for (int k = 0; k < PER; ++k) if (rt[k] == (int)(threadIdx.x + k * CC_T)) self_m |= 1ull << k;
-  CC_TICK(5);
-  if (!(fused & 1)) return;  // ip_rowcount / ip_compact follow (launch_ip)
-  // ---- fused a6: ordered compaction of the whole image (replaces ip_rowcount + ip_compact for this geometry).
-  // Chunk k = cells [1024 k, 1024 k + 1024) in row-major order, one cell per thread: per-(chunk, wavefront) counts of
-  // kept cells / outliers / feasible roots, one exclusive scan over the (chunk, wavefront) table, then every cell
-  // knows its output line.  Classification as ip_classify, with the component statistics still in LDS.
-  constexpr int NW = CC_T / 64;
-  __shared__ int s_cnt[3][PER * NW];
-  __shared__ int s_wtot[3][NW];
-  const int lane = lane_id(), wave = threadIdx.x >> 6;
-  unsigned long long keep_m = 0, outl_m = 0, root_m = 0;
-#pragma unroll
-  for (int k = 0; k < PER; ++k) {
-    const int v = threadIdx.x + k * CC_T;
-    int c = 0;
-    bool fr = false;
-    if (v < N) {
-      const unsigned f = flag_of(k);
-      const int row = cell_row(d, v), col = v - row * H;
-      if (f & 1) c = (col % 5 == 0 || col <= 4 || col >= H - 5) ? 1 : 0;
-      else if (f & 2) {
-        const bool feas = (feas_m >> k) & 1ull;
-        fr = feas && ((self_m >> k) & 1ull);
-        c = feas ? 1 : ((row > P.ground_scan_id && col % 5 == 0) ? 2 : 0);
-      }
-    }
-    if (c == 1) keep_m |= 1ull << k;
-    if (c == 2) outl_m |= 1ull << k;
-    if (fr) root_m |= 1ull << k;
-    const unsigned long long bk = __ballot(c == 1), bo = __ballot(c == 2), bf = __ballot(fr);
-    if (lane == 0) { s_cnt[0][k * NW + wave] = (int)__popcll(bk); s_cnt[1][k * NW + wave] = (int)__popcll(bo); s_cnt[2][k * NW + wave] = (int)__popcll(bf); }
-  }
-  __syncthreads();
-  CC_TICK(6);
-  {  // exclusive scan of the three count tables (PER * NW <= 1024 entries: one per thread)
-    const int e = threadIdx.x;
-    int v3[3], in3[3];
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      v3[a] = e < PER * NW ? s_cnt[a][e] : 0;
-      int incl = v3[a];
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
-      in3[a] = incl;
-      if (lane == 63) s_wtot[a][wave] = incl;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      int woff = 0;
-#pragma unroll
-      for (int w = 0; w < NW; ++w) if (w < wave) woff += s_wtot[a][w];
-      if (e < PER * NW) s_cnt[a][e] = woff + in3[a] - v3[a];
-    }
-    if (threadIdx.x == 0) {
-      int t3[3] = {0, 0, 0};
-#pragma unroll
-      for (int a = 0; a < 3; ++a) for (int w = 0; w < NW; ++w) t3[a] += s_wtot[a][w];
-      int* sc = d.scal + slot * SC_COUNT;
-      sc[SC_M] = t3[0]; sc[SC_NOUT] = t3[1]; sc[SC_NFEAS] = t3[2];
-      d.ring_end[slot * d.NS + d.NS - 1] = t3[0] - 1 - 5;   // :190 for the last row
-    }
-  }
-  __syncthreads();
-  CC_TICK(7);
-  const float4* pts = d.in_pts + ((size_t)slot * d.ring_len + ring_pos) * d.Pcap;
-  const unsigned long long below = (1ull << lane) - 1ull;
-  // batches of CB cells: owner indices, then the point gathers and ranges, then the stores — the loads of a batch are
-  // independent of each other, so each batch costs two memory latencies instead of two per cell
-  constexpr int CB = 6;
-  static_assert(PER % CB == 0, "cells per thread must be a multiple of the batch");
-  for (int k0 = 0; k0 < PER; k0 += CB) {
-    int own[CB];
-#pragma unroll
-    for (int b = 0; b < CB; ++b) {
-      const int k = k0 + b, v = threadIdx.x + k * CC_T;
-      const bool any = ((keep_m | outl_m) >> k) & 1ull;
-      own[b] = any ? d.owner[base + v] : 0;
-    }
-    float4 pt[CB];
-    float rg[CB];
-#pragma unroll
-    for (int b = 0; b < CB; ++b) {
-      const int k = k0 + b, v = threadIdx.x + k * CC_T;
-      const bool any = ((keep_m | outl_m) >> k) & 1ull;
-      pt[b] = any ? pts[own[b]] : make_float4(0.f, 0.f, 0.f, 0.f);
-      rg[b] = ((keep_m >> k) & 1ull) ? d.range_img[base + v] : 0.f;
-    }
-#pragma unroll
-    for (int b = 0; b < CB; ++b) {
-      const int k = k0 + b, v = threadIdx.x + k * CC_T;
-      const bool kp = (keep_m >> k) & 1ull, ol = (outl_m >> k) & 1ull, fr = (root_m >> k) & 1ull;
-      const unsigned long long bk = __ballot(kp), bo = __ballot(ol), bf = __ballot(fr);
-      if (v >= N) continue;
-      const int row = cell_row(d, v), col = v - row * H;
-      const int line = s_cnt[0][k * NW + wave] + (int)__popcll(bk & below);   // kept cells before this one
-      if (col == 0) {   // ring convention of :161,:190
-        d.ring_start[slot * d.NS + row] = line + 5;
-        if (row > 0) d.ring_end[slot * d.NS + row - 1] = line - 1 - 5;
-      }
-      if (kp || ol) {
-        float4 p = pt[b];
-        p.w = (float)(row + col / 10000.0);  // :101
-        if (kp) {
-          d.seg_pts[base + line] = p;
-          d.seg_ground[base + line] = (uint8_t)(flag_of(k) & 1);
-          d.seg_col[base + line] = col;
-          d.seg_range[base + line] = rg[b];
-        } else {
-          d.outlier[base + s_cnt[1][k * NW + wave] + (int)__popcll(bo & below)] = p;
-        }
-      }
-      // label_cnt_ numbering (:303-306); 0 for the root of an infeasible component (ip_labels turns it into 999999)
-      if ((self_m >> k) & 1ull) d.cc_label[base + v] = fr ? s_cnt[2][k * NW + wave] + (int)__popcll(bf & below) + 1 : 0;
-    }
-  }
-  __syncthreads();
-  CC_TICK(8);
-}
-
-
-// Register-light variant of cc_lds16.  cc_lds16 keeps the root of each of a thread's 36 cells in registers and unrolls
-// every pass: 128 VGPRs x 1024 threads is the whole register file of a CU, so a workgroup can only start on an EMPTY CU
-// and nothing runs next to it.  Here the flattened roots stay in the LDS parent array (the statistics get their own
-// array: 116 KB of LDS instead of 58), the passes are plain loops and the per-cell state is a handful of 64-bit masks:
-// other streams' wavefronts share the CU.
-__global__ void __attribute__((amdgpu_waves_per_eu(8, 8))) __launch_bounds__(CC_T) cc_lds16b(DevCtx d, int ring_pos, int fused) {
+// One workgroup per stream: column runs, union-find over the right-edges, component statistics, feasibility, and the
+// ordered compaction of the whole image (a6: replaces ip_rowcount + ip_compact for this geometry).
+// Register-light on purpose.  A first version kept the root of each of a thread's 36 cells in registers and unrolled every
+// pass: 128 VGPRs x 1024 threads is the whole register file of a CU, so a workgroup could only start on an EMPTY CU and
+// nothing ran next to it (the pipeline gained 3 % when it was replaced although the kernel itself takes as long).  Here
+// the flattened roots stay in the LDS parent array (the statistics get their own array: 4 B/cell of LDS in total), the
+// passes are plain loops over the thread's cells and the per-cell state is a handful of 64-bit masks: 64 VGPRs, other
+// streams' wavefronts share the CU.
+// Compaction: chunk k = cells [1024 k, 1024 k + 1024) in row-major order, one cell per thread: per-(chunk, wavefront)
+// counts of kept cells / outliers / feasible roots, one exclusive scan over the (chunk, wavefront) table, then every cell
+// knows its output line.  Classification as ip_classify.
+__global__ void __attribute__((amdgpu_waves_per_eu(8, 8))) __launch_bounds__(CC_T) cc_lds16(DevCtx d, int ring_pos, int fused) {
   const int slot = blockIdx.x + d.slot0;
   const size_t base = (size_t)slot * d.N;
   const int N = d.N, H = d.H, NWORD = (N + 1) / 2;
@@ -785,6 +555,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(8, 8))) __launch_bounds__(CC_
   constexpr int PER = (CC_LDS_MAXN + CC_T - 1) / CC_T;
   static_assert(PER <= 48, "three 64-bit words of 4-bit flags");
   const int lane = lane_id(), wave = threadIdx.x >> 6;
+  CC_TICK(0);
   unsigned long long f0 = 0, f1 = 0, f2 = 0;   // the 4 flag bits of this thread's cells, 16 cells per word
 #pragma unroll 1
   for (int w = 0; w < 3; ++w) {   // (one word at a time: 16 loads in flight, not 36 64-bit addresses in registers)
@@ -798,7 +569,11 @@ __global__ void __attribute__((amdgpu_waves_per_eu(8, 8))) __launch_bounds__(CC_
     if (w == 0) f0 = acc; else if (w == 1) f1 = acc; else f2 = acc;
   }
   auto flag_of = [&](int k) -> unsigned { const unsigned long long w = k < 16 ? f0 : (k < 32 ? f1 : f2); return (unsigned)(w >> ((k & 15) * 4)) & 15u; };
-  for (int c = threadIdx.x; c < H; c += CC_T) {   // vertical runs (see cc_lds16)
+  // Vertical neighbours (2 deg apart) pass the angle test far more often than horizontal ones (0.2 deg apart: a few cm of
+  // range difference already fail), so the components are mostly column strips.  One thread per column walks its rows
+  // bottom-up and gives every cell the start of its vertical run as parent (as cc_runs does on the global path): no
+  // atomics, and the union-find proper only has to process the right-edges.
+  for (int c = threadIdx.x; c < H; c += CC_T) {
     unsigned fcol[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) fcol[r] = r < d.NS ? (unsigned)fi[r * H + c] : 0u;
@@ -814,12 +589,14 @@ __global__ void __attribute__((amdgpu_waves_per_eu(8, 8))) __launch_bounds__(CC_
     }
   }
   __syncthreads();
+  CC_TICK(1);
 #pragma unroll 1
   for (int k = 0; k < PER; ++k) {
     const int v = threadIdx.x + k * CC_T;
     if (flag_of(k) & 4) { const int row = cell_row(d, v), col = v - row * H; ccl16_union(par, v, row * H + (col + 1 == H ? 0 : col + 1)); }
   }
   __syncthreads();
+  CC_TICK(2);
   // flatten: par[v] = root.  Concurrent walkers see either the old parent or the root of a cell, both are ancestors.
 #pragma unroll 1
   for (int k = 0; k < PER; ++k) {
@@ -828,6 +605,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(8, 8))) __launch_bounds__(CC_
   }
   for (int i = threadIdx.x; i < NWORD; i += CC_T) packed[i] = 0u;
   __syncthreads();
+  CC_TICK(3);
   const alego_params& P = d.P;
   unsigned long long head_m = 0;
 #pragma unroll 1
@@ -858,6 +636,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(8, 8))) __launch_bounds__(CC_
     }
   }
   __syncthreads();
+  CC_TICK(4);
   for (int i = threadIdx.x; i < NWORD; i += CC_T) packed[i] = 0u;
   __syncthreads();
 #pragma unroll 1
@@ -880,8 +659,9 @@ __global__ void __attribute__((amdgpu_waves_per_eu(8, 8))) __launch_bounds__(CC_
     }
     if ((fused & 2) && v < N) d.parent[base + v] = r;
   }
+  CC_TICK(5);
   if (!(fused & 1)) return;
-  // ---- ordered compaction (as cc_lds16)
+  // ---- ordered compaction
   constexpr int NW = CC_T / 64;
   __shared__ int s_cnt[3][PER * NW];
   __shared__ int s_wtot[3][NW];
@@ -908,6 +688,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(8, 8))) __launch_bounds__(CC_
     if (lane == 0) { s_cnt[0][k * NW + wave] = (int)__popcll(bk); s_cnt[1][k * NW + wave] = (int)__popcll(bo); s_cnt[2][k * NW + wave] = (int)__popcll(bf); }
   }
   __syncthreads();
+  CC_TICK(6);
   {
     const int e = threadIdx.x;
     int v3[3], in3[3];
@@ -938,6 +719,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(8, 8))) __launch_bounds__(CC_
     }
   }
   __syncthreads();
+  CC_TICK(7);
   const float4* pts = d.in_pts + ((size_t)slot * d.ring_len + ring_pos) * d.Pcap;
   const unsigned long long below = (1ull << lane) - 1ull;
   constexpr int CB = 3;
@@ -985,6 +767,8 @@ __global__ void __attribute__((amdgpu_waves_per_eu(8, 8))) __launch_bounds__(CC_
       if ((self_m >> k) & 1ull) d.cc_label[base + v] = fr ? s_cnt[2][k * NW + wave] + (int)__popcll(bf & below) + 1 : 0;
     }
   }
+  __syncthreads();
+  CC_TICK(8);
 }
 
 __global__ void __launch_bounds__(IP_BLOCK) cc_stats(DevCtx d) {
@@ -1174,12 +958,7 @@ void launch_ip(const DevCtx& d, int ring_pos, bool want_labels, hipStream_t st) 
     // bit 0: fused compaction; bit 1: write the root image to HBM (only ip_classify, ip_labels and alego_debug_get read it:
     // the single-scan entry points keep it, the batch path does not)
     const int cc_flags = (fused ? 1 : 0) | ((!fused || want_labels || d.n_launch == 1) ? 2 : 0);
-    // the register-light variant whenever its LDS fits (116 KB at 16x1800); ALEGO_CC_LIGHT=0 selects the register variant
-    const char* le_ = getenv("ALEGO_CC_LIGHT");
-    const bool light_env = !(le_ && atoi(le_) == 0);
-    const bool light = light_env && (size_t)8 * ((d.N + 1) / 2) <= 150 * 1024;
-    if (light) { ALEGO_LAUNCH(cc_lds16b, dim3(d.n_launch), dim3(CC_LDS_THREADS), (size_t)8 * ((d.N + 1) / 2), st, d, ring_pos, cc_flags); }
-    else { ALEGO_LAUNCH(cc_lds16, dim3(d.n_launch), dim3(CC_LDS_THREADS), (size_t)4 * ((d.N + 1) / 2), st, d, ring_pos, cc_flags); }
+    ALEGO_LAUNCH(cc_lds16, dim3(d.n_launch), dim3(CC_LDS_THREADS), (size_t)8 * ((d.N + 1) / 2), st, d, ring_pos, cc_flags);
   } else if (lds_cc) {
     ALEGO_LAUNCH(cc_lds, dim3(d.n_launch), dim3(CC_LDS_THREADS), (size_t)4 * d.N, st, d, ring_pos, 0);
   } else {
@@ -1202,8 +981,7 @@ void launch_atan2f_probe(const float* y, const float* x, float* out, int n, int 
 int ip_configure(const DevCtx& d) {
   if (d.N <= CC_LDS_MAXN) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(cc_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * d.N) != hipSuccess) return -1;
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(cc_lds16), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * ((d.N + 1) / 2)) != hipSuccess) return -1;
-    if (8 * ((d.N + 1) / 2) <= 150 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(cc_lds16b), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * ((d.N + 1) / 2)) != hipSuccess) return -1;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(cc_lds16), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * ((d.N + 1) / 2)) != hipSuccess) return -1;   // <= 147 KB
   }
   return 0;
 }

@@ -55,9 +55,8 @@ def kernel_bytes(name, c, NS, H, rebuilds_per_launch=0.0):
     t = {
         "ip_reset": 4 * N, "ip_project": 16 * P + 4 * P, "ip_image": 4 * N + 16 * P + 5 * N,
         "cc_edges": 5 * N + 17 * N, "cc_lds": N + 4 * N + 12 * N,
-        # cc_lds16(b): flags, owner, points + range in; cloud_info arrays + outliers out
+        # cc_lds16: flags, owner, points + range in; cloud_info arrays + outliers out
         "cc_lds16": N + 4 * N + 16 * (M + c["O"]) + 4 * M + 25 * M + 16 * c["O"],
-        "cc_lds16b": N + 4 * N + 16 * (M + c["O"]) + 4 * M + 25 * M + 16 * c["O"],
         "cc_runs": 5 * N, "cc_link": N + 8 * N, "cc_stats": 5 * N + 4 * N,
         "ip_rowcount": 5 * N, "ip_compact": 9 * N + 16 * M + 25 * M + 16 * c["O"], "ip_labels": 9 * N,
         "fe_curv": 8 * M + 5 * M, "fe_pick": 14 * M + 4 * M + 4 * (feats + M), "fe_voxel": 20 * M + 16 * c["Fs"],

@@ -1,4 +1,4 @@
-"""Phase timing of cc_lds16 (slot 0's workgroup, last launch) under the full bench load; build kernels_ip with -DALEGO_TIMING."""
+"""Phase timing of cc_lds16 (slot 0 workgroup, last launch) under load; build kernels_ip with -DALEGO_TIMING."""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
