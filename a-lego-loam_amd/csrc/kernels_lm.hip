@@ -24,6 +24,37 @@ DEV_INLINE int* lip(const LmCtx& L, int slot) { return L.li + (size_t)slot * LI_
 DEV_INLINE DQuat ldq(const double* p) { return DQuat{p[0], p[1], p[2], p[3]}; }
 DEV_INLINE void stq(double* p, const DQuat& q) { p[0] = q.w; p[1] = q.x; p[2] = q.y; p[3] = q.z; }
 
+// Map sequence = lm_concat, VoxelGrid of the two maps, lm_grid_*, at the start of every mapping frame.  lm_map_update
+// (called by lm_prepare's bookkeeping thread) replays the deque bookkeeping of extractSurroundingKeyFrames
+// (laserMapping.cpp:206-238) on the list of frame ids and decides whether the local map changed (the reference
+// re-assembles and re-filters the identical map on every mapping frame; here only when its content changes):
+//   deque not full yet  -> the newest min(n, K) key frames; content changes when a key frame was saved
+//   deque full          -> if latest_frame_id_ != n-1: pop front, push frame n-1.  latest_frame_id_ starts at -1, so the
+//                          first mapping frame after the deque filled up pushes frame K-1 a second time (and drops
+//                          frame 0) although no key frame was saved: the duplicate stays in the window for K-1 further
+//                          key frames and doubles that frame's weight in the voxel centroids.  Reproduced as is.
+// LI_REBUILD is cleared again by lm_finish at the end of the frame.
+DEV_INLINE void lm_map_update(const LmCtx& L, int slot, int* li) {
+  const int nkf = li[LI_NKF];
+  if (nkf == 0) return;   // :196-199
+  int* rec = L.rec + (size_t)slot * L.K;
+  const int cnt = li[LI_REC_CNT];
+  bool changed = false;
+  if (cnt < L.K) {
+    const int nk = min(nkf, L.K);
+    changed = li[LI_DIRTY] != 0;
+    for (int j = 0; j < nk; ++j) rec[j] = nkf - nk + j;
+    li[LI_REC_CNT] = nk;
+  } else if (li[LI_LATEST] != nkf - 1) {
+    for (int j = 0; j + 1 < L.K; ++j) rec[j] = rec[j + 1];
+    rec[L.K - 1] = nkf - 1;
+    li[LI_LATEST] = nkf - 1;
+    changed = true;
+  }
+  li[LI_DIRTY] = 0;
+  if (changed) { li[LI_REBUILD] = 1; li[LI_NREBUILD] += 1; }
+}
+
 // grid (8, 3, slots).  stage: copy /corner_last, /surf_last, /outlier of this scan into the LM inputs.
 __global__ void __launch_bounds__(LM_BLOCK) lm_prepare(DevCtx d, LmCtx L, int stage, int run_hint) {
   const int slot = blockIdx.z + d.slot0, kind = blockIdx.y;
@@ -49,7 +80,7 @@ __global__ void __launch_bounds__(LM_BLOCK) lm_prepare(DevCtx d, LmCtx L, int st
   if (blockIdx.x != 0 || kind != 0 || threadIdx.x != 0) return;
   double* ld = ldp(L, slot);
   double* po = d.poses + (size_t)slot * 16;
-  li[LI_RUN] = 0; li[LI_KF_ADDED] = 0; li[LI_OPTIMIZED] = 0; li[LI_FLAGS] = 0;   // LI_REBUILD belongs to the map sequence
+  li[LI_RUN] = 0; li[LI_REBUILD] = 0; li[LI_KF_ADDED] = 0; li[LI_OPTIMIZED] = 0; li[LI_FLAGS] = 0;
   if (!sc[SC_ODOM_VALID]) return;  // no /odom/lidar on the initialising scan -> no mapping frame
   // laserOdomHandler :154-166
   for (int k = 0; k < 3; ++k) ld[LD_T_O2L + k] = po[k];
@@ -67,48 +98,9 @@ __global__ void __launch_bounds__(LM_BLOCK) lm_prepare(DevCtx d, LmCtx L, int st
   li[LI_RUN] = run;
   if (run_hint >= 0 && run != run_hint) li[LI_OVERFLOW] = 2;  // host launch-skipping logic out of sync
   if (!run) { li[LI_FLAGS] = 8; return; }
+  lm_map_update(L, slot, li);
 }
 
-// Map sequence = lm_map_begin, lm_concat, VoxelGrid of the two maps, lm_grid_*, lm_map_end, at the start of every
-// mapping frame.  lm_map_begin replays the deque bookkeeping of extractSurroundingKeyFrames (laserMapping.cpp:206-238)
-// on the list of frame ids and decides whether the local map changed (the reference re-assembles and re-filters the
-// identical map on every mapping frame; here only when its content changes):
-//   deque not full yet  -> the newest min(n, K) key frames; content changes when a key frame was saved
-//   deque full          -> if latest_frame_id_ != n-1: pop front, push frame n-1.  latest_frame_id_ starts at -1, so the
-//                          first mapping frame after the deque filled up pushes frame K-1 a second time (and drops
-//                          frame 0) although no key frame was saved: the duplicate stays in the window for K-1 further
-//                          key frames and doubles that frame's weight in the voxel centroids.  Reproduced as is.
-__global__ void lm_map_begin(DevCtx d, LmCtx L) {
-  const int s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= d.n_launch) return;
-  const int slot = s + d.slot0;
-  int* li = lip(L, slot);
-  li[LI_REBUILD] = 0;
-  if (!li[LI_RUN]) return;
-  const int nkf = li[LI_NKF];
-  if (nkf == 0) return;   // :196-199
-  int* rec = L.rec + (size_t)slot * L.K;
-  const int cnt = li[LI_REC_CNT];
-  bool changed = false;
-  if (cnt < L.K) {
-    const int nk = min(nkf, L.K);
-    changed = li[LI_DIRTY] != 0;
-    for (int j = 0; j < nk; ++j) rec[j] = nkf - nk + j;
-    li[LI_REC_CNT] = nk;
-  } else if (li[LI_LATEST] != nkf - 1) {
-    for (int j = 0; j + 1 < L.K; ++j) rec[j] = rec[j + 1];
-    rec[L.K - 1] = nkf - 1;
-    li[LI_LATEST] = nkf - 1;
-    changed = true;
-  }
-  li[LI_DIRTY] = 0;
-  if (changed) { li[LI_REBUILD] = 1; li[LI_NREBUILD] += 1; }
-}
-__global__ void lm_map_end(DevCtx d, LmCtx L) {
-  const int s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= d.n_launch) return;
-  lip(L, s + d.slot0)[LI_REBUILD] = 0;
-}
 
 // grid (2, K, slots): chronological concatenation of the key-frame ring
 __global__ void __launch_bounds__(LM_BLOCK) lm_concat(DevCtx d, LmCtx L) {
@@ -675,6 +667,7 @@ __global__ void lm_finish(DevCtx d, LmCtx L) {
   const int slot = s + d.slot0;
   int* li = lip(L, slot);
   if (!li[LI_RUN]) return;
+  li[LI_REBUILD] = 0;   // the map sequence of this frame is done: no stale flag for a later round over the group's jobs
   double* ld = ldp(L, slot);
   const int nkf = li[LI_NKF];
   bool add = true;
@@ -748,12 +741,6 @@ void launch_lm_concat(const DevCtx& d, const LmCtx& L, hipStream_t st) {
 }
 void launch_lm_total(const DevCtx& d, const LmCtx& L, hipStream_t st) {
   ALEGO_LAUNCH(lm_total, dim3(8, d.n_launch), dim3(LM_BLOCK), 0, st, d, L);
-}
-void launch_lm_map_begin(const DevCtx& d, const LmCtx& L, hipStream_t st) {
-  ALEGO_LAUNCH(lm_map_begin, dim3((d.n_launch + 63) / 64), dim3(64), 0, st, d, L);
-}
-void launch_lm_map_end(const DevCtx& d, const LmCtx& L, hipStream_t st) {
-  ALEGO_LAUNCH(lm_map_end, dim3((d.n_launch + 63) / 64), dim3(64), 0, st, d, L);
 }
 void launch_lm_grid(const DevCtx& d, const LmCtx& L, hipStream_t st) {
   ALEGO_LAUNCH(lm_grid_setup, dim3(2, d.n_launch), dim3(LM_BLOCK), 0, st, d, L);

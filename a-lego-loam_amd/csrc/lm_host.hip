@@ -13,8 +13,6 @@
 void launch_lm_prepare(const DevCtx& d, const LmCtx& L, int stage, int run_hint, hipStream_t st);
 void launch_lm_concat(const DevCtx& d, const LmCtx& L, hipStream_t st);
 void launch_lm_total(const DevCtx& d, const LmCtx& L, hipStream_t st);
-void launch_lm_map_begin(const DevCtx& d, const LmCtx& L, hipStream_t st);
-void launch_lm_map_end(const DevCtx& d, const LmCtx& L, hipStream_t st);
 void launch_lm_grid(const DevCtx& d, const LmCtx& L, hipStream_t st);
 void launch_lm_register(const DevCtx& d, const LmCtx& L, hipStream_t st);
 
@@ -122,15 +120,13 @@ static bool dbg_sync(hipStream_t st, const char* what, std::string* err) {
   return true;
 }
 
-// lm_map_begin .. lm_map_end on stream `st` (see kernels_lm.hip)
+// concat + VoxelGrid of the maps + grid, for the slots whose window changed (LI_REBUILD, set by lm_prepare)
 static int map_sequence(LmHost* lm, const DevCtx& d, const LmCtx& L, int g, hipStream_t st, std::string* err) {
-  launch_lm_map_begin(d, L, st);
   launch_lm_concat(d, L, st);
   if (!dbg_sync(st, "lm_concat", err)) return ALEGO_ERR_HIP;
   if (int r = vox_run(lm->vm[g], st, err)) return r;
   if (!dbg_sync(st, "vox map", err)) return ALEGO_ERR_HIP;
   launch_lm_grid(d, L, st);
-  launch_lm_map_end(d, L, st);
   if (!dbg_sync(st, "lm_grid", err)) return ALEGO_ERR_HIP;
   return 0;
 }
