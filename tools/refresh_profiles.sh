@@ -4,6 +4,7 @@
 #   r01_bench_under_rocprof.json   the same command under rocprofv3 --kernel-trace --stats (without the CPU legs)
 #   r01_bench_kernel_stats.csv     rocprofv3's per-kernel summary of that run (all dispatches, priming included)
 #   r01_bench_kernel_stats_steady.csv  the same trace restricted to the dispatches of bench.py's HIP-event pass, side by side
+#   r01_pmc_sq.json                SQ counters per kernel (waves, wave cycles, VALU instructions, wait cycles)
 #   r01_pmc_traffic.json           HBM bytes per launch from two separate --pmc passes (FETCH_SIZE, WRITE_SIZE), taken after 700
 #                                  priming scans: around scan 560 every stream fills its 50-key-frame window and rebuilds its map at once
 set -u
@@ -25,4 +26,8 @@ for c in FETCH_SIZE WRITE_SIZE; do
   timeout 900 rocprofv3 --pmc $c --kernel-trace -d /tmp/pmc_$c -o p --output-format csv -- python bench.py --steps 8 --warmup 0 --prime 700 --no-cpu --no-profile > /tmp/pmc_$c.log 2>&1
 done
 python tools/pmc_traffic.py /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE "$PER" 16 > gpurun_out/r01_pmc_traffic.json
+# SQ counters (occupancy / issue statistics quoted in DESIGN.md section 4): one stream group, 512 streams
+rm -rf /tmp/pmc_sq
+ALEGO_STREAM_GROUPS=1 timeout 1500 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU GRBM_GUI_ACTIVE --kernel-trace -d /tmp/pmc_sq -o sq --output-format csv -- python bench.py --streams 512 --steps 6 --warmup 0 --prime 700 --no-cpu --no-profile > /tmp/pmc_sq.log 2>&1
+python tools/pmc_agg.py /tmp/pmc_sq 12 > gpurun_out/r01_pmc_sq.json
 ls -la gpurun_out/r01_*
