@@ -393,6 +393,33 @@ def test_batch_full_loop_equals_single_stream(params_a, nslot, groups, monkeypat
     hb.close()
 
 
+def test_batch_with_slots_out_of_phase(params_a):
+    """One slot has seen an extra scan before the batch starts: its mapping frames fall on the other slots' skipped frames
+    (the host cannot skip launches any more, the device-side gates decide per slot).  Every slot still equals a handle of its own."""
+    p = params_a
+    nslot, nscan = 3, 24
+    hb = binding.Handle(p, n_slots=nslot, ring_len=nscan)
+    for s in range(nslot):
+        for k in range(nscan):
+            hb.batch_load(s, k, synth.scan(p, k + 1, stream=s))
+    extra = synth.scan(p, 0, stream=1)
+    hb.scan_process(extra, stages=7, slot=1)          # overwrites ring position 0 of slot 1 ...
+    hb.batch_load(1, 0, synth.scan(p, 1, stream=1))   # ... which is restored before the batch
+    hb.batch_run(0, nscan, stages=7)
+    for s in range(nslot):
+        h1 = binding.Handle(p)
+        if s == 1:
+            h1.scan_process(extra, stages=7)
+        for k in range(nscan):
+            _, odom1, mp1 = h1.scan_process(synth.scan(p, k + 1, stream=s), stages=7)
+        _, odomb, mpb = hb.batch_get_pose(s)
+        assert_bit_equal(odomb["t"], odom1["t"], f"slot {s} odometry translation")
+        assert_bit_equal(mpb["t"], mp1["t"], f"slot {s} map translation")
+        assert_bit_equal(mpb["params"], mp1["params"], f"slot {s} LM params_")
+        h1.close()
+    hb.close()
+
+
 def test_degenerate_scans_do_not_break_the_loop(params_a):
     """Empty and tiny scans take the reference's guard paths (few correspondences, few features) on both sides."""
     p = params_a
