@@ -42,10 +42,28 @@ struct ProfScope {
 };
 
 // launch `kernel` bracketed by events when profiling is on
+#ifndef ALEGO_DUP_HOOK
 #define ALEGO_LAUNCH(kernel, grid, block, shmem, stream, ...)                 \
   do {                                                                        \
     ProfScope prof_scope_(#kernel, stream);                                   \
     hipLaunchKernelGGL((kernel), grid, block, shmem, stream, __VA_ARGS__);    \
   } while (0)
+#else
+// Development build (tools/marginal_cost.py): the kernel whose name contains $ALEGO_DUP is launched twice.  Launching an
+// idempotent kernel a second time and reading the change of the whole pipeline's throughput gives its marginal cost
+// under the real 4-group concurrency — what an isolated duration or a counter share cannot tell.
+#include <cstdlib>
+#include <cstring>
+inline bool alego_dup_match(const char* name) {
+  static const char* pat = std::getenv("ALEGO_DUP");
+  return pat && *pat && std::strstr(name, pat) != nullptr;
+}
+#define ALEGO_LAUNCH(kernel, grid, block, shmem, stream, ...)                 \
+  do {                                                                        \
+    ProfScope prof_scope_(#kernel, stream);                                   \
+    hipLaunchKernelGGL((kernel), grid, block, shmem, stream, __VA_ARGS__);    \
+    if (alego_dup_match(#kernel)) hipLaunchKernelGGL((kernel), grid, block, shmem, stream, __VA_ARGS__); \
+  } while (0)
+#endif
 
 #endif

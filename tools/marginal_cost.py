@@ -1,0 +1,20 @@
+"""Marginal cost of each (idempotent) kernel inside the concurrent pipeline: bench throughput with the kernel launched twice.
+Needs a library built with -DALEGO_DUP_HOOK (every .hip file).  usage: python tools/marginal_cost.py [streams] [steps]"""
+import json, os, subprocess, sys
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+streams = sys.argv[1] if len(sys.argv) > 1 else "1536"
+steps = sys.argv[2] if len(sys.argv) > 2 else "60"
+kernels = ["", "ip_reset", "ip_project", "ip_image", "cc_edges", "cc_lds16", "fe_curv", "fe_pick", "fe_voxel", "fe_gather", "fe_boxes",
+           "lo_assoc<0>", "lo_assoc<1>", "lm_concat", "vox_small", "vox_big", "lm_knn", "lm_fit", "lm_store_kf"]
+base = None
+for k in kernels:
+    env = dict(os.environ, ALEGO_DUP=k)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--streams", streams, "--steps", steps, "--warmup", "10",
+                          "--prime", "560", "--no-cpu", "--no-profile"], env=env, capture_output=True, text=True)
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    if not line:
+        print(k, "FAILED", out.stderr[-400:]); continue
+    j = json.loads(line[-1])
+    ms = j["ms_per_step"]
+    if base is None: base = ms
+    print(f"{k or 'baseline':14s} {j['value']:10.0f} scans/s  {ms:8.3f} ms/step  marginal {100 * (ms - base) / base:6.2f} %", flush=True)
