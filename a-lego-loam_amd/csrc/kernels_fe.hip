@@ -11,6 +11,7 @@
 //   fe_gather  ring-ascending concatenation into the four feature clouds       (:199-205,:245,:293)
 //   fe_boxes   bounding boxes of 32 consecutive less_flat / less_sharp points for the next scan's LaserOdometry
 #include <cstdlib>
+#include <type_traits>
 #include "dev_common.h"
 #include "prof.h"
 
@@ -231,6 +232,167 @@ __global__ void __launch_bounds__(64) fe_pick(DevCtx d) {
   if (lane == 0) {
     int* c = d.st_cnt + ((size_t)slot * d.NS + ring) * 8;
     c[0] = n_sharp; c[1] = n_ls; c[2] = n_flat; c[3] = n_lfs;
+  }
+}
+
+// fe_pick4<FE_T>: the same greedy pick with FOUR rings per wavefront, one DPP row (16 lanes) each.  The per-pick
+// overhead of the one-ring kernel (wave-wide arg-max, ballot, suppression window, uniform control flow: ~70 of its
+// ~100 instructions per pick) is issued once for four rings; the reductions stay inside a DPP row.  Lane gl of a row owns
+// the sector elements lsp + gl + 16 t (sector length <= 16 * FE_T).  Needs suppress_radius <= 8 (the forward checks sit in
+// lanes 0-7 of the row, the backward checks in lanes 8-15).  Dynamic LDS: 3 B per ring point, 4 rings.
+#define FP_G 4
+template <int FE_T>
+__global__ void __launch_bounds__(64) fe_pick4(DevCtx d) {
+  using mask_t = typename std::conditional<(FE_T > 32), unsigned long long, uint32_t>::type;
+  static_assert(FE_T <= 64, "one candidate bit per owned element");
+  const int slot = blockIdx.y + d.slot0, lane = threadIdx.x, g = lane >> 4, gl = lane & 15;
+  const int ring0 = blockIdx.x * FP_G, ring = ring0 + g;
+  const bool rv = ring < d.NS;
+  const size_t base = (size_t)slot * d.N;
+  const alego_params& P = d.P;
+  extern __shared__ __attribute__((aligned(16))) unsigned char fe_smem[];
+  uint16_t* s_col = reinterpret_cast<uint16_t*>(fe_smem);   // [FP_G][H]
+  uint8_t* s_flag = fe_smem + 2 * (size_t)FP_G * d.H;        // [FP_G][H]
+  for (int r = 0; r < FP_G && ring0 + r < d.NS; ++r) {       // whole wavefront stages one ring after the other
+    const int Sr = d.ring_start[slot * d.NS + ring0 + r], Er = d.ring_end[slot * d.NS + ring0 + r];
+    const int rfr = Sr - 5, cntr = Er - Sr + 11;
+    uint16_t* sc = s_col + (size_t)r * d.H;
+    uint8_t* sf = s_flag + (size_t)r * d.H;
+#pragma unroll 4
+    for (int k = lane; k < cntr; k += 64) {
+      const float a = fabsf(d.cd[base + rfr + k]);
+      const double ad = (double)a;
+      const double curv = ad * ad;  // (double)diff_range * diff_range, exact (:125)
+      sc[k] = (uint16_t)d.seg_col[base + rfr + k];
+      sf[k] = (uint8_t)((d.picked0[base + rfr + k] & 1) | (d.seg_ground[base + rfr + k] ? 2 : 0) |
+                        (curv > P.edge_thres ? 4 : 0) | (curv < P.surf_thres ? 8 : 0) | (1 << 4));
+    }
+  }
+  __syncthreads();
+  const int S = rv ? d.ring_start[slot * d.NS + ring] : 0, E = rv ? d.ring_end[slot * d.NS + ring] : 0;
+  const int rf = S - 5;
+  uint16_t* sc = s_col + (size_t)g * d.H;
+  uint8_t* sf = s_flag + (size_t)g * d.H;
+  const float* cdv = d.cd + base + rf;
+  int* st = d.st_idx + ((size_t)slot * d.NS + (rv ? ring : 0)) * d.st_stride;
+  int* st_sharp = st, *st_lsharp = st + d.cap_sharp, *st_flat = st_lsharp + d.cap_lsharp;
+  int n_sharp = 0, n_ls = 0, n_flat = 0;
+  const int NSEC = P.n_sectors, SR = P.suppress_radius;
+  for (int j = 0; j < NSEC; ++j) {
+    int sp, ep;
+    if (P.sector_formula == 0) { sp = (S * (NSEC - j) + E * j) / NSEC; ep = (S * (NSEC - 1 - j) + E * (j + 1)) / NSEC - 1; }
+    else { const int diff = E - S; sp = S + j * diff / NSEC; ep = S + (j + 1) * diff / NSEC - 1; }
+    const bool act0 = rv && sp < ep;
+    if (!__any(act0)) continue;
+    const int lsp = sp - rf, lep = ep - rf;
+    uint32_t key[FE_T];
+    mask_t sharp_m = 0, flat_m = 0;
+#pragma unroll
+    for (int t = 0; t < FE_T; ++t) {
+      const int c = lsp + gl + 16 * t;
+      key[t] = 0;
+      if (act0 && c <= lep) {
+        const uint8_t f = sf[c];
+        key[t] = (uint32_t)d_f2i(fabsf(cdv[c]));
+        if ((f & 7) == 4) sharp_m |= (mask_t)1 << t;
+        if ((f & 11) == 10) flat_m |= (mask_t)1 << t;
+      }
+    }
+    // marks c and its +-SR neighbours picked (:211-234) for the rows where `on`; `spread` rows look for column jumps first
+    auto mark = [&](int c, bool on, bool spread) {
+      bool bad = false;
+      if (spread) {
+        if (gl < SR) { const int cdf = (int)sc[c + gl + 1] - (int)sc[c + gl]; bad = (cdf < 0 ? -cdf : cdf) > P.suppress_col_diff; }
+        else if (gl >= 8 && gl < 8 + SR) { const int l = gl - 8; const int cdf = (int)sc[c - l - 1] - (int)sc[c - l]; bad = (cdf < 0 ? -cdf : cdf) > P.suppress_col_diff; }
+      }
+      const unsigned long long mb = __ballot(bad);
+      const unsigned gb = (unsigned)(mb >> (16 * g)) & 0xffffu;
+      const unsigned lo = gb & 0xffu, hi = gb >> 8;
+      int nf = 0, nbk = 0;
+      if (spread) { nf = lo ? min(SR, __ffs((int)lo) - 1) : SR; nbk = hi ? min(SR, __ffs((int)hi) - 1) : SR; }
+      const int first = c - nbk, last = c + nf;
+      if (on && gl <= last - first) sf[first + gl] |= 1;
+      const int off = (gl - (first - lsp)) & 15;   // the (single) owned element inside [first, last]
+      const int ct = first + off;
+      if (on && ct <= last && ct >= lsp && ct <= lep) { const mask_t bit = (mask_t)1 << ((ct - lsp - gl) >> 4); sharp_m &= ~bit; flat_m &= ~bit; }
+    };
+    // ---- sharp / less-sharp: descending curvature, ties -> larger index (:189-236) ----
+    int picked_num = 0;
+    bool act = act0;
+    while (true) {
+      uint32_t bk = 0;
+      int bt = 0;
+#pragma unroll
+      for (int t = 0; t < FE_T; ++t) if (((sharp_m >> t) & 1) && key[t] >= bk) { bk = key[t]; bt = t; }
+      if (!act) bk = 0;
+      const uint32_t kmax = row16_max_u32(bk);
+      act = act && kmax != 0;
+      if (!__any(act)) break;
+      const int c = (int)row16_max_u32(bk == kmax ? (uint32_t)(lsp + gl + 16 * bt) : 0u);   // ties -> larger index
+      if (act) ++picked_num;
+      int lab = 0;
+      if (picked_num <= P.n_sharp) lab = 2; else if (picked_num <= P.n_less_sharp) lab = 1;
+      if (act && gl == 0) {
+        if (lab) sf[c] = (uint8_t)((sf[c] & 0xCF) | ((lab + 1) << 4));
+        if (lab == 2) st_sharp[n_sharp] = c + rf;
+        if (lab) st_lsharp[n_ls] = c + rf;
+      }
+      if (act && lab == 2) ++n_sharp;
+      if (act && lab) ++n_ls;
+      mark(c, act, act && lab != 0);  // the 21st pick is marked but breaks before the suppression (:207-210)
+      if (!lab) act = false;
+    }
+    // ---- flat: ascending curvature, ground only, ties -> smaller index (:238-277) ----
+    picked_num = 0;
+    act = act0;
+    while (true) {
+      uint32_t bk = 0xFFFFFFFFu;
+      int bt = 0;
+#pragma unroll
+      for (int t = 0; t < FE_T; ++t) if (((flat_m >> t) & 1) && key[t] < bk) { bk = key[t]; bt = t; }
+      if (!act) bk = 0xFFFFFFFFu;
+      const uint32_t kmin = row16_min_u32(bk);
+      act = act && kmin != 0xFFFFFFFFu;
+      if (!__any(act)) break;
+      const int c = (int)row16_min_u32(bk == kmin ? (uint32_t)(lsp + gl + 16 * bt) : 0xFFFFFFFFu);   // ties -> smaller index
+      if (act) ++picked_num;
+      if (act && gl == 0) { sf[c] = (uint8_t)(sf[c] & 0xCF); st_flat[n_flat] = c + rf; }   // label -1
+      if (act) ++n_flat;
+      const bool stop = picked_num >= P.n_flat;
+      mark(c, act, act && !stop);  // the n_flat-th pick breaks before the suppression (:248-251)
+      if (stop) act = false;
+    }
+  }
+  __syncthreads();
+  if (rv && gl == 0) {
+    int* c = d.st_cnt + ((size_t)slot * d.NS + ring) * 8;
+    c[0] = n_sharp; c[1] = n_ls; c[2] = n_flat;
+  }
+  // ---- less-flat candidates in position order (:279-285) and the labels, one ring after the other with all 64 lanes.
+  // A sector's labels only change while that sector is picked, so reading them at the end is the same as reading them
+  // after the sector.
+  for (int r = 0; r < FP_G && ring0 + r < d.NS; ++r) {
+    const int Sr = d.ring_start[slot * d.NS + ring0 + r], Er = d.ring_end[slot * d.NS + ring0 + r];
+    const int rfr = Sr - 5, cntr = Er - Sr + 11;
+    const uint8_t* sfr = s_flag + (size_t)r * d.H;
+    int* st_lfs = d.st_idx + ((size_t)slot * d.NS + ring0 + r) * d.st_stride + d.cap_sharp + d.cap_lsharp + d.cap_flat;
+    int n_lfs = 0;
+    for (int j = 0; j < NSEC; ++j) {
+      int sp, ep;
+      if (P.sector_formula == 0) { sp = (Sr * (NSEC - j) + Er * j) / NSEC; ep = (Sr * (NSEC - 1 - j) + Er * (j + 1)) / NSEC - 1; }
+      else { const int diff = Er - Sr; sp = Sr + j * diff / NSEC; ep = Sr + (j + 1) * diff / NSEC - 1; }
+      if (sp >= ep) continue;
+      const int lsp = sp - rfr, lep = ep - rfr;
+      for (int c0 = lsp; c0 <= lep; c0 += 64) {
+        const int c = c0 + lane;
+        const bool take = c <= lep && ((sfr[c] >> 4) & 3) <= 1;   // label <= 0
+        const unsigned long long m = __ballot(take);
+        if (take) st_lfs[n_lfs + (int)__popcll(m & ((1ull << lane) - 1ull))] = c + rfr;
+        n_lfs += (int)__popcll(m);
+      }
+    }
+    for (int k = lane; k < cntr; k += 64) d.plabel[base + rfr + k] = (int)((sfr[k] >> 4) & 3) - 1;
+    if (lane == 0) d.st_cnt[((size_t)slot * d.NS + ring0 + r) * 8 + 3] = n_lfs;
   }
 }
 
@@ -543,7 +705,14 @@ void launch_fe(const DevCtx& d, hipStream_t st) {
   const int sector_max = (d.H + d.P.n_sectors - 1) / (d.P.n_sectors > 0 ? d.P.n_sectors : 1) + 2;
   // (padding this allocation by 16 KB cost 7 % of the whole pipeline: the LDS footprint decides how many rings share a CU)
   const int extra = 0;
-  if (sector_max <= 64 * 6) { ALEGO_LAUNCH(fe_pick<6>, dim3(d.NS, d.n_launch), dim3(64), (size_t)3 * d.H + extra, st, d); }
+  const char* ev = std::getenv("ALEGO_FE_PICK1");   // read per call: the tests switch it inside one process
+  const bool one_ring = (ev && ev[0] == '1') || d.P.suppress_radius > 8 || sector_max > 16 * 43;
+  const dim3 g4((d.NS + FP_G - 1) / FP_G, d.n_launch);
+  const size_t lds4 = (size_t)3 * FP_G * d.H;
+  if (!one_ring && sector_max <= 16 * 19) { ALEGO_LAUNCH(fe_pick4<19>, g4, dim3(64), lds4, st, d); }
+  else if (!one_ring && sector_max <= 16 * 24) { ALEGO_LAUNCH(fe_pick4<24>, g4, dim3(64), lds4, st, d); }
+  else if (!one_ring) { ALEGO_LAUNCH(fe_pick4<43>, g4, dim3(64), lds4, st, d); }
+  else if (sector_max <= 64 * 6) { ALEGO_LAUNCH(fe_pick<6>, dim3(d.NS, d.n_launch), dim3(64), (size_t)3 * d.H + extra, st, d); }
   else { ALEGO_LAUNCH(fe_pick<12>, dim3(d.NS, d.n_launch), dim3(64), (size_t)3 * d.H, st, d); }
   ALEGO_LAUNCH(fe_voxel, dim3(d.NS, d.n_launch), dim3(FE_BLOCK), (size_t)10 * d.H, st, d);
   ALEGO_LAUNCH(fe_gather, dim3(d.NS, d.n_launch), dim3(FE_BLOCK), 0, st, d);

@@ -489,8 +489,8 @@ __global__ void __launch_bounds__(CC_LDS_THREADS) cc_lds(DevCtx d, int ring_pos,
 // under load the kernel's duration is decided by that, not by its instruction count.  LDS has no 16-bit atomics: the union's
 // compare-and-swap goes through the aligned 32-bit word (a concurrent change of the other half makes it retry), the
 // path-halving stores are plain 16-bit stores (parents only ever decrease, any ancestor is a valid parent).  Component size
-// and row mask are accumulated one after the other in the same array with 32-bit atomics on packed halves (sizes < 65536
-// cannot carry into the neighbour; OR is bit-local).
+// and row mask are accumulated one after the other in the ROOTS' OWN parent entries with 32-bit atomics on the packed
+// halves (sizes < 65536 cannot carry into the neighbour; OR is bit-local): 2 B/cell of LDS in total.
 DEV_INLINE int ccl16_find(uint16_t* par, int v) {
   int curr = par[v];
   if (curr != v) {
@@ -538,7 +538,7 @@ extern "C" void alego_cc_times(long long* out) { (void)hipMemcpyFromSymbol(out, 
 // Register-light on purpose.  A first version kept the root of each of a thread's 36 cells in registers and unrolled every
 // pass: 128 VGPRs x 1024 threads is the whole register file of a CU, so a workgroup could only start on an EMPTY CU and
 // nothing ran next to it (the pipeline gained 3 % when it was replaced although the kernel itself takes as long).  Here
-// the flattened roots stay in the LDS parent array (the statistics get their own array: 4 B/cell of LDS in total), the
+// the flattened roots stay in the LDS parent array (the statistics reuse the roots' entries: 2 B/cell of LDS in total), the
 // passes are plain loops over the thread's cells and the per-cell state is a handful of 64-bit masks: 64 VGPRs, other
 // streams' wavefronts share the CU.
 // Compaction: chunk k = cells [1024 k, 1024 k + 1024) in row-major order, one cell per thread: per-(chunk, wavefront)
@@ -550,10 +550,10 @@ __global__ void __attribute__((amdgpu_waves_per_eu(8, 8))) __launch_bounds__(CC_
   const int N = d.N, H = d.H, NWORD = (N + 1) / 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char cc_smem[];
   uint16_t* par = reinterpret_cast<uint16_t*>(cc_smem);
-  unsigned* packed = reinterpret_cast<unsigned*>(cc_smem + 4 * (size_t)NWORD);   // behind the parent array
   const uint8_t* fi = d.flag_img + base;
   constexpr int PER = (CC_LDS_MAXN + CC_T - 1) / CC_T;
   static_assert(PER <= 48, "three 64-bit words of 4-bit flags");
+  const int per = (N + CC_T - 1) / CC_T;   // cells per thread of THIS image (29 at 16x1800; PER = 36 is the capacity)
   const int lane = lane_id(), wave = threadIdx.x >> 6;
   CC_TICK(0);
   unsigned long long f0 = 0, f1 = 0, f2 = 0;   // the 4 flag bits of this thread's cells, 16 cells per word
@@ -591,27 +591,37 @@ __global__ void __attribute__((amdgpu_waves_per_eu(8, 8))) __launch_bounds__(CC_
   __syncthreads();
   CC_TICK(1);
 #pragma unroll 1
-  for (int k = 0; k < PER; ++k) {
+  for (int k = 0; k < per; ++k) {
     const int v = threadIdx.x + k * CC_T;
     if (flag_of(k) & 4) { const int row = cell_row(d, v), col = v - row * H; ccl16_union(par, v, row * H + (col + 1 == H ? 0 : col + 1)); }
   }
   __syncthreads();
   CC_TICK(2);
   // flatten: par[v] = root.  Concurrent walkers see either the old parent or the root of a cell, both are ancestors.
+  unsigned long long self_m = 0;   // this thread's cells that are roots
 #pragma unroll 1
-  for (int k = 0; k < PER; ++k) {
+  for (int k = 0; k < per; ++k) {
     const int v = threadIdx.x + k * CC_T;
-    if (flag_of(k) & 2) { int r = par[v], nx; while (r > (nx = par[r])) r = nx; par[v] = (uint16_t)r; }
+    if (flag_of(k) & 2) { int r = par[v], nx; while (r > (nx = par[r])) r = nx; par[v] = (uint16_t)r; if (r == v) self_m |= 1ull << k; }
   }
-  for (int i = threadIdx.x; i < NWORD; i += CC_T) packed[i] = 0u;
   __syncthreads();
   CC_TICK(3);
+  // From here on a root's own entry (par[r] == r, known to its owner through self_m) is free: it becomes the component's
+  // 16-bit accumulator, first for the size, then for the row mask.  No second array: 2 B/cell of LDS in total.
+  unsigned* parw = reinterpret_cast<unsigned*>(par);
+  auto root_of = [&](int k, int v) -> int { return ((self_m >> k) & 1ull) ? v : (int)par[v]; };
+  auto zero_roots = [&]() {
+#pragma unroll 1
+    for (int k = 0; k < per; ++k) if ((self_m >> k) & 1ull) par[threadIdx.x + k * CC_T] = 0;
+    __syncthreads();
+  };
+  zero_roots();
   const alego_params& P = d.P;
   unsigned long long head_m = 0;
 #pragma unroll 1
-  for (int k = 0; k < PER; ++k) {   // component sizes: one atomic per run of equal roots in the wavefront
+  for (int k = 0; k < per; ++k) {   // component sizes: one atomic per run of equal roots in the wavefront
     const int v = threadIdx.x + k * CC_T;
-    const int r = (flag_of(k) & 2) ? (int)par[v] : -1;
+    const int r = (flag_of(k) & 2) ? root_of(k, v) : -1;
     const int prev_r = __shfl_up(r, 1, 64);
     const bool brk = lane == 0 || prev_r != r || (v - cell_row(d, v) * H) == 0;
     const unsigned long long starts = __ballot(brk);
@@ -619,17 +629,17 @@ __global__ void __attribute__((amdgpu_waves_per_eu(8, 8))) __launch_bounds__(CC_
       head_m |= 1ull << k;
       const unsigned long long after = lane == 63 ? 0ull : (starts >> (lane + 1));
       const int len = after ? __ffsll((long long)after) : 64 - lane;
-      atomicAdd(&packed[r >> 1], (unsigned)len << ((r & 1) * 16));
+      atomicAdd(&parw[r >> 1], (unsigned)len << ((r & 1) * 16));   // sizes < 65536: no carry into the neighbour's half
     }
   }
   __syncthreads();
   unsigned long long big_m = 0, mid_m = 0;
 #pragma unroll 1
-  for (int k = 0; k < PER; ++k) {
+  for (int k = 0; k < per; ++k) {
     const int v = threadIdx.x + k * CC_T;
     if (flag_of(k) & 2) {
-      const int r = par[v];
-      const int sz = (int)((packed[r >> 1] >> ((r & 1) * 16)) & 0xFFFFu);
+      const int r = root_of(k, v);
+      const int sz = (int)par[r];
       if (sz >= P.seg_big_num) big_m |= 1ull << k;
       else if (sz >= P.seg_valid_point_num) mid_m |= 1ull << k;
       if (!(fused & 1) && r == v) d.cc_size[base + v] = sz;
@@ -637,24 +647,22 @@ __global__ void __attribute__((amdgpu_waves_per_eu(8, 8))) __launch_bounds__(CC_
   }
   __syncthreads();
   CC_TICK(4);
-  for (int i = threadIdx.x; i < NWORD; i += CC_T) packed[i] = 0u;
-  __syncthreads();
+  zero_roots();
 #pragma unroll 1
-  for (int k = 0; k < PER; ++k) {   // rows touched by every component (a run lies in one row)
+  for (int k = 0; k < per; ++k) {   // rows touched by every component (a run lies in one row)
     const int v = threadIdx.x + k * CC_T;
-    if ((head_m >> k) & 1ull) { const int r = par[v]; atomicOr(&packed[r >> 1], (1u << cell_row(d, v)) << ((r & 1) * 16)); }
+    if ((head_m >> k) & 1ull) { const int r = root_of(k, v); atomicOr(&parw[r >> 1], (1u << cell_row(d, v)) << ((r & 1) * 16)); }
   }
   __syncthreads();
-  unsigned long long feas_m = big_m, self_m = 0;
+  unsigned long long feas_m = big_m;
 #pragma unroll 1
-  for (int k = 0; k < PER; ++k) {
+  for (int k = 0; k < per; ++k) {
     const int v = threadIdx.x + k * CC_T;
     int r = -1;
     if (flag_of(k) & 2) {
-      r = par[v];
-      const unsigned rows = (packed[r >> 1] >> ((r & 1) * 16)) & 0xFFFFu;
+      r = root_of(k, v);
+      const unsigned rows = par[r];
       if (((mid_m >> k) & 1ull) && __popc(rows) >= P.seg_valid_line_num) feas_m |= 1ull << k;
-      if (r == v) self_m |= 1ull << k;
       if (!(fused & 1) && r == v) d.cc_rows[base + v] = (unsigned long long)rows;
     }
     if ((fused & 2) && v < N) d.parent[base + v] = r;
@@ -667,7 +675,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(8, 8))) __launch_bounds__(CC_
   __shared__ int s_wtot[3][NW];
   unsigned long long keep_m = 0, outl_m = 0, root_m = 0;
 #pragma unroll 1
-  for (int k = 0; k < PER; ++k) {
+  for (int k = 0; k < per; ++k) {
     const int v = threadIdx.x + k * CC_T;
     int c = 0;
     bool fr = false;
@@ -694,7 +702,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(8, 8))) __launch_bounds__(CC_
     int v3[3], in3[3];
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-      v3[a] = e < PER * NW ? s_cnt[a][e] : 0;
+      v3[a] = e < per * NW ? s_cnt[a][e] : 0;
       int incl = v3[a];
 #pragma unroll
       for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
@@ -707,7 +715,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(8, 8))) __launch_bounds__(CC_
       int woff = 0;
 #pragma unroll
       for (int w = 0; w < NW; ++w) if (w < wave) woff += s_wtot[a][w];
-      if (e < PER * NW) s_cnt[a][e] = woff + in3[a] - v3[a];
+      if (e < per * NW) s_cnt[a][e] = woff + in3[a] - v3[a];
     }
     if (threadIdx.x == 0) {
       int t3[3] = {0, 0, 0};
@@ -725,7 +733,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(8, 8))) __launch_bounds__(CC_
   constexpr int CB = 3;
   static_assert(PER % CB == 0, "cells per thread must be a multiple of the batch");
 #pragma unroll 1
-  for (int k0 = 0; k0 < PER; k0 += CB) {
+  for (int k0 = 0; k0 < per; k0 += CB) {
     int own[CB];
     float4 pt[CB];
     float rg[CB];
@@ -958,7 +966,7 @@ void launch_ip(const DevCtx& d, int ring_pos, bool want_labels, hipStream_t st) 
     // bit 0: fused compaction; bit 1: write the root image to HBM (only ip_classify, ip_labels and alego_debug_get read it:
     // the single-scan entry points keep it, the batch path does not)
     const int cc_flags = (fused ? 1 : 0) | ((!fused || want_labels || d.n_launch == 1) ? 2 : 0);
-    ALEGO_LAUNCH(cc_lds16, dim3(d.n_launch), dim3(CC_LDS_THREADS), (size_t)8 * ((d.N + 1) / 2), st, d, ring_pos, cc_flags);
+    ALEGO_LAUNCH(cc_lds16, dim3(d.n_launch), dim3(CC_LDS_THREADS), (size_t)4 * ((d.N + 1) / 2), st, d, ring_pos, cc_flags);
   } else if (lds_cc) {
     ALEGO_LAUNCH(cc_lds, dim3(d.n_launch), dim3(CC_LDS_THREADS), (size_t)4 * d.N, st, d, ring_pos, 0);
   } else {

@@ -100,11 +100,16 @@ def _fe_compare(h, o, feat, tag):
         assert_bit_equal(feat[name], o.get(name), f"{tag} {name} cloud")
 
 
-@pytest.mark.parametrize("geom,nscan,box_lds", [((16, 1800), 6, None), ((16, 1800), 3, 0), ((16, 4000), 3, None), ((64, 2048), 3, None)])
+@pytest.mark.parametrize("geom,nscan,box_lds", [((16, 1800), 6, None), ((16, 1800), 3, 0), ((16, 1800), 3, "pick1"),
+                                                 ((16, 4000), 3, None), ((64, 2048), 3, None)])
 def test_fe_lo_teacher_forced(geom, nscan, box_lds, monkeypatch):
     """Each scan starts from the oracle's params_ (teacher forcing): indices exact, pose 1e-4.  box_lds = 0 makes lo_assoc
-    read its bounding boxes from HBM (the path of feature clouds too large for the LDS staging)."""
-    if box_lds is not None:
+    read its bounding boxes from HBM (the path of feature clouds too large for the LDS staging); "pick1" runs the
+    one-ring-per-wavefront fe_pick (the path of suppress_radius > 8) instead of fe_pick4.  The three geometries cover
+    fe_pick4<19>, <43> and <24>."""
+    if box_lds == "pick1":
+        monkeypatch.setenv("ALEGO_FE_PICK1", "1")
+    elif box_lds is not None:
         monkeypatch.setenv("ALEGO_LO_BOX_LDS", str(box_lds))
     p = synth.default_params(*geom)
     h, o = binding.Handle(p), O.Oracle(p)
