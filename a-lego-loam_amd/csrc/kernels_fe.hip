@@ -131,13 +131,12 @@ __global__ void __launch_bounds__(64) fe_pick(DevCtx d) {
 #pragma unroll
     for (int t = 0; t < FE_T; ++t) {
       const int c = lsp + lane + 64 * t;
-      key[t] = 0;
-      if (c <= lep) {
-        const uint8_t f = s_flag[c];
-        key[t] = (uint32_t)d_f2i(fabsf(cdv[c]));  // straight from HBM/L2: the LDS footprint decides how many rings fit a CU
-        if ((f & 7) == 4) sharp_m |= 1u << t;    // not picked, not ground, curvature > edge_thres
-        if ((f & 11) == 10) flat_m |= 1u << t;   // not picked, ground, curvature < surf_thres
-      }
+      const bool ok = c <= lep;   // unconditional loads (clamped address): all of them in flight together
+      const uint8_t f = s_flag[ok ? c : lsp];
+      const uint32_t kv = (uint32_t)d_f2i(fabsf(cdv[ok ? c : lsp]));  // straight from HBM/L2: the LDS footprint decides how many rings fit a CU
+      key[t] = ok ? kv : 0u;
+      if (ok && (f & 7) == 4) sharp_m |= 1u << t;    // not picked, not ground, curvature > edge_thres
+      if (ok && (f & 11) == 10) flat_m |= 1u << t;   // not picked, ground, curvature < surf_thres
     }
     // marks local index c and its +-SR neighbours picked (:211-234: stop at the first column jump), in LDS for
     // the later sectors and in the owners' candidate masks for this one
@@ -258,7 +257,7 @@ __global__ void __launch_bounds__(64) fe_pick4(DevCtx d) {
     const int rfr = Sr - 5, cntr = Er - Sr + 11;
     uint16_t* sc = s_col + (size_t)r * d.H;
     uint8_t* sf = s_flag + (size_t)r * d.H;
-#pragma unroll 4
+#pragma unroll 8
     for (int k = lane; k < cntr; k += 64) {
       const float a = fabsf(d.cd[base + rfr + k]);
       const double ad = (double)a;
@@ -273,7 +272,6 @@ __global__ void __launch_bounds__(64) fe_pick4(DevCtx d) {
   const int rf = S - 5;
   uint16_t* sc = s_col + (size_t)g * d.H;
   uint8_t* sf = s_flag + (size_t)g * d.H;
-  const float* cdv = d.cd + base + rf;
   int* st = d.st_idx + ((size_t)slot * d.NS + (rv ? ring : 0)) * d.st_stride;
   int* st_sharp = st, *st_lsharp = st + d.cap_sharp, *st_flat = st_lsharp + d.cap_lsharp;
   int n_sharp = 0, n_ls = 0, n_flat = 0;
@@ -289,14 +287,15 @@ __global__ void __launch_bounds__(64) fe_pick4(DevCtx d) {
     mask_t sharp_m = 0, flat_m = 0;
 #pragma unroll
     for (int t = 0; t < FE_T; ++t) {
+      // unconditional loads (clamped address): all FE_T of them in flight together.  Behind a branch the compiler waited
+      // for each load before it issued the next one: 19 global round trips per sector.
       const int c = lsp + gl + 16 * t;
-      key[t] = 0;
-      if (act0 && c <= lep) {
-        const uint8_t f = sf[c];
-        key[t] = (uint32_t)d_f2i(fabsf(cdv[c]));
-        if ((f & 7) == 4) sharp_m |= (mask_t)1 << t;
-        if ((f & 11) == 10) flat_m |= (mask_t)1 << t;
-      }
+      const bool ok = act0 && c <= lep;
+      const uint8_t f = sf[ok ? c : 0];
+      const uint32_t kv = (uint32_t)d_f2i(fabsf(d.cd[base + (ok ? rf + c : 0)]));
+      key[t] = ok ? kv : 0u;
+      if (ok && (f & 7) == 4) sharp_m |= (mask_t)1 << t;
+      if (ok && (f & 11) == 10) flat_m |= (mask_t)1 << t;
     }
     // marks c and its +-SR neighbours picked (:211-234) for the rows where `on`; `spread` rows look for column jumps first
     auto mark = [&](int c, bool on, bool spread) {

@@ -547,7 +547,7 @@ extern "C" void alego_cc_times(long long* out) { (void)hipMemcpyFromSymbol(out, 
 __global__ void __attribute__((amdgpu_waves_per_eu(8, 8))) __launch_bounds__(CC_T) cc_lds16(DevCtx d, int ring_pos, int fused) {
   const int slot = blockIdx.x + d.slot0;
   const size_t base = (size_t)slot * d.N;
-  const int N = d.N, H = d.H, NWORD = (N + 1) / 2;
+  const int N = d.N, H = d.H;
   extern __shared__ __attribute__((aligned(16))) unsigned char cc_smem[];
   uint16_t* par = reinterpret_cast<uint16_t*>(cc_smem);
   const uint8_t* fi = d.flag_img + base;
@@ -558,7 +558,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(8, 8))) __launch_bounds__(CC_
   CC_TICK(0);
   unsigned long long f0 = 0, f1 = 0, f2 = 0;   // the 4 flag bits of this thread's cells, 16 cells per word
 #pragma unroll 1
-  for (int w = 0; w < 3; ++w) {   // (one word at a time: 16 loads in flight, not 36 64-bit addresses in registers)
+  for (int w = 0; w < (per + 15) / 16; ++w) {   // (one word at a time: 16 loads in flight, not 36 64-bit addresses in registers)
     unsigned long long acc = 0;
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
