@@ -297,24 +297,38 @@ __global__ void __launch_bounds__(64) fe_pick4(DevCtx d) {
       if (ok && (f & 7) == 4) sharp_m |= (mask_t)1 << t;
       if (ok && (f & 11) == 10) flat_m |= (mask_t)1 << t;
     }
+    // One greedy pick is a few hundred DEPENDENT instructions of a single wavefront (126 of them per ring quad): the loop body
+    // is written branch-free.  LDS flag bytes are changed with no-return 32-bit atomics on the containing word (no read /
+    // wait / write round trip; an operand of 0 or a clamped address makes a lane's update a no-op), loads use clamped
+    // addresses, and only the list stores sit behind a (single) branch.
+    unsigned* fw = reinterpret_cast<unsigned*>(s_flag);   // 8 H bytes in front of s_flag: word-aligned
+    const int fo = g * d.H;                               // this ring's first flag byte
     // marks c and its +-SR neighbours picked (:211-234) for the rows where `on`; `spread` rows look for column jumps first
     auto mark = [&](int c, bool on, bool spread) {
-      bool bad = false;
-      if (spread) {
-        if (gl < SR) { const int cdf = (int)sc[c + gl + 1] - (int)sc[c + gl]; bad = (cdf < 0 ? -cdf : cdf) > P.suppress_col_diff; }
-        else if (gl >= 8 && gl < 8 + SR) { const int l = gl - 8; const int cdf = (int)sc[c - l - 1] - (int)sc[c - l]; bad = (cdf < 0 ? -cdf : cdf) > P.suppress_col_diff; }
-      }
+      const int role = gl & 7, rr = max(min(role, SR - 1), 0);   // lanes 0-7 look forward, 8-15 backward
+      const int a = spread ? (gl < 8 ? c + rr : c - rr - 1) : 0;
+      const int cdf = (int)sc[a + 1] - (int)sc[a];
+      const bool bad = spread && role < SR && (cdf < 0 ? -cdf : cdf) > P.suppress_col_diff;
       const unsigned long long mb = __ballot(bad);
       const unsigned gb = (unsigned)(mb >> (16 * g)) & 0xffffu;
       const unsigned lo = gb & 0xffu, hi = gb >> 8;
-      int nf = 0, nbk = 0;
-      if (spread) { nf = lo ? min(SR, __ffs((int)lo) - 1) : SR; nbk = hi ? min(SR, __ffs((int)hi) - 1) : SR; }
+      const int nf = spread ? (lo ? min(SR, __ffs((int)lo) - 1) : SR) : 0, nbk = spread ? (hi ? min(SR, __ffs((int)hi) - 1) : SR) : 0;
       const int first = c - nbk, last = c + nf;
-      if (on && gl <= last - first) sf[first + gl] |= 1;
+      const bool w = on && gl <= last - first;
+      const int bo = fo + (w ? first + gl : 0);
+      atomicOr(&fw[bo >> 2], (w ? 1u : 0u) << ((bo & 3) * 8));
       const int off = (gl - (first - lsp)) & 15;   // the (single) owned element inside [first, last]
       const int ct = first + off;
-      if (on && ct <= last && ct >= lsp && ct <= lep) { const mask_t bit = (mask_t)1 << ((ct - lsp - gl) >> 4); sharp_m &= ~bit; flat_m &= ~bit; }
+      const mask_t bit = (on && ct <= last && ct >= lsp && ct <= lep) ? (mask_t)1 << (((ct - lsp - gl) >> 4) & (8 * (int)sizeof(mask_t) - 1)) : (mask_t)0;
+      sharp_m &= ~bit; flat_m &= ~bit;
     };
+    // the label bits (4-5) of an unlabelled element hold 1 (label 0): 1 ^ 2 = 3 (sharp), 1 ^ 3 = 2 (less sharp), 1 ^ 1 = 0 (flat);
+    // an element is labelled at most once (it is marked picked with it)
+    auto relabel = [&](int c, unsigned x) {
+      const int bo = fo + (x ? c : 0);
+      atomicXor(&fw[bo >> 2], (x << 4) << ((bo & 3) * 8));
+    };
+    int* st_dummy = d.st_cnt + ((size_t)slot * d.NS + (rv ? ring : 0)) * 8 + 7;   // unused field
     // ---- sharp / less-sharp: descending curvature, ties -> larger index (:189-236) ----
     int picked_num = 0;
     bool act = act0;
@@ -328,18 +342,19 @@ __global__ void __launch_bounds__(64) fe_pick4(DevCtx d) {
       act = act && kmax != 0;
       if (!__any(act)) break;
       const int c = (int)row16_max_u32(bk == kmax ? (uint32_t)(lsp + gl + 16 * bt) : 0u);   // ties -> larger index
-      if (act) ++picked_num;
-      int lab = 0;
-      if (picked_num <= P.n_sharp) lab = 2; else if (picked_num <= P.n_less_sharp) lab = 1;
-      if (act && gl == 0) {
-        if (lab) sf[c] = (uint8_t)((sf[c] & 0xCF) | ((lab + 1) << 4));
-        if (lab == 2) st_sharp[n_sharp] = c + rf;
-        if (lab) st_lsharp[n_ls] = c + rf;
+      picked_num += act ? 1 : 0;
+      const int lab = picked_num <= P.n_sharp ? 2 : (picked_num <= P.n_less_sharp ? 1 : 0);
+      const bool w1 = act && gl == 0 && lab != 0;
+      relabel(c, w1 ? (lab == 2 ? 2u : 3u) : 0u);
+      if (w1) {
+        int* ps = lab == 2 ? st_sharp + n_sharp : st_dummy;
+        *ps = c + rf;
+        st_lsharp[n_ls] = c + rf;
       }
-      if (act && lab == 2) ++n_sharp;
-      if (act && lab) ++n_ls;
+      n_sharp += (act && lab == 2) ? 1 : 0;
+      n_ls += (act && lab) ? 1 : 0;
       mark(c, act, act && lab != 0);  // the 21st pick is marked but breaks before the suppression (:207-210)
-      if (!lab) act = false;
+      act = act && lab != 0;
     }
     // ---- flat: ascending curvature, ground only, ties -> smaller index (:238-277) ----
     picked_num = 0;
@@ -354,12 +369,14 @@ __global__ void __launch_bounds__(64) fe_pick4(DevCtx d) {
       act = act && kmin != 0xFFFFFFFFu;
       if (!__any(act)) break;
       const int c = (int)row16_min_u32(bk == kmin ? (uint32_t)(lsp + gl + 16 * bt) : 0xFFFFFFFFu);   // ties -> smaller index
-      if (act) ++picked_num;
-      if (act && gl == 0) { sf[c] = (uint8_t)(sf[c] & 0xCF); st_flat[n_flat] = c + rf; }   // label -1
-      if (act) ++n_flat;
+      picked_num += act ? 1 : 0;
+      const bool w1 = act && gl == 0;
+      relabel(c, w1 ? 1u : 0u);   // label -1
+      if (w1) st_flat[n_flat] = c + rf;
+      n_flat += act ? 1 : 0;
       const bool stop = picked_num >= P.n_flat;
       mark(c, act, act && !stop);  // the n_flat-th pick breaks before the suppression (:248-251)
-      if (stop) act = false;
+      act = act && !stop;
     }
   }
   __syncthreads();
