@@ -730,50 +730,44 @@ __global__ void __attribute__((amdgpu_waves_per_eu(8, 8))) __launch_bounds__(CC_
   CC_TICK(7);
   const float4* pts = d.in_pts + ((size_t)slot * d.ring_len + ring_pos) * d.Pcap;
   const unsigned long long below = (1ull << lane) - 1ull;
-  constexpr int CB = 3;
+  constexpr int CB = 3;   // cells per batch (emit() below is called CB times)
   static_assert(PER % CB == 0, "cells per thread must be a multiple of the batch");
+  const unsigned long long out_m = keep_m | outl_m;
+  // (scalars and a lambda instead of a float4 pt[CB] array: hipcc kept the array in scratch memory — a store and a load
+  //  through global memory per output cell in the longest phase of the kernel)
+  auto emit = [&](int k, const float4& q, float rg) {
+    const int v = threadIdx.x + k * CC_T;
+    const bool kp = (keep_m >> k) & 1ull, ol = (outl_m >> k) & 1ull, fr = (root_m >> k) & 1ull;
+    const unsigned long long bk = __ballot(kp), bo = __ballot(ol), bf = __ballot(fr);
+    if (v >= N) return;
+    const int row = cell_row(d, v), col = v - row * H;
+    const int line = s_cnt[0][k * NW + wave] + (int)__popcll(bk & below);
+    if (col == 0) {
+      d.ring_start[slot * d.NS + row] = line + 5;
+      if (row > 0) d.ring_end[slot * d.NS + row - 1] = line - 1 - 5;
+    }
+    if (kp || ol) {
+      const float4 p = make_float4(q.x, q.y, q.z, (float)(row + col / 10000.0));
+      if (kp) {
+        d.seg_pts[base + line] = p;
+        d.seg_ground[base + line] = (uint8_t)(flag_of(k) & 1);
+        d.seg_col[base + line] = col;
+        d.seg_range[base + line] = rg;
+      } else {
+        d.outlier[base + s_cnt[1][k * NW + wave] + (int)__popcll(bo & below)] = p;
+      }
+    }
+    if ((self_m >> k) & 1ull) d.cc_label[base + v] = fr ? s_cnt[2][k * NW + wave] + (int)__popcll(bf & below) + 1 : 0;
+  };
+  // clamped addresses instead of branches: the three owner loads, then the three point gathers and ranges, are in flight together
+  auto cell_of = [&](int k) -> int { return ((out_m >> k) & 1ull) ? threadIdx.x + k * CC_T : threadIdx.x; };
 #pragma unroll 1
   for (int k0 = 0; k0 < per; k0 += CB) {
-    int own[CB];
-    float4 pt[CB];
-    float rg[CB];
-#pragma unroll
-    for (int b = 0; b < CB; ++b) {
-      const int k = k0 + b, v = threadIdx.x + k * CC_T;
-      own[b] = (((keep_m | outl_m) >> k) & 1ull) ? d.owner[base + v] : 0;
-    }
-#pragma unroll
-    for (int b = 0; b < CB; ++b) {
-      const int k = k0 + b, v = threadIdx.x + k * CC_T;
-      pt[b] = (((keep_m | outl_m) >> k) & 1ull) ? pts[own[b]] : make_float4(0.f, 0.f, 0.f, 0.f);
-      rg[b] = ((keep_m >> k) & 1ull) ? d.range_img[base + v] : 0.f;
-    }
-#pragma unroll
-    for (int b = 0; b < CB; ++b) {
-      const int k = k0 + b, v = threadIdx.x + k * CC_T;
-      const bool kp = (keep_m >> k) & 1ull, ol = (outl_m >> k) & 1ull, fr = (root_m >> k) & 1ull;
-      const unsigned long long bk = __ballot(kp), bo = __ballot(ol), bf = __ballot(fr);
-      if (v >= N) continue;
-      const int row = cell_row(d, v), col = v - row * H;
-      const int line = s_cnt[0][k * NW + wave] + (int)__popcll(bk & below);
-      if (col == 0) {
-        d.ring_start[slot * d.NS + row] = line + 5;
-        if (row > 0) d.ring_end[slot * d.NS + row - 1] = line - 1 - 5;
-      }
-      if (kp || ol) {
-        float4 p = pt[b];
-        p.w = (float)(row + col / 10000.0);
-        if (kp) {
-          d.seg_pts[base + line] = p;
-          d.seg_ground[base + line] = (uint8_t)(flag_of(k) & 1);
-          d.seg_col[base + line] = col;
-          d.seg_range[base + line] = rg[b];
-        } else {
-          d.outlier[base + s_cnt[1][k * NW + wave] + (int)__popcll(bo & below)] = p;
-        }
-      }
-      if ((self_m >> k) & 1ull) d.cc_label[base + v] = fr ? s_cnt[2][k * NW + wave] + (int)__popcll(bf & below) + 1 : 0;
-    }
+    const int c0 = cell_of(k0), c1 = cell_of(k0 + 1), c2 = cell_of(k0 + 2);
+    const int o0 = d.owner[base + c0], o1 = d.owner[base + c1], o2 = d.owner[base + c2];
+    const float r0 = d.range_img[base + c0], r1 = d.range_img[base + c1], r2 = d.range_img[base + c2];
+    const float4 q0 = pts[max(o0, 0)], q1 = pts[max(o1, 0)], q2 = pts[max(o2, 0)];
+    emit(k0, q0, r0); emit(k0 + 1, q1, r1); emit(k0 + 2, q2, r2);
   }
   __syncthreads();
   CC_TICK(8);
