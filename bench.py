@@ -59,7 +59,7 @@ def kernel_bytes(name, c, NS, H, rebuilds_per_launch=0.0):
         "cc_lds16": N + 4 * N + 16 * (M + c["O"]) + 4 * M + 25 * M + 16 * c["O"],
         "cc_runs": 5 * N, "cc_link": N + 8 * N, "cc_stats": 5 * N + 4 * N,
         "ip_rowcount": 5 * N, "ip_compact": 9 * N + 16 * M + 25 * M + 16 * c["O"], "ip_labels": 9 * N,
-        "fe_curv": 8 * M + 5 * M, "fe_pick": 14 * M + 4 * M + 4 * (feats + M), "fe_voxel": 20 * M + 16 * c["Fs"],
+        "fe_curv": 8 * M + 5 * M, "fe_pick": 14 * M + 4 * M + 4 * (feats + M), "fe_pick4": 14 * M + 4 * M + 4 * (feats + M), "fe_voxel": 20 * M + 16 * c["Fs"],
         "fe_gather": 20 * (c["Qc"] + c["Fc"] + c["Qs"]) + 32 * c["Fs"],
         "lo_assoc": 16 * (c["Fc"] + c["Fs"] + c["Qc"] + c["Qs"]) / 2 + 16 * (c["Qc"] + c["Qs"]) / 2,
         "lo_solve": 16 * (c["Qc"] + c["Qs"]) + 64 * (c["Qc"] + c["Qs"]) + 104,
