@@ -2,12 +2,13 @@
 //
 //   fe_curv    a7,a8: 11-tap f32 curvature sum through an LDS window + occlusion / parallel-beam
 //              marking written as a gather (no atomics)                         (:122-159)
-//   fe_pick    a9: one wavefront per ring; the reference's "sort, then scan descending/ascending"
-//              is evaluated as repeated wave-wide arg-max / arg-min over the not-yet-picked
-//              candidates of the sector (identical result for the total order (curvature, index));
-//              +-5 neighbour suppression by ballot                              (:172-286)
-//   fe_voxel   a10: per-ring pcl::VoxelGrid(0.4): LDS bitonic sort of (voxel id, position),
-//              centroid in sorted (= original) order                           (:288-293)
+//   fe_pick4   a9: four rings per wavefront (one 16-lane DPP row each); the reference's "sort, then scan
+//              descending/ascending" is evaluated as repeated row-wide arg-max / arg-min over the
+//              not-yet-picked candidates of the sector (identical result for the total order
+//              (curvature, index)); +-5 neighbour suppression by ballot         (:172-286)
+//   fe_pick    the same with one ring per wavefront (suppress_radius > 8, very long sectors)
+//   fe_voxel   a10: per-ring pcl::VoxelGrid(0.4): runs of consecutive equal voxel ids ordered through
+//              monotone buckets in LDS, centroid in sorted (= original) order    (:288-293)
 //   fe_gather  ring-ascending concatenation into the four feature clouds       (:199-205,:245,:293)
 //   fe_boxes   bounding boxes of 32 consecutive less_flat / less_sharp points for the next scan's LaserOdometry
 #include <cstdlib>
@@ -661,10 +662,10 @@ __global__ void __launch_bounds__(FE_BLOCK) fe_gather(DevCtx d) {
   for (int k = 0; k < 3; ++k) {
     dstk[k] = d.feat[k] + ((size_t)slot * 2 + cur) * d.fcap[k] + s_off[k];
     dstik[k] = d.feat_idx[k] + ((size_t)slot * 2 + cur) * d.fcap[k] + s_off[k];
-    ixk[k] = tid < myc[k] ? stk[k][tid] : 0;
+    ixk[k] = stk[k][min(tid, max(myc[k] - 1, 0))];   // (clamped, unconditional: the five loads of this block are in flight together)
   }
 #pragma unroll
-  for (int u = 0; u < 2; ++u) lf[u] = tid + u * FE_BLOCK < n_lf ? src_lf[tid + u * FE_BLOCK] : make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int u = 0; u < 2; ++u) lf[u] = src_lf[min(tid + u * FE_BLOCK, d.H - 1)];
 #pragma unroll
   for (int k = 0; k < 3; ++k) ptk[k] = seg[ixk[k]];
 #pragma unroll

@@ -563,7 +563,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(8, 8))) __launch_bounds__(CC_
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
       const int k = w * 16 + q, v = threadIdx.x + k * CC_T;
-      const unsigned long long f = (k < PER && v < N) ? (unsigned long long)(fi[v] & 15u) : 0ull;
+      const unsigned long long f = (unsigned long long)(fi[min(v, N - 1)] & 15u) * (unsigned long long)(k < PER && v < N);   // (unconditional load: behind a branch each of the 16 waited for the previous one)
       acc |= f << (q * 4);
     }
     if (w == 0) f0 = acc; else if (w == 1) f1 = acc; else f2 = acc;

@@ -373,8 +373,10 @@ __global__ void __launch_bounds__(128) lm_knn(DevCtx d, LmCtx L) {
       const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.gx - 1);
       const bool in = z >= 0 && z < g.gz && y >= 0 && y < g.gy && x0 <= x1;
       const int c0 = x0 + g.gx * (y + g.gy * z), c1 = x1 + g.gx * (y + g.gy * z);
-      rs[r] = in ? cs[c0] : 0;
-      re[r] = in ? cs[c1 + 1] : 0;
+      // (clamped addresses, not `in ? cs[c0] : 0`: behind a branch every one of the 18 loads waited for the previous one)
+      const int a0 = cs[in ? c0 : 0], a1 = cs[in ? c1 + 1 : 0];
+      rs[r] = in ? a0 : 0;
+      re[r] = in ? a1 : 0;
     }
     auto consider = [&](const float4& a) {
       const int idx = __float_as_int(a.w);
@@ -393,9 +395,15 @@ __global__ void __launch_bounds__(128) lm_knn(DevCtx d, LmCtx L) {
         }
       }
     };
+    // the first candidate of each of the nine runs: nine independent loads (a run is usually exhausted by one or two turns)
+    float4 first[9];
+#pragma unroll
+    for (int r = 0; r < 9; ++r) first[r] = cp[rs[r] + sub < re[r] ? rs[r] + sub : 0];
+#pragma unroll
+    for (int r = 0; r < 9; ++r) if (rs[r] + sub < re[r]) consider(first[r]);
 #pragma unroll
     for (int r = 0; r < 9; ++r) {
-      for (int t = rs[r] + sub; t < re[r]; t += 2 * LM_KNN_LANES) {  // an x-run of cells is contiguous in the cell-sorted copy
+      for (int t = rs[r] + sub + LM_KNN_LANES; t < re[r]; t += 2 * LM_KNN_LANES) {  // an x-run of cells is contiguous in the cell-sorted copy
         const int t1 = t + LM_KNN_LANES;
         const float4 a0 = cp[t], a1 = cp[t1 < re[r] ? t1 : t];
         consider(a0);
