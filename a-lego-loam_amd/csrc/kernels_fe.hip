@@ -662,10 +662,10 @@ __global__ void __launch_bounds__(FE_BLOCK) fe_gather(DevCtx d) {
   for (int k = 0; k < 3; ++k) {
     dstk[k] = d.feat[k] + ((size_t)slot * 2 + cur) * d.fcap[k] + s_off[k];
     dstik[k] = d.feat_idx[k] + ((size_t)slot * 2 + cur) * d.fcap[k] + s_off[k];
-    ixk[k] = stk[k][min(tid, max(myc[k] - 1, 0))];   // (clamped, unconditional: the five loads of this block are in flight together)
+    ixk[k] = tid < myc[k] ? stk[k][tid] : 0;
   }
 #pragma unroll
-  for (int u = 0; u < 2; ++u) lf[u] = src_lf[min(tid + u * FE_BLOCK, d.H - 1)];
+  for (int u = 0; u < 2; ++u) lf[u] = tid + u * FE_BLOCK < n_lf ? src_lf[tid + u * FE_BLOCK] : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
   for (int k = 0; k < 3; ++k) ptk[k] = seg[ixk[k]];
 #pragma unroll
