@@ -535,19 +535,52 @@ __global__ void __launch_bounds__(LM_SOLVE_BLOCK) lm_solve(DevCtx d, LmCtx L) {
   const double* blocks = L.blocks + (size_t)slot * L.qcap * 8;
   const float4* qc = L.cur_corner_ds + (size_t)slot * L.kf_cap_c;
   const float4* qs = L.cur_total_ds + (size_t)slot * L.total_cap;
-  {  // correspondence counts (:465)
+  // ---- correspondence counts (:465) and the packed list of accepted rows.  About half of the queries have no
+  // correspondence; every solver evaluation streams the rows once, so they are packed once (thread-major order: the
+  // summation order of the normal equations is fixed by it, like before by the query index) and the ~30 evaluations of a
+  // mapping frame read half as much.
+  double* crows = L.crows + (size_t)slot * L.qcap * 10;
+  const int nrows_all = nqc + nqs;
+  {
+    constexpr int CU_ = 4;   // type flags of four rows in flight
     int cc = 0, cs = 0;
-    for (int i = threadIdx.x; i < nqc; i += LM_SOLVE_BLOCK) cc += blocks[(size_t)i * 8 + 7] != 0.0;
-    for (int i = threadIdx.x; i < nqs; i += LM_SOLVE_BLOCK) cs += blocks[(size_t)(L.kf_cap_c + i) * 8 + 7] != 0.0;
+    for (int i0 = threadIdx.x; i0 < nrows_all; i0 += LM_SOLVE_BLOCK * CU_) {
+      double ty[CU_];
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { cc += __shfl_xor(cc, o, 64); cs += __shfl_xor(cs, o, 64); }
-    if (lane_id() == 0) { s_cnt[0][threadIdx.x >> 6] = cc; s_cnt[1][threadIdx.x >> 6] = cs; }
+      for (int u = 0; u < CU_; ++u) { const int i = min(i0 + u * LM_SOLVE_BLOCK, nrows_all - 1); ty[u] = blocks[(size_t)(i < nqc ? i : L.kf_cap_c + (i - nqc)) * 8 + 7]; }
+#pragma unroll
+      for (int u = 0; u < CU_; ++u) { const int i = i0 + u * LM_SOLVE_BLOCK; if (i < nrows_all && ty[u] != 0.0) { if (i < nqc) ++cc; else ++cs; } }
+    }
+    // exclusive scan of (cc + cs) over the threads: wavefront scan, then the wavefront totals
+    const int mine = cc + cs;
+    int incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane_id() >= o) incl += t; }
+    int wc = cc, ws = cs;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { wc += __shfl_xor(wc, o, 64); ws += __shfl_xor(ws, o, 64); }
+    if (lane_id() == 0) { s_cnt[0][threadIdx.x >> 6] = wc; s_cnt[1][threadIdx.x >> 6] = ws; }
+    __syncthreads();
+    int woff = 0, ta = 0, tb = 0;
+    for (int w = 0; w < LM_SOLVE_BLOCK / 64; ++w) { const int c = s_cnt[0][w] + s_cnt[1][w]; if (w < (int)(threadIdx.x >> 6)) woff += c; ta += s_cnt[0][w]; tb += s_cnt[1][w]; }
+    int pos = woff + incl - mine;
+    for (int i = threadIdx.x; i < nrows_all; i += LM_SOLVE_BLOCK) {
+      const bool is_c = i < nqc;
+      const double4* b = reinterpret_cast<const double4*>(blocks + (size_t)(is_c ? i : L.kf_cap_c + (i - nqc)) * 8);
+      const double4 lo = b[0], hi = b[1];
+      if (hi.w != 0.0) {
+        const float4 pc = is_c ? qc[i] : qs[i - nqc];
+        double2* o = reinterpret_cast<double2*>(crows + (size_t)pos * 10);   // 80 B rows: 16-byte aligned (not 32: no double4 here)
+        o[0] = make_double2(lo.x, lo.y); o[1] = make_double2(lo.z, lo.w); o[2] = make_double2(hi.x, hi.y); o[3] = make_double2(hi.z, hi.w);
+        *reinterpret_cast<float4*>(o + 4) = pc;
+        ++pos;
+      }
+    }
+    __threadfence_block();
     __syncthreads();
     if (threadIdx.x == 0) {
-      int a = 0, b = 0;
-      for (int w = 0; w < LM_SOLVE_BLOCK / 64; ++w) { a += s_cnt[0][w]; b += s_cnt[1][w]; }
-      li[LI_NCC] = a; li[LI_NSC] = b; li[LI_OPTIMIZED] = 1;
-      s_cnt[0][0] = a + b;
+      li[LI_NCC] = ta; li[LI_NSC] = tb; li[LI_OPTIMIZED] = 1;
+      s_cnt[0][0] = ta + tb;
     }
     __syncthreads();
   }
@@ -567,31 +600,27 @@ __global__ void __launch_bounds__(LM_SOLVE_BLOCK) lm_solve(DevCtx d, LmCtx L) {
 #ifdef ALEGO_TIMING
     const long long c1_ = clock64();
 #endif
-    // software-pipelined: the (unconditional) loads of row i+1 are issued before row i is evaluated
-    struct Row { double4 lo, hi; float4 pc; };
+    // software-pipelined: the loads of row i+1 are issued before row i is evaluated
+    struct Row { double2 q0, q1, q2, q3; float4 pc; };   // a.xy | a.z b.x | b.yz | d, type
     auto load_row = [&](int i) {
       Row r;
-      const bool is_c = i < nqc;
-      const double4* b = reinterpret_cast<const double4*>(blocks + (size_t)(is_c ? i : L.kf_cap_c + (i - nqc)) * 8);
-      r.lo = b[0]; r.hi = b[1];
-      r.pc = is_c ? qc[i] : qs[i - nqc];
+      const double2* b = reinterpret_cast<const double2*>(crows + (size_t)i * 10);
+      r.q0 = b[0]; r.q1 = b[1]; r.q2 = b[2]; r.q3 = b[3];
+      r.pc = *reinterpret_cast<const float4*>(b + 4);
       return r;
     };
-    const int nrows = nqc + nqs;
     int i = threadIdx.x;
     Row cur;
-    if (i < nrows) cur = load_row(i);
-    while (i < nrows) {
+    if (i < R) cur = load_row(i);
+    while (i < R) {
       const int inext = i + LM_SOLVE_BLOCK;
       Row nxt = cur;
-      if (inext < nrows) nxt = load_row(inext);
-      const double ty = cur.hi.w;
-      if (ty != 0.0) {
-        const double cp[3] = {cur.pc.x, cur.pc.y, cur.pc.z}, a3[3] = {cur.lo.x, cur.lo.y, cur.lo.z}, b3[3] = {cur.lo.w, cur.hi.x, cur.hi.y}, c3[3] = {0, 0, 0};
-        double res, J[6];
-        eval_block(ty == 2.0 ? BLK_EDGE : BLK_PLANE, cp, a3, b3, c3, cur.hi.z, T, &res, J);
-        accumulate_block(res, J, P.huber_delta, acc);
-      }
+      if (inext < R) nxt = load_row(inext);
+      const double ty = cur.q3.y;
+      const double cp[3] = {cur.pc.x, cur.pc.y, cur.pc.z}, a3[3] = {cur.q0.x, cur.q0.y, cur.q1.x}, b3[3] = {cur.q1.y, cur.q2.x, cur.q2.y}, c3[3] = {0, 0, 0};
+      double res, J[6];
+      eval_block(ty == 2.0 ? BLK_EDGE : BLK_PLANE, cp, a3, b3, c3, cur.q3.x, T, &res, J);
+      accumulate_block(res, J, P.huber_delta, acc);
       cur = nxt;
       i = inext;
     }

@@ -66,6 +66,7 @@ struct LmCtx {
   int* knn;                                       // [slot][qcap][5] neighbour indices of every query (lm_knn -> lm_fit)
   // residual blocks
   double* blocks;                                 // [slot][qcap][8]: a/normal (3), b (3), d, type (0 = none)
+  double* crows;                                  // [slot][qcap][10]: the accepted rows only, packed for lm_solve: the 8 doubles above + the query point (float4)
 };
 
 #endif

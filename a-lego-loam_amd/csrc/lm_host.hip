@@ -70,7 +70,7 @@ LmHost* lm_host_create(const alego_params& P, const DevCtx& d, int n_slots, int 
   ok = ok && A(lm, &L.cur_total, B * L.total_cap, err) && A(lm, &L.cur_total_ds, B * L.total_cap, err);
   ok = ok && A(lm, &L.grid, B * 2, err) && A(lm, &L.cell_start, B * 2 * ((size_t)L.gcap + 1), err) && A(lm, &L.cell_cur, B * 2 * ((size_t)L.gcap + 1), err);
   ok = ok && A(lm, &L.cell_pts, B * 2 * L.map_cap_s, err);
-  ok = ok && A(lm, &L.blocks, B * L.qcap * 8, err) && A(lm, &L.knn, B * L.qcap * 5, err);
+  ok = ok && A(lm, &L.blocks, B * L.qcap * 8, err) && A(lm, &L.crows, B * L.qcap * 10, err) && A(lm, &L.knn, B * L.qcap * 5, err);
   if (!ok) { lm_host_destroy(lm); return nullptr; }
   // identity quaternions (laserMapping.cpp:56-61)
   std::vector<double> ld(B * LD_COUNT, 0.0);
