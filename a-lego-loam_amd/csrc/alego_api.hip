@@ -194,7 +194,10 @@ int alego_create(const alego_params* params, int device, int n_slots, int ring_l
     po[b * 16 + 3] = 1.0; po[b * 16 + 10] = 1.0;
   }
   std::vector<int> sc0(B * SC_COUNT, 0);
-  for (size_t b = 0; b < B; ++b) sc0[b * SC_COUNT + SC_CUR] = 1;  // the first scan writes feature buffer 0
+  for (size_t b = 0; b < B; ++b) {
+    sc0[b * SC_COUNT + SC_CUR] = 1;  // the first scan writes feature buffer 0
+    sc0[b * SC_COUNT + SC_FIRST] = 0x7fffffff; sc0[b * SC_COUNT + SC_LAST] = -1;   // accumulators of ip_project, re-armed by ip_image
+  }
   hipMemcpy(d.scal, sc0.data(), sc0.size() * sizeof(int), hipMemcpyHostToDevice);
   hipMemcpy(d.lo_state, st.data(), st.size() * sizeof(double), hipMemcpyHostToDevice);
   hipMemcpy(d.poses, po.data(), po.size() * sizeof(double), hipMemcpyHostToDevice);
@@ -311,7 +314,7 @@ int alego_batch_get_counts(alego_handle* h, int slot, int32_t* out, int cap) {
   HIP_TRY(h, hipMemcpyAsync(fc, h->d.feat_cnt + (size_t)slot * 8, sizeof(fc), hipMemcpyDeviceToHost, stream_of(h, slot)));
   HIP_TRY(h, hipStreamSynchronize(stream_of(h, slot)));
   const int cur = sc[SC_CUR];  // buffer written by the last processed scan
-  int v[16] = {sc[SC_PVALID], sc[SC_M], sc[SC_NOUT], fc[cur * 4 + 0], fc[cur * 4 + 1], fc[cur * 4 + 2], fc[cur * 4 + 3],
+  int v[16] = {sc[SC_PVALID_OUT], sc[SC_M], sc[SC_NOUT], fc[cur * 4 + 0], fc[cur * 4 + 1], fc[cur * 4 + 2], fc[cur * 4 + 3],
                sc[SC_LO_NSURF], sc[SC_LO_NCORNER], 0, 0, 0, 0, 0, 0, 0};  // v[15] = map rebuilds so far
   lm_host_get_counts(h->lm, slot, v + 9);
   for (int i = 0; i < cap && i < 16; ++i) out[i] = v[i];

@@ -29,8 +29,11 @@ enum {
   SC_ODOM_VALID,
   SC_LM_FRAME,    // LaserMapping frame_cnt (laserMapping.cpp:111)
   SC_LM_FLAGS,
+  SC_PVALID_OUT,  // valid input points of the last projected scan (SC_PVALID is an accumulator, cleared by ip_image)
   SC_COUNT = 32
 };
+
+#define IP_OWNER_TAG 0x40000000   // any tagged entry beats every plain one (index or -1) in ip_project's atomicMax
 
 // feature cloud kinds
 enum { F_SHARP = 0, F_LSHARP = 1, F_FLAT = 2, F_LFLAT = 3 };
@@ -51,7 +54,8 @@ struct DevCtx {
   float4* in_pts;  // [slot][ring][Pcap]
   int* in_n;       // [slot][ring]
   // ---- image projection ----
-  int* owner;           // [slot][N] winning input index per cell (last writer = max index), -1 empty
+  int* owner;           // [slot][N] winning input index per cell (last writer = max index), -1 empty; ip_project writes
+                        // IP_OWNER_TAG | index, ip_image turns every cell back into the plain form (= the reset for the next scan)
   float* range_img;     // [slot][N] f32 range, -1 empty
   uint8_t* flag_img;    // [slot][N] bit0 ground, bit1 active (filled, non-ground), bit2 edge->right, bit3 edge->down
   int* parent;          // [slot][N] union-find parent (root = min linear index of the component)

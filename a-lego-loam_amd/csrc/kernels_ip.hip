@@ -1,6 +1,5 @@
 // kernels_ip.hip — ImageProjection on gfx950 (replaces src/imageProjection.cpp:49-316).
 //
-//   ip_reset      owner image / per-slot scalars
 //   ip_project    a1-a3: NaN/near filter, row/col from the shared fdlibm atan2f, last-writer-wins
 //                 scatter resolved by atomicMax on the input index          (:58-59,:76-104)
 //   ip_image      a2,a3,a4: orientation, range image gather, per-column ground test (:62-72,:107-143)
@@ -20,18 +19,6 @@
 
 #define IP_BLOCK 256
 #define IP_PW 4   // points / cells per thread in the streaming kernels
-
-__global__ void __launch_bounds__(IP_BLOCK) ip_reset(DevCtx d) {
-  const int slot = blockIdx.y + d.slot0;
-  const int v0 = blockIdx.x * IP_BLOCK * IP_PW + threadIdx.x;
-#pragma unroll
-  for (int u = 0; u < IP_PW; ++u) { const int v = v0 + u * IP_BLOCK; if (v < d.N) d.owner[(size_t)slot * d.N + v] = -1; }
-  if (v0 == 0) {
-    int* sc = d.scal + slot * SC_COUNT;
-    sc[SC_FIRST] = 0x7fffffff; sc[SC_LAST] = -1; sc[SC_PVALID] = 0;
-
-  }
-}
 
 __global__ void __launch_bounds__(IP_BLOCK) ip_project(DevCtx d, int ring_pos) {
   const int slot = blockIdx.y + d.slot0;
@@ -82,7 +69,8 @@ __global__ void __launch_bounds__(IP_BLOCK) ip_project(DevCtx d, int ring_pos) {
       if (fabs(cfast - rint(cfast)) < 1e-9 * (1.0 + fabs(cfast))) col = (int)((ha / M_PI) / P.ang_res_x);
       if (col >= d.H) col -= d.H;
       if (row >= 0 && row < d.NS && col >= 0 && col < d.H)
-        atomicMax(&d.owner[(size_t)slot * d.N + col + row * d.H], i);  // later points overwrite earlier ones (:102-103)
+        atomicMax(&d.owner[(size_t)slot * d.N + col + row * d.H], IP_OWNER_TAG | i);  // later points overwrite earlier ones (:102-103);
+        // whatever the previous scan left in the cell (a plain index or -1, see ip_image) loses against a tagged entry: no reset pass
     }
   }
   if (valid) { vmin = min(vmin, i); vmax = max(vmax, i); ++nvalid; }
@@ -109,10 +97,13 @@ __global__ void __launch_bounds__(128) ip_image(DevCtx d, int ring_pos) {
   const alego_params& P = d.P;
   const float4* pts = d.in_pts + ((size_t)slot * d.ring_len + ring_pos) * d.Pcap;
   if (col == 0) {  // orientation, :62-72
-    const int* sc = d.scal + slot * SC_COUNT;
+    int* sc = d.scal + slot * SC_COUNT;
     float* ori = d.ori + slot * 4;
-    if (sc[SC_LAST] >= 0) {
-      const float4 p0 = pts[sc[SC_FIRST]], p1 = pts[sc[SC_LAST]];
+    const int first = sc[SC_FIRST], last = sc[SC_LAST];
+    sc[SC_PVALID_OUT] = sc[SC_PVALID];
+    sc[SC_FIRST] = 0x7fffffff; sc[SC_LAST] = -1; sc[SC_PVALID] = 0;   // re-armed for the next scan's ip_project
+    if (last >= 0) {
+      const float4 p0 = pts[first], p1 = pts[last];
       float so = -d_atan2f(p0.y, p0.x);
       float eo = (float)((double)(-d_atan2f(p1.y, p1.x)) + 2 * M_PI);
       if ((double)(eo - so) > 3 * M_PI) eo = (float)((double)eo - 2 * M_PI);
@@ -121,7 +112,7 @@ __global__ void __launch_bounds__(128) ip_image(DevCtx d, int ring_pos) {
     }
   }
   if (col >= d.H) return;
-  const int* owner = d.owner + (size_t)slot * d.N;
+  int* owner = d.owner + (size_t)slot * d.N;
   float* rimg = d.range_img + (size_t)slot * d.N;
   uint8_t* fimg = d.flag_img + (size_t)slot * d.N;
   unsigned long long filled = 0, ground = 0;
@@ -134,6 +125,13 @@ __global__ void __launch_bounds__(128) ip_image(DevCtx d, int ring_pos) {
   float4 pb[IM_U];
 #pragma unroll
   for (int u = 0; u < IM_U; ++u) ob[u] = row0 + u < d.NS ? owner[(row0 + u) * d.H + col] : -1;
+  // entries of this scan carry the tag; everything else is stale.  The plain form is written back for the later readers
+  // (compaction) and doubles as the reset for the next scan.
+#pragma unroll
+  for (int u = 0; u < IM_U; ++u) {
+    ob[u] = (ob[u] >= 0 && (ob[u] & IP_OWNER_TAG)) ? (ob[u] & ~IP_OWNER_TAG) : -1;
+    if (row0 + u < d.NS) owner[(row0 + u) * d.H + col] = ob[u];
+  }
 #pragma unroll
   for (int u = 0; u < IM_U; ++u) pb[u] = ob[u] >= 0 ? pts[ob[u]] : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
@@ -951,7 +949,6 @@ void launch_ip(const DevCtx& d, int ring_pos, bool want_labels, hipStream_t st) 
   const bool fused = fuse_env && d.N <= CC_LDS_MAXN && d.NS <= 16;   // cc_lds also does the compaction
   const dim3 gN((d.N + IP_BLOCK - 1) / IP_BLOCK, d.n_launch);
   const dim3 gN4((d.N + IP_BLOCK * IP_PW - 1) / (IP_BLOCK * IP_PW), d.n_launch), gP4((d.Pcap + IP_BLOCK * IP_PW - 1) / (IP_BLOCK * IP_PW), d.n_launch);
-  ALEGO_LAUNCH(ip_reset, gN4, dim3(IP_BLOCK), 0, st, d);
   ALEGO_LAUNCH(ip_project, gP4, dim3(IP_BLOCK), 0, st, d, ring_pos);
   ALEGO_LAUNCH(ip_image, dim3((d.H + 127) / 128, d.n_launch), dim3(128), 0, st, d, ring_pos);
   const bool lds_cc = d.N <= CC_LDS_MAXN, lds_stats = lds_cc && d.NS <= 16;

@@ -338,7 +338,6 @@ __global__ void __launch_bounds__(128) lm_knn(DevCtx d, LmCtx L) {
   if (li[LI_NCUR_C] < P.lm_min_corner || li[LI_NTOTAL] < P.lm_min_surf || li[LI_KDS_C] < P.lm_min_map_corner || li[LI_NKF] == 0) return;
   const int nq = kind == 0 ? li[LI_NCUR_C] : li[LI_NTOTAL_DS];
   const float4* qp = kind == 0 ? L.cur_corner_ds + (size_t)slot * L.kf_cap_c : L.cur_total_ds + (size_t)slot * L.total_cap;
-  const float4* mp = kind == 0 ? L.map_corner_ds + (size_t)slot * L.map_cap_c : L.map_surf_ds + (size_t)slot * L.map_cap_s;
   const int nmap = li[LI_KDS_C + kind];
   const GridGeom g = L.grid[(size_t)slot * 2 + kind];
   const int* cs = L.cell_start + ((size_t)slot * 2 + kind) * (L.gcap + 1);

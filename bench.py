@@ -53,7 +53,7 @@ def kernel_bytes(name, c, NS, H, rebuilds_per_launch=0.0):
     scan_pts = c["Fc"] + c["Fs"] + c["O"] + c["Ls"]  # points of the four current-scan VoxelGrid jobs
     rb = rebuilds_per_launch
     t = {
-        "ip_reset": 4 * N, "ip_project": 16 * P + 4 * P, "ip_image": 4 * N + 16 * P + 5 * N,
+        "ip_project": 16 * P + 4 * P, "ip_image": 8 * N + 16 * P + 5 * N,
         "cc_edges": 5 * N + 17 * N, "cc_lds": N + 4 * N + 12 * N,
         # cc_lds16: flags, owner, points + range in; cloud_info arrays + outliers out
         "cc_lds16": N + 4 * N + 16 * (M + c["O"]) + 4 * M + 25 * M + 16 * c["O"],

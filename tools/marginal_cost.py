@@ -4,7 +4,7 @@ import json, os, subprocess, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 streams = sys.argv[1] if len(sys.argv) > 1 else "1536"
 steps = sys.argv[2] if len(sys.argv) > 2 else "60"
-kernels = ["", "ip_reset", "ip_project", "ip_image", "cc_edges", "cc_lds16", "fe_curv", "fe_pick", "fe_voxel", "fe_gather", "fe_boxes",
+kernels = ["", "ip_project", "cc_edges", "cc_lds16", "fe_curv", "fe_pick", "fe_voxel", "fe_gather", "fe_boxes",
            "lo_assoc<0>", "lo_assoc<1>", "lm_concat", "vox_small", "vox_big", "lm_knn", "lm_fit", "lm_store_kf"]
 base = None
 for k in kernels:
