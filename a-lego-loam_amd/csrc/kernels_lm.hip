@@ -147,11 +147,23 @@ DEV_INLINE float vxl_dec(unsigned e) {
 }
 
 // grid (2, slots): grid geometry from the raw map bounding box, zero the cell counters
-__global__ void __launch_bounds__(LM_BLOCK) lm_grid_setup(DevCtx d, LmCtx L) {
+DEV_INLINE int grid_cell(const GridGeom& g, float x, float y, float z, int* cx, int* cy, int* cz) {
+  int ix = (int)floorf((x - g.ox) * g.inv), iy = (int)floorf((y - g.oy) * g.inv), iz = (int)floorf((z - g.oz) * g.inv);
+  *cx = ix; *cy = iy; *cz = iz;
+  ix = min(max(ix, 0), g.gx - 1); iy = min(max(iy, 0), g.gy - 1); iz = min(max(iz, 0), g.gz - 1);
+  return ix + g.gx * (iy + g.gy * iz);
+}
+
+// grid (2, slots): the whole uniform-grid build of one map by one workgroup — geometry from the VoxelGrid bounding box, cell
+// counts, exclusive scan, cell-sorted copy.  Only the streams whose map was rebuilt this frame do anything (≈1 in 16), and
+// a filtered map is a few thousand points: four launches (setup, count, scan, fill) cost more in launch latency than in work.
+__global__ void __launch_bounds__(LM_BLOCK) lm_grid_build(DevCtx d, LmCtx L) {
   const int slot = blockIdx.y + d.slot0, m = blockIdx.x;
   const int* li = lip(L, slot);
   if (!li[LI_REBUILD]) return;
   __shared__ GridGeom s_g;
+  __shared__ int s[LM_BLOCK / 64];
+  __shared__ int s_run;
   if (threadIdx.x == 0) {
     const unsigned* bb = L.vox_bbox + ((size_t)(slot - L.vox_slot0) * 2 + m) * 8;
     GridGeom g;
@@ -169,53 +181,31 @@ __global__ void __launch_bounds__(LM_BLOCK) lm_grid_setup(DevCtx d, LmCtx L) {
     g.ox = mn[0]; g.oy = mn[1]; g.oz = mn[2]; g.inv = 1.0f / cell; g.ncell = g.gx * g.gy * g.gz;
     s_g = g;
     L.grid[(size_t)slot * 2 + m] = g;
+    s_run = 0;
   }
   __syncthreads();
-  int* cs = L.cell_start + ((size_t)slot * 2 + m) * (L.gcap + 1);
-  for (int c = threadIdx.x; c <= s_g.ncell; c += LM_BLOCK) cs[c] = 0;
-}
-
-DEV_INLINE int grid_cell(const GridGeom& g, float x, float y, float z, int* cx, int* cy, int* cz) {
-  int ix = (int)floorf((x - g.ox) * g.inv), iy = (int)floorf((y - g.oy) * g.inv), iz = (int)floorf((z - g.oz) * g.inv);
-  *cx = ix; *cy = iy; *cz = iz;
-  ix = min(max(ix, 0), g.gx - 1); iy = min(max(iy, 0), g.gy - 1); iz = min(max(iz, 0), g.gz - 1);
-  return ix + g.gx * (iy + g.gy * iz);
-}
-
-// grid (8, 2, slots)
-__global__ void __launch_bounds__(LM_BLOCK) lm_grid_count(DevCtx d, LmCtx L, int fill) {
-  const int slot = blockIdx.z + d.slot0, m = blockIdx.y;
-  const int* li = lip(L, slot);
-  if (!li[LI_REBUILD]) return;
-  const GridGeom g = L.grid[(size_t)slot * 2 + m];
-  const int n = li[LI_KDS_C + m];
-  const float4* pts = (m == 0 ? L.map_corner_ds + (size_t)slot * L.map_cap_c : L.map_surf_ds + (size_t)slot * L.map_cap_s);
-  int* cs = (fill ? L.cell_cur : L.cell_start) + ((size_t)slot * 2 + m) * (L.gcap + 1);
-  float4* cp = L.cell_pts + ((size_t)slot * 2 + m) * L.map_cap_s;
-  for (int i = blockIdx.x * LM_BLOCK + threadIdx.x; i < n; i += gridDim.x * LM_BLOCK) {
-    const float4 p = pts[i];
-    int cx, cy, cz;
-    const int c = grid_cell(g, p.x, p.y, p.z, &cx, &cy, &cz);
-    const int pos = atomicAdd(&cs[c], 1);
-    if (fill) cp[pos] = make_float4(p.x, p.y, p.z, __int_as_float(i));  // cell-sorted copy: one contiguous read per cell run
-  }
-}
-
-// grid (2, slots): exclusive scan of the cell counts (in place) + fill cursors
-__global__ void __launch_bounds__(LM_BLOCK) lm_grid_scan(DevCtx d, LmCtx L) {
-  const int slot = blockIdx.y + d.slot0, m = blockIdx.x;
-  const int* li = lip(L, slot);
-  if (!li[LI_REBUILD]) return;
-  const int ncell = L.grid[(size_t)slot * 2 + m].ncell;
+  const GridGeom g = s_g;
+  const int ncell = g.ncell;
   int* cs = L.cell_start + ((size_t)slot * 2 + m) * (L.gcap + 1);
   int* cc = L.cell_cur + ((size_t)slot * 2 + m) * (L.gcap + 1);
-  __shared__ int s[LM_BLOCK / 64];
-  __shared__ int s_run;
-  if (threadIdx.x == 0) s_run = 0;
+  for (int c = threadIdx.x; c <= ncell; c += LM_BLOCK) cs[c] = 0;
+  __threadfence_block();
   __syncthreads();
+  const int n = li[LI_KDS_C + m];
+  const float4* pts = (m == 0 ? L.map_corner_ds + (size_t)slot * L.map_cap_c : L.map_surf_ds + (size_t)slot * L.map_cap_s);
+  float4* cp = L.cell_pts + ((size_t)slot * 2 + m) * L.map_cap_s;
+  for (int i = threadIdx.x; i < n; i += LM_BLOCK) {
+    const float4 p = pts[i];
+    int cx, cy, cz;
+    atomicAdd(&cs[grid_cell(g, p.x, p.y, p.z, &cx, &cy, &cz)], 1);
+  }
+  __threadfence_block();
+  __syncthreads();
+  // exclusive scan of the cell counts (in place) + fill cursors
   for (int c0 = 0; c0 <= ncell; c0 += LM_BLOCK) {
     const int c = c0 + threadIdx.x;
-    const int v = c < ncell ? cs[c] : 0;
+    // (the counts were accumulated by L2 atomics: read them past the CU's vector cache)
+    const int v = __hip_atomic_load(&cs[min(c, ncell)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * (c < ncell ? 1 : 0);
     int incl = v;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if ((threadIdx.x & 63) >= o) incl += t; }
@@ -225,10 +215,20 @@ __global__ void __launch_bounds__(LM_BLOCK) lm_grid_scan(DevCtx d, LmCtx L) {
 #pragma unroll
     for (int w = 0; w < LM_BLOCK / 64; ++w) { if (w < (int)(threadIdx.x >> 6)) woff += s[w]; tot += s[w]; }
     const int run = s_run;
-    if (c <= ncell) { const int e = run + woff + incl - v; cs[c] = e; cc[c] = e; }
+    if (c <= ncell) { const int e2 = run + woff + incl - v; cs[c] = e2; cc[c] = e2; }
     __syncthreads();
     if (threadIdx.x == 0) s_run = run + tot;
     __syncthreads();
+  }
+  __threadfence_block();
+  __syncthreads();
+  // cell-sorted copy: one contiguous read per cell run in lm_knn (the order inside a cell is whatever the atomics give:
+  // the k-NN result does not depend on it, ties are broken by the point index)
+  for (int i = threadIdx.x; i < n; i += LM_BLOCK) {
+    const float4 p = pts[i];
+    int cx, cy, cz;
+    const int pos = atomicAdd(&cc[grid_cell(g, p.x, p.y, p.z, &cx, &cy, &cz)], 1);
+    cp[pos] = make_float4(p.x, p.y, p.z, __int_as_float(i));
   }
 }
 
@@ -779,10 +779,7 @@ void launch_lm_total(const DevCtx& d, const LmCtx& L, hipStream_t st) {
   ALEGO_LAUNCH(lm_total, dim3(8, d.n_launch), dim3(LM_BLOCK), 0, st, d, L);
 }
 void launch_lm_grid(const DevCtx& d, const LmCtx& L, hipStream_t st) {
-  ALEGO_LAUNCH(lm_grid_setup, dim3(2, d.n_launch), dim3(LM_BLOCK), 0, st, d, L);
-  ALEGO_LAUNCH(lm_grid_count, dim3(8, 2, d.n_launch), dim3(LM_BLOCK), 0, st, d, L, 0);
-  ALEGO_LAUNCH(lm_grid_scan, dim3(2, d.n_launch), dim3(LM_BLOCK), 0, st, d, L);
-  ALEGO_LAUNCH(lm_grid_count, dim3(8, 2, d.n_launch), dim3(LM_BLOCK), 0, st, d, L, 1);
+  ALEGO_LAUNCH(lm_grid_build, dim3(2, d.n_launch), dim3(LM_BLOCK), 0, st, d, L);
 }
 void launch_lm_register(const DevCtx& d, const LmCtx& L, hipStream_t st) {
   ALEGO_LAUNCH(lm_knn, dim3(LM_ASSOC_GX, 2, d.n_launch), dim3(128), 0, st, d, L);

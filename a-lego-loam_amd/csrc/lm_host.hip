@@ -22,8 +22,10 @@ struct LmHost {
   int gsize;                   // slots per stream group
   std::vector<hipStream_t> st; // one HIP stream per group
   LmCtx L;
-  // per group — vm: map corner, map surf; v1: scan corner, scan surf, scan outlier; v2: scan surf_total
-  std::vector<VoxCtx> vm, v1, v2;
+  // per group — vm: map corner, map surf of every slot (jobs 2 b, 2 b + 1), then scan corner, scan surf, scan outlier of every
+  // slot: the filters of the current scan do not depend on the map, so they share the map round's three launches;
+  // v2: scan surf_total (needs the first round's outputs)
+  std::vector<VoxCtx> vm, v2;
   std::vector<void*> allocs;
   std::vector<long> frames;  // host mirror of frame_cnt per slot: only used to skip launches
 };
@@ -47,7 +49,7 @@ LmHost* lm_host_create(const alego_params& P, const DevCtx& d, int n_slots, int 
   LmHost* lm = new LmHost();
   lm->P = P; lm->n_slots = n_slots; lm->gsize = gsize; lm->st = st; lm->frames.assign(n_slots, 0);
   VoxCtx vz; std::memset(&vz, 0, sizeof(VoxCtx));
-  lm->vm.assign(st.size(), vz); lm->v1.assign(st.size(), vz); lm->v2.assign(st.size(), vz);
+  lm->vm.assign(st.size(), vz); lm->v2.assign(st.size(), vz);
   LmCtx& L = lm->L;
   std::memset(&L, 0, sizeof(L));
   L.K = P.recent_keyframe_num > 0 ? P.recent_keyframe_num : 1;
@@ -91,12 +93,13 @@ LmHost* lm_host_create(const alego_params& P, const DevCtx& d, int n_slots, int 
     j1.push_back(VoxJob{L.in_outl + b * L.in_cap_o, li + LI_NIN_O, L.cur_outl_ds + b * L.kf_cap_o, li + LI_NCUR_O, li + LI_RUN, P.lm_leaf_outlier, L.in_cap_o, 0});
     j2.push_back(VoxJob{L.cur_total + b * L.total_cap, li + LI_NTOTAL, L.cur_total_ds + b * L.total_cap, li + LI_NTOTAL_DS, li + LI_RUN, P.lm_leaf_surf, L.total_cap, 0});
   }
-  if (vox_create(&lm->vm[g], jm.data(), (int)jm.size(), err) || vox_create(&lm->v1[g], j1.data(), (int)j1.size(), err) || vox_create(&lm->v2[g], j2.data(), (int)j2.size(), err)) { lm_host_destroy(lm); return nullptr; }
+  const int ns = (int)jm.size() / 2;
+  jm.insert(jm.end(), j1.begin(), j1.end());
+  if (vox_create(&lm->vm[g], jm.data(), (int)jm.size(), err) || vox_create(&lm->v2[g], j2.data(), (int)j2.size(), err)) { lm_host_destroy(lm); return nullptr; }
   // Expected work per context: the maps are rebuilt for ~1 stream in 8 per mapping frame and are only small while a stream
   // is young; the current-scan clouds practically never exceed 8192 points.  Fewer persistent workgroups there (they loop).
-  const int ns = (int)jm.size() / 2;
-  lm->vm[g].grid_small = std::max(2, ns / 4); lm->vm[g].grid_big = std::max(2, ns / 2);
-  lm->v1[g].grid_big = std::max(1, ns / 16); lm->v2[g].grid_big = std::max(1, ns / 16);
+  lm->vm[g].grid_small = 3 * ns + std::max(2, ns / 4); lm->vm[g].grid_big = std::max(2, ns / 2);
+  lm->v2[g].grid_big = std::max(1, ns / 16);
   }
   return lm;
 }
@@ -104,7 +107,6 @@ LmHost* lm_host_create(const alego_params& P, const DevCtx& d, int n_slots, int 
 void lm_host_destroy(LmHost* lm) {
   if (!lm) return;
   for (auto& v : lm->vm) vox_destroy(&v);
-  for (auto& v : lm->v1) vox_destroy(&v);
   for (auto& v : lm->v2) vox_destroy(&v);
   for (void* p : lm->allocs) (void)hipFree(p);
   delete lm;
@@ -149,9 +151,7 @@ static int lm_sequence(LmHost* lm, const DevCtx& d, int stage, const std::vector
   launch_lm_prepare(d, L, stage, hint, st);
   if (!dbg_sync(st, "lm_prepare", err)) return ALEGO_ERR_HIP;
   if (n_run == 0) return 0;
-  if (int r = map_sequence(lm, d, L, g, st, err)) return r;
-  if (int r = vox_run(lm->v1[g], st, err)) return r;
-  if (!dbg_sync(st, "vox scan", err)) return ALEGO_ERR_HIP;
+  if (int r = map_sequence(lm, d, L, g, st, err)) return r;   // (includes the VoxelGrid filters of the scan's three clouds)
   launch_lm_total(d, L, st);
   if (int r = vox_run(lm->v2[g], st, err)) return r;
   if (!dbg_sync(st, "vox total", err)) return ALEGO_ERR_HIP;

@@ -67,7 +67,7 @@ def kernel_bytes(name, c, NS, H, rebuilds_per_launch=0.0):
         "vox_small": 16 * scan_pts / 2 + 16 * L / 2,
         "vox_big": (16 * kraw + 16 * kds) * rb,   # compulsory: read the raw map once, write the filtered map
         "fe_boxes": 16 * (c["Fc"] + c["Fs"]) + (c["Fc"] + c["Fs"]),
-        "lm_grid_count": 20 * kds * rb, "lm_knn": 16 * L + 16 * kds + 20 * L, "lm_fit": 20 * L + 5 * 16 * L + 64 * L,
+        "lm_grid_build": 40 * kds * rb, "lm_knn": 16 * L + 16 * kds + 20 * L, "lm_fit": 20 * L + 5 * 16 * L + 64 * L,
         "lm_solve": 80 * L + 104, "lm_store_kf": 32 * L,
     }
     return t.get(name)
