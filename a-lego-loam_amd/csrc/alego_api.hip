@@ -185,6 +185,32 @@ int alego_create(const alego_params* params, int device, int n_slots, int ring_l
   rc |= dalloc(h, &d.lo_box, B * 2 * 2 * d.lo_box_cap * 2);
   rc |= dalloc(h, &d.lo_state, B * LO_STATE_N);
   rc |= dalloc(h, &d.poses, B * 16);
+  {  // boundary tables of ip_project's fast path (kernels_ip.hip)
+    const double rx = params->ang_res_x, ry = params->ang_res_y;
+    std::vector<double> rt(2 * (NS + 6)), ct;
+    for (int k = 0; k < (int)NS + 6; ++k) {   // r = k - 3: the vertical angle at which (va + ang_bottom) / ang_res_y + 0.5 == r
+      const double phi = (((double)(k - 3) - 0.5) * ry - params->ang_bottom) * M_PI / 180.0;
+      rt[2 * k] = std::cos(phi); rt[2 * k + 1] = std::sin(phi);
+    }
+    d.ip_cmin = (int)std::floor(180.0 / rx) - 2;
+    d.ip_ncb = (int)std::floor(540.0 / rx) + 3 - d.ip_cmin;
+    ct.resize(2 * (size_t)d.ip_ncb);
+    for (int k = 0; k < d.ip_ncb; ++k) {      // raw column c: the horizontal angle at which ha / ang_res_x == c
+      const double A = (double)(d.ip_cmin + k) * rx * M_PI / 180.0;
+      ct[2 * k] = std::cos(A); ct[2 * k + 1] = std::sin(A);
+    }
+    double2 *rtd = nullptr, *ctd = nullptr;
+    rc |= dalloc(h, &rtd, NS + 6); rc |= dalloc(h, &ctd, (size_t)d.ip_ncb);
+    if (!rc) {
+      hipMemcpy(rtd, rt.data(), rt.size() * sizeof(double), hipMemcpyHostToDevice);
+      hipMemcpy(ctd, ct.data(), ct.size() * sizeof(double), hipMemcpyHostToDevice);
+    }
+    d.ip_rowtab = rtd; d.ip_coltab = ctd;
+    d.ip_fast = 0;
+    if (params->laser_type == ALEGO_LASER_UNIFORM && ry > 1e-3 && std::fabs(((double)NS + 2.5) * ry - params->ang_bottom) < 80.0 && std::fabs(-3.5 * ry - params->ang_bottom) < 80.0) d.ip_fast |= 1;
+    if (rx > 1e-3 && std::fabs((double)d.H * rx - 360.0) < 1e-9 && d.ip_ncb < (1 << 20)) d.ip_fast |= 2;
+    if (const char* e = getenv("ALEGO_IP_FAST")) d.ip_fast &= atoi(e);   // tests: 0 forces the reference expressions for every point
+  }
   if (rc) { *out = h; int e = ALEGO_ERR_HIP; std::fprintf(stderr, "alego_create: %s\n", h->err.c_str()); alego_destroy(h); *out = nullptr; return e; }
   // r_w_cur_ = identity, pose quaternions = identity (laserOdometry.cpp:46-47)
   std::vector<double> st(B * LO_STATE_N, 0.0), po(B * 16, 0.0);

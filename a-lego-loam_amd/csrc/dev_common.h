@@ -47,6 +47,11 @@ struct DevCtx {
   int cap_sharp, cap_lsharp, cap_flat;  // per-ring staging capacities: n_sharp*n_sectors, ...
   double sin_ax, cos_ax, sin_ay, cos_ay;  // sin/cos of seg_alpha_x / seg_alpha_y (host libm)
   double inv_res_x, inv_res_y;            // 1 / ang_res_x, 1 / ang_res_y (projection shortcut)
+  // ip_project fast path: (cos, sin) of the cell-boundary angles, rows r = -3 .. NS+2 (index r + 3) and raw columns
+  // c = ip_cmin .. ip_cmin + ip_ncb - 1; ip_fast bit 0 = rows usable (uniform laser), bit 1 = columns usable (H * ang_res_x == 360)
+  const double2* ip_rowtab;
+  const double2* ip_coltab;
+  int ip_cmin, ip_ncb, ip_fast;
   unsigned h_magic;                       // floor(2^32 / H) + 1: cell / H == umulhi(cell, h_magic) for every cell < 2^32 / H
   double tan_g_lo, tan_g_hi;              // tan of (sensor_mount_ang -/+ ground_angle_thres) (ground test shortcut; NaN disables)
   double tan_theta;                       // tan(seg_theta) for the edge predicate shortcut; NaN disables the shortcut

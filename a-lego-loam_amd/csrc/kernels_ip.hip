@@ -42,12 +42,61 @@ __global__ void __launch_bounds__(IP_BLOCK) ip_project(DevCtx d, int ring_pos) {
       if (p.x * p.x + p.y * p.y + p.z * p.z < th * th) valid = false;  // IP.cpp:91
     }
     if (valid) {
+      // ---- fast path: cell from the boundary tables.  The reference rounds atan2f / hypotf to f32 before it divides by the
+      // angular resolution, so its row / column is the cell of the TRUE angle unless that angle lies within ~7e-5 cells of a
+      // boundary.  A polynomial estimate (good to 0.03 cells) picks a boundary, the exact offset to it comes from one
+      // cross / dot product against the boundary's (cos, sin) (fp64 products, f32 quotient: error < 1e-6 cells), and a point
+      // closer than 2.5e-4 columns / 1e-4 rows to any boundary takes the reference expressions below.  Every comparison is
+      // written so that a NaN or an out-of-range estimate also lands there.
+      int row = -1, col = -1;
+      bool slow = true;
+      {
+        const float h2 = p.x * p.x + p.y * p.y, hf = __builtin_amdgcn_sqrtf(h2);   // (v_sqrt_f32 / v_rcp_f32: 1 ulp is plenty here)
+        bool okr = (d.ip_fast & 1) && hf > 1e-3f && hf < 1e6f && fabsf(p.z) < 1e6f;
+        const float t = p.z * __builtin_amdgcn_rcpf(hf), t2 = t * t;
+        okr = okr && fabsf(t) < 0.6f;
+        const float a = t * (0.99997726f + t2 * (-0.33262347f + t2 * (0.19354346f + t2 * (-0.11643287f + t2 * (0.05265332f + t2 * -0.01172120f)))));
+        const float r0 = (a * 57.29577951f + (float)P.ang_bottom) * (float)d.inv_res_y + 0.5f;
+        const float kf = floorf(r0);
+        okr = okr && kf >= -3.0f && kf <= (float)(d.NS + 1);
+        const int kk = okr ? (int)kf : 0;
+        const double2 cs = d.ip_rowtab[kk + 3];
+        const float cr = (float)((double)p.z * cs.x - (double)hf * cs.y), dt = (float)((double)hf * cs.x + (double)p.z * cs.y);
+        const float q = cr * __builtin_amdgcn_rcpf(dt);
+        const float frac = q * (1.0f - q * q * 0.33333333f) * (57.29577951f * (float)d.inv_res_y);
+        const float fl = floorf(frac), dlo = frac - fl, dhi = 1.0f - dlo;
+        const int rfl = kk + (int)fl;   // floor of the reference's r; (int)r truncates: r in (-1, 1) is row 0, so 0 is no boundary
+        okr = okr && dt > 0.0f && frac > -1.0f && frac < 2.0f && (dlo >= 1e-4f || rfl == 0) && (dhi >= 1e-4f || rfl + 1 == 0);
+        // columns
+        const float ax = fabsf(p.x), ay = fabsf(p.y), mn = fminf(ax, ay), mx = fmaxf(ax, ay);
+        bool okc = (d.ip_fast & 2) && mx > 1e-3f && mx < 1e6f;
+        const float u = mn * __builtin_amdgcn_rcpf(mx), u2 = u * u;
+        float b = u * (0.99997726f + u2 * (-0.33262347f + u2 * (0.19354346f + u2 * (-0.11643287f + u2 * (0.05265332f + u2 * -0.01172120f)))));
+        b = ay > ax ? 1.57079633f - b : b;
+        b = p.x < 0.0f ? 3.14159265f - b : b;
+        b = p.y < 0.0f ? -b : b;
+        const float cf = floorf((6.28318531f - b) * (57.29577951f * (float)d.inv_res_x)) - (float)d.ip_cmin;
+        okc = okc && cf >= 0.0f && cf <= (float)(d.ip_ncb - 1);
+        const int ci = okc ? (int)cf : 0;
+        const double2 cc = d.ip_coltab[ci];
+        const float crc = (float)(-(double)p.y * cc.x - (double)p.x * cc.y), dtc = (float)((double)p.x * cc.x - (double)p.y * cc.y);
+        const float qc = crc * __builtin_amdgcn_rcpf(dtc);
+        const float fc = qc * (1.0f - qc * qc * 0.33333333f) * (57.29577951f * (float)d.inv_res_x);
+        const float flc = floorf(fc), dloc = fc - flc;
+        okc = okc && dtc > 0.0f && fc > -1.0f && fc < 2.0f && dloc >= 2.5e-4f && 1.0f - dloc >= 2.5e-4f;
+        if (okr && okc) {
+          slow = false;
+          row = rfl >= 0 ? rfl : (rfl == -1 ? 0 : -1);
+          col = d.ip_cmin + ci + (int)flc;
+          if (col >= d.H) col -= d.H;
+        }
+      }
+      if (slow) {
       // imageProjection.cpp:79-80 (IP.cpp:142-172 for the RFANS table)
       // (a * 180.0) / M_PI and x / ang_res are IEEE fp64 divisions in the reference (~35 instructions each here).  The
       // integer part of the result only depends on the exact quotient when it lies within rounding error of an
       // integer: multiply by the reciprocals first and redo the reference expression only in that case.
       const double va = (double)d_atan2f(p.z, d_hypotf(p.x, p.y)) * 180.0;
-      int row;
       if (P.laser_type == ALEGO_LASER_UNIFORM) {
         const double r = (va * (1.0 / M_PI) + P.ang_bottom) * d.inv_res_y + 0.5;
         row = (int)r;
@@ -65,9 +114,10 @@ __global__ void __launch_bounds__(IP_BLOCK) ip_project(DevCtx d, int ring_pos) {
       // :87-97
       const double ha = ((double)(-d_atan2f(p.y, p.x)) + 2 * M_PI) * 180.0;
       const double cfast = ha * (1.0 / M_PI) * d.inv_res_x;
-      int col = (int)cfast;
+      col = (int)cfast;
       if (fabs(cfast - rint(cfast)) < 1e-9 * (1.0 + fabs(cfast))) col = (int)((ha / M_PI) / P.ang_res_x);
       if (col >= d.H) col -= d.H;
+      }
       if (row >= 0 && row < d.NS && col >= 0 && col < d.H)
         atomicMax(&d.owner[(size_t)slot * d.N + col + row * d.H], IP_OWNER_TAG | i);  // later points overwrite earlier ones (:102-103);
         // whatever the previous scan left in the cell (a plain index or -1, see ip_image) loses against a tagged entry: no reset pass

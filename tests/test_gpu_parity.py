@@ -31,11 +31,13 @@ def _ip_compare(h, o, pts, tag):
     return seg
 
 
-@pytest.mark.parametrize("geom,variant", [((16, 1800), None), ((16, 1800), "ALEGO_CC_FUSED"),
+@pytest.mark.parametrize("geom,variant", [((16, 1800), None), ((16, 1800), "ALEGO_CC_FUSED"), ((16, 1800), "ALEGO_IP_FAST"),
                                           ((16, 4000), None), ((64, 2048), None)])
 def test_ip_bit_exact(geom, variant, monkeypatch):
     """ImageProjection bit for bit.  16x1800 runs the fused LDS kernel (cc_lds16); ALEGO_CC_FUSED=0 keeps its union-find but
-    compacts with the separate ip_rowcount + ip_compact kernels; the larger geometries take the global-memory union-find."""
+    compacts with the separate ip_rowcount + ip_compact kernels; the larger geometries take the global-memory union-find.
+    ALEGO_IP_FAST=0 projects every point with the reference expressions (normally only the points within 2.5e-4 cells of a
+    cell boundary take them; the rest are placed by the boundary tables)."""
     if variant:
         monkeypatch.setenv(variant, "0")
     p = synth.default_params(*geom)
