@@ -63,6 +63,31 @@ def test_ip_jitter_nan_dups_shuffle(params_a):
     h.close()
 
 
+def test_ip_points_on_cell_boundaries(params_a):
+    """Points whose azimuth / elevation lies on a row or column boundary of the range image, or a few 1e-8 .. 1e-5 rad next
+    to it: the projection's table fast path has to hand exactly these to the reference expressions (the rounded f32
+    atan2f decides their cell), including the row-0 rule of (int) truncation, the column wrap and the +-pi seam."""
+    p = params_a
+    h, o = binding.Handle(p), O.Oracle(p)
+    rng = np.random.default_rng(11)
+    n = p.n_scan * p.horizon_scan
+    eps = np.array([0.0, 1e-8, -1e-8, 1e-7, -1e-7, 3e-7, -3e-7, 1e-6, -1e-6, 1e-5, -1e-5])
+    cols = rng.integers(0, 3 * p.horizon_scan, n)                    # raw columns incl. both sides of the wrap
+    az = -(cols * p.ang_res_x * np.pi / 180.0 - 2 * np.pi) + rng.choice(eps, n)
+    rows = rng.integers(-2, p.n_scan + 2, n)                          # incl. below row 0 and above the top ring
+    el = ((rows - 0.5) * p.ang_res_y - p.ang_bottom) * np.pi / 180.0 + rng.choice(eps, n)
+    half = n // 2                                                     # one half sits on column boundaries, the other on row boundaries
+    el[:half] = np.deg2rad(rng.uniform(-p.ang_bottom + 0.3, -p.ang_bottom + (p.n_scan - 1) * p.ang_res_y - 0.3, half))
+    az[half:] = rng.uniform(-np.pi, np.pi, n - half)
+    az[:64] = np.pi * np.where(np.arange(64) % 2, 1.0, -1.0) + rng.choice(eps, 64)   # the atan2 seam
+    r = rng.uniform(2.0, 60.0, n)
+    pts = np.zeros((n, 4), np.float32)
+    pts[:, 0] = r * np.cos(el) * np.cos(az); pts[:, 1] = r * np.cos(el) * np.sin(az); pts[:, 2] = r * np.sin(el)
+    pts[:8, :2] = 0.0                                                 # on the z axis: no azimuth at all
+    _ip_compare(h, o, pts, "boundary points")
+    h.close()
+
+
 def test_ip_options(params_a):
     p = params_a.copy()
     p.near_filter, p.laser_type = 1, 1  # IP.cpp: removeClosedPointCloud + RFANS ring table
