@@ -230,35 +230,43 @@ __device__ void vox_big_job(const VoxCtx& V, int job) {
       head[k] = i < seg1 && (i == 0 || (unsigned)(cur[k] >> 32) != (unsigned)(prv[k] >> 32));
     }
   };
-  int heads = 0;
-  for (int r0 = seg0; r0 < seg1; r0 += 64 * VG_U) {
-    bool head[VG_U];
-    head_rounds(r0, head);
-#pragma unroll
-    for (int k = 0; k < VG_U; ++k) heads += (int)__popcll(__ballot(head[k]));
-  }
-  if (lane == 0) s_w[wave] = heads;
-  __syncthreads();
-  int vbase = 0, nvox = 0;
-#pragma unroll
-  for (int w = 0; w < VG_W; ++w) { const int c = s_w[w]; if (w < wave) vbase += c; nvox += c; }
+  // One pass: every wavefront compacts the run starts of its own segment into the front of that segment of hl[] (a segment has
+  // at most as many heads as elements), then the per-wavefront counts give every voxel its (wavefront, local rank).
   int* hl = reinterpret_cast<int*>(keys);
+  __shared__ int s_wbase[VG_W + 1], s_nextfirst[VG_W + 1];
+  int heads = 0;
   for (int r0 = seg0; r0 < seg1; r0 += 64 * VG_U) {
     bool head[VG_U];
     head_rounds(r0, head);
 #pragma unroll
     for (int k = 0; k < VG_U; ++k) {
       const u64 hb = __ballot(head[k]);
-      if (head[k]) hl[vbase + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(hb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)hb, 0u))] = r0 + 64 * k + lane;
-      vbase += (int)__popcll(hb);
+      if (head[k]) hl[seg0 + heads + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(hb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)hb, 0u))] = r0 + 64 * k + lane;
+      heads += (int)__popcll(hb);
     }
   }
+  if (lane == 0) s_w[wave] = heads;
   __threadfence_block();
   __syncthreads();
+  if (tid == 0) {
+    int run = 0;
+    for (int w = 0; w < VG_W; ++w) { s_wbase[w] = run; run += s_w[w]; }
+    s_wbase[VG_W] = run;
+    int nf = n;   // start of the first run at or after wavefront w's segment (n behind the last one)
+    s_nextfirst[VG_W] = n;
+    for (int w = VG_W - 1; w >= 0; --w) { if (s_w[w] > 0) nf = hl[min(n, w * seglen)]; s_nextfirst[w] = nf; }
+  }
+  __syncthreads();
+  const int nvox = s_wbase[VG_W];
   VG_TICK(12);
   // ---- 5. centroids
   for (int r = tid; r < nvox; r += VG_T) {
-    const int a = hl[r], b = r + 1 < nvox ? hl[r + 1] : n;
+    int w = 0;
+#pragma unroll
+    for (int q = 1; q < VG_W; ++q) w += (r >= s_wbase[q]) ? 1 : 0;   // wavefront whose segment holds the start of voxel r
+    const int loc = r - s_wbase[w], ws0 = min(n, w * seglen);
+    const int a = hl[ws0 + loc], bn = hl[ws0 + min(loc + 1, s_w[w] - 1)];
+    const int b = loc + 1 < s_w[w] ? bn : s_nextfirst[w + 1];
     float sx = 0.f, sy = 0.f, sz = 0.f, si = 0.f;
     for (int j = a; j < b; j += 8) {
       unsigned q[8];
