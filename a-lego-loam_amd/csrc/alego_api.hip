@@ -119,6 +119,13 @@ int alego_create(const alego_params* params, int device, int n_slots, int ring_l
   if (n_slots <= 0) n_slots = 1;
   if (ring_len <= 0) ring_len = 1;
   if (params->n_scan < 1 || params->n_scan > 64 || params->horizon_scan < 64 || params->horizon_scan > 4096) return ALEGO_ERR_ARG;
+  // The feature pick marks up to suppress_radius neighbours on either side of a picked point; the segmented cloud only
+  // guarantees the reference's 5-point margin at both ends of a ring (laserOdometry.cpp:124,211-234 index i +- 5 unchecked).
+  if (params->suppress_radius < 0 || params->suppress_radius > 5 || params->n_sectors < 1 || params->n_sharp < 0 ||
+      params->n_less_sharp < params->n_sharp || params->n_flat < 1) {
+    std::fprintf(stderr, "alego_create: feature-pick parameters out of range (0 <= suppress_radius <= 5, n_sectors >= 1, 0 <= n_sharp <= n_less_sharp, n_flat >= 1)\n");
+    return ALEGO_ERR_ARG;
+  }
   alego_handle* h = new alego_handle();
   h->P = *params;
   h->device = device;

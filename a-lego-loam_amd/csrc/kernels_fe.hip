@@ -6,7 +6,7 @@
 //              descending/ascending" is evaluated as repeated row-wide arg-max / arg-min over the
 //              not-yet-picked candidates of the sector (identical result for the total order
 //              (curvature, index)); +-5 neighbour suppression by ballot         (:172-286)
-//   fe_pick    the same with one ring per wavefront (suppress_radius > 8, very long sectors)
+//   fe_pick    the same with one ring per wavefront (suppress_radius > 7, very long sectors)
 //   fe_voxel   a10: per-ring pcl::VoxelGrid(0.4): runs of consecutive equal voxel ids ordered through
 //              monotone buckets in LDS, centroid in sorted (= original) order    (:288-293)
 //   fe_gather  ring-ascending concatenation into the four feature clouds       (:199-205,:245,:293)
@@ -238,8 +238,8 @@ __global__ void __launch_bounds__(64) fe_pick(DevCtx d) {
 // fe_pick4<FE_T>: the same greedy pick with FOUR rings per wavefront, one DPP row (16 lanes) each.  The per-pick
 // overhead of the one-ring kernel (wave-wide arg-max, ballot, suppression window, uniform control flow: ~70 of its
 // ~100 instructions per pick) is issued once for four rings; the reductions stay inside a DPP row.  Lane gl of a row owns
-// the sector elements lsp + gl + 16 t (sector length <= 16 * FE_T).  Needs suppress_radius <= 8 (the forward checks sit in
-// lanes 0-7 of the row, the backward checks in lanes 8-15).  Dynamic LDS: 3 B per ring point, 4 rings.
+// the sector elements lsp + gl + 16 t (sector length <= 16 * FE_T).  Needs suppress_radius <= 7: the forward checks sit in
+// lanes 0-7 of the row, the backward checks in lanes 8-15, and the 2 * radius + 1 marked elements get one lane each.  Dynamic LDS: 3 B per ring point, 4 rings.
 #define FP_G 4
 template <int FE_T>
 __global__ void __launch_bounds__(64) fe_pick4(DevCtx d) {
@@ -723,7 +723,7 @@ void launch_fe(const DevCtx& d, hipStream_t st) {
   // (padding this allocation by 16 KB cost 7 % of the whole pipeline: the LDS footprint decides how many rings share a CU)
   const int extra = 0;
   const char* ev = std::getenv("ALEGO_FE_PICK1");   // read per call: the tests switch it inside one process
-  const bool one_ring = (ev && ev[0] == '1') || d.P.suppress_radius > 8 || sector_max > 16 * 43;
+  const bool one_ring = (ev && ev[0] == '1') || d.P.suppress_radius > 7 || sector_max > 16 * 43;   // (2 * radius + 1 marked elements <= 16 lanes)
   const dim3 g4((d.NS + FP_G - 1) / FP_G, d.n_launch);
   const size_t lds4 = (size_t)3 * FP_G * d.H;
   if (!one_ring && sector_max <= 16 * 19) { ALEGO_LAUNCH(fe_pick4<19>, g4, dim3(64), lds4, st, d); }

@@ -57,7 +57,7 @@ typedef struct alego_params {
   int32_t n_sharp;           /* 2               laserOdometry.cpp:196 */
   int32_t n_less_sharp;      /* 20              laserOdometry.cpp:202 */
   int32_t n_flat;            /* 4               laserOdometry.cpp:248 */
-  int32_t suppress_radius;   /* 5               laserOdometry.cpp:211 */
+  int32_t suppress_radius;   /* 5               laserOdometry.cpp:211; 0..5 (the 5-point ring margin): alego_create rejects more */
   int32_t suppress_col_diff; /* 10              laserOdometry.cpp:214 */
   float less_flat_leaf;      /* 0.4 m           laserOdometry.cpp:290 */
   int32_t sort_mode;         /* 0 = total order (curvature, index); 1 = libstdc++ std::sort

@@ -132,7 +132,7 @@ def _fe_compare(h, o, feat, tag):
 def test_fe_lo_teacher_forced(geom, nscan, box_lds, monkeypatch):
     """Each scan starts from the oracle's params_ (teacher forcing): indices exact, pose 1e-4.  box_lds = 0 makes lo_assoc
     read its bounding boxes from HBM (the path of feature clouds too large for the LDS staging); "pick1" runs the
-    one-ring-per-wavefront fe_pick (the path of suppress_radius > 8) instead of fe_pick4.  The three geometries cover
+    one-ring-per-wavefront fe_pick (the path of suppress_radius > 7) instead of fe_pick4.  The three geometries cover
     fe_pick4<19>, <43> and <24>."""
     if box_lds == "pick1":
         monkeypatch.setenv("ALEGO_FE_PICK1", "1")
@@ -187,6 +187,40 @@ def test_fe_lo_standalone_node_variants(params_a):
         if k:
             np.testing.assert_allclose(odom["params"], o.get("lo_params"), rtol=0, atol=1e-7)
     h.close()
+
+
+@pytest.mark.parametrize("geom,mods", [((10, 1000), dict(suppress_radius=3, n_sectors=4, n_less_sharp=10, n_flat=3)),
+                                       ((16, 1800), dict(suppress_radius=0)),
+                                       ((16, 1800), dict(suppress_radius=5, n_sharp=1, n_less_sharp=30)),
+                                       ((16, 1800), dict(suppress_radius=2, n_sharp=3, n_less_sharp=25, n_flat=6)),
+                                       ((6, 1440), dict(n_sectors=8)),
+                                       ((32, 1024), dict(n_sectors=3))])
+def test_feature_pick_parameter_variants(geom, mods):
+    """Other ring counts (not a multiple of the four rings a wavefront of fe_pick4 takes), sector counts, pick counts and
+    suppression radii than the reference's literals: segmentation, feature lists and the LO pose against the oracle."""
+    p = synth.default_params(*geom)
+    for k, v in mods.items():
+        setattr(p, k, v)
+    h, o = binding.Handle(p), O.Oracle(p)
+    for k in range(4):
+        pts = synth.scan(p, k)
+        seg = _ip_compare(h, o, pts, f"{geom} scan {k}")
+        h.set_lo_params(o.get("lo_params"))
+        o.lo()
+        flags, feat, odom = h.lo_process(seg)
+        _fe_compare(h, o, feat, f"{geom} {mods} scan {k}")
+        if k:
+            np.testing.assert_allclose(odom["params"], o.get("lo_params"), rtol=0, atol=1e-7)
+    h.close()
+
+
+def test_create_rejects_out_of_range_pick_parameters(params_a):
+    """The pick marks suppress_radius neighbours on either side of a point and the segmented cloud only has the reference's
+    5-point margin at the ends of a ring: a larger radius is refused, not clamped."""
+    p = params_a.copy()
+    p.suppress_radius = 6
+    with pytest.raises(Exception):
+        binding.Handle(p)
 
 
 def test_full_loop_on_jittered_scans_with_nan_returns(params_a):
