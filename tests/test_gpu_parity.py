@@ -194,10 +194,13 @@ def test_fe_lo_standalone_node_variants(params_a):
                                        ((16, 1800), dict(suppress_radius=5, n_sharp=1, n_less_sharp=30)),
                                        ((16, 1800), dict(suppress_radius=2, n_sharp=3, n_less_sharp=25, n_flat=6)),
                                        ((6, 1440), dict(n_sectors=8)),
-                                       ((32, 1024), dict(n_sectors=3))])
+                                       ((32, 1024), dict(n_sectors=3)),
+                                       ((16, 1800), dict(ang_res_x=0.21)),                    # H * res != 360: no column table
+                                       ((16, 1800), dict(ang_bottom=11.3, ang_res_y=1.33))])  # other row boundaries
 def test_feature_pick_parameter_variants(geom, mods):
-    """Other ring counts (not a multiple of the four rings a wavefront of fe_pick4 takes), sector counts, pick counts and
-    suppression radii than the reference's literals: segmentation, feature lists and the LO pose against the oracle."""
+    """Other ring counts (not a multiple of the four rings a wavefront of fe_pick4 takes), sector counts, pick counts,
+    suppression radii and angular resolutions than the reference's literals: segmentation, feature lists and the LO pose
+    against the oracle."""
     p = synth.default_params(*geom)
     for k, v in mods.items():
         setattr(p, k, v)
