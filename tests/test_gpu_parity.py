@@ -316,10 +316,20 @@ def _lm_compare(h, o, k, tag):
     np.testing.assert_allclose(h.debug_get("lm_state")[0:6], o.get("lm_params"), rtol=0, atol=1e-6, err_msg=f"{tag} params_")
 
 
-@pytest.mark.parametrize("geom,nscan", [((16, 1800), 36), ((64, 2048), 8)])
-def test_full_loop_teacher_forced(geom, nscan):
+@pytest.mark.parametrize("geom,nscan,mods", [
+    ((16, 1800), 36, {}), ((64, 2048), 8, {}),
+    # other LaserMapping literals: leaf sizes, every frame mapped, a 3-key-frame window that slides inside the test, looser
+    # correspondence gates, one outer iteration with fewer solver iterations
+    ((16, 1800), 30, dict(lm_leaf_corner=0.3, lm_leaf_surf=0.5, lm_leaf_outlier=0.7, lm_every=1, recent_keyframe_num=3,
+                          min_keyframe_dist=0.04, knn_max_dist=2.0, line_ratio=2.5, plane_tol=0.3, lm_outer_iters=1, lm_max_iters=8)),
+    ((16, 1800), 24, dict(less_flat_leaf=0.3, lo_iters_surf=3, lo_iters_corner=7, ring_window=1, huber_delta=0.05, lm_every=3,
+                          lm_min_surf=50)),
+])
+def test_full_loop_teacher_forced(geom, nscan, mods):
     """IP -> LO -> LM on the device, each scan started from the oracle's LO/LM params_."""
     p = synth.default_params(*geom)
+    for k, v in mods.items():
+        setattr(p, k, v)
     h, o = binding.Handle(p), O.Oracle(p)
     for k in range(nscan):
         pts = synth.scan(p, k)
@@ -333,7 +343,7 @@ def test_full_loop_teacher_forced(geom, nscan):
         want = o.get("map_pose")
         assert np.abs(mp["t"] - want[:3]).max() < POSE_TOL, (k, mp["t"], want[:3])
         assert quat_angle(mp["q"], want[3:]) < POSE_TOL
-    assert o.get("lm_info")[11] >= 3 or geom[0] == 64
+    assert o.get("lm_info")[11] >= 3 or geom[0] == 64 or mods
     h.close()
 
 
