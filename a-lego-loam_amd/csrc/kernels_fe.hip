@@ -239,7 +239,7 @@ __global__ void __launch_bounds__(64) fe_pick(DevCtx d) {
 // overhead of the one-ring kernel (wave-wide arg-max, ballot, suppression window, uniform control flow: ~70 of its
 // ~100 instructions per pick) is issued once for four rings; the reductions stay inside a DPP row.  Lane gl of a row owns
 // the sector elements lsp + gl + 16 t (sector length <= 16 * FE_T).  Needs suppress_radius <= 7: the forward checks sit in
-// lanes 0-7 of the row, the backward checks in lanes 8-15, and the 2 * radius + 1 marked elements get one lane each.  Dynamic LDS: 2 B per ring point, 4 rings.
+// lanes 0-7 of the row, the backward checks in lanes 8-15, and the 2 * radius + 1 marked elements get one lane each.  Dynamic LDS: 1 B per ring point, 4 rings.
 #define FP_G 4
 template <int FE_T>
 __global__ void __launch_bounds__(64) fe_pick4(DevCtx d) {
@@ -251,30 +251,27 @@ __global__ void __launch_bounds__(64) fe_pick4(DevCtx d) {
   const size_t base = (size_t)slot * d.N;
   const alego_params& P = d.P;
   extern __shared__ __attribute__((aligned(16))) unsigned char fe_smem[];
-  // 2 B per ring point: the kernel's LDS footprint (one wavefront, four rings) is what limits how many of these workgroups —
-  // and how much of the other stream groups' work — fit a CU.  The suppression only ever compares |col[k+1] - col[k]| with
-  // suppress_col_diff (< 255, checked by the launcher): one byte per point holds that difference, clipped at 255.
-  uint8_t* s_dcol = fe_smem;                                  // [FP_G][H]  min(|col[k+1] - col[k]|, 255)
-  uint8_t* s_flag = fe_smem + (size_t)FP_G * d.H;             // [FP_G][H]
+  // 1 B per ring point: the kernel's LDS footprint (one wavefront, four rings) is what limits how many of these workgroups —
+  // and how much of the other stream groups' work — fit a CU.  The suppression only ever asks whether |col[k+1] - col[k]|
+  // exceeds suppress_col_diff: that is bit 6 of the point's flag byte.
+  uint8_t* s_flag = fe_smem;                                  // [FP_G][H]
   for (int r = 0; r < FP_G && ring0 + r < d.NS; ++r) {       // whole wavefront stages one ring after the other
     const int Sr = d.ring_start[slot * d.NS + ring0 + r], Er = d.ring_end[slot * d.NS + ring0 + r];
     const int rfr = Sr - 5, cntr = Er - Sr + 11;
-    uint8_t* sc = s_dcol + (size_t)r * d.H;
     uint8_t* sf = s_flag + (size_t)r * d.H;
 #pragma unroll 8
     for (int k = lane; k < cntr; k += 64) {
       const float a = fabsf(d.cd[base + rfr + k]);
       const double ad = (double)a;
       const double curv = ad * ad;  // (double)diff_range * diff_range, exact (:125)
-      { const int dc = d.seg_col[base + rfr + min(k + 1, cntr - 1)] - d.seg_col[base + rfr + k]; sc[k] = (uint8_t)min(dc < 0 ? -dc : dc, 255); }
+      const int dc = d.seg_col[base + rfr + min(k + 1, cntr - 1)] - d.seg_col[base + rfr + k];
       sf[k] = (uint8_t)((d.picked0[base + rfr + k] & 1) | (d.seg_ground[base + rfr + k] ? 2 : 0) |
-                        (curv > P.edge_thres ? 4 : 0) | (curv < P.surf_thres ? 8 : 0) | (1 << 4));
+                        (curv > P.edge_thres ? 4 : 0) | (curv < P.surf_thres ? 8 : 0) | (1 << 4) | ((dc < 0 ? -dc : dc) > P.suppress_col_diff ? 64 : 0));
     }
   }
   __syncthreads();
   const int S = rv ? d.ring_start[slot * d.NS + ring] : 0, E = rv ? d.ring_end[slot * d.NS + ring] : 0;
   const int rf = S - 5;
-  const uint8_t* sc = s_dcol + (size_t)g * d.H;
   uint8_t* sf = s_flag + (size_t)g * d.H;
   int* st = d.st_idx + ((size_t)slot * d.NS + (rv ? ring : 0)) * d.st_stride;
   int* st_sharp = st, *st_lsharp = st + d.cap_sharp, *st_flat = st_lsharp + d.cap_lsharp;
@@ -305,13 +302,13 @@ __global__ void __launch_bounds__(64) fe_pick4(DevCtx d) {
     // is written branch-free.  LDS flag bytes are changed with no-return 32-bit atomics on the containing word (no read /
     // wait / write round trip; an operand of 0 or a clamped address makes a lane's update a no-op), loads use clamped
     // addresses, and only the list stores sit behind a (single) branch.
-    unsigned* fw = reinterpret_cast<unsigned*>(s_flag);   // 4 H bytes in front of s_flag: word-aligned
+    unsigned* fw = reinterpret_cast<unsigned*>(s_flag);
     const int fo = g * d.H;                               // this ring's first flag byte
     // marks c and its +-SR neighbours picked (:211-234) for the rows where `on`; `spread` rows look for column jumps first
     auto mark = [&](int c, bool on, bool spread) {
       const int role = gl & 7, rr = max(min(role, SR - 1), 0);   // lanes 0-7 look forward, 8-15 backward
       const int a = spread ? (gl < 8 ? c + rr : c - rr - 1) : 0;
-      const bool bad = spread && role < SR && (int)sc[a] > P.suppress_col_diff;
+      const bool bad = spread && role < SR && (sf[a] & 64);
       const unsigned long long mb = __ballot(bad);
       const unsigned gb = (unsigned)(mb >> (16 * g)) & 0xffffu;
       const unsigned lo = gb & 0xffu, hi = gb >> 8;
@@ -725,9 +722,9 @@ void launch_fe(const DevCtx& d, hipStream_t st) {
   // (padding this allocation by 16 KB cost 7 % of the whole pipeline: the LDS footprint decides how many rings share a CU)
   const int extra = 0;
   const char* ev = std::getenv("ALEGO_FE_PICK1");   // read per call: the tests switch it inside one process
-  const bool one_ring = (ev && ev[0] == '1') || d.P.suppress_radius > 7 || sector_max > 16 * 43 || d.P.suppress_col_diff >= 255 || d.P.suppress_col_diff < 0;   // (2 * radius + 1 marked elements <= 16 lanes)
+  const bool one_ring = (ev && ev[0] == '1') || d.P.suppress_radius > 7 || sector_max > 16 * 43;   // (2 * radius + 1 marked elements <= 16 lanes)
   const dim3 g4((d.NS + FP_G - 1) / FP_G, d.n_launch);
-  const size_t lds4 = (size_t)2 * FP_G * d.H;
+  const size_t lds4 = (size_t)FP_G * d.H;
   if (!one_ring && sector_max <= 16 * 19) { ALEGO_LAUNCH(fe_pick4<19>, g4, dim3(64), lds4, st, d); }
   else if (!one_ring && sector_max <= 16 * 24) { ALEGO_LAUNCH(fe_pick4<24>, g4, dim3(64), lds4, st, d); }
   else if (!one_ring) { ALEGO_LAUNCH(fe_pick4<43>, g4, dim3(64), lds4, st, d); }
