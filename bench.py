@@ -45,7 +45,7 @@ def kernel_bytes(name, c, NS, H, rebuilds_per_launch=0.0):
     Arrays a kernel only re-reads from a producer in the same stage are charged to it as well, so the per-kernel
     figures sum to more than B_scan.  The map VoxelGrid kernels only work for the streams whose key-frame set
     changed: their bytes are scaled by the measured rebuilds per launch."""
-    name = name.split("<")[0]
+    name = name.strip("()").split("<")[0]
     N, P, M = NS * H, c["P"], c["M"]
     feats = c["Qc"] + c["Fc"] + c["Qs"] + c["Fs"]
     kraw, kds = c["Kraw_c"] + c["Kraw_s"], c["Kds_c"] + c["Kds_s"]
@@ -82,7 +82,7 @@ def pmc_traffic(kernel, streams_per_launch):
             d = json.load(f)
         if d.get("streams_per_launch") != streams_per_launch:
             return None
-        return d["kernels"].get(kernel.split("<")[0], {}).get("hbm_bytes_per_launch")
+        return d["kernels"].get(kernel.strip("()").split("<")[0], {}).get("hbm_bytes_per_launch")
     except (OSError, ValueError, KeyError):
         return None
 
