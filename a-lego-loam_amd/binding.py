@@ -22,6 +22,9 @@ EXPORTS = [
     "alego_ip_process", "alego_lo_process", "alego_lm_process", "alego_scan_process",
     "alego_batch_load", "alego_batch_run", "alego_synchronize", "alego_batch_get_pose", "alego_batch_get_counts",
     "alego_stream", "alego_stream_groups", "alego_profile_enable", "alego_profile_report", "alego_set_lo_params", "alego_set_lm_params", "alego_debug_get", "alego_debug_voxel", "alego_debug_atan2f",
+    "alego_debug_math", "alego_debug_eval_blocks", "alego_debug_transform_to_start", "alego_debug_set_option",
+    "alego_lm_keyframe_count", "alego_lm_get_keyframe", "alego_lm_set_keypose", "alego_lm_reset_window", "alego_lm_apply_correction",
+    "alego_lm_add_keyframe", "alego_pc2_to_points",
 ]
 
 REPLAY_PINGPONG = 0x100
@@ -53,6 +56,17 @@ class Pose(C.Structure):
 
     def as_dict(self):
         return dict(t=np.array(self.t[:]), q=np.array(self.q[:]), params=np.array(self.params[:]), valid=int(self.valid))
+
+
+class KeyFrame(C.Structure):
+    _fields_ = [("id", C.c_int32), ("pose", C.c_float * 6),
+                ("corner", C.c_void_p), ("corner_cap", C.c_int32), ("n_corner", C.c_int32),
+                ("surf", C.c_void_p), ("surf_cap", C.c_int32), ("n_surf", C.c_int32),
+                ("outlier", C.c_void_p), ("outlier_cap", C.c_int32), ("n_outlier", C.c_int32)]
+
+
+class Pc2Field(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("offset", C.c_uint32), ("datatype", C.c_uint8), ("count", C.c_uint32)]
 
 
 def lib_path():
@@ -112,6 +126,29 @@ def lib():
         L.alego_debug_voxel.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_int]
         L.alego_debug_atan2f.restype = C.c_int
         L.alego_debug_atan2f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.alego_debug_math.restype = C.c_int
+        L.alego_debug_math.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.alego_debug_eval_blocks.restype = C.c_int
+        L.alego_debug_eval_blocks.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.alego_debug_transform_to_start.restype = C.c_int
+        L.alego_debug_transform_to_start.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.alego_debug_set_option.restype = C.c_int
+        L.alego_debug_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+        L.alego_lm_keyframe_count.restype = C.c_int
+        L.alego_lm_keyframe_count.argtypes = [C.c_void_p, C.c_int]
+        L.alego_lm_get_keyframe.restype = C.c_int
+        L.alego_lm_get_keyframe.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(KeyFrame)]
+        L.alego_lm_set_keypose.restype = C.c_int
+        L.alego_lm_set_keypose.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.alego_lm_reset_window.restype = C.c_int
+        L.alego_lm_reset_window.argtypes = [C.c_void_p, C.c_int]
+        L.alego_lm_apply_correction.restype = C.c_int
+        L.alego_lm_apply_correction.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.alego_lm_add_keyframe.restype = C.c_int
+        L.alego_lm_add_keyframe.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]
+        L.alego_pc2_to_points.restype = C.c_int
+        L.alego_pc2_to_points.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int,
+                                          C.POINTER(Pc2Field), C.c_int, C.c_void_p, C.c_int32]
         if L.alego_params_sizeof() != C.sizeof(AlegoParams):
             raise RuntimeError("alego_params layout mismatch between params.py and include/alego_params.h")
         _lib = L
@@ -120,6 +157,21 @@ def lib():
 
 class AlegoError(RuntimeError):
     pass
+
+
+def pc2_to_points(data: bytes, width, height, point_step, row_step, fields, is_bigendian=False, cap=None):
+    """sensor_msgs/PointCloud2 payload -> (n, 4) float32 (x, y, z, intensity); fields = [(name, offset, datatype, count), ...].
+    Host-side (no GPU needed): the ROS-free equivalent of pcl::fromROSMsg<PointXYZI> in front of alego_ip_process."""
+    n = width * height
+    cap = n if cap is None else cap
+    out = np.empty((max(cap, 1), 4), np.float32)
+    arr = (Pc2Field * len(fields))(*[Pc2Field(nm.encode(), off, dt, cnt) for nm, off, dt, cnt in fields])
+    buf = (C.c_uint8 * len(data)).from_buffer_copy(data) if len(data) else None
+    rc = lib().alego_pc2_to_points(buf, len(data), width, height, point_step, row_step, 1 if is_bigendian else 0, arr, len(fields),
+                                   out.ctypes.data, cap)
+    if rc < 0:
+        raise AlegoError(f"alego_pc2_to_points failed ({rc})")
+    return out[:rc].copy()
 
 
 _CLOUDS = {"seg_cloud", "outlier", "sharp", "less_sharp", "flat", "less_flat"}
@@ -314,6 +366,65 @@ class Handle:
         out = np.empty((max(a.shape[0], 1), 4), np.float32)
         n = self._check(lib().alego_debug_voxel(self._h, a.ctypes.data, a.shape[0], leaf, out.ctypes.data, out.shape[0]), "alego_debug_voxel")
         return out[:n].copy()
+
+    def math(self, mode, a, b=None):
+        """device single-precision functions: mode 0 atan2f(a, b), 1 hypotf(a, b), 2 sinf(a), 3 cosf(a)"""
+        a = np.ascontiguousarray(a, np.float32)
+        b = None if b is None else np.ascontiguousarray(b, np.float32)
+        out = np.empty_like(a)
+        self._check(lib().alego_debug_math(self._h, mode, a.ctypes.data, None if b is None else b.ctypes.data, out.ctypes.data, a.size), "alego_debug_math")
+        return out
+
+    def eval_blocks(self, btype, geom13, params6):
+        """(residuals[n], jacobians[n, 6]) of cost functor `btype` evaluated on the device as the solvers do"""
+        g = np.ascontiguousarray(geom13, np.float64).reshape(-1, 13)
+        p = np.ascontiguousarray(params6, np.float64)
+        r, J = np.empty(g.shape[0]), np.empty((g.shape[0], 6))
+        self._check(lib().alego_debug_eval_blocks(self._h, btype, g.shape[0], g.ctypes.data, p.ctypes.data, r.ctypes.data, J.ctypes.data), "alego_debug_eval_blocks")
+        return r, J
+
+    def transform_to_start(self, params6, pts):
+        p = np.ascontiguousarray(params6, np.float64)
+        a = np.ascontiguousarray(pts, np.float32)
+        out = np.empty_like(a)
+        self._check(lib().alego_debug_transform_to_start(self._h, p.ctypes.data, a.ctypes.data, a.shape[0], out.ctypes.data), "alego_debug_transform_to_start")
+        return out
+
+    def set_option(self, name, value):
+        self._check(lib().alego_debug_set_option(self._h, name.encode(), int(value)), f"alego_debug_set_option({name})")
+
+    # ---- key-frame pass-through (host pose graph) ----
+    def lm_keyframe_count(self, slot=0):
+        return self._check(lib().alego_lm_keyframe_count(self._h, slot), "alego_lm_keyframe_count")
+
+    def lm_get_keyframe(self, kf_id=-1, slot=0):
+        """dict(id, pose[6], corner, surf, outlier): a resident key frame as saveKeyFramesAndFactor stored it"""
+        N = self.N
+        bufs = [np.empty((N, 4), np.float32) for _ in range(3)]
+        k = KeyFrame()
+        k.corner, k.corner_cap = bufs[0].ctypes.data, N
+        k.surf, k.surf_cap = bufs[1].ctypes.data, N
+        k.outlier, k.outlier_cap = bufs[2].ctypes.data, N
+        self._check(lib().alego_lm_get_keyframe(self._h, slot, kf_id, C.byref(k)), "alego_lm_get_keyframe")
+        return dict(id=int(k.id), pose=np.array(k.pose[:], np.float32), corner=bufs[0][:k.n_corner].copy(), surf=bufs[1][:k.n_surf].copy(),
+                    outlier=bufs[2][:k.n_outlier].copy())
+
+    def lm_set_keypose(self, kf_id, pose6, slot=0):
+        a = np.ascontiguousarray(pose6, np.float32)
+        self._check(lib().alego_lm_set_keypose(self._h, slot, kf_id, a.ctypes.data), "alego_lm_set_keypose")
+
+    def lm_reset_window(self, slot=0):
+        self._check(lib().alego_lm_reset_window(self._h, slot), "alego_lm_reset_window")
+
+    def lm_apply_correction(self, rc12, slot=0):
+        a = np.ascontiguousarray(rc12, np.float64).reshape(12)
+        self._check(lib().alego_lm_apply_correction(self._h, slot, a.ctypes.data), "alego_lm_apply_correction")
+
+    def lm_add_keyframe(self, pose6, corner, surf, outlier, slot=0):
+        a = np.ascontiguousarray(pose6, np.float32)
+        c, s, o = (np.ascontiguousarray(v, np.float32).reshape(-1, 4) for v in (corner, surf, outlier))
+        self._check(lib().alego_lm_add_keyframe(self._h, slot, a.ctypes.data, c.ctypes.data, c.shape[0], s.ctypes.data, s.shape[0],
+                                                o.ctypes.data, o.shape[0]), "alego_lm_add_keyframe")
 
     def atan2f(self, y, x):
         y = np.ascontiguousarray(y, np.float32)

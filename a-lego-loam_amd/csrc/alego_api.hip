@@ -23,6 +23,8 @@ void launch_ip(const DevCtx& d, int ring_pos, bool want_labels, hipStream_t st);
 void launch_fe(const DevCtx& d, hipStream_t st);
 void launch_lo(const DevCtx& d, hipStream_t st);
 void launch_atan2f_probe(const float* y, const float* x, float* out, int n, int mode, hipStream_t st);
+void launch_dbg_eval_blocks(int type, int n, const double* geom13, const double* params6, double* res, double* jac6, hipStream_t st);
+void launch_dbg_transform_to_start(const double* params6, const float4* pts, int n, float4* out, hipStream_t st);
 int ip_configure(const DevCtx& d);
 int lo_configure();
 int lm_configure();
@@ -41,6 +43,7 @@ struct alego_handle {
   std::vector<long> lo_scans;  // LO steps enqueued per slot (the first one only initialises, laserOdometry.cpp:316-324)
   LmHost* lm = nullptr;
   Profiler prof;
+  int ip_fast_capable = 0;  // which of ip_project's table fast paths this geometry supports
 };
 
 namespace {
@@ -80,6 +83,15 @@ hipError_t sync_all(const alego_handle* h) {
   for (hipStream_t s : h->streams) { hipError_t e = hipStreamSynchronize(s); if (e != hipSuccess) r = e; }
   return r;
 }
+
+// frees temporary device buffers on every exit path of the debug entries
+struct DevTemps {
+  std::vector<void*> p;
+  template <class T> hipError_t get(T** q, size_t bytes) { void* v = nullptr; hipError_t e = hipMalloc(&v, bytes ? bytes : 16); if (e == hipSuccess) p.push_back(v); *q = (T*)v; return e; }
+  ~DevTemps() { for (void* v : p) (void)hipFree(v); }
+};
+
+int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
 
 int check_slot(alego_handle* h, int slot) {
   if (!h) return ALEGO_ERR_ARG;
@@ -126,6 +138,14 @@ int alego_create(const alego_params* params, int device, int n_slots, int ring_l
     std::fprintf(stderr, "alego_create: feature-pick parameters out of range (0 <= suppress_radius <= 5, n_sectors >= 1, 0 <= n_sharp <= n_less_sharp, n_flat >= 1)\n");
     return ALEGO_ERR_ARG;
   }
+  {
+    // the feature pick keeps a sector's candidates in registers: 16 lanes x 43 (fe_pick4) or 64 lanes x 12 (fe_pick) elements
+    const int sector_max = (params->horizon_scan + params->n_sectors - 1) / params->n_sectors + 2;
+    if (sector_max > 64 * 12) {
+      std::fprintf(stderr, "alego_create: ceil(horizon_scan / n_sectors) + 2 = %d exceeds the 768 sector elements the feature pick holds\n", sector_max);
+      return ALEGO_ERR_ARG;
+    }
+  }
   alego_handle* h = new alego_handle();
   h->P = *params;
   h->device = device;
@@ -168,6 +188,10 @@ int alego_create(const alego_params* params, int device, int n_slots, int ring_l
   d.h_magic = (unsigned)((1ull << 32) / (unsigned long long)d.H) + 1u;
   d.inv_res_x = 1.0 / params->ang_res_x; d.inv_res_y = 1.0 / params->ang_res_y;
   d.tan_theta = (params->seg_theta > 0.0 && params->seg_theta < 1.5) ? std::tan(params->seg_theta) : std::nan("");
+  d.opt_cc_fused = env_int("ALEGO_CC_FUSED", 1) != 0;
+  d.opt_fe_pick1 = env_int("ALEGO_FE_PICK1", 0) != 0;
+  d.opt_lo_box_lds = env_int("ALEGO_LO_BOX_LDS", 1 << 20);
+  d.opt_map_merge = env_int("ALEGO_MAP_MERGE", 1) != 0;
   const size_t B = n_slots, N = d.N, NS = d.NS;
   int rc = 0;
   rc |= dalloc(h, &d.in_pts, B * ring_len * d.Pcap, false);
@@ -208,15 +232,14 @@ int alego_create(const alego_params* params, int device, int n_slots, int ring_l
     }
     double2 *rtd = nullptr, *ctd = nullptr;
     rc |= dalloc(h, &rtd, NS + 6); rc |= dalloc(h, &ctd, (size_t)d.ip_ncb);
-    if (!rc) {
-      hipMemcpy(rtd, rt.data(), rt.size() * sizeof(double), hipMemcpyHostToDevice);
-      hipMemcpy(ctd, ct.data(), ct.size() * sizeof(double), hipMemcpyHostToDevice);
-    }
+    if (!rc && (hipMemcpy(rtd, rt.data(), rt.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
+                hipMemcpy(ctd, ct.data(), ct.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess)) { h->err = "upload of the projection tables failed"; rc = ALEGO_ERR_HIP; }
     d.ip_rowtab = rtd; d.ip_coltab = ctd;
     d.ip_fast = 0;
     if (params->laser_type == ALEGO_LASER_UNIFORM && ry > 1e-3 && std::fabs(((double)NS + 2.5) * ry - params->ang_bottom) < 80.0 && std::fabs(-3.5 * ry - params->ang_bottom) < 80.0) d.ip_fast |= 1;
     if (rx > 1e-3 && std::fabs((double)d.H * rx - 360.0) < 1e-9 && d.ip_ncb < (1 << 20)) d.ip_fast |= 2;
-    if (const char* e = getenv("ALEGO_IP_FAST")) d.ip_fast &= atoi(e);   // tests: 0 forces the reference expressions for every point
+    h->ip_fast_capable = d.ip_fast;
+    d.ip_fast &= env_int("ALEGO_IP_FAST", 3);   // tests: 0 forces the reference expressions for every point
   }
   if (rc) { *out = h; int e = ALEGO_ERR_HIP; std::fprintf(stderr, "alego_create: %s\n", h->err.c_str()); alego_destroy(h); *out = nullptr; return e; }
   // r_w_cur_ = identity, pose quaternions = identity (laserOdometry.cpp:46-47)
@@ -231,9 +254,11 @@ int alego_create(const alego_params* params, int device, int n_slots, int ring_l
     sc0[b * SC_COUNT + SC_CUR] = 1;  // the first scan writes feature buffer 0
     sc0[b * SC_COUNT + SC_FIRST] = 0x7fffffff; sc0[b * SC_COUNT + SC_LAST] = -1;   // accumulators of ip_project, re-armed by ip_image
   }
-  hipMemcpy(d.scal, sc0.data(), sc0.size() * sizeof(int), hipMemcpyHostToDevice);
-  hipMemcpy(d.lo_state, st.data(), st.size() * sizeof(double), hipMemcpyHostToDevice);
-  hipMemcpy(d.poses, po.data(), po.size() * sizeof(double), hipMemcpyHostToDevice);
+  if (hipMemcpy(d.scal, sc0.data(), sc0.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(d.lo_state, st.data(), st.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(d.poses, po.data(), po.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) {
+    std::fprintf(stderr, "alego_create: initial state upload failed\n"); alego_destroy(h); return ALEGO_ERR_HIP;
+  }
   if (ip_configure(d) != 0 || lo_configure() != 0 || lm_configure() != 0) { h->err = "hipFuncSetAttribute failed"; std::fprintf(stderr, "alego_create: %s\n", h->err.c_str()); alego_destroy(h); return ALEGO_ERR_HIP; }
   h->lm = lm_host_create(h->P, d, n_slots, h->gsize, h->streams, &h->err);
   if (!h->lm) { std::fprintf(stderr, "alego_create: %s\n", h->err.c_str()); alego_destroy(h); return ALEGO_ERR_HIP; }
@@ -408,7 +433,8 @@ int alego_lo_process(alego_handle* h, const alego_seg_out* in, alego_feat_out* f
   if (!h || !in) return ALEGO_ERR_ARG;
   hipSetDevice(h->device);
   const DevCtx& d = h->d;
-  if (in->m > d.N) { h->err = "segmented cloud larger than n_scan*horizon_scan"; return ALEGO_ERR_CAPACITY; }
+  if (in->m < 0 || in->m > d.N) { h->err = "segmented cloud larger than n_scan*horizon_scan"; return ALEGO_ERR_CAPACITY; }
+  if (!in->ring_start || !in->ring_end || (in->m > 0 && (!in->seg || !in->ground || !in->col || !in->range))) { h->err = "alego_lo_process: null input array"; return ALEGO_ERR_ARG; }
   const size_t M = in->m;
   HIP_TRY(h, hipMemcpyAsync(d.seg_pts, in->seg, M * 16, hipMemcpyHostToDevice, h->stream));
   HIP_TRY(h, hipMemcpyAsync(d.seg_ground, in->ground, M, hipMemcpyHostToDevice, h->stream));
@@ -420,7 +446,8 @@ int alego_lo_process(alego_handle* h, const alego_seg_out* in, alego_feat_out* f
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   if (int r = enqueue_scan(h, 0, 1, 0, 2, false)) return r;
   if (feat) { if (int r = download_feat(h, 0, feat)) return r; }
-  return fetch_pose(h, 0, odom, nullptr) & 7;
+  const int r = fetch_pose(h, 0, odom, nullptr);
+  return r < 0 ? r : (r & 7);
 }
 
 int alego_lm_process(alego_handle* h, const alego_point* corner_last, int32_t n_corner, const alego_point* surf_last,
@@ -486,41 +513,131 @@ int alego_profile_report(alego_handle* h, char* names, int names_cap, double* to
 }
 
 int alego_debug_voxel(alego_handle* h, const alego_point* pts, int n, float leaf, alego_point* out, int cap) {
-  if (!h || n < 0) return ALEGO_ERR_ARG;
+  if (!h || n < 0 || (n > 0 && !pts)) return ALEGO_ERR_ARG;
   hipSetDevice(h->device);
   g_prof = &h->prof;
+  DevTemps T;
   float4 *din = nullptr, *dout = nullptr;
   int* cnt = nullptr;
   const int c = n > 0 ? n : 1;
-  HIP_TRY(h, hipMalloc((void**)&din, (size_t)c * 16)); HIP_TRY(h, hipMalloc((void**)&dout, (size_t)c * 16)); HIP_TRY(h, hipMalloc((void**)&cnt, 8));
+  HIP_TRY(h, T.get(&din, (size_t)c * 16)); HIP_TRY(h, T.get(&dout, (size_t)c * 16)); HIP_TRY(h, T.get(&cnt, 8));
   const int hc[2] = {n, 0};
   HIP_TRY(h, hipMemcpy(cnt, hc, 8, hipMemcpyHostToDevice));
   if (n) HIP_TRY(h, hipMemcpy(din, pts, (size_t)n * 16, hipMemcpyHostToDevice));
-  VoxJob job{din, cnt, dout, cnt + 1, nullptr, leaf, c, 0};
+  VoxJob job{din, cnt, dout, cnt + 1, nullptr, leaf, c, c, nullptr, 0};
   VoxCtx V;
   if (vox_create(&V, &job, 1, &h->err)) return ALEGO_ERR_HIP;
   int rc = vox_run(V, h->stream, &h->err);
-  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  hipError_t e = hipStreamSynchronize(h->stream);
   int nout = 0;
-  HIP_TRY(h, hipMemcpy(&nout, cnt + 1, 4, hipMemcpyDeviceToHost));
-  if (rc == 0 && nout > cap) { h->err = "debug_voxel: output capacity"; rc = ALEGO_ERR_CAPACITY; }
-  if (rc == 0 && nout) HIP_TRY(h, hipMemcpy(out, dout, (size_t)nout * 16, hipMemcpyDeviceToHost));
+  if (e == hipSuccess) e = hipMemcpy(&nout, cnt + 1, 4, hipMemcpyDeviceToHost);
+  if (e == hipSuccess && rc == 0 && nout > cap) { h->err = "debug_voxel: output capacity"; rc = ALEGO_ERR_CAPACITY; }
+  if (e == hipSuccess && rc == 0 && nout) e = hipMemcpy(out, dout, (size_t)nout * 16, hipMemcpyDeviceToHost);
   vox_destroy(&V);
-  hipFree(din); hipFree(dout); hipFree(cnt);
+  if (e != hipSuccess) { h->err = std::string("debug_voxel: ") + hipGetErrorString(e); return ALEGO_ERR_HIP; }
   return rc ? rc : nout;
 }
 
-int alego_debug_atan2f(alego_handle* h, const float* y, const float* x, float* out, int n) {
-  if (!h) return ALEGO_ERR_ARG;
+int alego_debug_math(alego_handle* h, int mode, const float* a, const float* b, float* out, int n) {
+  if (!h || n < 0 || mode < 0 || mode > 3 || (n > 0 && (!a || !out || (mode < 2 && !b)))) return ALEGO_ERR_ARG;
+  if (n == 0) return 0;
   hipSetDevice(h->device);
-  float *dy, *dx, *dout;
-  HIP_TRY(h, hipMalloc((void**)&dy, n * 4)); HIP_TRY(h, hipMalloc((void**)&dx, n * 4)); HIP_TRY(h, hipMalloc((void**)&dout, n * 4));
-  HIP_TRY(h, hipMemcpy(dy, y, n * 4, hipMemcpyHostToDevice)); HIP_TRY(h, hipMemcpy(dx, x, n * 4, hipMemcpyHostToDevice));
-  launch_atan2f_probe(dy, dx, dout, n, 0, h->stream);
+  DevTemps T;
+  float *da, *db, *dout;
+  HIP_TRY(h, T.get(&da, (size_t)n * 4)); HIP_TRY(h, T.get(&db, (size_t)n * 4)); HIP_TRY(h, T.get(&dout, (size_t)n * 4));
+  HIP_TRY(h, hipMemcpy(da, a, (size_t)n * 4, hipMemcpyHostToDevice));
+  if (b) HIP_TRY(h, hipMemcpy(db, b, (size_t)n * 4, hipMemcpyHostToDevice));
+  // the probe kernel takes (y, x): atan2f(y, x), hypotf(x, y), sinf(y), cosf(y)
+  launch_atan2f_probe(da, db, dout, n, mode, h->stream);
   HIP_TRY(h, hipStreamSynchronize(h->stream));
-  HIP_TRY(h, hipMemcpy(out, dout, n * 4, hipMemcpyDeviceToHost));
-  hipFree(dy); hipFree(dx); hipFree(dout);
+  HIP_TRY(h, hipMemcpy(out, dout, (size_t)n * 4, hipMemcpyDeviceToHost));
   return 0;
+}
+int alego_debug_atan2f(alego_handle* h, const float* y, const float* x, float* out, int n) { return alego_debug_math(h, 0, y, x, out, n); }
+
+int alego_debug_eval_blocks(alego_handle* h, int type, int n, const double* geom13, const double* params6, double* res, double* jac6) {
+  if (!h || n < 0 || type < 0 || type > 3 || !params6 || (n > 0 && (!geom13 || !res || !jac6))) return ALEGO_ERR_ARG;
+  if (n == 0) return 0;
+  hipSetDevice(h->device);
+  DevTemps T;
+  double *dg, *dp, *dr, *dj;
+  HIP_TRY(h, T.get(&dg, (size_t)n * 13 * 8)); HIP_TRY(h, T.get(&dp, 48)); HIP_TRY(h, T.get(&dr, (size_t)n * 8)); HIP_TRY(h, T.get(&dj, (size_t)n * 48));
+  HIP_TRY(h, hipMemcpy(dg, geom13, (size_t)n * 13 * 8, hipMemcpyHostToDevice));
+  HIP_TRY(h, hipMemcpy(dp, params6, 48, hipMemcpyHostToDevice));
+  launch_dbg_eval_blocks(type, n, dg, dp, dr, dj, h->stream);
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  HIP_TRY(h, hipMemcpy(res, dr, (size_t)n * 8, hipMemcpyDeviceToHost));
+  HIP_TRY(h, hipMemcpy(jac6, dj, (size_t)n * 48, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int alego_debug_transform_to_start(alego_handle* h, const double* params6, const alego_point* pts, int n, alego_point* out) {
+  if (!h || n < 0 || !params6 || (n > 0 && (!pts || !out))) return ALEGO_ERR_ARG;
+  if (n == 0) return 0;
+  hipSetDevice(h->device);
+  DevTemps T;
+  double* dp;
+  float4 *di, *dout;
+  HIP_TRY(h, T.get(&dp, 48)); HIP_TRY(h, T.get(&di, (size_t)n * 16)); HIP_TRY(h, T.get(&dout, (size_t)n * 16));
+  HIP_TRY(h, hipMemcpy(dp, params6, 48, hipMemcpyHostToDevice));
+  HIP_TRY(h, hipMemcpy(di, pts, (size_t)n * 16, hipMemcpyHostToDevice));
+  launch_dbg_transform_to_start(dp, di, n, dout, h->stream);
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  HIP_TRY(h, hipMemcpy(out, dout, (size_t)n * 16, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int alego_debug_set_option(alego_handle* h, const char* name, int value) {
+  if (!h || !name) return ALEGO_ERR_ARG;
+  const std::string s(name);
+  DevCtx& d = h->d;
+  if (s == "ALEGO_CC_FUSED") d.opt_cc_fused = value != 0;
+  else if (s == "ALEGO_FE_PICK1") d.opt_fe_pick1 = value != 0;
+  else if (s == "ALEGO_LO_BOX_LDS") d.opt_lo_box_lds = value;
+  else if (s == "ALEGO_MAP_MERGE") d.opt_map_merge = value != 0;
+  else if (s == "ALEGO_IP_FAST") d.ip_fast = h->ip_fast_capable & value;
+  else { h->err = "unknown option " + s; return ALEGO_ERR_ARG; }
+  return 0;
+}
+
+// ---- key-frame pass-through ---------------------------------------------------------------------------------------
+int alego_lm_keyframe_count(alego_handle* h, int slot) {
+  if (int r = check_slot(h, slot)) return r;
+  hipSetDevice(h->device);
+  return lm_host_keyframe_count(h->lm, slot);
+}
+int alego_lm_get_keyframe(alego_handle* h, int slot, int kf_id, alego_keyframe* out) {
+  if (int r = check_slot(h, slot)) return r;
+  if (!out) return ALEGO_ERR_ARG;
+  hipSetDevice(h->device);
+  return lm_host_get_keyframe(h->lm, slot, kf_id, out, &h->err);
+}
+int alego_lm_set_keypose(alego_handle* h, int slot, int kf_id, const float pose6[6]) {
+  if (int r = check_slot(h, slot)) return r;
+  if (!pose6) return ALEGO_ERR_ARG;
+  hipSetDevice(h->device);
+  g_prof = &h->prof;
+  return lm_host_set_keypose(h->lm, h->d, slot, kf_id, pose6, &h->err);
+}
+int alego_lm_reset_window(alego_handle* h, int slot) {
+  if (int r = check_slot(h, slot)) return r;
+  hipSetDevice(h->device);
+  return lm_host_reset_window(h->lm, slot, &h->err);
+}
+int alego_lm_apply_correction(alego_handle* h, int slot, const double rc[12]) {
+  if (int r = check_slot(h, slot)) return r;
+  if (!rc) return ALEGO_ERR_ARG;
+  hipSetDevice(h->device);
+  g_prof = &h->prof;
+  return lm_host_apply_correction(h->lm, h->d, slot, rc, &h->err);
+}
+int alego_lm_add_keyframe(alego_handle* h, int slot, const float pose6[6], const alego_point* corner, int32_t n_corner,
+                          const alego_point* surf, int32_t n_surf, const alego_point* outlier, int32_t n_outlier) {
+  if (int r = check_slot(h, slot)) return r;
+  if (!pose6) return ALEGO_ERR_ARG;
+  hipSetDevice(h->device);
+  g_prof = &h->prof;
+  return lm_host_add_keyframe(h->lm, h->d, slot, pose6, corner, n_corner, surf, n_surf, outlier, n_outlier, &h->err);
 }
 
 int alego_debug_get(alego_handle* h, int slot, const char* name, void* out, int cap_bytes, int* count, int* dtype) {

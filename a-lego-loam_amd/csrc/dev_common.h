@@ -55,6 +55,11 @@ struct DevCtx {
   unsigned h_magic;                       // floor(2^32 / H) + 1: cell / H == umulhi(cell, h_magic) for every cell < 2^32 / H
   double tan_g_lo, tan_g_hi;              // tan of (sensor_mount_ang -/+ ground_angle_thres) (ground test shortcut; NaN disables)
   double tan_theta;                       // tan(seg_theta) for the edge predicate shortcut; NaN disables the shortcut
+  // ---- kernel-variant switches (read once from the environment by alego_create, alego_debug_set_option overrides) ----
+  int opt_cc_fused;     // ALEGO_CC_FUSED   1: cc_lds16 also compacts; 0: ip_rowcount + ip_compact
+  int opt_fe_pick1;     // ALEGO_FE_PICK1   1: one ring per wavefront (fe_pick) instead of fe_pick4
+  int opt_lo_box_lds;   // ALEGO_LO_BOX_LDS boxes staged in LDS by lo_assoc (0: straight from HBM)
+  int opt_map_merge;    // ALEGO_MAP_MERGE  1: local map from the pre-sorted key frames; 0: concat + radix VoxelGrid
   // ---- input ring ----
   float4* in_pts;  // [slot][ring][Pcap]
   int* in_n;       // [slot][ring]
@@ -199,6 +204,45 @@ DEV_INLINE float d_atan2f(float y, float x) {
 
 // glibc 2.35 hypotf: evaluated in double, rounded once
 DEV_INLINE float d_hypotf(float x, float y) { return (float)sqrt((double)x * (double)x + (double)y * (double)y); }
+
+// ---------------------------------------------------------------------------
+// sinf / cosf of glibc >= 2.28 (what Eigen's Quaternionf(AngleAxisf) in transformPointCloud,
+// laserMapping.h:166-173, calls on x86-64 Linux): fast quadrant reduction, fp64 minimax polynomial, one
+// rounding.  Not the correctly rounded value (1.3 % of the inputs differ), so the algorithm itself is
+// shared with the parity checker; plain fp64 + - * only, built with -ffp-contract=off.  |x| < 120 (a key
+// pose's half angles lie in [-pi/2, pi/2]); beyond that the correctly rounded value is returned.
+// ---------------------------------------------------------------------------
+DEV_INLINE uint32_t d_abstop12(float x) { return ((uint32_t)d_f2i(x) >> 20) & 0x7ffu; }
+DEV_INLINE float d_sincos_poly(double x, double x2, bool neg, int n) {
+  if ((n & 1) == 0) {
+    const double s1c = -0x1.555545995a603p-3, s2c = 0x1.1107605230bc4p-7, s3c = -0x1.994eb3774cf24p-13;
+    const double x3 = x * x2, s1 = s2c + x2 * s3c, x7 = x3 * x2, s = x + x3 * s1c;
+    return (float)(s + x7 * s1);
+  }
+  const double sg = neg ? -1.0 : 1.0;   // the second table of glibc holds the negated cosine coefficients (exact sign flips)
+  const double c0 = sg * 0x1p0, c1c = sg * -0x1.ffffffd0c621cp-2, c2c = sg * 0x1.55553e1068f19p-5, c3c = sg * -0x1.6c087e89a359dp-10,
+               c4c = sg * 0x1.99343027bf8c3p-16;
+  const double x4 = x2 * x2, c2 = c3c + x2 * c4c, c1 = c0 + x2 * c1c, x6 = x4 * x2, c = c1 + x4 * c2c;
+  return (float)(c + x6 * c2);
+}
+DEV_INLINE float d_sincosf(float y, int is_cos) {
+  double x = (double)y;
+  if (d_abstop12(y) < d_abstop12(0x1.921FB6p-1f)) {
+    if (d_abstop12(y) < d_abstop12(0x1p-12f)) return is_cos ? 1.0f : y;
+    return d_sincos_poly(x, x * x, false, is_cos);
+  }
+  if (d_abstop12(y) < d_abstop12(120.0f)) {
+    const double r = x * 0x1.45F306DC9C883p+23;
+    const int n = ((int32_t)r + 0x800000) >> 24;
+    x = x - (double)n * 0x1.921FB54442D18p0;
+    const int q = n + is_cos;
+    const double s = ((q & 3) == 1 || (q & 3) == 2) ? -1.0 : 1.0;
+    return d_sincos_poly(x * s, x * x, (q & 2) != 0, n ^ is_cos);
+  }
+  return is_cos ? (float)cos((double)y) : (float)sin((double)y);
+}
+DEV_INLINE float d_sinf(float y) { return d_sincosf(y, 0); }
+DEV_INLINE float d_cosf(float y) { return d_sincosf(y, 1); }
 
 // ---------------------------------------------------------------------------
 // wavefront (64 lanes) helpers

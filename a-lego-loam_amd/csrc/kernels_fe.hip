@@ -721,8 +721,7 @@ void launch_fe(const DevCtx& d, hipStream_t st) {
   const int sector_max = (d.H + d.P.n_sectors - 1) / (d.P.n_sectors > 0 ? d.P.n_sectors : 1) + 2;
   // (padding this allocation by 16 KB cost 7 % of the whole pipeline: the LDS footprint decides how many rings share a CU)
   const int extra = 0;
-  const char* ev = std::getenv("ALEGO_FE_PICK1");   // read per call: the tests switch it inside one process
-  const bool one_ring = (ev && ev[0] == '1') || d.P.suppress_radius > 7 || sector_max > 16 * 43;   // (2 * radius + 1 marked elements <= 16 lanes)
+  const bool one_ring = d.opt_fe_pick1 || d.P.suppress_radius > 7 || sector_max > 16 * 43;   // (2 * radius + 1 marked elements <= 16 lanes)
   const dim3 g4((d.NS + FP_G - 1) / FP_G, d.n_launch);
   const size_t lds4 = (size_t)FP_G * d.H;
   if (!one_ring && sector_max <= 16 * 19) { ALEGO_LAUNCH(fe_pick4<19>, g4, dim3(64), lds4, st, d); }

@@ -36,12 +36,15 @@ __global__ void __launch_bounds__(IP_BLOCK) ip_project(DevCtx d, int ring_pos) {
   bool valid = false;
   if (i < n) {
     const float4 p = pin[u];
-    valid = isfinite(p.x) && isfinite(p.y) && isfinite(p.z);
+    // pcl::removeNaNFromPointCloud only filters when the message is not dense (alego_params.input_is_dense); an unfiltered
+    // non-finite point still counts as first / last point of the scan and is rejected by the row test (int(NaN) < 0)
+    const bool finite = isfinite(p.x) && isfinite(p.y) && isfinite(p.z);
+    valid = finite || P.input_is_dense != 0;
     if (valid && P.near_filter) {
       const float th = (float)P.near_thres;
       if (p.x * p.x + p.y * p.y + p.z * p.z < th * th) valid = false;  // IP.cpp:91
     }
-    if (valid) {
+    if (valid && finite) {
       // ---- fast path: cell from the boundary tables.  The reference rounds atan2f / hypotf to f32 before it divides by the
       // angular resolution, so its row / column is the cell of the TRUE angle unless that angle lies within ~7e-5 cells of a
       // boundary.  A polynomial estimate (good to 0.03 cells) picks a boundary, the exact offset to it comes from one
@@ -989,14 +992,12 @@ __global__ void __launch_bounds__(IP_BLOCK) ip_labels(DevCtx d) {
 
 __global__ void atan2f_probe(const float* y, const float* x, float* out, int n, int mode) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) out[i] = mode == 0 ? d_atan2f(y[i], x[i]) : d_hypotf(x[i], y[i]);
+  if (i < n) out[i] = mode == 0 ? d_atan2f(y[i], x[i]) : mode == 1 ? d_hypotf(x[i], y[i]) : mode == 2 ? d_sinf(y[i]) : d_cosf(y[i]);
 }
 
 // ---- host-side launchers -------------------------------------------------------
 void launch_ip(const DevCtx& d, int ring_pos, bool want_labels, hipStream_t st) {
-  const char* fe_ = getenv("ALEGO_CC_FUSED");   // (per call: the parity tests switch variants inside one process)
-  const bool fuse_env = !(fe_ && atoi(fe_) == 0);
-  const bool fused = fuse_env && d.N <= CC_LDS_MAXN && d.NS <= 16;   // cc_lds also does the compaction
+  const bool fused = d.opt_cc_fused && d.N <= CC_LDS_MAXN && d.NS <= 16;   // cc_lds also does the compaction
   const dim3 gN((d.N + IP_BLOCK - 1) / IP_BLOCK, d.n_launch);
   const dim3 gN4((d.N + IP_BLOCK * IP_PW - 1) / (IP_BLOCK * IP_PW), d.n_launch), gP4((d.Pcap + IP_BLOCK * IP_PW - 1) / (IP_BLOCK * IP_PW), d.n_launch);
   ALEGO_LAUNCH(ip_project, gP4, dim3(IP_BLOCK), 0, st, d, ring_pos);

@@ -673,12 +673,12 @@ __global__ void __launch_bounds__(LM_SOLVE_BLOCK) lm_solve(DevCtx d, LmCtx L) {
 }
 
 // f32 4x4 of transformPointCloud (laserMapping.h:166-173): AngleAxisf(yaw,Z)*AngleAxisf(pitch,Y)*AngleAxisf(roll,X).
-// sin/cos of the half angles are evaluated in double and rounded to f32 (deviation from sinf/cosf).
+// sin/cos of the half angles are glibc's sinf / cosf (dev_common.h), as Eigen's Quaternionf(AngleAxisf) calls them.
 DEV_INLINE void keypose_matrix(const float* kp, float m[3][4]) {
   const float hz = 0.5f * kp[5], hy = 0.5f * kp[4], hx = 0.5f * kp[3];
-  const float qz[4] = {(float)cos((double)hz), 0.f, 0.f, (float)sin((double)hz)};
-  const float qy[4] = {(float)cos((double)hy), 0.f, (float)sin((double)hy), 0.f};
-  const float qx[4] = {(float)cos((double)hx), (float)sin((double)hx), 0.f, 0.f};
+  const float qz[4] = {d_cosf(hz), 0.f, 0.f, d_sinf(hz)};
+  const float qy[4] = {d_cosf(hy), 0.f, d_sinf(hy), 0.f};
+  const float qx[4] = {d_cosf(hx), d_sinf(hx), 0.f, 0.f};
   float t[4], q[4];
   t[0] = qz[0] * qy[0] - qz[1] * qy[1] - qz[2] * qy[2] - qz[3] * qy[3];
   t[1] = qz[0] * qy[1] + qz[1] * qy[0] + qz[2] * qy[3] - qz[3] * qy[2];
@@ -735,22 +735,31 @@ __global__ void lm_finish(DevCtx d, LmCtx L) {
   for (int k = 0; k < 3; ++k) ld[LD_T_M2O + k] = ld[LD_T_M2L + k] - r[k];
 }
 
-// grid (8, 3, slots): transform the down-sampled scan by the new key pose into the ring (laserMapping.h:164-177)
-__global__ void __launch_bounds__(LM_BLOCK) lm_store_kf(DevCtx d, LmCtx L) {
+// grid (8, 3, slots): a key frame enters the ring (saveKeyFramesAndFactor :546-555 keeps the down-sampled clouds of the
+// frame in the sensor frame; extractSurroundingKeyFrames :216-218,:240-242 transforms them by the f32 key pose,
+// laserMapping.h:164-177).  Both forms are kept: the raw clouds are what the host pose graph reads back and what a
+// corrected key pose is applied to (alego_lm_get_keyframe / alego_lm_set_keypose).
+//   only_ring < 0: the slots whose LI_KF_ADDED is set store their current scan (raw copy + transform)
+//   only_ring >= 0: re-transform ring entry `only_ring` of every slot of the launch from its raw clouds (set_keypose / add_keyframe)
+__global__ void __launch_bounds__(LM_BLOCK) lm_store_kf(DevCtx d, LmCtx L, int only_ring) {
   const int slot = blockIdx.z + d.slot0, kind = blockIdx.y;
   int* li = lip(L, slot);
-  if (!li[LI_KF_ADDED]) return;
-  const int ring = (li[LI_NKF] - 1) % L.K;
+  if (only_ring < 0 && !li[LI_KF_ADDED]) return;
+  const int ring = only_ring < 0 ? (li[LI_NKF] - 1) % L.K : only_ring;
   const float* kp = L.kf_pose + ((size_t)slot * L.K + ring) * 8;
   float m[3][4];
   keypose_matrix(kp, m);
-  const float4* src = kind == 0 ? L.cur_corner_ds + (size_t)slot * L.kf_cap_c : (kind == 1 ? L.cur_surf_ds + (size_t)slot * L.kf_cap_s : L.cur_outl_ds + (size_t)slot * L.kf_cap_o);
-  float4* dst = kind == 0 ? L.kf_corner + ((size_t)slot * L.K + ring) * L.kf_cap_c
-                          : (kind == 1 ? L.kf_surf + ((size_t)slot * L.K + ring) * L.kf_cap_s : L.kf_outl + ((size_t)slot * L.K + ring) * L.kf_cap_o);
+  const size_t rs = (size_t)slot * L.K + ring;
+  float4* raw = kind == 0 ? L.kf_raw_c + rs * L.kf_cap_c : (kind == 1 ? L.kf_raw_s + rs * L.kf_cap_s : L.kf_raw_o + rs * L.kf_cap_o);
+  const float4* cur = kind == 0 ? L.cur_corner_ds + (size_t)slot * L.kf_cap_c : (kind == 1 ? L.cur_surf_ds + (size_t)slot * L.kf_cap_s : L.cur_outl_ds + (size_t)slot * L.kf_cap_o);
+  float4* dst = kind == 0 ? L.kf_corner + rs * L.kf_cap_c : (kind == 1 ? L.kf_surf + rs * L.kf_cap_s : L.kf_outl + rs * L.kf_cap_o);
+  const int cap = kind == 0 ? L.kf_cap_c : (kind == 1 ? L.kf_cap_s : L.kf_cap_o);
   const int n_c = li[LI_NCUR_C], n_s = li[LI_NCUR_S], n_o = li[LI_NCUR_O];
-  const int n = kind == 0 ? n_c : (kind == 1 ? n_s : n_o);
+  const int n_new = min(kind == 0 ? n_c : (kind == 1 ? n_s : n_o), cap);
+  const int n = only_ring < 0 ? n_new : L.kf_cnt[rs * 4 + kind];
   for (int i = blockIdx.x * LM_BLOCK + threadIdx.x; i < n; i += gridDim.x * LM_BLOCK) {
-    const float4 p = src[i];
+    float4 p;
+    if (only_ring < 0) { p = cur[i]; raw[i] = p; } else { p = raw[i]; }
     float4 o;
     o.x = m[0][0] * p.x + m[0][1] * p.y + m[0][2] * p.z + m[0][3];
     o.y = m[1][0] * p.x + m[1][1] * p.y + m[1][2] * p.z + m[1][3];
@@ -758,7 +767,20 @@ __global__ void __launch_bounds__(LM_BLOCK) lm_store_kf(DevCtx d, LmCtx L) {
     o.w = p.w;
     dst[i] = o;
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) L.kf_cnt[((size_t)slot * L.K + ring) * 4 + kind] = n;
+  if (only_ring < 0 && blockIdx.x == 0 && threadIdx.x == 0) L.kf_cnt[rs * 4 + kind] = n;
+}
+
+// one thread: correctPoses :579-580 on map -> odom with the 3x4 [R | c] of the loop-closure correction
+__global__ void lm_apply_correction(DevCtx d, LmCtx L, int slot, const double* rc) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double* ld = ldp(L, slot);
+  double R[9], M[9], t[3];
+  dq_to_mat(ldq(ld + LD_Q_M2O), R);
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) M[i * 3 + j] = rc[i * 4 + 0] * R[0 * 3 + j] + rc[i * 4 + 1] * R[1 * 3 + j] + rc[i * 4 + 2] * R[2 * 3 + j];
+  for (int i = 0; i < 3; ++i) t[i] = rc[i * 4 + 0] * ld[LD_T_M2O + 0] + rc[i * 4 + 1] * ld[LD_T_M2O + 1] + rc[i * 4 + 2] * ld[LD_T_M2O + 2] + rc[i * 4 + 3];
+  stq(ld + LD_Q_M2O, dq_from_mat(M));
+  for (int i = 0; i < 3; ++i) ld[LD_T_M2O + i] = t[i];
 }
 
 #define LM_SOLVE_LDS ((size_t)(28 * (LM_SOLVE_BLOCK / 4) + 28 * (LM_SOLVE_BLOCK / 128)) * sizeof(double))
@@ -786,5 +808,11 @@ void launch_lm_register(const DevCtx& d, const LmCtx& L, hipStream_t st) {
   ALEGO_LAUNCH(lm_fit, dim3(LM_FIT_GX, 2, d.n_launch), dim3(128), 0, st, d, L);
   ALEGO_LAUNCH(lm_solve, dim3(d.n_launch), dim3(LM_SOLVE_BLOCK), LM_SOLVE_LDS, st, d, L);
   ALEGO_LAUNCH(lm_finish, dim3((d.n_launch + 63) / 64), dim3(64), 0, st, d, L);
-  ALEGO_LAUNCH(lm_store_kf, dim3(8, 3, d.n_launch), dim3(LM_BLOCK), 0, st, d, L);
+  ALEGO_LAUNCH(lm_store_kf, dim3(8, 3, d.n_launch), dim3(LM_BLOCK), 0, st, d, L, -1);
+}
+void launch_lm_retransform(const DevCtx& d, const LmCtx& L, int ring, hipStream_t st) {
+  ALEGO_LAUNCH(lm_store_kf, dim3(8, 3, d.n_launch), dim3(LM_BLOCK), 0, st, d, L, ring);
+}
+void launch_lm_apply_correction(const DevCtx& d, const LmCtx& L, int slot, const double* rc_dev, hipStream_t st) {
+  ALEGO_LAUNCH(lm_apply_correction, dim3(1), dim3(64), 0, st, d, L, slot, rc_dev);
 }

@@ -474,14 +474,43 @@ __global__ void __launch_bounds__(LO_SOLVE_BLOCK) lo_solve(DevCtx d, int phase) 
 #endif
 }
 
+// ---- debug entries (alego_debug_eval_blocks / alego_debug_transform_to_start): the device functions the solvers and the
+// association kernel call, on caller-provided data, for direct parity tests against the oracle
+__global__ void dbg_eval_blocks(int type, int n, const double* geom13, const double* params6, double* res, double* jac6) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const PoseTerms T = pose_terms(params6);
+  const double* g = geom13 + (size_t)i * 13;
+  const double cp[3] = {g[0], g[1], g[2]}, a[3] = {g[3], g[4], g[5]}, b[3] = {g[6], g[7], g[8]}, c[3] = {g[9], g[10], g[11]};
+  double r, J[6];
+  eval_block(type, cp, a, b, c, g[12], T, &r, J);
+  res[i] = r;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) jac6[(size_t)i * 6 + k] = J[k];
+}
+__global__ void dbg_transform_to_start(const double* params6, const float4* pts, int n, float4* out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double R[9];
+  pose_rotation(params6, R);
+  float o[3];
+  transform_to_start(R, params6, pts[i], o);
+  out[i] = make_float4(o[0], o[1], o[2], pts[i].w);
+}
+void launch_dbg_eval_blocks(int type, int n, const double* geom13, const double* params6, double* res, double* jac6, hipStream_t st) {
+  hipLaunchKernelGGL(dbg_eval_blocks, dim3((n + 63) / 64), dim3(64), 0, st, type, n, geom13, params6, res, jac6);
+}
+void launch_dbg_transform_to_start(const double* params6, const float4* pts, int n, float4* out, hipStream_t st) {
+  hipLaunchKernelGGL(dbg_transform_to_start, dim3((n + 63) / 64), dim3(64), 0, st, params6, pts, n, out);
+}
+
 #define LO_SOLVE_LDS ((size_t)(28 * (LO_SOLVE_BLOCK / 4) + 28 * (LO_SOLVE_BLOCK / 128)) * sizeof(double))
 int lo_configure() {
   return hipFuncSetAttribute(reinterpret_cast<const void*>(lo_solve), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LO_SOLVE_LDS) == hipSuccess ? 0 : -1;
 }
 
 void launch_lo(const DevCtx& d, hipStream_t st) {
-  const char* ble = getenv("ALEGO_LO_BOX_LDS");   // (read per call: the parity tests switch it inside one process)
-  const int box_lds_max = ble ? std::min(atoi(ble), (int)LO_BOX_LDS) : (int)LO_BOX_LDS;
+  const int box_lds_max = std::min(d.opt_lo_box_lds, (int)LO_BOX_LDS);
   ALEGO_LAUNCH(lo_assoc<0>, dim3(std::min((d.lo_qcap_surf + LO_QPB - 1) / LO_QPB, 8), d.n_launch), dim3(LO_BLOCK), 0, st, d, box_lds_max);
   ALEGO_LAUNCH(lo_solve, dim3(d.n_launch), dim3(LO_SOLVE_BLOCK), LO_SOLVE_LDS, st, d, 0);
   ALEGO_LAUNCH(lo_assoc<1>, dim3(std::min((d.lo_qcap_corner + LO_QPB - 1) / LO_QPB, 12), d.n_launch), dim3(LO_BLOCK), 0, st, d, box_lds_max);

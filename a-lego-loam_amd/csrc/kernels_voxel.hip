@@ -106,8 +106,8 @@ __device__ void vox_big_job(const VoxCtx& V, int job) {
   }
   const long long dx = (long long)((mx[0] - mn[0]) * inv) + 1, dy = (long long)((mx[1] - mn[1]) * inv) + 1, dz = (long long)((mx[2] - mn[2]) * inv) + 1;
   if (dx * dy * dz > 2147483647LL) {  // PCL: "leaf size too small" -> output = input
-    for (int i = tid; i < n; i += VG_T) J.out[i] = J.in[i];
-    if (tid == 0) *J.n_out = n;
+    for (int i = tid; i < min(n, J.out_cap); i += VG_T) J.out[i] = J.in[i];
+    if (tid == 0) { *J.n_out = min(n, J.out_cap); if (n > J.out_cap && J.overflow) *J.overflow = 1; }
     return;
   }
   int minb[3], divb[3];
@@ -260,7 +260,7 @@ __device__ void vox_big_job(const VoxCtx& V, int job) {
   const int nvox = s_wbase[VG_W];
   VG_TICK(12);
   // ---- 5. centroids
-  for (int r = tid; r < nvox; r += VG_T) {
+  for (int r = tid; r < min(nvox, J.out_cap); r += VG_T) {
     int w = 0;
 #pragma unroll
     for (int q = 1; q < VG_W; ++q) w += (r >= s_wbase[q]) ? 1 : 0;   // wavefront whose segment holds the start of voxel r
@@ -281,7 +281,7 @@ __device__ void vox_big_job(const VoxCtx& V, int job) {
     const float fn = (float)(b - a);
     J.out[r] = make_float4(sx / fn, sy / fn, sz / fn, si / fn);
   }
-  if (tid == 0) *J.n_out = nvox;
+  if (tid == 0) { *J.n_out = min(nvox, J.out_cap); if (nvox > J.out_cap && J.overflow) *J.overflow = 1; }
   __syncthreads();
   VG_TICK(13);
 }
@@ -349,8 +349,8 @@ __device__ void vox_small_job(const VoxCtx& V, int job) {
   }
   const long long dx = (long long)((mx[0] - mn[0]) * inv) + 1, dy = (long long)((mx[1] - mn[1]) * inv) + 1, dz = (long long)((mx[2] - mn[2]) * inv) + 1;
   if (dx * dy * dz > 2147483647LL) {  // PCL: "leaf size too small" -> output = input
-    for (int i = tid; i < n; i += VX_SB) J.out[i] = J.in[i];
-    if (tid == 0) *J.n_out = n;
+    for (int i = tid; i < min(n, J.out_cap); i += VX_SB) J.out[i] = J.in[i];
+    if (tid == 0) { *J.n_out = min(n, J.out_cap); if (n > J.out_cap && J.overflow) *J.overflow = 1; }
     return;
   }
   VG_TICK(1);
@@ -456,7 +456,7 @@ __device__ void vox_small_job(const VoxCtx& V, int job) {
   VG_TICK(5);
   VG_TICK(6);
   // ---- centroids: one thread per voxel, f32 sums in sorted (= original) order, four gathers in flight
-  for (int r = tid; r < nvox; r += VX_SB) {
+  for (int r = tid; r < min(nvox, J.out_cap); r += VX_SB) {
     const int a = hl[r], b = r + 1 < nvox ? (int)hl[r + 1] : n;
     float sx = 0.f, sy = 0.f, sz = 0.f, si = 0.f;
     for (int j = a; j < b; j += 4) {
@@ -469,7 +469,7 @@ __device__ void vox_small_job(const VoxCtx& V, int job) {
     const float fn = (float)(b - a);
     J.out[r] = make_float4(sx / fn, sy / fn, sz / fn, si / fn);
   }
-  if (tid == 0) *J.n_out = nvox;
+  if (tid == 0) { *J.n_out = min(nvox, J.out_cap); if (nvox > J.out_cap && J.overflow) *J.overflow = 1; }
   __syncthreads();
   VG_TICK(7);
 }

@@ -49,6 +49,8 @@ struct LmCtx {
   float4 *in_corner, *in_surf, *in_outl;          // [slot][in_cap_*]
   // key-frame ring (clouds already transformed into the map frame, laserMapping.cpp:216-218)
   float4 *kf_corner, *kf_surf, *kf_outl;          // [slot][K][kf_cap_*]
+  // the same key frames as saveKeyFramesAndFactor stores them (sensor frame, :553-555): host read-back + pose correction
+  float4 *kf_raw_c, *kf_raw_s, *kf_raw_o;         // [slot][K][kf_cap_*]
   int* rec;                                       // [slot][K] frame ids held by recent_*_keyframes_, front first
   int* kf_cnt;                                    // [slot][K][4]
   float* kf_pose;                                 // [slot][K][8]  x y z roll pitch yaw (PointXYZIRPYT f32)

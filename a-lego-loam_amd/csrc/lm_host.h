@@ -21,5 +21,12 @@ int lm_host_process_host(LmHost* lm, const DevCtx& d, const alego_point* corner_
 void lm_host_get_params(LmHost* lm, int slot, double* p6);
 int lm_host_set_params(LmHost* lm, int slot, const double* p6, std::string* err);
 void lm_host_get_counts(LmHost* lm, int slot, int* out6);
+int lm_host_keyframe_count(LmHost* lm, int slot);
+int lm_host_get_keyframe(LmHost* lm, int slot, int kf_id, alego_keyframe* out, std::string* err);
+int lm_host_set_keypose(LmHost* lm, const DevCtx& d, int slot, int kf_id, const float* pose6, std::string* err);
+int lm_host_reset_window(LmHost* lm, int slot, std::string* err);
+int lm_host_apply_correction(LmHost* lm, const DevCtx& d, int slot, const double* rc12, std::string* err);
+int lm_host_add_keyframe(LmHost* lm, const DevCtx& d, int slot, const float* pose6, const alego_point* corner, int nc, const alego_point* surf, int ns,
+                         const alego_point* outlier, int no, std::string* err);
 int lm_host_debug_get(LmHost* lm, int slot, const char* name, void* out, int cap_bytes, int* count, int* dtype, std::string* err);
 #endif

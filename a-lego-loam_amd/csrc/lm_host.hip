@@ -15,6 +15,8 @@ void launch_lm_concat(const DevCtx& d, const LmCtx& L, hipStream_t st);
 void launch_lm_total(const DevCtx& d, const LmCtx& L, hipStream_t st);
 void launch_lm_grid(const DevCtx& d, const LmCtx& L, hipStream_t st);
 void launch_lm_register(const DevCtx& d, const LmCtx& L, hipStream_t st);
+void launch_lm_retransform(const DevCtx& d, const LmCtx& L, int ring, hipStream_t st);
+void launch_lm_apply_correction(const DevCtx& d, const LmCtx& L, int slot, const double* rc_dev, hipStream_t st);
 
 struct LmHost {
   alego_params P;
@@ -64,6 +66,7 @@ LmHost* lm_host_create(const alego_params& P, const DevCtx& d, int n_slots, int 
   ok = ok && A(lm, &L.li, B * LI_COUNT, err) && A(lm, &L.ld, B * LD_COUNT, err);
   ok = ok && A(lm, &L.in_corner, B * L.in_cap_c, err) && A(lm, &L.in_surf, B * L.in_cap_s, err) && A(lm, &L.in_outl, B * L.in_cap_o, err);
   ok = ok && A(lm, &L.kf_corner, B * L.K * L.kf_cap_c, err) && A(lm, &L.kf_surf, B * L.K * L.kf_cap_s, err) && A(lm, &L.kf_outl, B * L.K * L.kf_cap_o, err);
+  ok = ok && A(lm, &L.kf_raw_c, B * L.K * L.kf_cap_c, err) && A(lm, &L.kf_raw_s, B * L.K * L.kf_cap_s, err) && A(lm, &L.kf_raw_o, B * L.K * L.kf_cap_o, err);
   ok = ok && A(lm, &L.rec, B * L.K, err);
   ok = ok && A(lm, &L.kf_cnt, B * L.K * 4, err) && A(lm, &L.kf_pose, B * L.K * 8, err);
   ok = ok && A(lm, &L.map_corner_raw, B * L.map_cap_c, err) && A(lm, &L.map_surf_raw, B * L.map_cap_s, err);
@@ -77,21 +80,21 @@ LmHost* lm_host_create(const alego_params& P, const DevCtx& d, int n_slots, int 
   // identity quaternions (laserMapping.cpp:56-61)
   std::vector<double> ld(B * LD_COUNT, 0.0);
   for (size_t b = 0; b < B; ++b) { ld[b * LD_COUNT + LD_Q_M2O] = 1.0; ld[b * LD_COUNT + LD_Q_O2L] = 1.0; ld[b * LD_COUNT + LD_Q_M2L] = 1.0; }
-  (void)hipMemcpy(L.ld, ld.data(), ld.size() * sizeof(double), hipMemcpyHostToDevice);
+  if (hipMemcpy(L.ld, ld.data(), ld.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) { *err = "lm_host_create: upload failed"; lm_host_destroy(lm); return nullptr; }
   std::vector<int> li0(B * LI_COUNT, 0);
   for (size_t b = 0; b < B; ++b) li0[b * LI_COUNT + LI_LATEST] = -1;   // laserMapping.cpp:50
-  (void)hipMemcpy(L.li, li0.data(), li0.size() * sizeof(int), hipMemcpyHostToDevice);
+  if (hipMemcpy(L.li, li0.data(), li0.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) { *err = "lm_host_create: upload failed"; lm_host_destroy(lm); return nullptr; }
   // VoxelGrid job tables (laserMapping.cpp:37-39,316-319,329-342)
   for (size_t g = 0; g < st.size(); ++g) {
   std::vector<VoxJob> jm, j1, j2;
   for (size_t b = g * gsize; b < B && b < (g + 1) * (size_t)gsize; ++b) {
     int* li = L.li + b * LI_COUNT;
-    jm.push_back(VoxJob{L.map_corner_raw + b * L.map_cap_c, li + LI_KRAW_C, L.map_corner_ds + b * L.map_cap_c, li + LI_KDS_C, li + LI_REBUILD, P.lm_leaf_corner, L.map_cap_c, 0});
-    jm.push_back(VoxJob{L.map_surf_raw + b * L.map_cap_s, li + LI_KRAW_S, L.map_surf_ds + b * L.map_cap_s, li + LI_KDS_S, li + LI_REBUILD, P.lm_leaf_surf, L.map_cap_s, 0});
-    j1.push_back(VoxJob{L.in_corner + b * L.in_cap_c, li + LI_NIN_C, L.cur_corner_ds + b * L.kf_cap_c, li + LI_NCUR_C, li + LI_RUN, P.lm_leaf_corner, L.kf_cap_c, 0});
-    j1.push_back(VoxJob{L.in_surf + b * L.in_cap_s, li + LI_NIN_S, L.cur_surf_ds + b * L.kf_cap_s, li + LI_NCUR_S, li + LI_RUN, P.lm_leaf_surf, L.in_cap_s, 0});
-    j1.push_back(VoxJob{L.in_outl + b * L.in_cap_o, li + LI_NIN_O, L.cur_outl_ds + b * L.kf_cap_o, li + LI_NCUR_O, li + LI_RUN, P.lm_leaf_outlier, L.in_cap_o, 0});
-    j2.push_back(VoxJob{L.cur_total + b * L.total_cap, li + LI_NTOTAL, L.cur_total_ds + b * L.total_cap, li + LI_NTOTAL_DS, li + LI_RUN, P.lm_leaf_surf, L.total_cap, 0});
+    jm.push_back(VoxJob{L.map_corner_raw + b * L.map_cap_c, li + LI_KRAW_C, L.map_corner_ds + b * L.map_cap_c, li + LI_KDS_C, li + LI_REBUILD, P.lm_leaf_corner, L.map_cap_c, L.map_cap_c, li + LI_OVERFLOW, 0});
+    jm.push_back(VoxJob{L.map_surf_raw + b * L.map_cap_s, li + LI_KRAW_S, L.map_surf_ds + b * L.map_cap_s, li + LI_KDS_S, li + LI_REBUILD, P.lm_leaf_surf, L.map_cap_s, L.map_cap_s, li + LI_OVERFLOW, 0});
+    j1.push_back(VoxJob{L.in_corner + b * L.in_cap_c, li + LI_NIN_C, L.cur_corner_ds + b * L.kf_cap_c, li + LI_NCUR_C, li + LI_RUN, P.lm_leaf_corner, L.in_cap_c, L.kf_cap_c, li + LI_OVERFLOW, 0});
+    j1.push_back(VoxJob{L.in_surf + b * L.in_cap_s, li + LI_NIN_S, L.cur_surf_ds + b * L.kf_cap_s, li + LI_NCUR_S, li + LI_RUN, P.lm_leaf_surf, L.in_cap_s, L.kf_cap_s, li + LI_OVERFLOW, 0});
+    j1.push_back(VoxJob{L.in_outl + b * L.in_cap_o, li + LI_NIN_O, L.cur_outl_ds + b * L.kf_cap_o, li + LI_NCUR_O, li + LI_RUN, P.lm_leaf_outlier, L.in_cap_o, L.kf_cap_o, li + LI_OVERFLOW, 0});
+    j2.push_back(VoxJob{L.cur_total + b * L.total_cap, li + LI_NTOTAL, L.cur_total_ds + b * L.total_cap, li + LI_NTOTAL_DS, li + LI_RUN, P.lm_leaf_surf, L.total_cap, L.total_cap, li + LI_OVERFLOW, 0});
   }
   const int ns = (int)jm.size() / 2;
   jm.insert(jm.end(), j1.begin(), j1.end());
@@ -121,6 +124,9 @@ static bool dbg_sync(hipStream_t st, const char* what, std::string* err) {
   if (e != hipSuccess) { *err = std::string(what) + ": " + hipGetErrorString(e); return false; }
   return true;
 }
+
+// a key frame's transformed clouds were (re)written outside the regular sequence (set_keypose / add_keyframe)
+static void lm_kf_changed(LmHost*, const DevCtx&, int, hipStream_t) {}
 
 // concat + VoxelGrid of the maps + grid, for the slots whose window changed (LI_REBUILD, set by lm_prepare)
 static int map_sequence(LmHost* lm, const DevCtx& d, const LmCtx& L, int g, hipStream_t st, std::string* err) {
@@ -186,25 +192,35 @@ int lm_host_process_host(LmHost* lm, const DevCtx& dfull, const alego_point* cor
   DevCtx d = dfull;
   d.slot0 = 0; d.n_launch = 1;
   hipStream_t st = lm->st[0];
-  (void)hipMemcpyAsync(L.in_corner, corner_last, (size_t)n_corner * 16, hipMemcpyHostToDevice, st);
-  (void)hipMemcpyAsync(L.in_surf, surf_last, (size_t)n_surf * 16, hipMemcpyHostToDevice, st);
-  (void)hipMemcpyAsync(L.in_outl, outlier, (size_t)n_outlier * 16, hipMemcpyHostToDevice, st);
+  if ((n_corner > 0 && !corner_last) || (n_surf > 0 && !surf_last) || (n_outlier > 0 && !outlier) || n_corner < 0 || n_surf < 0 || n_outlier < 0) { *err = "alego_lm_process: null cloud / negative count"; return ALEGO_ERR_ARG; }
+  hipError_t e = hipSuccess;
+  auto up = [&](void* dst, const void* src, size_t bytes) { if (e == hipSuccess && bytes) e = hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st); };
+  up(L.in_corner, corner_last, (size_t)n_corner * 16);
+  up(L.in_surf, surf_last, (size_t)n_surf * 16);
+  up(L.in_outl, outlier, (size_t)n_outlier * 16);
   const int nin[3] = {n_corner, n_surf, n_outlier};
-  (void)hipMemcpyAsync(L.li + LI_NIN_C, nin, sizeof(nin), hipMemcpyHostToDevice, st);
+  up(L.li + LI_NIN_C, nin, sizeof(nin));
   double po[7] = {odom->t[0], odom->t[1], odom->t[2], odom->q[0], odom->q[1], odom->q[2], odom->q[3]};
-  (void)hipMemcpyAsync(d.poses, po, sizeof(po), hipMemcpyHostToDevice, st);
+  up(d.poses, po, sizeof(po));
   const int one = 1;
-  (void)hipMemcpyAsync(d.scal + SC_ODOM_VALID, &one, sizeof(int), hipMemcpyHostToDevice, st);
-  if (hipStreamSynchronize(st) != hipSuccess) { *err = "alego_lm_process: upload failed"; return ALEGO_ERR_HIP; }
+  up(d.scal + SC_ODOM_VALID, &one, sizeof(int));
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  if (e != hipSuccess) { *err = std::string("alego_lm_process: upload failed: ") + hipGetErrorString(e); return ALEGO_ERR_HIP; }
   clear_run_flags_outside(lm, d);
   if (int r = lm_sequence(lm, d, 0, std::vector<char>(1, 1), err)) return r;
   double out[16], ld[LD_COUNT];
   int li[LI_COUNT];
-  (void)hipMemcpyAsync(out, d.poses, sizeof(out), hipMemcpyDeviceToHost, st);
-  (void)hipMemcpyAsync(ld, L.ld, sizeof(ld), hipMemcpyDeviceToHost, st);
-  (void)hipMemcpyAsync(li, L.li, sizeof(li), hipMemcpyDeviceToHost, st);
-  if (hipStreamSynchronize(st) != hipSuccess) { *err = "alego_lm_process: kernels failed"; return ALEGO_ERR_HIP; }
-  if (li[LI_OVERFLOW]) { *err = "alego_lm_process: device capacity exceeded"; return ALEGO_ERR_CAPACITY; }
+  e = hipMemcpyAsync(out, d.poses, sizeof(out), hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipMemcpyAsync(ld, L.ld, sizeof(ld), hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipMemcpyAsync(li, L.li, sizeof(li), hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  if (e != hipSuccess) { *err = std::string("alego_lm_process: kernels failed: ") + hipGetErrorString(e); return ALEGO_ERR_HIP; }
+  if (li[LI_OVERFLOW]) {   // reported by the call that caused it, then cleared
+    const int zero = 0;
+    (void)hipMemcpy(L.li + LI_OVERFLOW, &zero, sizeof(int), hipMemcpyHostToDevice);
+    *err = li[LI_OVERFLOW] == 2 ? "alego_lm_process: launch logic out of sync" : "alego_lm_process: device capacity exceeded (cloud truncated)";
+    return ALEGO_ERR_CAPACITY;
+  }
   if (map_pose) {
     for (int i = 0; i < 3; ++i) map_pose->t[i] = out[7 + i];
     for (int i = 0; i < 4; ++i) map_pose->q[i] = out[10 + i];
@@ -221,16 +237,110 @@ int lm_host_set_params(LmHost* lm, int slot, const double* p6, std::string* err)
   if (hipMemcpy(lm->L.ld + (size_t)slot * LD_COUNT + LD_PARAMS, p6, 48, hipMemcpyHostToDevice) != hipSuccess) { *err = "set_lm_params failed"; return ALEGO_ERR_HIP; }
   return 0;
 }
+// LI_OVERFLOW stays set until it has been reported to the host once (the batch path only looks at the end of a run)
 int lm_host_get_flags(LmHost* lm, int slot) {
   int li[LI_COUNT];
-  (void)hipMemcpy(li, lm->L.li + (size_t)slot * LI_COUNT, sizeof(li), hipMemcpyDeviceToHost);
-  if (li[LI_OVERFLOW]) return ALEGO_ERR_CAPACITY;
+  if (hipMemcpy(li, lm->L.li + (size_t)slot * LI_COUNT, sizeof(li), hipMemcpyDeviceToHost) != hipSuccess) return ALEGO_ERR_HIP;
+  if (li[LI_OVERFLOW]) {
+    const int zero = 0;
+    (void)hipMemcpy(lm->L.li + (size_t)slot * LI_COUNT + LI_OVERFLOW, &zero, sizeof(int), hipMemcpyHostToDevice);
+    return ALEGO_ERR_CAPACITY;
+  }
   return li[LI_FLAGS];
 }
 void lm_host_get_counts(LmHost* lm, int slot, int* o) {  // o[7]
   int li[LI_COUNT];
   (void)hipMemcpy(li, lm->L.li + (size_t)slot * LI_COUNT, sizeof(li), hipMemcpyDeviceToHost);
   o[0] = li[LI_KRAW_C]; o[1] = li[LI_KRAW_S]; o[2] = li[LI_KDS_C]; o[3] = li[LI_KDS_S]; o[4] = li[LI_NCUR_C]; o[5] = li[LI_NTOTAL_DS]; o[6] = li[LI_NREBUILD];
+}
+
+// ---- key-frame pass-through (alego_lm_get_keyframe / set_keypose / reset_window / apply_correction / add_keyframe) ----
+static hipStream_t stream_of_slot(LmHost* lm, int slot) { return lm->st[slot / lm->gsize]; }
+int lm_host_keyframe_count(LmHost* lm, int slot) {
+  int n = 0;
+  if (hipStreamSynchronize(stream_of_slot(lm, slot)) != hipSuccess) return ALEGO_ERR_HIP;
+  if (hipMemcpy(&n, lm->L.li + (size_t)slot * LI_COUNT + LI_NKF, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return ALEGO_ERR_HIP;
+  return n;
+}
+int lm_host_get_keyframe(LmHost* lm, int slot, int kf_id, alego_keyframe* out, std::string* err) {
+  const LmCtx& L = lm->L;
+  const int nkf = lm_host_keyframe_count(lm, slot);
+  if (nkf < 0) { *err = "get_keyframe: device error"; return nkf; }
+  if (kf_id < 0) kf_id = nkf - 1;
+  if (kf_id < 0 || kf_id >= nkf || kf_id < nkf - L.K) { *err = "get_keyframe: key frame not resident (only the recent_keyframe_num newest are)"; return ALEGO_ERR_ARG; }
+  const size_t rs = (size_t)slot * L.K + kf_id % L.K;
+  int cnt[4];
+  float kp[8];
+  if (hipMemcpy(cnt, L.kf_cnt + rs * 4, sizeof(cnt), hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(kp, L.kf_pose + rs * 8, sizeof(kp), hipMemcpyDeviceToHost) != hipSuccess) { *err = "get_keyframe: copy failed"; return ALEGO_ERR_HIP; }
+  out->id = kf_id;
+  for (int k = 0; k < 6; ++k) out->pose[k] = kp[k];
+  out->n_corner = cnt[0]; out->n_surf = cnt[1]; out->n_outlier = cnt[2];
+  if ((out->corner && cnt[0] > out->corner_cap) || (out->surf && cnt[1] > out->surf_cap) || (out->outlier && cnt[2] > out->outlier_cap)) { *err = "get_keyframe: buffer too small"; return ALEGO_ERR_CAPACITY; }
+  hipError_t e = hipSuccess;
+  if (out->corner && cnt[0]) e = hipMemcpy(out->corner, L.kf_raw_c + rs * L.kf_cap_c, (size_t)cnt[0] * 16, hipMemcpyDeviceToHost);
+  if (e == hipSuccess && out->surf && cnt[1]) e = hipMemcpy(out->surf, L.kf_raw_s + rs * L.kf_cap_s, (size_t)cnt[1] * 16, hipMemcpyDeviceToHost);
+  if (e == hipSuccess && out->outlier && cnt[2]) e = hipMemcpy(out->outlier, L.kf_raw_o + rs * L.kf_cap_o, (size_t)cnt[2] * 16, hipMemcpyDeviceToHost);
+  if (e != hipSuccess) { *err = std::string("get_keyframe: ") + hipGetErrorString(e); return ALEGO_ERR_HIP; }
+  return 0;
+}
+static int retransform(LmHost* lm, const DevCtx& dfull, int slot, int ring, std::string* err) {
+  DevCtx d = dfull;
+  d.slot0 = slot; d.n_launch = 1;
+  hipStream_t st = stream_of_slot(lm, slot);
+  launch_lm_retransform(d, lm->L, ring, st);
+  lm_kf_changed(lm, d, ring, st);
+  if (hipStreamSynchronize(st) != hipSuccess) { *err = "key-frame transform failed"; return ALEGO_ERR_HIP; }
+  return 0;
+}
+int lm_host_set_keypose(LmHost* lm, const DevCtx& dfull, int slot, int kf_id, const float* pose6, std::string* err) {
+  const LmCtx& L = lm->L;
+  const int nkf = lm_host_keyframe_count(lm, slot);
+  if (nkf < 0) return nkf;
+  if (kf_id < 0 || kf_id >= nkf || kf_id < nkf - L.K) { *err = "set_keypose: key frame not resident"; return ALEGO_ERR_ARG; }
+  const int ring = kf_id % L.K;
+  if (hipMemcpy(L.kf_pose + ((size_t)slot * L.K + ring) * 8, pose6, 6 * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) { *err = "set_keypose: copy failed"; return ALEGO_ERR_HIP; }
+  return retransform(lm, dfull, slot, ring, err);
+}
+int lm_host_reset_window(LmHost* lm, int slot, std::string* err) {
+  // recent_*_keyframes_.clear() (:563-565): the next mapping frame refills the window from the newest key frames (:208-223)
+  const int v[2] = {0, 1};
+  int* li = lm->L.li + (size_t)slot * LI_COUNT;
+  if (hipStreamSynchronize(stream_of_slot(lm, slot)) != hipSuccess || hipMemcpy(li + LI_REC_CNT, &v[0], sizeof(int), hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(li + LI_DIRTY, &v[1], sizeof(int), hipMemcpyHostToDevice) != hipSuccess) { *err = "reset_window failed"; return ALEGO_ERR_HIP; }
+  return 0;
+}
+int lm_host_apply_correction(LmHost* lm, const DevCtx& dfull, int slot, const double* rc12, std::string* err) {
+  double* dev = nullptr;
+  hipStream_t st = stream_of_slot(lm, slot);
+  if (hipMalloc((void**)&dev, 12 * sizeof(double)) != hipSuccess) { *err = "apply_correction: hipMalloc"; return ALEGO_ERR_HIP; }
+  hipError_t e = hipMemcpy(dev, rc12, 12 * sizeof(double), hipMemcpyHostToDevice);
+  if (e == hipSuccess) { launch_lm_apply_correction(dfull, lm->L, slot, dev, st); e = hipStreamSynchronize(st); }
+  (void)hipFree(dev);
+  if (e != hipSuccess) { *err = std::string("apply_correction: ") + hipGetErrorString(e); return ALEGO_ERR_HIP; }
+  return 0;
+}
+int lm_host_add_keyframe(LmHost* lm, const DevCtx& dfull, int slot, const float* pose6, const alego_point* corner, int nc, const alego_point* surf, int ns,
+                         const alego_point* outlier, int no, std::string* err) {
+  const LmCtx& L = lm->L;
+  if (nc < 0 || ns < 0 || no < 0 || (nc && !corner) || (ns && !surf) || (no && !outlier)) { *err = "add_keyframe: null cloud / negative count"; return ALEGO_ERR_ARG; }
+  if (nc > L.kf_cap_c || ns > L.kf_cap_s || no > L.kf_cap_o) { *err = "add_keyframe: cloud exceeds the key-frame capacity"; return ALEGO_ERR_CAPACITY; }
+  const int nkf = lm_host_keyframe_count(lm, slot);
+  if (nkf < 0) return nkf;
+  const int ring = nkf % L.K;
+  const size_t rs = (size_t)slot * L.K + ring;
+  float kp[8] = {pose6[0], pose6[1], pose6[2], pose6[3], pose6[4], pose6[5], 0.f, 0.f};
+  const int cnt[4] = {nc, ns, no, 0};
+  int* li = L.li + (size_t)slot * LI_COUNT;
+  const int nkf1 = nkf + 1, one = 1;
+  hipError_t e = hipMemcpy(L.kf_pose + rs * 8, kp, sizeof(kp), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(L.kf_cnt + rs * 4, cnt, sizeof(cnt), hipMemcpyHostToDevice);
+  if (e == hipSuccess && nc) e = hipMemcpy(L.kf_raw_c + rs * L.kf_cap_c, corner, (size_t)nc * 16, hipMemcpyHostToDevice);
+  if (e == hipSuccess && ns) e = hipMemcpy(L.kf_raw_s + rs * L.kf_cap_s, surf, (size_t)ns * 16, hipMemcpyHostToDevice);
+  if (e == hipSuccess && no) e = hipMemcpy(L.kf_raw_o + rs * L.kf_cap_o, outlier, (size_t)no * 16, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(li + LI_NKF, &nkf1, sizeof(int), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(li + LI_DIRTY, &one, sizeof(int), hipMemcpyHostToDevice);
+  if (e != hipSuccess) { *err = std::string("add_keyframe: ") + hipGetErrorString(e); return ALEGO_ERR_HIP; }
+  return retransform(lm, dfull, slot, ring, err);
 }
 
 int lm_host_debug_get(LmHost* lm, int slot, const char* name, void* out, int cap_bytes, int* count, int* dtype, std::string* err) {
@@ -255,6 +365,16 @@ int lm_host_debug_get(LmHost* lm, int slot, const char* name, void* out, int cap
   else if (s == "lm_surf_total_ds") set(L.cur_total_ds + b * L.total_cap, (size_t)li[LI_NTOTAL_DS] * 4, 0);
   else if (s == "lm_blocks") set(L.blocks + b * L.qcap * 8, (size_t)L.qcap * 8, 1);
   else if (s == "lm_keyposes") set(L.kf_pose + b * L.K * 8, (size_t)L.K * 8, 0);
+  else if (s == "lm_kf_corner_map" || s == "lm_kf_surf_map" || s == "lm_kf_outlier_map") {   // newest key frame, transformed into the map frame
+    const int nkf = li[LI_NKF];
+    if (nkf <= 0) { *count = 0; *dtype = 0; return 0; }
+    const size_t rs = b * L.K + (size_t)((nkf - 1) % L.K);
+    int kc[4];
+    (void)hipMemcpy(kc, L.kf_cnt + rs * 4, sizeof(kc), hipMemcpyDeviceToHost);
+    if (s == "lm_kf_corner_map") set(L.kf_corner + rs * L.kf_cap_c, (size_t)kc[0] * 4, 0);
+    else if (s == "lm_kf_surf_map") set(L.kf_surf + rs * L.kf_cap_s, (size_t)kc[1] * 4, 0);
+    else set(L.kf_outl + rs * L.kf_cap_o, (size_t)kc[2] * 4, 0);
+  }
   else { *err = std::string("debug_get: unknown name ") + name; return ALEGO_ERR_ARG; }
   if ((size_t)cap_bytes < n * esz) { *err = "debug_get: buffer too small"; return ALEGO_ERR_CAPACITY; }
   if (n && hipMemcpy(out, src, n * esz, hipMemcpyDeviceToHost) != hipSuccess) { *err = "debug_get: copy failed"; return ALEGO_ERR_HIP; }

@@ -17,7 +17,9 @@ struct VoxJob {
   int* n_out;           // device count
   const int* enable;    // device flag (nullptr = always); a disabled job keeps its previous output
   float leaf;
-  int cap;              // capacity of in / out (points)
+  int cap;              // capacity of in (points)
+  int out_cap;          // capacity of out: further voxels are dropped and *overflow is raised
+  int* overflow;        // device flag (may be nullptr), set to 1 when the output was truncated
   int off;              // offset of this job's region in the key / pair scratch arrays (filled by vox_create)
 };
 

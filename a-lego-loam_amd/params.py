@@ -22,6 +22,7 @@ class AlegoParams(C.Structure):
         ("lm_outer_iters", _I), ("lm_max_iters", _I),
         ("knn_max_dist", _D), ("line_ratio", _D), ("line_half_len", _D), ("plane_tol", _D),
         ("lm_min_corner", _I), ("lm_min_surf", _I), ("lm_min_map_corner", _I),
+        ("input_is_dense", _I),
     ]
 
     def copy(self):

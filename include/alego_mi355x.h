@@ -161,6 +161,57 @@ int alego_debug_get(alego_handle* h, int slot, const char* name, void* out, int 
 int alego_debug_voxel(alego_handle* h, const alego_point* pts, int n, float leaf, alego_point* out, int cap);
 /* device atan2f / hypotf used by the projection kernel, for the libm-equivalence test */
 int alego_debug_atan2f(alego_handle* h, const float* y, const float* x, float* out, int n);
+/* the device's shared single-precision functions on arrays: mode 0 atan2f(a, b), 1 hypotf(a, b), 2 sinf(a), 3 cosf(a) */
+int alego_debug_math(alego_handle* h, int mode, const float* a, const float* b, float* out, int n);
+/* The four cost functors of include/alego/utility.h:122-349 evaluated on the device exactly as the solvers evaluate them
+ * (csrc/dev_cost.h): type 0 SurfCostFunction, 1 CornerCostFunction, 2 LidarEdgeCostFunction, 3 LidarPlaneCostFunction;
+ * geom13[i] = cp(3), lpj | normal(3), lpl(3), lpm(3), negative_OA_dot_norm; out: res[i], jac6[i][6] */
+int alego_debug_eval_blocks(alego_handle* h, int type, int n, const double* geom13, const double* params6, double* res, double* jac6);
+/* transformToStart (laserOdometry.cpp:728-740) of n points with LaserOdometry params_ = params6, as lo_assoc applies it */
+int alego_debug_transform_to_start(alego_handle* h, const double* params6, const alego_point* pts, int n, alego_point* out);
+/* Run-time switches of kernel variants (parity tests run both variants of a kernel inside one process).  Read once from
+ * the environment at alego_create (ALEGO_CC_FUSED, ALEGO_FE_PICK1, ALEGO_LO_BOX_LDS, ALEGO_MAP_MERGE, ALEGO_IP_FAST); this
+ * call overrides one of them by its environment name.  Not a hot-path call. */
+int alego_debug_set_option(alego_handle* h, const char* name, int value);
+
+/* ---- key-frame pass-through for a host-side pose graph (laserMapping.cpp:491-596) -------------------------------
+ * LaserMapping keeps the recent_keyframe_num newest key frames of every slot on the device: the down-sampled clouds as
+ * saveKeyFramesAndFactor stores them (corner_frames_ / surf_frames_ / outlier_frames_, sensor frame, :553-555) and the
+ * f32 key pose (cloud_keyposes_6d_, :531-537).  A host pose graph (GTSAM in the reference) reads every new key frame
+ * when ALEGO_FLAG_LM_KEYFRAME is returned, and writes corrected poses back after a loop closure. */
+typedef struct alego_keyframe {
+  int32_t id;            /* index in cloud_keyposes_3d_ (0-based); the reference's intensity field is id + 0.1 (:529) */
+  float pose[6];         /* x y z roll pitch yaw (PointXYZIRPYT, utility.h:83-92) */
+  alego_point* corner;   int32_t corner_cap;   int32_t n_corner;   /* laser_corner_ds_  of the frame (may be NULL) */
+  alego_point* surf;     int32_t surf_cap;     int32_t n_surf;     /* laser_surf_ds_ */
+  alego_point* outlier;  int32_t outlier_cap;  int32_t n_outlier;  /* laser_outlier_ds_ */
+} alego_keyframe;
+/* number of key frames saved so far by `slot` (cloud_keyposes_3d_->size()) */
+int alego_lm_keyframe_count(alego_handle* h, int slot);
+/* copy key frame kf_id (-1 = the newest) to the host; only the recent_keyframe_num newest ones are resident
+ * (older ids return ALEGO_ERR_ARG: the host keeps its own copy, as the reference does).  publish() (:586-596) is the
+ * `pose` of every frame. */
+int alego_lm_get_keyframe(alego_handle* h, int slot, int kf_id, alego_keyframe* out);
+/* correctPoses (:569-578): overwrite the key pose of a resident frame; the device re-transforms its clouds.  The local
+ * map is rebuilt at the next mapping frame once alego_lm_reset_window has been called (the reference clears the
+ * recent_* deques at :563-565 and refills them from the newest frames at :208-223). */
+int alego_lm_set_keypose(alego_handle* h, int slot, int kf_id, const float pose6[6]);
+int alego_lm_reset_window(alego_handle* h, int slot);
+/* correctPoses (:579-580): q_map2odom <- R q_map2odom, t_map2odom <- R t_map2odom + c, with the row-major 3x4 [R | c] */
+int alego_lm_apply_correction(alego_handle* h, int slot, const double rc[12]);
+/* push_back a key frame from host data (clouds in the sensor frame + pose): restores a saved session or lets the host
+ * pose graph insert a frame; equivalent to :531-555 with the given pose and clouds */
+int alego_lm_add_keyframe(alego_handle* h, int slot, const float pose6[6], const alego_point* corner, int32_t n_corner,
+                          const alego_point* surf, int32_t n_surf, const alego_point* outlier, int32_t n_outlier);
+
+/* ---- sensor_msgs/PointCloud2 to alego_point: pcl::fromROSMsg<PointXYZI>, imageProjection.cpp:54-55, IP.cpp:109-110 ----
+ * ROS-free mirror of sensor_msgs/PointField + the PointCloud2 layout fields.  Fields are matched by name ("x", "y", "z",
+ * "intensity") and must be FLOAT32 (datatype 7) with count 1, as PCL's field mapper requires; a missing intensity gives 0.
+ * Returns the number of points written (width * height), or ALEGO_ERR_ARG / ALEGO_ERR_CAPACITY. */
+typedef struct alego_pc2_field { const char* name; uint32_t offset; uint8_t datatype; uint32_t count; } alego_pc2_field;
+int alego_pc2_to_points(const uint8_t* data, uint64_t data_len, uint32_t width, uint32_t height, uint32_t point_step,
+                        uint32_t row_step, int is_bigendian, const alego_pc2_field* fields, int n_fields,
+                        alego_point* out, int32_t cap);
 
 #ifdef __cplusplus
 }

@@ -85,6 +85,11 @@ typedef struct alego_params {
   int32_t lm_min_corner;     /* 10              laserMapping.cpp:350 */
   int32_t lm_min_surf;       /* 100             laserMapping.cpp:350 */
   int32_t lm_min_map_corner; /* 10              laserMapping.cpp:350 */
+  /* ---- input message property ---- */
+  int32_t input_is_dense;    /* sensor_msgs/PointCloud2.is_dense of the driver.  0 (default): pcl::removeNaNFromPointCloud
+                                drops non-finite points (imageProjection.cpp:58-59).  1: PCL copies the cloud unfiltered;
+                                non-finite points then still count as first / last point of the orientation block (:62-63,
+                                giving NaN orientations) and are rejected by the row test (:81-85; int(NaN) is INT_MIN on x86-64) */
 } alego_params;
 
 /* Fill `p` with the reference defaults for an n_scan x horizon_scan sensor.
@@ -158,6 +163,7 @@ static inline void alego_default_params(alego_params* p, int n_scan, int horizon
   p->lm_min_corner = 10;
   p->lm_min_surf = 100;
   p->lm_min_map_corner = 10;
+  p->input_is_dense = 0;
 }
 
 /* PointXYZI as it crosses the boundary: the first 16 bytes-worth of the PCL

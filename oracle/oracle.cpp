@@ -131,12 +131,13 @@ struct ImageProjection {
   // pcCB, imageProjection.cpp:49-208 (IP.cpp:106-304 for the near filter / RFANS table)
   void process(const Pt* in, int n_in) {
     const int H = P.horizon_scan, NS = P.n_scan;
-    // a1: pcl::removeNaNFromPointCloud :58-59 (drop non-finite), IP.cpp:77-104,117
+    // a1: pcl::removeNaNFromPointCloud :58-59: filters non-finite points only when the message says is_dense == false,
+    // otherwise it is a plain copy and the row test below rejects them; IP.cpp:77-104,117
     std::vector<Pt> cloud;
     cloud.reserve(n_in);
     for (int i = 0; i < n_in; ++i) {
       const Pt& p = in[i];
-      if (!std::isfinite(p.x) || !std::isfinite(p.y) || !std::isfinite(p.z)) continue;
+      if (!P.input_is_dense && (!std::isfinite(p.x) || !std::isfinite(p.y) || !std::isfinite(p.z))) continue;
       if (P.near_filter) {
         float th = (float)P.near_thres;
         if (p.x * p.x + p.y * p.y + p.z * p.z < th * th) continue;  // IP.cpp:91
@@ -156,6 +157,10 @@ struct ImageProjection {
     // a3: projection :76-104
     for (int i = 0; i < cloud_size; ++i) {
       Pt p = cloud[i];
+      // is_dense == true with a non-finite point: NaN angles; `int(NaN)` is INT_MIN on x86-64 (cvttsd2si), so :81-85 / :93-97
+      // reject it (an infinite coordinate gives a finite angle but an infinite range: the reference would keep such a cell;
+      // treated like NaN here — no driver emits it)
+      if (!std::isfinite(p.x) || !std::isfinite(p.y) || !std::isfinite(p.z)) continue;
       double vertical_ang = rad2angle((double)omath::o_atan2f(p.z, omath::o_hypotf(p.x, p.y)));
       int row_id;
       if (P.laser_type == ALEGO_LASER_UNIFORM) {
@@ -1013,11 +1018,11 @@ struct LaserMapping {
 
   // transformPointCloud, laserMapping.h:164-177 (f32 4x4, pcl::transformPointCloud PCL 1.8 dense path)
   static void transform_cloud(const std::vector<Pt>& in, const KeyPose& kp, std::vector<Pt>& out) {
-    // Eigen evaluates sinf/cosf here; both this oracle and the HIP path evaluate in double and round
-    // once (DESIGN.md "deviations"): device and host libm then agree except w.p. ~2^-29 per call.
+    // Eigen's Quaternionf(AngleAxisf) evaluates std::cos / std::sin on the float half angle: glibc's cosf / sinf,
+    // restated in oracle_math.h (pinned bit for bit against this host's libm) and shared with the HIP path.
     auto qaxis = [](float angle, int axis, float q[4]) {
-      float ha = 0.5f * angle, s = (float)std::sin((double)ha);
-      q[0] = (float)std::cos((double)ha); q[1] = q[2] = q[3] = 0.f; q[1 + axis] = s;
+      float ha = 0.5f * angle, s = omath::o_sinf(ha);
+      q[0] = omath::o_cosf(ha); q[1] = q[2] = q[3] = 0.f; q[1 + axis] = s;
     };
     auto qmul = [](const float a[4], const float b[4], float o[4]) {
       o[0] = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
@@ -1346,6 +1351,44 @@ int oracle_process_scan(void* h, const alego_point* pts, int n, int stages) {
 void oracle_set_lo_params(void* h, const double* p6) { std::memcpy(((Ctx*)h)->lo.params, p6, 48); }
 void oracle_set_lm_params(void* h, const double* p6) { std::memcpy(((Ctx*)h)->lm.params, p6, 48); }
 
+// ---- host pose-graph pass-through (laserMapping.cpp:561-584 correctPoses; the GTSAM side stays outside) ----
+// correctPoses :569-578 for one frame: overwrite the stored key pose (f32 fields of PointXYZIRPYT)
+void oracle_lm_set_keypose(void* h, int id, const float* pose6) {
+  LaserMapping& lm = ((Ctx*)h)->lm;
+  if (id < 0 || id >= (int)lm.keyposes.size()) return;
+  lm.keyposes[id] = KeyPose{pose6[0], pose6[1], pose6[2], pose6[3], pose6[4], pose6[5]};
+}
+// correctPoses :563-565: recent_*_keyframes_.clear()
+void oracle_lm_reset_window(void* h) {
+  LaserMapping& lm = ((Ctx*)h)->lm;
+  lm.recent_corner.clear(); lm.recent_surf.clear(); lm.recent_outlier.clear();
+}
+// correctPoses :579-580 with correction_ = [R | c] (row-major 3x4)
+void oracle_lm_apply_correction(void* h, const double* rc) {
+  LaserMapping& lm = ((Ctx*)h)->lm;
+  double R[9], M[9], t[3];
+  quat_to_mat(lm.q_map2odom, R);
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) M[i * 3 + j] = rc[i * 4 + 0] * R[0 * 3 + j] + rc[i * 4 + 1] * R[1 * 3 + j] + rc[i * 4 + 2] * R[2 * 3 + j];
+  for (int i = 0; i < 3; ++i) t[i] = rc[i * 4 + 0] * lm.t_map2odom[0] + rc[i * 4 + 1] * lm.t_map2odom[1] + rc[i * 4 + 2] * lm.t_map2odom[2] + rc[i * 4 + 3];
+  lm.q_map2odom = mat_to_quat(M);
+  for (int i = 0; i < 3; ++i) lm.t_map2odom[i] = t[i];
+}
+// saveKeyFramesAndFactor :531-555 with a host-provided pose and clouds
+void oracle_lm_add_keyframe(void* h, const float* pose6, const alego_point* c, int nc, const alego_point* s, int ns, const alego_point* o, int no) {
+  LaserMapping& lm = ((Ctx*)h)->lm;
+  lm.keyposes.push_back(KeyPose{pose6[0], pose6[1], pose6[2], pose6[3], pose6[4], pose6[5]});
+  lm.corner_frames.emplace_back(c, c + nc); lm.surf_frames.emplace_back(s, s + ns); lm.outlier_frames.emplace_back(o, o + no);
+}
+// key frame `id` as stored by saveKeyFramesAndFactor: kind 0 corner_frames_, 1 surf_frames_, 2 outlier_frames_
+int oracle_lm_keyframe(void* h, int id, int kind, const void** ptr, int* n_points) {
+  LaserMapping& lm = ((Ctx*)h)->lm;
+  if (id < 0 || id >= (int)lm.keyposes.size() || kind < 0 || kind > 2) return -1;
+  const std::vector<Pt>& v = kind == 0 ? lm.corner_frames[id] : (kind == 1 ? lm.surf_frames[id] : lm.outlier_frames[id]);
+  *ptr = v.data(); *n_points = (int)v.size();
+  return 0;
+}
+
 // Generic read-only access to the last scan's intermediates.  count = number of scalars.
 int oracle_get(void* h, const char* name, const void** ptr, int* count, int* dtype) {
   Ctx* c = (Ctx*)h;
@@ -1432,6 +1475,10 @@ void oracle_atan2f_array(const float* y, const float* x, float* out, int n) { fo
 void oracle_hypotf_array(const float* x, const float* y, float* out, int n) { for (int i = 0; i < n; ++i) out[i] = omath::o_hypotf(x[i], y[i]); }
 void oracle_libm_atan2f_array(const float* y, const float* x, float* out, int n) { for (int i = 0; i < n; ++i) out[i] = std::atan2(y[i], x[i]); }
 void oracle_libm_hypotf_array(const float* x, const float* y, float* out, int n) { for (int i = 0; i < n; ++i) out[i] = std::hypot(x[i], y[i]); }
+// mode 0: restated sinf, 1: restated cosf, 2: this host's libm sinf, 3: libm cosf
+void oracle_sincosf_array(const float* x, float* out, int n, int mode) {
+  for (int i = 0; i < n; ++i) out[i] = mode == 0 ? omath::o_sinf(x[i]) : mode == 1 ? omath::o_cosf(x[i]) : mode == 2 ? std::sin(x[i]) : std::cos(x[i]);
+}
 
 int oracle_voxel_grid(const alego_point* in, int n, float leaf, int sort_mode, alego_point* out, int cap) {
   std::vector<Pt> v(in, in + n), o;
@@ -1475,5 +1522,18 @@ int oracle_knn(const alego_point* cloud, int n, const alego_point* q, int nq, in
 }
 
 void oracle_eig3(const double* A9, double* lam3, double* V9) { eig3(A9, lam3, V9); }
+
+// transformToStart (laserOdometry.cpp:728-740) with params_ = params6
+void oracle_transform_to_start(const double* params6, const alego_point* in, int n, alego_point* out) {
+  LaserOdometry lo;
+  std::memcpy(lo.params, params6, 48);
+  for (int i = 0; i < n; ++i) lo.transform_to_start(in[i], out[i]);
+}
+// transformPointCloud (laserMapping.h:164-177) by an f32 key pose (x y z roll pitch yaw)
+void oracle_transform_cloud(const float* pose6, const alego_point* in, int n, alego_point* out) {
+  std::vector<Pt> v(in, in + n), o;
+  LaserMapping::transform_cloud(v, KeyPose{pose6[0], pose6[1], pose6[2], pose6[3], pose6[4], pose6[5]}, o);
+  if (n) std::memcpy(out, o.data(), sizeof(Pt) * (size_t)n);
+}
 
 }  // extern "C"

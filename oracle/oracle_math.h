@@ -93,5 +93,76 @@ inline float o_atan2f(float y, float x) {
 // glibc 2.35 hypotf evaluates in double and rounds once (validated).
 inline float o_hypotf(float x, float y) { return (float)std::sqrt((double)x * (double)x + (double)y * (double)y); }
 
+// ---------------------------------------------------------------------------
+// sinf / cosf as Eigen's AngleAxisf -> Quaternionf conversion calls them in
+// transformPointCloud (include/alego/laserMapping.h:166-173: std::sin / std::cos on
+// float half angles).  glibc >= 2.28 (sysdeps/ieee754/flt-32/s_sinf.c, s_cosf.c,
+// sincosf.h) evaluates an fp64 minimax polynomial after a fast quadrant reduction and
+// rounds once; it is NOT the correctly rounded value ((float)sin((double)x) differs on
+// 1.3 % of the inputs in [-pi/2, pi/2], measured here).  Restated below for |x| < 120
+// (every half angle of a key pose lies in [-pi/2, pi/2]); the coefficient table was read
+// out of this container's libm.so.6 (.rodata, __sincosf_table) and
+// tests/test_oracle.py::test_sinf_cosf_equal_this_hosts_libm pins the result bit for bit.
+// Outside that range (never reached by a key pose) the correctly rounded value is used.
+// ---------------------------------------------------------------------------
+struct SinCosTab { double sign[4], hpi_inv, hpi, c0, c1, c2, c3, c4, s1, s2, s3; };
+inline const SinCosTab& sincos_tab(int neg) {
+  static const SinCosTab T[2] = {
+      {{1.0, -1.0, -1.0, 1.0}, 0x1.45F306DC9C883p+23, 0x1.921FB54442D18p0,
+       0x1p0, -0x1.ffffffd0c621cp-2, 0x1.55553e1068f19p-5, -0x1.6c087e89a359dp-10, 0x1.99343027bf8c3p-16,
+       -0x1.555545995a603p-3, 0x1.1107605230bc4p-7, -0x1.994eb3774cf24p-13},
+      {{1.0, -1.0, -1.0, 1.0}, 0x1.45F306DC9C883p+23, 0x1.921FB54442D18p0,
+       -0x1p0, 0x1.ffffffd0c621cp-2, -0x1.55553e1068f19p-5, 0x1.6c087e89a359dp-10, -0x1.99343027bf8c3p-16,
+       -0x1.555545995a603p-3, 0x1.1107605230bc4p-7, -0x1.994eb3774cf24p-13}};
+  return T[neg];
+}
+inline uint32_t abstop12(float x) { return ((uint32_t)f2i(x) >> 20) & 0x7ff; }
+inline float sincos_poly(double x, double x2, const SinCosTab& p, int n) {
+  if ((n & 1) == 0) {
+    const double x3 = x * x2, s1 = p.s2 + x2 * p.s3, x7 = x3 * x2, s = x + x3 * p.s1;
+    return (float)(s + x7 * s1);
+  }
+  const double x4 = x2 * x2, c2 = p.c3 + x2 * p.c4, c1 = p.c0 + x2 * p.c1, x6 = x4 * x2, c = c1 + x4 * p.c2;
+  return (float)(c + x6 * c2);
+}
+inline double sincos_reduce_fast(double x, const SinCosTab& p, int* np) {
+  const double r = x * p.hpi_inv;                     // hpi_inv is prescaled by 2^24: the quadrant ends up in bits 24..31
+  const int n = ((int32_t)r + 0x800000) >> 24;
+  *np = n;
+  return x - n * p.hpi;
+}
+inline float o_sinf(float y) {
+  double x = y;
+  const SinCosTab* p = &sincos_tab(0);
+  if (abstop12(y) < abstop12(0x1.921FB6p-1f)) {
+    if (abstop12(y) < abstop12(0x1p-12f)) return y;
+    return sincos_poly(x, x * x, *p, 0);
+  }
+  if (abstop12(y) < abstop12(120.0f)) {
+    int n;
+    x = sincos_reduce_fast(x, *p, &n);
+    const double s = p->sign[n & 3];
+    if (n & 2) p = &sincos_tab(1);
+    return sincos_poly(x * s, x * x, *p, n);
+  }
+  return (float)std::sin((double)y);
+}
+inline float o_cosf(float y) {
+  double x = y;
+  const SinCosTab* p = &sincos_tab(0);
+  if (abstop12(y) < abstop12(0x1.921FB6p-1f)) {
+    if (abstop12(y) < abstop12(0x1p-12f)) return 1.0f;
+    return sincos_poly(x, x * x, *p, 1);
+  }
+  if (abstop12(y) < abstop12(120.0f)) {
+    int n;
+    x = sincos_reduce_fast(x, *p, &n);
+    const double s = p->sign[(n + 1) & 3];
+    if ((n + 1) & 2) p = &sincos_tab(1);
+    return sincos_poly(x * s, x * x, *p, n ^ 1);
+  }
+  return (float)std::cos((double)y);
+}
+
 }  // namespace omath
 #endif

@@ -42,6 +42,15 @@ def lib():
         L.oracle_eig3.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         for f in ("oracle_atan2f_array", "oracle_hypotf_array", "oracle_libm_atan2f_array", "oracle_libm_hypotf_array"):
             getattr(L, f).argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.oracle_lm_set_keypose.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.oracle_lm_reset_window.argtypes = [C.c_void_p]
+        L.oracle_lm_apply_correction.argtypes = [C.c_void_p, C.c_void_p]
+        L.oracle_lm_add_keyframe.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        L.oracle_lm_keyframe.restype = C.c_int
+        L.oracle_lm_keyframe.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]
+        L.oracle_transform_to_start.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.oracle_transform_cloud.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.oracle_sincosf_array.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
         _lib = L
     return _lib
 
@@ -91,6 +100,37 @@ class Oracle:
     def set_lm_params(self, p6):
         a = np.ascontiguousarray(p6, dtype=np.float64)
         lib().oracle_set_lm_params(self._h, a.ctypes.data)
+
+    # ---- host pose-graph pass-through (correctPoses, laserMapping.cpp:561-584) ----
+    def lm_set_keypose(self, kf_id, pose6):
+        a = np.ascontiguousarray(pose6, dtype=np.float32)
+        lib().oracle_lm_set_keypose(self._h, kf_id, a.ctypes.data)
+
+    def lm_reset_window(self):
+        lib().oracle_lm_reset_window(self._h)
+
+    def lm_apply_correction(self, rc12):
+        a = np.ascontiguousarray(rc12, dtype=np.float64).reshape(12)
+        lib().oracle_lm_apply_correction(self._h, a.ctypes.data)
+
+    def lm_add_keyframe(self, pose6, corner, surf, outlier):
+        a = np.ascontiguousarray(pose6, dtype=np.float32)
+        c, s, o = self._pts(corner), self._pts(surf), self._pts(outlier)
+        lib().oracle_lm_add_keyframe(self._h, a.ctypes.data, c.ctypes.data, c.shape[0], s.ctypes.data, s.shape[0], o.ctypes.data, o.shape[0])
+
+    def lm_keyframe(self, kf_id):
+        """(corner, surf, outlier) clouds of key frame kf_id as saveKeyFramesAndFactor stored them."""
+        out = []
+        for kind in range(3):
+            ptr, n = C.c_void_p(), C.c_int()
+            if lib().oracle_lm_keyframe(self._h, kf_id, kind, C.byref(ptr), C.byref(n)) != 0:
+                raise KeyError(kf_id)
+            if n.value == 0 or not ptr.value:
+                out.append(np.zeros((0, 4), np.float32))
+            else:
+                buf = (C.c_char * (n.value * 16)).from_address(ptr.value)
+                out.append(np.frombuffer(buf, dtype=np.float32, count=n.value * 4).copy().reshape(-1, 4))
+        return out
 
     def get(self, name, cloud=None):
         ptr, cnt, dt = C.c_void_p(), C.c_int(), C.c_int()
@@ -146,3 +186,27 @@ def knn(cloud, queries, k):
     dist = np.empty((q.shape[0], k), dtype=np.float32)
     lib().oracle_knn(c.ctypes.data, c.shape[0], q.ctypes.data, q.shape[0], k, idx.ctypes.data, dist.ctypes.data)
     return idx, dist
+
+
+def transform_to_start(params6, pts):
+    p = np.ascontiguousarray(params6, dtype=np.float64)
+    a = np.ascontiguousarray(pts, dtype=np.float32)
+    out = np.empty_like(a)
+    lib().oracle_transform_to_start(p.ctypes.data, a.ctypes.data, a.shape[0], out.ctypes.data)
+    return out
+
+
+def transform_cloud(pose6, pts):
+    p = np.ascontiguousarray(pose6, dtype=np.float32)
+    a = np.ascontiguousarray(pts, dtype=np.float32)
+    out = np.empty_like(a)
+    lib().oracle_transform_cloud(p.ctypes.data, a.ctypes.data, a.shape[0], out.ctypes.data)
+    return out
+
+
+def sincosf(x, mode):
+    """mode 0: restated sinf, 1: restated cosf, 2 / 3: this host's libm"""
+    a = np.ascontiguousarray(x, dtype=np.float32)
+    out = np.empty_like(a)
+    lib().oracle_sincosf_array(a.ctypes.data, out.ctypes.data, a.size, mode)
+    return out

@@ -515,3 +515,284 @@ def test_degenerate_scans_do_not_break_the_loop(params_a):
         want = o.get("map_pose")
         assert np.abs(mp["t"] - want[:3]).max() < POSE_TOL, (k, mp["t"], want[:3])
     h.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# round 2: the steady state of the 50-key-frame window, the iteration budget of BASELINE.json's config 2, the
+# 200-key-frame window of config 5, the cost functors and small device functions on their own, the host pose-graph
+# pass-through and the is_dense / capacity edge cases
+# ---------------------------------------------------------------------------------------------------------------------
+def _index_outputs_compare(h, o, tag):
+    m = o.get("seg_cloud").shape[0]
+    for name in ("seg_col", "seg_ground", "sharp_idx", "less_sharp_idx", "flat_idx"):
+        assert_bit_equal(h.debug_get(name), o.get(name), f"{tag} {name}")
+    assert_bit_equal(h.debug_get("point_label")[5:m - 5], o.get("point_label")[5:m - 5], f"{tag} cloud_label_")
+    for name in ("seg_cloud", "outlier", "less_sharp", "less_flat"):
+        assert_bit_equal(h.debug_get(name), o.get(name), f"{tag} {name}")
+    oc = o.get("lo_surf_corr").reshape(-1, 4)
+    gc = h.debug_get("lo_surf_corr").reshape(-1, 4)
+    assert_bit_equal(gc[gc[:, 1] >= 0], oc, f"{tag} surf correspondences")
+    oc = o.get("lo_corner_corr").reshape(-1, 3)
+    gc = h.debug_get("lo_corner_corr").reshape(-1, 4)
+    assert_bit_equal(gc[gc[:, 1] >= 0][:, :3], oc, f"{tag} corner correspondences")
+
+
+def test_steady_state_620_scans_teacher_forced(params_a):
+    """BASELINE config 3 at reference parameters past the point where the 50-key-frame window fills (scan ~500), takes the
+    duplicate push of laserMapping.cpp:227-236 and starts to slide: EVERY scan's index outputs, filtered maps, accepted
+    correspondences, solver summaries and poses against the oracle (teacher forcing as everywhere: each scan starts from the
+    oracle's LO / LM params_)."""
+    p = params_a
+    h, o = binding.Handle(p), O.Oracle(p)
+    worst_t = worst_r = 0.0
+    for k in range(620):
+        pts = synth.scan(p, k)
+        h.set_lo_params(o.get("lo_params"))
+        h.set_lm_params(o.get("lm_params"))
+        o.process_scan(pts)
+        flags, odom, mp = h.scan_process(pts, stages=7)
+        if k == 0:
+            continue
+        _index_outputs_compare(h, o, f"scan {k}")
+        _lm_compare(h, o, k, f"scan {k}")
+        want = o.get("map_pose")
+        worst_t = max(worst_t, np.abs(mp["t"] - want[:3]).max())
+        worst_r = max(worst_r, quat_angle(mp["q"], want[3:]))
+        assert worst_t < POSE_TOL and worst_r < POSE_TOL, (k, worst_t, worst_r)
+    nkf = int(o.get("lm_info")[11])
+    print(f"620 scans teacher-forced: {nkf} key frames, max |dt| {worst_t:.3e} m, max angle {worst_r:.3e} rad")
+    assert nkf > p.recent_keyframe_num + 5, "the window has to fill, duplicate and slide inside the test"
+    h.close()
+
+
+def test_config2_readme_iteration_budget(params_a):
+    """BASELINE.json config 2: the LaserOdometry two-step with the README's budget (surf 5, corner 10 iterations,
+    README.md:54) instead of the 5 / 5 of the code at HEAD (laserOdometry.cpp:415,489)."""
+    p = params_a.copy()
+    p.lo_iters_surf, p.lo_iters_corner = 5, 10
+    h, o = binding.Handle(p), O.Oracle(p)
+    iters = []
+    for k in range(12):
+        pts = synth.scan(p, k)
+        seg = _ip_compare(h, o, pts, f"scan {k}")
+        h.set_lo_params(o.get("lo_params"))
+        o.lo()
+        flags, feat, odom = h.lo_process(seg)
+        _fe_compare(h, o, feat, f"scan {k}")
+        if k == 0:
+            continue
+        np.testing.assert_allclose(h.debug_get("lo_state")[18:24], o.get("lo_params_after_surf"), rtol=0, atol=1e-7)
+        np.testing.assert_allclose(odom["params"], o.get("lo_params"), rtol=0, atol=1e-7)
+        info = o.get("lo_solve_info")
+        sc = h.debug_get("scal")
+        assert (sc[10] & 0xFF, (sc[10] >> 8) & 0xFF, sc[10] >> 16) == tuple(info[0:3]), "surf solve summary"
+        assert (sc[11] & 0xFF, (sc[11] >> 8) & 0xFF, sc[11] >> 16) == tuple(info[3:6]), "corner solve summary"
+        iters.append(int(info[3]))
+        want = o.get("odom_pose")
+        assert np.abs(odom["t"] - want[:3]).max() < POSE_TOL and quat_angle(odom["q"], want[3:]) < POSE_TOL
+    assert max(iters) > 5, f"the corner solve never used more than 5 iterations ({iters}): the (5, 10) budget is not exercised"
+    h.close()
+
+
+def test_config5_geometry_200_keyframe_window():
+    """BASELINE.json config 5's shape: 64 x 2048 with recent_keyframe_num = 200.  min_keyframe_dist is lowered so that every
+    mapping frame saves a key frame and the 200-frame window fills, takes its duplicate and slides inside the test."""
+    p = synth.default_params(64, 2048)
+    p.recent_keyframe_num = 200
+    p.min_keyframe_dist = 0.0004
+    h, o = binding.Handle(p), O.Oracle(p)
+    for k in range(430):
+        pts = synth.scan(p, k)
+        h.set_lo_params(o.get("lo_params"))
+        h.set_lm_params(o.get("lm_params"))
+        o.process_scan(pts)
+        flags, odom, mp = h.scan_process(pts, stages=7)
+        if k == 0:
+            continue
+        if k % 16 == 1 or k > 400:
+            _index_outputs_compare(h, o, f"64x2048 scan {k}")
+        _lm_compare(h, o, k, f"64x2048/K=200 scan {k}")
+        want = o.get("map_pose")
+        assert np.abs(mp["t"] - want[:3]).max() < POSE_TOL and quat_angle(mp["q"], want[3:]) < POSE_TOL, k
+    assert o.get("lm_info")[11] > 205
+    h.close()
+
+
+def _ulp_diff(a, b):
+    """distance in units in the last place between two float64 arrays (same sign assumed where it matters)"""
+    ia, ib = np.ascontiguousarray(a, np.float64).view(np.int64), np.ascontiguousarray(b, np.float64).view(np.int64)
+    ia = np.where(ia < 0, np.int64(-2 ** 63) - ia, ia)
+    ib = np.where(ib < 0, np.int64(-2 ** 63) - ib, ib)
+    return np.abs(ia - ib)
+
+
+@pytest.mark.parametrize("btype", [0, 1, 2, 3])
+def test_cost_functors_device_vs_oracle(params_a, btype):
+    """The four Evaluate() bodies of include/alego/utility.h:122-349 as the device solvers run them (csrc/dev_cost.h),
+    against oracle_eval_block: residual and all six Jacobian columns, on geometry of the size the pipeline produces and at
+    poses with non-zero roll / pitch (the LM functors' pitch column carries the reference's dy_dp typo on both sides).
+    The only operations that may differ between device and host are the nine sin / cos of the pose (ocml vs glibc, both
+    < 1 ulp): the comparison allows 64 ulp of the largest term of a column, and demands exact zeros where the reference has them."""
+    h = binding.Handle(params_a)
+    rng = np.random.default_rng(100 + btype)
+    n = 4096
+    for params in ([0.11, -0.07, 0.03, 0.021, -0.017, 0.043], [-3.4, 12.8, 0.6, -0.05, 0.08, 2.7], [0, 0, 0, 0, 0, 0]):
+        g = np.zeros((n, 13))
+        g[:, 0:3] = rng.normal(size=(n, 3)) * [15, 15, 2]
+        g[:, 3:6] = g[:, 0:3] + rng.normal(size=(n, 3)) * 0.4
+        g[:, 6:9] = g[:, 3:6] + rng.normal(size=(n, 3)) * 0.8
+        g[:, 9:12] = g[:, 3:6] + rng.normal(size=(n, 3)) * 0.8
+        if btype == 3:
+            nrm = rng.normal(size=(n, 3))
+            g[:, 3:6] = nrm / np.linalg.norm(nrm, axis=1, keepdims=True)
+            g[:, 6:12] = 0
+            g[:, 12] = rng.normal(size=n)
+        r_dev, J_dev = h.eval_blocks(btype, g, params)
+        r_ref, J_ref = np.empty(n), np.empty((n, 6))
+        for i in range(n):
+            r_ref[i], J_ref[i] = O.eval_block(btype, g[i], np.array(params, np.float64))
+        scale = np.maximum(np.abs(J_ref).max(axis=1, keepdims=True), 1.0) * np.maximum(np.abs(g[:, 0:3]).max(axis=1, keepdims=True), 1.0)
+        assert np.all(np.abs(r_dev - r_ref) <= 64 * np.spacing(np.maximum(np.abs(r_ref), 1.0))), f"type {btype} residual"
+        assert np.all(np.abs(J_dev - J_ref) <= 64 * np.spacing(scale)), f"type {btype} Jacobian: max diff {np.abs(J_dev - J_ref).max()}"
+        assert np.array_equal(J_dev == 0, J_ref == 0), f"type {btype}: structural zeros of the Jacobian differ"
+        if not any(params):  # all trig terms exact: bit-level agreement up to the evaluation order of sqrt / division
+            assert _ulp_diff(r_dev, r_ref).max() <= 2 and _ulp_diff(J_dev, J_ref).max() <= 4, (btype, _ulp_diff(J_dev, J_ref).max())
+    h.close()
+
+
+def test_transform_to_start_device_vs_oracle(params_a):
+    """a11: transformToStart (laserOdometry.cpp:728-740) as lo_assoc applies it (cached rotation matrix) vs the oracle: the
+    f32 results agree bit for bit except where a 1-ulp difference of an fp64 sin / cos lands on an f32 rounding boundary."""
+    h = binding.Handle(params_a)
+    rng = np.random.default_rng(5)
+    pts = (rng.normal(size=(200000, 4)) * [20, 20, 3, 1]).astype(np.float32)
+    worst = 0
+    for params in ([0.1, -0.02, 0.003, 0.0, 0.0, 0.0175], [0.31, 0.12, -0.05, 0.01, -0.02, -0.4], [0, 0, 0, 0, 0, 0]):
+        got, want = h.transform_to_start(params, pts), O.transform_to_start(params, pts)
+        bad = (got.view(np.uint32) != want.view(np.uint32)).sum()
+        worst = max(worst, bad)
+        assert np.abs(got - want).max() <= 4e-6, "more than one f32 ulp at 20 m"
+    assert worst <= 40, f"{worst} of 800000 coordinates differ in the last bit"
+    h.close()
+
+
+def test_device_sinf_cosf_and_keypose_transform(params_a):
+    """transformPointCloud's f32 matrix (laserMapping.h:164-177) needs glibc's sinf / cosf, not the correctly rounded values:
+    the device functions against the oracle's restatement (itself pinned to this host's libm in tests/test_oracle.py) bit
+    for bit, and the transformed key-frame clouds of lm_store_kf against the oracle's transform_cloud."""
+    h = binding.Handle(params_a)
+    rng = np.random.default_rng(23)
+    x = np.concatenate([rng.uniform(-3.2, 3.2, 1 << 20), rng.uniform(-2e-3, 2e-3, 1 << 16), [0.0, -0.0, np.pi / 4, np.pi / 2, -np.pi / 2]]).astype(np.float32)
+    assert_bit_equal(h.math(2, x), O.sincosf(x, 0), "device sinf")
+    assert_bit_equal(h.math(3, x), O.sincosf(x, 1), "device cosf")
+    assert_bit_equal(h.math(2, x), O.sincosf(x, 2), "device sinf vs this host's libm")
+    # a key frame pushed from the host is transformed by the device exactly as transformPointCloud does
+    cloud = (rng.normal(size=(1500, 4)) * [20, 20, 2, 1]).astype(np.float32)
+    for pose in ([1.5, -2.25, 0.125, 0.01, -0.02, 0.7], [-12.0, 40.5, 1.0, -0.003, 0.004, -2.9], [0, 0, 0, 0, 0, 3.1415927]):
+        pose = np.array(pose, np.float32)
+        h.lm_add_keyframe(pose, cloud[:300], cloud[300:1200], cloud[1200:])
+        nkf = h.lm_keyframe_count()
+        kf = h.lm_get_keyframe(-1)
+        assert kf["id"] == nkf - 1
+        assert_bit_equal(kf["pose"], pose, "key pose read back")
+        assert_bit_equal(kf["surf"], cloud[300:1200], "raw key-frame cloud read back")
+        got = h.debug_get("lm_kf_surf_map", cap_bytes=1 << 22).reshape(-1, 4)
+        assert_bit_equal(got[:900], O.transform_cloud(pose, cloud[300:1200]), "transformed key-frame cloud")
+    h.close()
+
+
+def test_keyframe_pass_through_and_pose_correction(params_a):
+    """alego_lm_get_keyframe / set_keypose / reset_window / apply_correction: what a host pose graph does around
+    saveKeyFramesAndFactor and correctPoses (laserMapping.cpp:491-584).  Every saved key frame is read back and compared with
+    the oracle's corner_frames_ / surf_frames_ / outlier_frames_ and key pose; after 40 scans all key poses are rewritten
+    (a rigid 'loop closure' correction), the window is cleared and map->odom corrected on both sides, and the loop goes on:
+    the re-assembled maps, correspondences and poses must keep matching."""
+    p = params_a.copy()
+    p.recent_keyframe_num = 6
+    p.min_keyframe_dist = 0.09
+    h, o = binding.Handle(p), O.Oracle(p)
+    seen = 0
+    for k in range(64):
+        pts = synth.scan(p, k)
+        h.set_lo_params(o.get("lo_params"))
+        h.set_lm_params(o.get("lm_params"))
+        o.process_scan(pts)
+        flags, odom, mp = h.scan_process(pts, stages=7)
+        if k == 0:
+            continue
+        _lm_compare(h, o, k, f"scan {k}")
+        if flags & binding.FLAG_LM_KEYFRAME:
+            kf = h.lm_get_keyframe(-1)
+            assert kf["id"] == seen and h.lm_keyframe_count() == seen + 1
+            oc, os_, oo = o.lm_keyframe(seen)
+            assert_bit_equal(kf["corner"], oc, f"key frame {seen} corner cloud")
+            assert_bit_equal(kf["surf"], os_, f"key frame {seen} surf cloud")
+            assert_bit_equal(kf["outlier"], oo, f"key frame {seen} outlier cloud")
+            assert_bit_equal(kf["pose"], o.get("lm_keyposes").reshape(-1, 6)[seen], f"key frame {seen} pose")
+            seen += 1
+        if k == 40:   # "loop closure": shift + rotate every resident key pose, clear the window, correct map -> odom
+            nkf = h.lm_keyframe_count()
+            poses = o.get("lm_keyposes").reshape(-1, 6).copy()
+            c, s = np.cos(0.02), np.sin(0.02)
+            rc = np.array([[c, -s, 0, 0.15], [s, c, 0, -0.1], [0, 0, 1, 0.02]])
+            for i in range(nkf):
+                q = poses[i].astype(np.float64)
+                q[:3] = rc[:, :3] @ q[:3] + rc[:, 3]
+                q[5] += 0.02
+                q32 = q.astype(np.float32)
+                o.lm_set_keypose(i, q32)
+                if i >= nkf - p.recent_keyframe_num:
+                    h.lm_set_keypose(i, q32)
+            with pytest.raises(binding.AlegoError):
+                h.lm_set_keypose(nkf - p.recent_keyframe_num - 1, poses[0])   # not resident any more
+            o.lm_reset_window(); h.lm_reset_window()
+            o.lm_apply_correction(rc); h.lm_apply_correction(rc)
+            np.testing.assert_allclose(h.debug_get("lm_state")[6:13], o.get("lm_map2odom"), rtol=0, atol=1e-12)
+        want = o.get("map_pose")
+        assert np.abs(mp["t"] - want[:3]).max() < POSE_TOL and quat_angle(mp["q"], want[3:]) < POSE_TOL, k
+    assert seen >= 12
+    h.close()
+
+
+def test_is_dense_messages_keep_nan_points(params_a):
+    """pcl::removeNaNFromPointCloud is a plain copy for is_dense == true (SURVEY C.11): NaN returns then stay in the cloud, count
+    as first / last point of the orientation block and are rejected by the row test."""
+    p = params_a.copy()
+    p.input_is_dense = 1
+    h, o = binding.Handle(p), O.Oracle(p)
+    pts = synth.scan(p, 2, flags=2)          # NaN returns in the middle of the scan
+    assert np.isnan(pts).any()
+    _ip_compare(h, o, pts, "is_dense with NaN returns inside")
+    pts2 = pts.copy()
+    pts2[0, :3] = np.nan                      # first point NaN: the orientation fields become NaN on both sides
+    o.ip(pts2)
+    seg = h.ip_process(pts2, want_labels=True)
+    assert np.isnan(seg["orientation"]).all() and np.isnan(o.get("orientation")).all()
+    assert_bit_equal(seg["label_image"], o.get("label_img"), "labels with a NaN first point")
+    assert_bit_equal(seg["seg"], o.get("seg_cloud"), "segmented cloud with a NaN first point")
+    h.close()
+
+
+def test_lm_capacity_overflow_is_reported_not_written_past(params_a):
+    """alego_lm_process accepts up to n_scan * horizon_scan surf / outlier points, the per-key-frame buffers hold half / a
+    quarter of that: a sparse cloud whose 0.8 m / 1.0 m filter keeps more than that must be truncated and reported
+    (ALEGO_ERR_CAPACITY) by the call that caused it, and the handle must keep working."""
+    p = params_a
+    h = binding.Handle(p)
+    rng = np.random.default_rng(1)
+    N = p.n_scan * p.horizon_scan
+    sparse = np.zeros((N, 4), np.float32)
+    sparse[:, :3] = rng.uniform(-400, 400, size=(N, 3))          # practically one point per voxel
+    corner = sparse[:1500]
+    odom = dict(t=np.zeros(3), q=np.array([1.0, 0, 0, 0]))
+    with pytest.raises(binding.AlegoError):
+        h.lm_process(corner, sparse, sparse[: N // 2], odom)
+    o = O.Oracle(p)                                               # the same handle then processes ordinary scans correctly
+    h2 = binding.Handle(p)
+    for k in range(3):
+        pts = synth.scan(p, k)
+        o.process_scan(pts)
+        a = h.scan_process(pts, stages=3)
+        b = h2.scan_process(pts, stages=3)
+        assert_bit_equal(a[1]["t"], b[1]["t"], "odometry after the overflow")
+    h.close(); h2.close()

@@ -1,0 +1,123 @@
+"""-m "not gpu": host-side pieces of the C ABI that need no device (PointCloud2 parsing) and the oracle's
+pose-graph pass-through operations."""
+import struct
+
+import numpy as np
+import pytest
+
+from alego_amd import binding, synth
+from oracle import oracle_py as O
+from util import assert_bit_equal
+
+F32, U16 = 7, 4   # sensor_msgs/PointField datatypes
+
+
+def _pack(pts, step, offs, extra=b"", big=False):
+    fmt = ">f" if big else "<f"
+    out = bytearray()
+    for p in pts:
+        rec = bytearray(step)
+        for k, o in enumerate(offs):
+            if o is not None:
+                rec[o:o + 4] = struct.pack(fmt, float(p[k]))
+        out += rec
+    return bytes(out) + extra
+
+
+def test_pointcloud2_parser_layouts():
+    """alego_pc2_to_points = pcl::fromROSMsg<PointXYZI> (imageProjection.cpp:54-55): fields matched by name, FLOAT32 only."""
+    rng = np.random.default_rng(3)
+    pts = rng.normal(size=(257, 4)).astype(np.float32)
+    # PCL's own 32-byte layout: x y z @0/4/8, intensity @16
+    pcl = [("x", 0, F32, 1), ("y", 4, F32, 1), ("z", 8, F32, 1), ("intensity", 16, F32, 1)]
+    got = binding.pc2_to_points(_pack(pts, 32, (0, 4, 8, 16)), 257, 1, 32, 257 * 32, pcl)
+    assert_bit_equal(got, pts, "PCL layout")
+    # a driver layout: intensity first, a uint16 ring field in between, fields listed in another order
+    drv = [("ring", 4, U16, 1), ("z", 16, F32, 1), ("intensity", 0, F32, 1), ("x", 8, F32, 1), ("y", 12, F32, 1)]
+    got = binding.pc2_to_points(_pack(pts, 22, (8, 12, 16, 0)), 257, 1, 22, 257 * 22, drv)
+    assert_bit_equal(got, pts, "driver layout")
+    # organised cloud with padded rows (row_step > width * point_step)
+    w, hgt, step = 64, 4, 16
+    rows = b"".join(_pack(pts[r * w:(r + 1) * w], step, (0, 4, 8, 12)) + b"\xee" * 40 for r in range(hgt))
+    got = binding.pc2_to_points(rows, w, hgt, step, w * step + 40, [("x", 0, F32, 1), ("y", 4, F32, 1), ("z", 8, F32, 1), ("intensity", 12, F32, 1)])
+    assert_bit_equal(got, pts[:w * hgt], "padded rows")
+    # big-endian payload
+    got = binding.pc2_to_points(_pack(pts, 16, (0, 4, 8, 12), big=True), 257, 1, 16, 257 * 16,
+                                [("x", 0, F32, 1), ("y", 4, F32, 1), ("z", 8, F32, 1), ("intensity", 12, F32, 1)], is_bigendian=True)
+    assert_bit_equal(got, pts, "big endian")
+    # no intensity field (or one of another type): PCL leaves the member at 0
+    want = pts.copy(); want[:, 3] = 0
+    got = binding.pc2_to_points(_pack(pts, 12, (0, 4, 8, None)), 257, 1, 12, 257 * 12, [("x", 0, F32, 1), ("y", 4, F32, 1), ("z", 8, F32, 1)])
+    assert_bit_equal(got, want, "missing intensity")
+    got = binding.pc2_to_points(_pack(pts, 16, (0, 4, 8, 12)), 257, 1, 16, 257 * 16,
+                                [("x", 0, F32, 1), ("y", 4, F32, 1), ("z", 8, F32, 1), ("intensity", 12, 8, 1)])  # FLOAT64: no match
+    assert_bit_equal(got, want, "intensity of another datatype")
+    # empty message
+    assert binding.pc2_to_points(b"", 0, 1, 16, 0, pcl[:3]).shape == (0, 4)
+
+
+def test_pointcloud2_parser_rejects_bad_messages():
+    f = [("x", 0, F32, 1), ("y", 4, F32, 1), ("z", 8, F32, 1)]
+    data = bytes(16 * 10)
+    with pytest.raises(binding.AlegoError):
+        binding.pc2_to_points(data, 10, 1, 16, 160, f[:2])                       # no z
+    with pytest.raises(binding.AlegoError):
+        binding.pc2_to_points(data, 11, 1, 16, 176, f)                           # data shorter than width * point_step
+    with pytest.raises(binding.AlegoError):
+        binding.pc2_to_points(data, 10, 1, 16, 160, [("x", 0, F32, 1), ("y", 4, F32, 1), ("z", 14, F32, 1)])  # field beyond point_step
+    with pytest.raises(binding.AlegoError):
+        binding.pc2_to_points(data, 10, 1, 16, 160, f, cap=5)                    # caller buffer too small
+
+
+def test_pointcloud2_of_a_synthetic_scan_feeds_the_oracle(params_a):
+    """A scan serialised the way a driver publishes it and parsed back is the scan: same segmentation."""
+    pts = synth.scan(params_a, 1)
+    raw = bytearray(32 * len(pts))
+    v = np.frombuffer(raw, np.uint8).reshape(-1, 32)
+    v[:, 0:12] = pts[:, :3].copy().view(np.uint8).reshape(-1, 12)
+    v[:, 16:20] = pts[:, 3:4].copy().view(np.uint8).reshape(-1, 4)
+    got = binding.pc2_to_points(bytes(raw), len(pts), 1, 32, 32 * len(pts),
+                                [("x", 0, F32, 1), ("y", 4, F32, 1), ("z", 8, F32, 1), ("intensity", 16, F32, 1)])
+    assert_bit_equal(got, pts, "round trip")
+    a, b = O.Oracle(params_a), O.Oracle(params_a)
+    a.ip(pts), b.ip(got)
+    assert_bit_equal(a.get("label_img"), b.get("label_img"), "labels")
+
+
+def test_oracle_keyframe_pass_through(params_a):
+    """correctPoses on the oracle: rewriting the key poses + clearing the window re-assembles the map from the corrected poses;
+    rewriting them with their own values changes nothing beyond what clearing the window alone does (a full window holding
+    the duplicate of laserMapping.cpp:227-236 refills without it)."""
+    p = params_a.copy()
+    p.recent_keyframe_num, p.min_keyframe_dist = 5, 0.09
+    a, b = O.Oracle(p), O.Oracle(p)
+    for k in range(30):
+        pts = synth.scan(p, k)
+        a.process_scan(pts), b.process_scan(pts)
+    a.lm_reset_window()
+    poses = a.get("lm_keyposes").reshape(-1, 6)
+    assert len(poses) >= 6
+    c, s, o = a.lm_keyframe(len(poses) - 1)
+    assert len(c) and len(s)
+    for i in range(len(poses)):
+        b.lm_set_keypose(i, poses[i])
+    b.lm_reset_window()
+    for k in range(30, 34):
+        pts = synth.scan(p, k)
+        a.process_scan(pts), b.process_scan(pts)
+        assert_bit_equal(a.get("lm_surf_map_ds"), b.get("lm_surf_map_ds"), f"scan {k}: identity correction changes nothing")
+    poses = a.get("lm_keyposes").reshape(-1, 6)
+    shifted = poses.copy(); shifted[:, 0] += np.float32(0.25)
+    for i in range(len(poses)):
+        b.lm_set_keypose(i, shifted[i])
+    b.lm_reset_window()
+    a.lm_reset_window()   # same window content on both sides: only the poses differ
+    b.lm_apply_correction([1, 0, 0, 0.25, 0, 1, 0, 0, 0, 0, 1, 0])
+    pts = synth.scan(p, 34)
+    a.process_scan(pts), b.process_scan(pts)
+    pts = synth.scan(p, 35)
+    a.process_scan(pts), b.process_scan(pts)
+    ma, mb = a.get("lm_surf_map"), b.get("lm_surf_map")   # the window's transformed clouds before the VoxelGrid
+    assert ma.shape == mb.shape
+    assert np.abs(mb[:, 0] - ma[:, 0] - 0.25).max() < 1e-4 and np.abs(mb[:, 1:] - ma[:, 1:]).max() < 1e-4, "the corrected map is the old one shifted"
+    assert np.abs(b.get("map_pose")[:3] - a.get("map_pose")[:3] - [0.25, 0, 0]).max() < 0.02

@@ -64,6 +64,25 @@ def test_atan2f_hypotf_equal_this_hosts_libm():
     assert_bit_equal(a, b, "atan2f special values")
 
 
+def test_sinf_cosf_equal_this_hosts_libm():
+    """transformPointCloud (laserMapping.h:166-173) builds its f32 matrix from std::sin / std::cos of FLOAT half angles:
+    glibc's sinf / cosf, which are not the correctly rounded values.  The restatement shared by the oracle and the HIP
+    path must reproduce this host's libm bit for bit over the range a key pose can reach (half angles in [-pi/2, pi/2];
+    tested on [-3.2, 3.2] and around 0); (float)sin((double)x), which round 1 used on both sides, does not."""
+    rng = np.random.default_rng(17)
+    L = O.lib()
+    n = 6_000_000
+    x = np.concatenate([rng.uniform(-3.2, 3.2, n), rng.uniform(-1e-3, 1e-3, n // 10), [0.0, -0.0, np.pi / 4, -np.pi / 4, np.pi / 2, 1.5707964]]).astype(np.float32)
+    a, b = np.empty(x.size, np.float32), np.empty(x.size, np.float32)
+    for mode, name in ((0, "sinf"), (1, "cosf")):
+        L.oracle_sincosf_array(x.ctypes.data, a.ctypes.data, x.size, mode)
+        L.oracle_sincosf_array(x.ctypes.data, b.ctypes.data, x.size, mode + 2)
+        assert_bit_equal(a, b, name)
+    L.oracle_sincosf_array(x.ctypes.data, a.ctypes.data, x.size, 2)
+    rounded = np.sin(x.astype(np.float64)).astype(np.float32)
+    assert (a.view(np.uint32) != rounded.view(np.uint32)).mean() > 1e-3, "libm sinf is expected to differ from the correctly rounded sine"
+
+
 def test_cell_centred_rays_land_in_their_cell(params_a):
     """the synthetic rays are cell-centred, so row/col are immune to libm ulp differences."""
     p = params_a
