@@ -24,10 +24,11 @@ EXPORTS = [
     "alego_stream", "alego_stream_groups", "alego_profile_enable", "alego_profile_report", "alego_set_lo_params", "alego_set_lm_params", "alego_debug_get", "alego_debug_voxel", "alego_debug_atan2f",
     "alego_debug_math", "alego_debug_eval_blocks", "alego_debug_transform_to_start", "alego_debug_set_option",
     "alego_lm_keyframe_count", "alego_lm_get_keyframe", "alego_lm_set_keypose", "alego_lm_reset_window", "alego_lm_apply_correction",
-    "alego_lm_add_keyframe", "alego_pc2_to_points",
+    "alego_lm_add_keyframe", "alego_pc2_to_points", "alego_replay_create", "alego_replay_load", "alego_replay_assign",
 ]
 
 REPLAY_PINGPONG = 0x100
+REPLAY_BAG = 0x200
 FLAG_LO_INIT, FLAG_FEW_SURF, FLAG_FEW_CORNER, FLAG_LM_SKIPPED, FLAG_LM_FEW_FEATURES, FLAG_LM_KEYFRAME = 1, 2, 4, 8, 16, 32
 
 
@@ -149,6 +150,12 @@ def lib():
         L.alego_pc2_to_points.restype = C.c_int
         L.alego_pc2_to_points.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int,
                                           C.POINTER(Pc2Field), C.c_int, C.c_void_p, C.c_int32]
+        L.alego_replay_create.restype = C.c_int
+        L.alego_replay_create.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.alego_replay_load.restype = C.c_int
+        L.alego_replay_load.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int32]
+        L.alego_replay_assign.restype = C.c_int
+        L.alego_replay_assign.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
         if L.alego_params_sizeof() != C.sizeof(AlegoParams):
             raise RuntimeError("alego_params layout mismatch between params.py and include/alego_params.h")
         _lib = L
@@ -302,6 +309,16 @@ class Handle:
     def batch_load(self, slot, ring_pos, pts):
         a = np.ascontiguousarray(pts, dtype=np.float32)
         self._check(lib().alego_batch_load(self._h, slot, ring_pos, a.ctypes.data, a.shape[0]), "alego_batch_load")
+
+    def replay_create(self, n_bags, bag_len):
+        self._check(lib().alego_replay_create(self._h, n_bags, bag_len), "alego_replay_create")
+
+    def replay_load(self, bag, scan, pts):
+        a = np.ascontiguousarray(pts, dtype=np.float32)
+        self._check(lib().alego_replay_load(self._h, bag, scan, a.ctypes.data, a.shape[0]), "alego_replay_load")
+
+    def replay_assign(self, slot, bag, start_scan):
+        self._check(lib().alego_replay_assign(self._h, slot, bag, start_scan), "alego_replay_assign")
 
     def batch_run(self, first_pos, n_scans, stages=7, sync=True):
         self._check(lib().alego_batch_run(self._h, first_pos, n_scans, stages, 1 if sync else 0), "alego_batch_run")

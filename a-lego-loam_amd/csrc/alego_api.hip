@@ -44,6 +44,7 @@ struct alego_handle {
   LmHost* lm = nullptr;
   Profiler prof;
   int ip_fast_capable = 0;  // which of ip_project's table fast paths this geometry supports
+  bool replay_assigned = false;
 };
 
 namespace {
@@ -295,9 +296,38 @@ int alego_batch_load(alego_handle* h, int slot, int ring_pos, const alego_point*
   return 0;
 }
 
+int alego_replay_create(alego_handle* h, int n_bags, int bag_len) {
+  if (!h || n_bags < 1 || bag_len < 1) return ALEGO_ERR_ARG;
+  if (h->d.bag_pts) { h->err = "alego_replay_create: the bag store exists already"; return ALEGO_ERR_ARG; }
+  hipSetDevice(h->device);
+  float4* pts = nullptr; int* cnt = nullptr; int2* src = nullptr;
+  if (dalloc(h, &pts, (size_t)n_bags * bag_len * h->d.Pcap, false) || dalloc(h, &cnt, (size_t)n_bags * bag_len) || dalloc(h, &src, (size_t)h->d.n_slots)) return ALEGO_ERR_HIP;
+  h->d.bag_pts = pts; h->d.bag_n = cnt; h->d.bag_src = src; h->d.n_bags = n_bags; h->d.bag_len = bag_len;
+  return 0;
+}
+int alego_replay_load(alego_handle* h, int bag, int scan, const alego_point* pts, int32_t n) {
+  if (!h || !h->d.bag_pts || bag < 0 || bag >= h->d.n_bags || scan < 0 || scan >= h->d.bag_len || n < 0 || (n > 0 && !pts)) return ALEGO_ERR_ARG;
+  if (n > h->d.Pcap) { h->err = "scan larger than n_scan*horizon_scan"; return ALEGO_ERR_CAPACITY; }
+  hipSetDevice(h->device);
+  const size_t idx = (size_t)bag * h->d.bag_len + scan;
+  HIP_TRY(h, hipMemcpy(const_cast<float4*>(h->d.bag_pts) + idx * h->d.Pcap, pts, (size_t)n * sizeof(alego_point), hipMemcpyHostToDevice));
+  HIP_TRY(h, hipMemcpy(const_cast<int*>(h->d.bag_n) + idx, &n, sizeof(int), hipMemcpyHostToDevice));
+  return 0;
+}
+int alego_replay_assign(alego_handle* h, int slot, int bag, int start_scan) {
+  if (int r = check_slot(h, slot)) return r;
+  if (!h->d.bag_pts || bag < 0 || bag >= h->d.n_bags || start_scan < 0) return ALEGO_ERR_ARG;
+  hipSetDevice(h->device);
+  const int2 v = make_int2(bag, start_scan % h->d.bag_len);
+  HIP_TRY(h, hipMemcpy(const_cast<int2*>(h->d.bag_src) + slot, &v, sizeof(v), hipMemcpyHostToDevice));
+  h->replay_assigned = true;
+  return 0;
+}
+
 // enqueue IP -> FE -> LO -> LM for slots [slot0, slot0+n) on ring position `pos`
 static int enqueue_scan(alego_handle* h, int slot0, int n, int pos, int stages, bool want_labels) {
-  const DevCtx d = view(h, slot0, n);
+  DevCtx d = view(h, slot0, n);
+  d.replay_bag = (stages & ALEGO_REPLAY_BAG) ? 1 : 0;
   hipStream_t S = stream_of(h, slot0);  // [slot0, slot0+n) lies inside one stream group
   g_prof = &h->prof;
   static const bool dbg = getenv("ALEGO_DEBUG_SYNC") != nullptr;
@@ -318,9 +348,12 @@ int alego_batch_run(alego_handle* h, int first_pos, int n_scans, int stages, int
   if (!h) return ALEGO_ERR_ARG;
   hipSetDevice(h->device);
   const int R = h->d.ring_len;
+  if ((stages & ALEGO_REPLAY_BAG) && (!h->d.bag_pts || !h->replay_assigned)) { h->err = "alego_batch_run: ALEGO_REPLAY_BAG without alego_replay_create / alego_replay_assign"; return ALEGO_ERR_ARG; }
   for (int s = 0; s < n_scans; ++s) {
     int pos;
-    if ((stages & ALEGO_REPLAY_PINGPONG) && R > 1) {  // 0,1,..,R-1,R-2,..,1,0,1,.. : consecutive scans stay neighbours
+    if (stages & ALEGO_REPLAY_BAG) {
+      pos = (int)(((long long)first_pos + s) % h->d.bag_len);   // every slot adds its own start scan on the device
+    } else if ((stages & ALEGO_REPLAY_PINGPONG) && R > 1) {  // 0,1,..,R-1,R-2,..,1,0,1,.. : consecutive scans stay neighbours
       const int period = 2 * (R - 1);
       const int t = ((first_pos + s) % period + period) % period;
       pos = t < R ? t : period - t;
@@ -328,7 +361,7 @@ int alego_batch_run(alego_handle* h, int first_pos, int n_scans, int stages, int
       pos = ((first_pos + s) % R + R) % R;
     }
     for (int s0 = 0; s0 < h->d.n_slots; s0 += h->gsize)
-      if (int r = enqueue_scan(h, s0, std::min(h->gsize, h->d.n_slots - s0), pos, stages & 7, false)) return r;
+      if (int r = enqueue_scan(h, s0, std::min(h->gsize, h->d.n_slots - s0), pos, stages & (7 | ALEGO_REPLAY_BAG), false)) return r;
   }
   if (sync) HIP_TRY(h, sync_all(h));
   return 0;

@@ -63,6 +63,12 @@ struct DevCtx {
   // ---- input ring ----
   float4* in_pts;  // [slot][ring][Pcap]
   int* in_n;       // [slot][ring]
+  // ---- bag store (alego_replay_*): recorded streams shared by the slots; slot s replays bag bag_src[s].x from scan
+  // bag_src[s].y on, cyclically.  A launch with replay_bag != 0 reads it; its `ring_pos` is then the step index.
+  const float4* bag_pts;  // [bag][bag_len][Pcap]
+  const int* bag_n;       // [bag][bag_len]
+  const int2* bag_src;    // [slot]
+  int n_bags, bag_len, replay_bag;
   // ---- image projection ----
   int* owner;           // [slot][N] winning input index per cell (last writer = max index), -1 empty; ip_project writes
                         // IP_OWNER_TAG | index, ip_image turns every cell back into the plain form (= the reset for the next scan)
@@ -124,6 +130,14 @@ enum {
 #define LO_CH 32
 #endif
 // LO_CH: targets per bounding box of the LaserOdometry 1-NN / ring-walk pruning
+
+// the input scan of `slot` at ring position / replay step `pos`
+DEV_INLINE size_t scan_slot(const DevCtx& d, int slot, int pos) {
+  if (d.replay_bag) { const int2 s = d.bag_src[slot]; return (size_t)s.x * d.bag_len + (unsigned)(s.y + pos) % (unsigned)d.bag_len; }
+  return (size_t)slot * d.ring_len + pos;
+}
+DEV_INLINE const float4* scan_pts(const DevCtx& d, int slot, int pos) { return (d.replay_bag ? d.bag_pts : d.in_pts) + scan_slot(d, slot, pos) * d.Pcap; }
+DEV_INLINE int scan_count(const DevCtx& d, int slot, int pos) { return (d.replay_bag ? d.bag_n : d.in_n)[scan_slot(d, slot, pos)]; }
 
 // row of a cell index without an integer division (exact for v < 2^32 / H, i.e. for every supported image)
 DEV_INLINE int cell_row(const DevCtx& d, int v) { return (int)__umulhi((unsigned)v, d.h_magic); }

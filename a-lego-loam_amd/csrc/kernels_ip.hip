@@ -23,9 +23,9 @@
 __global__ void __launch_bounds__(IP_BLOCK) ip_project(DevCtx d, int ring_pos) {
   const int slot = blockIdx.y + d.slot0;
   const int i0 = blockIdx.x * IP_BLOCK * IP_PW + threadIdx.x;   // IP_PW points per thread, their loads in flight together
-  const int n = d.in_n[slot * d.ring_len + ring_pos];
+  const int n = scan_count(d, slot, ring_pos);
   const alego_params& P = d.P;
-  const float4* in = d.in_pts + ((size_t)slot * d.ring_len + ring_pos) * d.Pcap;
+  const float4* in = scan_pts(d, slot, ring_pos);
   float4 pin[IP_PW];
 #pragma unroll
   for (int u = 0; u < IP_PW; ++u) pin[u] = in[min(i0 + u * IP_BLOCK, max(n - 1, 0))];
@@ -148,7 +148,7 @@ __global__ void __launch_bounds__(128) ip_image(DevCtx d, int ring_pos) {
   const int slot = blockIdx.y + d.slot0;
   const int col = blockIdx.x * 128 + threadIdx.x;
   const alego_params& P = d.P;
-  const float4* pts = d.in_pts + ((size_t)slot * d.ring_len + ring_pos) * d.Pcap;
+  const float4* pts = scan_pts(d, slot, ring_pos);
   if (col == 0) {  // orientation, :62-72
     int* sc = d.scal + slot * SC_COUNT;
     float* ori = d.ori + slot * 4;
@@ -504,7 +504,7 @@ __global__ void __launch_bounds__(CC_LDS_THREADS) cc_lds(DevCtx d, int ring_pos,
     }
   }
   __syncthreads();
-  const float4* pts = d.in_pts + ((size_t)slot * d.ring_len + ring_pos) * d.Pcap;
+  const float4* pts = scan_pts(d, slot, ring_pos);
   const unsigned long long below = (1ull << lane) - 1ull;
 #pragma unroll 4
   for (int k = 0; k < PER; ++k) {
@@ -779,7 +779,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(8, 8))) __launch_bounds__(CC_
   }
   __syncthreads();
   CC_TICK(7);
-  const float4* pts = d.in_pts + ((size_t)slot * d.ring_len + ring_pos) * d.Pcap;
+  const float4* pts = scan_pts(d, slot, ring_pos);
   const unsigned long long below = (1ull << lane) - 1ull;
   constexpr int CB = 3;   // cells per batch (emit() below is called CB times)
   static_assert(PER % CB == 0, "cells per thread must be a multiple of the batch");
@@ -908,7 +908,7 @@ __global__ void __launch_bounds__(IP_BLOCK) ip_rowcount(DevCtx d) {
 __global__ void __launch_bounds__(IP_BLOCK) ip_compact(DevCtx d, int ring_pos) {
   const int slot = blockIdx.y + d.slot0, row = blockIdx.x;
   const size_t base = (size_t)slot * d.N;
-  const float4* pts = d.in_pts + ((size_t)slot * d.ring_len + ring_pos) * d.Pcap;
+  const float4* pts = scan_pts(d, slot, ring_pos);
   __shared__ int s_off[3];
   __shared__ int s_wave[3][IP_BLOCK / 64];
   // exclusive prefix over rows (NS <= 64 rows, recomputed by every block)

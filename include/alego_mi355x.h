@@ -128,6 +128,14 @@ int alego_synchronize(alego_handle* h);
 /* OR into `stages` of alego_batch_run: replay the resident ring back and forth (0..R-1,R-2..0,1..)
  * instead of wrapping, so that consecutive scans of a stream are always trajectory neighbours */
 #define ALEGO_REPLAY_PINGPONG 0x100
+/* Bag store: n_bags recorded streams of bag_len scans each, resident in HBM once and SHARED by the slots (a 560-scan lap of a
+ * 16x1800 sensor is 258 MB; a private copy per slot would not fit).  alego_replay_assign makes `slot` replay `bag` from
+ * scan `start_scan` on, cyclically; alego_batch_run with ALEGO_REPLAY_BAG in `stages` then advances every slot by n_scans
+ * scans of its bag: first_pos is the step index (slot s processes scan (start_scan + first_pos + i) mod bag_len at step i). */
+#define ALEGO_REPLAY_BAG 0x200
+int alego_replay_create(alego_handle* h, int n_bags, int bag_len);
+int alego_replay_load(alego_handle* h, int bag, int scan, const alego_point* pts, int32_t n);
+int alego_replay_assign(alego_handle* h, int slot, int bag, int start_scan);
 /* poses of the last processed scan of `slot` */
 int alego_batch_get_pose(alego_handle* h, int slot, alego_pose* odom, alego_pose* map_pose);
 /* per-scan device counters of the last processed scan of `slot`:

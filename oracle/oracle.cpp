@@ -29,8 +29,11 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <condition_variable>
 #include <deque>
 #include <map>
+#include <mutex>
+#include <thread>
 #include <queue>
 #include <string>
 #include <vector>
@@ -350,30 +353,36 @@ struct KdTree {
     }
     return s;
   }
-  void search_rec(int id, const Pt& q, int k, std::vector<Cand>& best) const {
+  // result set: ascending (distance, index), at most k entries, in a caller-provided array (as FLANN's KNNResultSet)
+  struct ResultSet { Cand* c; int n, k; };
+  void search_rec(int id, const Pt& q, ResultSet& best) const {
     const Node& nd = nodes[id];
-    if ((int)best.size() == k && box_dist(nd, q) * (1.0 - 1e-5) > (double)best.back().d) return;
+    if (best.n == best.k && box_dist(nd, q) * (1.0 - 1e-5) > (double)best.c[best.n - 1].d) return;
     if (nd.left < 0) {
       for (int i = nd.lo; i < nd.hi; ++i) {
         Cand c{dist2_f32(pts[order[i]], q), order[i]};
-        if ((int)best.size() < k || c < best.back()) {
-          auto it = std::upper_bound(best.begin(), best.end(), c);
-          best.insert(it, c);
-          if ((int)best.size() > k) best.pop_back();
+        if (best.n < best.k || c < best.c[best.n - 1]) {
+          int pos = best.n < best.k ? best.n : best.n - 1;   // insert, dropping the last entry of a full set
+          while (pos > 0 && c < best.c[pos - 1]) { best.c[pos] = best.c[pos - 1]; --pos; }
+          best.c[pos] = c;
+          if (best.n < best.k) ++best.n;
         }
       }
       return;
     }
     double dl = box_dist(nodes[nd.left], q), dr = box_dist(nodes[nd.right], q);
-    if (dl <= dr) { search_rec(nd.left, q, k, best); search_rec(nd.right, q, k, best); }
-    else { search_rec(nd.right, q, k, best); search_rec(nd.left, q, k, best); }
+    if (dl <= dr) { search_rec(nd.left, q, best); search_rec(nd.right, q, best); }
+    else { search_rec(nd.right, q, best); search_rec(nd.left, q, best); }
   }
   // returns number found (min(k, n)); ascending (distance, index)
   int knn(const Pt& q, int k, int* idx, float* dist) const {
-    std::vector<Cand> best; best.reserve(k + 1);
-    if (n > 0) search_rec(0, q, k, best);
-    for (size_t i = 0; i < best.size(); ++i) { idx[i] = best[i].i; dist[i] = best[i].d; }
-    return (int)best.size();
+    Cand small[16];
+    std::vector<Cand> big;
+    if (k > 16) big.resize(k);
+    ResultSet best{k > 16 ? big.data() : small, 0, k};
+    if (n > 0 && k > 0) search_rec(0, q, best);
+    for (int i = 0; i < best.n; ++i) { idx[i] = best.c[i].i; dist[i] = best.c[i].d; }
+    return best.n;
   }
 };
 
@@ -436,23 +445,22 @@ inline Quat quat_inverse(const Quat& q) {
   return Quat{q.w / n2, -q.x / n2, -q.y / n2, -q.z / n2};
 }
 
-// Householder QR least squares: min ||A x - b||, A is m x n column-major (overwritten).
-void qr_solve(std::vector<double>& A, std::vector<double>& b, int m, int n, double* x) {
+// Householder QR least squares: min ||A x - b||, A is m x n column-major (overwritten), v = scratch of m doubles.
+void qr_solve(double* A, double* b, int m, int n, double* x, double* v) {
   for (int k = 0; k < n; ++k) {
-    double* col = &A[(size_t)k * m];
+    double* col = A + (size_t)k * m;
     double norm2 = 0;
     for (int i = k; i < m; ++i) norm2 += col[i] * col[i];
     double norm = std::sqrt(norm2);
     if (norm == 0.0) continue;
     double alpha = col[k] > 0 ? -norm : norm;
-    std::vector<double> v(m - k);
     for (int i = k; i < m; ++i) v[i - k] = col[i];
     v[0] -= alpha;
     double vn2 = 0;
-    for (double e : v) vn2 += e * e;
+    for (int i = 0; i < m - k; ++i) vn2 += v[i] * v[i];
     if (vn2 == 0.0) continue;
     for (int j = k; j < n; ++j) {
-      double* cj = &A[(size_t)j * m];
+      double* cj = A + (size_t)j * m;
       double dot = 0;
       for (int i = k; i < m; ++i) dot += v[i - k] * cj[i];
       double f = 2.0 * dot / vn2;
@@ -468,6 +476,10 @@ void qr_solve(std::vector<double>& A, std::vector<double>& b, int m, int n, doub
     for (int j = k + 1; j < n; ++j) s -= A[(size_t)j * m + k] * x[j];
     x[k] = s / A[(size_t)k * m + k];
   }
+}
+void qr_solve(std::vector<double>& A, std::vector<double>& b, int m, int n, double* x) {
+  std::vector<double> v(m);
+  qr_solve(A.data(), b.data(), m, n, x, v.data());
 }
 
 // Symmetric 3x3 eigen-decomposition (cyclic Jacobi), eigenvalues ascending,
@@ -1161,13 +1173,13 @@ struct LaserMapping {
         Pt sel; point_associate_to_map(laser_surf_total_ds[i], sel);
         if (kd_surf_map.knn(sel, 5, nidx, ndist) < 5) continue;
         if ((double)ndist[4] < P.knn_max_dist) {
-          std::vector<double> A(15), b(5, -1.0);
+          double A[15], b[5] = {-1.0, -1.0, -1.0, -1.0, -1.0}, hv[5];   // Matrix<double, 5, 3> / Matrix<double, 5, 1>: fixed size, no heap
           for (int j = 0; j < 5; ++j) {
             const Pt& m = surf_from_map_ds[nidx[j]];
             A[0 * 5 + j] = m.x; A[1 * 5 + j] = m.y; A[2 * 5 + j] = m.z;
           }
           double norm[3];
-          qr_solve(A, b, 5, 3, norm);
+          qr_solve(A, b, 5, 3, norm, hv);
           double nn = std::sqrt(norm[0] * norm[0] + norm[1] * norm[1] + norm[2] * norm[2]);
           double negative_OA_dot_norm = 1 / nn;
           for (int a = 0; a < 3; ++a) norm[a] /= nn;
@@ -1345,6 +1357,82 @@ int oracle_process_scan(void* h, const alego_point* pts, int n, int stages) {
   }
   ++c->scans;
   return r;
+}
+
+// cpu_pipe3: the reference's deployment shape — ImageProjection, LaserOdometry and LaserMapping as three
+// threads (three nodelets of one manager, launch/test.launch:7-10) connected by message queues.  Every scan goes through
+// all three stages (the ROS nodes drop frames when they fall behind; here the queues block, so the figure is the
+// throughput of the slowest stage, with the hand-over copies a nodelet manager's shared_ptr messages avoid).
+// Returns the wall-clock seconds for the n scans; the context ends in the same state as n oracle_process_scan calls.
+}  // extern "C"
+namespace {
+template <class T>
+struct BoundedQueue {
+  std::mutex m; std::condition_variable cv_put, cv_get; std::deque<T> q; size_t cap = 4; bool closed = false;
+  void put(T&& v) { std::unique_lock<std::mutex> l(m); cv_put.wait(l, [&] { return q.size() < cap; }); q.push_back(std::move(v)); cv_get.notify_one(); }
+  bool get(T& v) { std::unique_lock<std::mutex> l(m); cv_get.wait(l, [&] { return !q.empty() || closed; }); if (q.empty()) return false; v = std::move(q.front()); q.pop_front(); cv_put.notify_one(); return true; }
+  void close() { std::unique_lock<std::mutex> l(m); closed = true; cv_get.notify_all(); }
+};
+struct SegMsg {   // /segmented_cloud + /seg_info + /outlier
+  std::vector<Pt> seg, outlier; std::vector<uint8_t> ground; std::vector<int> col, start, end; std::vector<float> range;
+};
+struct LoMsg {    // /corner_last + /surf_last + /outlier + /odom/lidar
+  std::vector<Pt> corner, surf, outlier; double odom[7]; bool valid;
+};
+}  // namespace
+extern "C" {
+double oracle_run_pipelined(void* h, const alego_point* const* scans, const int* counts, int n) {
+  Ctx* c = (Ctx*)h;
+  BoundedQueue<SegMsg> q1;
+  BoundedQueue<LoMsg> q2;
+  const auto t0 = std::chrono::steady_clock::now();
+  std::thread t_ip([&] {
+    for (int k = 0; k < n; ++k) {
+      c->ip.process(scans[k], counts[k]);
+      SegMsg m;
+      const int M = (int)c->ip.seg_cloud.size();
+      m.seg = c->ip.seg_cloud; m.outlier = c->ip.outlier_cloud;
+      m.ground.assign(c->ip.seg_ground.begin(), c->ip.seg_ground.begin() + M);
+      m.col.assign(c->ip.seg_col.begin(), c->ip.seg_col.begin() + M);
+      m.range.assign(c->ip.seg_range.begin(), c->ip.seg_range.begin() + M);
+      m.start = c->ip.start_ring; m.end = c->ip.end_ring;
+      q1.put(std::move(m));
+    }
+    q1.close();
+  });
+  std::thread t_lo([&] {
+    ImageProjection view;   // LaserOdometry reads the message through the same members it reads in the sequential path
+    view.P = c->P;
+    SegMsg m;
+    while (q1.get(m)) {
+      view.seg_cloud.swap(m.seg); view.seg_ground.swap(m.ground); view.seg_col.swap(m.col); view.seg_range.swap(m.range);
+      view.start_ring.swap(m.start); view.end_ring.swap(m.end);
+      view.seg_ground.resize(view.seg_cloud.size() + 16); view.seg_col.resize(view.seg_cloud.size() + 16); view.seg_range.resize(view.seg_cloud.size() + 16);
+      const bool ok = c->lo.process(view);
+      LoMsg o;
+      o.valid = ok;
+      if (ok) {
+        Quat q = mat_to_quat(c->lo.r_w);
+        c->odom_pose[0] = c->lo.t_w[0]; c->odom_pose[1] = c->lo.t_w[1]; c->odom_pose[2] = c->lo.t_w[2];
+        c->odom_pose[3] = q.w; c->odom_pose[4] = q.x; c->odom_pose[5] = q.y; c->odom_pose[6] = q.z;
+        o.corner = c->lo.corner_last; o.surf = c->lo.surf_last; o.outlier.swap(m.outlier);
+        std::memcpy(o.odom, c->odom_pose, sizeof(o.odom));
+      }
+      q2.put(std::move(o));
+    }
+    q2.close();
+  });
+  std::thread t_lm([&] {
+    LoMsg o;
+    while (q2.get(o)) {
+      if (!o.valid) continue;
+      Quat q{o.odom[3], o.odom[4], o.odom[5], o.odom[6]};
+      c->lm.process(o.corner, o.surf, o.outlier, o.odom, q, c->map_pose);
+    }
+  });
+  t_ip.join(); t_lo.join(); t_lm.join();
+  c->scans += n;
+  return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 }
 
 // teacher forcing: overwrite LO params_ / LM params_ (6 doubles)

@@ -50,6 +50,8 @@ def lib():
         L.oracle_lm_keyframe.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]
         L.oracle_transform_to_start.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.oracle_transform_cloud.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.oracle_run_pipelined.restype = C.c_double
+        L.oracle_run_pipelined.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.oracle_sincosf_array.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
         _lib = L
     return _lib
@@ -92,6 +94,13 @@ class Oracle:
     def process_scan(self, pts, stages=7):
         a = self._pts(pts)
         return lib().oracle_process_scan(self._h, a.ctypes.data, a.shape[0], stages)
+
+    def run_pipelined(self, scans):
+        """cpu_pipe3: IP, LO, LM as three threads over the list of scans; returns wall-clock seconds."""
+        arrs = [self._pts(a) for a in scans]
+        ptrs = (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+        cnts = (C.c_int * len(arrs))(*[a.shape[0] for a in arrs])
+        return float(lib().oracle_run_pipelined(self._h, ptrs, cnts, len(arrs)))
 
     def set_lo_params(self, p6):
         a = np.ascontiguousarray(p6, dtype=np.float64)

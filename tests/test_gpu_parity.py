@@ -796,3 +796,31 @@ def test_lm_capacity_overflow_is_reported_not_written_past(params_a):
         b = h2.scan_process(pts, stages=3)
         assert_bit_equal(a[1]["t"], b[1]["t"], "odometry after the overflow")
     h.close(); h2.close()
+
+
+def test_bag_replay_equals_single_stream(params_a):
+    """alego_replay_*: slots replaying shared, HBM-resident bags cyclically from their own start scans give bit-identical
+    poses to one-slot handles fed the same scan sequence through the host entry point (bench.py's workload)."""
+    p = params_a
+    n_bags, bag_len, steps = 2, 9, 31          # 31 steps: every slot wraps around its 9-scan bag three times
+    assign = [(0, 0), (1, 4), (0, 7), (1, 0)]
+    hb = binding.Handle(p, n_slots=len(assign), ring_len=1)
+    hb.replay_create(n_bags, bag_len)
+    bags = [[synth.scan(p, k, stream=b) for k in range(bag_len)] for b in range(n_bags)]
+    for b in range(n_bags):
+        for k in range(bag_len):
+            hb.replay_load(b, k, bags[b][k])
+    for s, (b, start) in enumerate(assign):
+        hb.replay_assign(s, b, start)
+    hb.batch_run(0, 20, stages=7 | binding.REPLAY_BAG)
+    hb.batch_run(20, steps - 20, stages=7 | binding.REPLAY_BAG)   # continued from step 20
+    for s, (b, start) in enumerate(assign):
+        h1 = binding.Handle(p)
+        for i in range(steps):
+            _, odom1, mp1 = h1.scan_process(bags[b][(start + i) % bag_len], stages=7)
+        _, odomb, mpb = hb.batch_get_pose(s)
+        assert_bit_equal(odomb["t"], odom1["t"], f"slot {s} odometry translation")
+        assert_bit_equal(mpb["t"], mp1["t"], f"slot {s} map translation")
+        assert_bit_equal(mpb["params"], mp1["params"], f"slot {s} LM params_")
+        h1.close()
+    hb.close()
