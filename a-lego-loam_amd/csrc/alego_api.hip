@@ -132,6 +132,7 @@ int alego_create(const alego_params* params, int device, int n_slots, int ring_l
   if (n_slots <= 0) n_slots = 1;
   if (ring_len <= 0) ring_len = 1;
   if (params->n_scan < 1 || params->n_scan > 64 || params->horizon_scan < 64 || params->horizon_scan > 4096) return ALEGO_ERR_ARG;
+  if (params->recent_keyframe_num > 512) { std::fprintf(stderr, "alego_create: recent_keyframe_num > 512 is not supported\n"); return ALEGO_ERR_ARG; }
   // The feature pick marks up to suppress_radius neighbours on either side of a picked point; the segmented cloud only
   // guarantees the reference's 5-point margin at both ends of a ring (laserOdometry.cpp:124,211-234 index i +- 5 unchecked).
   if (params->suppress_radius < 0 || params->suppress_radius > 5 || params->n_sectors < 1 || params->n_sharp < 0 ||
@@ -627,7 +628,7 @@ int alego_debug_set_option(alego_handle* h, const char* name, int value) {
   if (s == "ALEGO_CC_FUSED") d.opt_cc_fused = value != 0;
   else if (s == "ALEGO_FE_PICK1") d.opt_fe_pick1 = value != 0;
   else if (s == "ALEGO_LO_BOX_LDS") d.opt_lo_box_lds = value;
-  else if (s == "ALEGO_MAP_MERGE") d.opt_map_merge = value != 0;
+  else if (s == "ALEGO_MAP_MERGE") { if (int r = lm_host_set_map_merge(h->lm, value != 0, &h->err)) return r; d.opt_map_merge = value != 0; }
   else if (s == "ALEGO_IP_FAST") d.ip_fast = h->ip_fast_capable & value;
   else { h->err = "unknown option " + s; return ALEGO_ERR_ARG; }
   return 0;

@@ -143,13 +143,43 @@ __global__ void __launch_bounds__(IP_BLOCK) ip_project(DevCtx d, int ring_pos) {
   }
 }
 
-// one thread per column; rows walked bottom-up carrying the lower cell in registers
-__global__ void __launch_bounds__(128) ip_image(DevCtx d, int ring_pos) {
+DEV_INLINE int ld_agent(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+DEV_INLINE void st_agent(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// atan2(y, x) > theta for y > 0, x > 0 (y = d2 sin a, x = d1 - d2 cos a with d1 >= d2 > 0 and 0 < a < pi/2).
+// tan is monotone on (0, pi/2): the comparison is decided by the sign of y - x tan(theta) whenever that difference is
+// far (1e-9 relative) from zero — rounding errors of either form are ~1e-16 — and by the reference expression itself
+// otherwise.  Saves two fp64 atan2 per cell on all but a vanishing fraction of the edges.
+DEV_INLINE bool edge_angle_gt(double y, double x, double theta, double tan_theta) {
+  const double xt = x * tan_theta, m = y - xt;
+  if (fabs(m) > 1e-9 * (y + fabs(xt))) return m > 0.0;
+  return atan2(y, x) > theta;
+}
+
+// ip_front = range image + ground labelling + edge predicates in one launch (imageProjection.cpp:62-72,:107-143,:255-270).
+// A workgroup takes IPF_W - 1 consecutive columns plus the column to their right (halo, with wrap-around): one thread per
+// column walks its rows bottom-up (owner -> point gather -> range, ground test on consecutive rows), keeps the column's
+// ranges in LDS and its filled / ground masks in registers; after one barrier every thread knows its right neighbour's
+// column and evaluates the right- and down-edge predicates of its own cells.  The images that used to make an HBM / L2
+// round trip between ip_image and cc_edges (range 4 B/cell written + read three times, flags written + read + rewritten)
+// stay on chip: written are the flag byte per cell (bit0 ground, bit1 active, bit2 edge->right, bit3 edge->down), the plain
+// owner image (= the reset for the next scan), and — only for the single-scan entry points / tests — the range image.
+//   init: bit 0 parent (global union-find path), bit 1 component statistics (cc_stats path), bit 2 labels (ip_compact path),
+//         bit 3 write the range image
+#define IPF_W 128
+__global__ void __launch_bounds__(IPF_W) ip_front(DevCtx d, int ring_pos, int init) {
   const int slot = blockIdx.y + d.slot0;
-  const int col = blockIdx.x * 128 + threadIdx.x;
+  const int tid = threadIdx.x;
+  const int col_raw = blockIdx.x * (IPF_W - 1) + tid;          // thread IPF_W - 1 computes the halo column
+  const bool mine = tid < IPF_W - 1 && col_raw < d.H;           // this thread's column is written by this workgroup
+  const int col = col_raw < d.H ? col_raw : col_raw - d.H;      // wrap-around (:241-248); H >= IPF_W so one subtraction is enough
+  const bool have = col_raw <= d.H;                             // column exists (col_raw == H: the halo of the last workgroup is column 0)
   const alego_params& P = d.P;
   const float4* pts = scan_pts(d, slot, ring_pos);
-  if (col == 0) {  // orientation, :62-72
+  extern __shared__ __attribute__((aligned(16))) unsigned char ipf_smem[];
+  float* s_r = reinterpret_cast<float*>(ipf_smem);                                   // [NS][IPF_W] ranges (-1 empty)
+  unsigned long long* s_act = reinterpret_cast<unsigned long long*>(s_r + (size_t)d.NS * IPF_W);   // [IPF_W] active mask of a column
+  if (blockIdx.x == 0 && tid == 0) {  // orientation, :62-72
     int* sc = d.scal + slot * SC_COUNT;
     float* ori = d.ori + slot * 4;
     const int first = sc[SC_FIRST], last = sc[SC_LAST];
@@ -164,7 +194,6 @@ __global__ void __launch_bounds__(128) ip_image(DevCtx d, int ring_pos) {
       ori[0] = so; ori[1] = eo; ori[2] = eo - so;
     }
   }
-  if (col >= d.H) return;
   int* owner = d.owner + (size_t)slot * d.N;
   float* rimg = d.range_img + (size_t)slot * d.N;
   uint8_t* fimg = d.flag_img + (size_t)slot * d.N;
@@ -174,115 +203,78 @@ __global__ void __launch_bounds__(128) ip_image(DevCtx d, int ring_pos) {
   // rows in batches of IM_U: the owner indices of a batch, then its point gathers, are independent loads
   constexpr int IM_U = 8;
   for (int row0 = 0; row0 < d.NS; row0 += IM_U) {
-  int ob[IM_U];
-  float4 pb[IM_U];
+    int ob[IM_U];
+    float4 pb[IM_U];
 #pragma unroll
-  for (int u = 0; u < IM_U; ++u) ob[u] = row0 + u < d.NS ? owner[(row0 + u) * d.H + col] : -1;
-  // entries of this scan carry the tag; everything else is stale.  The plain form is written back for the later readers
-  // (compaction) and doubles as the reset for the next scan.
+    for (int u = 0; u < IM_U; ++u) ob[u] = (have && row0 + u < d.NS) ? owner[(row0 + u) * d.H + col] : -1;
+    // entries of this scan carry the tag; everything else is stale.  The plain form is written back (by the column's own
+    // workgroup) for the later readers (compaction) and doubles as the reset for the next scan.
 #pragma unroll
-  for (int u = 0; u < IM_U; ++u) {
-    ob[u] = (ob[u] >= 0 && (ob[u] & IP_OWNER_TAG)) ? (ob[u] & ~IP_OWNER_TAG) : -1;
-    if (row0 + u < d.NS) owner[(row0 + u) * d.H + col] = ob[u];
-  }
-#pragma unroll
-  for (int u = 0; u < IM_U; ++u) pb[u] = ob[u] >= 0 ? pts[ob[u]] : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-  for (int u = 0; u < IM_U; ++u) {
-    const int row = row0 + u;
-    if (row >= d.NS) break;
-    const int o = ob[u];
-    float r = -1.0f;
-    bool ok = o >= 0;
-    float x = 0, y = 0, z = 0;
-    if (ok) {
-      const float4 p = pb[u];
-      x = p.x; y = p.y; z = p.z;
-      r = sqrtf(x * x + y * y + z * z);  // :99
-      filled |= 1ull << row;
+    for (int u = 0; u < IM_U; ++u) {
+      ob[u] = (ob[u] >= 0 && (ob[u] & IP_OWNER_TAG)) ? (ob[u] & ~IP_OWNER_TAG) : -1;
+      if (mine && row0 + u < d.NS) owner[(row0 + u) * d.H + col] = ob[u];
     }
-    rimg[row * d.H + col] = r;
-    if (row >= 1 && row - 1 < P.ground_scan_id && ok && lower_ok) {  // :111-131, pair (row-1,row)
-      const double dx = (double)(x - lx), dy = (double)(y - ly), dz = (double)(z - lz);
-      // |deg(atan2(dz, hypot(dx, dy))) - mount| < thres  <=>  tan(lo) h < dz < tan(hi) h; decided by the two signed
-      // margins unless one of them is within 1e-9 (relative) of zero, where the reference expression decides
-      const double hq = sqrt(dx * dx + dy * dy);
-      const double m1 = dz - d.tan_g_lo * hq, m2 = d.tan_g_hi * hq - dz, tol = 1e-9 * (fabs(dz) + hq);
-      bool is_ground;
-      if (m1 > tol && m2 > tol) is_ground = true;
-      else if (m1 < -tol || m2 < -tol) is_ground = false;
-      else {
-        const double angle = (atan2(dz, hypot(dx, dy)) * 180.0) / M_PI;
-        is_ground = fabs(angle - P.sensor_mount_ang) < P.ground_angle_thres;
+#pragma unroll
+    for (int u = 0; u < IM_U; ++u) pb[u] = ob[u] >= 0 ? pts[ob[u]] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int u = 0; u < IM_U; ++u) {
+      const int row = row0 + u;
+      if (row >= d.NS) break;
+      const int o = ob[u];
+      float r = -1.0f;
+      const bool ok = o >= 0;
+      float x = 0, y = 0, z = 0;
+      if (ok) {
+        const float4 p = pb[u];
+        x = p.x; y = p.y; z = p.z;
+        r = sqrtf(x * x + y * y + z * z);  // :99
+        filled |= 1ull << row;
       }
-      if (is_ground) ground |= 3ull << (row - 1);
+      s_r[row * IPF_W + tid] = r;
+      if (mine && (init & 8)) rimg[row * d.H + col] = r;
+      if (row >= 1 && row - 1 < P.ground_scan_id && ok && lower_ok) {  // :111-131, pair (row-1,row)
+        const double dx = (double)(x - lx), dy = (double)(y - ly), dz = (double)(z - lz);
+        // |deg(atan2(dz, hypot(dx, dy))) - mount| < thres  <=>  tan(lo) h < dz < tan(hi) h; decided by the two signed
+        // margins unless one of them is within 1e-9 (relative) of zero, where the reference expression decides
+        const double hq = sqrt(dx * dx + dy * dy);
+        const double m1 = dz - d.tan_g_lo * hq, m2 = d.tan_g_hi * hq - dz, tol = 1e-9 * (fabs(dz) + hq);
+        bool is_ground;
+        if (m1 > tol && m2 > tol) is_ground = true;
+        else if (m1 < -tol || m2 < -tol) is_ground = false;
+        else {
+          const double angle = (atan2(dz, hypot(dx, dy)) * 180.0) / M_PI;
+          is_ground = fabs(angle - P.sensor_mount_ang) < P.ground_angle_thres;
+        }
+        if (is_ground) ground |= 3ull << (row - 1);
+      }
+      lx = x; ly = y; lz = z; lower_ok = ok;
     }
-    lx = x; ly = y; lz = z; lower_ok = ok;
   }
-  }
-  for (int row = 0; row < d.NS; ++row) {
-    const bool g = (ground >> row) & 1, f = (filled >> row) & 1;
-    fimg[row * d.H + col] = (uint8_t)((g ? 1 : 0) | ((f && !g) ? 2 : 0));
-  }
-}
-
-DEV_INLINE int ld_agent(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-DEV_INLINE void st_agent(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
-// atan2(y, x) > theta for y > 0, x > 0 (y = d2 sin a, x = d1 - d2 cos a with d1 >= d2 > 0 and 0 < a < pi/2).
-// tan is monotone on (0, pi/2): the comparison is decided by the sign of y - x tan(theta) whenever that difference is
-// far (1e-9 relative) from zero — rounding errors of either form are ~1e-16 — and by the reference expression itself
-// otherwise.  Saves two fp64 atan2 per cell on all but a vanishing fraction of the edges.
-DEV_INLINE bool edge_angle_gt(double y, double x, double theta, double tan_theta) {
-  const double xt = x * tan_theta, m = y - xt;
-  if (fabs(m) > 1e-9 * (y + fabs(xt))) return m > 0.0;
-  return atan2(y, x) > theta;
-}
-
-// init: bit 0 parent (global union-find path), bit 1 component statistics (cc_stats path), bit 2 labels (ip_compact path)
-__global__ void __launch_bounds__(IP_BLOCK) cc_edges(DevCtx d, int init) {
-  const int slot = blockIdx.y + d.slot0;
+  const unsigned long long act = filled & ~ground;
+  s_act[tid] = act;
+  __syncthreads();
+  if (!mine) return;
+  const unsigned long long act_r = s_act[tid + 1];
   const size_t base = (size_t)slot * d.N;
-  const float* rimg = d.range_img + base;
-  uint8_t* fimg = d.flag_img + base;
-  // IP_PW cells per thread; the flag and range loads of all of them are issued before the predicates are evaluated
-  int vv[IP_PW], uu[IP_PW];
-  uint8_t f[IP_PW], fu[IP_PW], fw[IP_PW];
-  float rv[IP_PW], ru[IP_PW], rw[IP_PW];
-#pragma unroll
-  for (int q = 0; q < IP_PW; ++q) {
-    const int v = blockIdx.x * IP_BLOCK * IP_PW + q * IP_BLOCK + threadIdx.x;
-    vv[q] = v;
-    const int vc = min(v, d.N - 1);
-    const int row = cell_row(d, vc), col = vc - row * d.H;
-    uu[q] = row * d.H + ((col + 1 == d.H) ? 0 : col + 1);   // right neighbour with column wrap-around (:241-248)
-    const int w = row + 1 < d.NS ? vc + d.H : vc;
-    f[q] = fimg[vc]; fu[q] = fimg[uu[q]]; fw[q] = fimg[w];
-    rv[q] = rimg[vc]; ru[q] = rimg[uu[q]]; rw[q] = rimg[w];
-  }
-#pragma unroll
-  for (int q = 0; q < IP_PW; ++q) {
-    const int v = vv[q];
-    if (v >= d.N) continue;
-    const bool active = f[q] & 2;
+  for (int row = 0; row < d.NS; ++row) {
+    const bool g = (ground >> row) & 1, a = (act >> row) & 1;
     uint8_t e = 0;
-    if (active) {
-      const int row = cell_row(d, v);
-      const double r0 = (double)rv[q];
-      if ((fu[q] & 2) && d.H > 1) {  // same row, seg_alpha_x (:258-261)
-        const double r1 = (double)ru[q];
+    if (a) {
+      const double r0 = (double)s_r[row * IPF_W + tid];
+      if (((act_r >> row) & 1) && d.H > 1) {  // same row, seg_alpha_x (:258-261)
+        const double r1 = (double)s_r[row * IPF_W + tid + 1];
         const double d1 = fmax(r0, r1), d2 = fmin(r0, r1);
         if (edge_angle_gt(d2 * d.sin_ax, d1 - d2 * d.cos_ax, d.P.seg_theta, d.tan_theta)) e |= 4;
       }
-      if (row + 1 < d.NS && (fw[q] & 2)) {  // same column, seg_alpha_y (:262-265)
-        const double r1 = (double)rw[q];
+      if (row + 1 < d.NS && ((act >> (row + 1)) & 1)) {  // same column, seg_alpha_y (:262-265)
+        const double r1 = (double)s_r[(row + 1) * IPF_W + tid];
         const double d1 = fmax(r0, r1), d2 = fmin(r0, r1);
         if (edge_angle_gt(d2 * d.sin_ay, d1 - d2 * d.cos_ay, d.P.seg_theta, d.tan_theta)) e |= 8;
       }
     }
-    // NOTE: bits 2/3 of a neighbour are never read by this kernel (only bit 1), so the in-place update is race-free
-    fimg[v] = (uint8_t)((f[q] & 3) | e);
-    if (init & 1) d.parent[base + v] = active ? v : -1;
+    const int v = row * d.H + col;
+    fimg[v] = (uint8_t)((g ? 1 : 0) | (a ? 2 : 0) | e);
+    if (init & 1) d.parent[base + v] = a ? v : -1;
     if (init & 2) { d.cc_size[base + v] = 0; d.cc_rows[base + v] = 0ull; }
     if (init & 4) d.cc_label[base + v] = 0;
   }
@@ -525,7 +517,7 @@ __global__ void __launch_bounds__(CC_LDS_THREADS) cc_lds(DevCtx d, int ring_pos,
         d.seg_pts[base + line] = p;
         d.seg_ground[base + line] = fi[v] & 1;
         d.seg_col[base + line] = col;
-        d.seg_range[base + line] = d.range_img[base + v];
+        d.seg_range[base + line] = sqrtf(p.x * p.x + p.y * p.y + p.z * p.z);   // = the range image's value (:99), recomputed from the point
       } else {
         d.outlier[base + s_cnt[1][k * NW + wave] + (int)__popcll(bo & below)] = p;
       }
@@ -816,9 +808,10 @@ __global__ void __attribute__((amdgpu_waves_per_eu(8, 8))) __launch_bounds__(CC_
   for (int k0 = 0; k0 < per; k0 += CB) {
     const int c0 = cell_of(k0), c1 = cell_of(k0 + 1), c2 = cell_of(k0 + 2);
     const int o0 = d.owner[base + c0], o1 = d.owner[base + c1], o2 = d.owner[base + c2];
-    const float r0 = d.range_img[base + c0], r1 = d.range_img[base + c1], r2 = d.range_img[base + c2];
     const float4 q0 = pts[max(o0, 0)], q1 = pts[max(o1, 0)], q2 = pts[max(o2, 0)];
-    emit(k0, q0, r0); emit(k0 + 1, q1, r1); emit(k0 + 2, q2, r2);
+    // segmentedCloudRange = the range image's value (:99,:184), recomputed from the point instead of read back
+    emit(k0, q0, sqrtf(q0.x * q0.x + q0.y * q0.y + q0.z * q0.z)); emit(k0 + 1, q1, sqrtf(q1.x * q1.x + q1.y * q1.y + q1.z * q1.z));
+    emit(k0 + 2, q2, sqrtf(q2.x * q2.x + q2.y * q2.y + q2.z * q2.z));
   }
   __syncthreads();
   CC_TICK(8);
@@ -963,7 +956,7 @@ __global__ void __launch_bounds__(IP_BLOCK) ip_compact(DevCtx d, int ring_pos) {
         d.seg_pts[base + line] = p;
         d.seg_ground[base + line] = d.flag_img[base + v] & 1;
         d.seg_col[base + line] = col;
-        d.seg_range[base + line] = d.range_img[base + v];
+        d.seg_range[base + line] = sqrtf(p.x * p.x + p.y * p.y + p.z * p.z);   // = the range image's value (:99)
       } else {
         d.outlier[base + run_o + wo + (int)__popcll(bo & below)] = p;
       }
@@ -1001,13 +994,14 @@ void launch_ip(const DevCtx& d, int ring_pos, bool want_labels, hipStream_t st) 
   const dim3 gN((d.N + IP_BLOCK - 1) / IP_BLOCK, d.n_launch);
   const dim3 gN4((d.N + IP_BLOCK * IP_PW - 1) / (IP_BLOCK * IP_PW), d.n_launch), gP4((d.Pcap + IP_BLOCK * IP_PW - 1) / (IP_BLOCK * IP_PW), d.n_launch);
   ALEGO_LAUNCH(ip_project, gP4, dim3(IP_BLOCK), 0, st, d, ring_pos);
-  ALEGO_LAUNCH(ip_image, dim3((d.H + 127) / 128, d.n_launch), dim3(128), 0, st, d, ring_pos);
   const bool lds_cc = d.N <= CC_LDS_MAXN, lds_stats = lds_cc && d.NS <= 16;
-  ALEGO_LAUNCH(cc_edges, gN4, dim3(IP_BLOCK), 0, st, d, (lds_cc ? 0 : 1) | (lds_stats ? 0 : 2) | (fused ? 0 : 4));
+  const bool keep_images = want_labels || d.n_launch == 1;   // the single-scan entry points / tests read the range and root images back
+  ALEGO_LAUNCH(ip_front, dim3((d.H + IPF_W - 2) / (IPF_W - 1), d.n_launch), dim3(IPF_W), (size_t)d.NS * IPF_W * 4 + IPF_W * 8, st, d, ring_pos,
+               (lds_cc ? 0 : 1) | (lds_stats ? 0 : 2) | (fused ? 0 : 4) | (keep_images ? 8 : 0));
   if (lds_stats) {
     // bit 0: fused compaction; bit 1: write the root image to HBM (only ip_classify, ip_labels and alego_debug_get read it:
     // the single-scan entry points keep it, the batch path does not)
-    const int cc_flags = (fused ? 1 : 0) | ((!fused || want_labels || d.n_launch == 1) ? 2 : 0);
+    const int cc_flags = (fused ? 1 : 0) | ((!fused || keep_images) ? 2 : 0);
     ALEGO_LAUNCH(cc_lds16, dim3(d.n_launch), dim3(CC_LDS_THREADS), (size_t)4 * ((d.N + 1) / 2), st, d, ring_pos, cc_flags);
   } else if (lds_cc) {
     ALEGO_LAUNCH(cc_lds, dim3(d.n_launch), dim3(CC_LDS_THREADS), (size_t)4 * d.N, st, d, ring_pos, 0);

@@ -34,7 +34,7 @@ DEV_INLINE void stq(double* p, const DQuat& q) { p[0] = q.w; p[1] = q.x; p[2] = 
 //                          frame 0) although no key frame was saved: the duplicate stays in the window for K-1 further
 //                          key frames and doubles that frame's weight in the voxel centroids.  Reproduced as is.
 // LI_REBUILD is cleared again by lm_finish at the end of the frame.
-DEV_INLINE void lm_map_update(const LmCtx& L, int slot, int* li) {
+DEV_INLINE void lm_map_update(const LmCtx& L, int slot, int* li, int merge) {
   const int nkf = li[LI_NKF];
   if (nkf == 0) return;   // :196-199
   int* rec = L.rec + (size_t)slot * L.K;
@@ -54,6 +54,7 @@ DEV_INLINE void lm_map_update(const LmCtx& L, int slot, int* li) {
   li[LI_DIRTY] = 0;
   if (changed) { li[LI_REBUILD] = 1; li[LI_NREBUILD] += 1; }
 }
+
 
 // grid (8, 3, slots).  stage: copy /corner_last, /surf_last, /outlier of this scan into the LM inputs.
 __global__ void __launch_bounds__(LM_BLOCK) lm_prepare(DevCtx d, LmCtx L, int stage, int run_hint) {
@@ -80,7 +81,7 @@ __global__ void __launch_bounds__(LM_BLOCK) lm_prepare(DevCtx d, LmCtx L, int st
   if (blockIdx.x != 0 || kind != 0 || threadIdx.x != 0) return;
   double* ld = ldp(L, slot);
   double* po = d.poses + (size_t)slot * 16;
-  li[LI_RUN] = 0; li[LI_REBUILD] = 0; li[LI_KF_ADDED] = 0; li[LI_OPTIMIZED] = 0; li[LI_FLAGS] = 0;
+  li[LI_RUN] = 0; li[LI_REBUILD] = 0; li[LI_REBUILD_FB] = 0; li[LI_KF_ADDED] = 0; li[LI_OPTIMIZED] = 0; li[LI_FLAGS] = 0;
   if (!sc[SC_ODOM_VALID]) return;  // no /odom/lidar on the initialising scan -> no mapping frame
   // laserOdomHandler :154-166
   for (int k = 0; k < 3; ++k) ld[LD_T_O2L + k] = po[k];
@@ -98,31 +99,37 @@ __global__ void __launch_bounds__(LM_BLOCK) lm_prepare(DevCtx d, LmCtx L, int st
   li[LI_RUN] = run;
   if (run_hint >= 0 && run != run_hint) li[LI_OVERFLOW] = 2;  // host launch-skipping logic out of sync
   if (!run) { li[LI_FLAGS] = 8; return; }
-  lm_map_update(L, slot, li);
+  lm_map_update(L, slot, li, d.opt_map_merge);
+  li[LI_REBUILD_FB] = li[LI_REBUILD] && !d.opt_map_merge;
 }
 
 
-// grid (2, K, slots): chronological concatenation of the key-frame ring
+// grid (2, K, slots): chronological concatenation of the window's key frames (:238-243), each transformed by its key pose, in
+// the reference's order (corner | surf then outlier per frame).  Only the concat + radix-sort VoxelGrid path (ALEGO_MAP_MERGE=0)
+// runs it; the default path merges the pre-sorted key frames (kernels_map.hip).
 __global__ void __launch_bounds__(LM_BLOCK) lm_concat(DevCtx d, LmCtx L) {
   const int slot = blockIdx.z + d.slot0, j = blockIdx.y;
   int* li = lip(L, slot);
-  if (!li[LI_REBUILD]) return;
+  if (!li[LI_REBUILD_FB]) return;
   const int nk = li[LI_REC_CNT];
   if (j >= nk) return;
-  const int* kc = L.kf_cnt + (size_t)slot * L.K * 4;
-  const int* rec = L.rec + (size_t)slot * L.K;   // frame f lives in ring slot f % K (a full deque only holds the last K frames)
+  const int* kc = L.kf_cnt + (size_t)slot * L.KR * 4;
+  const int* rec = L.rec + (size_t)slot * L.K;   // frame f lives in ring entry f % KR
   int offc = 0, offs = 0;
-  for (int i = 0; i < j; ++i) { const int r = rec[i] % L.K; offc += kc[r * 4 + 0]; offs += kc[r * 4 + 1] + kc[r * 4 + 2]; }
-  const int ring = rec[j] % L.K;
+  for (int i = 0; i < j; ++i) { const int r = rec[i] % L.KR; offc += kc[r * 4 + 0]; offs += kc[r * 4 + 1] + kc[r * 4 + 2]; }
+  const int ring = rec[j] % L.KR;
   const int nc = kc[ring * 4 + 0], ns = kc[ring * 4 + 1], no = kc[ring * 4 + 2];
-  const float4* sc_ = L.kf_corner + ((size_t)slot * L.K + ring) * L.kf_cap_c;
-  const float4* ss_ = L.kf_surf + ((size_t)slot * L.K + ring) * L.kf_cap_s;
-  const float4* so_ = L.kf_outl + ((size_t)slot * L.K + ring) * L.kf_cap_o;
+  const size_t rs = (size_t)slot * L.KR + ring;
+  float m[3][4];
+  keypose_matrix(L.kf_pose + rs * 8, m);
+  const float4* sc_ = L.kf_raw_c + rs * L.kf_cap_c;
+  const float4* ss_ = L.kf_raw_s + rs * L.kf_cap_s;
+  const float4* so_ = L.kf_raw_o + rs * L.kf_cap_o;
   float4* dc = L.map_corner_raw + (size_t)slot * L.map_cap_c + offc;
   float4* ds = L.map_surf_raw + (size_t)slot * L.map_cap_s + offs;  // surf then outlier per key frame (:241-242)
-  for (int i = blockIdx.x * LM_BLOCK + threadIdx.x; i < nc; i += gridDim.x * LM_BLOCK) dc[i] = sc_[i];
-  for (int i = blockIdx.x * LM_BLOCK + threadIdx.x; i < ns; i += gridDim.x * LM_BLOCK) ds[i] = ss_[i];
-  for (int i = blockIdx.x * LM_BLOCK + threadIdx.x; i < no; i += gridDim.x * LM_BLOCK) ds[ns + i] = so_[i];
+  for (int i = blockIdx.x * LM_BLOCK + threadIdx.x; i < nc; i += gridDim.x * LM_BLOCK) dc[i] = kf_transform(m, sc_[i]);
+  for (int i = blockIdx.x * LM_BLOCK + threadIdx.x; i < ns; i += gridDim.x * LM_BLOCK) ds[i] = kf_transform(m, ss_[i]);
+  for (int i = blockIdx.x * LM_BLOCK + threadIdx.x; i < no; i += gridDim.x * LM_BLOCK) ds[ns + i] = kf_transform(m, so_[i]);
   if (j == nk - 1 && blockIdx.x == 0 && threadIdx.x == 0) { li[LI_KRAW_C] = offc + nc; li[LI_KRAW_S] = offs + ns + no; }
 }
 
@@ -165,7 +172,7 @@ __global__ void __launch_bounds__(LM_BLOCK) lm_grid_build(DevCtx d, LmCtx L) {
   __shared__ int s[LM_BLOCK / 64];
   __shared__ int s_run;
   if (threadIdx.x == 0) {
-    const unsigned* bb = L.vox_bbox + ((size_t)(slot - L.vox_slot0) * 2 + m) * 8;
+    const unsigned* bb = d.opt_map_merge ? L.map_bbox + ((size_t)slot * 2 + m) * 8 : L.vox_bbox + ((size_t)(slot - L.vox_slot0) * 2 + m) * 8;
     GridGeom g;
     float mn[3], mx[3];
     for (int a = 0; a < 3; ++a) { mn[a] = vxl_dec(bb[a]); mx[a] = vxl_dec(~bb[4 + a]); }
@@ -672,30 +679,6 @@ __global__ void __launch_bounds__(LM_SOLVE_BLOCK) lm_solve(DevCtx d, LmCtx L) {
   }
 }
 
-// f32 4x4 of transformPointCloud (laserMapping.h:166-173): AngleAxisf(yaw,Z)*AngleAxisf(pitch,Y)*AngleAxisf(roll,X).
-// sin/cos of the half angles are glibc's sinf / cosf (dev_common.h), as Eigen's Quaternionf(AngleAxisf) calls them.
-DEV_INLINE void keypose_matrix(const float* kp, float m[3][4]) {
-  const float hz = 0.5f * kp[5], hy = 0.5f * kp[4], hx = 0.5f * kp[3];
-  const float qz[4] = {d_cosf(hz), 0.f, 0.f, d_sinf(hz)};
-  const float qy[4] = {d_cosf(hy), 0.f, d_sinf(hy), 0.f};
-  const float qx[4] = {d_cosf(hx), d_sinf(hx), 0.f, 0.f};
-  float t[4], q[4];
-  t[0] = qz[0] * qy[0] - qz[1] * qy[1] - qz[2] * qy[2] - qz[3] * qy[3];
-  t[1] = qz[0] * qy[1] + qz[1] * qy[0] + qz[2] * qy[3] - qz[3] * qy[2];
-  t[2] = qz[0] * qy[2] + qz[2] * qy[0] + qz[3] * qy[1] - qz[1] * qy[3];
-  t[3] = qz[0] * qy[3] + qz[3] * qy[0] + qz[1] * qy[2] - qz[2] * qy[1];
-  q[0] = t[0] * qx[0] - t[1] * qx[1] - t[2] * qx[2] - t[3] * qx[3];
-  q[1] = t[0] * qx[1] + t[1] * qx[0] + t[2] * qx[3] - t[3] * qx[2];
-  q[2] = t[0] * qx[2] + t[2] * qx[0] + t[3] * qx[1] - t[1] * qx[3];
-  q[3] = t[0] * qx[3] + t[3] * qx[0] + t[1] * qx[2] - t[2] * qx[1];
-  const float w = q[0], x = q[1], y = q[2], z = q[3];
-  const float tx = 2 * x, ty = 2 * y, tz = 2 * z;
-  const float twx = tx * w, twy = ty * w, twz = tz * w, txx = tx * x, txy = ty * x, txz = tz * x, tyy = ty * y, tyz = tz * y, tzz = tz * z;
-  m[0][0] = 1 - (tyy + tzz); m[0][1] = txy - twz; m[0][2] = txz + twy; m[0][3] = kp[0];
-  m[1][0] = txy + twz; m[1][1] = 1 - (txx + tzz); m[1][2] = tyz - twx; m[1][3] = kp[1];
-  m[2][0] = txz - twy; m[2][1] = tyz + twx; m[2][2] = 1 - (txx + tyy); m[2][3] = kp[2];
-}
-
 // grid (ceil(slots/64)): saveKeyFramesAndFactor :491-559 (no-loop-closure pass-through) + transformUpdate :481-489
 __global__ void lm_finish(DevCtx d, LmCtx L) {
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
@@ -708,7 +691,7 @@ __global__ void lm_finish(DevCtx d, LmCtx L) {
   const int nkf = li[LI_NKF];
   bool add = true;
   if (nkf > 0) {
-    const float* pre = L.kf_pose + ((size_t)slot * L.K + (nkf - 1) % L.K) * 8;
+    const float* pre = L.kf_pose + ((size_t)slot * L.KR + (nkf - 1) % L.KR) * 8;
     const double ex = ld[LD_T_M2L + 0] - (double)pre[0], ey = ld[LD_T_M2L + 1] - (double)pre[1], ez = ld[LD_T_M2L + 2] - (double)pre[2];
     if (ex * ex + ey * ey + ez * ez < d.P.min_keyframe_dist) add = false;  // :501-508
   }
@@ -718,7 +701,7 @@ __global__ void lm_finish(DevCtx d, LmCtx L) {
     const double roll = atan2(R[7], R[8]);
     const double pitch = atan2(-R[6], sqrt(R[7] * R[7] + R[8] * R[8]));
     const double yaw = atan2(R[3], R[0]);
-    float* kp = L.kf_pose + ((size_t)slot * L.K + nkf % L.K) * 8;
+    float* kp = L.kf_pose + ((size_t)slot * L.KR + nkf % L.KR) * 8;
     kp[0] = (float)ld[LD_T_M2L + 0]; kp[1] = (float)ld[LD_T_M2L + 1]; kp[2] = (float)ld[LD_T_M2L + 2];
     kp[3] = (float)roll; kp[4] = (float)pitch; kp[5] = (float)yaw;
     for (int k = 0; k < 6; ++k) ld[LD_PARAMS + k] = (double)kp[k];  // :539-544
@@ -737,37 +720,38 @@ __global__ void lm_finish(DevCtx d, LmCtx L) {
 
 // grid (8, 3, slots): a key frame enters the ring (saveKeyFramesAndFactor :546-555 keeps the down-sampled clouds of the
 // frame in the sensor frame; extractSurroundingKeyFrames :216-218,:240-242 transforms them by the f32 key pose,
-// laserMapping.h:164-177).  Both forms are kept: the raw clouds are what the host pose graph reads back and what a
-// corrected key pose is applied to (alego_lm_get_keyframe / alego_lm_set_keypose).
-//   only_ring < 0: the slots whose LI_KF_ADDED is set store their current scan (raw copy + transform)
+// laserMapping.h:164-177).  The raw clouds go to ring entry f % KR (what the host pose graph reads back and what a corrected
+// key pose is applied to); the transformed clouds go to kf_tmp_* (corner | surf followed by outlier) and are sorted by voxel key
+// into the ring by the next VoxelGrid round (LI_KF_PENDING).
+//   only_ring < 0: the slots whose LI_KF_ADDED is set store their current scan
 //   only_ring >= 0: re-transform ring entry `only_ring` of every slot of the launch from its raw clouds (set_keypose / add_keyframe)
 __global__ void __launch_bounds__(LM_BLOCK) lm_store_kf(DevCtx d, LmCtx L, int only_ring) {
   const int slot = blockIdx.z + d.slot0, kind = blockIdx.y;
   int* li = lip(L, slot);
   if (only_ring < 0 && !li[LI_KF_ADDED]) return;
-  const int ring = only_ring < 0 ? (li[LI_NKF] - 1) % L.K : only_ring;
-  const float* kp = L.kf_pose + ((size_t)slot * L.K + ring) * 8;
+  const int ring = only_ring < 0 ? (li[LI_NKF] - 1) % L.KR : only_ring;
+  const size_t rs = (size_t)slot * L.KR + ring;
   float m[3][4];
-  keypose_matrix(kp, m);
-  const size_t rs = (size_t)slot * L.K + ring;
+  keypose_matrix(L.kf_pose + rs * 8, m);
   float4* raw = kind == 0 ? L.kf_raw_c + rs * L.kf_cap_c : (kind == 1 ? L.kf_raw_s + rs * L.kf_cap_s : L.kf_raw_o + rs * L.kf_cap_o);
   const float4* cur = kind == 0 ? L.cur_corner_ds + (size_t)slot * L.kf_cap_c : (kind == 1 ? L.cur_surf_ds + (size_t)slot * L.kf_cap_s : L.cur_outl_ds + (size_t)slot * L.kf_cap_o);
-  float4* dst = kind == 0 ? L.kf_corner + rs * L.kf_cap_c : (kind == 1 ? L.kf_surf + rs * L.kf_cap_s : L.kf_outl + rs * L.kf_cap_o);
   const int cap = kind == 0 ? L.kf_cap_c : (kind == 1 ? L.kf_cap_s : L.kf_cap_o);
-  const int n_c = li[LI_NCUR_C], n_s = li[LI_NCUR_S], n_o = li[LI_NCUR_O];
-  const int n_new = min(kind == 0 ? n_c : (kind == 1 ? n_s : n_o), cap);
-  const int n = only_ring < 0 ? n_new : L.kf_cnt[rs * 4 + kind];
+  const int* kc = L.kf_cnt + rs * 4;
+  // counts of the three clouds of this key frame (new frame: the current scan's; re-transform: the stored ones)
+  const int n_c = only_ring < 0 ? min(li[LI_NCUR_C], L.kf_cap_c) : kc[0];
+  const int n_s = only_ring < 0 ? min(li[LI_NCUR_S], L.kf_cap_s) : kc[1];
+  const int n_o = only_ring < 0 ? min(li[LI_NCUR_O], L.kf_cap_o) : kc[2];
+  const int n = min(kind == 0 ? n_c : (kind == 1 ? n_s : n_o), cap);
+  float4* dst = kind == 0 ? L.kf_tmp_c + (size_t)slot * L.kf_cap_c : L.kf_tmp_s + (size_t)slot * L.total_cap + (kind == 1 ? 0 : n_s);
   for (int i = blockIdx.x * LM_BLOCK + threadIdx.x; i < n; i += gridDim.x * LM_BLOCK) {
     float4 p;
     if (only_ring < 0) { p = cur[i]; raw[i] = p; } else { p = raw[i]; }
-    float4 o;
-    o.x = m[0][0] * p.x + m[0][1] * p.y + m[0][2] * p.z + m[0][3];
-    o.y = m[1][0] * p.x + m[1][1] * p.y + m[1][2] * p.z + m[1][3];
-    o.z = m[2][0] * p.x + m[2][1] * p.y + m[2][2] * p.z + m[2][3];
-    o.w = p.w;
-    dst[i] = o;
+    dst[i] = kf_transform(m, p);
   }
-  if (only_ring < 0 && blockIdx.x == 0 && threadIdx.x == 0) L.kf_cnt[rs * 4 + kind] = n;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (only_ring < 0) L.kf_cnt[rs * 4 + kind] = n;
+    if (kind == 0) { li[LI_TMPN_C] = n_c; li[LI_TMPN_S] = n_s + n_o; li[LI_KF_PEND_RING] = ring; li[LI_KF_PENDING] = 1; }
+  }
 }
 
 // one thread: correctPoses :579-580 on map -> odom with the 3x4 [R | c] of the loop-closure correction

@@ -1,0 +1,364 @@
+// kernels_map.hip — the local map of LaserMapping from PRE-SORTED key frames
+// (replaces extractSurroundingKeyFrames' concatenation + pcl::VoxelGrid, src/laserMapping.cpp:238-243,:315-319).
+//
+// pcl::VoxelGrid orders its output by idx = i + j dx + k dx dy with (i, j, k) the voxel coordinates relative to the cloud's bounding
+// box: lexicographically by (floor(z/leaf), floor(y/leaf), floor(x/leaf)), whatever the box.  A key frame's transformed clouds never
+// change, so they are sorted by that key ONCE when the frame enters the ring (VoxelGrid kernels, mode 1), and the filtered map of
+// a window is the stable K-way merge of its sorted runs: one output point per occupied voxel in ascending key order, each the f32
+// sum of the voxel's points in window order (run after run, input order inside a run — exactly the order a stable sort of the
+// concatenation gives, which is what the radix-sort path and the oracle sum in) divided by the count.
+//
+//   map_update  (2 maps x slots) keeps, per map, the sorted list U of occupied voxel keys with their point counts.  A window
+//               changes by one run out / one run in, so U is updated incrementally: binary-search decrement for the run that
+//               left, binary-search increment + ordered insertion of the new voxels for the run that entered, empty voxels dropped.
+//               (Any other change — first use, pose corrections, a cleared window — rebuilds U by inserting the runs one by one.)
+//               The last workgroup of the launch writes the work list of map_accum.
+//   map_accum   one workgroup per 1024 consecutive voxels of a map: the runs are visited in window order; a run's points
+//               of the chunk are one contiguous piece (found by binary search), each point finds its voxel by binary search in
+//               the chunk's keys (LDS) and the head of every voxel-run of the piece adds its points to the accumulator (LDS).
+//
+// HBM traffic per rebuild: the window's points once (16 B each) + the new / old run twice + the output, against ~21x that for the
+// radix sort of the concatenation (rocprofv3 FETCH/WRITE counters, round 1).
+#include "dev_common.h"
+#include "lm_ctx.h"
+#include "prof.h"
+
+typedef unsigned long long u64;
+
+#define MU_T 512          // threads of map_update
+#define MA_T 256          // threads of map_accum
+#define MAP_R 1024        // voxels per map_accum work item
+#define MAP_KMAX 512      // window entries held in LDS (alego_create refuses a larger recent_keyframe_num)
+
+DEV_INLINE int* lipm(const LmCtx& L, int slot) { return L.li + (size_t)slot * LI_COUNT; }
+DEV_INLINE const float4* run_pts(const LmCtx& L, int slot, int m, int entry) {
+  return m == 0 ? L.kfs_c + ((size_t)slot * L.KR + entry) * L.kf_cap_c : L.kfs_s + ((size_t)slot * L.KR + entry) * L.total_cap;
+}
+DEV_INLINE int run_n(const LmCtx& L, int slot, int m, int entry) { return L.kfs_n[((size_t)slot * 2 + m) * L.KR + entry]; }
+DEV_INLINE const float* run_box(const LmCtx& L, int slot, int m, int entry) { return L.kfs_box + (((size_t)slot * 2 + m) * L.KR + entry) * 8; }
+DEV_INLINE u64* map_U(const LmCtx& L, int slot, int m) { return m == 0 ? L.U_c + (size_t)slot * L.map_cap_c : L.U_s + (size_t)slot * L.map_cap_s; }
+DEV_INLINE int* map_Ucnt(const LmCtx& L, int slot, int m) { return m == 0 ? L.Ucnt_c + (size_t)slot * L.map_cap_c : L.Ucnt_s + (size_t)slot * L.map_cap_s; }
+DEV_INLINE float4* map_out(const LmCtx& L, int slot, int m) { return m == 0 ? L.map_corner_ds + (size_t)slot * L.map_cap_c : L.map_surf_ds + (size_t)slot * L.map_cap_s; }
+
+DEV_INLINE int lower_bound_U(const u64* U, int n, u64 key) {   // first index with U[i] >= key
+  int lo = 0, hi = n;
+  while (lo < hi) { const int mid = (lo + hi) >> 1; if (U[mid] < key) lo = mid + 1; else hi = mid; }
+  return lo;
+}
+// first index of a sorted run whose key is >= key (strict = false) or > key (strict = true)
+DEV_INLINE int bound_run(const float4* pts, int n, float inv, u64 key, bool strict) {
+  int lo = 0, hi = n;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    const u64 k = vkey_of(pts[mid], inv);
+    if (strict ? k <= key : k < key) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+struct MapWork {
+  int* items;      // [cap] packed (slot - slot0) << 12 | m << 11 | chunk   (chunk < 2048)
+  int* count;      // [2]: items, ticket
+  int cap;
+};
+
+// block-wide exclusive scan of one int per thread (MU_T threads); returns the exclusive prefix, *total = sum
+DEV_INLINE int block_excl_scan(int v, int* s_w /*[MU_T/64 + 1]*/, int* total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int incl = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+  __syncthreads();
+  if (lane == 63) s_w[wave] = incl;
+  __syncthreads();
+  int woff = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < MU_T / 64; ++w) { const int c = s_w[w]; if (w < wave) woff += c; tot += c; }
+  *total = tot;
+  return woff + incl - v;
+}
+
+// grid (2, slots)
+__global__ void __launch_bounds__(MU_T) map_update(DevCtx d, LmCtx L, MapWork W) {
+  const int m = blockIdx.x, slot = blockIdx.y + d.slot0, tid = threadIdx.x;
+  int* li = lipm(L, slot);
+  __shared__ int s_rem[MAP_KMAX], s_add[MAP_KMAX], s_nrem, s_nadd, s_nU, s_nnew, s_err, s_pass;
+  __shared__ int s_w[MU_T / 64 + 1];
+  __shared__ int s_last;
+  const bool active = li[LI_REBUILD] && d.opt_map_merge;
+  if (active) {
+    const float inv = 1.0f / (m == 0 ? d.P.lm_leaf_corner : d.P.lm_leaf_surf);
+    const int cap = m == 0 ? L.map_cap_c : L.map_cap_s;
+    u64* U = map_U(L, slot, m);
+    int* cnt = map_Ucnt(L, slot, m);
+    const int* rec = L.rec + (size_t)slot * L.K;
+    const int ncur = li[LI_REC_CNT];
+    if (tid == 0) {
+      // multiset difference of the two windows (both are non-decreasing lists of frame ids)
+      const int* prev = L.rec_prev + (size_t)slot * L.K;
+      const int np = li[LI_PREV_CNT], nkf = li[LI_NKF];
+      int nr = 0, na = 0;
+      bool valid = li[LI_UVALID] != 0;
+      if (valid) {
+        int a = 0, b = 0;
+        while (a < np || b < ncur) {
+          if (b >= ncur || (a < np && prev[a] < rec[b])) { if (prev[a] < nkf - L.KR) valid = false; s_rem[nr++] = prev[a++] % L.KR; }   // its ring entry must still hold it
+          else if (a >= np || rec[b] < prev[a]) s_add[na++] = rec[b++] % L.KR;
+          else { ++a; ++b; }
+        }
+      }
+      if (!valid) {   // rebuild from nothing: every run of the window is inserted
+        nr = 0; na = 0;
+        for (int b = 0; b < ncur; ++b) s_add[na++] = rec[b] % L.KR;
+      }
+      s_nrem = nr; s_nadd = na; s_nU = valid ? li[LI_NU_C + m] : 0; s_err = 0; s_pass = 0;
+    }
+    __syncthreads();
+    int nU = s_nU;
+    // ---- the runs that left: one decrement per point
+    for (int r = 0; r < s_nrem; ++r) {
+      const float4* pts = run_pts(L, slot, m, s_rem[r]);
+      const int n = run_n(L, slot, m, s_rem[r]);
+      for (int i = tid; i < n; i += MU_T) {
+        const u64 key = vkey_of(pts[i], inv);
+        const int pos = lower_bound_U(U, nU, key);
+        if (pos < nU && U[pos] == key) atomicSub(&cnt[pos], 1); else s_err = 1;
+      }
+    }
+    __threadfence_block();
+    __syncthreads();
+    // ---- the runs that entered, one after the other
+    float4* nk = L.newkeys + ((size_t)slot * 2 + m) * L.total_cap;   // (key lo, key hi, lower bound, count) of the voxels this run adds
+    // scratch of the merge: the map's output buffer (rewritten by map_accum afterwards): keys | counts | exclusive keep-scan
+    u64* S_key = reinterpret_cast<u64*>(map_out(L, slot, m));
+    int* S_cnt = reinterpret_cast<int*>(S_key + cap);
+    int* S_E = S_cnt + cap;
+    const int nadd = s_nadd;
+    for (int a = 0; a <= nadd; ++a) {
+      // (iteration nadd is the purge-only pass when nothing was added but something left)
+      if (a == nadd && !(nadd == 0 && s_nrem > 0)) break;
+      const bool purge_only = a == nadd;
+      const float4* pts = purge_only ? nullptr : run_pts(L, slot, m, s_add[a]);
+      const int n = purge_only ? 0 : run_n(L, slot, m, s_add[a]);
+      if (tid == 0) s_nnew = 0;
+      __syncthreads();
+      // B1: known voxels count the point; the first point of every unknown voxel is collected in run order
+      for (int i0 = 0; i0 < n; i0 += MU_T) {
+        const int i = i0 + tid;
+        bool newhead = false;
+        u64 key = 0;
+        int pos = 0, c = 0;
+        if (i < n) {
+          key = vkey_of(pts[i], inv);
+          pos = lower_bound_U(U, nU, key);
+          const bool found = pos < nU && U[pos] == key;
+          if (found) atomicAdd(&cnt[pos], 1);
+          else if (i == 0 || vkey_of(pts[i - 1], inv) != key) {
+            newhead = true;
+            int i2 = i + 1;
+            while (i2 < n && vkey_of(pts[i2], inv) == key) ++i2;
+            c = i2 - i;
+          }
+        }
+        int tot;
+        const int ex = block_excl_scan(newhead ? 1 : 0, s_w, &tot);
+        const int base = s_nnew;
+        if (newhead) nk[base + ex] = make_float4(__uint_as_float((unsigned)key), __uint_as_float((unsigned)(key >> 32)), __int_as_float(pos), __int_as_float(c));
+        __syncthreads();
+        if (tid == 0) s_nnew = base + tot;
+        __syncthreads();
+      }
+      __threadfence_block();
+      __syncthreads();
+      const int nnew = s_nnew;
+      // B2: merge.  Old entry i (kept iff its count is > 0) goes to E(i) + #{new keys with lower bound <= i}; new key j to E(lb_j) + j,
+      // E = exclusive scan of the keep flags.
+      int kept_total = 0;
+      for (int i0 = 0; i0 < nU; i0 += MU_T) {
+        const int i = i0 + tid;
+        const int c = i < nU ? __hip_atomic_load(&cnt[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+        const int keep = c > 0 ? 1 : 0;
+        int tot;
+        const int ex = kept_total + block_excl_scan(keep, s_w, &tot);
+        if (i < nU) {
+          S_E[i] = ex;
+          if (keep) {
+            int lo = 0, hi = nnew;   // new keys with lower bound <= i
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (__float_as_int(nk[mid].z) <= i) lo = mid + 1; else hi = mid; }
+            const int p = ex + lo;
+            if (p < cap) { S_key[p] = U[i]; S_cnt[p] = c; }
+          }
+        }
+        kept_total += tot;
+      }
+      __threadfence_block();
+      __syncthreads();
+      for (int j = tid; j < nnew; j += MU_T) {
+        const float4 e = nk[j];
+        const int lb = __float_as_int(e.z);
+        const int p = (lb < nU ? S_E[lb] : kept_total) + j;
+        if (p < cap) { S_key[p] = ((u64)__float_as_uint(e.y) << 32) | (u64)__float_as_uint(e.x); S_cnt[p] = __float_as_int(e.w); }
+      }
+      __threadfence_block();
+      __syncthreads();
+      int nU2 = kept_total + nnew;
+      if (nU2 > cap) { nU2 = cap; if (tid == 0) s_err = 2; }
+      for (int i = tid; i < nU2; i += MU_T) { U[i] = S_key[i]; cnt[i] = S_cnt[i]; }
+      __threadfence_block();
+      __syncthreads();
+      nU = nU2;
+    }
+    // ---- window totals, bounding box (for PCL's leaf-size check and for the k-NN grid), outputs
+    float mn[3] = {3.402823466e+38f, 3.402823466e+38f, 3.402823466e+38f}, mx[3] = {-3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f};
+    int kraw = 0;
+    for (int j = 0; j < ncur; ++j) {   // (every thread: K <= 512 small loads, no reduction needed)
+      const int e = rec[j] % L.KR;
+      const int n = run_n(L, slot, m, e);
+      kraw += n;
+      if (n > 0) {
+        const float* b = run_box(L, slot, m, e);
+        mn[0] = fminf(mn[0], b[0]); mn[1] = fminf(mn[1], b[1]); mn[2] = fminf(mn[2], b[2]);
+        mx[0] = fmaxf(mx[0], b[4]); mx[1] = fmaxf(mx[1], b[5]); mx[2] = fmaxf(mx[2], b[6]);
+      }
+    }
+    const long long dx = (long long)((mx[0] - mn[0]) * inv) + 1, dy = (long long)((mx[1] - mn[1]) * inv) + 1, dz = (long long)((mx[2] - mn[2]) * inv) + 1;
+    const bool pass = kraw > 0 && dx * dy * dz > 2147483647LL;   // PCL: "leaf size too small" -> output = input (in the reference's order)
+    if (pass) {
+      float4* out = map_out(L, slot, m);
+      const int* kc = L.kf_cnt + (size_t)slot * L.KR * 4;
+      int off = 0;
+      for (int j = 0; j < ncur; ++j) {
+        const int e = rec[j] % L.KR;
+        const size_t rs = (size_t)slot * L.KR + e;
+        // (the sorted runs lost the input order: the raw clouds are transformed again, in the reference's order)
+        float mm[3][4];
+        keypose_matrix(L.kf_pose + rs * 8, mm);
+        const int n0 = m == 0 ? kc[e * 4 + 0] : kc[e * 4 + 1], n1 = m == 0 ? 0 : kc[e * 4 + 2];
+        const float4* a0 = m == 0 ? L.kf_raw_c + rs * L.kf_cap_c : L.kf_raw_s + rs * L.kf_cap_s;
+        const float4* a1 = L.kf_raw_o + rs * L.kf_cap_o;
+        for (int i = tid; i < n0 && off + i < cap; i += MU_T) out[off + i] = kf_transform(mm, a0[i]);
+        for (int i = tid; i < n1 && off + n0 + i < cap; i += MU_T) out[off + n0 + i] = kf_transform(mm, a1[i]);
+        const int n = n0 + n1;
+        off += n;
+      }
+    }
+    if (tid == 0) {
+      li[LI_NU_C + m] = nU;
+      li[LI_KRAW_C + m] = kraw;
+      li[LI_KDS_C + m] = pass ? min(kraw, cap) : nU;
+      if (pass) atomicOr(&li[LI_MAP_PASS], 1 << m); else atomicAnd(&li[LI_MAP_PASS], ~(1 << m));
+      if (s_err) li[LI_OVERFLOW] = s_err == 2 ? 1 : 4;   // 4: voxel list out of sync with the window (internal error)
+      unsigned* bb = L.map_bbox + ((size_t)slot * 2 + m) * 8;
+      for (int a = 0; a < 3; ++a) { bb[a] = vbox_enc(mn[a]); bb[4 + a] = ~vbox_enc(mx[a]); }
+    }
+  }
+  // ---- the last workgroup of the launch plans map_accum and closes the bookkeeping of every slot
+  __threadfence();
+  __syncthreads();
+  if (tid == 0) s_last = atomicAdd(&W.count[1], 1) == (int)(gridDim.x * gridDim.y) - 1;
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  if (tid == 0) {
+    int n = 0;
+    for (int s = 0; s < d.n_launch; ++s) {
+      int* l2 = lipm(L, s + d.slot0);
+      l2[LI_KF_PENDING] = 0;   // the VoxelGrid round before this kernel has sorted the pending key frame
+      if (!(l2[LI_REBUILD] && d.opt_map_merge)) continue;
+      for (int mm = 0; mm < 2; ++mm) {
+        if ((l2[LI_MAP_PASS] >> mm) & 1) continue;
+        const int nch = (l2[LI_NU_C + mm] + MAP_R - 1) / MAP_R;
+        for (int c = 0; c < nch; ++c) {
+          if (n < W.cap && c < 2048) W.items[n++] = (s << 12) | (mm << 11) | c; else l2[LI_OVERFLOW] = 1;
+        }
+      }
+      const int* rec = L.rec + (size_t)(s + d.slot0) * L.K;
+      int* prev = L.rec_prev + (size_t)(s + d.slot0) * L.K;
+      const int nc = l2[LI_REC_CNT];
+      for (int j = 0; j < nc; ++j) prev[j] = rec[j];
+      l2[LI_PREV_CNT] = nc; l2[LI_UVALID] = 1;
+    }
+    W.count[0] = n;
+    W.count[1] = 0;
+  }
+}
+
+// persistent workgroups over the work list
+__global__ void __launch_bounds__(MA_T) map_accum(DevCtx d, LmCtx L, MapWork W) {
+  __shared__ u64 s_key[MAP_R];
+  __shared__ float4 s_acc[MAP_R];
+  __shared__ int s_cnt[MAP_R];
+  __shared__ int s_lo[MAP_KMAX], s_hi[MAP_KMAX];
+  const int tid = threadIdx.x;
+  const int nitems = W.count[0];
+  for (int it = blockIdx.x; it < nitems; it += gridDim.x) {
+    const int item = W.items[it];
+    const int slot = (item >> 12) + d.slot0, m = (item >> 11) & 1, chunk = item & 2047;
+    const int* li = lipm(L, slot);
+    const float inv = 1.0f / (m == 0 ? d.P.lm_leaf_corner : d.P.lm_leaf_surf);
+    const u64* U = map_U(L, slot, m);
+    const int nU = li[LI_NU_C + m];
+    const int r0 = chunk * MAP_R, nr = min(MAP_R, nU - r0);
+    const int* rec = L.rec + (size_t)slot * L.K;
+    const int nwin = li[LI_REC_CNT];
+    __syncthreads();   // LDS of the previous item is reused
+    for (int r = tid; r < nr; r += MA_T) { s_key[r] = U[r0 + r]; s_acc[r] = make_float4(0.f, 0.f, 0.f, 0.f); s_cnt[r] = 0; }
+    __syncthreads();
+    const u64 key_lo = s_key[0], key_hi = s_key[nr - 1];
+    for (int j = tid; j < nwin; j += MA_T) {   // the piece of every run that falls into this chunk's key range
+      const int e = rec[j] % L.KR;
+      const float4* pts = run_pts(L, slot, m, e);
+      const int n = run_n(L, slot, m, e);
+      s_lo[j] = bound_run(pts, n, inv, key_lo, false);
+      s_hi[j] = bound_run(pts, n, inv, key_hi, true);
+    }
+    __syncthreads();
+    for (int j = 0; j < nwin; ++j) {   // window order = the reference's summation order
+      const int lo = s_lo[j], hi = s_hi[j];
+      if (lo < hi) {
+        const float4* pts = run_pts(L, slot, m, rec[j] % L.KR);
+        for (int i0 = lo; i0 < hi; i0 += MA_T) {
+          const int i = i0 + tid;
+          if (i < hi) {
+            const float4 p = pts[i];
+            const u64 key = vkey_of(p, inv);
+            const bool head = i == lo || vkey_of(pts[i - 1], inv) != key;
+            if (head) {   // the first point of a voxel-run adds the whole run, in order
+              int a = 0, b = nr;
+              while (a < b) { const int mid = (a + b) >> 1; if (s_key[mid] < key) a = mid + 1; else b = mid; }
+              if (a >= nr || s_key[a] != key) { const_cast<int*>(li)[LI_OVERFLOW] = 4; a = min(a, nr - 1); }   // voxel list out of sync (internal error)
+              float4 acc = s_acc[a];
+              int c = 0;
+              float4 q = p;
+              int i2 = i;
+              while (true) {
+                acc.x += q.x; acc.y += q.y; acc.z += q.z; acc.w += q.w; ++c;
+                if (++i2 >= hi) break;
+                q = pts[i2];
+                if (vkey_of(q, inv) != key) break;
+              }
+              s_acc[a] = acc;
+              s_cnt[a] += c;
+            }
+          }
+        }
+      }
+      __syncthreads();
+    }
+    float4* out = map_out(L, slot, m);
+    const int cap = m == 0 ? L.map_cap_c : L.map_cap_s;
+    for (int r = tid; r < nr; r += MA_T) {
+      const float4 a = s_acc[r];
+      const float fn = (float)s_cnt[r];
+      if (r0 + r < cap) out[r0 + r] = make_float4(a.x / fn, a.y / fn, a.z / fn, a.w / fn);
+    }
+  }
+}
+
+void launch_map_update(const DevCtx& d, const LmCtx& L, const MapWork& W, hipStream_t st) {
+  ALEGO_LAUNCH(map_update, dim3(2, d.n_launch), dim3(MU_T), 0, st, d, L, W);
+}
+void launch_map_accum(const DevCtx& d, const LmCtx& L, const MapWork& W, hipStream_t st) {
+  const int grid = std::min(1024, std::max(16, 4 * d.n_launch));
+  ALEGO_LAUNCH(map_accum, dim3(grid), dim3(MA_T), 0, st, d, L, W);
+}

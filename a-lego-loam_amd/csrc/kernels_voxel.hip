@@ -105,9 +105,14 @@ __device__ void vox_big_job(const VoxCtx& V, int job) {
     bb[4 + tid] = ~vx_enc(tid == 0 ? mx[0] : tid == 1 ? mx[1] : mx[2]);
   }
   const long long dx = (long long)((mx[0] - mn[0]) * inv) + 1, dy = (long long)((mx[1] - mn[1]) * inv) + 1, dz = (long long)((mx[2] - mn[2]) * inv) + 1;
+  const int sel = (J.mode == 1 && J.out_sel) ? *J.out_sel : 0;
+  float4* const outp = J.out + (size_t)sel * (J.mode == 1 ? J.out_stride : 0);
+  if (J.mode == 1 && tid < 6 && J.box_out) J.box_out[(size_t)sel * 8 + (tid < 3 ? tid : tid + 1)] = tid == 0 ? mn[0] : tid == 1 ? mn[1] : tid == 2 ? mn[2] : tid == 3 ? mx[0] : tid == 4 ? mx[1] : mx[2];
   if (dx * dy * dz > 2147483647LL) {  // PCL: "leaf size too small" -> output = input
-    for (int i = tid; i < min(n, J.out_cap); i += VG_T) J.out[i] = J.in[i];
-    if (tid == 0) { *J.n_out = min(n, J.out_cap); if (n > J.out_cap && J.overflow) *J.overflow = 1; }
+    // (mode 1: a cloud that cannot be ordered by a 31-bit voxel id is reported as a capacity error)
+    for (int i = tid; i < min(n, J.out_cap); i += VG_T) outp[i] = J.in[i];
+    if (tid == 0) { *J.n_out = min(n, J.out_cap); if ((n > J.out_cap || J.mode == 1) && J.overflow) *J.overflow = J.mode == 1 ? 3 : 1;
+                    if (J.mode == 1 && J.n_sel_out) J.n_sel_out[(size_t)sel * J.n_sel_stride] = min(n, J.out_cap); }
     return;
   }
   int minb[3], divb[3];
@@ -215,6 +220,13 @@ __device__ void vox_big_job(const VoxCtx& V, int job) {
   __threadfence_block();
   __syncthreads();
   VG_TICK(11);
+  if (J.mode == 1) {   // sort only: the points in sorted order
+    for (int i = tid; i < min(n, J.out_cap); i += VG_T) outp[i] = J.in[(unsigned)srt[i]];
+    if (tid == 0) { *J.n_out = min(n, J.out_cap); if (n > J.out_cap && J.overflow) *J.overflow = 1;
+                    if (J.n_sel_out) J.n_sel_out[(size_t)sel * J.n_sel_stride] = min(n, J.out_cap); }
+    __syncthreads();
+    return;
+  }
   // ---- 4. voxel heads: count per segment, prefix over the wavefronts, list of run starts (reuses keys[])
   // head(i) = voxel id differs from the predecessor; bit k of `hm` = lane's element of round k is a head
   auto head_rounds = [&](int r0, bool* head) {
@@ -319,7 +331,9 @@ __device__ void vox_small_job(const VoxCtx& V, int job) {
   __shared__ float s_red[6][VX_SB / 64];
   __shared__ int s_scan[VX_SB / 64];
   __shared__ int s_tot[VS_ND];
-  if (n == 0) { if (tid == 0) *J.n_out = 0; return; }
+  const int sel = (J.mode == 1 && J.out_sel) ? *J.out_sel : 0;
+  float4* const outp = J.out + (size_t)sel * (J.mode == 1 ? J.out_stride : 0);
+  if (n == 0) { if (tid == 0) { *J.n_out = 0; if (J.mode == 1 && J.n_sel_out) J.n_sel_out[(size_t)sel * J.n_sel_stride] = 0; } return; }
   const float inv = 1.0f / J.leaf;
   VG_TICK(0);
   // getMinMax3D
@@ -348,9 +362,11 @@ __device__ void vox_small_job(const VoxCtx& V, int job) {
     bb[4 + tid] = ~vx_enc(tid == 0 ? mx[0] : tid == 1 ? mx[1] : mx[2]);
   }
   const long long dx = (long long)((mx[0] - mn[0]) * inv) + 1, dy = (long long)((mx[1] - mn[1]) * inv) + 1, dz = (long long)((mx[2] - mn[2]) * inv) + 1;
+  if (J.mode == 1 && tid < 6 && J.box_out) J.box_out[(size_t)sel * 8 + (tid < 3 ? tid : tid + 1)] = tid == 0 ? mn[0] : tid == 1 ? mn[1] : tid == 2 ? mn[2] : tid == 3 ? mx[0] : tid == 4 ? mx[1] : mx[2];
   if (dx * dy * dz > 2147483647LL) {  // PCL: "leaf size too small" -> output = input
-    for (int i = tid; i < min(n, J.out_cap); i += VX_SB) J.out[i] = J.in[i];
-    if (tid == 0) { *J.n_out = min(n, J.out_cap); if (n > J.out_cap && J.overflow) *J.overflow = 1; }
+    for (int i = tid; i < min(n, J.out_cap); i += VX_SB) outp[i] = J.in[i];
+    if (tid == 0) { *J.n_out = min(n, J.out_cap); if ((n > J.out_cap || J.mode == 1) && J.overflow) *J.overflow = J.mode == 1 ? 3 : 1;
+                    if (J.mode == 1 && J.n_sel_out) J.n_sel_out[(size_t)sel * J.n_sel_stride] = min(n, J.out_cap); }
     return;
   }
   VG_TICK(1);
@@ -432,6 +448,13 @@ __device__ void vox_small_job(const VoxCtx& V, int job) {
   const unsigned short* srt = (P & 1) ? s_ia : s_ib;
   unsigned short* hl = (P & 1) ? s_ib : s_ia;   // the other buffer: list of voxel run starts
   VG_TICK(3);
+  if (J.mode == 1) {   // sort only: the points in sorted order
+    for (int i = tid; i < min(n, J.out_cap); i += VX_SB) outp[i] = J.in[srt[i]];
+    if (tid == 0) { *J.n_out = min(n, J.out_cap); if (n > J.out_cap && J.overflow) *J.overflow = 1;
+                    if (J.n_sel_out) J.n_sel_out[(size_t)sel * J.n_sel_stride] = min(n, J.out_cap); }
+    __syncthreads();
+    return;
+  }
   // ---- voxel heads: count per segment, prefix over the wavefronts, list of run starts
   int heads = 0;
   for (int r0 = seg0; r0 < seg1; r0 += 64) {
@@ -493,7 +516,7 @@ __global__ void __launch_bounds__(256) vox_plan(VoxCtx V) {
     const VoxJob J = V.jobs[j];
     if (!vx_enabled(J)) continue;
     const int n = min(*J.n_in, J.cap);
-    if (n == 0) { *J.n_out = 0; continue; }
+    if (n == 0) { *J.n_out = 0; if (J.mode == 1 && J.n_sel_out) J.n_sel_out[(size_t)(J.out_sel ? *J.out_sel : 0) * J.n_sel_stride] = 0; continue; }
     if (n <= VX_SMALL_MAX) V.list_small[atomicAdd(&s_n[0], 1)] = j;
     else V.list_big[atomicAdd(&s_n[1], 1)] = j;
   }

@@ -16,6 +16,9 @@ void launch_lm_total(const DevCtx& d, const LmCtx& L, hipStream_t st);
 void launch_lm_grid(const DevCtx& d, const LmCtx& L, hipStream_t st);
 void launch_lm_register(const DevCtx& d, const LmCtx& L, hipStream_t st);
 void launch_lm_retransform(const DevCtx& d, const LmCtx& L, int ring, hipStream_t st);
+struct MapWork { int* items; int* count; int cap; };   // kernels_map.hip
+void launch_map_update(const DevCtx& d, const LmCtx& L, const MapWork& W, hipStream_t st);
+void launch_map_accum(const DevCtx& d, const LmCtx& L, const MapWork& W, hipStream_t st);
 void launch_lm_apply_correction(const DevCtx& d, const LmCtx& L, int slot, const double* rc_dev, hipStream_t st);
 
 struct LmHost {
@@ -28,6 +31,9 @@ struct LmHost {
   // slot: the filters of the current scan do not depend on the map, so they share the map round's three launches;
   // v2: scan surf_total (needs the first round's outputs)
   std::vector<VoxCtx> vm, v2;
+  std::vector<VoxCtx> vk;      // per group: the two key-frame sort jobs of every slot alone (set_keypose / add_keyframe, outside the regular sequence)
+  std::vector<MapWork> work;   // per group: work list of map_accum
+  bool fallback_ok = true;     // buffers of the concat + radix VoxelGrid path (ALEGO_MAP_MERGE=0) are allocated
   std::vector<void*> allocs;
   std::vector<long> frames;  // host mirror of frame_cnt per slot: only used to skip launches
 };
@@ -51,10 +57,15 @@ LmHost* lm_host_create(const alego_params& P, const DevCtx& d, int n_slots, int 
   LmHost* lm = new LmHost();
   lm->P = P; lm->n_slots = n_slots; lm->gsize = gsize; lm->st = st; lm->frames.assign(n_slots, 0);
   VoxCtx vz; std::memset(&vz, 0, sizeof(VoxCtx));
-  lm->vm.assign(st.size(), vz); lm->v2.assign(st.size(), vz);
+  lm->vm.assign(st.size(), vz); lm->v2.assign(st.size(), vz); lm->vk.assign(st.size(), vz);
+  lm->work.assign(st.size(), MapWork{nullptr, nullptr, 0});
   LmCtx& L = lm->L;
   std::memset(&L, 0, sizeof(L));
   L.K = P.recent_keyframe_num > 0 ? P.recent_keyframe_num : 1;
+  L.KR = L.K + 1;
+  // the concat + radix-sort path needs the raw maps and 20 B of sort scratch per map point (~42 MB per stream at 16x1800 / K = 50): large
+  // batches only carry it when they are configured to use it
+  lm->fallback_ok = n_slots <= 64 || !d.opt_map_merge;
   L.in_cap_c = d.fcap[F_LSHARP]; L.in_cap_s = d.N; L.in_cap_o = d.N;
   L.kf_cap_c = d.fcap[F_LSHARP]; L.kf_cap_s = d.N / 2; L.kf_cap_o = d.N / 4;
   L.total_cap = L.kf_cap_s + L.kf_cap_o;
@@ -65,11 +76,15 @@ LmHost* lm_host_create(const alego_params& P, const DevCtx& d, int n_slots, int 
   bool ok = true;
   ok = ok && A(lm, &L.li, B * LI_COUNT, err) && A(lm, &L.ld, B * LD_COUNT, err);
   ok = ok && A(lm, &L.in_corner, B * L.in_cap_c, err) && A(lm, &L.in_surf, B * L.in_cap_s, err) && A(lm, &L.in_outl, B * L.in_cap_o, err);
-  ok = ok && A(lm, &L.kf_corner, B * L.K * L.kf_cap_c, err) && A(lm, &L.kf_surf, B * L.K * L.kf_cap_s, err) && A(lm, &L.kf_outl, B * L.K * L.kf_cap_o, err);
-  ok = ok && A(lm, &L.kf_raw_c, B * L.K * L.kf_cap_c, err) && A(lm, &L.kf_raw_s, B * L.K * L.kf_cap_s, err) && A(lm, &L.kf_raw_o, B * L.K * L.kf_cap_o, err);
-  ok = ok && A(lm, &L.rec, B * L.K, err);
-  ok = ok && A(lm, &L.kf_cnt, B * L.K * 4, err) && A(lm, &L.kf_pose, B * L.K * 8, err);
-  ok = ok && A(lm, &L.map_corner_raw, B * L.map_cap_c, err) && A(lm, &L.map_surf_raw, B * L.map_cap_s, err);
+  ok = ok && A(lm, &L.kfs_c, B * L.KR * L.kf_cap_c, err) && A(lm, &L.kfs_s, B * L.KR * L.total_cap, err);
+  ok = ok && A(lm, &L.kfs_n, B * 2 * L.KR, err) && A(lm, &L.kfs_box, B * 2 * L.KR * 8, err);
+  ok = ok && A(lm, &L.kf_tmp_c, B * L.kf_cap_c, err) && A(lm, &L.kf_tmp_s, B * L.total_cap, err);
+  ok = ok && A(lm, &L.kf_raw_c, B * L.KR * L.kf_cap_c, err) && A(lm, &L.kf_raw_s, B * L.KR * L.kf_cap_s, err) && A(lm, &L.kf_raw_o, B * L.KR * L.kf_cap_o, err);
+  ok = ok && A(lm, &L.rec, B * L.K, err) && A(lm, &L.rec_prev, B * L.K, err);
+  ok = ok && A(lm, &L.kf_cnt, B * L.KR * 4, err) && A(lm, &L.kf_pose, B * L.KR * 8, err);
+  ok = ok && A(lm, &L.U_c, B * L.map_cap_c, err) && A(lm, &L.U_s, B * L.map_cap_s, err) && A(lm, &L.Ucnt_c, B * L.map_cap_c, err) && A(lm, &L.Ucnt_s, B * L.map_cap_s, err);
+  ok = ok && A(lm, &L.newkeys, B * 2 * L.total_cap, err) && A(lm, &L.map_bbox, B * 2 * 8, err);
+  ok = ok && A(lm, &L.map_corner_raw, lm->fallback_ok ? B * L.map_cap_c : 1, err) && A(lm, &L.map_surf_raw, lm->fallback_ok ? B * L.map_cap_s : 1, err);
   ok = ok && A(lm, &L.map_corner_ds, B * L.map_cap_c, err) && A(lm, &L.map_surf_ds, B * L.map_cap_s, err);
   ok = ok && A(lm, &L.cur_corner_ds, B * L.kf_cap_c, err) && A(lm, &L.cur_surf_ds, B * L.kf_cap_s, err) && A(lm, &L.cur_outl_ds, B * L.kf_cap_o, err);
   ok = ok && A(lm, &L.cur_total, B * L.total_cap, err) && A(lm, &L.cur_total_ds, B * L.total_cap, err);
@@ -86,23 +101,39 @@ LmHost* lm_host_create(const alego_params& P, const DevCtx& d, int n_slots, int 
   if (hipMemcpy(L.li, li0.data(), li0.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) { *err = "lm_host_create: upload failed"; lm_host_destroy(lm); return nullptr; }
   // VoxelGrid job tables (laserMapping.cpp:37-39,316-319,329-342)
   for (size_t g = 0; g < st.size(); ++g) {
-  std::vector<VoxJob> jm, j1, j2;
+  std::vector<VoxJob> jm, j1, j2, jk;
   for (size_t b = g * gsize; b < B && b < (g + 1) * (size_t)gsize; ++b) {
     int* li = L.li + b * LI_COUNT;
-    jm.push_back(VoxJob{L.map_corner_raw + b * L.map_cap_c, li + LI_KRAW_C, L.map_corner_ds + b * L.map_cap_c, li + LI_KDS_C, li + LI_REBUILD, P.lm_leaf_corner, L.map_cap_c, L.map_cap_c, li + LI_OVERFLOW, 0});
-    jm.push_back(VoxJob{L.map_surf_raw + b * L.map_cap_s, li + LI_KRAW_S, L.map_surf_ds + b * L.map_cap_s, li + LI_KDS_S, li + LI_REBUILD, P.lm_leaf_surf, L.map_cap_s, L.map_cap_s, li + LI_OVERFLOW, 0});
+    if (lm->fallback_ok) {   // the maps by concat + radix sort (ALEGO_MAP_MERGE=0)
+      jm.push_back(VoxJob{L.map_corner_raw + b * L.map_cap_c, li + LI_KRAW_C, L.map_corner_ds + b * L.map_cap_c, li + LI_KDS_C, li + LI_REBUILD_FB, P.lm_leaf_corner, L.map_cap_c, L.map_cap_c, li + LI_OVERFLOW, 0});
+      jm.push_back(VoxJob{L.map_surf_raw + b * L.map_cap_s, li + LI_KRAW_S, L.map_surf_ds + b * L.map_cap_s, li + LI_KDS_S, li + LI_REBUILD_FB, P.lm_leaf_surf, L.map_cap_s, L.map_cap_s, li + LI_OVERFLOW, 0});
+    }
     j1.push_back(VoxJob{L.in_corner + b * L.in_cap_c, li + LI_NIN_C, L.cur_corner_ds + b * L.kf_cap_c, li + LI_NCUR_C, li + LI_RUN, P.lm_leaf_corner, L.in_cap_c, L.kf_cap_c, li + LI_OVERFLOW, 0});
     j1.push_back(VoxJob{L.in_surf + b * L.in_cap_s, li + LI_NIN_S, L.cur_surf_ds + b * L.kf_cap_s, li + LI_NCUR_S, li + LI_RUN, P.lm_leaf_surf, L.in_cap_s, L.kf_cap_s, li + LI_OVERFLOW, 0});
     j1.push_back(VoxJob{L.in_outl + b * L.in_cap_o, li + LI_NIN_O, L.cur_outl_ds + b * L.kf_cap_o, li + LI_NCUR_O, li + LI_RUN, P.lm_leaf_outlier, L.in_cap_o, L.kf_cap_o, li + LI_OVERFLOW, 0});
     j2.push_back(VoxJob{L.cur_total + b * L.total_cap, li + LI_NTOTAL, L.cur_total_ds + b * L.total_cap, li + LI_NTOTAL_DS, li + LI_RUN, P.lm_leaf_surf, L.total_cap, L.total_cap, li + LI_OVERFLOW, 0});
+    // the key frame waiting in kf_tmp_*: sorted by voxel key of the map's leaf into its ring entry (mode 1)
+    VoxJob kc{L.kf_tmp_c + b * L.kf_cap_c, li + LI_TMPN_C, L.kfs_c + b * L.KR * L.kf_cap_c, li + LI_SORT_N, li + LI_KF_PENDING, P.lm_leaf_corner, L.kf_cap_c, L.kf_cap_c, li + LI_OVERFLOW, 0};
+    kc.mode = 1; kc.out_sel = li + LI_KF_PEND_RING; kc.out_stride = L.kf_cap_c;
+    kc.box_out = L.kfs_box + (b * 2 + 0) * L.KR * 8; kc.n_sel_out = L.kfs_n + (b * 2 + 0) * L.KR; kc.n_sel_stride = 1;
+    VoxJob ks{L.kf_tmp_s + b * L.total_cap, li + LI_TMPN_S, L.kfs_s + b * L.KR * L.total_cap, li + LI_SORT_N + 1, li + LI_KF_PENDING, P.lm_leaf_surf, L.total_cap, L.total_cap, li + LI_OVERFLOW, 0};
+    ks.mode = 1; ks.out_sel = li + LI_KF_PEND_RING; ks.out_stride = L.total_cap;
+    ks.box_out = L.kfs_box + (b * 2 + 1) * L.KR * 8; ks.n_sel_out = L.kfs_n + (b * 2 + 1) * L.KR; ks.n_sel_stride = 1;
+    jk.push_back(kc); jk.push_back(ks);
   }
-  const int ns = (int)jm.size() / 2;
+  const int ns = (int)j1.size() / 3;
   jm.insert(jm.end(), j1.begin(), j1.end());
-  if (vox_create(&lm->vm[g], jm.data(), (int)jm.size(), err) || vox_create(&lm->v2[g], j2.data(), (int)j2.size(), err)) { lm_host_destroy(lm); return nullptr; }
-  // Expected work per context: the maps are rebuilt for ~1 stream in 8 per mapping frame and are only small while a stream
-  // is young; the current-scan clouds practically never exceed 8192 points.  Fewer persistent workgroups there (they loop).
-  lm->vm[g].grid_small = 3 * ns + std::max(2, ns / 4); lm->vm[g].grid_big = std::max(2, ns / 2);
+  jm.insert(jm.end(), jk.begin(), jk.end());
+  if (vox_create(&lm->vm[g], jm.data(), (int)jm.size(), err) || vox_create(&lm->v2[g], j2.data(), (int)j2.size(), err) ||
+      vox_create(&lm->vk[g], jk.data(), (int)jk.size(), err)) { lm_host_destroy(lm); return nullptr; }
+  // Expected work per context: the current-scan clouds and key frames practically never exceed 8192 points (vox_small); a key frame
+  // is sorted for ~1 stream in 5 per mapping frame.  Fewer persistent workgroups where little is expected (they loop).
+  lm->vm[g].grid_small = 3 * ns + std::max(2, ns / 2); lm->vm[g].grid_big = std::max(2, ns / 2);
   lm->v2[g].grid_big = std::max(1, ns / 16);
+  lm->vk[g].grid_small = 2; lm->vk[g].grid_big = 2;
+  MapWork& W = lm->work[g];
+  W.cap = std::max(4096, 32 * ns);
+  if (!A(lm, &W.items, (size_t)W.cap, err) || !A(lm, &W.count, 2, err)) { lm_host_destroy(lm); return nullptr; }
   }
   return lm;
 }
@@ -111,6 +142,7 @@ void lm_host_destroy(LmHost* lm) {
   if (!lm) return;
   for (auto& v : lm->vm) vox_destroy(&v);
   for (auto& v : lm->v2) vox_destroy(&v);
+  for (auto& v : lm->vk) vox_destroy(&v);
   for (void* p : lm->allocs) (void)hipFree(p);
   delete lm;
 }
@@ -125,15 +157,34 @@ static bool dbg_sync(hipStream_t st, const char* what, std::string* err) {
   return true;
 }
 
-// a key frame's transformed clouds were (re)written outside the regular sequence (set_keypose / add_keyframe)
-static void lm_kf_changed(LmHost*, const DevCtx&, int, hipStream_t) {}
+// A key frame's clouds were (re)written outside the regular sequence (set_keypose / add_keyframe): sort it into the ring now and
+// make the next map update rebuild its voxel lists from scratch.
+static void lm_kf_changed(LmHost* lm, const DevCtx& d, int /*ring*/, hipStream_t st) {
+  const int g = d.slot0 / lm->gsize;
+  std::string e;
+  (void)vox_run(lm->vk[g], st, &e);
+  const int zero = 0;
+  int* li = lm->L.li + (size_t)d.slot0 * LI_COUNT;
+  (void)hipMemcpyAsync(li + LI_KF_PENDING, &zero, sizeof(int), hipMemcpyHostToDevice, st);
+  (void)hipMemcpyAsync(li + LI_UVALID, &zero, sizeof(int), hipMemcpyHostToDevice, st);
+}
 
-// concat + VoxelGrid of the maps + grid, for the slots whose window changed (LI_REBUILD, set by lm_prepare)
+// the local maps of the slots whose window changed (LI_REBUILD, set by lm_prepare) + the VoxelGrid filters of the scan's three
+// clouds + the sort of a pending key frame, then the k-NN grids
 static int map_sequence(LmHost* lm, const DevCtx& d, const LmCtx& L, int g, hipStream_t st, std::string* err) {
-  launch_lm_concat(d, L, st);
-  if (!dbg_sync(st, "lm_concat", err)) return ALEGO_ERR_HIP;
+  if (!d.opt_map_merge) {
+    if (!lm->fallback_ok) { *err = "ALEGO_MAP_MERGE=0 needs the handle to be created with it (more than 64 slots)"; return ALEGO_ERR_ARG; }
+    launch_lm_concat(d, L, st);
+    if (!dbg_sync(st, "lm_concat", err)) return ALEGO_ERR_HIP;
+  }
   if (int r = vox_run(lm->vm[g], st, err)) return r;
-  if (!dbg_sync(st, "vox map", err)) return ALEGO_ERR_HIP;
+  if (!dbg_sync(st, "vox round 1", err)) return ALEGO_ERR_HIP;
+  launch_map_update(d, L, lm->work[g], st);   // (also closes the key-frame sort's bookkeeping when the maps come from the radix path)
+  if (!dbg_sync(st, "map_update", err)) return ALEGO_ERR_HIP;
+  if (d.opt_map_merge) {
+    launch_map_accum(d, L, lm->work[g], st);
+    if (!dbg_sync(st, "map_accum", err)) return ALEGO_ERR_HIP;
+  }
   launch_lm_grid(d, L, st);
   if (!dbg_sync(st, "lm_grid", err)) return ALEGO_ERR_HIP;
   return 0;
@@ -268,7 +319,7 @@ int lm_host_get_keyframe(LmHost* lm, int slot, int kf_id, alego_keyframe* out, s
   if (nkf < 0) { *err = "get_keyframe: device error"; return nkf; }
   if (kf_id < 0) kf_id = nkf - 1;
   if (kf_id < 0 || kf_id >= nkf || kf_id < nkf - L.K) { *err = "get_keyframe: key frame not resident (only the recent_keyframe_num newest are)"; return ALEGO_ERR_ARG; }
-  const size_t rs = (size_t)slot * L.K + kf_id % L.K;
+  const size_t rs = (size_t)slot * L.KR + kf_id % L.KR;
   int cnt[4];
   float kp[8];
   if (hipMemcpy(cnt, L.kf_cnt + rs * 4, sizeof(cnt), hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(kp, L.kf_pose + rs * 8, sizeof(kp), hipMemcpyDeviceToHost) != hipSuccess) { *err = "get_keyframe: copy failed"; return ALEGO_ERR_HIP; }
@@ -287,6 +338,12 @@ static int retransform(LmHost* lm, const DevCtx& dfull, int slot, int ring, std:
   DevCtx d = dfull;
   d.slot0 = slot; d.n_launch = 1;
   hipStream_t st = stream_of_slot(lm, slot);
+  const int g = slot / lm->gsize;
+  const int zero = 0;
+  int* li = lm->L.li + (size_t)slot * LI_COUNT;
+  // a key frame saved by the last mapping frame may still wait in kf_tmp_* for its sort: flush it before the buffer is reused
+  if (int r = vox_run(lm->vk[g], st, err)) return r;
+  (void)hipMemcpyAsync(li + LI_KF_PENDING, &zero, sizeof(int), hipMemcpyHostToDevice, st);
   launch_lm_retransform(d, lm->L, ring, st);
   lm_kf_changed(lm, d, ring, st);
   if (hipStreamSynchronize(st) != hipSuccess) { *err = "key-frame transform failed"; return ALEGO_ERR_HIP; }
@@ -297,8 +354,8 @@ int lm_host_set_keypose(LmHost* lm, const DevCtx& dfull, int slot, int kf_id, co
   const int nkf = lm_host_keyframe_count(lm, slot);
   if (nkf < 0) return nkf;
   if (kf_id < 0 || kf_id >= nkf || kf_id < nkf - L.K) { *err = "set_keypose: key frame not resident"; return ALEGO_ERR_ARG; }
-  const int ring = kf_id % L.K;
-  if (hipMemcpy(L.kf_pose + ((size_t)slot * L.K + ring) * 8, pose6, 6 * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) { *err = "set_keypose: copy failed"; return ALEGO_ERR_HIP; }
+  const int ring = kf_id % L.KR;
+  if (hipMemcpy(L.kf_pose + ((size_t)slot * L.KR + ring) * 8, pose6, 6 * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) { *err = "set_keypose: copy failed"; return ALEGO_ERR_HIP; }
   return retransform(lm, dfull, slot, ring, err);
 }
 int lm_host_reset_window(LmHost* lm, int slot, std::string* err) {
@@ -306,7 +363,8 @@ int lm_host_reset_window(LmHost* lm, int slot, std::string* err) {
   const int v[2] = {0, 1};
   int* li = lm->L.li + (size_t)slot * LI_COUNT;
   if (hipStreamSynchronize(stream_of_slot(lm, slot)) != hipSuccess || hipMemcpy(li + LI_REC_CNT, &v[0], sizeof(int), hipMemcpyHostToDevice) != hipSuccess ||
-      hipMemcpy(li + LI_DIRTY, &v[1], sizeof(int), hipMemcpyHostToDevice) != hipSuccess) { *err = "reset_window failed"; return ALEGO_ERR_HIP; }
+      hipMemcpy(li + LI_DIRTY, &v[1], sizeof(int), hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(li + LI_UVALID, &v[0], sizeof(int), hipMemcpyHostToDevice) != hipSuccess) { *err = "reset_window failed"; return ALEGO_ERR_HIP; }
   return 0;
 }
 int lm_host_apply_correction(LmHost* lm, const DevCtx& dfull, int slot, const double* rc12, std::string* err) {
@@ -326,8 +384,8 @@ int lm_host_add_keyframe(LmHost* lm, const DevCtx& dfull, int slot, const float*
   if (nc > L.kf_cap_c || ns > L.kf_cap_s || no > L.kf_cap_o) { *err = "add_keyframe: cloud exceeds the key-frame capacity"; return ALEGO_ERR_CAPACITY; }
   const int nkf = lm_host_keyframe_count(lm, slot);
   if (nkf < 0) return nkf;
-  const int ring = nkf % L.K;
-  const size_t rs = (size_t)slot * L.K + ring;
+  const int ring = nkf % L.KR;
+  const size_t rs = (size_t)slot * L.KR + ring;
   float kp[8] = {pose6[0], pose6[1], pose6[2], pose6[3], pose6[4], pose6[5], 0.f, 0.f};
   const int cnt[4] = {nc, ns, no, 0};
   int* li = L.li + (size_t)slot * LI_COUNT;
@@ -341,6 +399,16 @@ int lm_host_add_keyframe(LmHost* lm, const DevCtx& dfull, int slot, const float*
   if (e == hipSuccess) e = hipMemcpy(li + LI_DIRTY, &one, sizeof(int), hipMemcpyHostToDevice);
   if (e != hipSuccess) { *err = std::string("add_keyframe: ") + hipGetErrorString(e); return ALEGO_ERR_HIP; }
   return retransform(lm, dfull, slot, ring, err);
+}
+
+// ALEGO_MAP_MERGE switched at run time (tests): the voxel lists no longer describe what the other path did in between
+int lm_host_set_map_merge(LmHost* lm, int on, std::string* err) {
+  if (!on && !lm->fallback_ok) { *err = "ALEGO_MAP_MERGE=0 needs the handle to be created with it (more than 64 slots)"; return ALEGO_ERR_ARG; }
+  for (hipStream_t s : lm->st) (void)hipStreamSynchronize(s);
+  const int zero = 0;
+  for (int b = 0; b < lm->n_slots; ++b)
+    if (hipMemcpy(lm->L.li + (size_t)b * LI_COUNT + LI_UVALID, &zero, sizeof(int), hipMemcpyHostToDevice) != hipSuccess) { *err = "set_map_merge: copy failed"; return ALEGO_ERR_HIP; }
+  return 0;
 }
 
 int lm_host_debug_get(LmHost* lm, int slot, const char* name, void* out, int cap_bytes, int* count, int* dtype, std::string* err) {
@@ -364,16 +432,19 @@ int lm_host_debug_get(LmHost* lm, int slot, const char* name, void* out, int cap
   else if (s == "lm_outlier_ds") set(L.cur_outl_ds + b * L.kf_cap_o, (size_t)li[LI_NCUR_O] * 4, 0);
   else if (s == "lm_surf_total_ds") set(L.cur_total_ds + b * L.total_cap, (size_t)li[LI_NTOTAL_DS] * 4, 0);
   else if (s == "lm_blocks") set(L.blocks + b * L.qcap * 8, (size_t)L.qcap * 8, 1);
-  else if (s == "lm_keyposes") set(L.kf_pose + b * L.K * 8, (size_t)L.K * 8, 0);
-  else if (s == "lm_kf_corner_map" || s == "lm_kf_surf_map" || s == "lm_kf_outlier_map") {   // newest key frame, transformed into the map frame
+  else if (s == "lm_keyposes") set(L.kf_pose + b * L.KR * 8, (size_t)L.KR * 8, 0);
+  else if (s == "lm_kf_corner_map" || s == "lm_kf_surf_map") {   // newest key frame in the map frame, sorted by voxel key (surf = surf + outlier)
     const int nkf = li[LI_NKF];
     if (nkf <= 0) { *count = 0; *dtype = 0; return 0; }
-    const size_t rs = b * L.K + (size_t)((nkf - 1) % L.K);
-    int kc[4];
-    (void)hipMemcpy(kc, L.kf_cnt + rs * 4, sizeof(kc), hipMemcpyDeviceToHost);
-    if (s == "lm_kf_corner_map") set(L.kf_corner + rs * L.kf_cap_c, (size_t)kc[0] * 4, 0);
-    else if (s == "lm_kf_surf_map") set(L.kf_surf + rs * L.kf_cap_s, (size_t)kc[1] * 4, 0);
-    else set(L.kf_outl + rs * L.kf_cap_o, (size_t)kc[2] * 4, 0);
+    const int e = (nkf - 1) % L.KR, m = s == "lm_kf_corner_map" ? 0 : 1;
+    int n = 0;
+    (void)hipMemcpy(&n, L.kfs_n + (b * 2 + m) * L.KR + e, sizeof(int), hipMemcpyDeviceToHost);
+    if (m == 0) set(L.kfs_c + (b * L.KR + e) * L.kf_cap_c, (size_t)n * 4, 0);
+    else set(L.kfs_s + (b * L.KR + e) * L.total_cap, (size_t)n * 4, 0);
+  }
+  else if (s == "lm_voxel_keys_c" || s == "lm_voxel_keys_s") {   // the sorted voxel-key list of a map as pairs of i32 (lo, hi)
+    const int m = s == "lm_voxel_keys_c" ? 0 : 1;
+    set(m == 0 ? (const void*)(L.U_c + b * L.map_cap_c) : (const void*)(L.U_s + b * L.map_cap_s), (size_t)li[LI_NU_C + m] * 2, 2);
   }
   else { *err = std::string("debug_get: unknown name ") + name; return ALEGO_ERR_ARG; }
   if ((size_t)cap_bytes < n * esz) { *err = "debug_get: buffer too small"; return ALEGO_ERR_CAPACITY; }

@@ -21,6 +21,15 @@ struct VoxJob {
   int out_cap;          // capacity of out: further voxels are dropped and *overflow is raised
   int* overflow;        // device flag (may be nullptr), set to 1 when the output was truncated
   int off;              // offset of this job's region in the key / pair scratch arrays (filled by vox_create)
+  // mode 1 ("sort only"): out = the input points in ascending voxel id (stable: the order inside a voxel is the input order),
+  // n_out = n.  Used when a key frame enters LaserMapping's ring: PCL's voxel id orders points by (floor(z/leaf), floor(y/leaf),
+  // floor(x/leaf)) whatever the bounding box, so key frames sorted once can be merged into every local map they belong to.
+  int mode;
+  const int* out_sel;   // mode 1 (may be nullptr): the output goes to out + *out_sel * out_stride (ring entry chosen on the device)
+  int out_stride;
+  float* box_out;       // mode 1 (may be nullptr): min xyz / max xyz of the cloud as 8 floats at box_out + *out_sel * 8
+  int* n_sel_out;       // mode 1 (may be nullptr): n is also stored at n_sel_out[*out_sel * n_sel_stride]
+  int n_sel_stride;
 };
 
 struct VoxCtx {

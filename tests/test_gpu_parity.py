@@ -347,15 +347,23 @@ def test_full_loop_teacher_forced(geom, nscan, mods):
     h.close()
 
 
-def test_recent_keyframe_deque_quirk():
+@pytest.mark.parametrize("map_path", ["merge", "radix", "switching"])
+def test_recent_keyframe_deque_quirk(map_path):
     """The local-map window past its fill-up: with latest_frame_id_ starting at -1 (laserMapping.cpp:50,227-236) the first
     mapping frame after the deque filled pushes the newest key frame a second time; the duplicate then slides through the
-    window.  4-key-frame window, a key frame every ~3 scans: fill, duplicate, slide-out, all compared map by map."""
+    window.  4-key-frame window, a key frame every ~3 scans: fill, duplicate, slide-out, all compared map by map.
+    map_path: the local map from the pre-sorted key frames with incrementally maintained voxel lists (default), from the
+    concatenation + radix-sort VoxelGrid (ALEGO_MAP_MERGE=0), or switching between the two every 7 scans (each switch makes
+    the merge path rebuild its voxel lists from scratch)."""
     p = synth.default_params(16, 1800)
     p.recent_keyframe_num = 4
     p.min_keyframe_dist = 0.09
     h, o = binding.Handle(p), O.Oracle(p)
+    if map_path == "radix":
+        h.set_option("ALEGO_MAP_MERGE", 0)
     for k in range(70):
+        if map_path == "switching" and k % 7 == 0:
+            h.set_option("ALEGO_MAP_MERGE", (k // 7) % 2)
         pts = synth.scan(p, k)
         h.set_lo_params(o.get("lo_params"))
         h.set_lm_params(o.get("lm_params"))
@@ -696,8 +704,18 @@ def test_device_sinf_cosf_and_keypose_transform(params_a):
         assert kf["id"] == nkf - 1
         assert_bit_equal(kf["pose"], pose, "key pose read back")
         assert_bit_equal(kf["surf"], cloud[300:1200], "raw key-frame cloud read back")
+        # the ring keeps the transformed clouds sorted by voxel key (surf followed by outlier as one run): same multiset
         got = h.debug_get("lm_kf_surf_map", cap_bytes=1 << 22).reshape(-1, 4)
-        assert_bit_equal(got[:900], O.transform_cloud(pose, cloud[300:1200]), "transformed key-frame cloud")
+        want = O.transform_cloud(pose, cloud[300:])
+        assert got.shape == want.shape
+        srt = lambda a: a[np.lexsort(a.view(np.uint32).T[::-1])]
+        assert_bit_equal(srt(got), srt(want), "transformed key-frame cloud (surf + outlier)")
+        inv = np.float32(1.0) / np.float32(params_a.lm_leaf_surf)
+        vox = np.floor(got[:, :3] * inv).astype(np.int64)
+        key = (vox[:, 2] << 42) + (vox[:, 1] << 21) + vox[:, 0]
+        assert np.all(np.diff(key) >= 0), "ring entry is not sorted by (z, y, x) voxel"
+        got_c = h.debug_get("lm_kf_corner_map", cap_bytes=1 << 22).reshape(-1, 4)
+        assert_bit_equal(srt(got_c), srt(O.transform_cloud(pose, cloud[:300])), "transformed key-frame cloud (corner)")
     h.close()
 
 

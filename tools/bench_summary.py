@@ -1,7 +1,12 @@
 import json, sys
-d = json.loads(sys.stdin.read().strip().splitlines()[-1])
+src = open(sys.argv[1]) if len(sys.argv) > 1 and not sys.argv[1].isdigit() else sys.stdin
+d = json.loads(src.read().strip().splitlines()[-1])
 print("value", d["value"], "ms/step", d["ms_per_step"], "single", d.get("single_stream_scans_per_s"), "cpu", (d.get("cpu_baseline") or {}).get("value"))
 if "roofline" in d: print("roofline", d["roofline"])
 print("pipeline", d.get("pipeline_roofline"))
-for k, v in list(d.get("kernels", {}).items())[:int(sys.argv[1]) if len(sys.argv) > 1 else 24]:
+print("counts", d.get("counts"))
+cb = d.get("cpu_baseline") or {}
+print("cpu_pipe3", cb.get("cpu_pipe3"), "cpu_replicas", cb.get("cpu_replicas"))
+print("parity", d.get("parity"))
+for k, v in list(d.get("kernels", {}).items())[:40]:
     print("%-28s %9.1f us x%4d %5.1f%%" % (k, v["avg_us"], v["launches"], 100 * v["share"]))
