@@ -26,8 +26,12 @@
 typedef unsigned long long u64;
 
 #define MU_T 512          // threads of map_update
-#define MA_T 256          // threads of map_accum
+#ifndef MA_T
+#define MA_T 256          // threads of map_accum (one wavefront per item of 256 voxels was measured: 533 us against 439 us per launch)
+#endif
+#ifndef MAP_R
 #define MAP_R 1024        // voxels per map_accum work item
+#endif
 #define MAP_KMAX 512      // window entries held in LDS (alego_create refuses a larger recent_keyframe_num)
 
 DEV_INLINE int* lipm(const LmCtx& L, int slot) { return L.li + (size_t)slot * LI_COUNT; }
@@ -78,13 +82,19 @@ DEV_INLINE int block_excl_scan(int v, int* s_w /*[MU_T/64 + 1]*/, int* total) {
   return woff + incl - v;
 }
 
-// grid (2, slots)
+#define MU_FCAP 4096      // points of a run whose voxel keys the fast path of map_update stages in LDS (2 x 32 KB)
+#define MU_E 16           // consecutive entries of the voxel list per thread in the fast path
+
+// grid (2, slots); dynamic LDS: 2 * MU_FCAP * 8 bytes
 __global__ void __launch_bounds__(MU_T) map_update(DevCtx d, LmCtx L, MapWork W) {
   const int m = blockIdx.x, slot = blockIdx.y + d.slot0, tid = threadIdx.x;
   int* li = lipm(L, slot);
   __shared__ int s_rem[MAP_KMAX], s_add[MAP_KMAX], s_nrem, s_nadd, s_nU, s_nnew, s_err, s_pass;
   __shared__ int s_w[MU_T / 64 + 1];
   __shared__ int s_last;
+  __shared__ float s_box[6][MU_T / 64];
+  __shared__ int s_kr_tot[MU_T / 64];
+  extern __shared__ __attribute__((aligned(16))) unsigned char mu_smem[];
   const bool active = li[LI_REBUILD] && d.opt_map_merge;
   if (active) {
     const float inv = 1.0f / (m == 0 ? d.P.lm_leaf_corner : d.P.lm_leaf_surf);
@@ -93,28 +103,95 @@ __global__ void __launch_bounds__(MU_T) map_update(DevCtx d, LmCtx L, MapWork W)
     int* cnt = map_Ucnt(L, slot, m);
     const int* rec = L.rec + (size_t)slot * L.K;
     const int ncur = li[LI_REC_CNT];
-    if (tid == 0) {
-      // multiset difference of the two windows (both are non-decreasing lists of frame ids)
+    {
+      // the two windows into LDS (s_add / s_rem double as staging), then their multiset difference by one thread:
+      // both are non-decreasing lists of frame ids
       const int* prev = L.rec_prev + (size_t)slot * L.K;
       const int np = li[LI_PREV_CNT], nkf = li[LI_NKF];
-      int nr = 0, na = 0;
-      bool valid = li[LI_UVALID] != 0;
-      if (valid) {
-        int a = 0, b = 0;
-        while (a < np || b < ncur) {
-          if (b >= ncur || (a < np && prev[a] < rec[b])) { if (prev[a] < nkf - L.KR) valid = false; s_rem[nr++] = prev[a++] % L.KR; }   // its ring entry must still hold it
-          else if (a >= np || rec[b] < prev[a]) s_add[na++] = rec[b++] % L.KR;
-          else { ++a; ++b; }
+      int* s_cur = reinterpret_cast<int*>(mu_smem);
+      int* s_prev = s_cur + MAP_KMAX;
+      for (int j = tid; j < ncur; j += MU_T) s_cur[j] = rec[j];
+      for (int j = tid; j < np; j += MU_T) s_prev[j] = prev[j];
+      __syncthreads();
+      if (tid == 0) {
+        int nr = 0, na = 0;
+        bool valid = li[LI_UVALID] != 0;
+        if (valid) {
+          int a = 0, b = 0;
+          while (a < np || b < ncur) {
+            if (b >= ncur || (a < np && s_prev[a] < s_cur[b])) { if (s_prev[a] < nkf - L.KR) valid = false; s_rem[nr++] = s_prev[a++] % L.KR; }   // its ring entry must still hold it
+            else if (a >= np || s_cur[b] < s_prev[a]) s_add[na++] = s_cur[b++] % L.KR;
+            else { ++a; ++b; }
+          }
         }
+        if (!valid) {   // rebuild from nothing: every run of the window is inserted
+          nr = 0; na = 0;
+          for (int b = 0; b < ncur; ++b) s_add[na++] = s_cur[b] % L.KR;
+        }
+        s_nrem = nr; s_nadd = na; s_nU = valid ? li[LI_NU_C + m] : 0; s_err = 0; s_pass = 0;
       }
-      if (!valid) {   // rebuild from nothing: every run of the window is inserted
-        nr = 0; na = 0;
-        for (int b = 0; b < ncur; ++b) s_add[na++] = rec[b] % L.KR;
-      }
-      s_nrem = nr; s_nadd = na; s_nU = valid ? li[LI_NU_C + m] : 0; s_err = 0; s_pass = 0;
     }
     __syncthreads();
     int nU = s_nU;
+    u64* S_key = reinterpret_cast<u64*>(map_out(L, slot, m));   // scratch of the merges: the map's output buffer (rewritten by map_accum afterwards)
+    int* S_cnt = reinterpret_cast<int*>(S_key + cap);
+    const int nR = s_nrem == 1 ? run_n(L, slot, m, s_rem[0]) : 0, nA = s_nadd == 1 ? run_n(L, slot, m, s_add[0]) : 0;
+    const bool fast = nU > 0 && s_nrem <= 1 && s_nadd <= 1 && nR <= MU_FCAP && nA <= MU_FCAP;
+    if (fast) {
+      // ---- steady state: one run out, one run in.  The voxel keys of both runs are staged in LDS (sorted, as the runs are);
+      // every thread owns MU_E consecutive entries of the list, finds the pieces of both runs that fall into its key interval by
+      // binary search and merges the three sorted sequences: counts go down / up, new voxels are inserted in order, empty ones
+      // disappear.  No atomics; two passes (count, write) around one scan.
+      u64* s_kr = reinterpret_cast<u64*>(mu_smem);
+      u64* s_ka = s_kr + MU_FCAP;
+      __syncthreads();   // (the window lists staged in the same LDS are dead)
+      if (nR) { const float4* pts = run_pts(L, slot, m, s_rem[0]); for (int i = tid; i < nR; i += MU_T) s_kr[i] = vkey_of(pts[i], inv); }
+      if (nA) { const float4* pts = run_pts(L, slot, m, s_add[0]); for (int i = tid; i < nA; i += MU_T) s_ka[i] = vkey_of(pts[i], inv); }
+      __syncthreads();
+      auto lb = [](const u64* k, int n, u64 key) { int lo = 0, hi = n; while (lo < hi) { const int mid = (lo + hi) >> 1; if (k[mid] < key) lo = mid + 1; else hi = mid; } return lo; };
+      int out_off = 0;
+      for (int t0 = 0; t0 < nU; t0 += MU_T * MU_E) {
+        const int i0 = t0 + tid * MU_E, ne = max(0, min(MU_E, nU - i0));
+        u64 uk[MU_E];
+        int uc[MU_E];
+#pragma unroll
+        for (int e = 0; e < MU_E; ++e) { const int i = min(i0 + e, nU - 1); uk[e] = U[i]; uc[e] = cnt[i]; }
+        const u64 klo = i0 == 0 ? 0ull : uk[0];
+        const u64 khi = (ne > 0 && i0 + ne < nU) ? U[i0 + ne] : ~0ull;
+        const int pr0 = ne > 0 ? lb(s_kr, nR, klo) : 0, pa0 = ne > 0 ? lb(s_ka, nA, klo) : 0, pa1 = ne > 0 ? (khi == ~0ull ? nA : lb(s_ka, nA, khi)) : 0;
+        // the merge of this thread's interval; emit(key, count) is called for every voxel of the new list, in order
+        auto merge = [&](auto&& emit) {
+          int r = pr0, a = pa0;
+#pragma unroll
+          for (int e = 0; e < MU_E; ++e) {
+            if (e < ne) {
+              const u64 key = uk[e];
+              while (a < pa1 && s_ka[a] < key) { const u64 k2 = s_ka[a]; int c = 0; while (a < pa1 && s_ka[a] == k2) { ++c; ++a; } emit(k2, c); }
+              while (r < nR && s_kr[r] < key) { ++r; s_err = 1; }   // a point that left was never counted: list out of sync
+              int c = uc[e];
+              while (r < nR && s_kr[r] == key) { --c; ++r; }
+              while (a < pa1 && s_ka[a] == key) { ++c; ++a; }
+              if (c > 0) emit(key, c);
+            }
+          }
+          while (a < pa1) { const u64 k2 = s_ka[a]; int c = 0; while (a < pa1 && s_ka[a] == k2) { ++c; ++a; } emit(k2, c); }
+        };
+        int nout = 0;
+        merge([&](u64, int) { ++nout; });
+        int tot;
+        int pos = out_off + block_excl_scan(nout, s_w, &tot);
+        merge([&](u64 k, int c) { if (pos < cap) { S_key[pos] = k; S_cnt[pos] = c; } ++pos; });
+        out_off += tot;
+      }
+      __threadfence_block();
+      __syncthreads();
+      int nU2 = out_off;
+      if (nU2 > cap) { nU2 = cap; if (tid == 0) s_err = 2; }
+      for (int i = tid; i < nU2; i += MU_T) { U[i] = S_key[i]; cnt[i] = S_cnt[i]; }
+      __threadfence_block();
+      __syncthreads();
+      nU = nU2;
+    } else {
     // ---- the runs that left: one decrement per point
     for (int r = 0; r < s_nrem; ++r) {
       const float4* pts = run_pts(L, slot, m, s_rem[r]);
@@ -129,10 +206,7 @@ __global__ void __launch_bounds__(MU_T) map_update(DevCtx d, LmCtx L, MapWork W)
     __syncthreads();
     // ---- the runs that entered, one after the other
     float4* nk = L.newkeys + ((size_t)slot * 2 + m) * L.total_cap;   // (key lo, key hi, lower bound, count) of the voxels this run adds
-    // scratch of the merge: the map's output buffer (rewritten by map_accum afterwards): keys | counts | exclusive keep-scan
-    u64* S_key = reinterpret_cast<u64*>(map_out(L, slot, m));
-    int* S_cnt = reinterpret_cast<int*>(S_key + cap);
-    int* S_E = S_cnt + cap;
+    int* S_E = S_cnt + cap;   // third part of the scratch: exclusive keep-scan
     const int nadd = s_nadd;
     for (int a = 0; a <= nadd; ++a) {
       // (iteration nadd is the purge-only pass when nothing was added but something left)
@@ -208,10 +282,11 @@ __global__ void __launch_bounds__(MU_T) map_update(DevCtx d, LmCtx L, MapWork W)
       __syncthreads();
       nU = nU2;
     }
+    }   // general path
     // ---- window totals, bounding box (for PCL's leaf-size check and for the k-NN grid), outputs
     float mn[3] = {3.402823466e+38f, 3.402823466e+38f, 3.402823466e+38f}, mx[3] = {-3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f};
     int kraw = 0;
-    for (int j = 0; j < ncur; ++j) {   // (every thread: K <= 512 small loads, no reduction needed)
+    for (int j = tid; j < ncur; j += MU_T) {
       const int e = rec[j] % L.KR;
       const int n = run_n(L, slot, m, e);
       kraw += n;
@@ -220,6 +295,20 @@ __global__ void __launch_bounds__(MU_T) map_update(DevCtx d, LmCtx L, MapWork W)
         mn[0] = fminf(mn[0], b[0]); mn[1] = fminf(mn[1], b[1]); mn[2] = fminf(mn[2], b[2]);
         mx[0] = fmaxf(mx[0], b[4]); mx[1] = fmaxf(mx[1], b[5]); mx[2] = fmaxf(mx[2], b[6]);
       }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      kraw += __shfl_xor(kraw, o, 64);
+#pragma unroll
+      for (int a = 0; a < 3; ++a) { mn[a] = fminf(mn[a], __shfl_xor(mn[a], o, 64)); mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], o, 64)); }
+    }
+    __syncthreads();
+    if ((tid & 63) == 0) { s_kr_tot[tid >> 6] = kraw; for (int a = 0; a < 3; ++a) { s_box[a][tid >> 6] = mn[a]; s_box[3 + a][tid >> 6] = mx[a]; } }
+    __syncthreads();
+    kraw = 0;
+    for (int w = 0; w < MU_T / 64; ++w) {
+      kraw += s_kr_tot[w];
+      for (int a = 0; a < 3; ++a) { mn[a] = fminf(w ? mn[a] : s_box[a][0], s_box[a][w]); mx[a] = fmaxf(w ? mx[a] : s_box[3 + a][0], s_box[3 + a][w]); }
     }
     const long long dx = (long long)((mx[0] - mn[0]) * inv) + 1, dy = (long long)((mx[1] - mn[1]) * inv) + 1, dz = (long long)((mx[2] - mn[2]) * inv) + 1;
     const bool pass = kraw > 0 && dx * dy * dz > 2147483647LL;   // PCL: "leaf size too small" -> output = input (in the reference's order)
@@ -259,26 +348,39 @@ __global__ void __launch_bounds__(MU_T) map_update(DevCtx d, LmCtx L, MapWork W)
   __syncthreads();
   if (!s_last) return;
   __threadfence();
-  if (tid == 0) {
-    int n = 0;
-    for (int s = 0; s < d.n_launch; ++s) {
-      int* l2 = lipm(L, s + d.slot0);
+  // (every thread takes slots tid, tid + MU_T, ...: a single thread walking a few hundred slots' counters in global memory took a millisecond)
+  int run_total = 0;
+  for (int s0 = 0; s0 < d.n_launch; s0 += MU_T) {
+    const int s = s0 + tid;
+    int nmine = 0, nch[2] = {0, 0};
+    int* l2 = s < d.n_launch ? lipm(L, s + d.slot0) : nullptr;
+    bool rebuilt = false;
+    if (l2) {
       l2[LI_KF_PENDING] = 0;   // the VoxelGrid round before this kernel has sorted the pending key frame
-      if (!(l2[LI_REBUILD] && d.opt_map_merge)) continue;
-      for (int mm = 0; mm < 2; ++mm) {
-        if ((l2[LI_MAP_PASS] >> mm) & 1) continue;
-        const int nch = (l2[LI_NU_C + mm] + MAP_R - 1) / MAP_R;
-        for (int c = 0; c < nch; ++c) {
-          if (n < W.cap && c < 2048) W.items[n++] = (s << 12) | (mm << 11) | c; else l2[LI_OVERFLOW] = 1;
-        }
+      rebuilt = l2[LI_REBUILD] && d.opt_map_merge;
+      if (rebuilt) {
+        for (int mm = 0; mm < 2; ++mm) nch[mm] = ((l2[LI_MAP_PASS] >> mm) & 1) ? 0 : (l2[LI_NU_C + mm] + MAP_R - 1) / MAP_R;
+        nmine = nch[0] + nch[1];
+        const int* rec = L.rec + (size_t)(s + d.slot0) * L.K;
+        int* prev = L.rec_prev + (size_t)(s + d.slot0) * L.K;
+        const int nc = l2[LI_REC_CNT];
+        for (int j = 0; j < nc; ++j) prev[j] = rec[j];
+        l2[LI_PREV_CNT] = nc; l2[LI_UVALID] = 1;
       }
-      const int* rec = L.rec + (size_t)(s + d.slot0) * L.K;
-      int* prev = L.rec_prev + (size_t)(s + d.slot0) * L.K;
-      const int nc = l2[LI_REC_CNT];
-      for (int j = 0; j < nc; ++j) prev[j] = rec[j];
-      l2[LI_PREV_CNT] = nc; l2[LI_UVALID] = 1;
     }
-    W.count[0] = n;
+    int tot;
+    int n = run_total + block_excl_scan(nmine, s_w, &tot);
+    if (rebuilt) {
+      for (int mm = 0; mm < 2; ++mm)
+        for (int c = 0; c < nch[mm]; ++c) {
+          if (n < W.cap && c < 2048) W.items[n] = (s << 12) | (mm << 11) | c; else l2[LI_OVERFLOW] = 1;
+          ++n;
+        }
+    }
+    run_total += tot;
+  }
+  if (tid == 0) {
+    W.count[0] = min(run_total, W.cap);
     W.count[1] = 0;
   }
 }
@@ -288,13 +390,13 @@ __global__ void __launch_bounds__(MA_T) map_accum(DevCtx d, LmCtx L, MapWork W) 
   __shared__ u64 s_key[MAP_R];
   __shared__ float4 s_acc[MAP_R];
   __shared__ int s_cnt[MAP_R];
-  __shared__ int s_lo[MAP_KMAX], s_hi[MAP_KMAX];
-  const int tid = threadIdx.x;
+  __shared__ int s_lo[MAP_KMAX], s_hi[MAP_KMAX], s_ent[MAP_KMAX];
+  const int tid = threadIdx.x, lane = tid & 63;
   const int nitems = W.count[0];
   for (int it = blockIdx.x; it < nitems; it += gridDim.x) {
     const int item = W.items[it];
     const int slot = (item >> 12) + d.slot0, m = (item >> 11) & 1, chunk = item & 2047;
-    const int* li = lipm(L, slot);
+    int* li = lipm(L, slot);
     const float inv = 1.0f / (m == 0 ? d.P.lm_leaf_corner : d.P.lm_leaf_surf);
     const u64* U = map_U(L, slot, m);
     const int nU = li[LI_NU_C + m];
@@ -309,38 +411,60 @@ __global__ void __launch_bounds__(MA_T) map_accum(DevCtx d, LmCtx L, MapWork W) 
       const int e = rec[j] % L.KR;
       const float4* pts = run_pts(L, slot, m, e);
       const int n = run_n(L, slot, m, e);
+      s_ent[j] = e;
       s_lo[j] = bound_run(pts, n, inv, key_lo, false);
       s_hi[j] = bound_run(pts, n, inv, key_hi, true);
     }
     __syncthreads();
-    for (int j = 0; j < nwin; ++j) {   // window order = the reference's summation order
+    // Runs in window order = the reference's summation order.  One barrier per run; the first MA_T points of the next run's
+    // piece (with the point before each, for the run-head test) are loaded before the barrier of the current one.
+    auto fetch = [&](int j, float4& p, float4& pp) {
+      const int lo = s_lo[j], hi = s_hi[j], i = lo + tid;
+      const float4* pts = run_pts(L, slot, m, s_ent[j]);
+      const int ic = hi > lo ? min(i, hi - 1) : 0;
+      p = pts[ic]; pp = pts[max(ic - 1, 0)];
+    };
+    float4 np_ = make_float4(0.f, 0.f, 0.f, 0.f), npp_ = np_;
+    if (nwin > 0) fetch(0, np_, npp_);
+    for (int j = 0; j < nwin; ++j) {
       const int lo = s_lo[j], hi = s_hi[j];
-      if (lo < hi) {
-        const float4* pts = run_pts(L, slot, m, rec[j] % L.KR);
-        for (int i0 = lo; i0 < hi; i0 += MA_T) {
-          const int i = i0 + tid;
-          if (i < hi) {
-            const float4 p = pts[i];
-            const u64 key = vkey_of(p, inv);
-            const bool head = i == lo || vkey_of(pts[i - 1], inv) != key;
-            if (head) {   // the first point of a voxel-run adds the whole run, in order
-              int a = 0, b = nr;
-              while (a < b) { const int mid = (a + b) >> 1; if (s_key[mid] < key) a = mid + 1; else b = mid; }
-              if (a >= nr || s_key[a] != key) { const_cast<int*>(li)[LI_OVERFLOW] = 4; a = min(a, nr - 1); }   // voxel list out of sync (internal error)
-              float4 acc = s_acc[a];
-              int c = 0;
-              float4 q = p;
-              int i2 = i;
-              while (true) {
-                acc.x += q.x; acc.y += q.y; acc.z += q.z; acc.w += q.w; ++c;
-                if (++i2 >= hi) break;
-                q = pts[i2];
-                if (vkey_of(q, inv) != key) break;
-              }
-              s_acc[a] = acc;
-              s_cnt[a] += c;
-            }
+      const float4* pts = run_pts(L, slot, m, s_ent[j]);
+      float4 p = np_, pp = npp_;
+      if (j + 1 < nwin) fetch(j + 1, np_, npp_);
+      for (int i0 = lo; i0 < hi; i0 += MA_T) {
+        const int i = i0 + tid;
+        if (i0 > lo) { const int ic = min(i, hi - 1); p = pts[ic]; pp = pts[max(ic - 1, 0)]; }
+        const bool valid = i < hi;
+        // (lanes past the piece carry a key no voxel has, different per lane, so that they neither start nor extend a run)
+        const u64 key = valid ? vkey_of(p, inv) : (~0ull - (u64)lane);
+        const bool head = valid && (i == lo || vkey_of(pp, inv) != key);
+        int a = 0;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        int c = 0;
+        if (head) {   // the first point of a voxel-run adds the whole run, in order, to what the earlier runs left
+          int b = nr;
+          while (a < b) { const int mid = (a + b) >> 1; if (s_key[mid] < key) a = mid + 1; else b = mid; }
+          if (a >= nr || s_key[a] != key) { li[LI_OVERFLOW] = 4; a = min(a, nr - 1); }   // voxel list out of sync (internal error)
+          acc = s_acc[a];
+          acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w; c = 1;
+        }
+        // the followers of a run sit in the next lanes: wave shuffles instead of dependent loads
+        bool cont = head;
+        for (int sft = 1; sft < 64; ++sft) {
+          const u64 ks = __shfl_down(key, sft, 64);
+          const bool inwave = lane + sft < 64;
+          const bool more = cont && inwave && ks == key;
+          if (!__any(more)) break;
+          const float qx = __shfl_down(p.x, sft, 64), qy = __shfl_down(p.y, sft, 64), qz = __shfl_down(p.z, sft, 64), qw = __shfl_down(p.w, sft, 64);
+          if (more) { acc.x += qx; acc.y += qy; acc.z += qz; acc.w += qw; ++c; } else if (inwave) cont = false;   // the run ended inside the wavefront
+        }
+        if (head) {
+          int i2 = i + c;
+          if (cont && lane + c >= 64) {   // the run reached the edge of the wavefront: the rest one by one
+            while (i2 < hi) { const float4 q = pts[i2]; if (vkey_of(q, inv) != key) break; acc.x += q.x; acc.y += q.y; acc.z += q.z; acc.w += q.w; ++c; ++i2; }
           }
+          s_acc[a] = acc;
+          s_cnt[a] += c;
         }
       }
       __syncthreads();
@@ -356,7 +480,9 @@ __global__ void __launch_bounds__(MA_T) map_accum(DevCtx d, LmCtx L, MapWork W) 
 }
 
 void launch_map_update(const DevCtx& d, const LmCtx& L, const MapWork& W, hipStream_t st) {
-  ALEGO_LAUNCH(map_update, dim3(2, d.n_launch), dim3(MU_T), 0, st, d, L, W);
+  static const bool cfg = hipFuncSetAttribute(reinterpret_cast<const void*>(map_update), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * MU_FCAP * 8) == hipSuccess;
+  (void)cfg;
+  ALEGO_LAUNCH(map_update, dim3(2, d.n_launch), dim3(MU_T), (size_t)2 * MU_FCAP * 8, st, d, L, W);
 }
 void launch_map_accum(const DevCtx& d, const LmCtx& L, const MapWork& W, hipStream_t st) {
   const int grid = std::min(1024, std::max(16, 4 * d.n_launch));

@@ -11,6 +11,7 @@
 // because a 50-key-frame map has ~17 points per voxel and every bucket needed a rank-by-counting sort).  The stable
 // radix sort needs no in-bucket sort at all, and since streams run concurrently (stream groups) one CU per job is
 // the right granularity: the other CUs are busy with other streams.
+#include <algorithm>
 #include <cstring>
 
 #include <hip/hip_runtime.h>
@@ -43,7 +44,7 @@ __device__ __forceinline__ bool vx_enabled(const VoxJob& J) { return J.enable ==
 //   4 voxel heads -> output ranks (ascending voxel id), list of run starts
 //   5 one thread per voxel: f32 sums in sorted (= original) order, divided by the count (pcl::CentroidPoint)
 #ifndef VG_T
-#define VG_T 1024
+#define VG_T 512   // = VX_SB: large jobs are taken by the same workgroups as the small ones (one launch per round)
 #endif
 #define VG_W (VG_T / 64)
 #define VG_DMAX 9               // radix digit width: 2 x 16 x 512 counters = 64 KB of LDS
@@ -63,14 +64,21 @@ __device__ long long vg_times[16];
 #else
 #define VG_TICK(k)
 #endif
-__device__ void vox_big_job(const VoxCtx& V, int job) {
+// LDS (carved from the launch's dynamic buffer, which vox_small_job uses for its own arrays): 2 x VG_W x VG_ND counters (32 KB),
+// VG_ND digit totals, a few per-wavefront scalars
+#define VG_LDS_BYTES ((2 * VG_W * VG_ND + VG_ND + 6 * VG_W + VG_W + 2 * (VG_W + 1)) * 4)
+__device__ void vox_big_job(const VoxCtx& V, int job, unsigned char* smem) {
   const VoxJob J = V.jobs[job];
   const int n = min(*J.n_in, J.cap);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  __shared__ int s_cnt[2][VG_W][VG_ND];
-  __shared__ int s_tot[VG_ND];
-  __shared__ float s_red[6][VG_W];
-  __shared__ int s_w[VG_W];
+  typedef int cnt_t[VG_W][VG_ND];
+  cnt_t* s_cnt = reinterpret_cast<cnt_t*>(smem);                                  // [2][VG_W][VG_ND]
+  int* s_tot = reinterpret_cast<int*>(smem) + 2 * VG_W * VG_ND;                   // [VG_ND]
+  typedef float red_t[VG_W];
+  red_t* s_red = reinterpret_cast<red_t*>(s_tot + VG_ND);                         // [6][VG_W]
+  int* s_w = reinterpret_cast<int*>(s_red + 6);                                   // [VG_W]
+  int* s_wbase = s_w + VG_W;                                                      // [VG_W + 1]
+  int* s_nextfirst = s_wbase + VG_W + 1;                                          // [VG_W + 1]
   const float inv = 1.0f / J.leaf;
   VG_TICK(0);
   // ---- 1. getMinMax3D
@@ -245,7 +253,6 @@ __device__ void vox_big_job(const VoxCtx& V, int job) {
   // One pass: every wavefront compacts the run starts of its own segment into the front of that segment of hl[] (a segment has
   // at most as many heads as elements), then the per-wavefront counts give every voxel its (wavefront, local rank).
   int* hl = reinterpret_cast<int*>(keys);
-  __shared__ int s_wbase[VG_W + 1], s_nextfirst[VG_W + 1];
   int heads = 0;
   for (int r0 = seg0; r0 < seg1; r0 += 64 * VG_U) {
     bool head[VG_U];
@@ -296,14 +303,6 @@ __device__ void vox_big_job(const VoxCtx& V, int job) {
   if (tid == 0) { *J.n_out = min(nvox, J.out_cap); if (nvox > J.out_cap && J.overflow) *J.overflow = 1; }
   __syncthreads();
   VG_TICK(13);
-}
-// persistent workgroups over the list of enabled jobs with more than VX_SMALL_MAX points (vox_plan)
-__global__ void __launch_bounds__(VG_T) vox_big(VoxCtx V) {
-  const int cnt = V.cnt[1];
-  for (int j = blockIdx.x; j < cnt; j += gridDim.x) {
-    vox_big_job(V, V.list_big[j]);
-    __syncthreads();   // LDS of the job just finished is reused by the next one
-  }
 }
 #ifdef ALEGO_TIMING
 extern "C" void alego_vg_times(long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(vg_times), sizeof(long long) * 16); }
@@ -496,11 +495,22 @@ __device__ void vox_small_job(const VoxCtx& V, int job) {
   __syncthreads();
   VG_TICK(7);
 }
+// One launch per round: persistent workgroups over the list of small jobs, then (the first grid_big of them) over the list of
+// large ones.  (The large jobs used to have a kernel of their own with 1024-thread workgroups: its launch cost ~150 us of
+// queueing under load even when the list was empty, which it is on every round once the maps come from the sorted key frames.)
 __global__ void __launch_bounds__(VX_SB) vox_small(VoxCtx V) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char vs_smem_k[];
   const int cnt = V.cnt[0];
   for (int j = blockIdx.x; j < cnt; j += gridDim.x) {
     vox_small_job(V, V.list_small[j]);
     __syncthreads();
+  }
+  const int nbig = V.cnt[1];
+  if ((int)blockIdx.x < V.grid_big) {
+    for (int j = blockIdx.x; j < nbig; j += min((int)gridDim.x, V.grid_big)) {
+      vox_big_job(V, V.list_big[j], vs_smem_k);
+      __syncthreads();   // LDS of the job just finished is reused by the next one
+    }
   }
 }
 
@@ -559,7 +569,7 @@ int vox_run(const VoxCtx& V, hipStream_t st, std::string* err) {
   (void)err;
   if (V.njobs == 0) return 0;
   ALEGO_LAUNCH(vox_plan, dim3(1), dim3(256), 0, st, V);
-  ALEGO_LAUNCH(vox_small, dim3(V.grid_small), dim3(VX_SB), (size_t)VX_SMALL_LDS, st, V);
-  ALEGO_LAUNCH(vox_big, dim3(V.grid_big), dim3(VG_T), 0, st, V);
+  static_assert(VG_T == VX_SB && VG_LDS_BYTES <= VX_SMALL_LDS, "large jobs run in vox_small's workgroups and LDS");
+  ALEGO_LAUNCH(vox_small, dim3(std::max(V.grid_small, V.grid_big)), dim3(VX_SB), (size_t)VX_SMALL_LDS, st, V);
   return 0;
 }

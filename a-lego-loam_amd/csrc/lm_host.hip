@@ -128,7 +128,8 @@ LmHost* lm_host_create(const alego_params& P, const DevCtx& d, int n_slots, int 
       vox_create(&lm->vk[g], jk.data(), (int)jk.size(), err)) { lm_host_destroy(lm); return nullptr; }
   // Expected work per context: the current-scan clouds and key frames practically never exceed 8192 points (vox_small); a key frame
   // is sorted for ~1 stream in 5 per mapping frame.  Fewer persistent workgroups where little is expected (they loop).
-  lm->vm[g].grid_small = 3 * ns + std::max(2, ns / 2); lm->vm[g].grid_big = std::max(2, ns / 2);
+  // (vox_big only has work on the radix path of the maps or for a scan cloud of more than 8192 points)
+  lm->vm[g].grid_small = 3 * ns + std::max(2, ns / 2); lm->vm[g].grid_big = d.opt_map_merge ? std::min(8, std::max(2, ns / 2)) : std::max(2, ns / 2);
   lm->v2[g].grid_big = std::max(1, ns / 16);
   lm->vk[g].grid_small = 2; lm->vk[g].grid_big = 2;
   MapWork& W = lm->work[g];
