@@ -337,7 +337,9 @@ DEV_INLINE unsigned long long row_min_u64(unsigned long long v) {
 // fixed work (pose transform, cell addressing, merge) is shared by 16 queries per wavefront.
 #define LM_ASSOC_GX 64
 __global__ void __launch_bounds__(128) lm_knn(DevCtx d, LmCtx L) {
-  const int slot = blockIdx.z + d.slot0, kind = blockIdx.y;
+  // grid (slots, 2, LM_ASSOC_GX): the slot is the FASTEST block index.  Workgroup b runs on XCD b % 8 (observed), so with a slot count that is
+  // a multiple of 8 all workgroups of a stream share one XCD and its L2: the map's cells are fetched into one L2 instead of eight.
+  const int slot = blockIdx.x + d.slot0, kind = blockIdx.y, bx = blockIdx.z, gx = gridDim.z;
   const int* li = lip(L, slot);
   if (!li[LI_RUN]) return;
   const alego_params& P = d.P;
@@ -355,7 +357,7 @@ __global__ void __launch_bounds__(128) lm_knn(DevCtx d, LmCtx L) {
   const int sub = threadIdx.x & (LM_KNN_LANES - 1);
   // every lane of a wavefront runs the same number of iterations (DPP reads neighbours' registers): clamp, don't exit
   const int nq_round = (nq + QPB - 1) / QPB * QPB;
-  for (int qq = blockIdx.x * QPB + threadIdx.x / LM_KNN_LANES; qq < nq_round; qq += gridDim.x * QPB) {
+  for (int qq = bx * QPB + threadIdx.x / LM_KNN_LANES; qq < nq_round; qq += gx * QPB) {
   const int q = min(qq, nq - 1);
   const float4 pin = qp[q];
   // pointAssociateToMap laserMapping.h:187-194 (pose predicted from odometry)
@@ -448,14 +450,14 @@ __global__ void __launch_bounds__(128) lm_knn(DevCtx d, LmCtx L) {
 // least squares (plane) on the five neighbours found by lm_knn
 #define LM_FIT_GX 20   // x 128 threads: the 1-2 k queries of a kind in one sweep; larger clouds grid-stride
 __global__ void __launch_bounds__(128) lm_fit(DevCtx d, LmCtx L) {
-  const int slot = blockIdx.z + d.slot0, kind = blockIdx.y;
+  const int slot = blockIdx.x + d.slot0, kind = blockIdx.y, bx = blockIdx.z, gx = gridDim.z;   // slot fastest: see lm_knn
   const int* li = lip(L, slot);
   if (!li[LI_RUN]) return;
   const alego_params& P = d.P;
   if (li[LI_NCUR_C] < P.lm_min_corner || li[LI_NTOTAL] < P.lm_min_surf || li[LI_KDS_C] < P.lm_min_map_corner || li[LI_NKF] == 0) return;
   const int nq = kind == 0 ? li[LI_NCUR_C] : li[LI_NTOTAL_DS];
   const float4* mp = kind == 0 ? L.map_corner_ds + (size_t)slot * L.map_cap_c : L.map_surf_ds + (size_t)slot * L.map_cap_s;
-  for (int q = blockIdx.x * 128 + threadIdx.x; q < nq; q += gridDim.x * 128) {
+  for (int q = bx * 128 + threadIdx.x; q < nq; q += gx * 128) {
   const int* kn = L.knn + ((size_t)slot * L.qcap + (kind == 0 ? 0 : L.kf_cap_c) + q) * 5;
   double* blk = L.blocks + ((size_t)slot * L.qcap + (kind == 0 ? 0 : L.kf_cap_c) + q) * 8;
   int bi[5];
@@ -788,8 +790,8 @@ void launch_lm_grid(const DevCtx& d, const LmCtx& L, hipStream_t st) {
   ALEGO_LAUNCH(lm_grid_build, dim3(2, d.n_launch), dim3(LM_BLOCK), 0, st, d, L);
 }
 void launch_lm_register(const DevCtx& d, const LmCtx& L, hipStream_t st) {
-  ALEGO_LAUNCH(lm_knn, dim3(LM_ASSOC_GX, 2, d.n_launch), dim3(128), 0, st, d, L);
-  ALEGO_LAUNCH(lm_fit, dim3(LM_FIT_GX, 2, d.n_launch), dim3(128), 0, st, d, L);
+  ALEGO_LAUNCH(lm_knn, dim3(d.n_launch, 2, LM_ASSOC_GX), dim3(128), 0, st, d, L);
+  ALEGO_LAUNCH(lm_fit, dim3(d.n_launch, 2, LM_FIT_GX), dim3(128), 0, st, d, L);
   ALEGO_LAUNCH(lm_solve, dim3(d.n_launch), dim3(LM_SOLVE_BLOCK), LM_SOLVE_LDS, st, d, L);
   ALEGO_LAUNCH(lm_finish, dim3((d.n_launch + 63) / 64), dim3(64), 0, st, d, L);
   ALEGO_LAUNCH(lm_store_kf, dim3(8, 3, d.n_launch), dim3(LM_BLOCK), 0, st, d, L, -1);

@@ -97,7 +97,7 @@ template <int kind>   // compile-time: the corner association has one class of s
 __global__ void __launch_bounds__(LO_BLOCK) lo_assoc(DevCtx d, int box_lds_max) {
   static_assert(LO_CH % 16 == 0, "a box is evaluated as LO_CH / 16 targets per lane of a 16-lane row");
   constexpr int TPL = LO_CH / 16;
-  const int slot = blockIdx.y + d.slot0;
+  const int slot = blockIdx.x + d.slot0, qb0 = blockIdx.y, qbn = gridDim.y;   // slot fastest: a stream's workgroups share an XCD / L2 (see lm_knn)
   const int cur = cur_in_flight(d, slot);
   const int* sc = d.scal + slot * SC_COUNT;
   if (!sc[SC_LO_INIT]) return;
@@ -105,7 +105,7 @@ __global__ void __launch_bounds__(LO_BLOCK) lo_assoc(DevCtx d, int box_lds_max) 
   const int last = cur ^ 1;
   const int qk = kind == 0 ? F_FLAT : F_SHARP, tk = kind == 0 ? F_LFLAT : F_LSHARP;
   const int nq = d.feat_cnt[((size_t)slot * 2 + cur) * 4 + qk];
-  if ((int)blockIdx.x * LO_QPB >= nq) return;
+  if (qb0 * LO_QPB >= nq) return;
   const int nt = d.feat_cnt[((size_t)slot * 2 + last) * 4 + tk];
   const float4* tg = d.feat[tk] + ((size_t)slot * 2 + last) * d.fcap[tk];
   const float4* bx = d.lo_box + (((size_t)slot * 2 + last) * 2 + kind) * d.lo_box_cap * 2;
@@ -137,7 +137,7 @@ __global__ void __launch_bounds__(LO_BLOCK) lo_assoc(DevCtx d, int box_lds_max) 
     for (int k = 0; k < 3; ++k) s_pose[9 + k] = st[LS_PARAMS + k];
   }
   // the launch covers the typical query count in one sweep; larger feature sets take further sweeps
-  for (int qb = blockIdx.x; qb * LO_QPB < nq; qb += gridDim.x) {
+  for (int qb = qb0; qb * LO_QPB < nq; qb += qbn) {
   __syncthreads();
   if (threadIdx.x < LO_QPB) {  // transformToStart once per query, shared through LDS
     const int q = min((int)(qb * LO_QPB + threadIdx.x), nq - 1);
@@ -511,8 +511,8 @@ int lo_configure() {
 
 void launch_lo(const DevCtx& d, hipStream_t st) {
   const int box_lds_max = std::min(d.opt_lo_box_lds, (int)LO_BOX_LDS);
-  ALEGO_LAUNCH(lo_assoc<0>, dim3(std::min((d.lo_qcap_surf + LO_QPB - 1) / LO_QPB, 8), d.n_launch), dim3(LO_BLOCK), 0, st, d, box_lds_max);
+  ALEGO_LAUNCH(lo_assoc<0>, dim3(d.n_launch, std::min((d.lo_qcap_surf + LO_QPB - 1) / LO_QPB, 8)), dim3(LO_BLOCK), 0, st, d, box_lds_max);
   ALEGO_LAUNCH(lo_solve, dim3(d.n_launch), dim3(LO_SOLVE_BLOCK), LO_SOLVE_LDS, st, d, 0);
-  ALEGO_LAUNCH(lo_assoc<1>, dim3(std::min((d.lo_qcap_corner + LO_QPB - 1) / LO_QPB, 12), d.n_launch), dim3(LO_BLOCK), 0, st, d, box_lds_max);
+  ALEGO_LAUNCH(lo_assoc<1>, dim3(d.n_launch, std::min((d.lo_qcap_corner + LO_QPB - 1) / LO_QPB, 12)), dim3(LO_BLOCK), 0, st, d, box_lds_max);
   ALEGO_LAUNCH(lo_solve, dim3(d.n_launch), dim3(LO_SOLVE_BLOCK), LO_SOLVE_LDS, st, d, 1);
 }
