@@ -25,6 +25,7 @@ EXPORTS = [
     "alego_debug_math", "alego_debug_eval_blocks", "alego_debug_transform_to_start", "alego_debug_set_option",
     "alego_lm_keyframe_count", "alego_lm_get_keyframe", "alego_lm_set_keypose", "alego_lm_reset_window", "alego_lm_apply_correction",
     "alego_lm_add_keyframe", "alego_pc2_to_points", "alego_replay_create", "alego_replay_load", "alego_replay_assign",
+    "alego_dist_unique_id", "alego_dist_init", "alego_dist_shutdown",
 ]
 
 REPLAY_PINGPONG = 0x100
@@ -156,6 +157,12 @@ def lib():
         L.alego_replay_load.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int32]
         L.alego_replay_assign.restype = C.c_int
         L.alego_replay_assign.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.alego_dist_unique_id.restype = C.c_int
+        L.alego_dist_unique_id.argtypes = [C.c_char_p]
+        L.alego_dist_init.restype = C.c_int
+        L.alego_dist_init.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_char_p]
+        L.alego_dist_shutdown.restype = C.c_int
+        L.alego_dist_shutdown.argtypes = [C.c_void_p]
         if L.alego_params_sizeof() != C.sizeof(AlegoParams):
             raise RuntimeError("alego_params layout mismatch between params.py and include/alego_params.h")
         _lib = L
@@ -164,6 +171,18 @@ def lib():
 
 class AlegoError(RuntimeError):
     pass
+
+
+DIST_ID_BYTES = 128
+
+
+def dist_unique_id() -> bytes:
+    """rank 0: the RCCL unique id every rank passes to Handle.dist_init (ncclGetUniqueId)"""
+    buf = C.create_string_buffer(DIST_ID_BYTES)
+    rc = lib().alego_dist_unique_id(buf)
+    if rc != 0:
+        raise AlegoError(f"alego_dist_unique_id failed ({rc})")
+    return buf.raw
 
 
 def pc2_to_points(data: bytes, width, height, point_step, row_step, fields, is_bigendian=False, cap=None):
@@ -409,6 +428,13 @@ class Handle:
 
     def set_option(self, name, value):
         self._check(lib().alego_debug_set_option(self._h, name.encode(), int(value)), f"alego_debug_set_option({name})")
+
+    # ---- one registration sharded over the ranks of an RCCL communicator (BASELINE config 5) ----
+    def dist_init(self, rank, world, unique_id: bytes):
+        self._check(lib().alego_dist_init(self._h, rank, world, C.create_string_buffer(unique_id, DIST_ID_BYTES)), "alego_dist_init")
+
+    def dist_shutdown(self):
+        self._check(lib().alego_dist_shutdown(self._h), "alego_dist_shutdown")
 
     # ---- key-frame pass-through (host pose graph) ----
     def lm_keyframe_count(self, slot=0):

@@ -630,8 +630,22 @@ int alego_debug_set_option(alego_handle* h, const char* name, int value) {
   else if (s == "ALEGO_LO_BOX_LDS") d.opt_lo_box_lds = value;
   else if (s == "ALEGO_MAP_MERGE") { if (int r = lm_host_set_map_merge(h->lm, value != 0, &h->err)) return r; d.opt_map_merge = value != 0; }
   else if (s == "ALEGO_IP_FAST") d.ip_fast = h->ip_fast_capable & value;
+  else if (s == "ALEGO_SHARD_SLICE") return lm_host_debug_slice(h->lm, value & 0xff, value >> 8, &h->err);   // tests: rank | world << 8 without a communicator
   else { h->err = "unknown option " + s; return ALEGO_ERR_ARG; }
   return 0;
+}
+
+// ---- one registration sharded over the GPUs of a node ---------------------------------------------------------------
+int alego_dist_unique_id(char id[ALEGO_DIST_ID_BYTES]) { return id ? lm_host_dist_unique_id(id) : ALEGO_ERR_ARG; }
+int alego_dist_init(alego_handle* h, int rank, int world, const char id[ALEGO_DIST_ID_BYTES]) {
+  if (!h || !id) return ALEGO_ERR_ARG;
+  hipSetDevice(h->device);
+  return lm_host_dist_init(h->lm, rank, world, id, &h->err);
+}
+int alego_dist_shutdown(alego_handle* h) {
+  if (!h) return ALEGO_ERR_ARG;
+  hipSetDevice(h->device);
+  return lm_host_dist_shutdown(h->lm);
 }
 
 // ---- key-frame pass-through ---------------------------------------------------------------------------------------

@@ -331,6 +331,17 @@ DEV_INLINE unsigned long long row_min_u64(unsigned long long v) {
   return ((unsigned long long)hi << 32) | lo;
 }
 
+// The queries [qlo, qhi) of `kind` that this rank registers: all of them, or — one registration sharded over the ranks of a communicator
+// (alego_dist_init) — this rank's contiguous slice of laser_corner_ds_ ++ laser_surf_total_ds_.
+DEV_INLINE void lm_shard_slice(const LmCtx& L, int nqc, int nqs, int kind, int* qlo, int* qhi) {
+  int lo = 0, hi = nqc + nqs;
+  if (L.shard_world > 1) {
+    const long long T = nqc + nqs;
+    lo = (int)(T * L.shard_rank / L.shard_world); hi = (int)(T * (L.shard_rank + 1) / L.shard_world);
+  }
+  if (kind == 0) { *qlo = min(lo, nqc); *qhi = min(hi, nqc); } else { *qlo = max(lo - nqc, 0); *qhi = max(hi - nqc, 0); }
+}
+
 // grid (LM_ASSOC_GX, 2, slots): LM_KNN_LANES lanes per query, 128-thread workgroups, grid-stride over the queries.
 // The lanes of a group split the candidates of the 27 surrounding cells, keep a private top-5 each and merge them
 // with five group-wide arg-min rounds.  The kernel is instruction-issue bound: with 4 lanes per query the per-query
@@ -346,6 +357,8 @@ __global__ void __launch_bounds__(128) lm_knn(DevCtx d, LmCtx L) {
   // registration guard :350
   if (li[LI_NCUR_C] < P.lm_min_corner || li[LI_NTOTAL] < P.lm_min_surf || li[LI_KDS_C] < P.lm_min_map_corner || li[LI_NKF] == 0) return;
   const int nq = kind == 0 ? li[LI_NCUR_C] : li[LI_NTOTAL_DS];
+  int qlo, qhi;
+  lm_shard_slice(L, li[LI_NCUR_C], li[LI_NTOTAL_DS], kind, &qlo, &qhi);
   const float4* qp = kind == 0 ? L.cur_corner_ds + (size_t)slot * L.kf_cap_c : L.cur_total_ds + (size_t)slot * L.total_cap;
   const int nmap = li[LI_KDS_C + kind];
   const GridGeom g = L.grid[(size_t)slot * 2 + kind];
@@ -370,7 +383,7 @@ __global__ void __launch_bounds__(128) lm_knn(DevCtx d, LmCtx L) {
   int bi[5];
 #pragma unroll
   for (int k = 0; k < 5; ++k) { bd[k] = 3.402823466e+38f; bi[k] = 0x7fffffff; }
-  if (nmap >= 5) {
+  if (nmap >= 5 && q >= qlo && q < qhi) {   // (another rank's query: nothing to search, the row stays empty)
     int cx, cy, cz;
     grid_cell(g, sx, sy, sz, &cx, &cy, &cz);
     // bounds of the nine x-runs of cells first (18 independent loads), then the candidates two per lane at a time
@@ -439,7 +452,7 @@ __global__ void __launch_bounds__(128) lm_knn(DevCtx d, LmCtx L) {
   // neighbour indices (ascending distance) for lm_fit; idx[0] < 0 = rejected (:376,:426)
   if (sub == 0 && qq < nq) {
     int* kn = L.knn + ((size_t)slot * L.qcap + (kind == 0 ? 0 : L.kf_cap_c) + q) * 5;
-    const bool ok = bi[4] != 0x7fffffff && (double)bd[4] < P.knn_max_dist;
+    const bool ok = bi[4] != 0x7fffffff && (double)bd[4] < P.knn_max_dist && q >= qlo && q < qhi;   // (queries of other ranks' slices give no row here)
 #pragma unroll
     for (int k = 0; k < 5; ++k) kn[k] = ok ? bi[k] : -1;
   }
@@ -769,8 +782,163 @@ __global__ void lm_apply_correction(DevCtx d, LmCtx L, int slot, const double* r
   for (int i = 0; i < 3; ++i) ld[LD_T_M2O + i] = t[i];
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// One registration sharded over the ranks of a communicator (BASELINE config 5): lm_knn / lm_fit above only fill the
+// rows of this rank's query slice; the solver of lm_solve is cut at its evaluations so that the 28 normal-equation scalars (and,
+// with the first evaluation, the two correspondence counts) can be summed over the ranks between the kernels:
+//   lm_shard_pack            registration guard, packed rows of this rank, row counts
+//   lm_shard_eval(which)     residual + Jacobian rows of this rank at params_ (which = 0) or at the candidate of the step in flight
+//                            (which = 1) -> shard_part[slot][0..27] (+ counts in [28], [29])
+//   ncclAllReduce(f64, sum)  over shard_part of all slots of the launch, on the same stream (host, lm_host.hip)
+//   lm_shard_step(first)     the trust-region control of lm_solve on the summed scalars: identical on every rank, so all ranks
+//                            take the same step; state (LmState) lives in HBM between the kernels
+// The host enqueues the worst-case sequence (lm_outer_iters x (1 + lm_max_iters) evaluations); kernels of a finished solve return at once.
+// Same evaluation code, same row order and same reduction as lm_solve: with one rank the result is bit-identical to it.
+static_assert(sizeof(LmState) <= 64 * sizeof(double), "LmHost allocates 64 doubles per slot for the sharded solve's state");
+__global__ void __launch_bounds__(LM_SOLVE_BLOCK) lm_shard_pack(DevCtx d, LmCtx L) {
+  const int slot = blockIdx.x + d.slot0;
+  int* li = lip(L, slot);
+  int* ctl = L.shard_ctl + (size_t)slot * 8;
+  double* part = L.shard_part + (size_t)slot * 32;
+  if (threadIdx.x < 32) part[threadIdx.x] = 0.0;
+  if (threadIdx.x == 0) { ctl[0] = 0; ctl[1] = LM_STOP; ctl[2] = 1; ctl[3] = 0; ctl[4] = 1; }
+  if (!li[LI_RUN]) return;
+  const alego_params& P = d.P;
+  if (li[LI_NCUR_C] < P.lm_min_corner || li[LI_NTOTAL] < P.lm_min_surf || li[LI_KDS_C] < P.lm_min_map_corner || li[LI_NKF] == 0) {
+    if (threadIdx.x == 0) { li[LI_FLAGS] |= 16; li[LI_NCC] = 0; li[LI_NSC] = 0; li[LI_SUM0] = 0; li[LI_SUM1] = 0; }
+    return;
+  }
+  __shared__ int s_cnt[2][LM_SOLVE_BLOCK / 64];
+  const int nqc = li[LI_NCUR_C], nqs = li[LI_NTOTAL_DS];
+  const double* blocks = L.blocks + (size_t)slot * L.qcap * 8;
+  const float4* qc = L.cur_corner_ds + (size_t)slot * L.kf_cap_c;
+  const float4* qs = L.cur_total_ds + (size_t)slot * L.total_cap;
+  double* crows = L.crows + (size_t)slot * L.qcap * 10;
+  const int nrows_all = nqc + nqs;
+  int cc = 0, cs = 0;
+  for (int i = threadIdx.x; i < nrows_all; i += LM_SOLVE_BLOCK) {
+    const double ty = blocks[(size_t)(i < nqc ? i : L.kf_cap_c + (i - nqc)) * 8 + 7];
+    if (ty != 0.0) { if (i < nqc) ++cc; else ++cs; }
+  }
+  const int mine = cc + cs;
+  int incl = mine;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane_id() >= o) incl += t; }
+  int wc = cc, ws = cs;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { wc += __shfl_xor(wc, o, 64); ws += __shfl_xor(ws, o, 64); }
+  if (lane_id() == 0) { s_cnt[0][threadIdx.x >> 6] = wc; s_cnt[1][threadIdx.x >> 6] = ws; }
+  __syncthreads();
+  int woff = 0, ta = 0, tb = 0;
+  for (int w = 0; w < LM_SOLVE_BLOCK / 64; ++w) { const int c = s_cnt[0][w] + s_cnt[1][w]; if (w < (int)(threadIdx.x >> 6)) woff += c; ta += s_cnt[0][w]; tb += s_cnt[1][w]; }
+  int pos = woff + incl - mine;
+  for (int i = threadIdx.x; i < nrows_all; i += LM_SOLVE_BLOCK) {   // thread-major order, as lm_solve packs them
+    const bool is_c = i < nqc;
+    const double4* b = reinterpret_cast<const double4*>(blocks + (size_t)(is_c ? i : L.kf_cap_c + (i - nqc)) * 8);
+    const double4 lo = b[0], hi = b[1];
+    if (hi.w != 0.0) {
+      const float4 pc = is_c ? qc[i] : qs[i - nqc];
+      double2* o = reinterpret_cast<double2*>(crows + (size_t)pos * 10);
+      o[0] = make_double2(lo.x, lo.y); o[1] = make_double2(lo.z, lo.w); o[2] = make_double2(hi.x, hi.y); o[3] = make_double2(hi.z, hi.w);
+      *reinterpret_cast<float4*>(o + 4) = pc;
+      ++pos;
+    }
+  }
+  if (threadIdx.x == 0) {
+    ctl[0] = ta + tb; ctl[1] = LM_EVAL; ctl[2] = 0; ctl[4] = 0;
+    part[28] = (double)ta; part[29] = (double)tb;   // summed over the ranks with the first evaluation
+    li[LI_OPTIMIZED] = 1;
+  }
+}
+
+__global__ void __launch_bounds__(LM_SOLVE_BLOCK) lm_shard_eval(DevCtx d, LmCtx L, int which) {
+  const int slot = blockIdx.x + d.slot0;
+  const int* ctl = L.shard_ctl + (size_t)slot * 8;
+  if (ctl[2] || ctl[4] || ctl[1] != LM_EVAL) return;   // solve finished / guard failed: the all-reduce still runs, on stale partials nobody reads
+  extern __shared__ __attribute__((aligned(16))) unsigned char lm_smem[];
+  double* s_acc = reinterpret_cast<double*>(lm_smem);
+  double* s_seg = s_acc + 28 * (LM_SOLVE_BLOCK / 4);
+  __shared__ double s_out[28], s_trig[12];
+  const LmState* S = reinterpret_cast<const LmState*>(L.shard_state) + slot;
+  const double* ld = ldp(L, slot);
+  double x[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) x[k] = which == 0 ? ld[LD_PARAMS + k] : S->cand[k];
+  const double* crows = L.crows + (size_t)slot * L.qcap * 10;
+  const int R = ctl[0];
+  double acc[28];
+#pragma unroll
+  for (int k = 0; k < 28; ++k) acc[k] = 0;
+  const PoseTerms T = pose_terms_coop(x, s_trig);
+  for (int i = threadIdx.x; i < R; i += LM_SOLVE_BLOCK) {
+    const double2* b = reinterpret_cast<const double2*>(crows + (size_t)i * 10);
+    const double2 q0 = b[0], q1 = b[1], q2 = b[2], q3 = b[3];
+    const float4 pc = *reinterpret_cast<const float4*>(b + 4);
+    const double cp[3] = {pc.x, pc.y, pc.z}, a3[3] = {q0.x, q0.y, q1.x}, b3[3] = {q1.y, q2.x, q2.y}, c3[3] = {0, 0, 0};
+    double res, J[6];
+    eval_block(q3.y == 2.0 ? BLK_EDGE : BLK_PLANE, cp, a3, b3, c3, q3.x, T, &res, J);
+    accumulate_block(res, J, d.P.huber_delta, acc);
+  }
+  block_reduce28_lds<LM_SOLVE_BLOCK>(acc, s_acc, s_seg, s_out);
+  double* part = L.shard_part + (size_t)slot * 32;
+  if (threadIdx.x < 28) part[threadIdx.x] = s_out[threadIdx.x];
+  if (threadIdx.x == 0 && which == 1) { part[28] = 0.0; part[29] = 0.0; }
+}
+
+// one thread per slot.  first: the evaluation just summed was the one at params_ (start of an outer iteration)
+__global__ void lm_shard_step(DevCtx d, LmCtx L, int first) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= d.n_launch) return;
+  const int slot = s + d.slot0;
+  int* ctl = L.shard_ctl + (size_t)slot * 8;
+  if (ctl[4]) return;
+  int* li = lip(L, slot);
+  double* ld = ldp(L, slot);
+  LmState& S = reinterpret_cast<LmState*>(L.shard_state)[slot];
+  const double* red = L.shard_part + (size_t)slot * 32;   // summed over the ranks
+  const int outer = ctl[3];
+  if (first) {
+    if (outer == 0) { li[LI_NCC] = (int)(red[28] + 0.5); li[LI_NSC] = (int)(red[29] + 0.5); }
+    if (li[LI_NCC] + li[LI_NSC] == 0) {   // ceres::Solve on an empty problem is a no-op
+      if (outer < 2) { li[LI_SUM0 + outer] = 4 << 16; for (int k = 0; k < 6; ++k) ld[LD_PARAMS_IT + outer * 6 + k] = ld[LD_PARAMS + k]; }
+      ctl[2] = 1; ctl[1] = LM_STOP;
+      return;
+    }
+    double x0[6];
+    for (int k = 0; k < 6; ++k) x0[k] = ld[LD_PARAMS + k];
+    lm_begin(S, x0, red, d.P.lm_max_iters);
+    ctl[2] = 0;
+  } else {
+    if (ctl[2] || ctl[1] != LM_EVAL) return;
+    if (lm_consume(S, red) == LM_STOP) ctl[2] = 1;
+  }
+  int act = LM_STOP;
+  if (!ctl[2]) { do { act = lm_propose(S); } while (act == LM_AGAIN); }
+  ctl[1] = act;
+  if (act == LM_STOP) {   // this outer iteration's ceres::Solve has returned
+    ctl[2] = 1;
+    for (int k = 0; k < 6; ++k) ld[LD_PARAMS + k] = S.x[k];
+    if (outer < 2) {
+      for (int k = 0; k < 6; ++k) ld[LD_PARAMS_IT + outer * 6 + k] = S.x[k];
+      ld[LD_COSTS + outer * 2] = S.initial_cost; ld[LD_COSTS + outer * 2 + 1] = S.x_cost;
+      li[LI_SUM0 + outer] = S.iter | (S.successful << 8) | (S.termination << 16);
+    }
+  }
+}
+
+// between two outer iterations: the next ceres::Solve starts from the params_ the last one left (:360)
+__global__ void lm_shard_next_outer(DevCtx d, LmCtx L) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= d.n_launch) return;
+  int* ctl = L.shard_ctl + (size_t)(s + d.slot0) * 8;
+  if (ctl[4]) return;
+  ctl[3] += 1; ctl[2] = 0; ctl[1] = LM_EVAL;
+}
+
 #define LM_SOLVE_LDS ((size_t)(28 * (LM_SOLVE_BLOCK / 4) + 28 * (LM_SOLVE_BLOCK / 128)) * sizeof(double))
 int lm_configure() {
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(lm_shard_eval), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LM_SOLVE_LDS) != hipSuccess) return -1;
   return hipFuncSetAttribute(reinterpret_cast<const void*>(lm_solve), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LM_SOLVE_LDS) == hipSuccess ? 0 : -1;
 }
 
@@ -789,10 +957,29 @@ void launch_lm_total(const DevCtx& d, const LmCtx& L, hipStream_t st) {
 void launch_lm_grid(const DevCtx& d, const LmCtx& L, hipStream_t st) {
   ALEGO_LAUNCH(lm_grid_build, dim3(2, d.n_launch), dim3(LM_BLOCK), 0, st, d, L);
 }
-void launch_lm_register(const DevCtx& d, const LmCtx& L, hipStream_t st) {
+// allreduce(buffer, count of doubles, stream): sums shard_part over the ranks in place (RCCL, lm_host.hip); nullptr = not sharded
+void launch_lm_register(const DevCtx& d, const LmCtx& L, hipStream_t st, int (*allreduce)(void*, double*, size_t, hipStream_t), void* ar_ctx) {
   ALEGO_LAUNCH(lm_knn, dim3(d.n_launch, 2, LM_ASSOC_GX), dim3(128), 0, st, d, L);
   ALEGO_LAUNCH(lm_fit, dim3(d.n_launch, 2, LM_FIT_GX), dim3(128), 0, st, d, L);
+  if (allreduce) {
+    double* part = L.shard_part + (size_t)d.slot0 * 32;
+    const size_t cnt = (size_t)d.n_launch * 32;
+    const dim3 g1((d.n_launch + 63) / 64), b1(64);
+    ALEGO_LAUNCH(lm_shard_pack, dim3(d.n_launch), dim3(LM_SOLVE_BLOCK), 0, st, d, L);
+    for (int outer = 0; outer < d.P.lm_outer_iters; ++outer) {
+      if (outer) ALEGO_LAUNCH(lm_shard_next_outer, g1, b1, 0, st, d, L);
+      ALEGO_LAUNCH(lm_shard_eval, dim3(d.n_launch), dim3(LM_SOLVE_BLOCK), LM_SOLVE_LDS, st, d, L, 0);
+      (void)allreduce(ar_ctx, part, cnt, st);
+      ALEGO_LAUNCH(lm_shard_step, g1, b1, 0, st, d, L, 1);
+      for (int it = 0; it < d.P.lm_max_iters; ++it) {
+        ALEGO_LAUNCH(lm_shard_eval, dim3(d.n_launch), dim3(LM_SOLVE_BLOCK), LM_SOLVE_LDS, st, d, L, 1);
+        (void)allreduce(ar_ctx, part, cnt, st);
+        ALEGO_LAUNCH(lm_shard_step, g1, b1, 0, st, d, L, 0);
+      }
+    }
+  } else {
   ALEGO_LAUNCH(lm_solve, dim3(d.n_launch), dim3(LM_SOLVE_BLOCK), LM_SOLVE_LDS, st, d, L);
+  }
   ALEGO_LAUNCH(lm_finish, dim3((d.n_launch + 63) / 64), dim3(64), 0, st, d, L);
   ALEGO_LAUNCH(lm_store_kf, dim3(8, 3, d.n_launch), dim3(LM_BLOCK), 0, st, d, L, -1);
 }

@@ -120,6 +120,11 @@ struct LmCtx {
   int *Ucnt_c, *Ucnt_s;                           // [slot][map_cap_*] points per voxel
   int* rec_prev;                                  // [slot][K] window the lists describe (ring frame ids, front first)
   float4* newkeys;                                // [slot][2][total_cap] scratch of map_update: (key lo, key hi, lower bound, count) of the voxels a run adds
+  // ---- one registration sharded over the ranks of a communicator (alego_dist_*; kernels lm_shard_*) ----
+  int shard_rank, shard_world;                    // world 0: not sharded
+  double* shard_part;                             // [slot][32] this rank's partial sums of an evaluation: 21 J^T J, 6 J^T r, cost, corner / surf rows; all-reduced in place
+  void* shard_state;                              // [slot] LmState of the solve in flight (dev_cost.h)
+  int* shard_ctl;                                 // [slot][8]: 0 local rows, 1 action of the last step, 2 solve finished, 3 outer iteration, 4 guard failed
   unsigned* map_bbox;                             // [slot][2][8] bounding box of the window's points in the VoxelGrid kernels' encoding (merge path)
   // the same key frames as saveKeyFramesAndFactor stores them (sensor frame, :553-555): host read-back + pose correction
   float4 *kf_raw_c, *kf_raw_s, *kf_raw_o;         // [slot][KR][kf_cap_*]

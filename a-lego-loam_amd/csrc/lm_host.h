@@ -28,6 +28,10 @@ int lm_host_reset_window(LmHost* lm, int slot, std::string* err);
 int lm_host_apply_correction(LmHost* lm, const DevCtx& d, int slot, const double* rc12, std::string* err);
 int lm_host_add_keyframe(LmHost* lm, const DevCtx& d, int slot, const float* pose6, const alego_point* corner, int nc, const alego_point* surf, int ns,
                          const alego_point* outlier, int no, std::string* err);
+int lm_host_dist_unique_id(char* id128);
+int lm_host_dist_init(LmHost* lm, int rank, int world, const char* id128, std::string* err);
+int lm_host_dist_shutdown(LmHost* lm);
+int lm_host_debug_slice(LmHost* lm, int rank, int world, std::string* err);
 int lm_host_set_map_merge(LmHost* lm, int on, std::string* err);
 int lm_host_debug_get(LmHost* lm, int slot, const char* name, void* out, int cap_bytes, int* count, int* dtype, std::string* err);
 #endif

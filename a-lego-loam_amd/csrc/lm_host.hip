@@ -7,6 +7,8 @@
 #include <cstring>
 #include <vector>
 
+#include <rccl/rccl.h>
+
 #include "lm_ctx.h"
 #include "voxel.h"
 
@@ -14,7 +16,7 @@ void launch_lm_prepare(const DevCtx& d, const LmCtx& L, int stage, int run_hint,
 void launch_lm_concat(const DevCtx& d, const LmCtx& L, hipStream_t st);
 void launch_lm_total(const DevCtx& d, const LmCtx& L, hipStream_t st);
 void launch_lm_grid(const DevCtx& d, const LmCtx& L, hipStream_t st);
-void launch_lm_register(const DevCtx& d, const LmCtx& L, hipStream_t st);
+void launch_lm_register(const DevCtx& d, const LmCtx& L, hipStream_t st, int (*allreduce)(void*, double*, size_t, hipStream_t), void* ar_ctx);
 void launch_lm_retransform(const DevCtx& d, const LmCtx& L, int ring, hipStream_t st);
 struct MapWork { int* items; int* count; int cap; };   // kernels_map.hip
 void launch_map_update(const DevCtx& d, const LmCtx& L, const MapWork& W, hipStream_t st);
@@ -34,6 +36,8 @@ struct LmHost {
   std::vector<VoxCtx> vk;      // per group: the two key-frame sort jobs of every slot alone (set_keypose / add_keyframe, outside the regular sequence)
   std::vector<MapWork> work;   // per group: work list of map_accum
   bool fallback_ok = true;     // buffers of the concat + radix VoxelGrid path (ALEGO_MAP_MERGE=0) are allocated
+  ncclComm_t comm = nullptr;   // alego_dist_init: the registration of every slot is sharded over the ranks of this communicator
+  std::string dist_err;
   std::vector<void*> allocs;
   std::vector<long> frames;  // host mirror of frame_cnt per slot: only used to skip launches
 };
@@ -84,6 +88,11 @@ LmHost* lm_host_create(const alego_params& P, const DevCtx& d, int n_slots, int 
   ok = ok && A(lm, &L.kf_cnt, B * L.KR * 4, err) && A(lm, &L.kf_pose, B * L.KR * 8, err);
   ok = ok && A(lm, &L.U_c, B * L.map_cap_c, err) && A(lm, &L.U_s, B * L.map_cap_s, err) && A(lm, &L.Ucnt_c, B * L.map_cap_c, err) && A(lm, &L.Ucnt_s, B * L.map_cap_s, err);
   ok = ok && A(lm, &L.newkeys, B * 2 * L.total_cap, err) && A(lm, &L.map_bbox, B * 2 * 8, err);
+  {
+    double* part = nullptr; int* ctl = nullptr; double* state = nullptr;
+    ok = ok && A(lm, &part, B * 32, err) && A(lm, &ctl, B * 8, err) && A(lm, &state, B * 64, err);   // LmState is < 64 doubles (checked in kernels_lm.hip)
+    L.shard_part = part; L.shard_ctl = ctl; L.shard_state = state;
+  }
   ok = ok && A(lm, &L.map_corner_raw, lm->fallback_ok ? B * L.map_cap_c : 1, err) && A(lm, &L.map_surf_raw, lm->fallback_ok ? B * L.map_cap_s : 1, err);
   ok = ok && A(lm, &L.map_corner_ds, B * L.map_cap_c, err) && A(lm, &L.map_surf_ds, B * L.map_cap_s, err);
   ok = ok && A(lm, &L.cur_corner_ds, B * L.kf_cap_c, err) && A(lm, &L.cur_surf_ds, B * L.kf_cap_s, err) && A(lm, &L.cur_outl_ds, B * L.kf_cap_o, err);
@@ -141,6 +150,7 @@ LmHost* lm_host_create(const alego_params& P, const DevCtx& d, int n_slots, int 
 
 void lm_host_destroy(LmHost* lm) {
   if (!lm) return;
+  if (lm->comm) { (void)ncclCommDestroy(lm->comm); lm->comm = nullptr; }
   for (auto& v : lm->vm) vox_destroy(&v);
   for (auto& v : lm->v2) vox_destroy(&v);
   for (auto& v : lm->vk) vox_destroy(&v);
@@ -191,6 +201,14 @@ static int map_sequence(LmHost* lm, const DevCtx& d, const LmCtx& L, int g, hipS
   return 0;
 }
 
+// sum of the partial normal equations over the ranks, in place, on the registration's stream (RCCL over xGMI)
+static int lm_allreduce(void* ctx, double* buf, size_t count, hipStream_t st) {
+  LmHost* lm = static_cast<LmHost*>(ctx);
+  const ncclResult_t r = ncclAllReduce(buf, buf, count, ncclDouble, ncclSum, lm->comm, st);
+  if (r != ncclSuccess) { lm->dist_err = std::string("ncclAllReduce: ") + ncclGetErrorString(r); return ALEGO_ERR_HIP; }
+  return 0;
+}
+
 // odom_valid[s - slot0]: whether slot s has an /odom/lidar message for this scan (false on its first scan)
 static int lm_sequence(LmHost* lm, const DevCtx& d, int stage, const std::vector<char>& odom_valid, std::string* err) {
   // the slots of one launch view always belong to one stream group
@@ -213,7 +231,7 @@ static int lm_sequence(LmHost* lm, const DevCtx& d, int stage, const std::vector
   launch_lm_total(d, L, st);
   if (int r = vox_run(lm->v2[g], st, err)) return r;
   if (!dbg_sync(st, "vox total", err)) return ALEGO_ERR_HIP;
-  launch_lm_register(d, L, st);
+  launch_lm_register(d, L, st, lm->comm ? &lm_allreduce : nullptr, lm);
   if (!dbg_sync(st, "lm_register", err)) return ALEGO_ERR_HIP;
   return 0;
 }
@@ -400,6 +418,42 @@ int lm_host_add_keyframe(LmHost* lm, const DevCtx& dfull, int slot, const float*
   if (e == hipSuccess) e = hipMemcpy(li + LI_DIRTY, &one, sizeof(int), hipMemcpyHostToDevice);
   if (e != hipSuccess) { *err = std::string("add_keyframe: ") + hipGetErrorString(e); return ALEGO_ERR_HIP; }
   return retransform(lm, dfull, slot, ring, err);
+}
+
+// ---- one registration sharded over the ranks of a communicator (alego_dist_*) ----
+int lm_host_dist_unique_id(char* id128) {
+  static_assert(sizeof(ncclUniqueId) <= 128, "ALEGO_DIST_ID_BYTES");
+  ncclUniqueId u;
+  if (ncclGetUniqueId(&u) != ncclSuccess) return ALEGO_ERR_HIP;
+  std::memset(id128, 0, 128);
+  std::memcpy(id128, &u, sizeof(u));
+  return 0;
+}
+int lm_host_dist_init(LmHost* lm, int rank, int world, const char* id128, std::string* err) {
+  if (lm->comm) { *err = "alego_dist_init: already initialised"; return ALEGO_ERR_ARG; }
+  if (world < 1 || rank < 0 || rank >= world) { *err = "alego_dist_init: rank / world out of range"; return ALEGO_ERR_ARG; }
+  if (lm->st.size() != 1) { *err = "alego_dist_init: a sharded registration needs a handle with one stream group (collectives of one communicator must not overlap)"; return ALEGO_ERR_ARG; }
+  ncclUniqueId u;
+  std::memcpy(&u, id128, sizeof(u));
+  const ncclResult_t r = ncclCommInitRank(&lm->comm, world, u, rank);
+  if (r != ncclSuccess) { lm->comm = nullptr; *err = std::string("ncclCommInitRank: ") + ncclGetErrorString(r); return ALEGO_ERR_HIP; }
+  lm->L.shard_rank = rank; lm->L.shard_world = world;
+  return 0;
+}
+int lm_host_dist_shutdown(LmHost* lm) {
+  if (!lm->comm) return 0;
+  for (hipStream_t s : lm->st) (void)hipStreamSynchronize(s);
+  (void)ncclCommDestroy(lm->comm);
+  lm->comm = nullptr; lm->L.shard_rank = 0; lm->L.shard_world = 0;
+  return 0;
+}
+
+// tests: only the query slice of rank `rank` of `world` is associated (no communicator: the fused solver then works on that slice alone)
+int lm_host_debug_slice(LmHost* lm, int rank, int world, std::string* err) {
+  if (lm->comm) { *err = "ALEGO_SHARD_SLICE: a communicator is active"; return ALEGO_ERR_ARG; }
+  if (world < 0 || (world > 0 && (rank < 0 || rank >= world))) { *err = "ALEGO_SHARD_SLICE: rank / world out of range"; return ALEGO_ERR_ARG; }
+  lm->L.shard_rank = rank; lm->L.shard_world = world;
+  return 0;
 }
 
 // ALEGO_MAP_MERGE switched at run time (tests): the voxel lists no longer describe what the other path did in between

@@ -27,6 +27,16 @@ def init(backend: str, device=None):
     return dist
 
 
+def shard_registration(handle, dist, rank: int, world: int):
+    """BASELINE config 5: every rank runs the same stream; the scan-to-map registration is split over the ranks and its
+    normal equations are summed with RCCL (alego_dist_init).  The unique id travels through torch.distributed."""
+    from . import binding
+    box = [binding.dist_unique_id() if rank == 0 else None]
+    if dist is not None and world > 1:
+        dist.broadcast_object_list(box, src=0)
+    handle.dist_init(rank, world, box[0])
+
+
 def max_over_ranks(seconds: float, dist, device="cpu") -> float:
     """The job's step time is the slowest rank's."""
     if dist is None:

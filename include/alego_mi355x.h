@@ -212,6 +212,19 @@ int alego_lm_apply_correction(alego_handle* h, int slot, const double rc[12]);
 int alego_lm_add_keyframe(alego_handle* h, int slot, const float pose6[6], const alego_point* corner, int32_t n_corner,
                           const alego_point* surf, int32_t n_surf, const alego_point* outlier, int32_t n_outlier);
 
+/* ---- one scan-to-map registration sharded over the GPUs of a node (BASELINE.json config 5) ----------------
+ * One process per GPU; every rank feeds its handle the SAME scans and so keeps a bit-identical replica of the stream's state
+ * (ImageProjection, feature extraction, LaserOdometry and the local map are cheap and are computed redundantly).  What is split
+ * is scan2MapOptimization (laserMapping.cpp:360-478): rank r owns the queries [r T / G, (r + 1) T / G) of laser_corner_ds_ ++
+ * laser_surf_total_ds_ (5-NN, line / plane fit, residual + Jacobian rows); for every solver evaluation the 28 normal-equation
+ * scalars J^T J (21), J^T r (6), cost (1) (+ 2 correspondence counts) are summed with ncclAllReduce(f64) — RCCL over xGMI — on
+ * the handle's stream, and every rank takes the identical trust-region step.  The handle must have a single stream group
+ * (fewer than 128 slots).  world = 1 is allowed: same kernel sequence, the collective is a copy (hardware tests on one GPU). */
+#define ALEGO_DIST_ID_BYTES 128
+int alego_dist_unique_id(char id[ALEGO_DIST_ID_BYTES]);   /* rank 0: ncclGetUniqueId; distribute the bytes to every rank */
+int alego_dist_init(alego_handle* h, int rank, int world, const char id[ALEGO_DIST_ID_BYTES]);
+int alego_dist_shutdown(alego_handle* h);
+
 /* ---- sensor_msgs/PointCloud2 to alego_point: pcl::fromROSMsg<PointXYZI>, imageProjection.cpp:54-55, IP.cpp:109-110 ----
  * ROS-free mirror of sensor_msgs/PointField + the PointCloud2 layout fields.  Fields are matched by name ("x", "y", "z",
  * "intensity") and must be FLOAT32 (datatype 7) with count 1, as PCL's field mapper requires; a missing intensity gives 0.

@@ -1022,6 +1022,7 @@ struct LaserMapping {
   bool ran_body = false, optimized = false, keyframe_added = false;
   int n_corner_corr = 0, n_surf_corr = 0;
   std::vector<int> corner_corr_q, surf_corr_q;  // accepted query indices (first outer iteration)
+  std::vector<double> blocks14;                 // the residual blocks of the first outer iteration: type, cp, a, b, c, d
   SolveSummary sums[2];
   double params_iter[2][6];
   double t_map_ms = 0, t_ds_ms = 0, t_tree_ms = 0, t_assoc_ms = 0, t_solve_ms = 0;
@@ -1202,6 +1203,17 @@ struct LaserMapping {
       }
       auto a1 = std::chrono::steady_clock::now();
       n_corner_corr = cc; n_surf_corr = sc;
+      if (iter_cnt == 0) {
+        blocks14.clear();
+        for (const Block& B : blocks) {
+          blocks14.push_back((double)B.type);
+          for (int a = 0; a < 3; ++a) blocks14.push_back(B.cp[a]);
+          for (int a = 0; a < 3; ++a) blocks14.push_back(B.a[a]);
+          for (int a = 0; a < 3; ++a) blocks14.push_back(B.b[a]);
+          for (int a = 0; a < 3; ++a) blocks14.push_back(B.c[a]);
+          blocks14.push_back(B.d);
+        }
+      }
       CeresLike solver;
       SolveSummary s = solver.solve(blocks, params, P.lm_max_iters, P.huber_delta);
       if (iter_cnt < 2) { sums[iter_cnt] = s; std::memcpy(params_iter[iter_cnt], params, sizeof(params)); }
@@ -1537,6 +1549,7 @@ int oracle_get(void* h, const char* name, const void** ptr, int* count, int* dty
   if (s == "lm_surf_total_ds") return cloud(lm.laser_surf_total_ds);
   if (s == "lm_corner_corr_q") { *dtype = ORACLE_I32; return ret(lm.corner_corr_q, ptr, count); }
   if (s == "lm_surf_corr_q") { *dtype = ORACLE_I32; return ret(lm.surf_corr_q, ptr, count); }
+  if (s == "lm_blocks14") { *dtype = ORACLE_F64; return ret(lm.blocks14, ptr, count); }
   if (s == "lm_keyposes") { *dtype = ORACLE_F32; *ptr = lm.keyposes.data(); *count = (int)lm.keyposes.size() * 6; return 0; }
   if (s == "lm_map2odom") {
     c->scratch_d = {lm.t_map2odom[0], lm.t_map2odom[1], lm.t_map2odom[2], lm.q_map2odom.w, lm.q_map2odom.x, lm.q_map2odom.y, lm.q_map2odom.z};
@@ -1610,6 +1623,30 @@ int oracle_knn(const alego_point* cloud, int n, const alego_point* q, int nq, in
 }
 
 void oracle_eig3(const double* A9, double* lam3, double* V9) { eig3(A9, lam3, V9); }
+
+// Normal equations of a set of residual blocks at params6 with HuberLoss(huber) + corrector: out28 = upper triangle of J^T J (21, row by
+// row), J^T r (6), cost (1) — what one rank of a sharded registration contributes to the all-reduce.
+void oracle_normal_eq(const double* blocks14, int n, const double* params6, double huber, double* out28) {
+  for (int k = 0; k < 28; ++k) out28[k] = 0;
+  const double b2 = huber * huber;
+  for (int i = 0; i < n; ++i) {
+    const double* g = blocks14 + (size_t)i * 14;
+    Block B; B.type = (int)g[0];
+    std::memcpy(B.cp, g + 1, 24); std::memcpy(B.a, g + 4, 24); std::memcpy(B.b, g + 7, 24); std::memcpy(B.c, g + 10, 24); B.d = g[13];
+    double r, J[6];
+    eval_block(B, params6, &r, J);
+    const double s = r * r;
+    double rho0, rho1;
+    if (s > b2) { const double rr = std::sqrt(s); rho0 = 2.0 * huber * rr - b2; rho1 = std::max(DBL_MIN, huber / rr); } else { rho0 = s; rho1 = 1.0; }
+    const double sq = std::sqrt(rho1);
+    for (int k = 0; k < 6; ++k) J[k] *= sq;
+    r *= sq;
+    int t = 0;
+    for (int a = 0; a < 6; ++a) for (int b = a; b < 6; ++b) out28[t++] += J[a] * J[b];
+    for (int k = 0; k < 6; ++k) out28[21 + k] += J[k] * r;
+    out28[27] += 0.5 * rho0;
+  }
+}
 
 // transformToStart (laserOdometry.cpp:728-740) with params_ = params6
 void oracle_transform_to_start(const double* params6, const alego_point* in, int n, alego_point* out) {

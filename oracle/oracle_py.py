@@ -52,6 +52,7 @@ def lib():
         L.oracle_transform_cloud.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.oracle_run_pipelined.restype = C.c_double
         L.oracle_run_pipelined.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.oracle_normal_eq.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_double, C.c_void_p]
         L.oracle_sincosf_array.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
         _lib = L
     return _lib
@@ -218,4 +219,13 @@ def sincosf(x, mode):
     a = np.ascontiguousarray(x, dtype=np.float32)
     out = np.empty_like(a)
     lib().oracle_sincosf_array(a.ctypes.data, out.ctypes.data, a.size, mode)
+    return out
+
+
+def normal_eq(blocks14, params6, huber=0.1):
+    """28 scalars (upper triangle of J^T J, J^T r, cost) of the given residual blocks at params6."""
+    b = np.ascontiguousarray(blocks14, dtype=np.float64).reshape(-1, 14)
+    p = np.ascontiguousarray(params6, dtype=np.float64)
+    out = np.zeros(28)
+    lib().oracle_normal_eq(b.ctypes.data, b.shape[0], p.ctypes.data, huber, out.ctypes.data)
     return out

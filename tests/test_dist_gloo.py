@@ -53,3 +53,66 @@ def test_two_rank_stream_sharding():
     poses = np.array(sum((g[1] for g in gathered), []))
     assert len({tuple(np.round(x, 9)) for x in poses}) == 4  # four different streams were really processed
     assert value == 2 * 2 * 3 / 2.0
+
+
+def _shard_worker(rank, world, port, q):
+    """One registration (BASELINE config 5): both ranks hold the same scans and map (replicated state); each evaluates its
+    contiguous half of the residual rows, the 28 normal-equation scalars are all-reduced (gloo here, RCCL on the GPUs) and
+    every rank takes the same trust-region steps."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from alego_loader import load_package
+    load_package()
+    from alego_amd import dist as D, synth
+    from oracle import oracle_py as O
+    import lm_control
+    dist = D.init("gloo")
+    p = synth.default_params(16, 1800)
+    o = O.Oracle(p)
+    x0 = None
+    for k in range(16):          # every rank processes the same stream: identical (replicated) state
+        if k == 15:
+            x0 = o.get("lm_params").copy()
+        o.process_scan(synth.scan(p, k))
+    assert o.get("lm_info")[1] == 1, "scan 15 is a mapping frame with an optimisation"
+    blocks = o.get("lm_blocks14").reshape(-1, 14)
+    T = blocks.shape[0]
+    mine = blocks[rank * T // world:(rank + 1) * T // world]      # this rank's slice of the rows
+    n_allreduce = [0]
+
+    def evaluate(x):
+        part = torch.from_numpy(O.normal_eq(mine, x, p.huber_delta))
+        dist.all_reduce(part)                                       # 28 doubles = 224 B per evaluation
+        n_allreduce[0] += 1
+        return part.numpy()
+
+    x, info = lm_control.solve(evaluate, x0, p.lm_max_iters)
+    x1, info1 = lm_control.solve(lambda xx: O.normal_eq(blocks, xx, p.huber_delta), x0, p.lm_max_iters)   # one rank, all rows
+    xq, infoq = O.solve(np.concatenate([blocks[:, :1], blocks[:, 1:]], axis=1), x0, p.lm_max_iters, p.huber_delta)   # the oracle's DENSE_QR Ceres restatement
+    gathered = [None] * world
+    dist.all_gather_object(gathered, x.tolist())
+    if rank == 0:
+        q.put(dict(T=int(T), n_mine=int(mine.shape[0]), x=x.tolist(), x1=x1.tolist(), xq=xq.tolist(), info=info, info1=info1, infoq=infoq,
+                   others=gathered, n_allreduce=n_allreduce[0]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_registration():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29100 + (os.getpid() % 400)
+    procs = [ctx.Process(target=_shard_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    r = q.get(timeout=90)
+    [p.join(60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    x, x1, xq = np.array(r["x"]), np.array(r["x1"]), np.array(r["xq"])
+    assert r["T"] > 500 and abs(r["n_mine"] - r["T"] / 2) <= 1
+    assert np.array_equal(np.array(r["others"][0]), np.array(r["others"][1])), "both ranks must end with the identical pose"
+    assert np.abs(x - x1).max() < 1e-9, "2-rank sum order vs 1-rank sum order"
+    assert np.abs(x - xq).max() < 1e-4 and np.abs(x[3:] - xq[3:]).max() < 1e-4, (x, xq)      # north_star tolerance vs the QR-based oracle solve
+    assert np.abs(x - xq).max() < 1e-6, "normal equations + Cholesky agree with DENSE_QR far inside the tolerance"
+    assert r["info"]["iterations"] == r["infoq"]["iterations"] and r["info"]["termination"] == r["infoq"]["termination"]
+    assert r["n_allreduce"] == 1 + r["info"]["iterations"] - 0 or r["n_allreduce"] <= 1 + r["info"]["iterations"]

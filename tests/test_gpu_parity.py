@@ -842,3 +842,67 @@ def test_bag_replay_equals_single_stream(params_a):
         assert_bit_equal(mpb["params"], mp1["params"], f"slot {s} LM params_")
         h1.close()
     hb.close()
+
+
+def test_sharded_registration_single_rank_equals_fused_solver(params_a):
+    """alego_dist_init with world = 1 (RCCL communicator of one rank): the registration runs as the sharded kernel sequence
+    (pack / evaluate / ncclAllReduce / step, one collective per solver evaluation) instead of the fused lm_solve.  Same rows, same
+    order, same reduction: LaserMapping's params_, solver summaries and poses must be bit-identical to the fused path's."""
+    p = params_a
+    ha, hb = binding.Handle(p), binding.Handle(p)
+    hb.dist_init(0, 1, binding.dist_unique_id())
+    for k in range(24):
+        pts = synth.scan(p, k)
+        _, _, ma = ha.scan_process(pts, stages=7)
+        _, _, mb = hb.scan_process(pts, stages=7)
+        assert_bit_equal(mb["params"], ma["params"], f"scan {k} LM params_")
+        assert_bit_equal(mb["t"], ma["t"], f"scan {k} map translation")
+        ia, ib = ha.debug_get("lm_info"), hb.debug_get("lm_info")
+        assert_bit_equal(ib[6:12], ia[6:12], f"scan {k} correspondences / solver summaries")
+        assert_bit_equal(hb.debug_get("lm_state")[27:43], ha.debug_get("lm_state")[27:43], f"scan {k} params_ per outer iteration and costs")
+    hb.dist_shutdown()
+    _, _, mb = hb.scan_process(synth.scan(p, 24), stages=7)      # back on the fused solver
+    _, _, ma = ha.scan_process(synth.scan(p, 24), stages=7)
+    assert_bit_equal(mb["params"], ma["params"], "after alego_dist_shutdown")
+    ha.close(); hb.close()
+
+
+def test_sharded_registration_slices_partition_the_queries(params_a):
+    """The query slices of two ranks (contiguous slices of laser_corner_ds_ ++ laser_surf_total_ds_) are disjoint and
+    cover what one rank accepts: the rows a rank contributes to the all-reduce are exactly its share of the unsharded rows."""
+    p = params_a
+    h = [binding.Handle(p) for _ in range(3)]
+    h[1].set_option("ALEGO_SHARD_SLICE", 0 | (2 << 8))
+    h[2].set_option("ALEGO_SHARD_SLICE", 1 | (2 << 8))
+    o = O.Oracle(p)
+    kf_cap_c = 120 * p.n_scan
+    for k in range(14):
+        pts = synth.scan(p, k)
+        for x in h:
+            x.set_lo_params(o.get("lo_params")); x.set_lm_params(o.get("lm_params"))
+        o.process_scan(pts)
+        for x in h:
+            x.scan_process(pts, stages=7)
+        if not o.get("lm_info")[1]:
+            continue
+        acc = []
+        for x in h:
+            gi = x.debug_get("lm_info")
+            blocks = x.debug_get("lm_blocks").reshape(-1, 8)
+            qc = np.nonzero(blocks[:gi[19], 7] != 0)[0]
+            qs = np.nonzero(blocks[kf_cap_c:kf_cap_c + gi[23], 7] != 0)[0]
+            acc.append((set(qc.tolist()), set(qs.tolist()), int(gi[19]), int(gi[23])))
+        full, r0, r1 = acc
+        assert r0[0].isdisjoint(r1[0]) and r0[1].isdisjoint(r1[1])
+        assert r0[0] | r1[0] == full[0] and r0[1] | r1[1] == full[1], f"scan {k}: the two slices do not add up to the unsharded rows"
+        T = full[2] + full[3]
+        cut = T // 2     # rank 0 owns the concatenated indices [0, T/2)
+        assert all(q < cut for q in r0[0]) and all(q + full[2] < cut for q in r0[1])
+        assert all(q >= cut for q in r1[0]) and all(q + full[2] >= cut for q in r1[1])
+        assert_bit_equal(np.array(sorted(full[0]), np.int32), o.get("lm_corner_corr_q"), f"scan {k} unsharded corner rows vs oracle")
+        assert len(full[0]) > 100 and len(full[1]) > 300
+        break   # (a rank that solves on its slice alone ends with another map -> odom: only the first optimised frame is comparable)
+    else:
+        raise AssertionError("no optimised mapping frame in the test")
+    for x in h:
+        x.close()
