@@ -25,7 +25,7 @@ EXPORTS = [
     "alego_debug_math", "alego_debug_eval_blocks", "alego_debug_transform_to_start", "alego_debug_set_option",
     "alego_lm_keyframe_count", "alego_lm_get_keyframe", "alego_lm_set_keypose", "alego_lm_reset_window", "alego_lm_apply_correction",
     "alego_lm_add_keyframe", "alego_pc2_to_points", "alego_replay_create", "alego_replay_load", "alego_replay_assign",
-    "alego_dist_unique_id", "alego_dist_init", "alego_dist_shutdown",
+    "alego_dist_unique_id", "alego_dist_init", "alego_dist_shutdown", "alego_stream_setup", "alego_stream_run",
 ]
 
 REPLAY_PINGPONG = 0x100
@@ -163,6 +163,10 @@ def lib():
         L.alego_dist_init.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_char_p]
         L.alego_dist_shutdown.restype = C.c_int
         L.alego_dist_shutdown.argtypes = [C.c_void_p]
+        L.alego_stream_setup.restype = C.c_int
+        L.alego_stream_setup.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.alego_stream_run.restype = C.c_int
+        L.alego_stream_run.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
         if L.alego_params_sizeof() != C.sizeof(AlegoParams):
             raise RuntimeError("alego_params layout mismatch between params.py and include/alego_params.h")
         _lib = L
@@ -338,6 +342,13 @@ class Handle:
 
     def replay_assign(self, slot, bag, start_scan):
         self._check(lib().alego_replay_assign(self._h, slot, bag, start_scan), "alego_replay_assign")
+
+    def stream_setup(self, bag, start_scan=0):
+        """slot 0 = one stream replaying `bag`; the other slots become its look-ahead lanes (alego_stream_run)"""
+        self._check(lib().alego_stream_setup(self._h, bag, start_scan), "alego_stream_setup")
+
+    def stream_run(self, first_step, n_scans, stages=7, sync=True):
+        self._check(lib().alego_stream_run(self._h, first_step, n_scans, stages, 1 if sync else 0), "alego_stream_run")
 
     def batch_run(self, first_pos, n_scans, stages=7, sync=True):
         self._check(lib().alego_batch_run(self._h, first_pos, n_scans, stages, 1 if sync else 0), "alego_batch_run")

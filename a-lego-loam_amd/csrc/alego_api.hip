@@ -45,6 +45,14 @@ struct alego_handle {
   Profiler prof;
   int ip_fast_capable = 0;  // which of ip_project's table fast paths this geometry supports
   bool replay_assigned = false;
+  // alego_stream_run: look-ahead lanes
+  bool stream_mode = false;
+  int lanes = 0;               // W: lanes per set (slots 1 .. W and W + 1 .. 2 W)
+  int pose_slot = 0;           // slot holding the poses of the last processed scan of slot 0 (its lane)
+  int last_lane = -1;          // lane of the previous scan (LaserOdometry's surf_last_ / corner_last_)
+  hipStream_t s_lo = nullptr, s_lm = nullptr;
+  std::vector<hipEvent_t> ev_pool;
+  size_t ev_next = 0;
 };
 
 namespace {
@@ -82,6 +90,7 @@ hipStream_t stream_of(const alego_handle* h, int slot) { return h->streams[slot 
 hipError_t sync_all(const alego_handle* h) {
   hipError_t r = hipSuccess;
   for (hipStream_t s : h->streams) { hipError_t e = hipStreamSynchronize(s); if (e != hipSuccess) r = e; }
+  for (hipStream_t s : {h->s_lo, h->s_lm}) if (s) { hipError_t e = hipStreamSynchronize(s); if (e != hipSuccess) r = e; }
   return r;
 }
 
@@ -174,6 +183,7 @@ int alego_create(const alego_params* params, int device, int n_slots, int ring_l
   std::memset(&d, 0, sizeof(d));
   d.P = *params;
   d.n_slots = n_slots; d.ring_len = ring_len; d.slot0 = 0; d.n_launch = n_slots;
+  d.fs_cur = d.fs_last = -1;
   d.NS = params->n_scan; d.H = params->horizon_scan; d.N = d.NS * d.H; d.Pcap = d.N;
   d.cap_sharp = params->n_sharp * params->n_sectors;
   d.cap_lsharp = params->n_less_sharp * params->n_sectors;
@@ -276,6 +286,9 @@ void alego_destroy(alego_handle* h) {
   if (h->lm) lm_host_destroy(h->lm);
   for (void* p : h->allocs) hipFree(p);
   for (hipStream_t s : h->streams) hipStreamDestroy(s);
+  if (h->s_lo) hipStreamDestroy(h->s_lo);
+  if (h->s_lm) hipStreamDestroy(h->s_lm);
+  for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
   delete h;
 }
 
@@ -325,6 +338,84 @@ int alego_replay_assign(alego_handle* h, int slot, int bag, int start_scan) {
   return 0;
 }
 
+int alego_stream_setup(alego_handle* h, int bag, int start_scan) {
+  if (!h) return ALEGO_ERR_ARG;
+  if (!h->d.bag_pts || bag < 0 || bag >= h->d.n_bags || start_scan < 0) { h->err = "alego_stream_setup: needs alego_replay_create and a valid bag"; return ALEGO_ERR_ARG; }
+  if (h->d.n_slots < 3 || h->streams.size() != 1) { h->err = "alego_stream_setup: the handle needs n_slots = 1 + 2 W >= 3 (one stream group)"; return ALEGO_ERR_ARG; }
+  hipSetDevice(h->device);
+  const int W = (h->d.n_slots - 1) / 2;
+  if (int r = alego_replay_assign(h, 0, bag, start_scan)) return r;
+  for (int set = 0; set < 2; ++set)
+    for (int j = 0; j < W; ++j)   // lane j of either set processes scan (start + group base + j)
+      if (int r = alego_replay_assign(h, 1 + set * W + j, bag, start_scan + j)) return r;
+  if (!h->s_lo && (hipStreamCreate(&h->s_lo) != hipSuccess || hipStreamCreate(&h->s_lm) != hipSuccess)) { h->err = "alego_stream_setup: hipStreamCreate failed"; return ALEGO_ERR_HIP; }
+  h->stream_mode = true; h->lanes = W; h->pose_slot = 0; h->last_lane = -1;
+  return 0;
+}
+
+int alego_stream_run(alego_handle* h, int first_step, int n_scans, int stages, int sync) {
+  if (!h) return ALEGO_ERR_ARG;
+  if (!h->stream_mode) { h->err = "alego_stream_run: call alego_stream_setup first"; return ALEGO_ERR_ARG; }
+  hipSetDevice(h->device);
+  g_prof = &h->prof;
+  const int W = h->lanes;
+  hipStream_t sA = h->streams[0], sB = h->s_lo, sC = h->s_lm;
+  auto ev = [&]() -> hipEvent_t {
+    if (h->ev_next == h->ev_pool.size()) { hipEvent_t e; (void)hipEventCreateWithFlags(&e, hipEventDisableTiming); h->ev_pool.push_back(e); }
+    return h->ev_pool[h->ev_next++];
+  };
+  h->ev_next = 0;
+  // the three streams start behind whatever any of them did before (earlier runs still in flight, host entry points)
+  {
+    hipEvent_t eb = ev(), ec = ev(), ea = ev();
+    HIP_TRY(h, hipEventRecord(eb, sB)); HIP_TRY(h, hipEventRecord(ec, sC));
+    HIP_TRY(h, hipStreamWaitEvent(sA, eb, 0)); HIP_TRY(h, hipStreamWaitEvent(sA, ec, 0));
+    HIP_TRY(h, hipEventRecord(ea, sA)); HIP_TRY(h, hipStreamWaitEvent(sB, ea, 0)); HIP_TRY(h, hipStreamWaitEvent(sC, ea, 0));
+  }
+  hipEvent_t lm_done[2] = {nullptr, nullptr};    // LaserMapping has consumed every lane of the set's previous use
+  hipEvent_t lo_first_done = nullptr;            // LaserOdometry of the first scan of the previous group (it still reads the last lane of the group before)
+  const bool do_lo = (stages & 2) != 0, do_lm = do_lo && (stages & 4);
+  int g = 0;
+  for (int base = 0; base < n_scans; base += W, ++g) {
+    const int w = std::min(W, n_scans - base), set = g & 1, lane0 = 1 + set * W;
+    // ---- ImageProjection + feature extraction of w scans, one per lane (stream A)
+    if (lm_done[set]) HIP_TRY(h, hipStreamWaitEvent(sA, lm_done[set], 0));
+    if (lo_first_done) HIP_TRY(h, hipStreamWaitEvent(sA, lo_first_done, 0));
+    DevCtx dl = view(h, lane0, w);
+    dl.replay_bag = 1;
+    const int pos = (int)(((long long)first_step + base) % h->d.bag_len);
+    if (stages & 1) launch_ip(dl, pos, false, sA);
+    if (do_lo) launch_fe(dl, sA);
+    hipEvent_t fe_done = ev();
+    HIP_TRY(h, hipEventRecord(fe_done, sA));
+    if (!do_lo) { h->pose_slot = lane0 + w - 1; continue; }
+    HIP_TRY(h, hipStreamWaitEvent(sB, fe_done, 0));
+    for (int j = 0; j < w; ++j) {
+      // ---- LaserOdometry of the stream (slot 0) on the features of lane (stream B)
+      DevCtx ds = view(h, 0, 1);
+      ds.fs_cur = lane0 + j; ds.fs_last = h->last_lane >= 0 ? h->last_lane : lane0 + j;   // (first scan ever: LaserOdometry only initialises)
+      launch_lo(ds, sB);
+      hipEvent_t lo_done = ev();
+      HIP_TRY(h, hipEventRecord(lo_done, sB));
+      if (j == 0) lo_first_done = lo_done;
+      const bool odom_valid = h->lo_scans[0]++ > 0;
+      if (do_lm) {
+        // ---- LaserMapping of that scan (stream C)
+        HIP_TRY(h, hipStreamWaitEvent(sC, lo_done, 0));
+        if (int r = lm_host_enqueue(h->lm, ds, std::vector<char>(1, odom_valid ? 1 : 0), &h->err, sC)) return r;
+      }
+      h->last_lane = lane0 + j;
+      h->pose_slot = lane0 + j;
+    }
+    hipEvent_t done = ev();
+    HIP_TRY(h, hipEventRecord(done, do_lm ? sC : sB));
+    lm_done[set] = done;
+  }
+  HIP_TRY(h, hipGetLastError());
+  if (sync) HIP_TRY(h, sync_all(h));
+  return 0;
+}
+
 // enqueue IP -> FE -> LO -> LM for slots [slot0, slot0+n) on ring position `pos`
 static int enqueue_scan(alego_handle* h, int slot0, int n, int pos, int stages, bool want_labels) {
   DevCtx d = view(h, slot0, n);
@@ -371,7 +462,9 @@ int alego_batch_run(alego_handle* h, int first_pos, int n_scans, int stages, int
 static int fetch_pose(alego_handle* h, int slot, alego_pose* odom, alego_pose* map_pose) {
   double po[16], st[LO_STATE_N];
   int sc[SC_COUNT];
-  HIP_TRY(h, hipMemcpyAsync(po, h->d.poses + (size_t)slot * 16, sizeof(po), hipMemcpyDeviceToHost, stream_of(h, slot)));
+  const int pslot = (h->stream_mode && slot == 0) ? h->pose_slot : slot;   // alego_stream_run: the last scan's poses live in its lane
+  if (h->stream_mode) HIP_TRY(h, sync_all(h));
+  HIP_TRY(h, hipMemcpyAsync(po, h->d.poses + (size_t)pslot * 16, sizeof(po), hipMemcpyDeviceToHost, stream_of(h, slot)));
   HIP_TRY(h, hipMemcpyAsync(st, h->d.lo_state + (size_t)slot * LO_STATE_N, sizeof(st), hipMemcpyDeviceToHost, stream_of(h, slot)));
   HIP_TRY(h, hipMemcpyAsync(sc, h->d.scal + (size_t)slot * SC_COUNT, sizeof(sc), hipMemcpyDeviceToHost, stream_of(h, slot)));
   HIP_TRY(h, hipStreamSynchronize(stream_of(h, slot)));
@@ -401,11 +494,16 @@ int alego_batch_get_pose(alego_handle* h, int slot, alego_pose* odom, alego_pose
 int alego_batch_get_counts(alego_handle* h, int slot, int32_t* out, int cap) {
   if (int r = check_slot(h, slot)) return r;
   hipSetDevice(h->device);
-  int sc[SC_COUNT], fc[8];
-  HIP_TRY(h, hipMemcpyAsync(sc, h->d.scal + (size_t)slot * SC_COUNT, sizeof(sc), hipMemcpyDeviceToHost, stream_of(h, slot)));
-  HIP_TRY(h, hipMemcpyAsync(fc, h->d.feat_cnt + (size_t)slot * 8, sizeof(fc), hipMemcpyDeviceToHost, stream_of(h, slot)));
+  int sc[SC_COUNT], fc[8], sl[SC_COUNT];
+  const bool lane = h->stream_mode && slot == 0;   // alego_stream_run: the per-scan counters of the last scan live in its lane (buffer 0)
+  const int cslot = lane ? h->pose_slot : slot;
+  if (lane) HIP_TRY(h, sync_all(h));
+  HIP_TRY(h, hipMemcpyAsync(sc, h->d.scal + (size_t)cslot * SC_COUNT, sizeof(sc), hipMemcpyDeviceToHost, stream_of(h, slot)));
+  HIP_TRY(h, hipMemcpyAsync(sl, h->d.scal + (size_t)slot * SC_COUNT, sizeof(sl), hipMemcpyDeviceToHost, stream_of(h, slot)));
+  HIP_TRY(h, hipMemcpyAsync(fc, h->d.feat_cnt + (size_t)cslot * 8, sizeof(fc), hipMemcpyDeviceToHost, stream_of(h, slot)));
   HIP_TRY(h, hipStreamSynchronize(stream_of(h, slot)));
-  const int cur = sc[SC_CUR];  // buffer written by the last processed scan
+  sc[SC_LO_NSURF] = sl[SC_LO_NSURF]; sc[SC_LO_NCORNER] = sl[SC_LO_NCORNER];   // LaserOdometry's counters belong to the stream's own slot
+  const int cur = lane ? 0 : sc[SC_CUR];  // buffer written by the last processed scan
   int v[16] = {sc[SC_PVALID_OUT], sc[SC_M], sc[SC_NOUT], fc[cur * 4 + 0], fc[cur * 4 + 1], fc[cur * 4 + 2], fc[cur * 4 + 3],
                sc[SC_LO_NSURF], sc[SC_LO_NCORNER], 0, 0, 0, 0, 0, 0, 0};  // v[15] = map rebuilds so far
   lm_host_get_counts(h->lm, slot, v + 9);

@@ -69,6 +69,11 @@ struct DevCtx {
   const int* bag_n;       // [bag][bag_len]
   const int2* bag_src;    // [slot]
   int n_bags, bag_len, replay_bag;
+  // ---- look-ahead lanes (alego_stream_run): ImageProjection + feature extraction carry no state across scans, so a single stream
+  // runs them for several scans ahead in one launch, each scan in a "lane" (a slot used only for its per-scan buffers).  LaserOdometry /
+  // LaserMapping of the stream's own slot then take the features, outliers and odometry hand-over of the scan in flight from lane
+  // fs_cur and the previous scan's features from lane fs_last (-1: the slot's own double buffers, the normal batch / single-scan mode).
+  int fs_cur, fs_last;
   // ---- image projection ----
   int* owner;           // [slot][N] winning input index per cell (last writer = max index), -1 empty; ip_project writes
                         // IP_OWNER_TAG | index, ip_image turns every cell back into the plain form (= the reset for the next scan)
@@ -144,6 +149,12 @@ DEV_INLINE int cell_row(const DevCtx& d, int v) { return (int)__umulhi((unsigned
 
 // buffer written by the scan in flight (valid from fe_gather until lo_solve phase 1 flips SC_CUR)
 DEV_INLINE int cur_in_flight(const DevCtx& d, int slot) { return d.scal[slot * SC_COUNT + SC_CUR] ^ 1; }
+// index into the [slot][2] feature arrays of the scan in flight / of the previous scan, as LaserOdometry sees them.  A lane never
+// runs lo_solve, so its SC_CUR stays at its initial 1 and feature extraction always fills its buffer 0.
+DEV_INLINE size_t fidx_cur(const DevCtx& d, int slot) { return d.fs_cur >= 0 ? (size_t)d.fs_cur * 2 : (size_t)slot * 2 + cur_in_flight(d, slot); }
+DEV_INLINE size_t fidx_last(const DevCtx& d, int slot) { return d.fs_last >= 0 ? (size_t)d.fs_last * 2 : (size_t)slot * 2 + (cur_in_flight(d, slot) ^ 1); }
+// slot whose per-scan outputs (poses, outlier cloud, outlier count) belong to the scan in flight
+DEV_INLINE int scan_slot_of(const DevCtx& d, int slot) { return d.fs_cur >= 0 ? d.fs_cur : slot; }
 
 DEV_INLINE int32_t d_f2i(float f) { return __float_as_int(f); }
 DEV_INLINE float d_i2f(int32_t i) { return __int_as_float(i); }

@@ -362,6 +362,7 @@ __global__ void __launch_bounds__(IP_BLOCK) cc_link(DevCtx d) {
 // Larger images (16x4000, 64x2048) use the global-memory path cc_runs + cc_link.
 #define CC_LDS_THREADS 1024
 #define CC_LDS_MAXN 36864
+#define CC_LDS16_MAXN 64512   // cc_lds16 (2 B/cell, <= 16 rings): 63 cells per thread; covers the reference geometry 16 x 4000 (126 KB of LDS)
 DEV_INLINE int ccl_find(int* parent, int v) {
   int curr = parent[v];
   if (curr != v) {
@@ -594,12 +595,12 @@ __global__ void __attribute__((amdgpu_waves_per_eu(8, 8))) __launch_bounds__(CC_
   extern __shared__ __attribute__((aligned(16))) unsigned char cc_smem[];
   uint16_t* par = reinterpret_cast<uint16_t*>(cc_smem);
   const uint8_t* fi = d.flag_img + base;
-  constexpr int PER = (CC_LDS_MAXN + CC_T - 1) / CC_T;
-  static_assert(PER <= 48, "three 64-bit words of 4-bit flags");
-  const int per = (N + CC_T - 1) / CC_T;   // cells per thread of THIS image (29 at 16x1800; PER = 36 is the capacity)
+  constexpr int PER = (CC_LDS16_MAXN + CC_T - 1) / CC_T;
+  static_assert(PER <= 64, "four 64-bit words of 4-bit flags, one bit per cell in the 64-bit masks");
+  const int per = (N + CC_T - 1) / CC_T;   // cells per thread of THIS image (29 at 16x1800, 63 at 16x4000; PER = 63 is the capacity)
   const int lane = lane_id(), wave = threadIdx.x >> 6;
   CC_TICK(0);
-  unsigned long long f0 = 0, f1 = 0, f2 = 0;   // the 4 flag bits of this thread's cells, 16 cells per word
+  unsigned long long f0 = 0, f1 = 0, f2 = 0, f3 = 0;   // the 4 flag bits of this thread's cells, 16 cells per word
 #pragma unroll 1
   for (int w = 0; w < (per + 15) / 16; ++w) {   // (one word at a time: 16 loads in flight, not 36 64-bit addresses in registers)
     unsigned long long acc = 0;
@@ -609,9 +610,9 @@ __global__ void __attribute__((amdgpu_waves_per_eu(8, 8))) __launch_bounds__(CC_
       const unsigned long long f = (unsigned long long)(fi[min(v, N - 1)] & 15u) * (unsigned long long)(k < PER && v < N);   // (unconditional load: behind a branch each of the 16 waited for the previous one)
       acc |= f << (q * 4);
     }
-    if (w == 0) f0 = acc; else if (w == 1) f1 = acc; else f2 = acc;
+    if (w == 0) f0 = acc; else if (w == 1) f1 = acc; else if (w == 2) f2 = acc; else f3 = acc;
   }
-  auto flag_of = [&](int k) -> unsigned { const unsigned long long w = k < 16 ? f0 : (k < 32 ? f1 : f2); return (unsigned)(w >> ((k & 15) * 4)) & 15u; };
+  auto flag_of = [&](int k) -> unsigned { const unsigned long long w = k < 16 ? f0 : (k < 32 ? f1 : (k < 48 ? f2 : f3)); return (unsigned)(w >> ((k & 15) * 4)) & 15u; };
   // Vertical neighbours (2 deg apart) pass the angle test far more often than horizontal ones (0.2 deg apart: a few cm of
   // range difference already fail), so the components are mostly column strips.  One thread per column walks its rows
   // bottom-up and gives every cell the start of its vertical run as parent (as cc_runs does on the global path): no
@@ -990,11 +991,12 @@ __global__ void atan2f_probe(const float* y, const float* x, float* out, int n, 
 
 // ---- host-side launchers -------------------------------------------------------
 void launch_ip(const DevCtx& d, int ring_pos, bool want_labels, hipStream_t st) {
-  const bool fused = d.opt_cc_fused && d.N <= CC_LDS_MAXN && d.NS <= 16;   // cc_lds also does the compaction
+  const bool lds16 = d.NS <= 16 && d.N <= CC_LDS16_MAXN;
+  const bool fused = d.opt_cc_fused && lds16;   // cc_lds16 also does the compaction
   const dim3 gN((d.N + IP_BLOCK - 1) / IP_BLOCK, d.n_launch);
   const dim3 gN4((d.N + IP_BLOCK * IP_PW - 1) / (IP_BLOCK * IP_PW), d.n_launch), gP4((d.Pcap + IP_BLOCK * IP_PW - 1) / (IP_BLOCK * IP_PW), d.n_launch);
   ALEGO_LAUNCH(ip_project, gP4, dim3(IP_BLOCK), 0, st, d, ring_pos);
-  const bool lds_cc = d.N <= CC_LDS_MAXN, lds_stats = lds_cc && d.NS <= 16;
+  const bool lds_cc = lds16 || d.N <= CC_LDS_MAXN, lds_stats = lds16;
   const bool keep_images = want_labels || d.n_launch == 1;   // the single-scan entry points / tests read the range and root images back
   ALEGO_LAUNCH(ip_front, dim3((d.H + IPF_W - 2) / (IPF_W - 1), d.n_launch), dim3(IPF_W), (size_t)d.NS * IPF_W * 4 + IPF_W * 8, st, d, ring_pos,
                (lds_cc ? 0 : 1) | (lds_stats ? 0 : 2) | (fused ? 0 : 4) | (keep_images ? 8 : 0));
@@ -1009,7 +1011,7 @@ void launch_ip(const DevCtx& d, int ring_pos, bool want_labels, hipStream_t st) 
     ALEGO_LAUNCH(cc_runs, dim3((d.H + 127) / 128, d.n_launch), dim3(128), 0, st, d);
     ALEGO_LAUNCH(cc_link, gN, dim3(IP_BLOCK), 0, st, d);
   }
-  if (!(d.N <= CC_LDS_MAXN && d.NS <= 16)) ALEGO_LAUNCH(cc_stats, gN, dim3(IP_BLOCK), 0, st, d);  // otherwise cc_lds produced the statistics
+  if (!lds16) ALEGO_LAUNCH(cc_stats, gN, dim3(IP_BLOCK), 0, st, d);  // otherwise cc_lds16 produced the statistics
   if (!fused) {
     ALEGO_LAUNCH(ip_rowcount, dim3(d.NS, d.n_launch), dim3(IP_BLOCK), 0, st, d);
     ALEGO_LAUNCH(ip_compact, dim3(d.NS, d.n_launch), dim3(IP_BLOCK), 0, st, d, ring_pos);
@@ -1023,9 +1025,8 @@ void launch_atan2f_probe(const float* y, const float* x, float* out, int n, int 
 
 // dynamic LDS above 64 KB has to be requested explicitly
 int ip_configure(const DevCtx& d) {
-  if (d.N <= CC_LDS_MAXN) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(cc_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * d.N) != hipSuccess) return -1;
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(cc_lds16), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * ((d.N + 1) / 2)) != hipSuccess) return -1;   // <= 147 KB
-  }
+  if (d.N <= CC_LDS_MAXN && hipFuncSetAttribute(reinterpret_cast<const void*>(cc_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * d.N) != hipSuccess) return -1;
+  if (d.NS <= 16 && d.N <= CC_LDS16_MAXN &&
+      hipFuncSetAttribute(reinterpret_cast<const void*>(cc_lds16), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * ((d.N + 1) / 2)) != hipSuccess) return -1;   // <= 126 KB
   return 0;
 }

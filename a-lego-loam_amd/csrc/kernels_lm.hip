@@ -60,16 +60,17 @@ DEV_INLINE void lm_map_update(const LmCtx& L, int slot, int* li, int merge) {
 __global__ void __launch_bounds__(LM_BLOCK) lm_prepare(DevCtx d, LmCtx L, int stage, int run_hint) {
   const int slot = blockIdx.z + d.slot0, kind = blockIdx.y;
   const int cur = d.scal[slot * SC_COUNT + SC_CUR];  // LO has completed: features of this scan
+  const int sslot = scan_slot_of(d, slot);           // where this scan's features, outliers and odometry hand-over live (its lane, or the slot itself)
   int* li = lip(L, slot);
   const int* sc = d.scal + slot * SC_COUNT;
   if (stage && run_hint != 0) {   // run_hint == 0: the host knows that no slot of this launch maps this scan (odd frame)
     // (written with unconditional loads + selects: a 3-way if/else chain here was lowered by hipcc 7.2 into
     //  a scalar switch that left the count pointer of the last arm undefined)
-    const size_t fb = (size_t)slot * 2 + cur;
-    const int n_c = d.feat_cnt[fb * 4 + F_LSHARP], n_s = d.feat_cnt[fb * 4 + F_LFLAT], n_o = sc[SC_NOUT];
+    const size_t fb = d.fs_cur >= 0 ? (size_t)d.fs_cur * 2 : (size_t)slot * 2 + cur;
+    const int n_c = d.feat_cnt[fb * 4 + F_LSHARP], n_s = d.feat_cnt[fb * 4 + F_LFLAT], n_o = d.scal[sslot * SC_COUNT + SC_NOUT];
     const float4* src_c = d.feat[F_LSHARP] + fb * d.fcap[F_LSHARP];
     const float4* src_s = d.feat[F_LFLAT] + fb * d.fcap[F_LFLAT];
-    const float4* src_o = d.outlier + (size_t)slot * d.N;
+    const float4* src_o = d.outlier + (size_t)sslot * d.N;
     const float4* src = kind == 0 ? src_c : (kind == 1 ? src_s : src_o);
     float4* dst = kind == 0 ? L.in_corner + (size_t)slot * L.in_cap_c : (kind == 1 ? L.in_surf + (size_t)slot * L.in_cap_s : L.in_outl + (size_t)slot * L.in_cap_o);
     const int cap = kind == 0 ? L.in_cap_c : (kind == 1 ? L.in_cap_s : L.in_cap_o);
@@ -80,9 +81,9 @@ __global__ void __launch_bounds__(LM_BLOCK) lm_prepare(DevCtx d, LmCtx L, int st
   }
   if (blockIdx.x != 0 || kind != 0 || threadIdx.x != 0) return;
   double* ld = ldp(L, slot);
-  double* po = d.poses + (size_t)slot * 16;
+  double* po = d.poses + (size_t)sslot * 16;
   li[LI_RUN] = 0; li[LI_REBUILD] = 0; li[LI_REBUILD_FB] = 0; li[LI_KF_ADDED] = 0; li[LI_OPTIMIZED] = 0; li[LI_FLAGS] = 0;
-  if (!sc[SC_ODOM_VALID]) return;  // no /odom/lidar on the initialising scan -> no mapping frame
+  if (!d.scal[sslot * SC_COUNT + SC_ODOM_VALID]) return;  // no /odom/lidar on the initialising scan -> no mapping frame
   // laserOdomHandler :154-166
   for (int k = 0; k < 3; ++k) ld[LD_T_O2L + k] = po[k];
   for (int k = 0; k < 4; ++k) ld[LD_Q_O2L + k] = po[3 + k];

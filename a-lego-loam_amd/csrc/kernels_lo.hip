@@ -98,19 +98,18 @@ __global__ void __launch_bounds__(LO_BLOCK) lo_assoc(DevCtx d, int box_lds_max) 
   static_assert(LO_CH % 16 == 0, "a box is evaluated as LO_CH / 16 targets per lane of a 16-lane row");
   constexpr int TPL = LO_CH / 16;
   const int slot = blockIdx.x + d.slot0, qb0 = blockIdx.y, qbn = gridDim.y;   // slot fastest: a stream's workgroups share an XCD / L2 (see lm_knn)
-  const int cur = cur_in_flight(d, slot);
+  const size_t fc = fidx_cur(d, slot), fl = fidx_last(d, slot);
   const int* sc = d.scal + slot * SC_COUNT;
   if (!sc[SC_LO_INIT]) return;
   const int lane = lane_id(), l16 = lane & 15;
-  const int last = cur ^ 1;
   const int qk = kind == 0 ? F_FLAT : F_SHARP, tk = kind == 0 ? F_LFLAT : F_LSHARP;
-  const int nq = d.feat_cnt[((size_t)slot * 2 + cur) * 4 + qk];
+  const int nq = d.feat_cnt[fc * 4 + qk];
   if (qb0 * LO_QPB >= nq) return;
-  const int nt = d.feat_cnt[((size_t)slot * 2 + last) * 4 + tk];
-  const float4* tg = d.feat[tk] + ((size_t)slot * 2 + last) * d.fcap[tk];
-  const float4* bx = d.lo_box + (((size_t)slot * 2 + last) * 2 + kind) * d.lo_box_cap * 2;
+  const int nt = d.feat_cnt[fl * 4 + tk];
+  const float4* tg = d.feat[tk] + fl * d.fcap[tk];
+  const float4* bx = d.lo_box + (fl * 2 + kind) * d.lo_box_cap * 2;
   const int nch = (nt + LO_CH - 1) / LO_CH;
-  const int* roff = d.ring_off + (((size_t)slot * 2 + last) * 2 + (kind == 0 ? 1 : 0)) * (d.NS + 1);
+  const int* roff = d.ring_off + (fl * 2 + (kind == 0 ? 1 : 0)) * (d.NS + 1);
   const double* st = d.lo_state + (size_t)slot * LO_STATE_N;
   LA_TICK(0);
   __shared__ float s_sel[LO_QPB][4];
@@ -142,7 +141,7 @@ __global__ void __launch_bounds__(LO_BLOCK) lo_assoc(DevCtx d, int box_lds_max) 
   if (threadIdx.x < LO_QPB) {  // transformToStart once per query, shared through LDS
     const int q = min((int)(qb * LO_QPB + threadIdx.x), nq - 1);
     float o[3];
-    transform_to_start(s_pose, s_pose + 9, d.feat[qk][((size_t)slot * 2 + cur) * d.fcap[qk] + q], o);
+    transform_to_start(s_pose, s_pose + 9, d.feat[qk][fc * d.fcap[qk] + q], o);
     s_sel[threadIdx.x][0] = o[0]; s_sel[threadIdx.x][1] = o[1]; s_sel[threadIdx.x][2] = o[2];
   }
   __syncthreads();
@@ -325,11 +324,10 @@ __global__ void __launch_bounds__(LO_BLOCK) lo_assoc(DevCtx d, int box_lds_max) 
 }
 
 // evaluate every valid correspondence row of [row0, row0+n) at pose p
-DEV_INLINE void lo_eval_rows(const DevCtx& d, int slot, int cur, int kind, int n, const PoseTerms& T, double acc[28]) {
-  const int last = cur ^ 1;
+DEV_INLINE void lo_eval_rows(const DevCtx& d, int slot, int kind, int n, const PoseTerms& T, double acc[28]) {
   const int qk = kind == 0 ? F_FLAT : F_SHARP, tk = kind == 0 ? F_LFLAT : F_LSHARP;
-  const float4* qpts = d.feat[qk] + ((size_t)slot * 2 + cur) * d.fcap[qk];
-  const float4* tg = d.feat[tk] + ((size_t)slot * 2 + last) * d.fcap[tk];
+  const float4* qpts = d.feat[qk] + fidx_cur(d, slot) * d.fcap[qk];
+  const float4* tg = d.feat[tk] + fidx_last(d, slot) * d.fcap[tk];
   const int* rows = d.lo_corr + ((size_t)slot * (d.lo_qcap_surf + d.lo_qcap_corner) + (kind == 0 ? 0 : d.lo_qcap_surf)) * 4;
   for (int i = threadIdx.x; i < n; i += LO_SOLVE_BLOCK) {
     const int4 r = *reinterpret_cast<const int4*>(rows + (size_t)i * 4);
@@ -367,15 +365,18 @@ __global__ void __launch_bounds__(LO_SOLVE_BLOCK) lo_solve(DevCtx d, int phase) 
   __shared__ LmState S;
   __shared__ int s_action, s_cnt[LO_SOLVE_BLOCK / 64];
   if (!sc[SC_LO_INIT]) {  // :316-324
-    if (phase == 1 && threadIdx.x == 0) { sc[SC_LO_INIT] = 1; sc[SC_ODOM_VALID] = 0; sc[SC_LO_FLAGS] = 1; sc[SC_LO_NSURF] = 0; sc[SC_LO_NCORNER] = 0; sc[SC_CUR] = cur; }
+    if (phase == 1 && threadIdx.x == 0) {
+      sc[SC_LO_INIT] = 1; sc[SC_LO_FLAGS] = 1; sc[SC_LO_NSURF] = 0; sc[SC_LO_NCORNER] = 0; sc[SC_CUR] = cur;
+      sc[SC_ODOM_VALID] = 0; d.scal[scan_slot_of(d, slot) * SC_COUNT + SC_ODOM_VALID] = 0;   // (the scan's own entry is what LaserMapping reads)
+    }
     return;
   }
 #ifdef ALEGO_TIMING
   const long long tk0_ = wall_clock64();
   if (threadIdx.x == 0 && blockIdx.x == 0) lo_times[7] += 1;
 #endif
-  const int nq_s = d.feat_cnt[((size_t)slot * 2 + cur) * 4 + F_FLAT];
-  const int nq_c = d.feat_cnt[((size_t)slot * 2 + cur) * 4 + F_SHARP];
+  const int nq_s = d.feat_cnt[fidx_cur(d, slot) * 4 + F_FLAT];
+  const int nq_c = d.feat_cnt[fidx_cur(d, slot) * 4 + F_SHARP];
   // count the correspondences of the kind associated just before this call
   {
     const int n = phase == 0 ? nq_s : nq_c;
@@ -404,8 +405,8 @@ __global__ void __launch_bounds__(LO_SOLVE_BLOCK) lo_solve(DevCtx d, int phase) 
       for (int k = 0; k < 28; ++k) acc[k] = 0;
       PoseTerms T;
       { LO_T0; T = pose_terms_coop(x, s_trig); LO_ACC(0); }
-      { LO_T0; lo_eval_rows(d, slot, cur, 0, nq_s, T, acc);
-        if (phase == 1) lo_eval_rows(d, slot, cur, 1, nq_c, T, acc); LO_ACC(1); }
+      { LO_T0; lo_eval_rows(d, slot, 0, nq_s, T, acc);
+        if (phase == 1) lo_eval_rows(d, slot, 1, nq_c, T, acc); LO_ACC(1); }
       { LO_T0; block_reduce28_lds<LO_SOLVE_BLOCK>(acc, s_acc, s_seg, s_out); LO_ACC(2); }
     };
     double x0[6];
@@ -463,9 +464,9 @@ __global__ void __launch_bounds__(LO_SOLVE_BLOCK) lo_solve(DevCtx d, int phase) 
 #pragma unroll
       for (int k = 0; k < 9; ++k) st[LS_RW + k] = nr[k];
       const DQuat q = dq_from_mat(nr);
-      double* po = d.poses + (size_t)slot * 16;
+      double* po = d.poses + (size_t)scan_slot_of(d, slot) * 16;   // /odom/lidar of this scan (its lane's entry when scans are processed ahead)
       po[0] = nt[0]; po[1] = nt[1]; po[2] = nt[2]; po[3] = q.w; po[4] = q.x; po[5] = q.y; po[6] = q.z;
-      sc[SC_ODOM_VALID] = 1;
+      sc[SC_ODOM_VALID] = 1; d.scal[scan_slot_of(d, slot) * SC_COUNT + SC_ODOM_VALID] = 1;
       sc[SC_CUR] = cur;  // surf_last_ / corner_last_ <- this scan's features (:531-534)
     }
   }

@@ -13,7 +13,8 @@ struct LmHost;
 LmHost* lm_host_create(const alego_params& P, const DevCtx& d, int n_slots, int gsize, const std::vector<hipStream_t>& streams, std::string* err);
 void lm_host_destroy(LmHost* lm);
 // LaserMapping for the scan just processed by LO, for the slots of view `d`
-int lm_host_enqueue(LmHost* lm, const DevCtx& d, const std::vector<char>& odom_valid, std::string* err);
+// st_override: enqueue on this stream instead of the slot's group stream (alego_stream_run pipelines LaserMapping on a stream of its own)
+int lm_host_enqueue(LmHost* lm, const DevCtx& d, const std::vector<char>& odom_valid, std::string* err, hipStream_t st_override = nullptr);
 int lm_host_get_flags(LmHost* lm, int slot);
 int lm_host_process_host(LmHost* lm, const DevCtx& d, const alego_point* corner_last, int n_corner, const alego_point* surf_last,
                          int n_surf, const alego_point* outlier, int n_outlier, const alego_pose* odom, alego_pose* map_pose,

@@ -210,10 +210,10 @@ static int lm_allreduce(void* ctx, double* buf, size_t count, hipStream_t st) {
 }
 
 // odom_valid[s - slot0]: whether slot s has an /odom/lidar message for this scan (false on its first scan)
-static int lm_sequence(LmHost* lm, const DevCtx& d, int stage, const std::vector<char>& odom_valid, std::string* err) {
+static int lm_sequence(LmHost* lm, const DevCtx& d, int stage, const std::vector<char>& odom_valid, std::string* err, hipStream_t st_override = nullptr) {
   // the slots of one launch view always belong to one stream group
   const int g = d.slot0 / lm->gsize;
-  hipStream_t st = lm->st[g];
+  hipStream_t st = st_override ? st_override : lm->st[g];
   LmCtx L = lm->L;
   L.vox_bbox = lm->vm[g].bbox; L.vox_slot0 = g * lm->gsize;
   int n_run = 0, n_norun = 0;
@@ -249,9 +249,9 @@ static void clear_run_flags_outside(LmHost* lm, const DevCtx& d) {
   }
 }
 
-int lm_host_enqueue(LmHost* lm, const DevCtx& d, const std::vector<char>& odom_valid, std::string* err) {
-  clear_run_flags_outside(lm, d);
-  return lm_sequence(lm, d, 1, odom_valid, err);
+int lm_host_enqueue(LmHost* lm, const DevCtx& d, const std::vector<char>& odom_valid, std::string* err, hipStream_t st_override) {
+  if (!st_override) clear_run_flags_outside(lm, d);   // (alego_stream_run: the other slots of the group are look-ahead lanes, LaserMapping never ran on them)
+  return lm_sequence(lm, d, 1, odom_valid, err, st_override);
 }
 
 int lm_host_process_host(LmHost* lm, const DevCtx& dfull, const alego_point* corner_last, int n_corner, const alego_point* surf_last,

@@ -136,6 +136,15 @@ int alego_synchronize(alego_handle* h);
 int alego_replay_create(alego_handle* h, int n_bags, int bag_len);
 int alego_replay_load(alego_handle* h, int bag, int scan, const alego_point* pts, int32_t n);
 int alego_replay_assign(alego_handle* h, int slot, int bag, int start_scan);
+/* ONE stream replayed from the bag store as fast as the device allows (BASELINE config 3 as written: a single bag).  Slot 0 carries
+ * the stream's state; the other slots of the handle are look-ahead lanes in two sets of W = (n_slots - 1) / 2: ImageProjection and feature
+ * extraction have no state across scans, so they run for W scans ahead in one launch per kernel (one scan per lane), while LaserOdometry
+ * (sequential by nature: params_, the previous scan's features) and LaserMapping (the key-frame map) follow scan by scan on two
+ * further HIP streams, each started by an event of its producer — the three-nodelet pipeline of launch/test.launch on the device.
+ * Results are bit-identical to alego_batch_run on a one-slot handle.  The handle needs n_slots >= 3 (odd) and a bag store;
+ * `first_step` / `n_scans` as in alego_batch_run with ALEGO_REPLAY_BAG (scan (start_scan + first_step + i) mod bag_len at step i). */
+int alego_stream_setup(alego_handle* h, int bag, int start_scan);
+int alego_stream_run(alego_handle* h, int first_step, int n_scans, int stages, int sync);
 /* poses of the last processed scan of `slot` */
 int alego_batch_get_pose(alego_handle* h, int slot, alego_pose* odom, alego_pose* map_pose);
 /* per-scan device counters of the last processed scan of `slot`:

@@ -906,3 +906,38 @@ def test_sharded_registration_slices_partition_the_queries(params_a):
         raise AssertionError("no optimised mapping frame in the test")
     for x in h:
         x.close()
+
+
+@pytest.mark.parametrize("lanes", [1, 4])
+def test_stream_run_with_lookahead_lanes_is_bit_identical(params_a, lanes):
+    """alego_stream_run: ONE stream with ImageProjection + feature extraction running `lanes` scans ahead in shared launches and
+    LaserOdometry / LaserMapping following on their own HIP streams — against the plain one-slot replay of the same bag, pose by pose
+    (several calls, group sizes that do not divide the call lengths, a wrap around the bag)."""
+    p = params_a
+    bag_len = 23
+    scans = [synth.scan(p, k) for k in range(bag_len)]
+    ha = binding.Handle(p, n_slots=1, ring_len=1)
+    hb = binding.Handle(p, n_slots=1 + 2 * lanes, ring_len=1)
+    for h in (ha, hb):
+        h.replay_create(1, bag_len)
+        for k, a in enumerate(scans):
+            h.replay_load(0, k, a)
+    ha.replay_assign(0, 0, 3)
+    hb.stream_setup(0, 3)
+    step = 0
+    for n in (1, 2, 7, 10, 13):
+        ha.batch_run(step, n, stages=7 | binding.REPLAY_BAG)
+        hb.stream_run(step, n, stages=7)
+        step += n
+        fa, oa, ma = ha.batch_get_pose(0)
+        fb, ob, mb = hb.batch_get_pose(0)
+        assert_bit_equal(ob["t"], oa["t"], f"after {step} scans: odometry translation")
+        assert_bit_equal(ob["q"], oa["q"], f"after {step} scans: odometry rotation")
+        assert_bit_equal(ob["params"], oa["params"], f"after {step} scans: LO params_")
+        assert_bit_equal(mb["t"], ma["t"], f"after {step} scans: map translation")
+        assert_bit_equal(mb["params"], ma["params"], f"after {step} scans: LM params_")
+        assert fa == fb, (fa, fb)
+        ca, cb = ha.batch_get_counts(0), hb.batch_get_counts(0)
+        assert ca == cb, (ca, cb)
+    assert_bit_equal(hb.debug_get("lm_surf_map_ds"), ha.debug_get("lm_surf_map_ds"), "filtered surf map")
+    ha.close(); hb.close()
