@@ -50,6 +50,7 @@ struct alego_handle {
   int lanes = 0;               // W: lanes per set (slots 1 .. W and W + 1 .. 2 W)
   int pose_slot = 0;           // slot holding the poses of the last processed scan of slot 0 (its lane)
   int last_lane = -1;          // lane of the previous scan (LaserOdometry's surf_last_ / corner_last_)
+  int next_set = 0;            // lane set the next group of scans uses (the other one still holds the previous scan's features)
   hipStream_t s_lo = nullptr, s_lm = nullptr;
   std::vector<hipEvent_t> ev_pool;
   size_t ev_next = 0;
@@ -349,7 +350,7 @@ int alego_stream_setup(alego_handle* h, int bag, int start_scan) {
     for (int j = 0; j < W; ++j)   // lane j of either set processes scan (start + group base + j)
       if (int r = alego_replay_assign(h, 1 + set * W + j, bag, start_scan + j)) return r;
   if (!h->s_lo && (hipStreamCreate(&h->s_lo) != hipSuccess || hipStreamCreate(&h->s_lm) != hipSuccess)) { h->err = "alego_stream_setup: hipStreamCreate failed"; return ALEGO_ERR_HIP; }
-  h->stream_mode = true; h->lanes = W; h->pose_slot = 0; h->last_lane = -1;
+  h->stream_mode = true; h->lanes = W; h->pose_slot = 0; h->last_lane = -1; h->next_set = 0;
   return 0;
 }
 
@@ -377,7 +378,8 @@ int alego_stream_run(alego_handle* h, int first_step, int n_scans, int stages, i
   const bool do_lo = (stages & 2) != 0, do_lm = do_lo && (stages & 4);
   int g = 0;
   for (int base = 0; base < n_scans; base += W, ++g) {
-    const int w = std::min(W, n_scans - base), set = g & 1, lane0 = 1 + set * W;
+    const int w = std::min(W, n_scans - base), set = h->next_set, lane0 = 1 + set * W;
+    h->next_set ^= 1;
     // ---- ImageProjection + feature extraction of w scans, one per lane (stream A)
     if (lm_done[set]) HIP_TRY(h, hipStreamWaitEvent(sA, lm_done[set], 0));
     if (lo_first_done) HIP_TRY(h, hipStreamWaitEvent(sA, lo_first_done, 0));

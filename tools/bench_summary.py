@@ -1,7 +1,7 @@
 import json, sys
 src = open(sys.argv[1]) if len(sys.argv) > 1 and not sys.argv[1].isdigit() else sys.stdin
 d = json.loads(src.read().strip().splitlines()[-1])
-print("value", d["value"], "ms/step", d["ms_per_step"], "single", d.get("single_stream_scans_per_s"), "cpu", (d.get("cpu_baseline") or {}).get("value"))
+print("value", d["value"], "ms/step", d["ms_per_step"], "single", d.get("single_stream_scans_per_s"), "serial", d.get("single_stream_serial_scans_per_s"), d.get("single_stream_note"), "cpu", (d.get("cpu_baseline") or {}).get("value"))
 if "roofline" in d: print("roofline", d["roofline"])
 print("pipeline", d.get("pipeline_roofline"))
 print("counts", d.get("counts"))
