@@ -26,6 +26,7 @@ EXPORTS = [
     "alego_lm_keyframe_count", "alego_lm_get_keyframe", "alego_lm_set_keypose", "alego_lm_reset_window", "alego_lm_apply_correction",
     "alego_lm_add_keyframe", "alego_pc2_to_points", "alego_replay_create", "alego_replay_load", "alego_replay_assign",
     "alego_dist_unique_id", "alego_dist_init", "alego_dist_shutdown", "alego_stream_setup", "alego_stream_run",
+    "alego_loop_detect", "alego_loop_closure_icp",
 ]
 
 REPLAY_PINGPONG = 0x100
@@ -65,6 +66,16 @@ class KeyFrame(C.Structure):
                 ("corner", C.c_void_p), ("corner_cap", C.c_int32), ("n_corner", C.c_int32),
                 ("surf", C.c_void_p), ("surf_cap", C.c_int32), ("n_surf", C.c_int32),
                 ("outlier", C.c_void_p), ("outlier_cap", C.c_int32), ("n_outlier", C.c_int32)]
+
+
+class KfIn(C.Structure):
+    _fields_ = [("pose", C.c_float * 6), ("corner", C.c_void_p), ("n_corner", C.c_int32), ("surf", C.c_void_p), ("n_surf", C.c_int32),
+                ("outlier", C.c_void_p), ("n_outlier", C.c_int32)]
+
+
+class IcpResult(C.Structure):
+    _fields_ = [("converged", C.c_int32), ("iterations", C.c_int32), ("n_source", C.c_int32), ("n_target", C.c_int32),
+                ("fitness", C.c_double), ("correction", C.c_float * 16)]
 
 
 class Pc2Field(C.Structure):
@@ -167,6 +178,10 @@ def lib():
         L.alego_stream_setup.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.alego_stream_run.restype = C.c_int
         L.alego_stream_run.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.alego_loop_detect.restype = C.c_int
+        L.alego_loop_detect.argtypes = [C.POINTER(AlegoParams), C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
+        L.alego_loop_closure_icp.restype = C.c_int
+        L.alego_loop_closure_icp.argtypes = [C.c_void_p, C.POINTER(KfIn), C.POINTER(KfIn), C.c_int32, C.POINTER(IcpResult), C.c_void_p, C.c_int32]
         if L.alego_params_sizeof() != C.sizeof(AlegoParams):
             raise RuntimeError("alego_params layout mismatch between params.py and include/alego_params.h")
         _lib = L
@@ -187,6 +202,14 @@ def dist_unique_id() -> bytes:
     if rc != 0:
         raise AlegoError(f"alego_dist_unique_id failed ({rc})")
     return buf.raw
+
+
+def loop_detect(params, keyposes6, stamps, cur_xyz):
+    """detectLoopClosure's closest_history_frame_id_ (host code of the library; -1 = no candidate)"""
+    kp = np.ascontiguousarray(keyposes6, np.float32).reshape(-1, 6)
+    t = np.ascontiguousarray(stamps, np.float64)
+    c = np.ascontiguousarray(cur_xyz, np.float64)
+    return int(lib().alego_loop_detect(C.byref(params), kp.ctypes.data, t.ctypes.data, kp.shape[0], c.ctypes.data))
 
 
 def pc2_to_points(data: bytes, width, height, point_step, row_step, fields, is_bigendian=False, cap=None):
@@ -439,6 +462,27 @@ class Handle:
 
     def set_option(self, name, value):
         self._check(lib().alego_debug_set_option(self._h, name.encode(), int(value)), f"alego_debug_set_option({name})")
+
+    # ---- loop closure ----
+    def loop_closure_icp(self, frames):
+        """frames = [(pose6, corner, surf, outlier), ...]: the newest key frame, then the history frames.  Returns (result dict, target cloud)."""
+        keep, kfs = [], (KfIn * len(frames))()
+        total = 0
+        for i, f in enumerate(frames):
+            kfs[i].pose[:] = [float(v) for v in f[0]]
+            arrs = [np.ascontiguousarray(c, np.float32).reshape(-1, 4) for c in f[1:4]]
+            keep.append(arrs)
+            kfs[i].corner, kfs[i].n_corner = arrs[0].ctypes.data, arrs[0].shape[0]
+            kfs[i].surf, kfs[i].n_surf = arrs[1].ctypes.data, arrs[1].shape[0]
+            kfs[i].outlier, kfs[i].n_outlier = arrs[2].ctypes.data, arrs[2].shape[0]
+            total += sum(a.shape[0] for a in arrs)
+        out = IcpResult()
+        tgt = np.empty((max(total, 1), 4), np.float32)
+        hist = C.cast(C.byref(kfs, C.sizeof(KfIn)), C.POINTER(KfIn)) if len(frames) > 1 else None
+        self._check(lib().alego_loop_closure_icp(self._h, C.byref(kfs[0]), hist, len(frames) - 1, C.byref(out), tgt.ctypes.data, tgt.shape[0]),
+                    "alego_loop_closure_icp")
+        return dict(converged=int(out.converged), iterations=int(out.iterations), n_source=int(out.n_source), n_target=int(out.n_target),
+                    fitness=float(out.fitness), T=np.array(out.correction[:], np.float32).reshape(4, 4)), tgt[:out.n_target].copy()
 
     # ---- one registration sharded over the ranks of an RCCL communicator (BASELINE config 5) ----
     def dist_init(self, rank, world, unique_id: bytes):

@@ -24,6 +24,8 @@ void launch_fe(const DevCtx& d, hipStream_t st);
 void launch_lo(const DevCtx& d, hipStream_t st);
 void launch_atan2f_probe(const float* y, const float* x, float* out, int n, int mode, hipStream_t st);
 void launch_dbg_eval_blocks(int type, int n, const double* geom13, const double* params6, double* res, double* jac6, hipStream_t st);
+int icp_run(const alego_params& P, const alego_kf_in* latest, const alego_kf_in* history, int n_history, alego_icp_result* out,
+            alego_point* target_out, int target_cap, hipStream_t st, std::string* err);
 void launch_dbg_transform_to_start(const double* params6, const float4* pts, int n, float4* out, hipStream_t st);
 int ip_configure(const DevCtx& d);
 int lo_configure();
@@ -733,6 +735,31 @@ int alego_debug_set_option(alego_handle* h, const char* name, int value) {
   else if (s == "ALEGO_SHARD_SLICE") return lm_host_debug_slice(h->lm, value & 0xff, value >> 8, &h->err);   // tests: rank | world << 8 without a communicator
   else { h->err = "unknown option " + s; return ALEGO_ERR_ARG; }
   return 0;
+}
+
+// ---- loop closure ---------------------------------------------------------------------------------------------------
+int alego_loop_detect(const alego_params* P, const float* keyposes6, const double* stamps, int32_t n, const double cur_xyz[3]) {
+  // detectLoopClosure :771-790 (pcl::KdTreeFLANN::radiusSearch: f32 squared distances, ascending; ties by index)
+  if (!P || n <= 0 || !keyposes6 || !stamps || !cur_xyz) return -1;
+  const float cx = (float)cur_xyz[0], cy = (float)cur_xyz[1], cz = (float)cur_xyz[2];
+  const float r2 = (float)(P->lc_search_radius * P->lc_search_radius);
+  std::vector<std::pair<float, int>> cand;
+  for (int i = 0; i < n; ++i) {
+    float r = 0.f, df;
+    df = keyposes6[i * 6 + 0] - cx; r += df * df; df = keyposes6[i * 6 + 1] - cy; r += df * df; df = keyposes6[i * 6 + 2] - cz; r += df * df;
+    if (r < r2) cand.emplace_back(r, i);
+  }
+  std::sort(cand.begin(), cand.end());
+  for (const auto& c : cand)
+    if (stamps[n - 1] - stamps[c.second] > P->lc_min_time_gap) return c.second;
+  return -1;
+}
+int alego_loop_closure_icp(alego_handle* h, const alego_kf_in* latest, const alego_kf_in* history, int32_t n_history, alego_icp_result* out,
+                           alego_point* target_out, int32_t target_cap) {
+  if (!h || !latest || !out || n_history < 0 || (n_history > 0 && !history)) return ALEGO_ERR_ARG;
+  hipSetDevice(h->device);
+  g_prof = &h->prof;
+  return icp_run(h->P, latest, history, n_history, out, target_out, target_out ? target_cap : 0, h->stream, &h->err);
 }
 
 // ---- one registration sharded over the GPUs of a node ---------------------------------------------------------------

@@ -22,6 +22,8 @@ class AlegoParams(C.Structure):
         ("lm_outer_iters", _I), ("lm_max_iters", _I),
         ("knn_max_dist", _D), ("line_ratio", _D), ("line_half_len", _D), ("plane_tol", _D),
         ("lm_min_corner", _I), ("lm_min_surf", _I), ("lm_min_map_corner", _I),
+        ("lc_search_radius", _D), ("lc_search_num", _I), ("lc_fitness_max", _D), ("lc_leaf", _F), ("lc_min_time_gap", _D),
+        ("icp_max_corr_dist", _D), ("icp_max_iters", _I), ("icp_trans_eps", _D), ("icp_fitness_eps", _D),
         ("input_is_dense", _I),
     ]
 

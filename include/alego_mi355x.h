@@ -221,6 +221,32 @@ int alego_lm_apply_correction(alego_handle* h, int slot, const double rc[12]);
 int alego_lm_add_keyframe(alego_handle* h, int slot, const float pose6[6], const alego_point* corner, int32_t n_corner,
                           const alego_point* surf, int32_t n_surf, const alego_point* outlier, int32_t n_outlier);
 
+/* ---- loop closure (laserMapping.cpp:633-824): the host keeps the pose graph (GTSAM in the reference) and every key frame; the
+ * library does the per-point work of one closure attempt.
+ *   alego_loop_detect        detectLoopClosure's choice (:771-790), plain host code: the key pose nearest to `cur_xyz` within
+ *                            lc_search_radius whose stamp is more than lc_min_time_gap older than the newest key frame's; -1 = none
+ *   alego_loop_closure_icp   sub-map assembly (:794-812: the newest key frame as ICP source; the history frames
+ *                            closest - lc_search_num .. closest + lc_search_num, transformed by their key poses, concatenated and
+ *                            VoxelGrid(lc_leaf)-filtered as target) and pcl::IterativeClosestPoint as configured at :670-692.
+ *                            `correction` = getFinalTransformation() (row-major 4x4, f32), `fitness` = getFitnessScore().  The caller
+ *                            applies :697 (converged && fitness <= lc_fitness_max), adds the Between factor (:716-733) and, after the
+ *                            graph update, writes the corrected poses back (alego_lm_set_keypose / reset_window / apply_correction).
+ *                            target_out (may be NULL): near_history_keyframes_ for /history_keyframes. */
+typedef struct alego_kf_in {
+  float pose[6];                                   /* x y z roll pitch yaw of the key frame */
+  const alego_point* corner;   int32_t n_corner;   /* corner_frames_[id], surf_frames_[id], outlier_frames_[id] (sensor frame) */
+  const alego_point* surf;     int32_t n_surf;
+  const alego_point* outlier;  int32_t n_outlier;
+} alego_kf_in;
+typedef struct alego_icp_result {
+  int32_t converged, iterations, n_source, n_target;
+  double fitness;
+  float correction[16];
+} alego_icp_result;
+int alego_loop_detect(const alego_params* params, const float* keyposes6, const double* stamps, int32_t n, const double cur_xyz[3]);
+int alego_loop_closure_icp(alego_handle* h, const alego_kf_in* latest, const alego_kf_in* history, int32_t n_history,
+                           alego_icp_result* out, alego_point* target_out, int32_t target_cap);
+
 /* ---- one scan-to-map registration sharded over the GPUs of a node (BASELINE.json config 5) ----------------
  * One process per GPU; every rank feeds its handle the SAME scans and so keeps a bit-identical replica of the stream's state
  * (ImageProjection, feature extraction, LaserOdometry and the local map are cheap and are computed redundantly).  What is split

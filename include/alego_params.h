@@ -85,6 +85,16 @@ typedef struct alego_params {
   int32_t lm_min_corner;     /* 10              laserMapping.cpp:350 */
   int32_t lm_min_surf;       /* 100             laserMapping.cpp:350 */
   int32_t lm_min_map_corner; /* 10              laserMapping.cpp:350 */
+  /* ---- loop closure (laserMapping.cpp:633-824; nodelet values, LM.cpp's in brackets) ---- */
+  double lc_search_radius;   /* 20.0 [10.0]     history_search_radius_   laserMapping.cpp:76 */
+  int32_t lc_search_num;     /* 25              history_search_num_      laserMapping.cpp:77 */
+  double lc_fitness_max;     /* 0.4 [0.3]       history_fitness_score_   laserMapping.cpp:78 */
+  float lc_leaf;             /* 1.0 [0.4]       ds_history_keyframes_    laserMapping.cpp:41 */
+  double lc_min_time_gap;    /* 30.0 s          laserMapping.cpp:782 */
+  double icp_max_corr_dist;  /* 100.0           laserMapping.cpp:671 */
+  int32_t icp_max_iters;     /* 100             laserMapping.cpp:672 */
+  double icp_trans_eps;      /* 1e-6            laserMapping.cpp:673 */
+  double icp_fitness_eps;    /* 1e-6            laserMapping.cpp:674 */
   /* ---- input message property ---- */
   int32_t input_is_dense;    /* sensor_msgs/PointCloud2.is_dense of the driver.  0 (default): pcl::removeNaNFromPointCloud
                                 drops non-finite points (imageProjection.cpp:58-59).  1: PCL copies the cloud unfiltered;
@@ -163,6 +173,15 @@ static inline void alego_default_params(alego_params* p, int n_scan, int horizon
   p->lm_min_corner = 10;
   p->lm_min_surf = 100;
   p->lm_min_map_corner = 10;
+  p->lc_search_radius = 20.0;
+  p->lc_search_num = 25;
+  p->lc_fitness_max = 0.4;
+  p->lc_leaf = 1.0f;
+  p->lc_min_time_gap = 30.0;
+  p->icp_max_corr_dist = 100.0;
+  p->icp_max_iters = 100;
+  p->icp_trans_eps = 1e-6;
+  p->icp_fitness_eps = 1e-6;
   p->input_is_dense = 0;
 }
 

@@ -40,6 +40,7 @@
 
 #include "../include/alego_params.h"
 #include "oracle_math.h"
+#include "oracle_icp.h"
 
 namespace {
 
@@ -1623,6 +1624,101 @@ int oracle_knn(const alego_point* cloud, int n, const alego_point* q, int nq, in
 }
 
 void oracle_eig3(const double* A9, double* lam3, double* V9) { eig3(A9, lam3, V9); }
+
+// ---- loop closure (src/laserMapping.cpp:652-824) ------------------------------------------------------------------------------
+// detectLoopClosure :760-790: the key pose nearest to the current position (radius search, ascending distance) that is more than
+// lc_min_time_gap older than the newest key frame; -1 if there is none.  keyposes6 = n x (x y z roll pitch yaw) f32, times = n stamps.
+int oracle_loop_detect(const alego_params* P, const float* keyposes6, const double* times, int n, const double* cur_xyz) {
+  if (n <= 0) return -1;
+  const Pt cur{(float)cur_xyz[0], (float)cur_xyz[1], (float)cur_xyz[2], 0.f};
+  std::vector<std::pair<float, int>> cand;
+  const float r2 = (float)(P->lc_search_radius * P->lc_search_radius);
+  for (int i = 0; i < n; ++i) {
+    const Pt kp{keyposes6[i * 6 + 0], keyposes6[i * 6 + 1], keyposes6[i * 6 + 2], 0.f};
+    const float d = dist2_f32(kp, cur);
+    if (d < r2) cand.emplace_back(d, i);   // flann RadiusResultSet: dist < radius^2
+  }
+  std::sort(cand.begin(), cand.end());
+  for (const auto& c : cand)
+    if (times[n - 1] - times[c.second] > P->lc_min_time_gap) return c.second;
+  return -1;
+}
+
+// performLoopClosure :670-697 on caller-provided key frames.  poses6 = (1 + nh) x 6 f32 (the newest key frame first, then the
+// history frames closest_history_frame_id_ - 25 .. + 25 in ascending order); pts = their clouds back to back in the order corner,
+// surf, outlier per frame with offs[(1 + nh) * 3 + 1] prefix offsets.  out[0..] = converged, iterations, n_source, n_target (as
+// doubles), fitness, then the 16 entries of getFinalTransformation() (row-major, f32 values).  target_out (may be NULL, cap points)
+// receives near_history_keyframes_.
+int oracle_loop_icp(const alego_params* P, const float* poses6, const alego_point* pts, const int* offs, int nh, double* out21,
+                    alego_point* target_out, int target_cap) {
+  auto frame = [&](int f, int kind, std::vector<Pt>& dst) {   // transformPointCloud(frames_[f], pose[f]) appended
+    std::vector<Pt> in(pts + offs[f * 3 + kind], pts + offs[f * 3 + kind + 1]), tr;
+    const float* kp = poses6 + f * 6;
+    LaserMapping::transform_cloud(in, KeyPose{kp[0], kp[1], kp[2], kp[3], kp[4], kp[5]}, tr);
+    dst.insert(dst.end(), tr.begin(), tr.end());
+  };
+  std::vector<Pt> src, raw, tgt;
+  frame(0, 1, src); frame(0, 0, src); frame(0, 2, src);                                   // :794-796: surf, corner, outlier
+  for (int f = 1; f <= nh; ++f) { frame(f, 1, raw); frame(f, 0, raw); frame(f, 2, raw); }   // :805-807
+  voxel_grid(raw, P->lc_leaf, tgt, P->sort_mode);                                            // :811-812
+  if (target_out) std::memcpy(target_out, tgt.data(), sizeof(Pt) * std::min((size_t)target_cap, tgt.size()));
+  for (int k = 0; k < 21; ++k) out21[k] = 0;
+  out21[2] = (double)src.size(); out21[3] = (double)tgt.size();
+  float Tf[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};   // final_transformation_ (Matrix4f)
+  auto finish = [&](int conv, int it, double fit) { out21[0] = conv; out21[1] = it; out21[4] = fit; for (int k = 0; k < 16; ++k) out21[5 + k] = Tf[k]; return 0; };
+  if (src.empty() || tgt.empty()) return finish(0, 0, DBL_MAX);
+  KdTree kd; kd.build(tgt);
+  std::vector<Pt> cur = src;   // input_transformed
+  const double max_d2 = P->icp_max_corr_dist * P->icp_max_corr_dist;
+  double prev_mse = DBL_MAX;
+  int it = 0, converged = 0;
+  while (true) {
+    double S[15] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, mse = 0;
+    long n = 0;
+    for (const Pt& p : cur) {   // determineCorrespondences: 1-NN in the target, kept within the maximum correspondence distance
+      int idx; float d2;
+      if (kd.knn(p, 1, &idx, &d2) < 1 || (double)d2 > max_d2) continue;
+      const Pt& q = tgt[idx];
+      const double a[3] = {p.x, p.y, p.z}, b[3] = {q.x, q.y, q.z};
+      for (int k = 0; k < 3; ++k) { S[k] += a[k]; S[3 + k] += b[k]; }
+      for (int u = 0; u < 3; ++u) for (int v = 0; v < 3; ++v) S[6 + u * 3 + v] += a[u] * b[v];
+      mse += (double)d2;
+      ++n;
+    }
+    if (n < 3) { converged = 0; break; }   // "Not enough correspondences found"
+    mse /= (double)n;
+    double RT[12];
+    oicp::horn_transform(S, (double)n, RT);
+    float M[16] = {(float)RT[0], (float)RT[1], (float)RT[2], (float)RT[3], (float)RT[4], (float)RT[5], (float)RT[6], (float)RT[7],
+                   (float)RT[8], (float)RT[9], (float)RT[10], (float)RT[11], 0, 0, 0, 1};   // transformation_ (Matrix4f)
+    for (Pt& p : cur) {   // transformCloud (f32)
+      const float x = p.x, y = p.y, z = p.z;
+      p.x = M[0] * x + M[1] * y + M[2] * z + M[3]; p.y = M[4] * x + M[5] * y + M[6] * z + M[7]; p.z = M[8] * x + M[9] * y + M[10] * z + M[11];
+    }
+    float N[16];   // final_transformation_ = transformation_ * final_transformation_
+    for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) N[r * 4 + c] = M[r * 4 + 0] * Tf[0 * 4 + c] + M[r * 4 + 1] * Tf[1 * 4 + c] + M[r * 4 + 2] * Tf[2 * 4 + c] + M[r * 4 + 3] * Tf[3 * 4 + c];
+    std::memcpy(Tf, N, sizeof(N));
+    ++it;
+    // DefaultConvergenceCriteria::hasConverged (rotation threshold 0.99999, absolute MSE 1e-12: PCL's defaults)
+    if (it >= P->icp_max_iters) { converged = 1; break; }
+    const double cos_angle = 0.5 * ((double)M[0] + (double)M[5] + (double)M[10] - 1.0);
+    const double tr2 = (double)M[3] * M[3] + (double)M[7] * M[7] + (double)M[11] * M[11];
+    if (cos_angle >= 0.99999 && tr2 <= P->icp_trans_eps) { converged = 1; break; }
+    if (std::fabs(mse - prev_mse) < 1e-12) { converged = 1; break; }
+    if (std::fabs(mse - prev_mse) / prev_mse < P->icp_fitness_eps) { converged = 1; break; }
+    prev_mse = mse;
+  }
+  // getFitnessScore(): the source under the final transformation against the target
+  double fit = 0; long nf = 0;
+  for (const Pt& p0 : src) {
+    Pt p;
+    p.x = Tf[0] * p0.x + Tf[1] * p0.y + Tf[2] * p0.z + Tf[3]; p.y = Tf[4] * p0.x + Tf[5] * p0.y + Tf[6] * p0.z + Tf[7]; p.z = Tf[8] * p0.x + Tf[9] * p0.y + Tf[10] * p0.z + Tf[11];
+    p.intensity = p0.intensity;
+    int idx; float d2;
+    if (kd.knn(p, 1, &idx, &d2) == 1) { fit += (double)d2; ++nf; }
+  }
+  return finish(converged, it, nf ? fit / (double)nf : DBL_MAX);
+}
 
 // Normal equations of a set of residual blocks at params6 with HuberLoss(huber) + corrector: out28 = upper triangle of J^T J (21, row by
 // row), J^T r (6), cost (1) — what one rank of a sharded registration contributes to the all-reduce.

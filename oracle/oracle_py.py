@@ -52,6 +52,10 @@ def lib():
         L.oracle_transform_cloud.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.oracle_run_pipelined.restype = C.c_double
         L.oracle_run_pipelined.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.oracle_loop_detect.restype = C.c_int
+        L.oracle_loop_detect.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.oracle_loop_icp.restype = C.c_int
+        L.oracle_loop_icp.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
         L.oracle_normal_eq.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_double, C.c_void_p]
         L.oracle_sincosf_array.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
         _lib = L
@@ -229,3 +233,34 @@ def normal_eq(blocks14, params6, huber=0.1):
     out = np.zeros(28)
     lib().oracle_normal_eq(b.ctypes.data, b.shape[0], p.ctypes.data, huber, out.ctypes.data)
     return out
+
+
+def loop_detect(params, keyposes6, times, cur_xyz):
+    """detectLoopClosure's choice of closest_history_frame_id_ (or -1)."""
+    kp = np.ascontiguousarray(keyposes6, dtype=np.float32).reshape(-1, 6)
+    t = np.ascontiguousarray(times, dtype=np.float64)
+    c = np.ascontiguousarray(cur_xyz, dtype=np.float64)
+    return int(lib().oracle_loop_detect(C.addressof(params), kp.ctypes.data, t.ctypes.data, kp.shape[0], c.ctypes.data))
+
+
+def pack_frames(frames):
+    """frames = [(pose6, corner, surf, outlier), ...] -> (poses6, points, offsets) as the loop-closure entry points take them"""
+    poses = np.ascontiguousarray([f[0] for f in frames], dtype=np.float32).reshape(-1, 6)
+    clouds, offs = [], [0]
+    for f in frames:
+        for c in f[1:4]:
+            c = np.ascontiguousarray(c, dtype=np.float32).reshape(-1, 4)
+            clouds.append(c)
+            offs.append(offs[-1] + c.shape[0])
+    pts = np.concatenate(clouds) if clouds else np.zeros((0, 4), np.float32)
+    return poses, np.ascontiguousarray(pts), np.array(offs, np.int32)
+
+
+def loop_icp(params, frames):
+    """performLoopClosure's ICP: frames[0] = newest key frame, frames[1:] = history frames.  Returns (result dict, target cloud)."""
+    poses, pts, offs = pack_frames(frames)
+    out = np.zeros(21)
+    tgt = np.empty((max(pts.shape[0], 1), 4), np.float32)
+    lib().oracle_loop_icp(C.addressof(params), poses.ctypes.data, pts.ctypes.data, offs.ctypes.data, len(frames) - 1, out.ctypes.data, tgt.ctypes.data, tgt.shape[0])
+    return dict(converged=int(out[0]), iterations=int(out[1]), n_source=int(out[2]), n_target=int(out[3]), fitness=float(out[4]),
+                T=out[5:21].astype(np.float32).reshape(4, 4)), tgt[:int(out[3])].copy()

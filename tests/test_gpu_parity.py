@@ -941,3 +941,36 @@ def test_stream_run_with_lookahead_lanes_is_bit_identical(params_a, lanes):
         assert ca == cb, (ca, cb)
     assert_bit_equal(hb.debug_get("lm_surf_map_ds"), ha.debug_get("lm_surf_map_ds"), "filtered surf map")
     ha.close(); hb.close()
+
+
+def test_loop_closure_icp_device_vs_oracle(params_a):
+    """f3: detectLoopClosure's sub-map + pcl::IterativeClosestPoint of performLoopClosure (laserMapping.cpp:652-824) on the device
+    against the oracle's restatement, on a real revisit of the T0 lap and with a wrong newest key pose.  The VoxelGrid-filtered
+    target is bit-exact; the alignment sums its correspondences in another order (per-workgroup partials), so the f32
+    transformation of an iteration can differ in its last bit: iterations within one, correction within 1e-5, fitness within 1e-6."""
+    p = params_a
+    o = O.Oracle(p)
+    for k in range(420):
+        o.process_scan(synth.scan(p, k))
+    poses = o.get("lm_keyposes").reshape(-1, 6)
+    n = len(poses)
+    closest = O.loop_detect(p, poses, np.arange(n) * 1.05, o.get("map_pose")[:3])
+    assert closest >= 0
+    frames = [(poses[n - 1],) + tuple(o.lm_keyframe(n - 1))]
+    for j in range(closest - p.lc_search_num, closest + p.lc_search_num + 1):
+        if 0 <= j < n - 1:
+            frames.append((poses[j],) + tuple(o.lm_keyframe(j)))
+    h = binding.Handle(p)
+    bad = poses[n - 1].copy()
+    bad[0] += 0.4; bad[1] -= 0.25; bad[5] += 0.03
+    for tag, fr in (("clean", frames), ("wrong newest pose", [(bad,) + frames[0][1:]] + frames[1:]), ("no history", frames[:1])):
+        want, wt = O.loop_icp(p, fr)
+        got, gt = h.loop_closure_icp(fr)
+        assert_bit_equal(gt, wt, f"{tag}: near_history_keyframes_")
+        assert (got["n_source"], got["n_target"], got["converged"]) == (want["n_source"], want["n_target"], want["converged"]), (tag, got, want)
+        if want["n_target"] == 0:
+            continue
+        assert abs(got["iterations"] - want["iterations"]) <= 1, (tag, got["iterations"], want["iterations"])
+        assert np.abs(got["T"] - want["T"]).max() < 1e-5, (tag, got["T"], want["T"])
+        assert abs(got["fitness"] - want["fitness"]) < 1e-6 * max(1.0, want["fitness"]), (tag, got["fitness"], want["fitness"])
+    h.close()

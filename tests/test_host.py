@@ -121,3 +121,50 @@ def test_oracle_keyframe_pass_through(params_a):
     assert ma.shape == mb.shape
     assert np.abs(mb[:, 0] - ma[:, 0] - 0.25).max() < 1e-4 and np.abs(mb[:, 1:] - ma[:, 1:]).max() < 1e-4, "the corrected map is the old one shifted"
     assert np.abs(b.get("map_pose")[:3] - a.get("map_pose")[:3] - [0.25, 0, 0]).max() < 0.02
+
+
+def _loop_frames(p, o, closest):
+    poses = o.get("lm_keyposes").reshape(-1, 6)
+    n = len(poses)
+    frames = [(poses[n - 1],) + tuple(o.lm_keyframe(n - 1))]
+    for j in range(closest - p.lc_search_num, closest + p.lc_search_num + 1):
+        if 0 <= j < n - 1:                                   # laserMapping.cpp:802: j < 0 || j >= latest_history_frame_id_ skipped
+            frames.append((poses[j],) + tuple(o.lm_keyframe(j)))
+    return frames
+
+
+def test_loop_detect_and_oracle_icp(params_a):
+    """detectLoopClosure's selection (host code of the library) against the oracle's, and the oracle's ICP restatement on a real
+    revisit: three quarters round the T0 lap the sensor sees the start area again; the ICP of the newest key frame against the
+    sub-map around the oldest ones converges, and it recovers a pose error put into the newest key pose."""
+    p = params_a
+    o = O.Oracle(p)
+    for k in range(420):
+        o.process_scan(synth.scan(p, k))
+    poses = o.get("lm_keyposes").reshape(-1, 6)
+    n = len(poses)
+    stamps = np.arange(n) * 1.05                              # ~1 key frame per second at 10 Hz
+    cur = o.get("map_pose")[:3]
+    rng = np.random.default_rng(4)
+    for trial in range(40):                                    # the library's host helper == the oracle on random queries
+        q = cur + rng.normal(size=3) * [8, 8, 0.5]
+        st = np.sort(rng.uniform(0, 60, n))
+        assert binding.loop_detect(p, poses, st, q) == O.loop_detect(p, poses, st, q)
+    closest = O.loop_detect(p, poses, stamps, cur)
+    assert closest == binding.loop_detect(p, poses, stamps, cur) and 0 <= closest < 8, closest
+    assert O.loop_detect(p, poses, np.arange(n) * 0.5, cur) == -1, "nothing is 30 s old yet"
+    frames = _loop_frames(p, o, closest)
+    r, tgt = O.loop_icp(p, frames)
+    assert r["converged"] == 1 and 2 <= r["iterations"] < p.icp_max_iters and r["fitness"] < p.lc_fitness_max
+    assert r["n_target"] == len(tgt) > 1000 and r["n_source"] == sum(len(c) for c in frames[0][1:])
+    assert np.abs(r["T"][:3, 3]).max() < 0.1, "an un-drifted trajectory needs (almost) no correction"
+    # a wrong newest key pose: the correction composed with it must land where the clean alignment landed
+    bad = poses[n - 1].copy()
+    bad[0] += 0.4; bad[1] -= 0.25; bad[5] += 0.03
+    r2, _ = O.loop_icp(p, [(bad,) + frames[0][1:]] + frames[1:])
+    assert r2["converged"] == 1 and r2["fitness"] < p.lc_fitness_max
+    pts = frames[0][2][:, :3].astype(np.float64)               # surf points of the newest frame, sensor frame
+    def world(pose, T):
+        w = O.transform_cloud(pose, frames[0][2])[:, :3].astype(np.float64)
+        return w @ T[:3, :3].astype(np.float64).T + T[:3, 3].astype(np.float64)
+    assert np.abs(world(bad, r2["T"]) - world(poses[n - 1], r["T"])).max() < 0.05
