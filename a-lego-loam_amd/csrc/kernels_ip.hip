@@ -208,11 +208,14 @@ __global__ void __launch_bounds__(IPF_W) ip_front(DevCtx d, int ring_pos, int in
 #pragma unroll
     for (int u = 0; u < IM_U; ++u) ob[u] = (have && row0 + u < d.NS) ? owner[(row0 + u) * d.H + col] : -1;
     // entries of this scan carry the tag; everything else is stale.  The plain form is written back (by the column's own
-    // workgroup) for the later readers (compaction) and doubles as the reset for the next scan.
+    // workgroup) for the later readers (compaction) and doubles as the reset for the next scan — except for the workgroup's
+    // FIRST column: the workgroup to the left reads that column as its halo, possibly much later (workgroups of one launch are
+    // not co-scheduled when other streams keep the CUs busy), and would find the tag gone = an empty column = missing
+    // right-edges.  Those columns stay tagged here; ip_strip_halo_columns (next kernel in the stream) finishes them.
 #pragma unroll
     for (int u = 0; u < IM_U; ++u) {
       ob[u] = (ob[u] >= 0 && (ob[u] & IP_OWNER_TAG)) ? (ob[u] & ~IP_OWNER_TAG) : -1;
-      if (mine && row0 + u < d.NS) owner[(row0 + u) * d.H + col] = ob[u];
+      if (mine && tid != 0 && row0 + u < d.NS) owner[(row0 + u) * d.H + col] = ob[u];
     }
 #pragma unroll
     for (int u = 0; u < IM_U; ++u) pb[u] = ob[u] >= 0 ? pts[ob[u]] : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -280,6 +283,20 @@ __global__ void __launch_bounds__(IPF_W) ip_front(DevCtx d, int ring_pos, int in
   }
 }
 
+// The owner entries ip_front left tagged (the first column of each of its workgroups) -> plain form / -1.  Called by exactly one
+// kernel per scan after ip_front (cc_lds16, cc_lds or cc_runs); readers of the owner image in the same kernel mask the tag off
+// (ip_owner_index), so they may see either form.
+DEV_INLINE void ip_strip_halo_columns(const DevCtx& d, int slot, int t, int nt) {
+  int* owner = d.owner + (size_t)slot * d.N;
+  const int nb = (d.H + IPF_W - 2) / (IPF_W - 1);
+  for (int j = t; j < nb * d.NS; j += nt) {
+    const int row = j / nb, col = (j - row * nb) * (IPF_W - 1);
+    const int v = owner[row * d.H + col];
+    owner[row * d.H + col] = (v >= 0 && (v & IP_OWNER_TAG)) ? (v & ~IP_OWNER_TAG) : -1;
+  }
+}
+DEV_INLINE int ip_owner_index(int v) { return v & ~IP_OWNER_TAG; }   // of a FILLED cell (never -1)
+
 // ECL-CC style find with intermediate pointer jumping; parents only ever decrease.
 DEV_INLINE int cc_find(int* parent, int v) {
   int curr = ld_agent(parent + v);
@@ -324,6 +341,10 @@ __global__ void __launch_bounds__(128) cc_runs(DevCtx d) {
   const size_t base = (size_t)slot * d.N;
   const uint8_t* f = d.flag_img + base;
   int* parent = d.parent + base;
+  if (col % (IPF_W - 1) == 0) {   // ip_strip_halo_columns, one column per thread
+    int* owner = d.owner + base;
+    for (int row = 0; row < d.NS; ++row) { const int v = owner[row * d.H + col]; owner[row * d.H + col] = (v >= 0 && (v & IP_OWNER_TAG)) ? (v & ~IP_OWNER_TAG) : -1; }
+  }
   int start = 0;
   uint8_t prev = 0;
   for (int row = 0; row < d.NS; ++row) {
@@ -391,6 +412,7 @@ __global__ void __launch_bounds__(CC_LDS_THREADS) cc_lds(DevCtx d, int ring_pos,
   const uint8_t* fi = d.flag_img + base;
   const int N = d.N, H = d.H;
   for (int v = threadIdx.x; v < N; v += CC_LDS_THREADS) parent[v] = v;
+  ip_strip_halo_columns(d, slot, threadIdx.x, CC_LDS_THREADS);
   __syncthreads();
   for (int v = threadIdx.x; v < N; v += CC_LDS_THREADS) {
     const uint8_t f = fi[v];
@@ -512,7 +534,7 @@ __global__ void __launch_bounds__(CC_LDS_THREADS) cc_lds(DevCtx d, int ring_pos,
       if (row > 0) d.ring_end[slot * d.NS + row - 1] = line - 1 - 5;
     }
     if (kp || ol) {
-      float4 p = pts[d.owner[base + v]];
+      float4 p = pts[ip_owner_index(d.owner[base + v])];
       p.w = (float)(row + col / 10000.0);  // :101
       if (kp) {
         d.seg_pts[base + line] = p;
@@ -600,6 +622,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(8, 8))) __launch_bounds__(CC_
   const int per = (N + CC_T - 1) / CC_T;   // cells per thread of THIS image (29 at 16x1800, 63 at 16x4000; PER = 63 is the capacity)
   const int lane = lane_id(), wave = threadIdx.x >> 6;
   CC_TICK(0);
+  ip_strip_halo_columns(d, slot, threadIdx.x, CC_T);
   unsigned long long f0 = 0, f1 = 0, f2 = 0, f3 = 0;   // the 4 flag bits of this thread's cells, 16 cells per word
 #pragma unroll 1
   for (int w = 0; w < (per + 15) / 16; ++w) {   // (one word at a time: 16 loads in flight, not 36 64-bit addresses in registers)
@@ -809,7 +832,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(8, 8))) __launch_bounds__(CC_
   for (int k0 = 0; k0 < per; k0 += CB) {
     const int c0 = cell_of(k0), c1 = cell_of(k0 + 1), c2 = cell_of(k0 + 2);
     const int o0 = d.owner[base + c0], o1 = d.owner[base + c1], o2 = d.owner[base + c2];
-    const float4 q0 = pts[max(o0, 0)], q1 = pts[max(o1, 0)], q2 = pts[max(o2, 0)];
+    const float4 q0 = pts[ip_owner_index(max(o0, 0))], q1 = pts[ip_owner_index(max(o1, 0))], q2 = pts[ip_owner_index(max(o2, 0))];
     // segmentedCloudRange = the range image's value (:99,:184), recomputed from the point instead of read back
     emit(k0, q0, sqrtf(q0.x * q0.x + q0.y * q0.y + q0.z * q0.z)); emit(k0 + 1, q1, sqrtf(q1.x * q1.x + q1.y * q1.y + q1.z * q1.z));
     emit(k0 + 2, q2, sqrtf(q2.x * q2.x + q2.y * q2.y + q2.z * q2.z));
@@ -949,7 +972,7 @@ __global__ void __launch_bounds__(IP_BLOCK) ip_compact(DevCtx d, int ring_pos) {
       tk += a; to += b; tf += e;
     }
     if (c == 1 || c == 2) {
-      const int o = d.owner[base + v];
+      const int o = ip_owner_index(d.owner[base + v]);
       float4 p = pts[o];
       p.w = (float)(row + col / 10000.0);  // :101
       if (c == 1) {

@@ -480,6 +480,34 @@ def test_batch_full_loop_equals_single_stream(params_a, nslot, groups, monkeypat
     hb.close()
 
 
+def test_batch_stream_groups_are_repeatable(params_a, monkeypatch):
+    """The same 5-slot batch on 3 concurrent HIP streams, 12 times: every run gives the bits of the first.  (Workgroups of one
+    launch are not co-scheduled when other streams keep the CUs busy; ip_front once let a workgroup clear the owner tags of a
+    column its left neighbour still had to read as its halo — about one run in eight then segmented a scan differently.)"""
+    p = params_a
+    nslot, nscan = 5, 40
+    scans = [[synth.scan(p, k, stream=s) for k in range(nscan)] for s in range(nslot)]
+    first = None
+    for rep in range(12):
+        monkeypatch.setenv("ALEGO_STREAM_GROUPS", "3")
+        hb = binding.Handle(p, n_slots=nslot, ring_len=nscan)
+        for s in range(nslot):
+            for k in range(nscan):
+                hb.batch_load(s, k, scans[s][k])
+        hb.batch_run(0, nscan, stages=7)
+        cur = []
+        for s in range(nslot):
+            _, odom, mp = hb.batch_get_pose(s)
+            cur.append((odom["t"].copy(), mp["params"].copy(), hb.debug_get("scal", slot=s).copy(), hb.debug_get("seg_cloud", slot=s).copy()))
+        hb.close()
+        if first is None:
+            first = cur
+            continue
+        for s in range(nslot):
+            for a, b, what in zip(cur[s], first[s], ("odometry", "LM params_", "scalars", "segmented cloud")):
+                assert_bit_equal(a, b, f"run {rep} slot {s} {what}")
+
+
 def test_batch_with_slots_out_of_phase(params_a):
     """One slot has seen an extra scan before the batch starts: its mapping frames fall on the other slots' skipped frames
     (the host cannot skip launches any more, the device-side gates decide per slot).  Every slot still equals a handle of its own."""
