@@ -22,7 +22,7 @@ EXPORTS = [
     "alego_ip_process", "alego_lo_process", "alego_lm_process", "alego_scan_process",
     "alego_batch_load", "alego_batch_run", "alego_synchronize", "alego_batch_get_pose", "alego_batch_get_counts",
     "alego_stream", "alego_stream_groups", "alego_profile_enable", "alego_profile_report", "alego_set_lo_params", "alego_set_lm_params", "alego_debug_get", "alego_debug_voxel", "alego_debug_atan2f",
-    "alego_debug_math", "alego_debug_eval_blocks", "alego_debug_transform_to_start", "alego_debug_set_option",
+    "alego_debug_math", "alego_debug_std_sort", "alego_debug_eval_blocks", "alego_debug_transform_to_start", "alego_debug_set_option",
     "alego_lm_keyframe_count", "alego_lm_get_keyframe", "alego_lm_set_keypose", "alego_lm_reset_window", "alego_lm_apply_correction",
     "alego_lm_add_keyframe", "alego_pc2_to_points", "alego_replay_create", "alego_replay_load", "alego_replay_assign",
     "alego_dist_unique_id", "alego_dist_init", "alego_dist_shutdown", "alego_stream_setup", "alego_stream_run",
@@ -139,6 +139,8 @@ def lib():
         L.alego_debug_voxel.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_int]
         L.alego_debug_atan2f.restype = C.c_int
         L.alego_debug_atan2f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.alego_debug_std_sort.restype = C.c_int
+        L.alego_debug_std_sort.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.alego_debug_math.restype = C.c_int
         L.alego_debug_math.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.alego_debug_eval_blocks.restype = C.c_int
@@ -443,6 +445,13 @@ class Handle:
         b = None if b is None else np.ascontiguousarray(b, np.float32)
         out = np.empty_like(a)
         self._check(lib().alego_debug_math(self._h, mode, a.ctypes.data, None if b is None else b.ctypes.data, out.ctypes.data, a.size), "alego_debug_math")
+        return out
+
+    def std_sort(self, keys, depth_limit=-1):
+        """index order libstdc++'s std::sort gives 0..n-1 under `keys[a] < keys[b]`, as the device reproduces it (sort_mode 2)"""
+        k = np.ascontiguousarray(keys, np.uint32)
+        out = np.empty(k.size, np.int32)
+        self._check(lib().alego_debug_std_sort(self._h, k.ctypes.data, k.size, depth_limit, out.ctypes.data), "alego_debug_std_sort")
         return out
 
     def eval_blocks(self, btype, geom13, params6):

@@ -23,6 +23,7 @@ void launch_ip(const DevCtx& d, int ring_pos, bool want_labels, hipStream_t st);
 void launch_fe(const DevCtx& d, hipStream_t st);
 void launch_lo(const DevCtx& d, hipStream_t st);
 void launch_atan2f_probe(const float* y, const float* x, float* out, int n, int mode, hipStream_t st);
+int launch_stdsort_probe(const uint32_t* keys, int n, int depth_limit, int* pos_out, hipStream_t st);
 void launch_dbg_eval_blocks(int type, int n, const double* geom13, const double* params6, double* res, double* jac6, hipStream_t st);
 int icp_run(const alego_params& P, const alego_kf_in* latest, const alego_kf_in* history, int n_history, alego_icp_result* out,
             alego_point* target_out, int target_cap, hipStream_t st, std::string* err);
@@ -144,6 +145,7 @@ int alego_create(const alego_params* params, int device, int n_slots, int ring_l
   if (n_slots <= 0) n_slots = 1;
   if (ring_len <= 0) ring_len = 1;
   if (params->n_scan < 1 || params->n_scan > 64 || params->horizon_scan < 64 || params->horizon_scan > 4096) return ALEGO_ERR_ARG;
+  if (params->sort_mode != 0 && params->sort_mode != 2) { std::fprintf(stderr, "alego_create: sort_mode %d is an oracle-only setting (0 = (curvature, index) order, 2 = libstdc++ std::sort tie order in the sector sort)\n", params->sort_mode); return ALEGO_ERR_ARG; }
   if (params->recent_keyframe_num > 512) { std::fprintf(stderr, "alego_create: recent_keyframe_num > 512 is not supported\n"); return ALEGO_ERR_ARG; }
   // The feature pick marks up to suppress_radius neighbours on either side of a picked point; the segmented cloud only
   // guarantees the reference's 5-point margin at both ends of a ring (laserOdometry.cpp:124,211-234 index i +- 5 unchecked).
@@ -690,6 +692,26 @@ int alego_debug_math(alego_handle* h, int mode, const float* a, const float* b, 
   return 0;
 }
 int alego_debug_atan2f(alego_handle* h, const float* y, const float* x, float* out, int n) { return alego_debug_math(h, 0, y, x, out, n); }
+
+int alego_debug_std_sort(alego_handle* h, const uint32_t* keys, int n, int depth_limit, int32_t* order) {
+  if (!h || n < 0 || n > 4096 || (n > 0 && (!keys || !order))) return ALEGO_ERR_ARG;
+  if (n == 0) return 0;
+  hipSetDevice(h->device);
+  DevTemps T;
+  uint32_t* dk;
+  int* dp;
+  HIP_TRY(h, T.get(&dk, (size_t)n * 4)); HIP_TRY(h, T.get(&dp, (size_t)n * 4));
+  HIP_TRY(h, hipMemcpy(dk, keys, (size_t)n * 4, hipMemcpyHostToDevice));
+  if (launch_stdsort_probe(dk, n, depth_limit, dp, h->stream)) return ALEGO_ERR_ARG;
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  std::vector<int> pos(n), arr(n);
+  HIP_TRY(h, hipMemcpy(pos.data(), dp, (size_t)n * 4, hipMemcpyDeviceToHost));
+  // the device returns where the partition phase left every element; __final_insertion_sort is a stable sort of that arrangement
+  for (int i = 0; i < n; ++i) { if (pos[i] < 0 || pos[i] >= n) { h->err = "alego_debug_std_sort: arrangement out of range"; return ALEGO_ERR_HIP; } arr[pos[i]] = i; }
+  std::stable_sort(arr.begin(), arr.end(), [&](int a, int b) { return keys[a] < keys[b]; });
+  for (int i = 0; i < n; ++i) order[i] = arr[i];
+  return 0;
+}
 
 int alego_debug_eval_blocks(alego_handle* h, int type, int n, const double* geom13, const double* params6, double* res, double* jac6) {
   if (!h || n < 0 || type < 0 || type > 3 || !params6 || (n > 0 && (!geom13 || !res || !jac6))) return ALEGO_ERR_ARG;

@@ -15,6 +15,7 @@
 #include <type_traits>
 #include "dev_common.h"
 #include "prof.h"
+#include "stdsort_emu.h"
 
 #define FE_BLOCK 256
 #define FE_HALO 6
@@ -93,9 +94,14 @@ __global__ void __launch_bounds__(FE_BLOCK) fe_curv(DevCtx d) {
 // one wavefront per (ring, slot).  Dynamic LDS: 3 bytes per ring point (column u16, flags + label u8); the
 // kernel's duration under load is set by how many rings fit a CU next to the other streams' workgroups.
 // flag bits: 0 picked, 1 ground, 2 curvature > edge_thres, 3 curvature < surf_thres, 4-5 cloud_label_ + 1
-template <int FE_T>
+// STDSORT (alego_params.sort_mode = 2): candidates with EQUAL curvature are taken in the order libstdc++'s std::sort leaves them in
+// (laserOdometry.cpp:185 sorts with a comparator on the curvature alone) instead of by index.  The picks only ever ask for the
+// best remaining candidate, so the sort itself is not needed — only, when several candidates tie for it, where std::sort's
+// partition phase would have left each of them (stdsort_emu.h); that arrangement is computed once per sector, on the first tie.
+template <int FE_T, bool STDSORT>
 __global__ void __launch_bounds__(64) fe_pick(DevCtx d) {
   const int slot = blockIdx.y + d.slot0, ring = blockIdx.x, lane = threadIdx.x;
+  __shared__ typename std::conditional<STDSORT, SortEmu<64 * FE_T>, char>::type s_emu;
   const size_t base = (size_t)slot * d.N;
   const alego_params& P = d.P;
   const int S = d.ring_start[slot * d.NS + ring], E = d.ring_end[slot * d.NS + ring];
@@ -159,6 +165,16 @@ __global__ void __launch_bounds__(64) fe_pick(DevCtx d) {
       const int ct = first + off;
       if (ct <= last && ct >= lsp && ct <= lep) { const uint32_t bit = 1u << ((ct - lsp - lane) / 64); sharp_m &= ~bit; flat_m &= ~bit; }
     };
+    bool have_arr = false;
+    auto sector_arrangement = [&]() {
+      if constexpr (STDSORT) {
+        const int n = lep - lsp + 1;
+        __syncthreads();
+        for (int i = lane; i < n; i += 64) s_emu.ak[i] = (uint32_t)d_f2i(fabsf(cdv[lsp + i]));   // |cd| bits order like the f64 curvature, equal iff it is
+        __syncthreads();
+        stdsort_arrangement(s_emu, n);
+      }
+    };
     // ---- sharp / less-sharp: descending curvature, ties -> larger index (:189-236) ----
     int picked_num = 0;
     while (true) {
@@ -171,8 +187,25 @@ __global__ void __launch_bounds__(64) fe_pick(DevCtx d) {
       // almost always exactly one lane holds the maximum: its index comes through v_readlane; equal keys in several
       // lanes (ties -> larger index) take the second reduction
       const unsigned long long tie = __ballot(sharp_m && bk == kmax);
-      int c;
-      if ((tie & (tie - 1)) == 0) {
+      int c = 0;
+      bool by_arrangement = false;
+      if constexpr (STDSORT) {
+        int cnt = 0;
+#pragma unroll
+        for (int t = 0; t < FE_T; ++t) cnt += (((sharp_m >> t) & 1) && key[t] == kmax) ? 1 : 0;
+        const unsigned long long a1 = __ballot(cnt > 0), a2 = __ballot(cnt > 1);
+        by_arrangement = a2 != 0 || (a1 & (a1 - 1)) != 0;
+        if (by_arrangement) {   // the scan runs k = ep .. sp: of the tied candidates the one std::sort placed last comes first
+          if (!have_arr) { sector_arrangement(); have_arr = true; }
+          uint32_t best = 0;
+#pragma unroll
+          for (int t = 0; t < FE_T; ++t)
+            if (((sharp_m >> t) & 1) && key[t] == kmax) best = max(best, (((uint32_t)s_emu.pos[lane + 64 * t] + 1u) << 16) | (uint32_t)(lane + 64 * t));
+          c = lsp + (int)(wave_max_u32(best) & 0xFFFFu);
+        }
+      }
+      if (by_arrangement) {
+      } else if ((tie & (tie - 1)) == 0) {
         const int wl = __ffsll((long long)tie) - 1;
         c = lsp + wl + 64 * __builtin_amdgcn_readlane(bt, wl);
       } else {
@@ -202,8 +235,25 @@ __global__ void __launch_bounds__(64) fe_pick(DevCtx d) {
       const uint32_t kmin = wave_min_u32(bk);
       if (kmin == 0xFFFFFFFFu) break;
       const unsigned long long tie = __ballot(flat_m && bk == kmin);
-      int c;
-      if ((tie & (tie - 1)) == 0) {
+      int c = 0;
+      bool by_arrangement = false;
+      if constexpr (STDSORT) {
+        int cnt = 0;
+#pragma unroll
+        for (int t = 0; t < FE_T; ++t) cnt += (((flat_m >> t) & 1) && key[t] == kmin) ? 1 : 0;
+        const unsigned long long a1 = __ballot(cnt > 0), a2 = __ballot(cnt > 1);
+        by_arrangement = a2 != 0 || (a1 & (a1 - 1)) != 0;
+        if (by_arrangement) {   // k = sp .. ep: the tied candidate std::sort placed first
+          if (!have_arr) { sector_arrangement(); have_arr = true; }
+          uint32_t best = 0xFFFFFFFFu;
+#pragma unroll
+          for (int t = 0; t < FE_T; ++t)
+            if (((flat_m >> t) & 1) && key[t] == kmin) best = min(best, ((uint32_t)s_emu.pos[lane + 64 * t] << 16) | (uint32_t)(lane + 64 * t));
+          c = lsp + (int)(wave_min_u32(best) & 0xFFFFu);
+        }
+      }
+      if (by_arrangement) {
+      } else if ((tie & (tie - 1)) == 0) {
         const int wl = __ffsll((long long)tie) - 1;
         c = lsp + wl + 64 * __builtin_amdgcn_readlane(bt, wl);
       } else {
@@ -715,20 +765,37 @@ __global__ void __launch_bounds__(FE_BLOCK) fe_boxes(DevCtx d) {
   }
 }
 
+// alego_debug_std_sort: the emulation on its own (one wavefront, up to 4096 keys)
+#define STDSORT_PROBE_MAX 4096
+__global__ void __launch_bounds__(64) stdsort_probe(const uint32_t* keys, int n, int depth_limit, int* pos_out) {
+  __shared__ SortEmu<STDSORT_PROBE_MAX> E;
+  for (int i = threadIdx.x; i < n; i += 64) E.ak[i] = keys[i];
+  __syncthreads();
+  stdsort_arrangement(E, n, depth_limit);
+  for (int i = threadIdx.x; i < n; i += 64) pos_out[i] = E.pos[i];
+}
+int launch_stdsort_probe(const uint32_t* keys, int n, int depth_limit, int* pos_out, hipStream_t st) {
+  if (n > STDSORT_PROBE_MAX) return -1;
+  hipLaunchKernelGGL(stdsort_probe, dim3(1), dim3(64), 0, st, keys, n, depth_limit, pos_out);
+  return 0;
+}
+
 void launch_fe(const DevCtx& d, hipStream_t st) {
   ALEGO_LAUNCH(fe_curv, dim3((d.N + FE_CW - 1) / FE_CW, d.n_launch), dim3(FE_BLOCK), 0, st, d);
   // the longest sector holds at most ceil(H / n_sectors) + 1 points
   const int sector_max = (d.H + d.P.n_sectors - 1) / (d.P.n_sectors > 0 ? d.P.n_sectors : 1) + 2;
   // (padding this allocation by 16 KB cost 7 % of the whole pipeline: the LDS footprint decides how many rings share a CU)
   const int extra = 0;
-  const bool one_ring = d.opt_fe_pick1 || d.P.suppress_radius > 7 || sector_max > 16 * 43;   // (2 * radius + 1 marked elements <= 16 lanes)
+  const bool one_ring = d.opt_fe_pick1 || d.P.sort_mode == 2 || d.P.suppress_radius > 7 || sector_max > 16 * 43;   // (2 * radius + 1 marked elements <= 16 lanes)
   const dim3 g4((d.NS + FP_G - 1) / FP_G, d.n_launch);
   const size_t lds4 = (size_t)FP_G * d.H;
   if (!one_ring && sector_max <= 16 * 19) { ALEGO_LAUNCH(fe_pick4<19>, g4, dim3(64), lds4, st, d); }
   else if (!one_ring && sector_max <= 16 * 24) { ALEGO_LAUNCH(fe_pick4<24>, g4, dim3(64), lds4, st, d); }
   else if (!one_ring) { ALEGO_LAUNCH(fe_pick4<43>, g4, dim3(64), lds4, st, d); }
-  else if (sector_max <= 64 * 6) { ALEGO_LAUNCH(fe_pick<6>, dim3(d.NS, d.n_launch), dim3(64), (size_t)3 * d.H + extra, st, d); }
-  else { ALEGO_LAUNCH(fe_pick<12>, dim3(d.NS, d.n_launch), dim3(64), (size_t)3 * d.H, st, d); }
+  else if (d.P.sort_mode == 2 && sector_max <= 64 * 6) { ALEGO_LAUNCH((fe_pick<6, true>), dim3(d.NS, d.n_launch), dim3(64), (size_t)3 * d.H, st, d); }
+  else if (d.P.sort_mode == 2) { ALEGO_LAUNCH((fe_pick<12, true>), dim3(d.NS, d.n_launch), dim3(64), (size_t)3 * d.H, st, d); }
+  else if (sector_max <= 64 * 6) { ALEGO_LAUNCH((fe_pick<6, false>), dim3(d.NS, d.n_launch), dim3(64), (size_t)3 * d.H + extra, st, d); }
+  else { ALEGO_LAUNCH((fe_pick<12, false>), dim3(d.NS, d.n_launch), dim3(64), (size_t)3 * d.H, st, d); }
   ALEGO_LAUNCH(fe_voxel, dim3(d.NS, d.n_launch), dim3(FE_BLOCK), (size_t)10 * d.H, st, d);
   ALEGO_LAUNCH(fe_gather, dim3(d.NS, d.n_launch), dim3(FE_BLOCK), 0, st, d);
   ALEGO_LAUNCH(fe_boxes, dim3(24, 2, d.n_launch), dim3(FE_BLOCK), 0, st, d);  // 24 x 8 boxes = 6144 targets per sweep

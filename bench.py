@@ -248,6 +248,7 @@ def main():
     ap.add_argument("--prime", type=int, default=LAP, help="untimed scans per stream to fill the local map (one lap fills 50 key frames)")
     ap.add_argument("--geometry", default="16x1800", help="n_scan x horizon_scan: 16x1800 (BASELINE metric), 16x4000, 64x2048")
     ap.add_argument("--keyframes", type=int, default=0, help="local-map window (0 = reference default 50; config 5 uses 200)")
+    ap.add_argument("--sort-mode", type=int, default=0, help="2 = feature picks in libstdc++ std::sort tie order (alego_params.sort_mode)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     args = ap.parse_args()
@@ -265,6 +266,7 @@ def main():
     p = synth.default_params(ns, hs)
     if args.keyframes > 0:
         p.recent_keyframe_num = args.keyframes
+    p.sort_mode = args.sort_mode
     B = args.streams
     bags = make_bags(p, args.bags, first_stream=rank * args.bags)
     h = binding.Handle(p, device=local, n_slots=B, ring_len=1)

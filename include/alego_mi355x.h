@@ -173,11 +173,15 @@ int alego_set_lm_params(alego_handle* h, int slot, const double* p6);
  * dtype: 0 f32, 1 f64, 2 i32, 3 u8.  Names mirror oracle_get(). */
 int alego_debug_get(alego_handle* h, int slot, const char* name, void* out, int cap_bytes,
                     int* count, int* dtype);
-/* the device pcl::VoxelGrid replacement on a host cloud (both the one-launch LDS path for <= 8192 points and the
- * multi-kernel bucket-sort path), for direct parity tests against the oracle; returns the output count */
+/* the device pcl::VoxelGrid replacement on a host cloud (the LDS-resident radix sort for <= 8192 points, the HBM-scratch
+ * radix sort above), for direct parity tests against the oracle; returns the output count */
 int alego_debug_voxel(alego_handle* h, const alego_point* pts, int n, float leaf, alego_point* out, int cap);
 /* device atan2f / hypotf used by the projection kernel, for the libm-equivalence test */
 int alego_debug_atan2f(alego_handle* h, const float* y, const float* x, float* out, int n);
+/* libstdc++ std::sort(idx, idx + n, [](a, b) { return keys[a] < keys[b]; }) on idx = 0..n-1 (n <= 4096) as the device reproduces
+ * it for alego_params.sort_mode = 2 (laserOdometry.cpp:185): order[k] = the element at sorted position k.  depth_limit < 0 = std::sort's
+ * own 2 floor(log2 n); >= 0 overrides __introsort_loop's depth limit (0 = heap sort at once) so that tests reach that branch */
+int alego_debug_std_sort(alego_handle* h, const uint32_t* keys, int n, int depth_limit, int32_t* order);
 /* the device's shared single-precision functions on arrays: mode 0 atan2f(a, b), 1 hypotf(a, b), 2 sinf(a), 3 cosf(a) */
 int alego_debug_math(alego_handle* h, int mode, const float* a, const float* b, float* out, int n);
 /* The four cost functors of include/alego/utility.h:122-349 evaluated on the device exactly as the solvers evaluate them

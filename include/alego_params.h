@@ -60,8 +60,11 @@ typedef struct alego_params {
   int32_t suppress_radius;   /* 5               laserOdometry.cpp:211; 0..5 (the 5-point ring margin): alego_create rejects more */
   int32_t suppress_col_diff; /* 10              laserOdometry.cpp:214 */
   float less_flat_leaf;      /* 0.4 m           laserOdometry.cpp:290 */
-  int32_t sort_mode;         /* 0 = total order (curvature, index); 1 = libstdc++ std::sort
-                                tie order (oracle only — SURVEY.md C.1) */
+  int32_t sort_mode;         /* tie order of equal curvatures in the sector sort (laserOdometry.cpp:185, std::sort with a
+                                comparator on the curvature alone) and of the points of one voxel in pcl::VoxelGrid's sort:
+                                0 = total order (curvature, index) / input order inside a voxel (the default build rule);
+                                2 = sector sort in libstdc++'s std::sort order (what the reference binary does), VoxelGrid as 0;
+                                1 = both in std::sort order (oracle only: alego_create rejects it) */
   /* ---- scan-to-scan odometry: laserOdometry.cpp:328-508 ---- */
   double nearest_feature_dist; /* 25.0 (squared) utility.h:73 */
   int32_t ring_window;       /* 2               laserOdometry.cpp:350,441 */

@@ -843,7 +843,7 @@ struct LaserOdometry {
         else { int diff = E - S; sp = S + j * diff / NSEC; ep = S + (j + 1) * diff / NSEC - 1; }
         if (sp >= ep) continue;
         auto cmp = [this](int a, int b) { return curvature[a] < curvature[b]; };
-        if (P.sort_mode == 1) std::sort(sort_idx.begin() + sp, sort_idx.begin() + ep + 1, cmp);
+        if (P.sort_mode == 1 || P.sort_mode == 2) std::sort(sort_idx.begin() + sp, sort_idx.begin() + ep + 1, cmp);   // :185
         else std::stable_sort(sort_idx.begin() + sp, sort_idx.begin() + ep + 1, cmp);
         int picked_num = 0;
         for (int k = ep; k >= sp; --k) {
@@ -1580,6 +1580,21 @@ void oracle_libm_hypotf_array(const float* x, const float* y, float* out, int n)
 // mode 0: restated sinf, 1: restated cosf, 2: this host's libm sinf, 3: libm cosf
 void oracle_sincosf_array(const float* x, float* out, int n, int mode) {
   for (int i = 0; i < n; ++i) out[i] = mode == 0 ? omath::o_sinf(x[i]) : mode == 1 ? omath::o_cosf(x[i]) : mode == 2 ? std::sin(x[i]) : std::cos(x[i]);
+}
+
+// std::sort itself (this container's libstdc++) on idx = 0..n-1 with the reference's kind of comparator (keys only):
+// laserOdometry.cpp:185.  depth_limit >= 0 calls the two phases of std::sort (bits/stl_algo.h) with that depth limit instead of
+// 2 floor(log2 n), so that the heap-sort branch of __introsort_loop can be reached without adversarial input.
+void oracle_std_sort_order(const uint32_t* keys, int n, int depth_limit, int* order) {
+  std::vector<int> idx(n);
+  for (int i = 0; i < n; ++i) idx[i] = i;
+  auto cmp = [keys](int a, int b) { return keys[a] < keys[b]; };
+  if (depth_limit < 0) std::sort(idx.begin(), idx.end(), cmp);
+  else if (n > 0) {
+    std::__introsort_loop(idx.begin(), idx.end(), (long)depth_limit, __gnu_cxx::__ops::__iter_comp_iter(cmp));
+    std::__final_insertion_sort(idx.begin(), idx.end(), __gnu_cxx::__ops::__iter_comp_iter(cmp));
+  }
+  for (int i = 0; i < n; ++i) order[i] = idx[i];
 }
 
 int oracle_voxel_grid(const alego_point* in, int n, float leaf, int sort_mode, alego_point* out, int cap) {

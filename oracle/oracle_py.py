@@ -33,6 +33,8 @@ def lib():
         L.oracle_set_lm_params.argtypes = [C.c_void_p, C.c_void_p]
         L.oracle_get.restype = C.c_int
         L.oracle_get.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.oracle_std_sort_order.restype = None
+        L.oracle_std_sort_order.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.oracle_voxel_grid.restype = C.c_int
         L.oracle_voxel_grid.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_int]
         L.oracle_eval_block.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -166,6 +168,14 @@ class Oracle:
 _CLOUDS = {"seg_cloud", "outlier", "sharp", "less_sharp", "flat", "less_flat", "surf_last", "corner_last",
            "lm_corner_map_ds", "lm_surf_map_ds", "lm_corner_map", "lm_surf_map", "lm_corner_ds", "lm_surf_ds",
            "lm_outlier_ds", "lm_surf_total_ds"}
+
+
+def std_sort_order(keys, depth_limit=-1):
+    """libstdc++ std::sort of 0..n-1 by `keys[a] < keys[b]` (laserOdometry.cpp:185's kind of comparator)"""
+    k = np.ascontiguousarray(keys, np.uint32)
+    out = np.empty(k.size, np.int32)
+    lib().oracle_std_sort_order(k.ctypes.data, k.size, depth_limit, out.ctypes.data)
+    return out
 
 
 def voxel_grid(pts, leaf, sort_mode=0):

@@ -480,6 +480,86 @@ def test_batch_full_loop_equals_single_stream(params_a, nslot, groups, monkeypat
     hb.close()
 
 
+def _tie_cases():
+    rng = np.random.default_rng(11)
+    cases = []
+    for n in (1, 2, 3, 16, 17, 18, 33, 100, 300, 301, 768, 1500, 4096):
+        cases.append((f"random few values n={n}", rng.integers(0, 7, n)))
+        cases.append((f"random distinct-ish n={n}", rng.integers(0, 1 << 30, n)))
+        cases.append((f"ascending with ties n={n}", np.sort(rng.integers(0, max(2, n // 3), n))))
+        cases.append((f"descending with ties n={n}", np.sort(rng.integers(0, max(2, n // 3), n))[::-1]))
+        cases.append((f"all equal n={n}", np.full(n, 5)))
+        cases.append((f"organ pipe n={n}", np.concatenate([np.arange(n // 2), np.arange(n - n // 2)[::-1]])))
+    return cases
+
+
+def test_device_std_sort_arrangement(params_a):
+    """alego_params.sort_mode = 2: the device reproduces where libstdc++'s std::sort (laserOdometry.cpp:185, comparator on the
+    curvature alone) leaves equal keys.  Checked against std::sort itself, and — with the depth limit forced down so that
+    __introsort_loop falls into its heap sort after 0, 1, 2, 3 partitions — against the two phases of std::sort called directly."""
+    h = binding.Handle(params_a)
+    for tag, keys in _tie_cases():
+        keys = np.asarray(keys, np.uint32)
+        assert_bit_equal(h.std_sort(keys), O.std_sort_order(keys), f"std::sort order, {tag}")
+        for depth in (0, 1, 2, 3):
+            assert_bit_equal(h.std_sort(keys, depth), O.std_sort_order(keys, depth), f"depth limit {depth}, {tag}")
+    h.close()
+
+
+def _quantised(pts, step=0.05):
+    """ranges rounded to `step`: neighbouring returns of a wall get identical range differences -> many exactly equal curvatures"""
+    pts = pts.copy()
+    r = np.linalg.norm(pts[:, :3].astype(np.float64), axis=1)
+    ok = r > 0
+    pts[ok, :3] = (pts[ok, :3].astype(np.float64) * ((np.round(r[ok] / step) * step) / r[ok])[:, None]).astype(np.float32)
+    return pts
+
+
+@pytest.mark.parametrize("geom", [(16, 1800), (16, 4000), (64, 2048)])
+def test_fe_std_sort_tie_order(geom):
+    """sort_mode = 2: feature picks with tied curvatures in libstdc++'s std::sort order (the reference binary's behaviour), bit-exact
+    against the oracle running the real std::sort — on scans with quantised ranges (every scan has ties that change the picks
+    under the (curvature, index) rule) and on plain ones."""
+    p = synth.default_params(*geom)
+    p.sort_mode = 2
+    p0 = p.copy()
+    p0.sort_mode = 0
+    h, o, o0 = binding.Handle(p), O.Oracle(p), O.Oracle(p0)
+    changed = 0
+    for k in range(8):
+        pts = synth.scan(p, k)
+        if k < 6:
+            pts = _quantised(pts)
+        seg = _ip_compare(h, o, pts, f"{geom} scan {k}")
+        h.set_lo_params(o.get("lo_params"))
+        o.lo()
+        o0.ip(pts), o0.fe()
+        flags, feat, odom = h.lo_process(seg)
+        _fe_compare(h, o, feat, f"{geom} sort_mode 2 scan {k}")
+        changed += not all(np.array_equal(o.get(n), o0.get(n)) for n in ("sharp_idx", "less_sharp_idx", "flat_idx"))
+    assert changed >= 4, "the fixture is supposed to contain ties that matter"
+    h.close()
+
+
+def test_full_loop_with_std_sort_tie_order(params_a):
+    """IP -> LO -> LM with sort_mode = 2 on both sides, teacher-forced, quantised scans."""
+    p = params_a.copy()
+    p.sort_mode = 2
+    h, o = binding.Handle(p), O.Oracle(p)
+    for k in range(14):
+        pts = _quantised(synth.scan(p, k))
+        o.process_scan(pts)
+        flags, odom, mp = h.scan_process(pts, stages=7)
+        assert_bit_equal(h.debug_get("less_sharp_idx"), o.get("less_sharp_idx"), f"scan {k} less_sharp_idx")
+        assert_bit_equal(h.debug_get("flat_idx"), o.get("flat_idx"), f"scan {k} flat_idx")
+        if k > 0:
+            want = o.get("odom_pose")
+            assert np.abs(odom["t"] - want[:3]).max() < POSE_TOL
+        h.set_lo_params(o.get("lo_params"))
+        h.set_lm_params(o.get("lm_params"))
+    h.close()
+
+
 def test_batch_stream_groups_are_repeatable(params_a, monkeypatch):
     """The same 5-slot batch on 3 concurrent HIP streams, 12 times: every run gives the bits of the first.  (Workgroups of one
     launch are not co-scheduled when other streams keep the CUs busy; ip_front once let a workgroup clear the owner tags of a

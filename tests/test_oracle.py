@@ -281,3 +281,17 @@ def test_reference_option_variants(params_a):
     c.ip(pts), c.fe()
     same = np.array_equal(a.get("less_sharp_idx"), c.get("less_sharp_idx"))
     print("std::sort vs stable tie order gives identical picks on this scan:", same)
+
+
+def test_std_sort_phases_equal_std_sort():
+    """oracle_std_sort_order(depth_limit >= 0) calls libstdc++'s __introsort_loop + __final_insertion_sort directly (to force the
+    heap-sort branch in the device's tie-order test); with std::sort's own depth limit 2 floor(log2 n) it must be std::sort."""
+    rng = np.random.default_rng(5)
+    for n in (1, 2, 17, 100, 300, 1000, 4096):
+        for hi in (4, 1 << 30):
+            keys = rng.integers(0, hi, n).astype(np.uint32)
+            a = O.std_sort_order(keys)
+            b = O.std_sort_order(keys, 2 * (int(n).bit_length() - 1))
+            assert_bit_equal(a, b, f"n={n} hi={hi}")
+            assert np.array_equal(keys[a], np.sort(keys)), "sorted"
+            assert np.array_equal(np.sort(a), np.arange(n)), "permutation"
