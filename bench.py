@@ -62,8 +62,8 @@ def kernel_bytes(name, c, NS, H, rebuilds_per_launch=0.0):
     rb = rebuilds_per_launch
     t = {
         # B_IP = 16 P (in) + 25 M + 16 O + 8 NS + 12 (out)
-        "ip_project": 16 * P, "ip_front": 16 * P, "cc_lds16": 25 * M + 16 * O + 8 * NS + 12, "cc_lds": 25 * M + 16 * O + 8 * NS + 12,
-        "ip_compact": 25 * M + 16 * O + 8 * NS + 12,
+        "ip_project": 16 * P, "ip_front": 12, "cc_lds16": 25 * M + 16 * O + 8 * NS, "cc_lds": 25 * M + 16 * O + 8 * NS,
+        "ip_compact": 25 * M + 16 * O + 8 * NS,
         # B_FE = 9 M (range, col, ground in) + 16 feats (out)
         "fe_curv": 8 * M, "fe_pick4": M, "fe_pick": M, "fe_gather": 16 * feats,
         # B_LO = 16 (F' + Q) + 104
