@@ -35,7 +35,8 @@ def _ip_compare(h, o, pts, tag):
                                           ((16, 4000), None), ((64, 2048), None)])
 def test_ip_bit_exact(geom, variant, monkeypatch):
     """ImageProjection bit for bit.  16x1800 runs the fused LDS kernel (cc_lds16); ALEGO_CC_FUSED=0 keeps its union-find but
-    compacts with the separate ip_rowcount + ip_compact kernels; the larger geometries take the global-memory union-find.
+    compacts with the separate ip_rowcount + ip_compact kernels; 16x4000 runs cc_lds16 at 126 KB of LDS, 64x2048 the global-memory
+    union-find (cc_runs + cc_link + cc_stats).
     ALEGO_IP_FAST=0 projects every point with the reference expressions (normally only the points within 2.5e-4 cells of a
     cell boundary take them; the rest are placed by the boundary tables)."""
     if variant:
@@ -418,7 +419,7 @@ def test_lm_process_host_entry(params_a):
                                          (8193, 0.8, "gauss"), (60000, 0.4, "gauss"), (60000, 0.8, "dense"), (120000, 0.8, "wall"),
                                          (5000, 0.001, "gauss"), (20000, 50.0, "gauss")])
 def test_device_voxel_grid_bit_exact(params_a, n, leaf, kind):
-    """Both device VoxelGrid paths (one-launch LDS path up to 8192 points, bucket-sort path above) against the
+    """Both device VoxelGrid paths (LDS-resident radix sort up to 8192 points, the HBM-scratch radix sort above) against the
     oracle's restatement of pcl::VoxelGrid: small, large, skewed (thousands of points in one voxel), leaf too small
     (PCL returns the input) and leaf larger than the cloud (a single voxel)."""
     h = binding.Handle(params_a)
@@ -436,7 +437,7 @@ def test_device_voxel_grid_bit_exact(params_a, n, leaf, kind):
 
 
 def test_full_loop_reference_geometry_16x4000():
-    """Reference geometry 16 x 4000 (utility.h:50-55): global-memory union-find path, fe_pick<12>."""
+    """Reference geometry 16 x 4000 (utility.h:50-55): cc_lds16 with 63 cells per thread, fe_pick4<43>."""
     p = synth.default_params(16, 0)
     h, o = binding.Handle(p), O.Oracle(p)
     for k in range(8):
