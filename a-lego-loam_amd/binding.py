@@ -22,7 +22,7 @@ EXPORTS = [
     "alego_ip_process", "alego_lo_process", "alego_lm_process", "alego_scan_process",
     "alego_batch_load", "alego_batch_run", "alego_synchronize", "alego_batch_get_pose", "alego_batch_get_counts",
     "alego_stream", "alego_stream_groups", "alego_profile_enable", "alego_profile_report", "alego_set_lo_params", "alego_set_lm_params", "alego_debug_get", "alego_debug_voxel", "alego_debug_atan2f",
-    "alego_debug_math", "alego_debug_std_sort", "alego_debug_eval_blocks", "alego_debug_transform_to_start", "alego_debug_set_option",
+    "alego_lo_push_imu", "alego_debug_math", "alego_debug_std_sort", "alego_debug_eval_blocks", "alego_debug_transform_to_start", "alego_debug_set_option",
     "alego_lm_keyframe_count", "alego_lm_get_keyframe", "alego_lm_set_keypose", "alego_lm_reset_window", "alego_lm_apply_correction",
     "alego_lm_add_keyframe", "alego_pc2_to_points", "alego_replay_create", "alego_replay_load", "alego_replay_assign",
     "alego_dist_unique_id", "alego_dist_init", "alego_dist_shutdown", "alego_stream_setup", "alego_stream_run",
@@ -43,7 +43,7 @@ class SegOut(C.Structure):
                 ("ground", C.c_void_p), ("col", C.c_void_p), ("range", C.c_void_p),
                 ("ring_start", C.c_void_p), ("ring_end", C.c_void_p), ("orientation", C.c_float * 3),
                 ("outlier", C.c_void_p), ("outlier_cap", C.c_int32), ("n_outlier", C.c_int32),
-                ("label_image", C.c_void_p)]
+                ("label_image", C.c_void_p), ("stamp", C.c_double)]
 
 
 class FeatOut(C.Structure):
@@ -139,6 +139,8 @@ def lib():
         L.alego_debug_voxel.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_int]
         L.alego_debug_atan2f.restype = C.c_int
         L.alego_debug_atan2f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.alego_lo_push_imu.restype = C.c_int
+        L.alego_lo_push_imu.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int32]
         L.alego_debug_std_sort.restype = C.c_int
         L.alego_debug_std_sort.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.alego_debug_math.restype = C.c_int
@@ -229,7 +231,7 @@ def pc2_to_points(data: bytes, width, height, point_step, row_step, fields, is_b
     return out[:rc].copy()
 
 
-_CLOUDS = {"seg_cloud", "outlier", "sharp", "less_sharp", "flat", "less_flat"}
+_CLOUDS = {"seg_cloud", "undistorted", "outlier", "sharp", "less_sharp", "flat", "less_flat"}
 
 
 class Handle:
@@ -301,19 +303,21 @@ class Handle:
                     point_label=None if b["point_label"] is None else (b["point_label"][:m].copy() if m is not None else b["point_label"].copy()))
 
     @staticmethod
-    def _scan(pts):
+    def _scan(pts, stamp=0.0):
         a = np.ascontiguousarray(pts, dtype=np.float32)
         assert a.ndim == 2 and a.shape[1] == 4
         s = ScanIn()
-        s.pts, s.n, s.stamp = a.ctypes.data, a.shape[0], 0.0
+        s.pts, s.n, s.stamp = a.ctypes.data, a.shape[0], float(stamp)
         return s, a
 
     # ---- nodelet-shaped entry points ----
-    def ip_process(self, pts, want_labels=True):
-        sin, keep = self._scan(pts)
+    def ip_process(self, pts, want_labels=True, stamp=0.0):
+        sin, keep = self._scan(pts, stamp)
         s, b = self._seg_bufs(want_labels)
         self._check(lib().alego_ip_process(self._h, C.byref(sin), C.byref(s)), "alego_ip_process")
-        return self._seg_result(s, b)
+        r = self._seg_result(s, b)
+        r["stamp"] = s.stamp
+        return r
 
     def lo_process(self, seg):
         """seg: dict as returned by ip_process (what LO receives on /segmented_cloud + /seg_info)."""
@@ -325,6 +329,9 @@ class Handle:
         s.seg, s.seg_cap, s.m = arrs[0].ctypes.data, m, m
         s.ground, s.col, s.range = arrs[1].ctypes.data, arrs[2].ctypes.data, arrs[3].ctypes.data
         s.ring_start, s.ring_end = arrs[4].ctypes.data, arrs[5].ctypes.data
+        if "orientation" in seg:
+            s.orientation[:] = [float(v) for v in seg["orientation"]]
+        s.stamp = float(seg.get("stamp", 0.0))
         f, fb = self._feat_bufs()
         odom = Pose()
         flags = self._check(lib().alego_lo_process(self._h, C.byref(s), C.byref(f), C.byref(odom)), "alego_lo_process")
@@ -340,8 +347,8 @@ class Handle:
                                                     o.ctypes.data, o.shape[0], C.byref(po), C.byref(pm)), "alego_lm_process")
         return flags, pm.as_dict()
 
-    def scan_process(self, pts, stages=7, slot=0, want_outputs=False):
-        sin, keep = self._scan(pts)
+    def scan_process(self, pts, stages=7, slot=0, want_outputs=False, stamp=0.0):
+        sin, keep = self._scan(pts, stamp)
         odom, mp = Pose(), Pose()
         if want_outputs:
             s, b = self._seg_bufs(True)
@@ -446,6 +453,11 @@ class Handle:
         out = np.empty_like(a)
         self._check(lib().alego_debug_math(self._h, mode, a.ctypes.data, None if b is None else b.ctypes.data, out.ctypes.data, a.size), "alego_debug_math")
         return out
+
+    def push_imu(self, samples, slot=0):
+        """samples[n, 11]: stamp, orientation w x y z, linear_acceleration xyz, angular_velocity xyz (sensor_msgs/Imu)"""
+        a = np.ascontiguousarray(samples, np.float64).reshape(-1, 11)
+        self._check(lib().alego_lo_push_imu(self._h, slot, a.ctypes.data, a.shape[0]), "alego_lo_push_imu")
 
     def std_sort(self, keys, depth_limit=-1):
         """index order libstdc++'s std::sort gives 0..n-1 under `keys[a] < keys[b]`, as the device reproduces it (sort_mode 2)"""

@@ -24,6 +24,8 @@ void launch_fe(const DevCtx& d, hipStream_t st);
 void launch_lo(const DevCtx& d, hipStream_t st);
 void launch_atan2f_probe(const float* y, const float* x, float* out, int n, int mode, hipStream_t st);
 int launch_stdsort_probe(const uint32_t* keys, int n, int depth_limit, int* pos_out, hipStream_t st);
+void launch_lo_imu_push(const DevCtx& d, int slot, const double* smp_dev, int n, hipStream_t st);
+void launch_lo_deskew(const DevCtx& d, hipStream_t st);
 void launch_dbg_eval_blocks(int type, int n, const double* geom13, const double* params6, double* res, double* jac6, hipStream_t st);
 int icp_run(const alego_params& P, const alego_kf_in* latest, const alego_kf_in* history, int n_history, alego_icp_result* out,
             alego_point* target_out, int target_cap, hipStream_t st, std::string* err);
@@ -53,6 +55,7 @@ struct alego_handle {
   int lanes = 0;               // W: lanes per set (slots 1 .. W and W + 1 .. 2 W)
   int pose_slot = 0;           // slot holding the poses of the last processed scan of slot 0 (its lane)
   int last_lane = -1;          // lane of the previous scan (LaserOdometry's surf_last_ / corner_last_)
+  std::vector<double> imu_last_stamp;   // per slot: stamp of the newest IMU sample (alego_lo_push_imu wants them non-decreasing)
   int next_set = 0;            // lane set the next group of scans uses (the other one still holds the previous scan's features)
   hipStream_t s_lo = nullptr, s_lm = nullptr;
   std::vector<hipEvent_t> ev_pool;
@@ -146,6 +149,8 @@ int alego_create(const alego_params* params, int device, int n_slots, int ring_l
   if (ring_len <= 0) ring_len = 1;
   if (params->n_scan < 1 || params->n_scan > 64 || params->horizon_scan < 64 || params->horizon_scan > 4096) return ALEGO_ERR_ARG;
   if (params->sort_mode != 0 && params->sort_mode != 2) { std::fprintf(stderr, "alego_create: sort_mode %d is an oracle-only setting (0 = (curvature, index) order, 2 = libstdc++ std::sort tie order in the sector sort)\n", params->sort_mode); return ALEGO_ERR_ARG; }
+  if (params->deskew_mode != 0 && params->deskew_mode != 1) { std::fprintf(stderr, "alego_create: deskew_mode must be 0 or 1\n"); return ALEGO_ERR_ARG; }
+  if (params->deskew_mode && !(params->scan_period > 0)) { std::fprintf(stderr, "alego_create: scan_period must be positive\n"); return ALEGO_ERR_ARG; }
   if (params->recent_keyframe_num > 512) { std::fprintf(stderr, "alego_create: recent_keyframe_num > 512 is not supported\n"); return ALEGO_ERR_ARG; }
   // The feature pick marks up to suppress_radius neighbours on either side of a picked point; the segmented cloud only
   // guarantees the reference's 5-point margin at both ends of a ring (laserOdometry.cpp:124,211-234 index i +- 5 unchecked).
@@ -233,6 +238,8 @@ int alego_create(const alego_params* params, int device, int n_slots, int ring_l
   rc |= dalloc(h, &d.lo_box, B * 2 * 2 * d.lo_box_cap * 2);
   rc |= dalloc(h, &d.lo_state, B * LO_STATE_N);
   rc |= dalloc(h, &d.poses, B * 16);
+  rc |= dalloc(h, &d.imu_ring, B * ALEGO_IMU_Q * 10); rc |= dalloc(h, &d.imu_ptr, B * 4); rc |= dalloc(h, &d.scan_stamp, B);
+  rc |= dalloc(h, &d.seg_dsk, h->P.deskew_mode ? B * N : 1);
   {  // boundary tables of ip_project's fast path (kernels_ip.hip)
     const double rx = params->ang_res_x, ry = params->ang_res_y;
     std::vector<double> rt(2 * (NS + 6)), ct;
@@ -271,6 +278,11 @@ int alego_create(const alego_params* params, int device, int n_slots, int ring_l
     sc0[b * SC_COUNT + SC_CUR] = 1;  // the first scan writes feature buffer 0
     sc0[b * SC_COUNT + SC_FIRST] = 0x7fffffff; sc0[b * SC_COUNT + SC_LAST] = -1;   // accumulators of ip_project, re-armed by ip_image
   }
+  d.seg_lo = h->P.deskew_mode ? d.seg_dsk : d.seg_pts;
+  std::vector<int> ip0(B * 4, 0);
+  for (size_t b = 0; b < B; ++b) ip0[b * 4] = -1;   // imu_ptr_last_ = -1, imu_ptr_front_ = imu_ptr_last_iter_ = 0 (laserOdometry.cpp:17-19)
+  if (hipMemcpy(d.imu_ptr, ip0.data(), ip0.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) { std::fprintf(stderr, "alego_create: initial state upload failed\n"); alego_destroy(h); return ALEGO_ERR_HIP; }
+  h->imu_last_stamp.assign(B, -1e300);
   if (hipMemcpy(d.scal, sc0.data(), sc0.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess ||
       hipMemcpy(d.lo_state, st.data(), st.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
       hipMemcpy(d.poses, po.data(), po.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) {
@@ -432,6 +444,7 @@ static int enqueue_scan(alego_handle* h, int slot0, int n, int pos, int stages, 
   auto chk = [&](const char* what) { if (dbg) { hipError_t e = hipStreamSynchronize(S); fprintf(stderr, "[alego dbg] %s: %s\n", what, hipGetErrorString(e)); } };
   if (stages & 1) { launch_ip(d, pos, want_labels, S); chk("ip"); }
   if (stages & 2) {
+    if (d.P.deskew_mode) { launch_lo_deskew(d, S); chk("deskew"); }   // adjustDistortion(segmented_cloud, t1), laserOdometry.cpp:115
     launch_fe(d, S); chk("fe");
     launch_lo(d, S); chk("lo");
     std::vector<char> odom_valid(n);
@@ -446,6 +459,7 @@ int alego_batch_run(alego_handle* h, int first_pos, int n_scans, int stages, int
   if (!h) return ALEGO_ERR_ARG;
   hipSetDevice(h->device);
   const int R = h->d.ring_len;
+  if (h->P.deskew_mode && (stages & 2)) { h->err = "alego_batch_run: the motion de-skew needs every scan's stamp (alego_scan_process / alego_lo_process)"; return ALEGO_ERR_ARG; }
   if ((stages & ALEGO_REPLAY_BAG) && (!h->d.bag_pts || !h->replay_assigned)) { h->err = "alego_batch_run: ALEGO_REPLAY_BAG without alego_replay_create / alego_replay_assign"; return ALEGO_ERR_ARG; }
   for (int s = 0; s < n_scans; ++s) {
     int pos;
@@ -564,6 +578,7 @@ int alego_ip_process(alego_handle* h, const alego_scan_in* in, alego_seg_out* ou
   g_prof = &h->prof;
   launch_ip(d, 0, out->label_image != nullptr, h->stream);
   HIP_TRY(h, hipGetLastError());
+  out->stamp = in->stamp;   // /segmented_cloud and /seg_info carry the input's stamp (imageProjection.cpp:318-336)
   return download_seg(h, 0, out);
 }
 
@@ -581,6 +596,8 @@ int alego_lo_process(alego_handle* h, const alego_seg_out* in, alego_feat_out* f
   HIP_TRY(h, hipMemcpyAsync(d.ring_start, in->ring_start, d.NS * 4, hipMemcpyHostToDevice, h->stream));
   HIP_TRY(h, hipMemcpyAsync(d.ring_end, in->ring_end, d.NS * 4, hipMemcpyHostToDevice, h->stream));
   HIP_TRY(h, hipMemcpyAsync(d.scal + SC_M, &in->m, 4, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(d.ori, in->orientation, 12, hipMemcpyHostToDevice, h->stream));       // seg_info's start / end orientation: adjustDistortion reads them
+  HIP_TRY(h, hipMemcpyAsync(d.scan_stamp, &in->stamp, 8, hipMemcpyHostToDevice, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   if (int r = enqueue_scan(h, 0, 1, 0, 2, false)) return r;
   if (feat) { if (int r = download_feat(h, 0, feat)) return r; }
@@ -602,8 +619,10 @@ int alego_scan_process(alego_handle* h, int slot, const alego_scan_in* in, int s
   if (!in) return ALEGO_ERR_ARG;
   hipSetDevice(h->device);
   if (int r = alego_batch_load(h, slot, 0, in->pts, in->n)) return r;
+  HIP_TRY(h, hipMemcpyAsync(h->d.scan_stamp + slot, &in->stamp, 8, hipMemcpyHostToDevice, stream_of(h, slot)));
+  HIP_TRY(h, hipStreamSynchronize(stream_of(h, slot)));   // (`in` is the caller's)
   if (int r = enqueue_scan(h, slot, 1, 0, stages, seg && seg->label_image)) return r;
-  if (seg) { if (int r = download_seg(h, slot, seg)) return r; }
+  if (seg) { if (int r = download_seg(h, slot, seg)) return r; seg->stamp = in->stamp; }
   if (feat && (stages & 2)) { if (int r = download_feat(h, slot, feat)) return r; }
   return fetch_pose(h, slot, odom, map_pose);
 }
@@ -619,6 +638,60 @@ int alego_set_lm_params(alego_handle* h, int slot, const double* p6) {
   if (int r = check_slot(h, slot)) return r;
   hipSetDevice(h->device);
   return lm_host_set_params(h->lm, slot, p6, &h->err);
+}
+
+// imuHandler (laserOdometry.cpp:761-802): the per-sample trigonometry here, ring bookkeeping + dead reckoning on the device
+int alego_lo_push_imu(alego_handle* h, int slot, const alego_imu* smp, int32_t n) {
+  if (int r = check_slot(h, slot)) return r;
+  if (n < 0 || (n > 0 && !smp)) return ALEGO_ERR_ARG;
+  if (n == 0) return 0;
+  hipSetDevice(h->device);
+  std::vector<double> pre((size_t)n * 7);
+  double prev = h->imu_last_stamp[slot];
+  for (int i = 0; i < n; ++i) {
+    const alego_imu& m = smp[i];
+    if (!(m.stamp >= prev)) { h->err = "alego_lo_push_imu: IMU stamps must not decrease"; return ALEGO_ERR_ARG; }
+    prev = m.stamp;
+    const double qw = m.orientation[0], qx = m.orientation[1], qy = m.orientation[2], qz = m.orientation[3];
+    // tf::Matrix3x3(ori).getRPY(roll, pitch, yaw) (:765-767)  [upstream tf: setRotation + getEulerYPR, solution 1]
+    double roll, pitch, yaw;
+    {
+      const double dd = qx * qx + qy * qy + qz * qz + qw * qw, sc = 2.0 / dd;
+      const double xs = qx * sc, ys = qy * sc, zs = qz * sc;
+      const double wx = qw * xs, wy = qw * ys, wz = qw * zs, xx = qx * xs, xy = qx * ys, xz = qx * zs, yy = qy * ys, yz = qy * zs, zz = qz * zs;
+      const double m00 = 1.0 - (yy + zz), m10 = xy + wz, m20 = xz - wy, m21 = yz + wx, m22 = 1.0 - (xx + yy);
+      if (std::fabs(m20) >= 1) {
+        yaw = 0;
+        const double delta = std::atan2(m21, m22);
+        if (m20 < 0) { pitch = M_PI / 2.0; roll = delta; } else { pitch = -M_PI / 2.0; roll = delta; }
+      } else {
+        pitch = -std::asin(m20);
+        roll = std::atan2(m21 / std::cos(pitch), m22 / std::cos(pitch));
+        yaw = std::atan2(m10 / std::cos(pitch), m00 / std::cos(pitch));
+      }
+    }
+    const double acc_x = m.linear_acceleration[0] + 9.81 * std::sin(pitch);                      // :768-770
+    const double acc_y = m.linear_acceleration[1] - 9.81 * std::cos(pitch) * std::sin(roll);
+    const double acc_z = m.linear_acceleration[2] - 9.81 * std::cos(pitch) * std::cos(roll);
+    // Eigen::Quaternionf(w, x, y, z).toRotationMatrix() * Vector3f(acc) in f32 (:785-786)
+    const float w = (float)qw, x = (float)qx, y = (float)qy, z = (float)qz;
+    const float tx = 2 * x, ty = 2 * y, tz = 2 * z;
+    const float twx = tx * w, twy = ty * w, twz = tz * w, txx = tx * x, txy = ty * x, txz = tz * x, tyy = ty * y, tyz = tz * y, tzz = tz * z;
+    const float R[3][3] = {{1 - (tyy + tzz), txy - twz, txz + twy}, {txy + twz, 1 - (txx + tzz), tyz - twx}, {txz - twy, tyz + twx, 1 - (txx + tyy)}};
+    const float a[3] = {(float)acc_x, (float)acc_y, (float)acc_z};
+    double* o = &pre[(size_t)i * 7];
+    o[0] = m.stamp; o[1] = roll; o[2] = pitch; o[3] = yaw;
+    for (int k = 0; k < 3; ++k) o[4 + k] = (double)(R[k][0] * a[0] + (R[k][1] * a[1] + R[k][2] * a[2]));
+  }
+  DevTemps T;
+  double* dp;
+  HIP_TRY(h, T.get(&dp, pre.size() * 8));
+  hipStream_t S = stream_of(h, slot);
+  HIP_TRY(h, hipMemcpyAsync(dp, pre.data(), pre.size() * 8, hipMemcpyHostToDevice, S));
+  launch_lo_imu_push(h->d, slot, dp, n, S);
+  HIP_TRY(h, hipStreamSynchronize(S));
+  h->imu_last_stamp[slot] = prev;
+  return 0;
 }
 
 int alego_profile_enable(alego_handle* h, int on) {
@@ -861,6 +934,9 @@ int alego_debug_get(alego_handle* h, int slot, const char* name, void* out, int 
   else if (s == "parent") set(d.parent + base, d.N, 2);
   else if (s == "seg_cloud") set(d.seg_pts + base, (size_t)M * 4, 0);
   else if (s == "outlier") set(d.outlier + base, (size_t)sc[SC_NOUT] * 4, 0);
+  else if (s == "undistorted" && d.P.deskew_mode) set(d.seg_dsk + base, (size_t)M * 4, 0);
+  else if (s == "imu_ptr") set(d.imu_ptr + (size_t)slot * 4, 3, 2);
+  else if (s == "imu_ring") set(d.imu_ring + (size_t)slot * ALEGO_IMU_Q * 10, ALEGO_IMU_Q * 10, 1);
   else if (s == "seg_ground") set(d.seg_ground + base, M, 3);
   else if (s == "seg_col") set(d.seg_col + base, M, 2);
   else if (s == "seg_range") set(d.seg_range + base, M, 0);

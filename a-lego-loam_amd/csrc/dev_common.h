@@ -114,9 +114,16 @@ struct DevCtx {
   float4* lo_box;       // [slot][2 buffers][2 kinds][lo_box_cap][2]: min / max corner of every LO_CH consecutive targets
   int lo_box_cap;       //   (kind 0: less_flat, 1: less_sharp), written by fe_boxes next to the feature clouds
   double* lo_state;     // [slot][LO_STATE_N]
+  // ---- motion de-skew (adjustDistortion, laserOdometry.cpp:557-726; alego_params.deskew_mode) ----
+  double* imu_ring;     // [slot][ALEGO_IMU_Q][10]: time, roll, pitch, yaw, shift xyz, velo xyz (imu_time_ ... imu_velo_z_)
+  int* imu_ptr;         // [slot][4]: imu_ptr_last_, imu_ptr_front_, imu_ptr_last_iter_
+  double* scan_stamp;   // [slot] stamp of the segmented cloud being processed (t1, :111)
+  float4* seg_dsk;      // [slot][N] the LaserOdometry's own copy of the segmented cloud after adjustDistortion (/undistorted)
+  const float4* seg_lo; // what feature extraction reads: seg_dsk when deskew_mode != 0, else seg_pts
   // ---- outputs ----
   double* poses;        // [slot][16]: odom t(3) q(4), map t(3) q(4), pad
 };
+#define ALEGO_IMU_Q 200   // imu_queue_length, utility.h:70
 
 enum {
   LS_PARAMS = 0,        // params_[6]

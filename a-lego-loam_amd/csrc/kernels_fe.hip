@@ -484,7 +484,7 @@ __global__ void __launch_bounds__(FE_BLOCK) fe_voxel(DevCtx d) {
   const int n = cnts[3];
   const int* lfs = d.st_idx + ((size_t)slot * d.NS + ring) * d.st_stride + d.cap_sharp + d.cap_lsharp + d.cap_flat;
   float4* out = d.st_lfds + ((size_t)slot * d.NS + ring) * d.H;
-  const float4* seg = d.seg_pts + base;
+  const float4* seg = d.seg_lo + base;
   extern __shared__ __attribute__((aligned(16))) unsigned char fv_smem[];
   uint32_t* s_key = reinterpret_cast<uint32_t*>(fv_smem);                       // voxel id per point      [H]
   uint32_t* s_rvid = s_key;                                                     // voxel id per run, compacted in place (run r <= its first point)
@@ -696,7 +696,7 @@ __global__ void __launch_bounds__(FE_BLOCK) fe_gather(DevCtx d) {
   const int* st = d.st_idx + ((size_t)slot * d.NS + ring) * d.st_stride;
   const int* stk[3] = {st, st + d.cap_sharp, st + d.cap_sharp + d.cap_lsharp};
   const int* myc = allc + ring * 8;
-  const float4* seg = d.seg_pts + base;
+  const float4* seg = d.seg_lo + base;
   // A ring contributes at most a few hundred points per cloud: the first FE_BLOCK entries of the three index lists and
   // the first 2 FE_BLOCK less_flat points are loaded together (one latency for all the indices, one for all the points);
   // the loops behind only run for unusually large rings.

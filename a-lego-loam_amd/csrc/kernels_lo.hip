@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include "dev_cost.h"
+#include "lm_ctx.h"
 #include "prof.h"
 
 #define LO_BLOCK 256
@@ -508,6 +509,171 @@ void launch_dbg_transform_to_start(const double* params6, const float4* pts, int
 #define LO_SOLVE_LDS ((size_t)(28 * (LO_SOLVE_BLOCK / 4) + 28 * (LO_SOLVE_BLOCK / 128)) * sizeof(double))
 int lo_configure() {
   return hipFuncSetAttribute(reinterpret_cast<const void*>(lo_solve), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LO_SOLVE_LDS) == hipSuccess ? 0 : -1;
+}
+
+// ---- IMU ring + motion de-skew (laserOdometry.cpp:557-726,761-802; dead in the reference: the call at :115 is commented out) ----
+// imuHandler's ring bookkeeping and dead-reckoning for n samples of one slot; the per-sample trigonometry (tf getRPY, gravity
+// removal, the f32 rotation of the acceleration) is done by the host in alego_lo_push_imu: smp[i] = time, roll, pitch, yaw, acc xyz.
+__global__ void lo_imu_push(DevCtx d, int slot, const double* smp, int n) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  int* ptr = d.imu_ptr + (size_t)slot * 4;
+  double* ring = d.imu_ring + (size_t)slot * ALEGO_IMU_Q * 10;
+  int last = ptr[0], front = ptr[1];
+  for (int i = 0; i < n; ++i) {
+    const double* s = smp + 7 * i;
+    last = (last + 1) % ALEGO_IMU_Q;                                                  // :773-777
+    if ((last + 1) % ALEGO_IMU_Q == front) front = (front + 1) % ALEGO_IMU_Q;
+    double* r = ring + last * 10;
+    r[0] = s[0]; r[1] = s[1]; r[2] = s[2]; r[3] = s[3];
+    const double* b = ring + ((last - 1 + ALEGO_IMU_Q) % ALEGO_IMU_Q) * 10;
+    const double td = r[0] - b[0];
+    if (td < 1.) {                                                                    // :793-802
+      for (int k = 0; k < 3; ++k) {
+        r[4 + k] = b[4 + k] + b[7 + k] * td + s[4 + k] * td * td * 0.5;
+        r[7 + k] = b[7 + k] + s[4 + k] * td;
+      }
+    }
+  }
+  ptr[0] = last; ptr[1] = front;
+}
+
+DEV_INLINE void dsk_mul3(const float m[3][3], const float v[3], float o[3]) {   // Eigen's unrolled 3-term reduction: a0 + (a1 + a2)
+#pragma unroll
+  for (int i = 0; i < 3; ++i) o[i] = m[i][0] * v[0] + (m[i][1] * v[1] + m[i][2] * v[2]);
+}
+
+// adjustDistortion, IMU branch, one workgroup per slot.  The reference walks the points in order with a forward-only cursor into
+// the IMU ring (imu_ptr_front_ starts at imu_ptr_last_iter_ and only advances while cur_time >= imu_time_[front]); with
+// non-decreasing IMU stamps (alego_lo_push_imu enforces them) point i's cursor is the running maximum over points 0..i of each
+// point's own first ring step with cur_time < imu_time_: a binary search per point + a max-scan in point order.  The first point
+// whose cursor entry is more than scan_period away aborts the function (:604-608): it and everything after it stay as they are.
+#define DSK_T 256
+__global__ void __launch_bounds__(DSK_T) lo_deskew(DevCtx d) {
+  const int slot = blockIdx.x + d.slot0, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const size_t base = (size_t)slot * d.N;
+  const int M = d.scal[(size_t)slot * SC_COUNT + SC_M];
+  const float4* in = d.seg_pts + base;
+  float4* out = d.seg_dsk + base;
+  int* ptr = d.imu_ptr + (size_t)slot * 4;
+  const double* ring = d.imu_ring + (size_t)slot * ALEGO_IMU_Q * 10;
+  const int last = ptr[0], it0 = ptr[2];
+  if (!(last > 0)) {                                                                  // :593
+    for (int i = tid; i < M; i += DSK_T) out[i] = in[i];
+    return;
+  }
+  __shared__ double s_time[ALEGO_IMU_Q];
+  __shared__ int s_wmax[DSK_T / 64], s_abort, s_front_a, s_iter_a;
+  __shared__ float s_start[15];   // shift_start, velo_start, r_s_i
+  for (int j = tid; j < ALEGO_IMU_Q; j += DSK_T) s_time[j] = ring[j * 10];
+  if (tid == 0) { s_abort = 0x7fffffff; s_front_a = -1; s_iter_a = -1; }
+  const int H = d.H;
+  const float so = d.ori[(size_t)slot * 4], eo = d.ori[(size_t)slot * 4 + 1];
+  int start_ori = (int)(((double)so + 2 * M_PI) / H), end_ori = (int)(((double)eo + 2 * M_PI) / H);   // :562-563 (sic)
+  if (start_ori >= H) start_ori -= H;
+  if (end_ori >= H) end_ori -= H;
+  int ori_diff = end_ori - start_ori;
+  if (ori_diff <= 0) ori_diff = H;
+  const double scan_time = d.scan_stamp[slot], period = d.P.scan_period;
+  const int span = (last - it0 + ALEGO_IMU_Q) % ALEGO_IMU_Q;
+  __syncthreads();
+  int carry = 0;   // cursor (ring steps from it0) after the points before this chunk
+  for (int c0 = 0; c0 < M; c0 += DSK_T) {
+    const int i = c0 + tid;
+    const bool valid = i < M;
+    const int col = valid ? d.seg_col[base + i] : 0;
+    const double rel_time = (col - start_ori) * period / ori_diff;                    // :588
+    const double cur_time = scan_time + rel_time;
+    int k = 0;
+    if (valid) {   // first step k in [0, span) with cur_time < imu_time_[(it0 + k) % Q], else span (the cursor stops at imu_ptr_last_)
+      int lo = 0, hi = span;
+      while (lo < hi) { const int mid = (lo + hi) >> 1; if (cur_time < s_time[(it0 + mid) % ALEGO_IMU_Q]) hi = mid; else lo = mid + 1; }
+      k = lo;
+    }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(k, o, 64); if (lane >= o) k = max(k, t); }
+    if (lane == 63) s_wmax[wave] = k;
+    __syncthreads();
+    int before = carry, total = carry;
+#pragma unroll
+    for (int w = 0; w < DSK_T / 64; ++w) { const int v = s_wmax[w]; if (w < wave) before = max(before, v); total = max(total, v); }
+    k = max(k, before);
+    const int front = (it0 + k) % ALEGO_IMU_Q;
+    const bool viol = valid && fabs(cur_time - s_time[front]) > period;               // :604
+    const unsigned long long vm = __ballot(viol);
+    if (vm && lane == 0) atomicMin(&s_abort, c0 + wave * 64 + (__ffsll((long long)vm) - 1));
+    __syncthreads();
+    const int a = s_abort;
+    const bool process = valid && i < a;
+    float rpy[3] = {0, 0, 0}, sh[3] = {0, 0, 0}, ve[3] = {0, 0, 0}, rc[3][3];
+    if (process) {
+      const double* R = ring + front * 10;
+      if (cur_time > s_time[front]) {                                                 // :610-621
+        rpy[0] = (float)R[1]; rpy[1] = (float)R[2]; rpy[2] = (float)R[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) { sh[q] = (float)R[4 + q]; ve[q] = (float)R[7 + q]; }
+      } else {                                                                        // :622-637
+        const double* B = ring + ((front - 1 + ALEGO_IMU_Q) % ALEGO_IMU_Q) * 10;
+        const double rf = (cur_time - B[0]) / (R[0] - B[0]), rb = 1. - rf;
+        rpy[0] = (float)(R[1] * rf + B[1] * rb); rpy[1] = (float)(R[2] * rf + B[2] * rb); rpy[2] = (float)(R[3] * rf + B[3] * rb);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) { sh[q] = (float)(R[4 + q] * rf + B[4 + q] * rb); ve[q] = (float)(R[7 + q] * rf + B[7 + q] * rb); }
+      }
+      const float kp[6] = {0.f, 0.f, 0.f, rpy[0], rpy[1], rpy[2]};
+      float m[3][4];
+      keypose_matrix(kp, m);                                                          // :639: (AngleAxisf(yaw, Z) * AngleAxisf(pitch, Y) * AngleAxisf(roll, X)).toRotationMatrix()
+#pragma unroll
+      for (int r = 0; r < 3; ++r) { rc[r][0] = m[r][0]; rc[r][1] = m[r][1]; rc[r][2] = m[r][2]; }
+      if (i == 0) {                                                                   // :641-647; r_c.inverse(): cofactors / determinant (Eigen Inverse.h, size 3)
+        auto cof = [&](int r, int c) { return rc[(r + 1) % 3][(c + 1) % 3] * rc[(r + 2) % 3][(c + 2) % 3] - rc[(r + 1) % 3][(c + 2) % 3] * rc[(r + 2) % 3][(c + 1) % 3]; };
+        const float c0v[3] = {cof(0, 0), cof(1, 0), cof(2, 0)};
+        const float det = c0v[0] * rc[0][0] + (c0v[1] * rc[1][0] + c0v[2] * rc[2][0]);
+        const float invdet = 1.0f / det;
+        s_start[0] = sh[0]; s_start[1] = sh[1]; s_start[2] = sh[2]; s_start[3] = ve[0]; s_start[4] = ve[1]; s_start[5] = ve[2];
+        s_start[6] = c0v[0] * invdet; s_start[7] = c0v[1] * invdet; s_start[8] = c0v[2] * invdet;
+        s_start[9] = cof(0, 1) * invdet; s_start[10] = cof(1, 1) * invdet; s_start[11] = cof(2, 1) * invdet;
+        s_start[12] = cof(0, 2) * invdet; s_start[13] = cof(1, 2) * invdet; s_start[14] = cof(2, 2) * invdet;
+      }
+    }
+    if (valid && i == a) s_front_a = front;                   // the cursor had already moved for the point that aborts (:595-603)
+    if (valid && i == a - 1) s_iter_a = front;                // imu_ptr_last_iter_ of the last point that completed (:653)
+    __syncthreads();
+    if (valid) {
+      float4 p = in[i];
+      if (process && i > 0) {                                                         // :648-654
+        const float rt = (float)rel_time;
+        float rsi[3][3], sfs[3], v[3], w[3], o[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) { rsi[r][0] = s_start[6 + 3 * r]; rsi[r][1] = s_start[7 + 3 * r]; rsi[r][2] = s_start[8 + 3 * r]; }
+#pragma unroll
+        for (int q = 0; q < 3; ++q) sfs[q] = (sh[q] - s_start[q]) - s_start[3 + q] * rt;
+        const float pv[3] = {p.x, p.y, p.z};
+        dsk_mul3(rc, pv, v);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) w[q] = v[q] + sfs[q];
+        dsk_mul3(rsi, w, o);
+        p.x = o[0]; p.y = o[1]; p.z = o[2];
+      }
+      out[i] = p;
+    }
+    if (a != 0x7fffffff) {   // aborted inside this chunk: the rest of the cloud stays as it is
+      for (int j = c0 + DSK_T + tid; j < M; j += DSK_T) out[j] = in[j];
+      if (tid == 0) {
+        ptr[1] = s_front_a;
+        ptr[2] = s_iter_a >= 0 ? s_iter_a : (a == 0 ? it0 : (it0 + carry) % ALEGO_IMU_Q);
+      }
+      return;
+    }
+    carry = total;
+    __syncthreads();
+  }
+  if (tid == 0 && M > 0) { ptr[1] = (it0 + carry) % ALEGO_IMU_Q; ptr[2] = (it0 + carry) % ALEGO_IMU_Q; }
+}
+
+void launch_lo_imu_push(const DevCtx& d, int slot, const double* smp_dev, int n, hipStream_t st) {
+  hipLaunchKernelGGL(lo_imu_push, dim3(1), dim3(1), 0, st, d, slot, smp_dev, n);
+}
+void launch_lo_deskew(const DevCtx& d, hipStream_t st) {
+  ALEGO_LAUNCH(lo_deskew, dim3(d.n_launch), dim3(DSK_T), 0, st, d);
 }
 
 void launch_lo(const DevCtx& d, hipStream_t st) {

@@ -25,6 +25,7 @@ class AlegoParams(C.Structure):
         ("lc_search_radius", _D), ("lc_search_num", _I), ("lc_fitness_max", _D), ("lc_leaf", _F), ("lc_min_time_gap", _D),
         ("icp_max_corr_dist", _D), ("icp_max_iters", _I), ("icp_trans_eps", _D), ("icp_fitness_eps", _D),
         ("input_is_dense", _I),
+        ("deskew_mode", _I), ("scan_period", _D),
     ]
 
     def copy(self):

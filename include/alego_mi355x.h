@@ -74,6 +74,7 @@ typedef struct alego_seg_out {
   float orientation[3];  /* startOrientation, endOrientation, orientationDiff */
   alego_point* outlier;  int32_t outlier_cap;  int32_t n_outlier;
   int32_t* label_image;  /* optional (may be NULL): label_mat_ [n_scan][horizon_scan] */
+  double stamp;          /* header stamp of /segmented_cloud + /seg_info = the input scan's (t1 of laserOdometry.cpp:111; read by the de-skew) */
 } alego_seg_out;
 
 /* /corner, /corner_less, /surf, /surf_less (laserOdometry.cpp:299-314); the
@@ -165,6 +166,19 @@ int alego_stream_groups(const alego_handle* h, int* slots_per_group);
 int alego_profile_enable(alego_handle* h, int on);
 /* names: ';'-separated kernel names; total_ms / launches per kernel.  Returns the kernel count. */
 int alego_profile_report(alego_handle* h, char* names, int names_cap, double* total_ms, int* launches, int cap);
+
+/* ---- motion de-skew (LaserOdometry::adjustDistortion, laserOdometry.cpp:557-726; alego_params.deskew_mode = 1) --------------
+ * sensor_msgs/Imu as LaserOdometry::imuHandler (:761-802) receives it.  The handler's ring of 200 dead-reckoned samples lives on
+ * the device; with deskew_mode = 1 every scan's segmented cloud is de-skewed against it before feature extraction (the call the
+ * reference has commented out at :115), by alego_lo_process / alego_scan_process (the stamps come from alego_seg_out.stamp /
+ * alego_scan_in.stamp).  Stamps must not decrease. */
+typedef struct alego_imu {
+  double stamp;
+  double orientation[4];          /* w, x, y, z */
+  double linear_acceleration[3];
+  double angular_velocity[3];     /* carried by the message, unused by the reference (:787-789) */
+} alego_imu;
+int alego_lo_push_imu(alego_handle* h, int slot, const alego_imu* samples, int32_t n);
 
 /* ---- state access for parity tests (teacher forcing) ---------------------- */
 int alego_set_lo_params(alego_handle* h, int slot, const double* p6);

@@ -103,6 +103,11 @@ typedef struct alego_params {
                                 drops non-finite points (imageProjection.cpp:58-59).  1: PCL copies the cloud unfiltered;
                                 non-finite points then still count as first / last point of the orientation block (:62-63,
                                 giving NaN orientations) and are rejected by the row test (:81-85; int(NaN) is INT_MIN on x86-64) */
+  /* ---- motion de-skew: LaserOdometry::adjustDistortion, laserOdometry.cpp:557-726 (its call at :115 is commented out in the
+   *      reference, so 0 is the reference as shipped) ---- */
+  int32_t deskew_mode;       /* 0 = off; 1 = adjustDistortion with the IMU branch (use_imu = true, utility.h:68) on the samples given to
+                                alego_lo_push_imu, before feature extraction */
+  double scan_period;        /* 0.2 s           utility.h:53 */
 } alego_params;
 
 /* Fill `p` with the reference defaults for an n_scan x horizon_scan sensor.
@@ -155,6 +160,8 @@ static inline void alego_default_params(alego_params* p, int n_scan, int horizon
   p->suppress_col_diff = 10;
   p->less_flat_leaf = 0.4f;
   p->sort_mode = 0;
+  p->deskew_mode = 0;
+  p->scan_period = 0.2;
   p->nearest_feature_dist = 25.0;
   p->ring_window = 2;
   p->huber_delta = 0.1;

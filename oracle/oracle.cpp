@@ -760,6 +760,154 @@ struct LaserOdometry {
   int n_surf_corr = 0, n_corner_corr = 0;
   double t_fe_ms = 0, t_assoc_ms = 0, t_solve_ms = 0;
 
+  // ---- IMU ring + motion de-skew (laserOdometry.cpp:17-29,557-726,761-802; the call at :115 is commented out in the reference:
+  //      deskew_mode = 0 is the reference as shipped) ----
+  static const int IMU_Q = 200;   // imu_queue_length, utility.h:70
+  int imu_ptr_front = 0, imu_ptr_last = -1, imu_ptr_last_iter = 0;
+  double imu_time[IMU_Q], imu_roll[IMU_Q], imu_pitch[IMU_Q], imu_yaw[IMU_Q], imu_shift[3][IMU_Q], imu_velo[3][IMU_Q];
+  double scan_time = 0;            // t1: stamp of the segmented cloud (:111-115)
+  std::vector<Pt> undistorted;     // the LO's copy of the segmented cloud after adjustDistortion (/undistorted, :719-726)
+  bool deskew_aborted = false;
+
+  // imuHandler :761-802.  sample = stamp, orientation (w x y z), linear_acceleration, angular_velocity (unused: :787-789)
+  void imu_handler(const double* smp) {
+    const double stamp = smp[0], qw = smp[1], qx = smp[2], qy = smp[3], qz = smp[4];
+    // tf::Matrix3x3(ori).getRPY(roll, pitch, yaw)  [upstream tf: setRotation + getEulerYPR, solution 1]
+    double roll, pitch, yaw;
+    {
+      const double d = qx * qx + qy * qy + qz * qz + qw * qw, sc = 2.0 / d;
+      const double xs = qx * sc, ys = qy * sc, zs = qz * sc;
+      const double wx = qw * xs, wy = qw * ys, wz = qw * zs, xx = qx * xs, xy = qx * ys, xz = qx * zs, yy = qy * ys, yz = qy * zs, zz = qz * zs;
+      const double m00 = 1.0 - (yy + zz), m10 = xy + wz, m20 = xz - wy, m21 = yz + wx, m22 = 1.0 - (xx + yy), m01 = xy - wz, m02 = xz + wy;
+      if (std::fabs(m20) >= 1) {
+        yaw = 0;
+        const double delta = std::atan2(m21, m22);
+        if (m20 < 0) { pitch = M_PI / 2.0; roll = delta; } else { pitch = -M_PI / 2.0; roll = delta; }
+        (void)m01; (void)m02;
+      } else {
+        pitch = -std::asin(m20);
+        roll = std::atan2(m21 / std::cos(pitch), m22 / std::cos(pitch));
+        yaw = std::atan2(m10 / std::cos(pitch), m00 / std::cos(pitch));
+      }
+    }
+    const double acc_x = smp[5] + 9.81 * std::sin(pitch);
+    const double acc_y = smp[6] - 9.81 * std::cos(pitch) * std::sin(roll);
+    const double acc_z = smp[7] - 9.81 * std::cos(pitch) * std::cos(roll);
+    imu_ptr_last = (imu_ptr_last + 1) % IMU_Q;
+    if ((imu_ptr_last + 1) % IMU_Q == imu_ptr_front) imu_ptr_front = (imu_ptr_front + 1) % IMU_Q;
+    imu_time[imu_ptr_last] = stamp; imu_roll[imu_ptr_last] = roll; imu_pitch[imu_ptr_last] = pitch; imu_yaw[imu_ptr_last] = yaw;
+    // Eigen::Quaternionf(w, x, y, z).toRotationMatrix() * Vector3f(acc): f32 (:785-786)
+    const float w = (float)qw, x = (float)qx, y = (float)qy, z = (float)qz;
+    const float tx = 2 * x, ty = 2 * y, tz = 2 * z;
+    const float twx = tx * w, twy = ty * w, twz = tz * w, txx = tx * x, txy = ty * x, txz = tz * x, tyy = ty * y, tyz = tz * y, tzz = tz * z;
+    const float R[3][3] = {{1 - (tyy + tzz), txy - twz, txz + twy}, {txy + twz, 1 - (txx + tzz), tyz - twx}, {txz - twy, tyz + twx, 1 - (txx + tyy)}};
+    const float a[3] = {(float)acc_x, (float)acc_y, (float)acc_z};
+    float acc[3];
+    for (int i = 0; i < 3; ++i) acc[i] = R[i][0] * a[0] + (R[i][1] * a[1] + R[i][2] * a[2]);   // Eigen's unrolled 3-term reduction: a0 + (a1 + a2)
+    const int back = (imu_ptr_last - 1 + IMU_Q) % IMU_Q;
+    const double time_diff = imu_time[imu_ptr_last] - imu_time[back];
+    if (time_diff < 1.) {
+      for (int k = 0; k < 3; ++k) {
+        imu_shift[k][imu_ptr_last] = imu_shift[k][back] + imu_velo[k][back] * time_diff + acc[k] * time_diff * time_diff * 0.5;
+        imu_velo[k][imu_ptr_last] = imu_velo[k][back] + acc[k] * time_diff;
+      }
+    }
+  }
+
+  static void rpy_matrix(const float rpy[3], float m[3][3]) {   // (AngleAxisf(yaw, Z) * AngleAxisf(pitch, Y) * AngleAxisf(roll, X)).toRotationMatrix()
+    auto qaxis = [](float angle, int axis, float q[4]) {
+      float ha = 0.5f * angle, sn = omath::o_sinf(ha);
+      q[0] = omath::o_cosf(ha); q[1] = q[2] = q[3] = 0.f; q[1 + axis] = sn;
+    };
+    auto qmul = [](const float a[4], const float b[4], float o[4]) {
+      o[0] = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
+      o[1] = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];
+      o[2] = a[0] * b[2] + a[2] * b[0] + a[3] * b[1] - a[1] * b[3];
+      o[3] = a[0] * b[3] + a[3] * b[0] + a[1] * b[2] - a[2] * b[1];
+    };
+    float qz[4], qy[4], qx[4], qzy[4], q[4];
+    qaxis(rpy[2], 2, qz); qaxis(rpy[1], 1, qy); qaxis(rpy[0], 0, qx);
+    qmul(qz, qy, qzy); qmul(qzy, qx, q);
+    const float w = q[0], x = q[1], y = q[2], z = q[3];
+    const float tx = 2 * x, ty = 2 * y, tz = 2 * z;
+    const float twx = tx * w, twy = ty * w, twz = tz * w, txx = tx * x, txy = ty * x, txz = tz * x, tyy = ty * y, tyz = tz * y, tzz = tz * z;
+    m[0][0] = 1 - (tyy + tzz); m[0][1] = txy - twz; m[0][2] = txz + twy;
+    m[1][0] = txy + twz; m[1][1] = 1 - (txx + tzz); m[1][2] = tyz - twx;
+    m[2][0] = txz - twy; m[2][1] = tyz + twx; m[2][2] = 1 - (txx + tyy);
+  }
+  static void inverse3(const float m[3][3], float r[3][3]) {   // Eigen Matrix3f::inverse(): cofactors / determinant (Inverse.h, size 3)
+    auto cof = [&](int i, int j) { return m[(i + 1) % 3][(j + 1) % 3] * m[(i + 2) % 3][(j + 2) % 3] - m[(i + 1) % 3][(j + 2) % 3] * m[(i + 2) % 3][(j + 1) % 3]; };
+    const float c0[3] = {cof(0, 0), cof(1, 0), cof(2, 0)};
+    const float det = c0[0] * m[0][0] + (c0[1] * m[1][0] + c0[2] * m[2][0]);
+    const float invdet = 1.0f / det;
+    for (int j = 0; j < 3; ++j) r[0][j] = c0[j] * invdet;
+    r[1][0] = cof(0, 1) * invdet; r[1][1] = cof(1, 1) * invdet; r[1][2] = cof(2, 1) * invdet;
+    r[2][0] = cof(0, 2) * invdet; r[2][1] = cof(1, 2) * invdet; r[2][2] = cof(2, 2) * invdet;
+  }
+  static void mul3(const float m[3][3], const float v[3], float o[3]) {
+    for (int i = 0; i < 3; ++i) o[i] = m[i][0] * v[0] + (m[i][1] * v[1] + m[i][2] * v[2]);
+  }
+
+  // adjustDistortion :557-726, IMU branch (use_imu = true, utility.h:68)
+  void adjust_distortion(std::vector<Pt>& cloud, const ImageProjection& ip) {
+    deskew_aborted = false;
+    const int H = P.horizon_scan;
+    const int cloud_size = (int)cloud.size();
+    int start_ori = (int)((ip.ori[0] + 2 * M_PI) / H);   // :562-563 (sic: an angle in radians divided by Horizon_SCAN)
+    int end_ori = (int)((ip.ori[1] + 2 * M_PI) / H);
+    if (start_ori >= H) start_ori -= H;
+    if (end_ori >= H) end_ori -= H;
+    int ori_diff = end_ori - start_ori;
+    if (ori_diff <= 0) ori_diff = H;
+    float rpy_start[3] = {0, 0, 0}, shift_start[3] = {0, 0, 0}, velo_start[3] = {0, 0, 0}, rpy_cur[3], shift_cur[3], velo_cur[3];
+    float r_s_i[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}}, r_c[3][3];
+    (void)rpy_start;
+    for (int i = 0; i < cloud_size; ++i) {
+      Pt& p = cloud[i];
+      const double rel_time = (ip.seg_col[i] - start_ori) * P.scan_period / ori_diff;
+      const double cur_time = scan_time + rel_time;
+      if (imu_ptr_last > 0) {
+        imu_ptr_front = imu_ptr_last_iter;
+        while (imu_ptr_front != imu_ptr_last) {
+          if (cur_time < imu_time[imu_ptr_front]) break;
+          imu_ptr_front = (imu_ptr_front + 1) % IMU_Q;
+        }
+        if (std::abs(cur_time - imu_time[imu_ptr_front]) > P.scan_period) { deskew_aborted = true; return; }   // :604-608
+        const int fr = imu_ptr_front;
+        if (cur_time > imu_time[fr]) {
+          rpy_cur[0] = (float)imu_roll[fr]; rpy_cur[1] = (float)imu_pitch[fr]; rpy_cur[2] = (float)imu_yaw[fr];
+          for (int k = 0; k < 3; ++k) { shift_cur[k] = (float)imu_shift[k][fr]; velo_cur[k] = (float)imu_velo[k][fr]; }
+        } else {
+          const int bk = (fr - 1 + IMU_Q) % IMU_Q;
+          const double ratio_front = (cur_time - imu_time[bk]) / (imu_time[fr] - imu_time[bk]);
+          const double ratio_back = 1. - ratio_front;
+          rpy_cur[0] = (float)(imu_roll[fr] * ratio_front + imu_roll[bk] * ratio_back);
+          rpy_cur[1] = (float)(imu_pitch[fr] * ratio_front + imu_pitch[bk] * ratio_back);
+          rpy_cur[2] = (float)(imu_yaw[fr] * ratio_front + imu_yaw[bk] * ratio_back);
+          for (int k = 0; k < 3; ++k) {
+            shift_cur[k] = (float)(imu_shift[k][fr] * ratio_front + imu_shift[k][bk] * ratio_back);
+            velo_cur[k] = (float)(imu_velo[k][fr] * ratio_front + imu_velo[k][bk] * ratio_back);
+          }
+        }
+        rpy_matrix(rpy_cur, r_c);
+        if (i == 0) {
+          for (int k = 0; k < 3; ++k) { rpy_start[k] = rpy_cur[k]; shift_start[k] = shift_cur[k]; velo_start[k] = velo_cur[k]; }
+          inverse3(r_c, r_s_i);
+        } else {
+          const float rt = (float)rel_time;   // Vector3f * double: the scalar is converted to the vector's scalar type
+          float sfs[3], v[3], w[3], o[3];
+          for (int k = 0; k < 3; ++k) sfs[k] = (shift_cur[k] - shift_start[k]) - velo_start[k] * rt;
+          const float pv[3] = {p.x, p.y, p.z};
+          mul3(r_c, pv, v);
+          for (int k = 0; k < 3; ++k) w[k] = v[k] + sfs[k];
+          mul3(r_s_i, w, o);
+          p.x = o[0]; p.y = o[1]; p.z = o[2];
+        }
+        imu_ptr_last_iter = imu_ptr_front;
+      }
+    }
+  }
+
   void init(const Params& p) {
     P = p; N = P.n_scan * P.horizon_scan;
     curvature.assign(N, 0); picked.assign(N, 0); label.assign(N, 0); sort_idx.assign(N, 0);
@@ -768,6 +916,11 @@ struct LaserOdometry {
     t_w[0] = t_w[1] = t_w[2] = 0;
     for (int i = 0; i < 9; ++i) r_w[i] = (i % 4 == 0) ? 1 : 0;
     surf_last.clear(); corner_last.clear();
+    imu_ptr_front = 0; imu_ptr_last = -1; imu_ptr_last_iter = 0;   // :17-29
+    for (int i = 0; i < IMU_Q; ++i) {
+      imu_time[i] = imu_roll[i] = imu_pitch[i] = imu_yaw[i] = 0;
+      for (int k = 0; k < 3; ++k) imu_shift[k][i] = imu_velo[k][i] = 0;
+    }
   }
 
   // transformToStart, laserOdometry.cpp:728-740
@@ -783,7 +936,8 @@ struct LaserOdometry {
   }
 
   void extract_features(const ImageProjection& ip) {
-    const std::vector<Pt>& seg = ip.seg_cloud;
+    if (P.deskew_mode == 1) { undistorted = ip.seg_cloud; adjust_distortion(undistorted, ip); }   // :115 (commented out in the reference)
+    const std::vector<Pt>& seg = P.deskew_mode == 1 ? undistorted : ip.seg_cloud;
     const int cloud_size = (int)seg.size();
     const float* rng = ip.seg_range.data();
     const int* colv = ip.seg_col.data();
@@ -1340,6 +1494,14 @@ int oracle_lo(void* h) {
   return ok ? 1 : 0;
 }
 
+// sensor_msgs/Imu samples for the LO's IMU ring (imuHandler :761-802): smp[i] = stamp, orientation w x y z, linear_acceleration xyz,
+// angular_velocity xyz (11 doubles); oracle_set_scan_time = the stamp of the next segmented cloud (t1, :111)
+void oracle_push_imu(void* h, const double* smp, int n) {
+  Ctx* c = (Ctx*)h;
+  for (int i = 0; i < n; ++i) c->lo.imu_handler(smp + 11 * i);
+}
+void oracle_set_scan_time(void* h, double t) { ((Ctx*)h)->lo.scan_time = t; }
+
 // feature extraction only (a7-a10), no odometry state change (config 1)
 int oracle_fe(void* h) {
   Ctx* c = (Ctx*)h;
@@ -1501,6 +1663,21 @@ int oracle_get(void* h, const char* name, const void** ptr, int* count, int* dty
   if (s == "label_img") { *dtype = ORACLE_I32; return ret(ip.out_label_img, ptr, count); }
   if (s == "ground_img") { *dtype = ORACLE_U8; return ret(ip.out_ground_img, ptr, count); }
   if (s == "seg_cloud") return cloud(ip.seg_cloud);
+  if (s == "undistorted") return cloud(lo.undistorted);
+  if (s == "imu_ptr") {
+    static thread_local int iptr[3];
+    iptr[0] = lo.imu_ptr_last; iptr[1] = lo.imu_ptr_front; iptr[2] = lo.imu_ptr_last_iter;
+    *dtype = ORACLE_I32; *ptr = iptr; *count = 3; return 0;
+  }
+  if (s == "imu_ring") {   // [200][10]: time, roll, pitch, yaw, shift xyz, velo xyz
+    static thread_local double ring[LaserOdometry::IMU_Q * 10];
+    for (int i = 0; i < LaserOdometry::IMU_Q; ++i) {
+      double* r = ring + i * 10;
+      r[0] = lo.imu_time[i]; r[1] = lo.imu_roll[i]; r[2] = lo.imu_pitch[i]; r[3] = lo.imu_yaw[i];
+      for (int k = 0; k < 3; ++k) { r[4 + k] = lo.imu_shift[k][i]; r[7 + k] = lo.imu_velo[k][i]; }
+    }
+    *dtype = ORACLE_F64; *ptr = ring; *count = LaserOdometry::IMU_Q * 10; return 0;
+  }
   if (s == "outlier") return cloud(ip.outlier_cloud);
   if (s == "seg_ground") { *dtype = ORACLE_U8; *ptr = ip.seg_ground.data(); *count = M; return 0; }
   if (s == "seg_col") { *dtype = ORACLE_I32; *ptr = ip.seg_col.data(); *count = M; return 0; }

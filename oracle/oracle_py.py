@@ -33,6 +33,10 @@ def lib():
         L.oracle_set_lm_params.argtypes = [C.c_void_p, C.c_void_p]
         L.oracle_get.restype = C.c_int
         L.oracle_get.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.oracle_push_imu.restype = None
+        L.oracle_push_imu.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.oracle_set_scan_time.restype = None
+        L.oracle_set_scan_time.argtypes = [C.c_void_p, C.c_double]
         L.oracle_std_sort_order.restype = None
         L.oracle_std_sort_order.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.oracle_voxel_grid.restype = C.c_int
@@ -91,6 +95,15 @@ class Oracle:
 
     def fe(self):
         return lib().oracle_fe(self._h)
+
+    def push_imu(self, samples):
+        """samples[n, 11]: stamp, orientation w x y z, linear_acceleration xyz, angular_velocity xyz (imuHandler)"""
+        a = np.ascontiguousarray(samples, np.float64).reshape(-1, 11)
+        lib().oracle_push_imu(self._h, a.ctypes.data, a.shape[0])
+
+    def set_scan_time(self, t):
+        """stamp of the next segmented cloud (t1 of LaserOdometry::mainLoop), read by adjustDistortion"""
+        lib().oracle_set_scan_time(self._h, float(t))
 
     def lo(self):
         return lib().oracle_lo(self._h)
@@ -165,7 +178,7 @@ class Oracle:
         return out.reshape(-1, 4) if cloud else out
 
 
-_CLOUDS = {"seg_cloud", "outlier", "sharp", "less_sharp", "flat", "less_flat", "surf_last", "corner_last",
+_CLOUDS = {"seg_cloud", "undistorted", "outlier", "sharp", "less_sharp", "flat", "less_flat", "surf_last", "corner_last",
            "lm_corner_map_ds", "lm_surf_map_ds", "lm_corner_map", "lm_surf_map", "lm_corner_ds", "lm_surf_ds",
            "lm_outlier_ds", "lm_surf_total_ds"}
 

@@ -31,6 +31,7 @@ class LaserOdometry : public nodelet::Nodelet {
     sub_seg_ = nh_.subscribe<sensor_msgs::PointCloud2>("/segmented_cloud", 10, &LaserOdometry::segCloudHandler, this);
     sub_info_ = nh_.subscribe<alego::cloud_info>("/seg_info", 10, &LaserOdometry::segInfoHandler, this);
     sub_outlier_ = nh_.subscribe<sensor_msgs::PointCloud2>("/outlier", 10, &LaserOdometry::outlierHandler, this);
+    sub_imu_ = nh_.subscribe<sensor_msgs::Imu>("/imu/data", 100, &LaserOdometry::imuHandler, this);   // :65-68 (use_imu)
     static std::thread main_thread(&LaserOdometry::mainLoop, this);   // :76
   }
 
@@ -38,6 +39,18 @@ class LaserOdometry : public nodelet::Nodelet {
   void segCloudHandler(const sensor_msgs::PointCloud2ConstPtr& m) { std::lock_guard<std::mutex> l(m_buf_); seg_buf_.push(m); }
   void segInfoHandler(const alego::cloud_infoConstPtr& m) { std::lock_guard<std::mutex> l(m_buf_); info_buf_.push(m); }
   void outlierHandler(const sensor_msgs::PointCloud2ConstPtr& m) { std::lock_guard<std::mutex> l(m_buf_); outlier_buf_.push(m); }
+  // :761-802: the handler's ring of dead-reckoned samples lives in the library; it is only read when alego_params.deskew_mode = 1
+  // (the reference's adjustDistortion call at :115 is commented out)
+  void imuHandler(const sensor_msgs::ImuConstPtr& m) {
+    if (!h_) return;
+    alego_imu s{};
+    s.stamp = m->header.stamp.toSec();
+    s.orientation[0] = m->orientation.w; s.orientation[1] = m->orientation.x; s.orientation[2] = m->orientation.y; s.orientation[3] = m->orientation.z;
+    s.linear_acceleration[0] = m->linear_acceleration.x; s.linear_acceleration[1] = m->linear_acceleration.y; s.linear_acceleration[2] = m->linear_acceleration.z;
+    s.angular_velocity[0] = m->angular_velocity.x; s.angular_velocity[1] = m->angular_velocity.y; s.angular_velocity[2] = m->angular_velocity.z;
+    std::lock_guard<std::mutex> l(m_lib_);   // a handle is single-threaded: the main loop takes the same lock around alego_lo_process
+    if (alego_lo_push_imu(h_, 0, &s, 1) < 0) NODELET_WARN_THROTTLE(1.0, "alego_lo_push_imu: %s", alego_last_error(h_));
+  }
 
   void mainLoop() {
     ros::Rate rate(100);
@@ -67,8 +80,11 @@ class LaserOdometry : public nodelet::Nodelet {
       alego_feat_out f{};
       f.sharp = sharp_.data(); f.sharp_cap = n_; f.less_sharp = less_sharp_.data(); f.less_sharp_cap = n_;
       f.flat = flat_.data(); f.flat_cap = n_; f.less_flat = less_flat_.data(); f.less_flat_cap = n_;
+      in.orientation[0] = info->startOrientation; in.orientation[1] = info->endOrientation; in.orientation[2] = info->orientationDiff;
+      in.stamp = seg->header.stamp.toSec();   // t1 (:111)
       alego_pose odom;
-      const int flags = alego_lo_process(h_, &in, &f, &odom);
+      int flags;
+      { std::lock_guard<std::mutex> l(m_lib_); flags = alego_lo_process(h_, &in, &f, &odom); }
       if (flags < 0) { NODELET_ERROR("alego_lo_process: %s", alego_last_error(h_)); continue; }
       std_msgs::Header hd = seg->header;
       hd.frame_id = "/laser";
@@ -98,10 +114,10 @@ class LaserOdometry : public nodelet::Nodelet {
   }
 
   ros::NodeHandle nh_;
-  ros::Subscriber sub_seg_, sub_info_, sub_outlier_;
+  ros::Subscriber sub_seg_, sub_info_, sub_outlier_, sub_imu_;
   ros::Publisher pub_corner_, pub_corner_less_, pub_surf_, pub_surf_less_, pub_odom_, pub_surf_last_, pub_corner_last_;
   tf::TransformBroadcaster tf_;
-  std::mutex m_buf_;
+  std::mutex m_buf_, m_lib_;
   std::queue<sensor_msgs::PointCloud2ConstPtr> seg_buf_, outlier_buf_;
   std::queue<alego::cloud_infoConstPtr> info_buf_;
   alego_handle* h_ = nullptr;

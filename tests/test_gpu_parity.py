@@ -8,7 +8,7 @@ import pytest
 
 from alego_amd import binding, synth
 from oracle import oracle_py as O
-from util import assert_bit_equal, quat_angle
+from util import assert_bit_equal, imu_stream, quat_angle
 
 pytestmark = pytest.mark.gpu
 POSE_TOL = 1e-4
@@ -558,6 +558,62 @@ def test_full_loop_with_std_sort_tie_order(params_a):
             assert np.abs(odom["t"] - want[:3]).max() < POSE_TOL
         h.set_lo_params(o.get("lo_params"))
         h.set_lm_params(o.get("lm_params"))
+    h.close()
+
+
+def test_motion_deskew_device_vs_oracle(params_a):
+    """§8f row 4: LaserOdometry::adjustDistortion (laserOdometry.cpp:557-726; dead in the reference, deskew_mode = 1) + the IMU
+    ring of imuHandler (:761-802).  The de-skewed cloud (/undistorted), the ring and its three cursors are compared bit for bit
+    after every scan, the features and the LO pose as everywhere else.  Covered: fewer than two IMU samples (nothing happens),
+    regular operation incl. the ring wrapping around (> 200 samples), and IMU data ending early so that the function gives up in
+    the middle of a cloud (:604-608)."""
+    p = params_a.copy()
+    p.deskew_mode = 1
+    p.scan_period = 0.1
+    h, o = binding.Handle(p), O.Oracle(p)
+    imu = imu_stream(-0.2, 3.0)
+    fed = 0
+
+    def feed(upto):
+        nonlocal fed
+        n = int(np.searchsorted(imu[:, 0], upto, side="right"))
+        if n > fed:
+            h.push_imu(imu[fed:n]), o.push_imu(imu[fed:n])
+            fed = n
+
+    aborted_midway = complete = 0
+    for k in range(26):
+        t = 0.1 * k
+        if k == 0:
+            feed(-0.2)                      # a single sample: imu_ptr_last_ = 0, the function does nothing (:593)
+        elif k == 20:
+            pass                            # no new samples: the newest one is 0.04 s older than this scan -> gives up after ~60 % of ring 0
+        else:
+            feed(t + 0.06)                  # (the cursor only moves forward: a later ring's early columns extrapolate from where ring 0 left it)
+        pts = synth.scan(p, k)
+        o.set_scan_time(t)
+        seg = _ip_compare(h, o, pts, f"deskew scan {k}")
+        seg["stamp"] = t
+        h.set_lo_params(o.get("lo_params"))
+        o.lo()
+        flags, feat, odom = h.lo_process(seg)
+        assert_bit_equal(h.debug_get("undistorted"), o.get("undistorted"), f"scan {k} de-skewed cloud")
+        assert_bit_equal(h.debug_get("imu_ptr"), o.get("imu_ptr"), f"scan {k} imu_ptr_last_/front_/last_iter_")
+        assert_bit_equal(h.debug_get("imu_ring"), o.get("imu_ring"), f"scan {k} IMU ring")
+        _fe_compare(h, o, feat, f"deskew scan {k}")
+        if k:
+            np.testing.assert_allclose(odom["params"], o.get("lo_params"), rtol=0, atol=1e-7)
+        moved = np.abs(o.get("undistorted")[:, :3] - o.get("seg_cloud")[:, :3]).max(1) > 0
+        if k == 0:
+            assert not moved.any()
+        elif moved[:300].any() and not moved[-1000:].any():
+            aborted_midway += 1
+        elif moved.mean() > 0.9:
+            complete += 1
+    assert aborted_midway >= 1 and complete >= 15, (aborted_midway, complete)
+    assert fed > 250, "the ring wrapped"
+    with pytest.raises(binding.AlegoError):
+        h.push_imu(imu[:1])                 # stamps must not decrease
     h.close()
 
 

@@ -295,3 +295,32 @@ def test_std_sort_phases_equal_std_sort():
             assert_bit_equal(a, b, f"n={n} hi={hi}")
             assert np.array_equal(keys[a], np.sort(keys)), "sorted"
             assert np.array_equal(np.sort(a), np.arange(n)), "permutation"
+
+
+def test_motion_deskew_restatement(params_a):
+    """adjustDistortion (laserOdometry.cpp:557-726, dead in the reference: deskew_mode = 1 switches it on).  A platform at rest
+    leaves the cloud untouched bit for bit; a pure yaw rate turns every point by the yaw the IMU integrated between the first
+    point's time and the point's own (`col * scan_period / Horizon_SCAN`), checked against a double-precision formula."""
+    from util import imu_stream
+    p = params_a.copy()
+    p.deskew_mode = 1
+    pts = synth.scan(p, 3)
+    o = O.Oracle(p)
+    o.push_imu(imu_stream(-0.1, 0.5, yaw_rate=0.0, acc=(0, 0, 0), tilt=(0, 0)))
+    o.set_scan_time(0.0)
+    o.ip(pts), o.fe()
+    assert_bit_equal(o.get("undistorted"), o.get("seg_cloud"), "platform at rest")
+    w = 0.5
+    o = O.Oracle(p)
+    o.push_imu(imu_stream(-0.1, 0.5, yaw_rate=w, acc=(0, 0, 0), tilt=(0, 0)))
+    o.set_scan_time(0.0)
+    o.ip(pts), o.fe()
+    seg, und, col = o.get("seg_cloud").reshape(-1, 4), o.get("undistorted").reshape(-1, 4), o.get("seg_col")
+    t = col * p.scan_period / p.horizon_scan
+    t0 = t[0]
+    a = w * (t - t0)                     # yaw gained since the first point; R_start^-1 R_cur = Rz(a)
+    want = np.stack([np.cos(a) * seg[:, 0] - np.sin(a) * seg[:, 1], np.sin(a) * seg[:, 0] + np.cos(a) * seg[:, 1], seg[:, 2]], 1)
+    err = np.abs(und[:, :3] - want).max()
+    assert err < 2e-3, err                 # the IMU's yaw is linear between 100 Hz samples; f32 rotation of points up to 50 m away
+    assert np.abs(und[:, :3] - seg[:, :3]).max() > 0.05, "the cloud did move"
+    assert_bit_equal(und[0], seg[0], "the first point defines the start pose and is not touched (:641-647)")

@@ -29,3 +29,21 @@ def quat_angle(q1, q2):
 
 def scans(params, n, stream=0, flags=0, start=0):
     return [synth.scan(params, start + k, stream, flags) for k in range(n)]
+
+
+def imu_stream(t0, t1, rate=100.0, yaw_rate=0.3, acc=(0.4, -0.2, 0.0), tilt=(0.02, -0.015)):
+    """sensor_msgs/Imu samples [n, 11] (stamp, orientation w x y z, linear_acceleration, angular_velocity) of a platform that turns
+    at `yaw_rate` rad/s with a small constant roll / pitch and accelerates by `acc` (body frame, gravity added as an IMU reports it)."""
+    n = int(round((t1 - t0) * rate)) + 1
+    out = np.zeros((n, 11))
+    for i in range(n):
+        t = t0 + i / rate
+        r, p, y = tilt[0], tilt[1], yaw_rate * t
+        cr, sr, cp, sp, cy, sy = np.cos(r / 2), np.sin(r / 2), np.cos(p / 2), np.sin(p / 2), np.cos(y / 2), np.sin(y / 2)
+        q = (cy * cp * cr + sy * sp * sr, cy * cp * sr - sy * sp * cr, cy * sp * cr + sy * cp * sr, sy * cp * cr - cy * sp * sr)   # Rz Ry Rx
+        g = 9.81
+        out[i, 0] = t
+        out[i, 1:5] = q
+        out[i, 5:8] = (acc[0] - g * np.sin(p), acc[1] + g * np.cos(p) * np.sin(r), acc[2] + g * np.cos(p) * np.cos(r))
+        out[i, 8:11] = (0.0, 0.0, yaw_rate)
+    return out
