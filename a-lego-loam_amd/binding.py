@@ -83,7 +83,8 @@ class Pc2Field(C.Structure):
 
 
 def lib_path():
-    return os.path.join(_HERE, "libalego_mi355x.so")
+    # ALEGO_LIB: a development build of the same library (e.g. with -DALEGO_TIMING for tools/*_timing.py)
+    return os.environ.get("ALEGO_LIB") or os.path.join(_HERE, "libalego_mi355x.so")
 
 
 def lib():

@@ -359,6 +359,7 @@ int alego_stream_setup(alego_handle* h, int bag, int start_scan) {
   if (!h) return ALEGO_ERR_ARG;
   if (!h->d.bag_pts || bag < 0 || bag >= h->d.n_bags || start_scan < 0) { h->err = "alego_stream_setup: needs alego_replay_create and a valid bag"; return ALEGO_ERR_ARG; }
   if (h->d.n_slots < 3 || h->streams.size() != 1) { h->err = "alego_stream_setup: the handle needs n_slots = 1 + 2 W >= 3 (one stream group)"; return ALEGO_ERR_ARG; }
+  if (h->P.deskew_mode) { h->err = "alego_stream_setup: bags carry no stamps / IMU data; the motion de-skew runs through alego_scan_process / alego_lo_process"; return ALEGO_ERR_ARG; }
   hipSetDevice(h->device);
   const int W = (h->d.n_slots - 1) / 2;
   if (int r = alego_replay_assign(h, 0, bag, start_scan)) return r;
