@@ -45,3 +45,15 @@ def test_product_does_not_link_the_oracle():
                 assert "oracle_py" not in txt and "liboracle" not in txt and "oracle/" not in txt.replace("// oracle/", ""), f
     so = open(binding.lib_path(), "rb").read()
     assert b"liboracle" not in so
+
+
+def test_cpp_example_fails_loudly_without_a_gpu():
+    """examples/replay.cpp drives the C ABI from plain C++.  In a container without an MI355X it must stop at alego_create with
+    ALEGO_ERR_NO_DEVICE — there is no CPU fallback for the product path (on the GPU box tests/test_gpu_parity.py runs it for real)."""
+    import subprocess
+    exe = os.path.join(ROOT, "examples", "replay")
+    assert os.path.exists(exe), "__graft_entry__.build() compiles it"
+    r = subprocess.run([exe, "2"], capture_output=True, text=True, timeout=120)
+    if r.returncode == 0:
+        pytest.skip("a GPU is present")
+    assert r.returncode == 1 and "no CPU fallback" in r.stderr, (r.returncode, r.stderr)

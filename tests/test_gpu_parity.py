@@ -617,6 +617,30 @@ def test_motion_deskew_device_vs_oracle(params_a):
     h.close()
 
 
+def test_cpp_host_program_equals_python_binding(params_a):
+    """examples/replay.cpp (plain C++ over the C ABI, what a host that links the library looks like) and the ctypes binding give
+    the same bits for the same 40 scans, key-frame pass-through included."""
+    import json, os, subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "replay")
+    r = subprocess.run([exe, "40"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    got = json.loads(r.stdout.strip().splitlines()[-1])
+    p = params_a
+    h = binding.Handle(p)
+    kfs = 0
+    for k in range(40):
+        flags, odom, mp = h.scan_process(synth.scan(p, k), stages=7, stamp=0.1 * k)
+        if flags & binding.FLAG_LM_KEYFRAME:
+            kfs += 1
+            last = h.lm_get_keyframe(-1)
+    assert got["key_frames"] == kfs == got["resident_key_frames"] and kfs >= 3
+    assert_bit_equal(np.array(got["odom_t"]), odom["t"], "odometry translation")
+    assert_bit_equal(np.array(got["map_t"]), mp["t"], "map translation")
+    assert_bit_equal(np.array(got["map_params"]), mp["params"], "LM params_")
+    assert_bit_equal(np.array(got["last_key_pose"], np.float32), np.asarray(last["pose"], np.float32), "newest key pose")
+    h.close()
+
+
 def test_batch_stream_groups_are_repeatable(params_a, monkeypatch):
     """The same 5-slot batch on 3 concurrent HIP streams, 12 times: every run gives the bits of the first.  (Workgroups of one
     launch are not co-scheduled when other streams keep the CUs busy; ip_front once let a workgroup clear the owner tags of a
