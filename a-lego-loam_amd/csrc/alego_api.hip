@@ -151,6 +151,7 @@ int alego_create(const alego_params* params, int device, int n_slots, int ring_l
   if (params->sort_mode != 0 && params->sort_mode != 2) { std::fprintf(stderr, "alego_create: sort_mode %d is an oracle-only setting (0 = (curvature, index) order, 2 = libstdc++ std::sort tie order in the sector sort)\n", params->sort_mode); return ALEGO_ERR_ARG; }
   if (params->deskew_mode != 0 && params->deskew_mode != 1) { std::fprintf(stderr, "alego_create: deskew_mode must be 0 or 1\n"); return ALEGO_ERR_ARG; }
   if (params->deskew_mode && !(params->scan_period > 0)) { std::fprintf(stderr, "alego_create: scan_period must be positive\n"); return ALEGO_ERR_ARG; }
+  if (params->kf_cap_surf < 0 || params->kf_cap_outlier < 0) { std::fprintf(stderr, "alego_create: negative key-frame capacity\n"); return ALEGO_ERR_ARG; }
   if (params->recent_keyframe_num > 512) { std::fprintf(stderr, "alego_create: recent_keyframe_num > 512 is not supported\n"); return ALEGO_ERR_ARG; }
   // The feature pick marks up to suppress_radius neighbours on either side of a picked point; the segmented cloud only
   // guarantees the reference's 5-point margin at both ends of a ring (laserOdometry.cpp:124,211-234 index i +- 5 unchecked).

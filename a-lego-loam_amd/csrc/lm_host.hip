@@ -71,7 +71,10 @@ LmHost* lm_host_create(const alego_params& P, const DevCtx& d, int n_slots, int 
   // batches only carry it when they are configured to use it
   lm->fallback_ok = n_slots <= 64 || !d.opt_map_merge;
   L.in_cap_c = d.fcap[F_LSHARP]; L.in_cap_s = d.N; L.in_cap_o = d.N;
-  L.kf_cap_c = d.fcap[F_LSHARP]; L.kf_cap_s = d.N / 2; L.kf_cap_o = d.N / 4;
+  L.kf_cap_c = d.fcap[F_LSHARP];
+  L.kf_cap_s = P.kf_cap_surf > 0 ? std::min(P.kf_cap_surf, d.N) : d.N / 2;
+  L.kf_cap_o = P.kf_cap_outlier > 0 ? std::min(P.kf_cap_outlier, d.N) : d.N / 4;
+  L.kf_cap_s = std::max(L.kf_cap_s, L.kf_cap_c - L.kf_cap_o);   // (scratch shared by both maps is sized by surf + outlier)
   L.total_cap = L.kf_cap_s + L.kf_cap_o;
   L.map_cap_c = L.K * L.kf_cap_c; L.map_cap_s = L.K * L.total_cap;
   L.gcap = n_slots <= 64 ? (1 << 20) : (1 << 18);

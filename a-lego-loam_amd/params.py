@@ -26,6 +26,7 @@ class AlegoParams(C.Structure):
         ("icp_max_corr_dist", _D), ("icp_max_iters", _I), ("icp_trans_eps", _D), ("icp_fitness_eps", _D),
         ("input_is_dense", _I),
         ("deskew_mode", _I), ("scan_period", _D),
+        ("kf_cap_surf", _I), ("kf_cap_outlier", _I),
     ]
 
     def copy(self):

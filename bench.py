@@ -248,6 +248,7 @@ def main():
     ap.add_argument("--prime", type=int, default=LAP, help="untimed scans per stream to fill the local map (one lap fills 50 key frames)")
     ap.add_argument("--geometry", default="16x1800", help="n_scan x horizon_scan: 16x1800 (BASELINE metric), 16x4000, 64x2048")
     ap.add_argument("--keyframes", type=int, default=0, help="local-map window (0 = reference default 50; config 5 uses 200)")
+    ap.add_argument("--kf-cap", type=int, default=0, help="points per key-frame surf cloud (alego_params.kf_cap_surf; outliers a quarter of it); 0 = worst case")
     ap.add_argument("--sort-mode", type=int, default=0, help="2 = feature picks in libstdc++ std::sort tie order (alego_params.sort_mode)")
     ap.add_argument("--shard-registration", action="store_true",
                     help="BASELINE config 5: every rank replays the SAME streams and each scan-to-map registration is split over the ranks "
@@ -270,6 +271,8 @@ def main():
     if args.keyframes > 0:
         p.recent_keyframe_num = args.keyframes
     p.sort_mode = args.sort_mode
+    if args.kf_cap > 0:
+        p.kf_cap_surf, p.kf_cap_outlier = args.kf_cap, max(256, args.kf_cap // 4)
     B = args.streams
     shard = args.shard_registration
     bags = make_bags(p, args.bags, first_stream=0 if shard else rank * args.bags)   # config 5: every rank holds the same streams
@@ -354,15 +357,20 @@ def main():
         if world == 1 and not args.no_cpu:
             out.update(single_stream(p, bags[0], local, args.prime, max(args.steps, 200)))
             out["cpu_baseline"], out["parity"] = cpu_legs(p, bags, args.prime, device=local)
-        try:   # RCCL prints its version banner through C stdio, which is buffered when stdout is a file: push it out first so that
-            import ctypes   # the JSON line is the last thing on stdout
-            ctypes.CDLL(None).fflush(None)
-        except OSError:
-            pass
-        print(json.dumps(out), flush=True)
     h.close()
+    # RCCL prints its version banner through C stdio, which is buffered when stdout is a pipe / file: every rank pushes it out,
+    # then rank 0 prints the JSON line after the barrier, so that it is the last line of the job's stdout
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except OSError:
+        pass
+    sys.stdout.flush()
     if dist is not None:
         dist.barrier()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist is not None:
         dist.destroy_process_group()
 
 

@@ -108,6 +108,11 @@ typedef struct alego_params {
   int32_t deskew_mode;       /* 0 = off; 1 = adjustDistortion with the IMU branch (use_imu = true, utility.h:68) on the samples given to
                                 alego_lo_push_imu, before feature extraction */
   double scan_period;        /* 0.2 s           utility.h:53 */
+  /* ---- capacities (no counterpart in the reference, whose clouds are std::vectors) ---- */
+  int32_t kf_cap_surf;       /* points a key frame's laser_surf_ds_ / laser_outlier_ds_ may hold (laserMapping.cpp:547-555); 0 = the worst */
+  int32_t kf_cap_outlier;    /* case n_scan*horizon_scan / 2 resp. / 4.  The local map of K key frames is sized K x (surf + outlier): with 64 x 2048
+                                and K = 200 the worst case is 1.5 GB per stream while real frames hold ~2 k points.  A frame that does not fit
+                                is truncated and reported (ALEGO_ERR_CAPACITY), never written past */
 } alego_params;
 
 /* Fill `p` with the reference defaults for an n_scan x horizon_scan sensor.
@@ -162,6 +167,8 @@ static inline void alego_default_params(alego_params* p, int n_scan, int horizon
   p->sort_mode = 0;
   p->deskew_mode = 0;
   p->scan_period = 0.2;
+  p->kf_cap_surf = 0;
+  p->kf_cap_outlier = 0;
   p->nearest_feature_dist = 25.0;
   p->ring_window = 2;
   p->huber_delta = 0.1;

@@ -15,5 +15,5 @@ run() {  # tag, bench args...
   tail -c 600 gpurun_out/${R}_geo_${tag}.json; echo; head -8 gpurun_out/${R}_geo_${tag}_kernel_stats.csv
 }
 run 16x4000 --geometry 16x4000 --streams 768 --steps 60 --warmup 10
-run 64x2048_k200 --geometry 64x2048 --keyframes 200 --streams 96 --bags 4 --prime 2400 --steps 40 --warmup 10
+run 64x2048_k200 --geometry 64x2048 --keyframes 200 --kf-cap 8192 --streams 512 --bags 4 --prime 2400 --steps 40 --warmup 10
 ls -la gpurun_out/${R}_geo_*
