@@ -1005,6 +1005,32 @@ def test_lm_capacity_overflow_is_reported_not_written_past(params_a):
     h.close(); h2.close()
 
 
+def test_keyframe_capacity_parameters(params_a):
+    """alego_params.kf_cap_surf / kf_cap_outlier size the key-frame ring and the local map (bench.py --kf-cap: 1.5 GB -> 0.26 GB per
+    stream at 64x2048 / K = 200).  Capacities that hold every frame change nothing, bit for bit; capacities that do not are
+    reported by the call that overflows and nothing is written past a buffer (the handle keeps running)."""
+    p = params_a
+    q = p.copy()
+    q.kf_cap_surf, q.kf_cap_outlier = 4096, 512          # a 16x1800 frame keeps ~1.8 k surf and ~40 outlier points
+    r = p.copy()
+    r.kf_cap_surf, r.kf_cap_outlier = 1024, 16
+    h0, h1, h2 = binding.Handle(p), binding.Handle(q), binding.Handle(r)
+    overflowed = 0
+    for k in range(24):
+        pts = synth.scan(p, k)
+        a = h0.scan_process(pts, stages=7)
+        b = h1.scan_process(pts, stages=7)
+        assert_bit_equal(b[2]["params"], a[2]["params"], f"scan {k} LM params_ with bounded capacities")
+        assert_bit_equal(b[1]["t"], a[1]["t"], f"scan {k} odometry")
+        try:
+            h2.scan_process(pts, stages=7)
+        except binding.AlegoError:
+            overflowed += 1
+    assert_bit_equal(h1.debug_get("lm_surf_map_ds"), h0.debug_get("lm_surf_map_ds"), "filtered surf map")
+    assert overflowed >= 5
+    h0.close(); h1.close(); h2.close()
+
+
 def test_bag_replay_equals_single_stream(params_a):
     """alego_replay_*: slots replaying shared, HBM-resident bags cyclically from their own start scans give bit-identical
     poses to one-slot handles fed the same scan sequence through the host entry point (bench.py's workload)."""
