@@ -243,7 +243,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--streams", type=int, default=1536, help="independent streams resident per GPU")
+    ap.add_argument("--streams", type=int, default=2048, help="independent streams resident per GPU")
     ap.add_argument("--bags", type=int, default=8, help="recorded 560-scan streams resident per GPU (shared by the streams)")
     ap.add_argument("--prime", type=int, default=LAP, help="untimed scans per stream to fill the local map (one lap fills 50 key frames)")
     ap.add_argument("--geometry", default="16x1800", help="n_scan x horizon_scan: 16x1800 (BASELINE metric), 16x4000, 64x2048")
