@@ -141,8 +141,12 @@ LmHost* lm_host_create(const alego_params& P, const DevCtx& d, int n_slots, int 
   // Expected work per context: the current-scan clouds and key frames practically never exceed 8192 points (vox_small); a key frame
   // is sorted for ~1 stream in 5 per mapping frame.  Fewer persistent workgroups where little is expected (they loop).
   // (vox_big only has work on the radix path of the maps or for a scan cloud of more than 8192 points)
-  lm->vm[g].grid_small = 3 * ns + std::max(2, ns / 2); lm->vm[g].grid_big = d.opt_map_merge ? std::min(8, std::max(2, ns / 2)) : std::max(2, ns / 2);
-  lm->v2[g].grid_big = std::max(1, ns / 16);
+  // (with 64 rings the scan's own surf clouds exceed 8192 points on every mapping frame: as many workgroups for the large jobs as
+  //  mapping frames are expected per round, instead of a handful for the rare one — 64x2048: 1.85 -> see profiles/r02_geo_64x2048*)
+  const bool big_scans = d.N > 8 * 8192;
+  lm->vm[g].grid_small = 3 * ns + std::max(2, ns / 2);
+  lm->vm[g].grid_big = (!d.opt_map_merge || big_scans) ? std::max(2, ns / 2) : std::min(8, std::max(2, ns / 2));
+  lm->v2[g].grid_big = big_scans ? std::max(2, ns / 2) : std::max(1, ns / 16);
   lm->vk[g].grid_small = 2; lm->vk[g].grid_big = 2;
   MapWork& W = lm->work[g];
   W.cap = std::max(4096, 32 * ns);
