@@ -212,6 +212,7 @@ int alego_create(const alego_params* params, int device, int n_slots, int ring_l
   d.inv_res_x = 1.0 / params->ang_res_x; d.inv_res_y = 1.0 / params->ang_res_y;
   d.tan_theta = (params->seg_theta > 0.0 && params->seg_theta < 1.5) ? std::tan(params->seg_theta) : std::nan("");
   d.opt_cc_fused = env_int("ALEGO_CC_FUSED", 1) != 0;
+  d.opt_cc_tile = env_int("ALEGO_CC_TILE", 1) != 0;
   d.opt_fe_pick1 = env_int("ALEGO_FE_PICK1", 0) != 0;
   d.opt_lo_box_lds = env_int("ALEGO_LO_BOX_LDS", 1 << 20);
   d.opt_map_merge = env_int("ALEGO_MAP_MERGE", 1) != 0;
@@ -825,6 +826,7 @@ int alego_debug_set_option(alego_handle* h, const char* name, int value) {
   const std::string s(name);
   DevCtx& d = h->d;
   if (s == "ALEGO_CC_FUSED") d.opt_cc_fused = value != 0;
+  else if (s == "ALEGO_CC_TILE") d.opt_cc_tile = value != 0;
   else if (s == "ALEGO_FE_PICK1") d.opt_fe_pick1 = value != 0;
   else if (s == "ALEGO_LO_BOX_LDS") d.opt_lo_box_lds = value;
   else if (s == "ALEGO_MAP_MERGE") { if (int r = lm_host_set_map_merge(h->lm, value != 0, &h->err)) return r; d.opt_map_merge = value != 0; }

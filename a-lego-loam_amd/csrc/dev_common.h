@@ -57,6 +57,7 @@ struct DevCtx {
   double tan_theta;                       // tan(seg_theta) for the edge predicate shortcut; NaN disables the shortcut
   // ---- kernel-variant switches (read once from the environment by alego_create, alego_debug_set_option overrides) ----
   int opt_cc_fused;     // ALEGO_CC_FUSED   1: cc_lds16 also compacts; 0: ip_rowcount + ip_compact
+  int opt_cc_tile;      // ALEGO_CC_TILE    1: images beyond the LDS paths are labelled band by band in LDS (cc_tile + cc_seam); 0: cc_runs + cc_link
   int opt_fe_pick1;     // ALEGO_FE_PICK1   1: one ring per wavefront (fe_pick) instead of fe_pick4
   int opt_lo_box_lds;   // ALEGO_LO_BOX_LDS boxes staged in LDS by lo_assoc (0: straight from HBM)
   int opt_map_merge;    // ALEGO_MAP_MERGE  1: local map from the pre-sorted key frames; 0: concat + radix VoxelGrid

@@ -404,6 +404,61 @@ DEV_INLINE void ccl_union(int* parent, int a, int b) {
     }
   } while (repeat);
 }
+// Images too large for one workgroup's LDS (more than 16 rings with more than CC_LDS_MAXN cells: 64x2048): two-level labelling.
+// cc_tile: a workgroup takes a band of columns that fits LDS (<= CC_TILE_CELLS cells, all rows), runs the same union-find as
+// cc_lds on it — right-edges that stay inside the band, all down-edges — and writes every cell's band root (as a global linear index;
+// row-major order inside a band is the global order restricted to it, so the band root is the minimum global index of the piece).
+// cc_seam: the right-edges that cross a band boundary (incl. the wrap-around column) are linked with the global-memory union
+// (cc_union, as cc_link did for EVERY right-edge: NS x bands edges instead of ~N / 4).  cc_stats then resolves every cell to
+// its final root with a read-only find whose chains are at most a few band roots long.
+#define CC_TILE_CELLS 16384
+#define CC_TILE_T 512
+DEV_INLINE int cc_tile_width(const DevCtx& d) { return max(1, CC_TILE_CELLS / d.NS); }
+__global__ void __launch_bounds__(CC_TILE_T) cc_tile(DevCtx d) {
+  const int slot = blockIdx.y + d.slot0, tid = threadIdx.x;
+  const size_t base = (size_t)slot * d.N;
+  const int H = d.H, TW0 = cc_tile_width(d);
+  const int c0 = blockIdx.x * TW0, TW = min(TW0, H - c0), n = TW * d.NS;
+  __shared__ int parent[CC_TILE_CELLS];
+  const uint8_t* fi = d.flag_img + base;
+  if (blockIdx.x == 0) ip_strip_halo_columns(d, slot, tid, CC_TILE_T);
+  for (int l = tid; l < n; l += CC_TILE_T) parent[l] = l;
+  __syncthreads();
+  for (int l = tid; l < n; l += CC_TILE_T) {
+    const int row = l / TW, lc = l - row * TW;
+    const uint8_t f = fi[row * H + c0 + lc];
+    if ((f & 4) && lc + 1 < TW) ccl_union(parent, l, l + 1);
+    if (f & 8) ccl_union(parent, l, l + TW);
+  }
+  __syncthreads();
+  int* gp = d.parent + base;
+  for (int l = tid; l < n; l += CC_TILE_T) {
+    const int row = l / TW, lc = l - row * TW;
+    const int v = row * H + c0 + lc;
+    int out = -1;
+    if (fi[v] & 2) {
+      int r = parent[l], nx;
+      while (r > (nx = parent[r])) r = nx;   // read-only find: nobody writes any more
+      const int rr = r / TW;
+      out = rr * H + c0 + (r - rr * TW);
+    }
+    gp[v] = out;
+  }
+}
+__global__ void __launch_bounds__(256) cc_seam(DevCtx d) {
+  const int slot = blockIdx.x + d.slot0;
+  const size_t base = (size_t)slot * d.N;
+  const int H = d.H, TW0 = cc_tile_width(d), nt = (H + TW0 - 1) / TW0;
+  const uint8_t* fi = d.flag_img + base;
+  int* parent = d.parent + base;
+  for (int e = threadIdx.x; e < nt * d.NS; e += 256) {
+    const int t = e / d.NS, row = e - t * d.NS;
+    const int col = min((t + 1) * TW0, H) - 1;           // last column of band t
+    const int v = row * H + col;
+    if (fi[v] & 4) cc_union(parent, v, row * H + (col + 1 == H ? 0 : col + 1));
+  }
+}
+
 __global__ void __launch_bounds__(CC_LDS_THREADS) cc_lds(DevCtx d, int ring_pos, int fused) {
   const int slot = blockIdx.x + d.slot0;
   const size_t base = (size_t)slot * d.N;
@@ -1030,6 +1085,10 @@ void launch_ip(const DevCtx& d, int ring_pos, bool want_labels, hipStream_t st) 
     ALEGO_LAUNCH(cc_lds16, dim3(d.n_launch), dim3(CC_LDS_THREADS), (size_t)4 * ((d.N + 1) / 2), st, d, ring_pos, cc_flags);
   } else if (lds_cc) {
     ALEGO_LAUNCH(cc_lds, dim3(d.n_launch), dim3(CC_LDS_THREADS), (size_t)4 * d.N, st, d, ring_pos, 0);
+  } else if (d.opt_cc_tile && d.NS <= CC_TILE_CELLS / 16) {
+    const int tw = std::max(1, CC_TILE_CELLS / d.NS);
+    ALEGO_LAUNCH(cc_tile, dim3((d.H + tw - 1) / tw, d.n_launch), dim3(CC_TILE_T), 0, st, d);
+    ALEGO_LAUNCH(cc_seam, dim3(d.n_launch), dim3(256), 0, st, d);
   } else {
     ALEGO_LAUNCH(cc_runs, dim3((d.H + 127) / 128, d.n_launch), dim3(128), 0, st, d);
     ALEGO_LAUNCH(cc_link, gN, dim3(IP_BLOCK), 0, st, d);
