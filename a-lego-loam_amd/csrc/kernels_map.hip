@@ -27,7 +27,7 @@ typedef unsigned long long u64;
 
 #define MU_T 512          // threads of map_update
 #ifndef MA_T
-#define MA_T 256          // threads of map_accum (one wavefront per item of 256 voxels was measured: 533 us against 439 us per launch)
+#define MA_T 512          // threads of map_accum: a run's piece of a chunk (a few hundred points) in one prefetched sweep (256: two or three dependent sweeps per run)
 #endif
 #ifndef MAP_R
 #define MAP_R 1024        // voxels per map_accum work item
