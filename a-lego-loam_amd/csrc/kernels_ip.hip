@@ -422,13 +422,29 @@ __global__ void __launch_bounds__(CC_TILE_T) cc_tile(DevCtx d) {
   __shared__ int parent[CC_TILE_CELLS];
   const uint8_t* fi = d.flag_img + base;
   if (blockIdx.x == 0) ip_strip_halo_columns(d, slot, tid, CC_TILE_T);
-  for (int l = tid; l < n; l += CC_TILE_T) parent[l] = l;
+  // vertical runs without atomics (most edges are vertical, see cc_runs): one thread per column, a run's representative is its lowest row
+  for (int lc = tid; lc < TW; lc += CC_TILE_T) {
+    int start = 0;
+    uint8_t prev = 0;
+    for (int row = 0; row < d.NS; ++row) {
+      const uint8_t fl = fi[row * H + c0 + lc];
+      if (!(prev & 8)) start = row;
+      parent[row * TW + lc] = start * TW + lc;
+      prev = fl;
+    }
+  }
   __syncthreads();
+  // right-edges inside the band between the runs; skipped when the cell below already links the same pair of runs
   for (int l = tid; l < n; l += CC_TILE_T) {
     const int row = l / TW, lc = l - row * TW;
-    const uint8_t f = fi[row * H + c0 + lc];
-    if ((f & 4) && lc + 1 < TW) ccl_union(parent, l, l + 1);
-    if (f & 8) ccl_union(parent, l, l + TW);
+    if (lc + 1 >= TW) continue;
+    const int v = row * H + c0 + lc;
+    if (!(fi[v] & 4)) continue;
+    if (row > 0) {
+      const uint8_t fb = fi[v - H];
+      if ((fb & 8) && (fb & 4) && (fi[v + 1 - H] & 8)) continue;
+    }
+    ccl_union(parent, l, l + 1);
   }
   __syncthreads();
   int* gp = d.parent + base;
