@@ -1160,14 +1160,18 @@ def test_stream_run_with_lookahead_lanes_is_bit_identical(params_a, lanes):
     ha.close(); hb.close()
 
 
-def test_loop_closure_icp_device_vs_oracle(params_a):
-    """f3: detectLoopClosure's sub-map + pcl::IterativeClosestPoint of performLoopClosure (laserMapping.cpp:652-824) on the device
+@pytest.mark.parametrize("standalone", [False, True])
+def test_loop_closure_icp_device_vs_oracle(params_a, standalone):
+    """(standalone = the literals of src/LM.cpp:175,210,212 instead of the nodelet's: history leaf 0.4, radius 10 m, fitness 0.3.)
+    f3: detectLoopClosure's sub-map + pcl::IterativeClosestPoint of performLoopClosure (laserMapping.cpp:652-824) on the device
     against the oracle's restatement, on a real revisit of the T0 lap and with a wrong newest key pose.  The VoxelGrid-filtered
     target is bit-exact; the alignment sums its correspondences in another order (per-workgroup partials), so the f32
     transformation of an iteration can differ in its last bit: iterations within one, correction within 1e-5, fitness within 1e-6."""
-    p = params_a
+    p = params_a.copy()
+    if standalone:
+        p.lc_leaf, p.lc_search_radius, p.lc_fitness_max = 0.4, 10.0, 0.3
     o = O.Oracle(p)
-    for k in range(420):
+    for k in range(545 if standalone else 420):   # (a 10 m radius only finds the start of the lap once the lap is almost closed)
         o.process_scan(synth.scan(p, k))
     poses = o.get("lm_keyposes").reshape(-1, 6)
     n = len(poses)
