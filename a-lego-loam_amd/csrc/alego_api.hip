@@ -278,7 +278,7 @@ int alego_create(const alego_params* params, int device, int n_slots, int ring_l
   std::vector<int> sc0(B * SC_COUNT, 0);
   for (size_t b = 0; b < B; ++b) {
     sc0[b * SC_COUNT + SC_CUR] = 1;  // the first scan writes feature buffer 0
-    sc0[b * SC_COUNT + SC_FIRST] = 0x7fffffff; sc0[b * SC_COUNT + SC_LAST] = -1;   // accumulators of ip_project, re-armed by ip_image
+    sc0[b * SC_COUNT + SC_FIRST] = 0x7fffffff; sc0[b * SC_COUNT + SC_LAST] = -1;   // accumulators of ip_project, re-armed by ip_front
   }
   d.seg_lo = h->P.deskew_mode ? d.seg_dsk : d.seg_pts;
   std::vector<int> ip0(B * 4, 0);

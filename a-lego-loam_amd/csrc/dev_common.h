@@ -29,7 +29,7 @@ enum {
   SC_ODOM_VALID,
   SC_LM_FRAME,    // LaserMapping frame_cnt (laserMapping.cpp:111)
   SC_LM_FLAGS,
-  SC_PVALID_OUT,  // valid input points of the last projected scan (SC_PVALID is an accumulator, cleared by ip_image)
+  SC_PVALID_OUT,  // valid input points of the last projected scan (SC_PVALID is an accumulator, cleared by ip_front)
   SC_COUNT = 32
 };
 
@@ -77,7 +77,8 @@ struct DevCtx {
   int fs_cur, fs_last;
   // ---- image projection ----
   int* owner;           // [slot][N] winning input index per cell (last writer = max index), -1 empty; ip_project writes
-                        // IP_OWNER_TAG | index, ip_image turns every cell back into the plain form (= the reset for the next scan)
+                        // IP_OWNER_TAG | index; ip_front (and, for its workgroups' first columns, the kernel after it) turns every
+                        // cell back into the plain form (= the reset for the next scan)
   float* range_img;     // [slot][N] f32 range, -1 empty
   uint8_t* flag_img;    // [slot][N] bit0 ground, bit1 active (filled, non-ground), bit2 edge->right, bit3 edge->down
   int* parent;          // [slot][N] union-find parent (root = min linear index of the component)

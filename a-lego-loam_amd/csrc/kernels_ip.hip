@@ -2,10 +2,13 @@
 //
 //   ip_project    a1-a3: NaN/near filter, row/col from the shared fdlibm atan2f, last-writer-wins
 //                 scatter resolved by atomicMax on the input index          (:58-59,:76-104)
-//   ip_image      a2,a3,a4: orientation, range image gather, per-column ground test (:62-72,:107-143)
-//   cc_edges      a5: 4-neighbour edge predicate atan2(d2 sin a, d1 - d2 cos a) > theta (:255-270)
-//   cc_runs       a5: vertical runs, one thread per column (no atomics)
-//   cc_link       a5: lock-free union-find over the runs, root = minimum linear index == BFS discovery order (:147-156)
+//   ip_front      a2,a3,a4 + a5's edges: orientation, range gather, per-column ground test, 4-neighbour edge predicate
+//                 atan2(d2 sin a, d1 - d2 cos a) > theta, one launch (:62-72,:107-143,:255-270)
+//   cc_lds16      a5 + a6 for <= 16 rings (16x1800, 16x4000): union-find with 2 B/cell in LDS, statistics, feasibility and the
+//                 ordered compaction in one workgroup per stream (:147-191,:210-316)
+//   cc_lds        a5 for small images with more than 16 rings (4 B/cell in LDS)
+//   cc_tile / cc_seam   a5 for larger images (64x2048): column bands labelled in LDS, seams linked in global memory
+//   cc_runs / cc_link   a5, the global-memory union-find they replaced (ALEGO_CC_TILE=0): root = minimum linear index == BFS discovery order (:147-156)
 //   cc_stats      a5: per-component size and row mask -> feasibility (:282-301)
 //   ip_rowcount / ip_compact  a6: per-row ballot compaction with the +5/-6 ring convention (:158-191)
 //   ip_labels     label_mat_ numbering 1,2,.. in discovery order / 999999 / -1 (:303-314)
@@ -123,7 +126,7 @@ __global__ void __launch_bounds__(IP_BLOCK) ip_project(DevCtx d, int ring_pos) {
       }
       if (row >= 0 && row < d.NS && col >= 0 && col < d.H)
         atomicMax(&d.owner[(size_t)slot * d.N + col + row * d.H], IP_OWNER_TAG | i);  // later points overwrite earlier ones (:102-103);
-        // whatever the previous scan left in the cell (a plain index or -1, see ip_image) loses against a tagged entry: no reset pass
+        // whatever the previous scan left in the cell (a plain index or -1, see ip_front) loses against a tagged entry: no reset pass
     }
   }
   if (valid) { vmin = min(vmin, i); vmax = max(vmax, i); ++nvalid; }

@@ -62,7 +62,6 @@ __global__ void __launch_bounds__(LM_BLOCK) lm_prepare(DevCtx d, LmCtx L, int st
   const int cur = d.scal[slot * SC_COUNT + SC_CUR];  // LO has completed: features of this scan
   const int sslot = scan_slot_of(d, slot);           // where this scan's features, outliers and odometry hand-over live (its lane, or the slot itself)
   int* li = lip(L, slot);
-  const int* sc = d.scal + slot * SC_COUNT;
   if (stage && run_hint != 0) {   // run_hint == 0: the host knows that no slot of this launch maps this scan (odd frame)
     // (written with unconditional loads + selects: a 3-way if/else chain here was lowered by hipcc 7.2 into
     //  a scalar switch that left the count pointer of the last arm undefined)

@@ -89,7 +89,7 @@ DEV_INLINE int block_excl_scan(int v, int* s_w /*[MU_T/64 + 1]*/, int* total) {
 __global__ void __launch_bounds__(MU_T) map_update(DevCtx d, LmCtx L, MapWork W) {
   const int m = blockIdx.x, slot = blockIdx.y + d.slot0, tid = threadIdx.x;
   int* li = lipm(L, slot);
-  __shared__ int s_rem[MAP_KMAX], s_add[MAP_KMAX], s_nrem, s_nadd, s_nU, s_nnew, s_err, s_pass;
+  __shared__ int s_rem[MAP_KMAX], s_add[MAP_KMAX], s_nrem, s_nadd, s_nU, s_nnew, s_err;
   __shared__ int s_w[MU_T / 64 + 1];
   __shared__ int s_last;
   __shared__ float s_box[6][MU_T / 64];
@@ -128,7 +128,7 @@ __global__ void __launch_bounds__(MU_T) map_update(DevCtx d, LmCtx L, MapWork W)
           nr = 0; na = 0;
           for (int b = 0; b < ncur; ++b) s_add[na++] = s_cur[b] % L.KR;
         }
-        s_nrem = nr; s_nadd = na; s_nU = valid ? li[LI_NU_C + m] : 0; s_err = 0; s_pass = 0;
+        s_nrem = nr; s_nadd = na; s_nU = valid ? li[LI_NU_C + m] : 0; s_err = 0;
       }
     }
     __syncthreads();
