@@ -290,10 +290,14 @@ __global__ void __launch_bounds__(64) fe_pick(DevCtx d) {
 // ~100 instructions per pick) is issued once for four rings; the reductions stay inside a DPP row.  Lane gl of a row owns
 // the sector elements lsp + gl + 16 t (sector length <= 16 * FE_T).  Needs suppress_radius <= 7: the forward checks sit in
 // lanes 0-7 of the row, the backward checks in lanes 8-15, and the 2 * radius + 1 marked elements get one lane each.  Dynamic LDS: 1 B per ring point, 4 rings.
+// STDSORT (sort_mode 2): as in fe_pick — when several candidates of a row tie for the best curvature, the whole wavefront computes
+// where libstdc++'s std::sort would have left that ring's sector (stdsort_emu.h), once per ring and sector, and the row picks by it.
 #define FP_G 4
-template <int FE_T>
+template <int FE_T, bool STDSORT = false>
 __global__ void __launch_bounds__(64) fe_pick4(DevCtx d) {
   using mask_t = typename std::conditional<(FE_T > 32), unsigned long long, uint32_t>::type;
+  __shared__ typename std::conditional<STDSORT, SortEmu<16 * FE_T>, char>::type s_emu;
+  __shared__ uint16_t s_pos[STDSORT ? FP_G : 1][STDSORT ? 16 * FE_T : 1];
   static_assert(FE_T <= 64, "one candidate bit per owned element");
   const int slot = blockIdx.y + d.slot0, lane = threadIdx.x, g = lane >> 4, gl = lane & 15;
   const int ring0 = blockIdx.x * FP_G, ring = ring0 + g;
@@ -379,6 +383,25 @@ __global__ void __launch_bounds__(64) fe_pick4(DevCtx d) {
       atomicXor(&fw[bo >> 2], (x << 4) << ((bo & 3) * 8));
     };
     int* st_dummy = d.st_cnt + ((size_t)slot * d.NS + (rv ? ring : 0)) * 8 + 7;   // unused field
+    // (STDSORT) the sector arrangement of every ring whose row reports a tie and has none yet, ring by ring with all 64 lanes
+    unsigned have_arr = 0;   // wavefront-uniform: bit r = ring r's arrangement of this sector is in s_pos[r]
+    auto ring_arrangements = [&](bool tied) {
+      if constexpr (STDSORT) {
+        for (int r = 0; r < FP_G; ++r) {
+          const bool want = __shfl((int)tied, 16 * r, 64) != 0;
+          if (!want || ((have_arr >> r) & 1u)) continue;
+          const int lsp_r = __shfl(lsp, 16 * r, 64), lep_r = __shfl(lep, 16 * r, 64), rf_r = __shfl(rf, 16 * r, 64);
+          const int n = lep_r - lsp_r + 1;
+          __syncthreads();
+          for (int i = lane; i < n; i += 64) s_emu.ak[i] = (uint32_t)d_f2i(fabsf(d.cd[base + rf_r + lsp_r + i]));
+          __syncthreads();
+          stdsort_arrangement(s_emu, n);
+          for (int i = lane; i < n; i += 64) s_pos[r][i] = s_emu.pos[i];
+          __syncthreads();
+          have_arr |= 1u << r;
+        }
+      }
+    };
     // ---- sharp / less-sharp: descending curvature, ties -> larger index (:189-236) ----
     int picked_num = 0;
     bool act = act0;
@@ -391,7 +414,23 @@ __global__ void __launch_bounds__(64) fe_pick4(DevCtx d) {
       const uint32_t kmax = row16_max_u32(bk);
       act = act && kmax != 0;
       if (!__any(act)) break;
-      const int c = (int)row16_max_u32(bk == kmax ? (uint32_t)(lsp + gl + 16 * bt) : 0u);   // ties -> larger index
+      int c = (int)row16_max_u32(bk == kmax ? (uint32_t)(lsp + gl + 16 * bt) : 0u);   // ties -> larger index
+      if constexpr (STDSORT) {
+        int cnt = 0;
+#pragma unroll
+        for (int t = 0; t < FE_T; ++t) cnt += (((sharp_m >> t) & 1) && key[t] == kmax) ? 1 : 0;
+        if (!act) cnt = 0;
+        const bool tied = row16_max_u32((uint32_t)cnt) > 1u || __popc((unsigned)(__ballot(cnt > 0) >> (16 * g)) & 0xffffu) > 1;
+        if (__any(tied)) {
+          ring_arrangements(tied);
+          uint32_t best = 0;   // k = ep .. sp: of the tied candidates the one std::sort placed last comes first
+#pragma unroll
+          for (int t = 0; t < FE_T; ++t)
+            if (((sharp_m >> t) & 1) && key[t] == kmax) best = max(best, (((uint32_t)s_pos[g][gl + 16 * t] + 1u) << 16) | (uint32_t)(gl + 16 * t));
+          const int ca = lsp + (int)(row16_max_u32(tied ? best : 0u) & 0xFFFFu);
+          c = tied ? ca : c;
+        }
+      }
       picked_num += act ? 1 : 0;
       const int lab = picked_num <= P.n_sharp ? 2 : (picked_num <= P.n_less_sharp ? 1 : 0);
       const bool w1 = act && gl == 0 && lab != 0;
@@ -418,7 +457,23 @@ __global__ void __launch_bounds__(64) fe_pick4(DevCtx d) {
       const uint32_t kmin = row16_min_u32(bk);
       act = act && kmin != 0xFFFFFFFFu;
       if (!__any(act)) break;
-      const int c = (int)row16_min_u32(bk == kmin ? (uint32_t)(lsp + gl + 16 * bt) : 0xFFFFFFFFu);   // ties -> smaller index
+      int c = (int)row16_min_u32(bk == kmin ? (uint32_t)(lsp + gl + 16 * bt) : 0xFFFFFFFFu);   // ties -> smaller index
+      if constexpr (STDSORT) {
+        int cnt = 0;
+#pragma unroll
+        for (int t = 0; t < FE_T; ++t) cnt += (((flat_m >> t) & 1) && key[t] == kmin) ? 1 : 0;
+        if (!act) cnt = 0;
+        const bool tied = row16_max_u32((uint32_t)cnt) > 1u || __popc((unsigned)(__ballot(cnt > 0) >> (16 * g)) & 0xffffu) > 1;
+        if (__any(tied)) {
+          ring_arrangements(tied);
+          uint32_t best = 0xFFFFFFFFu;   // k = sp .. ep: the tied candidate std::sort placed first
+#pragma unroll
+          for (int t = 0; t < FE_T; ++t)
+            if (((flat_m >> t) & 1) && key[t] == kmin) best = min(best, ((uint32_t)s_pos[g][gl + 16 * t] << 16) | (uint32_t)(gl + 16 * t));
+          const int ca = lsp + (int)(row16_min_u32(tied ? best : 0xFFFFFFFFu) & 0xFFFFu);
+          c = tied ? ca : c;
+        }
+      }
       picked_num += act ? 1 : 0;
       const bool w1 = act && gl == 0;
       relabel(c, w1 ? 1u : 0u);   // label -1
@@ -786,10 +841,14 @@ void launch_fe(const DevCtx& d, hipStream_t st) {
   const int sector_max = (d.H + d.P.n_sectors - 1) / (d.P.n_sectors > 0 ? d.P.n_sectors : 1) + 2;
   // (padding this allocation by 16 KB cost 7 % of the whole pipeline: the LDS footprint decides how many rings share a CU)
   const int extra = 0;
-  const bool one_ring = d.opt_fe_pick1 || d.P.sort_mode == 2 || d.P.suppress_radius > 7 || sector_max > 16 * 43;   // (2 * radius + 1 marked elements <= 16 lanes)
+  const bool one_ring = d.opt_fe_pick1 || d.P.suppress_radius > 7 || sector_max > 16 * 43;   // (2 * radius + 1 marked elements <= 16 lanes)
   const dim3 g4((d.NS + FP_G - 1) / FP_G, d.n_launch);
   const size_t lds4 = (size_t)FP_G * d.H;
-  if (!one_ring && sector_max <= 16 * 19) { ALEGO_LAUNCH(fe_pick4<19>, g4, dim3(64), lds4, st, d); }
+  const bool ss = d.P.sort_mode == 2;
+  if (!one_ring && ss && sector_max <= 16 * 19) { ALEGO_LAUNCH((fe_pick4<19, true>), g4, dim3(64), lds4, st, d); }
+  else if (!one_ring && ss && sector_max <= 16 * 24) { ALEGO_LAUNCH((fe_pick4<24, true>), g4, dim3(64), lds4, st, d); }
+  else if (!one_ring && ss) { ALEGO_LAUNCH((fe_pick4<43, true>), g4, dim3(64), lds4, st, d); }
+  else if (!one_ring && sector_max <= 16 * 19) { ALEGO_LAUNCH(fe_pick4<19>, g4, dim3(64), lds4, st, d); }
   else if (!one_ring && sector_max <= 16 * 24) { ALEGO_LAUNCH(fe_pick4<24>, g4, dim3(64), lds4, st, d); }
   else if (!one_ring) { ALEGO_LAUNCH(fe_pick4<43>, g4, dim3(64), lds4, st, d); }
   else if (d.P.sort_mode == 2 && sector_max <= 64 * 6) { ALEGO_LAUNCH((fe_pick<6, true>), dim3(d.NS, d.n_launch), dim3(64), (size_t)3 * d.H, st, d); }

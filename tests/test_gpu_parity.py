@@ -518,11 +518,14 @@ def _quantised(pts, step=0.05):
     return pts
 
 
-@pytest.mark.parametrize("geom", [(16, 1800), (16, 4000), (64, 2048)])
-def test_fe_std_sort_tie_order(geom):
+@pytest.mark.parametrize("geom,pick1", [((16, 1800), False), ((16, 1800), True), ((16, 4000), False), ((64, 2048), False)])
+def test_fe_std_sort_tie_order(geom, pick1, monkeypatch):
     """sort_mode = 2: feature picks with tied curvatures in libstdc++'s std::sort order (the reference binary's behaviour), bit-exact
     against the oracle running the real std::sort — on scans with quantised ranges (every scan has ties that change the picks
-    under the (curvature, index) rule) and on plain ones."""
+    under the (curvature, index) rule) and on plain ones.  Both pick kernels: four rings per wavefront (fe_pick4<19 / 43 / 24, true>) and,
+    with ALEGO_FE_PICK1, one ring per wavefront."""
+    if pick1:
+        monkeypatch.setenv("ALEGO_FE_PICK1", "1")
     p = synth.default_params(*geom)
     p.sort_mode = 2
     p0 = p.copy()
