@@ -257,13 +257,19 @@ def main():
     ap.add_argument("--no-profile", action="store_true")
     args = ap.parse_args()
 
-    import torch
     rank, local, world = D.env()
+    use_dist = world > 1 or bool(os.environ.get("ALEGO_BENCH_FORCE_DIST") and "RANK" in os.environ)   # (second form: the launcher path at N = 1, for testing)
+    if use_dist:
+        # An RCCL communicator brings HIP streams of its own.  With the runtime's default of 4 hardware queues they alias with the
+        # handle's 4 stream groups, two of which then share a queue and serialise: 293 k instead of 329 k scans/s with the communicator
+        # merely alive (measured at N = 1 under the launcher; 8 queues: 329.7 k).  Must be set before the HIP runtime initialises.
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the product path")
     torch.cuda.set_device(local)
     dist = None
-    if world > 1:
+    if use_dist:
         dist = D.init("nccl", torch.device("cuda", local))  # RCCL: only the barrier + max-over-ranks use it
 
     ns, hs = (int(v) for v in args.geometry.lower().split("x"))
