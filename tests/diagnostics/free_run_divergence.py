@@ -1,6 +1,6 @@
 """Where does a free-running device stream start to differ from the oracle?  (diagnostic)"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from alego_loader import load_package; load_package()
 from alego_amd import binding, synth

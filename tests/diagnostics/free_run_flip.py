@@ -9,7 +9,7 @@ reported with the margin of the decision that flipped, evaluated under BOTH side
   * solver summary: the costs and the step-acceptance ratio's inputs of both sides
 Writes gpurun_out/free_run_flip.json (copied to profiles/ by hand)."""
 import json, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from alego_loader import load_package; load_package()
 from alego_amd import binding, synth

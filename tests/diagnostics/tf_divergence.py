@@ -1,6 +1,6 @@
 """Teacher-forced full loop: per scan compare LO correspondences / params / solver summaries and LM outputs (diagnostic)."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from alego_loader import load_package; load_package()
 from alego_amd import binding, synth
