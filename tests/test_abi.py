@@ -45,6 +45,13 @@ def test_product_does_not_link_the_oracle():
                 assert "oracle_py" not in txt and "liboracle" not in txt and "oracle/" not in txt.replace("// oracle/", ""), f
     so = open(binding.lib_path(), "rb").read()
     assert b"liboracle" not in so
+    # neither do the host-side sources around it: the development tools, the C++ example, the ROS adapters, the headers
+    for sub in ("tools", "examples", "ros_adapter", "include"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, sub)):
+            for f in files:
+                if f.endswith((".py", ".hip", ".h", ".cpp", ".sh")):
+                    txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                    assert "oracle_py" not in txt and "liboracle" not in txt and "from oracle" not in txt, os.path.join(sub, f)
 
 
 def test_cpp_example_fails_loudly_without_a_gpu():
