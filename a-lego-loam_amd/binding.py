@@ -22,7 +22,7 @@ EXPORTS = [
     "alego_ip_process", "alego_lo_process", "alego_lm_process", "alego_scan_process",
     "alego_batch_load", "alego_batch_run", "alego_synchronize", "alego_batch_get_pose", "alego_batch_get_counts",
     "alego_stream", "alego_stream_groups", "alego_profile_enable", "alego_profile_report", "alego_set_lo_params", "alego_set_lm_params", "alego_debug_get", "alego_debug_voxel", "alego_debug_atan2f",
-    "alego_lo_push_imu", "alego_debug_math", "alego_debug_std_sort", "alego_debug_eval_blocks", "alego_debug_transform_to_start", "alego_debug_set_option",
+    "alego_lo_push_imu", "alego_trajectory_enable", "alego_trajectory_get", "alego_debug_math", "alego_debug_std_sort", "alego_debug_eval_blocks", "alego_debug_transform_to_start", "alego_debug_set_option",
     "alego_lm_keyframe_count", "alego_lm_get_keyframe", "alego_lm_set_keypose", "alego_lm_reset_window", "alego_lm_apply_correction",
     "alego_lm_add_keyframe", "alego_pc2_to_points", "alego_replay_create", "alego_replay_load", "alego_replay_assign",
     "alego_dist_unique_id", "alego_dist_init", "alego_dist_shutdown", "alego_stream_setup", "alego_stream_run",
@@ -140,6 +140,10 @@ def lib():
         L.alego_debug_voxel.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_int]
         L.alego_debug_atan2f.restype = C.c_int
         L.alego_debug_atan2f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.alego_trajectory_enable.restype = C.c_int
+        L.alego_trajectory_enable.argtypes = [C.c_void_p, C.c_int32]
+        L.alego_trajectory_get.restype = C.c_int
+        L.alego_trajectory_get.argtypes = [C.c_void_p, C.c_int, C.c_int32, C.c_int32, C.c_void_p]
         L.alego_lo_push_imu.restype = C.c_int
         L.alego_lo_push_imu.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int32]
         L.alego_debug_std_sort.restype = C.c_int
@@ -453,6 +457,18 @@ class Handle:
         b = None if b is None else np.ascontiguousarray(b, np.float32)
         out = np.empty_like(a)
         self._check(lib().alego_debug_math(self._h, mode, a.ctypes.data, None if b is None else b.ctypes.data, out.ctypes.data, a.size), "alego_debug_math")
+        return out
+
+    def trajectory_enable(self, capacity):
+        self._check(lib().alego_trajectory_enable(self._h, capacity), "alego_trajectory_enable")
+        self._traj_cap = capacity
+
+    def trajectory(self, slot=0, first=0, n=None):
+        """poses[n, 14] logged for `slot`: odom t(3) q(4), map t(3) q(4) per processed scan"""
+        if n is None:
+            n = min(self._check(lib().alego_trajectory_get(self._h, slot, 0, 0, None), "alego_trajectory_get"), self._traj_cap) - first
+        out = np.empty((max(n, 0), 14), np.float64)
+        self._check(lib().alego_trajectory_get(self._h, slot, first, max(n, 0), out.ctypes.data), "alego_trajectory_get")
         return out
 
     def push_imu(self, samples, slot=0):

@@ -26,6 +26,7 @@ void launch_atan2f_probe(const float* y, const float* x, float* out, int n, int 
 int launch_stdsort_probe(const uint32_t* keys, int n, int depth_limit, int* pos_out, hipStream_t st);
 void launch_lo_imu_push(const DevCtx& d, int slot, const double* smp_dev, int n, hipStream_t st);
 void launch_lo_deskew(const DevCtx& d, hipStream_t st);
+void launch_traj_log(const DevCtx& d, hipStream_t st);
 void launch_dbg_eval_blocks(int type, int n, const double* geom13, const double* params6, double* res, double* jac6, hipStream_t st);
 int icp_run(const alego_params& P, const alego_kf_in* latest, const alego_kf_in* history, int n_history, alego_icp_result* out,
             alego_point* target_out, int target_cap, hipStream_t st, std::string* err);
@@ -361,6 +362,7 @@ int alego_stream_setup(alego_handle* h, int bag, int start_scan) {
   if (!h) return ALEGO_ERR_ARG;
   if (!h->d.bag_pts || bag < 0 || bag >= h->d.n_bags || start_scan < 0) { h->err = "alego_stream_setup: needs alego_replay_create and a valid bag"; return ALEGO_ERR_ARG; }
   if (h->d.n_slots < 3 || h->streams.size() != 1) { h->err = "alego_stream_setup: the handle needs n_slots = 1 + 2 W >= 3 (one stream group)"; return ALEGO_ERR_ARG; }
+  if (h->d.traj) { h->err = "alego_stream_setup: the per-scan pose log belongs to the batch path"; return ALEGO_ERR_ARG; }
   if (h->P.deskew_mode) { h->err = "alego_stream_setup: bags carry no stamps / IMU data; the motion de-skew runs through alego_scan_process / alego_lo_process"; return ALEGO_ERR_ARG; }
   hipSetDevice(h->device);
   const int W = (h->d.n_slots - 1) / 2;
@@ -453,6 +455,7 @@ static int enqueue_scan(alego_handle* h, int slot0, int n, int pos, int stages, 
     std::vector<char> odom_valid(n);
     for (int i = 0; i < n; ++i) odom_valid[i] = h->lo_scans[slot0 + i]++ > 0;
     if (stages & 4) { if (int r = lm_host_enqueue(h->lm, d, odom_valid, &h->err)) return r; }
+    if (d.traj) launch_traj_log(d, S);
   }
   HIP_TRY(h, hipGetLastError());
   return 0;
@@ -512,6 +515,35 @@ int alego_batch_get_pose(alego_handle* h, int slot, alego_pose* odom, alego_pose
   if (int r = check_slot(h, slot)) return r;
   hipSetDevice(h->device);
   return fetch_pose(h, slot, odom, map_pose);
+}
+
+int alego_trajectory_enable(alego_handle* h, int32_t capacity_scans) {
+  if (!h || capacity_scans <= 0) return ALEGO_ERR_ARG;
+  if (h->stream_mode) { h->err = "alego_trajectory_enable: not available with alego_stream_setup (the poses of a look-ahead stream live in its lanes)"; return ALEGO_ERR_ARG; }
+  if (h->d.traj) { h->err = "alego_trajectory_enable: already enabled"; return ALEGO_ERR_ARG; }
+  hipSetDevice(h->device);
+  HIP_TRY(h, sync_all(h));
+  double* t = nullptr;
+  int* n = nullptr;
+  if (dalloc(h, &t, (size_t)h->d.n_slots * capacity_scans * 14) || dalloc(h, &n, (size_t)h->d.n_slots)) return ALEGO_ERR_HIP;
+  h->d.traj = t; h->d.traj_n = n; h->d.traj_cap = capacity_scans;
+  return 0;
+}
+int alego_trajectory_get(alego_handle* h, int slot, int32_t first, int32_t n, double* out14) {
+  if (int r = check_slot(h, slot)) return r;
+  if (!h->d.traj || first < 0 || n < 0 || (n > 0 && !out14)) return ALEGO_ERR_ARG;
+  hipSetDevice(h->device);
+  hipStream_t S = stream_of(h, slot);
+  int logged = 0;
+  HIP_TRY(h, hipMemcpyAsync(&logged, h->d.traj_n + slot, sizeof(int), hipMemcpyDeviceToHost, S));
+  HIP_TRY(h, hipStreamSynchronize(S));
+  const int have = std::min(logged, h->d.traj_cap);
+  if (first + n > have) { h->err = "alego_trajectory_get: range beyond the scans logged"; return ALEGO_ERR_ARG; }
+  if (n > 0) {
+    HIP_TRY(h, hipMemcpyAsync(out14, h->d.traj + ((size_t)slot * h->d.traj_cap + first) * 14, (size_t)n * 14 * sizeof(double), hipMemcpyDeviceToHost, S));
+    HIP_TRY(h, hipStreamSynchronize(S));
+  }
+  return logged;
 }
 
 int alego_batch_get_counts(alego_handle* h, int slot, int32_t* out, int cap) {

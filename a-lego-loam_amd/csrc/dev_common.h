@@ -124,6 +124,9 @@ struct DevCtx {
   const float4* seg_lo; // what feature extraction reads: seg_dsk when deskew_mode != 0, else seg_pts
   // ---- outputs ----
   double* poses;        // [slot][16]: odom t(3) q(4), map t(3) q(4), pad
+  double* traj;         // [slot][traj_cap][14] per-scan log of `poses` (alego_trajectory_enable), else null
+  int* traj_n;          // [slot] scans logged so far (keeps counting past traj_cap; entries beyond it are dropped)
+  int traj_cap;
 };
 #define ALEGO_IMU_Q 200   // imu_queue_length, utility.h:70
 

@@ -669,6 +669,24 @@ __global__ void __launch_bounds__(DSK_T) lo_deskew(DevCtx d) {
   if (tid == 0 && M > 0) { ptr[1] = (it0 + carry) % ALEGO_IMU_Q; ptr[2] = (it0 + carry) % ALEGO_IMU_Q; }
 }
 
+// per-scan pose log (alego_trajectory_*): what a bag replay publishes on /odom/lidar and /odom_aft_mapped, kept on the device so that
+// a batch replay needs no host synchronisation per scan
+__global__ void traj_log(DevCtx d) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= d.n_launch) return;
+  const int slot = i + d.slot0;
+  const int k = d.traj_n[slot];
+  d.traj_n[slot] = k + 1;
+  if (k >= d.traj_cap) return;
+  const double* po = d.poses + (size_t)slot * 16;
+  double* o = d.traj + ((size_t)slot * d.traj_cap + k) * 14;
+#pragma unroll
+  for (int j = 0; j < 14; ++j) o[j] = po[j];
+}
+void launch_traj_log(const DevCtx& d, hipStream_t st) {
+  hipLaunchKernelGGL(traj_log, dim3((d.n_launch + 63) / 64), dim3(64), 0, st, d);
+}
+
 void launch_lo_imu_push(const DevCtx& d, int slot, const double* smp_dev, int n, hipStream_t st) {
   hipLaunchKernelGGL(lo_imu_push, dim3(1), dim3(1), 0, st, d, slot, smp_dev, n);
 }

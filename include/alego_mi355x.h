@@ -148,6 +148,14 @@ int alego_stream_setup(alego_handle* h, int bag, int start_scan);
 int alego_stream_run(alego_handle* h, int first_step, int n_scans, int stages, int sync);
 /* poses of the last processed scan of `slot` */
 int alego_batch_get_pose(alego_handle* h, int slot, alego_pose* odom, alego_pose* map_pose);
+/* Per-scan pose log: what a bag replay publishes on /odom/lidar (laserOdometry.cpp:513-529) and /odom_aft_mapped
+ * (laserMapping.cpp:167-181) for every scan, kept on the device so that alego_batch_run needs no host synchronisation per scan
+ * (the bench-path export with a poses_out argument that SURVEY.md 8b proposes).  After alego_trajectory_enable(h, capacity) every scan a slot processes through
+ * alego_batch_run / alego_scan_process appends 14 doubles: odometry t(3) q(4: w x y z), map pose t(3) q(4).  alego_trajectory_get
+ * copies entries [first, first + n) of `slot` and returns the number of scans logged so far (entries beyond the capacity are
+ * dropped, the count keeps running). */
+int alego_trajectory_enable(alego_handle* h, int32_t capacity_scans);
+int alego_trajectory_get(alego_handle* h, int slot, int32_t first, int32_t n, double* out14);
 /* per-scan device counters of the last processed scan of `slot`:
  * out[0..] = P (valid input points), M, n_outlier, n_sharp, n_less_sharp, n_flat, n_less_flat,
  *            n_surf_corr, n_corner_corr, lm: Kraw_corner, Kraw_surf, Kds_corner, Kds_surf, Lc, Ls,

@@ -1010,6 +1010,38 @@ def test_lm_capacity_overflow_is_reported_not_written_past(params_a):
     h.close(); h2.close()
 
 
+def test_trajectory_log_equals_per_scan_poses(params_a, monkeypatch):
+    """alego_trajectory_*: the poses a batch replay logs on the device for every scan (two stream groups, no host synchronisation
+    inside the run) are the poses the per-scan entry point returns, bit for bit; entries beyond the capacity are dropped and counted."""
+    p = params_a
+    nslot, nscan = 3, 30
+    monkeypatch.setenv("ALEGO_STREAM_GROUPS", "2")
+    hb = binding.Handle(p, n_slots=nslot, ring_len=nscan)
+    monkeypatch.delenv("ALEGO_STREAM_GROUPS")
+    hb.trajectory_enable(nscan - 4)
+    for s in range(nslot):
+        for k in range(nscan):
+            hb.batch_load(s, k, synth.scan(p, k, stream=s))
+    hb.batch_run(0, nscan, stages=7)
+    for s in range(nslot):
+        tr = hb.trajectory(s)
+        assert tr.shape == (nscan - 4, 14)
+        assert lib_count(hb, s) == nscan
+        h1 = binding.Handle(p)
+        for k in range(nscan - 4):
+            _, odom, mp = h1.scan_process(synth.scan(p, k, stream=s), stages=7)
+            assert_bit_equal(tr[k, 0:3], odom["t"], f"slot {s} scan {k} odometry t")
+            assert_bit_equal(tr[k, 3:7], odom["q"], f"slot {s} scan {k} odometry q")
+            assert_bit_equal(tr[k, 7:10], mp["t"], f"slot {s} scan {k} map t")
+            assert_bit_equal(tr[k, 10:14], mp["q"], f"slot {s} scan {k} map q")
+        h1.close()
+    hb.close()
+
+
+def lib_count(h, slot):
+    return binding.lib().alego_trajectory_get(h._h, slot, 0, 0, None)
+
+
 def test_keyframe_capacity_parameters(params_a):
     """alego_params.kf_cap_surf / kf_cap_outlier size the key-frame ring and the local map (bench.py --kf-cap: 1.5 GB -> 0.26 GB per
     stream at 64x2048 / K = 200).  Capacities that hold every frame change nothing, bit for bit; capacities that do not are
