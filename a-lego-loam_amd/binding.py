@@ -250,7 +250,8 @@ class Handle:
         h = C.c_void_p()
         rc = L.alego_create(C.byref(params), device, n_slots, ring_len, C.byref(h))
         if rc != 0:
-            raise AlegoError(f"alego_create failed ({rc}): no gfx950 device / HIP error — there is no CPU fallback")
+            why = {-1: "no gfx950 device (there is no CPU fallback)", -2: "a HIP call failed", -3: "capacity", -4: "a parameter is outside the supported range (see stderr)"}.get(rc, "?")
+            raise AlegoError(f"alego_create failed ({rc}): {why}")
         self._h = h
 
     def close(self):

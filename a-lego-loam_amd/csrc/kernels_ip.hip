@@ -901,7 +901,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(8, 8))) __launch_bounds__(CC_
     if ((self_m >> k) & 1ull) d.cc_label[base + v] = fr ? s_cnt[2][k * NW + wave] + (int)__popcll(bf & below) + 1 : 0;
   };
   // clamped addresses instead of branches: the three owner loads, then the three point gathers and ranges, are in flight together
-  auto cell_of = [&](int k) -> int { return ((out_m >> k) & 1ull) ? threadIdx.x + k * CC_T : threadIdx.x; };
+  auto cell_of = [&](int k) -> int { return ((out_m >> k) & 1ull) ? threadIdx.x + k * CC_T : min((int)threadIdx.x, N - 1); };   // (images of fewer than CC_T cells exist: 1 x 720)
 #pragma unroll 1
   for (int k0 = 0; k0 < per; k0 += CB) {
     const int c0 = cell_of(k0), c1 = cell_of(k0 + 1), c2 = cell_of(k0 + 2);

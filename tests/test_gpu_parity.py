@@ -1010,6 +1010,25 @@ def test_lm_capacity_overflow_is_reported_not_written_past(params_a):
     h.close(); h2.close()
 
 
+def test_unusual_geometries_in_one_process():
+    """Tiny and odd sensors through the whole loop, one handle after the other in the same process (an out-of-bounds read of
+    cc_lds16's output phase for images of fewer than 1024 cells only faulted once another handle's memory lay next to it), and
+    geometries beyond the supported range are refused by alego_create, not run."""
+    for geom in [(16, 100), (16, 127), (16, 128), (16, 200), (4, 360), (2, 720), (1, 720), (3, 720), (1, 512), (8, 129)]:
+        p = synth.default_params(*geom)
+        h, o = binding.Handle(p), O.Oracle(p)
+        for k in range(3):
+            pts = synth.scan(p, k)
+            o.process_scan(pts)
+            h.scan_process(pts, stages=7)
+            for name in ("seg_cloud", "outlier", "less_sharp_idx", "flat_idx", "less_flat"):
+                assert_bit_equal(h.debug_get(name), o.get(name), f"{geom} scan {k} {name}")
+        h.close()
+    for geom in [(128, 512), (16, 6000)]:
+        with pytest.raises(binding.AlegoError):
+            binding.Handle(synth.default_params(*geom))
+
+
 def test_trajectory_log_equals_per_scan_poses(params_a, monkeypatch):
     """alego_trajectory_*: the poses a batch replay logs on the device for every scan (two stream groups, no host synchronisation
     inside the run) are the poses the per-scan entry point returns, bit for bit; entries beyond the capacity are dropped and counted."""
