@@ -22,7 +22,7 @@ EXPORTS = [
     "alego_ip_process", "alego_lo_process", "alego_lm_process", "alego_scan_process",
     "alego_batch_load", "alego_batch_run", "alego_synchronize", "alego_batch_get_pose", "alego_batch_get_counts",
     "alego_stream", "alego_stream_groups", "alego_profile_enable", "alego_profile_report", "alego_set_lo_params", "alego_set_lm_params", "alego_debug_get", "alego_debug_voxel", "alego_debug_atan2f",
-    "alego_lo_push_imu", "alego_trajectory_enable", "alego_trajectory_get", "alego_debug_math", "alego_debug_std_sort", "alego_debug_eval_blocks", "alego_debug_transform_to_start", "alego_debug_set_option",
+    "alego_lo_push_imu", "alego_trajectory_enable", "alego_trajectory_get", "alego_debug_check_guards", "alego_debug_math", "alego_debug_std_sort", "alego_debug_eval_blocks", "alego_debug_transform_to_start", "alego_debug_set_option",
     "alego_lm_keyframe_count", "alego_lm_get_keyframe", "alego_lm_set_keypose", "alego_lm_reset_window", "alego_lm_apply_correction",
     "alego_lm_add_keyframe", "alego_pc2_to_points", "alego_replay_create", "alego_replay_load", "alego_replay_assign",
     "alego_dist_unique_id", "alego_dist_init", "alego_dist_shutdown", "alego_stream_setup", "alego_stream_run",
@@ -146,6 +146,8 @@ def lib():
         L.alego_trajectory_get.argtypes = [C.c_void_p, C.c_int, C.c_int32, C.c_int32, C.c_void_p]
         L.alego_lo_push_imu.restype = C.c_int
         L.alego_lo_push_imu.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int32]
+        L.alego_debug_check_guards.restype = C.c_int
+        L.alego_debug_check_guards.argtypes = [C.c_char_p, C.c_int]
         L.alego_debug_std_sort.restype = C.c_int
         L.alego_debug_std_sort.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.alego_debug_math.restype = C.c_int
@@ -213,6 +215,12 @@ def dist_unique_id() -> bytes:
     return buf.raw
 
 
+def check_guards():
+    """(count, report) of damaged allocation guards; count = -1 unless ALEGO_DEBUG_CANARY is set"""
+    buf = C.create_string_buffer(4096)
+    return lib().alego_debug_check_guards(buf, 4096), buf.value.decode(errors="replace")
+
+
 def loop_detect(params, keyposes6, stamps, cur_xyz):
     """detectLoopClosure's closest_history_frame_id_ (host code of the library; -1 = no candidate)"""
     kp = np.ascontiguousarray(keyposes6, np.float32).reshape(-1, 6)
@@ -256,8 +264,11 @@ class Handle:
 
     def close(self):
         if getattr(self, "_h", None):
+            bad, rep = check_guards()   # (ALEGO_DEBUG_CANARY=1: did a kernel write outside a buffer?  -1 = not enabled)
             lib().alego_destroy(self._h)
             self._h = None
+            if bad > 0:
+                raise AlegoError(f"device memory guards damaged: {rep}")
 
     def __del__(self):
         self.close()

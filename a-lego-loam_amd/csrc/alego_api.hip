@@ -13,6 +13,7 @@
 
 #include "../../include/alego_mi355x.h"
 #include "dev_common.h"
+#include "guard_alloc.h"
 #include "lm_host.h"
 #include "prof.h"
 #include "voxel.h"
@@ -79,7 +80,7 @@ int dalloc(alego_handle* h, T** p, size_t count, bool zero = true) {
   void* q = nullptr;
   size_t bytes = count * sizeof(T);
   if (bytes == 0) bytes = sizeof(T);
-  hipError_t e = hipMalloc(&q, bytes);
+  hipError_t e = guard_malloc(&q, bytes);
   if (e != hipSuccess) { h->err = std::string("hipMalloc: ") + hipGetErrorString(e); return ALEGO_ERR_HIP; }
   h->allocs.push_back(q);
   if (zero) { e = hipMemset(q, 0, bytes); if (e != hipSuccess) { h->err = "hipMemset failed"; return ALEGO_ERR_HIP; } }
@@ -304,7 +305,7 @@ void alego_destroy(alego_handle* h) {
   (void)sync_all(h);
   if (g_prof == &h->prof) g_prof = nullptr;
   if (h->lm) lm_host_destroy(h->lm);
-  for (void* p : h->allocs) hipFree(p);
+  for (void* p : h->allocs) (void)guard_free(p);
   for (hipStream_t s : h->streams) hipStreamDestroy(s);
   if (h->s_lo) hipStreamDestroy(h->s_lo);
   if (h->s_lm) hipStreamDestroy(h->s_lm);
@@ -853,6 +854,13 @@ int alego_debug_transform_to_start(alego_handle* h, const double* params6, const
   return 0;
 }
 
+int alego_debug_check_guards(char* report, int cap) {
+  std::string r;
+  const int bad = guard_check(&r);
+  if (report && cap > 0) { std::strncpy(report, r.c_str(), (size_t)cap - 1); report[cap - 1] = 0; }
+  return bad;
+}
+
 int alego_debug_set_option(alego_handle* h, const char* name, int value) {
   if (!h || !name) return ALEGO_ERR_ARG;
   const std::string s(name);
@@ -863,6 +871,7 @@ int alego_debug_set_option(alego_handle* h, const char* name, int value) {
   else if (s == "ALEGO_LO_BOX_LDS") d.opt_lo_box_lds = value;
   else if (s == "ALEGO_MAP_MERGE") { if (int r = lm_host_set_map_merge(h->lm, value != 0, &h->err)) return r; d.opt_map_merge = value != 0; }
   else if (s == "ALEGO_IP_FAST") d.ip_fast = h->ip_fast_capable & value;
+  else if (s == "ALEGO_POKE_GUARD") { HIP_TRY(h, hipMemset(d.scal + (size_t)d.n_slots * SC_COUNT + value, 0xFF, 4)); }   // tests of the guard pages: a write `value` ints past the end of an array
   else if (s == "ALEGO_SHARD_SLICE") return lm_host_debug_slice(h->lm, value & 0xff, value >> 8, &h->err);   // tests: rank | world << 8 without a communicator
   else { h->err = "unknown option " + s; return ALEGO_ERR_ARG; }
   return 0;

@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "voxel.h"
+#include "guard_alloc.h"
 #include "prof.h"
 
 typedef unsigned long long u64;
@@ -548,7 +549,7 @@ int vox_create(VoxCtx* V, const VoxJob* jobs, int njobs, std::string* err) {
   if (total > 0x7fffffffull) { *err = "vox_create: scratch exceeds 2^31 elements"; return -3; }
   V->njobs = njobs; V->total = (unsigned)total;
   hipError_t e = hipSuccess;
-  auto A = [&](void** p, size_t bytes) { if (e == hipSuccess) { e = hipMalloc(p, bytes ? bytes : 16); if (e == hipSuccess) e = hipMemset(*p, 0, bytes ? bytes : 16); } };
+  auto A = [&](void** p, size_t bytes) { if (e == hipSuccess) { e = guard_malloc(p, bytes ? bytes : 16); if (e == hipSuccess) e = hipMemset(*p, 0, bytes ? bytes : 16); } };
   A((void**)&V->jobs, sizeof(VoxJob) * njobs);
   A((void**)&V->bbox, (size_t)njobs * 8 * 4);
   A((void**)&V->keys, total * 4); A((void**)&V->pairs_a, total * 8); A((void**)&V->pairs_b, total * 8);
@@ -561,7 +562,7 @@ int vox_create(VoxCtx* V, const VoxJob* jobs, int njobs, std::string* err) {
 
 void vox_destroy(VoxCtx* V) {
   void* ps[] = {V->jobs, V->bbox, V->keys, V->pairs_a, V->pairs_b, V->list_small, V->list_big, V->cnt};
-  for (void* p : ps) if (p) (void)hipFree(p);
+  for (void* p : ps) if (p) (void)guard_free(p);
   std::memset(V, 0, sizeof(*V));
 }
 

@@ -1,5 +1,6 @@
 // lm_host.hip — LaserMapping: HBM allocation and kernel sequencing (no numerics here).
 #include "lm_host.h"
+#include "guard_alloc.h"
 
 #include <cstdio>
 #include <cstdlib>
@@ -48,7 +49,7 @@ bool A(LmHost* lm, T** p, size_t count, std::string* err) {
   void* q = nullptr;
   size_t bytes = count * sizeof(T);
   if (bytes == 0) bytes = 16;
-  hipError_t e = hipMalloc(&q, bytes);
+  hipError_t e = guard_malloc(&q, bytes);
   if (e == hipSuccess) e = hipMemset(q, 0, bytes);
   if (e != hipSuccess) { *err = std::string("lm hipMalloc: ") + hipGetErrorString(e); return false; }
   lm->allocs.push_back(q);
@@ -161,7 +162,7 @@ void lm_host_destroy(LmHost* lm) {
   for (auto& v : lm->vm) vox_destroy(&v);
   for (auto& v : lm->v2) vox_destroy(&v);
   for (auto& v : lm->vk) vox_destroy(&v);
-  for (void* p : lm->allocs) (void)hipFree(p);
+  for (void* p : lm->allocs) (void)guard_free(p);
   delete lm;
 }
 

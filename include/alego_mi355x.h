@@ -212,6 +212,10 @@ int alego_debug_math(alego_handle* h, int mode, const float* a, const float* b, 
 int alego_debug_eval_blocks(alego_handle* h, int type, int n, const double* geom13, const double* params6, double* res, double* jac6);
 /* transformToStart (laserOdometry.cpp:728-740) of n points with LaserOdometry params_ = params6, as lo_assoc applies it */
 int alego_debug_transform_to_start(alego_handle* h, const double* params6, const alego_point* pts, int n, alego_point* out);
+/* development aid: with ALEGO_DEBUG_CANARY=1 in the environment every device allocation of the library is framed by 4 KB guard
+ * pages of a known pattern; returns how many allocations have a damaged guard (0 = none, -1 = guards not enabled) and describes
+ * them in `report` */
+int alego_debug_check_guards(char* report, int cap);
 /* Run-time switches of kernel variants (parity tests run both variants of a kernel inside one process).  Read once from
  * the environment at alego_create (ALEGO_CC_FUSED, ALEGO_FE_PICK1, ALEGO_LO_BOX_LDS, ALEGO_MAP_MERGE, ALEGO_IP_FAST); this
  * call overrides one of them by its environment name.  Not a hot-path call. */

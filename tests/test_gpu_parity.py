@@ -1010,6 +1010,26 @@ def test_lm_capacity_overflow_is_reported_not_written_past(params_a):
     h.close(); h2.close()
 
 
+def test_allocation_guards_detect_a_stray_write():
+    """ALEGO_DEBUG_CANARY=1 frames every device allocation with guard pages; a write one int past an array is reported, a clean run
+    is not.  (The whole -m gpu suite was run once under the guards: no kernel writes outside its buffers.)"""
+    import os, subprocess, sys
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "from alego_loader import load_package; load_package()\n"
+        "from alego_amd import binding, synth\n"
+        "p = synth.default_params(16, 1800)\n"
+        "h = binding.Handle(p)\n"
+        "for k in range(4): h.scan_process(synth.scan(p, k), stages=7)\n"
+        "print('clean', binding.check_guards()[0])\n"
+        "h.set_option('ALEGO_POKE_GUARD', 0)\n"
+        "print('poked', binding.check_guards()[0])\n"
+    ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ALEGO_DEBUG_CANARY="1")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+    assert "clean 0" in r.stdout and "poked 1" in r.stdout, (r.stdout, r.stderr[-500:])
+
+
 def test_unusual_geometries_in_one_process():
     """Tiny and odd sensors through the whole loop, one handle after the other in the same process (an out-of-bounds read of
     cc_lds16's output phase for images of fewer than 1024 cells only faulted once another handle's memory lay next to it), and
