@@ -309,7 +309,7 @@ def _lm_compare(h, o, k, tag):
         ncur = gi[19]
         qc = np.nonzero(blocks[:ncur, 7] != 0)[0]
         assert_bit_equal(qc.astype(np.int32), o.get("lm_corner_corr_q"), f"{tag} accepted corner queries")
-        kf_cap_c = 120 * h.params.n_scan
+        kf_cap_c = h.params.n_less_sharp * h.params.n_sectors * h.params.n_scan   # capacity of laser_corner_ds_ = of corner_last (lm_host.hip)
         qs = np.nonzero(blocks[kf_cap_c:kf_cap_c + gi[23], 7] != 0)[0]
         assert_bit_equal(qs.astype(np.int32), o.get("lm_surf_corr_q"), f"{tag} accepted surf queries")
         st = h.debug_get("lm_state")
@@ -347,6 +347,75 @@ def test_full_loop_teacher_forced(geom, nscan, mods):
         assert np.abs(mp["t"] - want[:3]).max() < POSE_TOL, (k, mp["t"], want[:3])
         assert quat_angle(mp["q"], want[3:]) < POSE_TOL
     assert o.get("lm_info")[11] >= 3 or geom[0] == 64 or mods
+    h.close()
+
+
+def _random_params(seed):
+    """a parameter set drawn inside the ranges alego_create accepts, on a small sensor (seeded: the test is deterministic)"""
+    rng = np.random.default_rng(seed)
+    ns = int(rng.choice([5, 8, 12, 16, 24]))
+    hs = int(rng.choice([360, 500, 720, 900, 1200]))
+    p = synth.default_params(ns, hs)
+    p.n_sectors = int(rng.integers(max(1, -(-hs // 766)), 9))   # (a sector holds at most 768 points: alego_create refuses more)
+    p.sector_formula = int(rng.integers(0, 2))
+    p.suppress_radius = int(rng.integers(0, 6))
+    p.suppress_col_diff = int(rng.integers(3, 15))
+    p.n_sharp = int(rng.integers(1, 5))
+    p.n_less_sharp = int(rng.integers(p.n_sharp, 26))
+    p.n_flat = int(rng.integers(1, 7))
+    p.edge_thres = float(rng.choice([0.05, 0.1, 0.3]))
+    p.surf_thres = float(rng.choice([0.05, 0.1, 0.2]))
+    p.occl_f32 = int(rng.integers(0, 2))
+    p.occl_col_diff = int(rng.integers(5, 15))
+    p.less_flat_leaf = float(rng.choice([0.2, 0.4, 0.6]))
+    p.near_filter = int(rng.integers(0, 2))
+    p.ground_scan_id = int(rng.integers(1, ns))
+    p.seg_valid_point_num = int(rng.integers(3, 8))
+    p.seg_valid_line_num = int(rng.integers(2, 4))
+    p.seg_big_num = int(rng.integers(15, 40))
+    p.ring_window = int(rng.integers(1, 4))
+    p.lo_iters_surf = int(rng.integers(2, 7))
+    p.lo_iters_corner = int(rng.integers(2, 11))
+    p.lo_min_corr = int(rng.integers(5, 15))
+    p.huber_delta = float(rng.choice([0.05, 0.1, 0.2]))
+    p.recent_keyframe_num = int(rng.integers(1, 7))
+    p.min_keyframe_dist = float(rng.choice([0.01, 0.04, 0.09, 0.25]))
+    p.lm_every = int(rng.integers(1, 4))
+    p.lm_outer_iters = int(rng.integers(1, 3))
+    p.lm_max_iters = int(rng.integers(4, 21))
+    p.lm_leaf_corner = float(rng.choice([0.2, 0.4, 0.6]))
+    p.lm_leaf_surf = float(rng.choice([0.4, 0.8, 1.2]))
+    p.lm_leaf_outlier = float(rng.choice([0.5, 1.0]))
+    p.knn_max_dist = float(rng.choice([1.0, 2.0]))
+    p.lm_min_corner = int(rng.integers(3, 12))
+    p.lm_min_surf = int(rng.integers(20, 110))
+    p.lm_min_map_corner = int(rng.integers(3, 12))
+    p.sort_mode = int(rng.choice([0, 2]))
+    return p
+
+
+@pytest.mark.parametrize("seed", list(range(1, 17)))
+def test_random_parameter_sets_teacher_forced(seed):
+    """Sixteen seeded draws from the whole parameter space (sensor size, sector / pick / suppression counts, thresholds, leaf sizes,
+    iteration budgets, window size, mapping cadence, tie order): IP -> LO -> LM against the oracle, teacher-forced, 14 scans each."""
+    p = _random_params(seed)
+    h, o = binding.Handle(p), O.Oracle(p)
+    for k in range(14):
+        pts = synth.scan(p, k)
+        h.set_lo_params(o.get("lo_params"))
+        h.set_lm_params(o.get("lm_params"))
+        o.process_scan(pts)
+        flags, odom, mp, seg, feat = h.scan_process(pts, stages=7, want_outputs=True)
+        tag = f"seed {seed} ({p.n_scan}x{p.horizon_scan}) scan {k}"
+        assert_bit_equal(seg["seg"], o.get("seg_cloud"), f"{tag} segmented cloud")
+        assert_bit_equal(seg["outlier"], o.get("outlier"), f"{tag} outliers")
+        _fe_compare(h, o, feat, tag)
+        if k == 0:
+            continue
+        np.testing.assert_allclose(odom["params"], o.get("lo_params"), rtol=0, atol=1e-7, err_msg=tag)
+        _lm_compare(h, o, k, tag)
+        want = o.get("map_pose")
+        assert np.abs(mp["t"] - want[:3]).max() < POSE_TOL and quat_angle(mp["q"], want[3:]) < POSE_TOL, tag
     h.close()
 
 
