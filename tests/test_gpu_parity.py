@@ -1079,6 +1079,48 @@ def test_lm_capacity_overflow_is_reported_not_written_past(params_a):
     h.close(); h2.close()
 
 
+@pytest.mark.parametrize("dense", [0, 1])
+def test_non_finite_zero_and_denormal_points(params_a, dense):
+    """Scans with inf / -inf / NaN coordinates, points at the origin, signed zeros, denormals and points scaled down to 1e-20 m
+    sprinkled in (also as the first and last point, which the orientation block reads), as a dense and as a non-dense message:
+    the whole loop against the oracle.  (Finite coordinates beyond ~200 km are outside the contract: the reference's own
+    VoxelGrid arithmetic overflows there — tests/diagnostics/special_values_probe.py.)"""
+    rng = np.random.default_rng(3)
+    p = params_a.copy()
+    p.input_is_dense = dense
+    h, o = binding.Handle(p), O.Oracle(p)
+    specials = np.array([np.inf, -np.inf, np.nan, 0.0, -0.0, 1e-40, 1e-30], np.float32)
+    for k in range(5):
+        pts = synth.scan(p, k).copy()
+        idx = rng.choice(len(pts), 400, replace=False)
+        for j, i in enumerate(idx):
+            c = j % 7
+            if c < 3:
+                pts[i, c] = specials[rng.integers(len(specials))]
+            elif c == 3:
+                pts[i, :3] = 0.0
+            elif c == 4:
+                pts[i, :3] = specials[rng.integers(len(specials))]
+            elif c == 5:
+                pts[i, 2] = specials[rng.integers(len(specials))]; pts[i, 0] = 0.0; pts[i, 1] = 0.0
+            else:
+                pts[i, :3] *= np.float32(1e-20)
+        if k == 0:
+            pts[0, :3] = 0.0
+            pts[-1, 0] = np.inf
+        o.process_scan(pts)
+        flags, odom, mp, seg, feat = h.scan_process(pts, stages=7, want_outputs=True)
+        tag = f"dense={dense} scan {k}"
+        assert_bit_equal(seg["seg"], o.get("seg_cloud"), f"{tag} segmented cloud")
+        assert_bit_equal(seg["outlier"], o.get("outlier"), f"{tag} outliers")
+        assert_bit_equal(seg["orientation"], o.get("orientation"), f"{tag} orientation")
+        _fe_compare(h, o, feat, tag)
+        if k:
+            want = o.get("map_pose")
+            assert np.abs(mp["t"] - want[:3]).max() < POSE_TOL and quat_angle(mp["q"], want[3:]) < POSE_TOL, tag
+    h.close()
+
+
 def test_allocation_guards_detect_a_stray_write():
     """ALEGO_DEBUG_CANARY=1 frames every device allocation with guard pages; a write one int past an array is reported, a clean run
     is not.  (The whole -m gpu suite was run once under the guards: no kernel writes outside its buffers.)"""
