@@ -321,11 +321,11 @@ int alego_synchronize(alego_handle* h) {
 
 int alego_batch_load(alego_handle* h, int slot, int ring_pos, const alego_point* pts, int32_t n) {
   if (int r = check_slot(h, slot)) return r;
-  if (ring_pos < 0 || ring_pos >= h->d.ring_len || n < 0) { h->err = "ring_pos/n out of range"; return ALEGO_ERR_ARG; }
+  if (ring_pos < 0 || ring_pos >= h->d.ring_len || n < 0 || (n > 0 && !pts)) { h->err = "ring_pos / n out of range or null points"; return ALEGO_ERR_ARG; }
   if (n > h->d.Pcap) { h->err = "scan larger than n_scan*horizon_scan"; return ALEGO_ERR_CAPACITY; }
   hipSetDevice(h->device);
   float4* dst = h->d.in_pts + ((size_t)slot * h->d.ring_len + ring_pos) * h->d.Pcap;
-  HIP_TRY(h, hipMemcpyAsync(dst, pts, (size_t)n * sizeof(alego_point), hipMemcpyHostToDevice, stream_of(h, slot)));
+  if (n > 0) HIP_TRY(h, hipMemcpyAsync(dst, pts, (size_t)n * sizeof(alego_point), hipMemcpyHostToDevice, stream_of(h, slot)));
   HIP_TRY(h, hipMemcpyAsync(h->d.in_n + slot * h->d.ring_len + ring_pos, &n, sizeof(int), hipMemcpyHostToDevice, stream_of(h, slot)));
   HIP_TRY(h, hipStreamSynchronize(stream_of(h, slot)));
   return 0;
@@ -463,7 +463,7 @@ static int enqueue_scan(alego_handle* h, int slot0, int n, int pos, int stages, 
 }
 
 int alego_batch_run(alego_handle* h, int first_pos, int n_scans, int stages, int sync) {
-  if (!h) return ALEGO_ERR_ARG;
+  if (!h || n_scans < 0) return ALEGO_ERR_ARG;
   hipSetDevice(h->device);
   const int R = h->d.ring_len;
   if (h->P.deskew_mode && (stages & 2)) { h->err = "alego_batch_run: the motion de-skew needs every scan's stamp (alego_scan_process / alego_lo_process)"; return ALEGO_ERR_ARG; }

@@ -16,7 +16,7 @@ for dense in (0, 1):
         pts = synth.scan(p, k).copy()
         n = len(pts)
         idx = rng.choice(n, 400, replace=False)
-        specials = np.array({'nonfinite': [np.inf, -np.inf, np.nan, 0.0, -0.0, 1e-40, 1e-30], 'huge': [1e30, -1e30, 1e19, 3.4e38], 'large': [1e6, -1e6, 3e5, 1e7]}[sys.argv[1]], np.float32)
+        specials = np.array({'nonfinite': [np.inf, -np.inf, np.nan, 0.0, -0.0, 1e-40, 1e-30], 'huge': [1e30, -1e30, 1e19, 3.4e38], 'large': [1e6, -1e6, 3e5, 1e7], 'km': [5000.0, -3000.0, 8000.0, 20000.0]}[sys.argv[1]], np.float32)
         for j, i in enumerate(idx):
             c = j % 7
             if c < 3:

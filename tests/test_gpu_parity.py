@@ -1121,6 +1121,52 @@ def test_non_finite_zero_and_denormal_points(params_a, dense):
     h.close()
 
 
+def test_api_misuse_returns_error_codes(params_a):
+    """Bad slots, ring positions, counts, null pointers, calls out of order: every one comes back as a negative ALEGO_ERR_* code (the
+    C ABI never throws or faults), and the handle keeps working afterwards."""
+    import ctypes as C
+    L = binding.lib()
+    p = params_a
+    h = binding.Handle(p, n_slots=3, ring_len=2)
+    H = h._h
+    pts = synth.scan(p, 0)
+    big = np.zeros((p.n_scan * p.horizon_scan + 10, 4), np.float32)
+    odom, mp, kf = binding.Pose(), binding.Pose(), binding.KeyFrame()
+    bad = {
+        "batch_load slot=-1": L.alego_batch_load(H, -1, 0, pts.ctypes.data, len(pts)),
+        "batch_load slot=3": L.alego_batch_load(H, 3, 0, pts.ctypes.data, len(pts)),
+        "batch_load ring position 2 of 2": L.alego_batch_load(H, 0, 2, pts.ctypes.data, len(pts)),
+        "batch_load n > capacity": L.alego_batch_load(H, 0, 0, big.ctypes.data, len(big)),
+        "batch_load n < 0": L.alego_batch_load(H, 0, 0, pts.ctypes.data, -5),
+        "batch_load null points": L.alego_batch_load(H, 0, 0, None, 10),
+        "batch_run n_scans < 0": L.alego_batch_run(H, 0, -1, 7, 1),
+        "batch_run bag replay without bags": L.alego_batch_run(H, 0, 1, 7 | binding.REPLAY_BAG, 1),
+        "batch_get_pose slot=7": L.alego_batch_get_pose(H, 7, C.byref(odom), C.byref(mp)),
+        "scan_process null input": L.alego_scan_process(H, 0, None, 7, None, None, None, None),
+        "lm_keyframe_count slot=9": L.alego_lm_keyframe_count(H, 9),
+        "lm_get_keyframe before any key frame": L.alego_lm_get_keyframe(H, 0, -1, C.byref(kf)),
+        "lm_set_keypose unknown id": L.alego_lm_set_keypose(H, 0, 99, (C.c_float * 6)()),
+        "lm_apply_correction null": L.alego_lm_apply_correction(H, 0, None),
+        "replay_create 0 bags": L.alego_replay_create(H, 0, 10),
+        "replay_assign before create": L.alego_replay_assign(H, 0, 0, 0),
+        "stream_setup without bags": L.alego_stream_setup(H, 0, 0),
+        "trajectory_get before enable": L.alego_trajectory_get(H, 0, 0, 1, None),
+        "debug_get unknown name": L.alego_debug_get(H, 0, b"no_such_thing", None, 0, None, None),
+        "set_option unknown": L.alego_debug_set_option(H, b"NOPE", 1),
+        "lo_push_imu n < 0": L.alego_lo_push_imu(H, 0, None, -1),
+        "null handle": L.alego_batch_run(None, 0, 1, 7, 1),
+    }
+    assert all(rc < 0 for rc in bad.values()), {k: v for k, v in bad.items() if v >= 0}
+    assert L.alego_batch_load(H, 0, 0, None, 0) == 0                      # an empty scan is a scan
+    assert L.alego_batch_get_pose(H, 0, None, None) >= 0                  # outputs are optional
+    h2 = binding.Handle(p)
+    for k in range(3):
+        a = h.scan_process(synth.scan(p, k), stages=7)
+        b = h2.scan_process(synth.scan(p, k), stages=7)
+    assert_bit_equal(a[2]["params"], b[2]["params"], "the handle after the misuse")
+    h.close(); h2.close()
+
+
 def test_allocation_guards_detect_a_stray_write():
     """ALEGO_DEBUG_CANARY=1 frames every device allocation with guard pages; a write one int past an array is reported, a clean run
     is not.  (The whole -m gpu suite was run once under the guards: no kernel writes outside its buffers.)"""
