@@ -416,6 +416,23 @@ int lm_host_add_keyframe(LmHost* lm, const DevCtx& dfull, int slot, const float*
   float kp[8] = {pose6[0], pose6[1], pose6[2], pose6[3], pose6[4], pose6[5], 0.f, 0.f};
   const int cnt[4] = {nc, ns, no, 0};
   int* li = L.li + (size_t)slot * LI_COUNT;
+  {
+    // A full window advances by ONE frame per mapping frame (pop the oldest, push the newest, laserMapping.cpp:224-237): it keeps its
+    // K - 1 other frames however many frames were added in between, and falls behind the newest frames by one for every extra frame.
+    // The device holds the K + 1 newest frames, so the window may lag by one: the frame inserted here (id nkf) is refused when the
+    // oldest frame the next window still needs, rec[1], would no longer be among the K + 1 newest, i.e. rec[1] < nkf - K.
+    int rec_cnt = 0;
+    if (hipMemcpy(&rec_cnt, li + LI_REC_CNT, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) { *err = "add_keyframe: device read failed"; return ALEGO_ERR_HIP; }
+    if (rec_cnt >= L.K && L.K >= 2) {
+      int rec1 = 0;
+      if (hipMemcpy(&rec1, L.rec + (size_t)slot * L.K + 1, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) { *err = "add_keyframe: device read failed"; return ALEGO_ERR_HIP; }
+      if (rec1 < nkf - L.K) {
+        *err = "add_keyframe: the full local-map window already lags one frame behind the newest key frames (it advances by one frame per mapping frame); "
+               "insert at most one extra key frame per window length, or call alego_lm_reset_window first (the window is then rebuilt from the newest frames)";
+        return ALEGO_ERR_CAPACITY;
+      }
+    }
+  }
   const int nkf1 = nkf + 1, one = 1;
   hipError_t e = hipMemcpy(L.kf_pose + rs * 8, kp, sizeof(kp), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(L.kf_cnt + rs * 4, cnt, sizeof(cnt), hipMemcpyHostToDevice);
@@ -496,6 +513,7 @@ int lm_host_debug_get(LmHost* lm, int slot, const char* name, void* out, int cap
   else if (s == "lm_surf_total_ds") set(L.cur_total_ds + b * L.total_cap, (size_t)li[LI_NTOTAL_DS] * 4, 0);
   else if (s == "lm_blocks") set(L.blocks + b * L.qcap * 8, (size_t)L.qcap * 8, 1);
   else if (s == "lm_keyposes") set(L.kf_pose + b * L.KR * 8, (size_t)L.KR * 8, 0);
+  else if (s == "lm_window") set(L.rec + b * L.K, (size_t)li[LI_REC_CNT], 2);   // frame ids of recent_*_keyframes_
   else if (s == "lm_kf_corner_map" || s == "lm_kf_surf_map") {   // newest key frame in the map frame, sorted by voxel key (surf = surf + outlier)
     const int nkf = li[LI_NKF];
     if (nkf <= 0) { *count = 0; *dtype = 0; return 0; }

@@ -247,7 +247,10 @@ int alego_lm_reset_window(alego_handle* h, int slot);
 /* correctPoses (:579-580): q_map2odom <- R q_map2odom, t_map2odom <- R t_map2odom + c, with the row-major 3x4 [R | c] */
 int alego_lm_apply_correction(alego_handle* h, int slot, const double rc[12]);
 /* push_back a key frame from host data (clouds in the sensor frame + pose): restores a saved session or lets the host
- * pose graph insert a frame; equivalent to :531-555 with the given pose and clouds */
+ * pose graph insert a frame; equivalent to :531-555 with the given pose and clouds.  The device keeps the recent_keyframe_num + 1
+ * newest frames.  A FULL window only advances by one frame per mapping frame (:224-237) and so falls behind the newest frames by
+ * one for every extra frame inserted; it may lag by one.  An insertion that would make it lag further returns ALEGO_ERR_CAPACITY —
+ * call alego_lm_reset_window first when inserting in bulk (the window is then rebuilt from the newest frames, :208-223). */
 int alego_lm_add_keyframe(alego_handle* h, int slot, const float pose6[6], const alego_point* corner, int32_t n_corner,
                           const alego_point* surf, int32_t n_surf, const alego_point* outlier, int32_t n_outlier);
 

@@ -1035,6 +1035,67 @@ def test_keyframe_pass_through_and_pose_correction(params_a):
     h.close()
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_random_keyframe_operations(params_a, seed):
+    """A host pose graph poking at the key frames at arbitrary moments: seeded random sequences of alego_lm_set_keypose (single
+    frames, without clearing the window — the reference's deques then keep the stale transformed clouds until the frame is
+    re-transformed), reset_window, apply_correction and add_keyframe between the scans of a teacher-forced run; after every
+    operation the next mapping frames' maps, correspondences and poses must match the oracle doing the same."""
+    rng = np.random.default_rng(100 + seed)
+    p = params_a.copy()
+    p.recent_keyframe_num = int(rng.integers(3, 8))
+    p.min_keyframe_dist = 0.09
+    h, o = binding.Handle(p), O.Oracle(p)
+    ops = refused = 0
+    history = []
+    for k in range(70):
+        pts = synth.scan(p, k)
+        h.set_lo_params(o.get("lo_params"))
+        h.set_lm_params(o.get("lm_params"))
+        o.process_scan(pts)
+        flags, odom, mp = h.scan_process(pts, stages=7)
+        if k == 0:
+            continue
+        tag = f"seed {seed} scan {k} after {history[-4:]}"
+        _lm_compare(h, o, k, tag)
+        want = o.get("map_pose")
+        assert np.abs(mp["t"] - want[:3]).max() < POSE_TOL and quat_angle(mp["q"], want[3:]) < POSE_TOL, tag
+        nkf = h.lm_keyframe_count()
+        if nkf < 2 or rng.random() > 0.35:
+            continue
+        ops += 1
+        op = int(rng.integers(0, 4))
+        history.append((k, ("set_all+reset", "reset", "correction", "add")[op], nkf))
+        poses = o.get("lm_keyposes").reshape(-1, 6).copy()
+        if op == 0:      # correctPoses-like: rewrite every resident key pose, clear the window (:563-578)
+            d = rng.normal(0, 0.05, 6).astype(np.float32) * np.array([1, 1, 0.2, 0.1, 0.1, 0.3], np.float32)
+            for i in range(nkf):
+                q = (poses[i] + d).astype(np.float32)
+                o.lm_set_keypose(i, q)
+                if i >= nkf - p.recent_keyframe_num:
+                    h.lm_set_keypose(i, q)
+            o.lm_reset_window(); h.lm_reset_window()
+        elif op == 1:    # only the window is cleared
+            o.lm_reset_window(); h.lm_reset_window()
+        elif op == 2:    # map -> odom correction alone (:579-580)
+            a = float(rng.normal(0, 0.01))
+            rc = np.array([[np.cos(a), -np.sin(a), 0, rng.normal(0, 0.05)], [np.sin(a), np.cos(a), 0, rng.normal(0, 0.05)], [0, 0, 1, rng.normal(0, 0.01)]])
+            o.lm_apply_correction(rc); h.lm_apply_correction(rc)
+        else:            # a frame inserted by the host: a copy of an older frame at a shifted pose
+            src = int(rng.integers(max(0, nkf - p.recent_keyframe_num), nkf))
+            c, s_, ol = o.lm_keyframe(src)
+            q = poses[src].copy(); q[:2] += rng.normal(0, 0.3, 2).astype(np.float32)
+            try:
+                h.lm_add_keyframe(q, c, s_, ol)
+            except binding.AlegoError:      # full window, two frames already waiting for the next mapping frame (see alego_mi355x.h)
+                refused += 1
+                continue
+            o.lm_add_keyframe(q, c, s_, ol)
+            assert h.lm_keyframe_count() == nkf + 1
+    assert ops >= 10
+    h.close()
+
+
 def test_is_dense_messages_keep_nan_points(params_a):
     """pcl::removeNaNFromPointCloud is a plain copy for is_dense == true (SURVEY C.11): NaN returns then stay in the cloud, count
     as first / last point of the orientation block and are rejected by the row test."""
