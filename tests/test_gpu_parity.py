@@ -743,6 +743,44 @@ def test_batch_stream_groups_are_repeatable(params_a, monkeypatch):
                 assert_bit_equal(a, b, f"run {rep} slot {s} {what}")
 
 
+@pytest.mark.parametrize("seed,nslot,groups", [(1, 7, 3), (2, 5, 2), (3, 9, 4)])
+def test_batch_of_ragged_streams_equals_single_handles(params_a, seed, nslot, groups, monkeypatch):
+    """Slots whose streams misbehave differently — empty scans, scans cut short, NaN returns, a slot that starts a scan later than
+    the others — advanced together on several HIP streams: every slot ends with the bits a handle of its own produces."""
+    rng = np.random.default_rng(seed)
+    p = params_a
+    nscan = 26
+    seqs = []
+    for s in range(nslot):
+        seq = []
+        for k in range(nscan):
+            pts = synth.scan(p, k + (1 if s % 3 == 2 else 0), stream=s, flags=int(rng.integers(0, 4)) if rng.random() < 0.3 else 0)
+            r = rng.random()
+            if r < 0.08:
+                pts = pts[:0]
+            elif r < 0.2:
+                pts = pts[: int(rng.integers(1, len(pts)))]
+            seq.append(pts)
+        seqs.append(seq)
+    monkeypatch.setenv("ALEGO_STREAM_GROUPS", str(groups))
+    hb = binding.Handle(p, n_slots=nslot, ring_len=nscan)
+    monkeypatch.delenv("ALEGO_STREAM_GROUPS")
+    for s in range(nslot):
+        for k in range(nscan):
+            hb.batch_load(s, k, seqs[s][k])
+    hb.batch_run(0, nscan, stages=7)
+    for s in range(nslot):
+        h1 = binding.Handle(p)
+        for k in range(nscan):
+            _, odom1, mp1 = h1.scan_process(seqs[s][k], stages=7)
+        _, odomb, mpb = hb.batch_get_pose(s)
+        assert_bit_equal(odomb["t"], odom1["t"], f"seed {seed} slot {s} odometry")
+        assert_bit_equal(mpb["params"], mp1["params"], f"seed {seed} slot {s} LM params_")
+        assert_bit_equal(hb.debug_get("lm_surf_map_ds", slot=s), h1.debug_get("lm_surf_map_ds"), f"seed {seed} slot {s} surf map")
+        h1.close()
+    hb.close()
+
+
 def test_batch_with_slots_out_of_phase(params_a):
     """One slot has seen an extra scan before the batch starts: its mapping frames fall on the other slots' skipped frames
     (the host cannot skip launches any more, the device-side gates decide per slot).  Every slot still equals a handle of its own."""
