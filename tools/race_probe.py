@@ -5,7 +5,7 @@ import numpy as np
 from alego_loader import load_package; load_package()
 from alego_amd import binding, synth
 p = synth.default_params(16, 1800)
-nslot, nscan = 5, int(sys.argv[1]) if len(sys.argv) > 1 else 80
+nslot, nscan = int(os.environ.get("PROBE_SLOTS", "5")), int(sys.argv[1]) if len(sys.argv) > 1 else 80
 os.environ["ALEGO_STREAM_GROUPS"] = sys.argv[2] if len(sys.argv) > 2 else "3"
 scans = [[synth.scan(p, k, stream=s) for k in range(nscan)] for s in range(nslot)]
 def run():
