@@ -407,77 +407,6 @@ DEV_INLINE void ccl_union(int* parent, int a, int b) {
     }
   } while (repeat);
 }
-// Images too large for one workgroup's LDS (more than 16 rings with more than CC_LDS_MAXN cells: 64x2048): two-level labelling.
-// cc_tile: a workgroup takes a band of columns that fits LDS (<= CC_TILE_CELLS cells, all rows), runs the same union-find as
-// cc_lds on it — right-edges that stay inside the band, all down-edges — and writes every cell's band root (as a global linear index;
-// row-major order inside a band is the global order restricted to it, so the band root is the minimum global index of the piece).
-// cc_seam: the right-edges that cross a band boundary (incl. the wrap-around column) are linked with the global-memory union
-// (cc_union, as cc_link did for EVERY right-edge: NS x bands edges instead of ~N / 4).  cc_stats then resolves every cell to
-// its final root with a read-only find whose chains are at most a few band roots long.
-#define CC_TILE_CELLS 16384
-#define CC_TILE_T 512
-DEV_INLINE int cc_tile_width(const DevCtx& d) { return max(1, CC_TILE_CELLS / d.NS); }
-__global__ void __launch_bounds__(CC_TILE_T) cc_tile(DevCtx d) {
-  const int slot = blockIdx.y + d.slot0, tid = threadIdx.x;
-  const size_t base = (size_t)slot * d.N;
-  const int H = d.H, TW0 = cc_tile_width(d);
-  const int c0 = blockIdx.x * TW0, TW = min(TW0, H - c0), n = TW * d.NS;
-  __shared__ int parent[CC_TILE_CELLS];
-  const uint8_t* fi = d.flag_img + base;
-  if (blockIdx.x == 0) ip_strip_halo_columns(d, slot, tid, CC_TILE_T);
-  // vertical runs without atomics (most edges are vertical, see cc_runs): one thread per column, a run's representative is its lowest row
-  for (int lc = tid; lc < TW; lc += CC_TILE_T) {
-    int start = 0;
-    uint8_t prev = 0;
-    for (int row = 0; row < d.NS; ++row) {
-      const uint8_t fl = fi[row * H + c0 + lc];
-      if (!(prev & 8)) start = row;
-      parent[row * TW + lc] = start * TW + lc;
-      prev = fl;
-    }
-  }
-  __syncthreads();
-  // right-edges inside the band between the runs; skipped when the cell below already links the same pair of runs
-  for (int l = tid; l < n; l += CC_TILE_T) {
-    const int row = l / TW, lc = l - row * TW;
-    if (lc + 1 >= TW) continue;
-    const int v = row * H + c0 + lc;
-    if (!(fi[v] & 4)) continue;
-    if (row > 0) {
-      const uint8_t fb = fi[v - H];
-      if ((fb & 8) && (fb & 4) && (fi[v + 1 - H] & 8)) continue;
-    }
-    ccl_union(parent, l, l + 1);
-  }
-  __syncthreads();
-  int* gp = d.parent + base;
-  for (int l = tid; l < n; l += CC_TILE_T) {
-    const int row = l / TW, lc = l - row * TW;
-    const int v = row * H + c0 + lc;
-    int out = -1;
-    if (fi[v] & 2) {
-      int r = parent[l], nx;
-      while (r > (nx = parent[r])) r = nx;   // read-only find: nobody writes any more
-      const int rr = r / TW;
-      out = rr * H + c0 + (r - rr * TW);
-    }
-    gp[v] = out;
-  }
-}
-__global__ void __launch_bounds__(256) cc_seam(DevCtx d) {
-  const int slot = blockIdx.x + d.slot0;
-  const size_t base = (size_t)slot * d.N;
-  const int H = d.H, TW0 = cc_tile_width(d), nt = (H + TW0 - 1) / TW0;
-  const uint8_t* fi = d.flag_img + base;
-  int* parent = d.parent + base;
-  for (int e = threadIdx.x; e < nt * d.NS; e += 256) {
-    const int t = e / d.NS, row = e - t * d.NS;
-    const int col = min((t + 1) * TW0, H) - 1;           // last column of band t
-    const int v = row * H + col;
-    if (fi[v] & 4) cc_union(parent, v, row * H + (col + 1 == H ? 0 : col + 1));
-  }
-}
-
 __global__ void __launch_bounds__(CC_LDS_THREADS) cc_lds(DevCtx d, int ring_pos, int fused) {
   const int slot = blockIdx.x + d.slot0;
   const size_t base = (size_t)slot * d.N;
@@ -665,6 +594,78 @@ DEV_INLINE void ccl16_union(uint16_t* par, int a, int b) {
     }
   } while (repeat);
 }
+
+// Images too large for one workgroup's LDS (more than 16 rings with more than CC_LDS_MAXN cells: 64x2048): two-level labelling.
+// cc_tile: a workgroup takes a band of columns that fits LDS (<= CC_TILE_CELLS cells, all rows), runs the same union-find as
+// cc_lds on it — right-edges that stay inside the band, all down-edges — and writes every cell's band root (as a global linear index;
+// row-major order inside a band is the global order restricted to it, so the band root is the minimum global index of the piece).
+// cc_seam: the right-edges that cross a band boundary (incl. the wrap-around column) are linked with the global-memory union
+// (cc_union, as cc_link did for EVERY right-edge: NS x bands edges instead of ~N / 4).  cc_stats then resolves every cell to
+// its final root with a read-only find whose chains are at most a few band roots long.
+#define CC_TILE_CELLS 16384
+#define CC_TILE_T 512
+DEV_INLINE int cc_tile_width(const DevCtx& d) { return max(1, CC_TILE_CELLS / d.NS); }
+__global__ void __launch_bounds__(CC_TILE_T) cc_tile(DevCtx d) {
+  const int slot = blockIdx.y + d.slot0, tid = threadIdx.x;
+  const size_t base = (size_t)slot * d.N;
+  const int H = d.H, TW0 = cc_tile_width(d);
+  const int c0 = blockIdx.x * TW0, TW = min(TW0, H - c0), n = TW * d.NS;
+  __shared__ uint16_t parent[CC_TILE_CELLS];   // 16-bit parents (a band has <= 16384 cells): 32 KB, four of these workgroups per CU
+  const uint8_t* fi = d.flag_img + base;
+  if (blockIdx.x == 0) ip_strip_halo_columns(d, slot, tid, CC_TILE_T);
+  // vertical runs without atomics (most edges are vertical, see cc_runs): one thread per column, a run's representative is its lowest row
+  for (int lc = tid; lc < TW; lc += CC_TILE_T) {
+    int start = 0;
+    uint8_t prev = 0;
+    for (int row = 0; row < d.NS; ++row) {
+      const uint8_t fl = fi[row * H + c0 + lc];
+      if (!(prev & 8)) start = row;
+      parent[row * TW + lc] = (uint16_t)(start * TW + lc);
+      prev = fl;
+    }
+  }
+  __syncthreads();
+  // right-edges inside the band between the runs; skipped when the cell below already links the same pair of runs
+  for (int l = tid; l < n; l += CC_TILE_T) {
+    const int row = l / TW, lc = l - row * TW;
+    if (lc + 1 >= TW) continue;
+    const int v = row * H + c0 + lc;
+    if (!(fi[v] & 4)) continue;
+    if (row > 0) {
+      const uint8_t fb = fi[v - H];
+      if ((fb & 8) && (fb & 4) && (fi[v + 1 - H] & 8)) continue;
+    }
+    ccl16_union(parent, l, l + 1);
+  }
+  __syncthreads();
+  int* gp = d.parent + base;
+  for (int l = tid; l < n; l += CC_TILE_T) {
+    const int row = l / TW, lc = l - row * TW;
+    const int v = row * H + c0 + lc;
+    int out = -1;
+    if (fi[v] & 2) {
+      int r = parent[l], nx;
+      while (r > (nx = parent[r])) r = nx;   // read-only find: nobody writes any more
+      const int rr = r / TW;
+      out = rr * H + c0 + (r - rr * TW);
+    }
+    gp[v] = out;
+  }
+}
+__global__ void __launch_bounds__(256) cc_seam(DevCtx d) {
+  const int slot = blockIdx.x + d.slot0;
+  const size_t base = (size_t)slot * d.N;
+  const int H = d.H, TW0 = cc_tile_width(d), nt = (H + TW0 - 1) / TW0;
+  const uint8_t* fi = d.flag_img + base;
+  int* parent = d.parent + base;
+  for (int e = threadIdx.x; e < nt * d.NS; e += 256) {
+    const int t = e / d.NS, row = e - t * d.NS;
+    const int col = min((t + 1) * TW0, H) - 1;           // last column of band t
+    const int v = row * H + col;
+    if (fi[v] & 4) cc_union(parent, v, row * H + (col + 1 == H ? 0 : col + 1));
+  }
+}
+
 #ifdef ALEGO_TIMING
 __device__ long long cc_times[16];
 #define CC_TICK(k) do { if (threadIdx.x == 0 && blockIdx.x == 0) cc_times[k] = wall_clock64(); } while (0)
