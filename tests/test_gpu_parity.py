@@ -719,6 +719,46 @@ def test_cpp_host_program_equals_python_binding(params_a):
     h.close()
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_motion_deskew_with_irregular_imu(params_a, seed):
+    """adjustDistortion against IMU streams that misbehave: bursts, gaps longer than a scan, pauses of more than a second (the
+    handler then does not integrate, :793), repeated stamps (a zero interval in the interpolation), scans stamped before the first or
+    after the last sample, a ring that wraps several times.  De-skewed cloud, ring and cursors bit for bit against the oracle."""
+    rng = np.random.default_rng(40 + seed)
+    p = params_a.copy()
+    p.deskew_mode = 1
+    p.scan_period = float(rng.choice([0.05, 0.1, 0.2]))
+    h, o = binding.Handle(p), O.Oracle(p)
+    t_imu, t_scan = -0.3, 0.0
+    for k in range(18):
+        # a random batch of IMU samples before this scan
+        n = int(rng.choice([0, 1, 3, 10, 40, 120]))
+        smp = np.zeros((n, 11))
+        for i in range(n):
+            t_imu += float(rng.choice([0.0, 0.002, 0.01, 0.01, 0.01, 0.05, 0.3, 1.5]))
+            yaw, roll, pitch = 0.4 * t_imu + rng.normal(0, 0.01), rng.normal(0, 0.02), rng.normal(0, 0.02)
+            cr, sr, cp_, sp, cy, sy = np.cos(roll / 2), np.sin(roll / 2), np.cos(pitch / 2), np.sin(pitch / 2), np.cos(yaw / 2), np.sin(yaw / 2)
+            smp[i, 0] = t_imu
+            smp[i, 1:5] = (cy * cp_ * cr + sy * sp * sr, cy * cp_ * sr - sy * sp * cr, cy * sp * cr + sy * cp_ * sr, sy * cp_ * cr - cy * sp * sr)
+            smp[i, 5:8] = rng.normal(0, 0.5, 3) + (0, 0, 9.81)
+        if n:
+            h.push_imu(smp), o.push_imu(smp)
+        t_scan += float(rng.choice([0.1, 0.1, 0.1, 0.0, 0.5, -0.05]))
+        pts = synth.scan(p, k)
+        o.set_scan_time(t_scan)
+        seg = _ip_compare(h, o, pts, f"seed {seed} scan {k}")
+        seg["stamp"] = t_scan
+        h.set_lo_params(o.get("lo_params"))
+        o.lo()
+        flags, feat, odom = h.lo_process(seg)
+        tag = f"seed {seed} scan {k} (scan time {t_scan:.2f}, newest IMU {t_imu:.2f})"
+        assert_bit_equal(h.debug_get("imu_ptr"), o.get("imu_ptr"), f"{tag} cursors")
+        assert_bit_equal(h.debug_get("imu_ring"), o.get("imu_ring"), f"{tag} ring")
+        assert_bit_equal(h.debug_get("undistorted"), o.get("undistorted"), f"{tag} de-skewed cloud")
+        _fe_compare(h, o, feat, tag)
+    h.close()
+
+
 def test_batch_stream_groups_are_repeatable(params_a, monkeypatch):
     """The same 5-slot batch on 3 concurrent HIP streams, 12 times: every run gives the bits of the first.  (Workgroups of one
     launch are not co-scheduled when other streams keep the CUs busy; ip_front once let a workgroup clear the owner tags of a
