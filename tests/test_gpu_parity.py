@@ -1264,6 +1264,51 @@ def test_non_finite_zero_and_denormal_points(params_a, dense):
     h.close()
 
 
+def test_handles_are_independent_across_host_threads(params_a, monkeypatch):
+    """"A handle is single-threaded, different handles are independent" (alego_mi355x.h): four host threads, each with a handle of
+    its own (one of them a two-slot batch on two HIP streams), run at the same time; every one ends with the bits of a run alone."""
+    import threading
+    monkeypatch.setenv("ALEGO_STREAM_GROUPS", "2")   # (the two-slot batch handle gets one HIP stream per slot)
+    p = params_a
+    nscan = 30
+    scans = [[synth.scan(p, k, stream=s) for k in range(nscan)] for s in range(5)]
+
+    def single(s, out, key):
+        h = binding.Handle(p)
+        for k in range(nscan):
+            _, od, mp = h.scan_process(scans[s][k], stages=7)
+        out[key] = (od["t"].copy(), mp["params"].copy())
+        h.close()
+
+    def batch(out, key):
+        h = binding.Handle(p, n_slots=2, ring_len=nscan)
+        for s in (3, 4):
+            for k in range(nscan):
+                h.batch_load(s - 3, k, scans[s][k])
+        h.batch_run(0, nscan, stages=7)
+        res = []
+        for s in (0, 1):
+            _, od, mp = h.batch_get_pose(s)
+            res.append((od["t"].copy(), mp["params"].copy()))
+        out[key] = res
+        h.close()
+
+    alone, together = {}, {}
+    for s in range(5):
+        single(s, alone, s)
+    ths = [threading.Thread(target=single, args=(s, together, s)) for s in range(3)] + [threading.Thread(target=batch, args=(together, "b"))]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    for s in range(3):
+        assert_bit_equal(together[s][0], alone[s][0], f"thread {s} odometry")
+        assert_bit_equal(together[s][1], alone[s][1], f"thread {s} LM params_")
+    for i, s in enumerate((3, 4)):
+        assert_bit_equal(together["b"][i][0], alone[s][0], f"batch slot {i} odometry")
+        assert_bit_equal(together["b"][i][1], alone[s][1], f"batch slot {i} LM params_")
+
+
 def test_api_misuse_returns_error_codes(params_a):
     """Bad slots, ring positions, counts, null pointers, calls out of order: every one comes back as a negative ALEGO_ERR_* code (the
     C ABI never throws or faults), and the handle keeps working afterwards."""
