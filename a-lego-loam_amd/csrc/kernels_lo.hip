@@ -325,12 +325,13 @@ __global__ void __launch_bounds__(LO_BLOCK) lo_assoc(DevCtx d, int box_lds_max) 
 }
 
 // evaluate every valid correspondence row of [row0, row0+n) at pose p
+template <int BLK>
 DEV_INLINE void lo_eval_rows(const DevCtx& d, int slot, int kind, int n, const PoseTerms& T, double acc[28]) {
   const int qk = kind == 0 ? F_FLAT : F_SHARP, tk = kind == 0 ? F_LFLAT : F_LSHARP;
   const float4* qpts = d.feat[qk] + fidx_cur(d, slot) * d.fcap[qk];
   const float4* tg = d.feat[tk] + fidx_last(d, slot) * d.fcap[tk];
   const int* rows = d.lo_corr + ((size_t)slot * (d.lo_qcap_surf + d.lo_qcap_corner) + (kind == 0 ? 0 : d.lo_qcap_surf)) * 4;
-  for (int i = threadIdx.x; i < n; i += LO_SOLVE_BLOCK) {
+  for (int i = threadIdx.x; i < n; i += BLK) {
     const int4 r = *reinterpret_cast<const int4*>(rows + (size_t)i * 4);
     if (r.y < 0) continue;
     const float4 pc = qpts[r.x], pa = tg[r.y], pb = tg[r.z];
@@ -354,17 +355,18 @@ extern "C" void alego_lo_times(long long* out) { (void)hipMemcpyFromSymbol(out, 
 #define LO_T0
 #define LO_ACC(k)
 #endif
-__global__ void __launch_bounds__(LO_SOLVE_BLOCK) lo_solve(DevCtx d, int phase) {
+template <int BLK>
+__global__ void __launch_bounds__(BLK) lo_solve_t(DevCtx d, int phase) {
   const int slot = blockIdx.x + d.slot0;
   const int cur = cur_in_flight(d, slot);
   int* sc = d.scal + slot * SC_COUNT;
   double* st = d.lo_state + (size_t)slot * LO_STATE_N;
   extern __shared__ __attribute__((aligned(16))) unsigned char lo_smem[];
-  double* s_acc = reinterpret_cast<double*>(lo_smem);                // [28][LO_SOLVE_BLOCK]
-  double* s_seg = s_acc + 28 * (LO_SOLVE_BLOCK / 4);                        // [28][LO_SOLVE_BLOCK/128]
+  double* s_acc = reinterpret_cast<double*>(lo_smem);                // [28][BLK]
+  double* s_seg = s_acc + 28 * (BLK / 4);                        // [28][BLK/128]
   __shared__ double s_out[28], s_trig[12];
   __shared__ LmState S;
-  __shared__ int s_action, s_cnt[LO_SOLVE_BLOCK / 64];
+  __shared__ int s_action, s_cnt[BLK / 64];
   if (!sc[SC_LO_INIT]) {  // :316-324
     if (phase == 1 && threadIdx.x == 0) {
       sc[SC_LO_INIT] = 1; sc[SC_LO_FLAGS] = 1; sc[SC_LO_NSURF] = 0; sc[SC_LO_NCORNER] = 0; sc[SC_CUR] = cur;
@@ -383,14 +385,14 @@ __global__ void __launch_bounds__(LO_SOLVE_BLOCK) lo_solve(DevCtx d, int phase) 
     const int n = phase == 0 ? nq_s : nq_c;
     const int* rows = d.lo_corr + ((size_t)slot * (d.lo_qcap_surf + d.lo_qcap_corner) + (phase == 0 ? 0 : d.lo_qcap_surf)) * 4;
     int c = 0;
-    for (int i = threadIdx.x; i < n; i += LO_SOLVE_BLOCK) c += rows[(size_t)i * 4 + 1] >= 0;
+    for (int i = threadIdx.x; i < n; i += BLK) c += rows[(size_t)i * 4 + 1] >= 0;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
     if (lane_id() == 0) s_cnt[threadIdx.x >> 6] = c;
     __syncthreads();
     if (threadIdx.x == 0) {
       int t = 0;
-      for (int w = 0; w < LO_SOLVE_BLOCK / 64; ++w) t += s_cnt[w];
+      for (int w = 0; w < BLK / 64; ++w) t += s_cnt[w];
       s_cnt[0] = t;
       sc[phase == 0 ? SC_LO_NSURF : SC_LO_NCORNER] = t;
       if (phase == 0) sc[SC_LO_FLAGS] = 0;
@@ -406,9 +408,9 @@ __global__ void __launch_bounds__(LO_SOLVE_BLOCK) lo_solve(DevCtx d, int phase) 
       for (int k = 0; k < 28; ++k) acc[k] = 0;
       PoseTerms T;
       { LO_T0; T = pose_terms_coop(x, s_trig); LO_ACC(0); }
-      { LO_T0; lo_eval_rows(d, slot, 0, nq_s, T, acc);
-        if (phase == 1) lo_eval_rows(d, slot, 1, nq_c, T, acc); LO_ACC(1); }
-      { LO_T0; block_reduce28_lds<LO_SOLVE_BLOCK>(acc, s_acc, s_seg, s_out); LO_ACC(2); }
+      { LO_T0; lo_eval_rows<BLK>(d, slot, 0, nq_s, T, acc);
+        if (phase == 1) lo_eval_rows<BLK>(d, slot, 1, nq_c, T, acc); LO_ACC(1); }
+      { LO_T0; block_reduce28_lds<BLK>(acc, s_acc, s_seg, s_out); LO_ACC(2); }
     };
     double x0[6];
 #pragma unroll
@@ -506,9 +508,12 @@ void launch_dbg_transform_to_start(const double* params6, const float4* pts, int
   hipLaunchKernelGGL(dbg_transform_to_start, dim3((n + 63) / 64), dim3(64), 0, st, params6, pts, n, out);
 }
 
-#define LO_SOLVE_LDS ((size_t)(28 * (LO_SOLVE_BLOCK / 4) + 28 * (LO_SOLVE_BLOCK / 128)) * sizeof(double))
+#define LO_SOLVE_LDS_OF(B) ((size_t)(28 * ((B) / 4) + 28 * ((B) / 128 + 1)) * sizeof(double))
+#define LO_SOLVE_WIDE 256   // solver workgroup of sensors with more than LO_WIDE_ROWS correspondence rows (64 rings: ~1.5 k rows, 23 per lane of one wavefront)
+#define LO_WIDE_ROWS 1024
 int lo_configure() {
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(lo_solve), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LO_SOLVE_LDS) == hipSuccess ? 0 : -1;
+  return (hipFuncSetAttribute(reinterpret_cast<const void*>(lo_solve_t<LO_SOLVE_BLOCK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LO_SOLVE_LDS_OF(LO_SOLVE_BLOCK)) == hipSuccess &&
+          hipFuncSetAttribute(reinterpret_cast<const void*>(lo_solve_t<LO_SOLVE_WIDE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LO_SOLVE_LDS_OF(LO_SOLVE_WIDE)) == hipSuccess) ? 0 : -1;
 }
 
 // ---- IMU ring + motion de-skew (laserOdometry.cpp:557-726,761-802; dead in the reference: the call at :115 is commented out) ----
@@ -697,7 +702,12 @@ void launch_lo_deskew(const DevCtx& d, hipStream_t st) {
 void launch_lo(const DevCtx& d, hipStream_t st) {
   const int box_lds_max = std::min(d.opt_lo_box_lds, (int)LO_BOX_LDS);
   ALEGO_LAUNCH(lo_assoc<0>, dim3(d.n_launch, std::min((d.lo_qcap_surf + LO_QPB - 1) / LO_QPB, 8)), dim3(LO_BLOCK), 0, st, d, box_lds_max);
-  ALEGO_LAUNCH(lo_solve, dim3(d.n_launch), dim3(LO_SOLVE_BLOCK), LO_SOLVE_LDS, st, d, 0);
+  const bool wide = d.lo_qcap_surf + d.lo_qcap_corner > LO_WIDE_ROWS;   // (fixed by the geometry: every handle of a sensor sums its rows in the same order)
+  auto solve = [&](int phase) {
+    if (wide) { ALEGO_LAUNCH(lo_solve_t<LO_SOLVE_WIDE>, dim3(d.n_launch), dim3(LO_SOLVE_WIDE), LO_SOLVE_LDS_OF(LO_SOLVE_WIDE), st, d, phase); }
+    else { ALEGO_LAUNCH(lo_solve_t<LO_SOLVE_BLOCK>, dim3(d.n_launch), dim3(LO_SOLVE_BLOCK), LO_SOLVE_LDS_OF(LO_SOLVE_BLOCK), st, d, phase); }
+  };
+  solve(0);
   ALEGO_LAUNCH(lo_assoc<1>, dim3(d.n_launch, std::min((d.lo_qcap_corner + LO_QPB - 1) / LO_QPB, 12)), dim3(LO_BLOCK), 0, st, d, box_lds_max);
-  ALEGO_LAUNCH(lo_solve, dim3(d.n_launch), dim3(LO_SOLVE_BLOCK), LO_SOLVE_LDS, st, d, 1);
+  solve(1);
 }

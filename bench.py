@@ -67,7 +67,7 @@ def kernel_bytes(name, c, NS, H, rebuilds_per_launch=0.0):
         # B_FE = 9 M (range, col, ground in) + 16 feats (out)
         "fe_curv": 8 * M, "fe_pick4": M, "fe_pick": M, "fe_gather": 16 * feats,
         # B_LO = 16 (F' + Q) + 104
-        "lo_assoc": 16 * (c["Fc"] + c["Fs"] + c["Qc"] + c["Qs"]) / 2, "lo_solve": 104 / 2,
+        "lo_assoc": 16 * (c["Fc"] + c["Fs"] + c["Qc"] + c["Qs"]) / 2, "lo_solve": 104 / 2, "lo_solve_t": 104 / 2,
         # B_LM = 16 Kraw + 32 Kds + 16 L + 104 per mapping frame
         "vox_big": (16 * kraw + 16 * kds) * rb, "map_accum": (16 * kraw + 16 * kds) * rb, "lm_grid_build": 16 * kds * rb,
         "lm_knn": 16 * L, "lm_solve": 104,
