@@ -27,6 +27,8 @@ EXPORTS = [
     "alego_lm_add_keyframe", "alego_pc2_to_points", "alego_replay_create", "alego_replay_load", "alego_replay_assign",
     "alego_dist_unique_id", "alego_dist_init", "alego_dist_shutdown", "alego_stream_setup", "alego_stream_run",
     "alego_loop_detect", "alego_loop_closure_icp",
+    "alego_bag_open", "alego_bag_close", "alego_bag_last_error", "alego_bag_topic_count", "alego_bag_topic_info", "alego_bag_message_count",
+    "alego_bag_read_raw", "alego_bag_read_pc2",
 ]
 
 REPLAY_PINGPONG = 0x100
@@ -193,6 +195,22 @@ def lib():
         L.alego_loop_detect.argtypes = [C.POINTER(AlegoParams), C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
         L.alego_loop_closure_icp.restype = C.c_int
         L.alego_loop_closure_icp.argtypes = [C.c_void_p, C.POINTER(KfIn), C.POINTER(KfIn), C.c_int32, C.POINTER(IcpResult), C.c_void_p, C.c_int32]
+        L.alego_bag_open.restype = C.c_int
+        L.alego_bag_open.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
+        L.alego_bag_close.restype = None
+        L.alego_bag_close.argtypes = [C.c_void_p]
+        L.alego_bag_last_error.restype = C.c_char_p
+        L.alego_bag_last_error.argtypes = [C.c_void_p]
+        L.alego_bag_topic_count.restype = C.c_int
+        L.alego_bag_topic_count.argtypes = [C.c_void_p]
+        L.alego_bag_topic_info.restype = C.c_int
+        L.alego_bag_topic_info.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(C.c_int64)]
+        L.alego_bag_message_count.restype = C.c_int64
+        L.alego_bag_message_count.argtypes = [C.c_void_p, C.c_char_p]
+        L.alego_bag_read_raw.restype = C.c_int
+        L.alego_bag_read_raw.argtypes = [C.c_void_p, C.c_char_p, C.c_int64, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(C.c_double)]
+        L.alego_bag_read_pc2.restype = C.c_int
+        L.alego_bag_read_pc2.argtypes = [C.c_void_p, C.c_char_p, C.c_int64, C.c_void_p, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int32)]
         if L.alego_params_sizeof() != C.sizeof(AlegoParams):
             raise RuntimeError("alego_params layout mismatch between params.py and include/alego_params.h")
         _lib = L
@@ -242,6 +260,58 @@ def pc2_to_points(data: bytes, width, height, point_step, row_step, fields, is_b
     if rc < 0:
         raise AlegoError(f"alego_pc2_to_points failed ({rc})")
     return out[:rc].copy()
+
+
+class Bag:
+    """A rosbag format 2.0 file opened by the library's own reader (no ROS): topics, and the PointCloud2 messages of a topic in
+    time order — what `rosbag play` + the /lslidar_point_cloud subscriber + pcl::fromROSMsg deliver to ImageProjection."""
+
+    def __init__(self, path):
+        h = C.c_void_p()
+        rc = lib().alego_bag_open(os.fsencode(path), C.byref(h))
+        if rc != 0:
+            raise AlegoError(f"alego_bag_open({path}) failed ({rc}): not a readable rosbag 2.0 file (see stderr)")
+        self._b = h
+
+    def close(self):
+        if getattr(self, "_b", None):
+            lib().alego_bag_close(self._b)
+            self._b = None
+
+    def __del__(self):
+        self.close()
+
+    def _err(self):
+        return lib().alego_bag_last_error(self._b).decode(errors="replace")
+
+    def topics(self):
+        """{topic: (datatype, number of messages)}"""
+        out = {}
+        for i in range(lib().alego_bag_topic_count(self._b)):
+            t, d, n = C.c_char_p(), C.c_char_p(), C.c_int64()
+            lib().alego_bag_topic_info(self._b, i, C.byref(t), C.byref(d), C.byref(n))
+            out[t.value.decode()] = (d.value.decode(), int(n.value))
+        return out
+
+    def message_count(self, topic):
+        return int(lib().alego_bag_message_count(self._b, topic.encode()))
+
+    def read_raw(self, topic, index):
+        """(serialized message bytes, bag time)"""
+        p, n, t = C.c_void_p(), C.c_uint64(), C.c_double()
+        rc = lib().alego_bag_read_raw(self._b, topic.encode(), index, C.byref(p), C.byref(n), C.byref(t))
+        if rc != 0:
+            raise AlegoError(f"alego_bag_read_raw failed ({rc}): {self._err()}")
+        return C.string_at(p.value, n.value), float(t.value)
+
+    def read_pc2(self, topic, index, cap=1 << 20):
+        """(points[n, 4] float32, header stamp, is_dense)"""
+        out = np.empty((cap, 4), np.float32)
+        st, dn = C.c_double(), C.c_int32()
+        n = lib().alego_bag_read_pc2(self._b, topic.encode(), index, out.ctypes.data, cap, C.byref(st), C.byref(dn))
+        if n < 0:
+            raise AlegoError(f"alego_bag_read_pc2 failed ({n}): {self._err()}")
+        return out[:n].copy(), float(st.value), bool(dn.value)
 
 
 _CLOUDS = {"seg_cloud", "undistorted", "outlier", "sharp", "less_sharp", "flat", "less_flat"}

@@ -539,7 +539,7 @@ int alego_trajectory_get(alego_handle* h, int slot, int32_t first, int32_t n, do
   HIP_TRY(h, hipMemcpyAsync(&logged, h->d.traj_n + slot, sizeof(int), hipMemcpyDeviceToHost, S));
   HIP_TRY(h, hipStreamSynchronize(S));
   const int have = std::min(logged, h->d.traj_cap);
-  if (first + n > have) { h->err = "alego_trajectory_get: range beyond the scans logged"; return ALEGO_ERR_ARG; }
+  if (first > have || n > have - first) { h->err = "alego_trajectory_get: range beyond the scans logged"; return ALEGO_ERR_ARG; }   // (not first + n: it overflows for large arguments)
   if (n > 0) {
     HIP_TRY(h, hipMemcpyAsync(out14, h->d.traj + ((size_t)slot * h->d.traj_cap + first) * 14, (size_t)n * 14 * sizeof(double), hipMemcpyDeviceToHost, S));
     HIP_TRY(h, hipStreamSynchronize(S));

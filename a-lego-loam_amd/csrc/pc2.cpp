@@ -3,6 +3,7 @@
 // PCL's field mapper matches the message fields to the point type BY NAME and requires identical datatype and count;
 // PointXYZI = x, y, z, intensity, all FLOAT32 (sensor_msgs/PointField datatype 7).  A field that is missing (or has
 // another type) is left out of the mapping: PCL warns and the member keeps the value of a default-constructed point (0).
+// PCL's FieldMatches accepts count == 1 and, for single-element fields, count == 0 (drivers that leave it unset).
 #include <cstdint>
 #include <cstring>
 
@@ -29,7 +30,7 @@ extern "C" int alego_pc2_to_points(const uint8_t* data, uint64_t data_len, uint3
   for (int f = 0; f < n_fields; ++f) {
     if (!fields[f].name) return ALEGO_ERR_ARG;
     for (int k = 0; k < 4; ++k)
-      if (std::strcmp(fields[f].name, names[k]) == 0 && fields[f].datatype == 7 && fields[f].count == 1) off[k] = fields[f].offset;
+      if (std::strcmp(fields[f].name, names[k]) == 0 && fields[f].datatype == 7 && fields[f].count <= 1) off[k] = fields[f].offset;
   }
   if (off[0] < 0 || off[1] < 0 || off[2] < 0) return ALEGO_ERR_ARG;   // fromROSMsg cannot fill an XYZ point without x, y, z
   for (int k = 0; k < 4; ++k)

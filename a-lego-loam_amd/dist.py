@@ -50,3 +50,14 @@ def max_over_ranks(seconds: float, dist, device="cpu") -> float:
 def aggregate_scans_per_s(world: int, streams_per_gpu: int, steps: int, seconds: float) -> float:
     """Whole-job throughput: every rank advanced `streams_per_gpu` streams by `steps` scans in `seconds`."""
     return world * streams_per_gpu * steps / seconds
+
+
+def gather_floats(value: float, dist, device="cpu"):
+    """[value of rank 0, value of rank 1, ...] on every rank (all_gather of one double)."""
+    if dist is None:
+        return [float(value)]
+    import torch
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [float(x.item()) for x in out]

@@ -35,7 +35,7 @@ from alego_amd import dist as D  # noqa: E402
 
 HBM_PEAK = 8.0e12  # B/s, MI355X spec (MI355X_MICROARCH.md)
 LAP = 560          # scans per T0 lap
-PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
 
 
 def algorithmic_bytes(c, NS):
@@ -73,6 +73,22 @@ def kernel_bytes(name, c, NS, H, rebuilds_per_launch=0.0):
         "lm_knn": 16 * L, "lm_solve": 104,
     }
     return t.get(name)
+
+
+def kernel_table(rep):
+    tot = sum(v[0] for v in rep.values())
+    return {k: dict(ms_total=round(v[0], 3), launches=v[1], avg_us=round(1e3 * v[0] / max(v[1], 1), 2),
+                    share=round(v[0] / tot, 4)) for k, v in sorted(rep.items(), key=lambda kv: -kv[1][0])}
+
+
+def pmc_bytes_per_scan():
+    """measured HBM bytes per scan of the whole pipeline (tools/pmc_traffic.py: per-kernel bytes per launch x launches per scan)"""
+    try:
+        with open(PMC_FILE) as f:
+            d = json.load(f)
+        return dict(corrected=d["hbm_bytes_per_scan"], uncorrected=d["hbm_bytes_per_scan_uncorrected"])
+    except (OSError, ValueError, KeyError):
+        return None
 
 
 def pmc_traffic(kernel, streams_per_launch):
@@ -140,6 +156,65 @@ def single_stream(p, bag, device, prime, steps, lanes=8):
     return res
 
 
+CHECK_ARRAYS = ("seg_cloud", "seg_col", "less_sharp", "less_flat", "lm_corner_map_ds", "lm_surf_map_ds")
+
+
+def timed_handle_check(h, p, bags, B, total_steps, device, oracle_map_t=None, per_group=4):
+    """The handle that was TIMED (all its slots, all its stream groups, bag replay) against one-slot handles: `per_group` slots of
+    every stream group (first and last slot of the group included) are replayed alone — same bag, same start scan, same number
+    of steps — and odometry pose, LaserMapping params_ / pose, the segmented cloud, both feature clouds and both filtered maps
+    must agree bit for bit.  The replica of slot 0 also logs its per-scan poses, which are set against the free-running oracle
+    (`oracle_map_t`: map translation per scan of the same sequence) up to the first scan beyond 1e-4 m."""
+    groups, per = h.stream_groups()
+    slots = []
+    for g in range(groups):
+        lo, hi = g * per, min((g + 1) * per, B) - 1
+        for j in range(per_group):
+            slots.append(lo + (hi - lo) * j // max(per_group - 1, 1))
+    slots = sorted(set(slots))
+    st = 7 | binding.REPLAY_BAG
+    bad, truncated = [], []
+    vs_oracle = None
+    for s in slots:
+        b, start = slot_source(s, len(bags))
+        h1 = binding.Handle(p, device=device, n_slots=1, ring_len=1)
+        h1.replay_create(1, LAP)
+        for k, a in enumerate(bags[b]):
+            h1.replay_load(0, k, a)
+        h1.replay_assign(0, 0, start)
+        if s == 0 and oracle_map_t is not None:
+            h1.trajectory_enable(total_steps)
+        h1.batch_run(0, total_steps, st)
+        try:
+            f1, o1, m1 = h1.batch_get_pose(0)
+            fb, ob, mb = h.batch_get_pose(s)
+        except binding.AlegoError:
+            truncated.append(s); h1.close(); continue
+        same = all(np.array_equal(bits(ob[k]), bits(o1[k])) for k in ("t", "q", "params")) and \
+            all(np.array_equal(bits(mb[k]), bits(m1[k])) for k in ("t", "q", "params")) and fb == f1
+        for name in CHECK_ARRAYS:
+            a, c = h.debug_get(name, slot=s), h1.debug_get(name)
+            same = same and a.shape == c.shape and np.array_equal(bits(a), bits(c))
+        if not same:
+            bad.append(s)
+        if s == 0 and oracle_map_t is not None:
+            tr = h1.trajectory(0)
+            n = min(len(oracle_map_t), tr.shape[0])
+            err = np.linalg.norm(tr[:n, 7:10] - np.asarray(oracle_map_t)[:n], axis=1)
+            beyond = np.nonzero(err > 1e-4)[0]
+            hz = int(beyond[0]) if beyond.size else None
+            vs_oracle = dict(scans_compared=n, first_scan_beyond_tolerance=hz, max_err_m_before=float(err[:hz].max()) if (hz is None or hz > 0) else 0.0,
+                             note="replica of slot 0 (bit-equal to the timed slot 0) free-running vs the oracle on the same scans")
+        h1.close()
+    return dict(slots=len(slots), slot_ids=slots, stream_groups=groups, slots_per_group=per, steps_replayed=total_steps, arrays=list(CHECK_ARRAYS) + ["odom pose", "LM params_ / pose", "flags"],
+                bit_equal=not bad and not truncated, differing_slots=bad, capacity_errors=truncated, stream0_vs_oracle=vs_oracle)
+
+
+def bits(a):
+    a = np.ascontiguousarray(a)
+    return a.view(np.uint32) if a.dtype == np.float32 else (a.view(np.uint64) if a.dtype == np.float64 else a)
+
+
 def quat_angle(q1, q2):
     return 2.0 * float(np.arccos(min(1.0, abs(float(np.dot(q1, q2))))))
 
@@ -160,11 +235,13 @@ def cpu_legs(p, bags, prime, seconds=10.0, device=None):
     hf = binding.Handle(p, device=device) if device is not None else None   # teacher-forced: the 1e-4 contract of the parity tests
     hg = binding.Handle(p, device=device) if device is not None else None   # free-running: reported, not a tolerance claim
     et, er, gt, exact, checked, horizon = [], [], [], 0, 0, None
+    oracle_map_t = []   # the (free-running) oracle's map translation per scan of stream 0's sequence: timed_handle_check compares the device against it
     for k in range(prime):
         pts = seq_of(0, k)
         if hf is not None:
             hf.set_lo_params(o.get("lo_params")); hf.set_lm_params(o.get("lm_params"))
         o.process_scan(pts)
+        oracle_map_t.append(o.get("map_pose")[:3].copy())
         if hf is not None:
             _, _, mp = hf.scan_process(pts, stages=7)
             _, _, mg = hg.scan_process(pts, stages=7)
@@ -195,9 +272,13 @@ def cpu_legs(p, bags, prime, seconds=10.0, device=None):
     # ---- cpu_seq
     n, t0 = 0, time.perf_counter()
     stage = np.zeros(3)
+    lo_solve_ms = 0.0
     while time.perf_counter() - t0 < seconds:
         o.process_scan(seq_of(0, prime + n))
-        stage += o.get("timing_ms")[:3]
+        tm = o.get("timing_ms")
+        stage += tm[:3]
+        lo_solve_ms += float(tm[5])   # lo.t_solve_ms: the two ceres::Solve calls of LaserOdometry (README.md:50,54 time exactly these)
+        oracle_map_t.append(o.get("map_pose")[:3].copy())
         n += 1
     dt = time.perf_counter() - t0
     info = o.get("lm_info")
@@ -235,7 +316,8 @@ def cpu_legs(p, bags, prime, seconds=10.0, device=None):
                 cpu_pipe3=dict(value=n3 / t3, unit="scans/s", cores=3, sample=f"IP || LO || LM threads (launch/test.launch:7-10), steps {prime}..{prime + n3 - 1} of the same sequence, {t3:.1f} s"),
                 cpu_replicas=dict(value=sum(m_ for m_, _ in done) / tr, unit="scans/s", cores=C,
                                   sample=f"{C} independent oracles on the sequences of GPU streams 0..{C - 1}, each primed {prime} scans, {tr:.1f} s"),
-                host_cores=os.cpu_count()), parity
+                lo_opt_ms_per_frame=round(lo_solve_ms / max(n, 1), 4),
+                host_cores=os.cpu_count()), parity, oracle_map_t
 
 
 def main():
@@ -255,6 +337,8 @@ def main():
                          "(alego_dist_init: query slices + one ncclAllReduce of the normal equations per solver evaluation); strong scaling")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--no-check", action="store_true", help="skip timed_handle_check (slots of the timed handle against one-slot replicas)")
+    ap.add_argument("--no-isolated", action="store_true", help="skip the one-group pass that gives the kernels' isolated durations")
     args = ap.parse_args()
 
     rank, local, world = D.env()
@@ -306,6 +390,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     step += args.steps
+    dt_local = dt
     dt = D.max_over_ranks(dt, dist, device="cuda")
     sample = range(0, B, max(1, B // 64))
     cs = [h.batch_get_counts(s) for s in sample]
@@ -313,7 +398,7 @@ def main():
     flags, odom, mp = h.batch_get_pose(0)
     rebuilds0 = sum(h.batch_get_counts(s)["n_rebuild"] for s in range(B))
 
-    roof, kern = None, None
+    roof, kern, rebuilds, per, groups = None, None, 0, B, 1
     if rank == 0 and not args.no_profile:
         # per-kernel durations with HIP events on the handle's streams, over another K steps.  One launch covers one
         # stream group (`per` streams); the groups run concurrently, exactly as in the timed region.
@@ -322,25 +407,8 @@ def main():
         h.batch_run(step, args.steps, stages); step += args.steps
         rep = h.profile_report()
         h.profile_enable(False)
-        tot = sum(v[0] for v in rep.values())
-        kern = {k: dict(ms_total=round(v[0], 3), launches=v[1], avg_us=round(1e3 * v[0] / max(v[1], 1), 2),
-                        share=round(v[0] / tot, 4)) for k, v in sorted(rep.items(), key=lambda kv: -kv[1][0])}
+        kern = kernel_table(rep)
         rebuilds = sum(h.batch_get_counts(s)["n_rebuild"] for s in range(B)) - rebuilds0
-        dom, kb = None, None
-        for name in kern:  # the kernel with the largest share of the device time that has a §8(d) term of its own
-            rb = rebuilds / max(kern[name]["launches"], 1) / per  # map rebuilds per launch and stream
-            kb = kernel_bytes(name, counts, p.n_scan, p.horizon_scan, rb)
-            if kb:
-                dom = name
-                break
-        if dom is not None:
-            ach = kb * per / (kern[dom]["avg_us"] * 1e-6)
-            tr = pmc_traffic(dom, per)
-            roof = dict(bound="hbm", kernel=dom, achieved=round(ach / 1e9, 3), peak=HBM_PEAK / 1e9, unit="GB/s",
-                        frac=round(ach / HBM_PEAK, 6), traffic=tr,
-                        algorithmic_bytes_per_launch=int(kb * per), streams_per_launch=per, concurrent_stream_groups=groups,
-                        avg_launch_us=kern[dom]["avg_us"],
-                        map_rebuilds_per_launch=round(rebuilds / max(kern[dom]["launches"], 1), 2))
     value = D.aggregate_scans_per_s(1 if shard else world, B, args.steps, dt)   # config 5: the ranks share the streams
     out = {
         "metric": f"scans/sec ({ns}x{hs} LiDAR) full IP->LO->LM loop", "value": round(value, 1), "unit": "scans/s",
@@ -351,19 +419,80 @@ def main():
                                f"(one scan per stream per step)",
                    "streams_per_gpu": B, "bags_per_gpu": args.bags, "bag_scans": LAP, "primed_scans": args.prime, "parallelism": (f"registration sharded x{world} (RCCL all-reduce of the normal equations)" if shard else f"streams x{world}")},
     }
+    # every rank reports its own rate; rank 0 prints them (the driver computes scaling from `value`, this is for the reader)
+    per_rank = D.gather_floats(B * args.steps / dt_local, dist, device="cuda")
     if rank == 0:
+        out["per_rank_scans_per_s"] = [round(v, 1) for v in per_rank]
+        out["ranks_seen_by_rccl"] = len(per_rank) if dist is not None else 1
+        # a key frame that does not fit kf_cap_surf / kf_cap_outlier is truncated and reported by the slot's next pose query:
+        # every slot is asked, not just slot 0 (a truncated stream is cheaper to process)
+        trunc = 0
+        for s in range(B):
+            try:
+                h.batch_get_pose(s)
+            except binding.AlegoError:
+                trunc += 1
+        out["truncated_streams"] = trunc
         ab = algorithmic_bytes(counts, p.n_scan)
-        out["pipeline_roofline"] = dict(B_scan=int(ab["B_scan"]), achieved_GBps=round(value / world * ab["B_scan"] / 1e9, 3),
-                                        frac_of_hbm_peak=round(value / world * ab["B_scan"] / HBM_PEAK, 6), **{k: int(v) for k, v in ab.items() if k != "B_scan"})
+        # the device rebuilds a local map only when the stream's key-frame set changed; SURVEY 8(d)'s B_LM charges the map terms on
+        # every mapping frame (the reference re-concatenates every time).  Both figures are reported.
+        launches_lm = max(kern["lm_solve"]["launches"], 1) if kern and "lm_solve" in kern else 0
+        rb_frac = (rebuilds / (launches_lm * per)) if launches_lm else None      # rebuilds per mapping frame and stream
+        kraw, kds = counts["Kraw_c"] + counts["Kraw_s"], counts["Kds_c"] + counts["Kds_s"]
+        pr = dict(B_scan=int(ab["B_scan"]), achieved_GBps=round(value / world * ab["B_scan"] / 1e9, 3),
+                  frac_of_hbm_peak=round(value / world * ab["B_scan"] / HBM_PEAK, 6), **{k: int(v) for k, v in ab.items() if k != "B_scan"})
+        if rb_frac is not None:
+            b_lm_dev = (16 * kraw + 16 * kds) * rb_frac + 16 * kds + 16 * (counts["Lc"] + counts["Ls"]) + 104
+            b_dev = ab["B_IP"] + ab["B_FE"] + ab["B_LO"] + b_lm_dev / 2
+            pr.update(map_rebuild_fraction=round(rb_frac, 4), B_scan_device=int(b_dev), achieved_GBps_device=round(value / world * b_dev / 1e9, 3),
+                      frac_of_hbm_peak_device=round(value / world * b_dev / HBM_PEAK, 6))
+        pm = pmc_bytes_per_scan()
+        if pm is not None:
+            pr.update(measured_hbm_bytes_per_scan=int(pm["corrected"]), measured_hbm_bytes_per_scan_uncorrected=int(pm["uncorrected"]),
+                      measured_over_algorithmic=round(pm["corrected"] / ab["B_scan"], 3), measured_source=os.path.relpath(PMC_FILE, ROOT))
+        out["pipeline_roofline"] = pr
         out["counts"] = counts
-        if roof is not None:
-            out["roofline"] = roof
         if kern is not None:
             out["kernels"] = kern
+        omt = None
         if world == 1 and not args.no_cpu:
             out.update(single_stream(p, bags[0], local, args.prime, max(args.steps, 200)))
-            out["cpu_baseline"], out["parity"] = cpu_legs(p, bags, args.prime, device=local)
+            out["cpu_baseline"], out["parity"], omt = cpu_legs(p, bags, args.prime, device=local)
+        if not args.no_check and not shard:
+            out["timed_handle_check"] = timed_handle_check(h, p, bags, B, step, local, omt)
     h.close()
+    if rank == 0 and kern is not None:
+        # the same launch shape (`per` streams per launch) ALONE on the chip: one stream group, nothing else resident
+        iso = None
+        if not args.no_isolated and groups > 1:
+            os.environ["ALEGO_STREAM_GROUPS"] = "1"
+            hi = binding.Handle(p, device=local, n_slots=per, ring_len=1)
+            os.environ.pop("ALEGO_STREAM_GROUPS")
+            setup_replay(hi, bags, per)
+            hi.batch_run(0, args.prime + args.warmup, stages)
+            hi.profile_enable(True)
+            hi.batch_run(args.prime + args.warmup, args.steps, stages)
+            iso = kernel_table(hi.profile_report())
+            hi.close()
+        roofs = []
+        for name in kern:  # kernels in the order of their share of the device time; those with a §8(d) term of their own
+            rb = rebuilds / max(kern[name]["launches"], 1) / per  # map rebuilds per launch and stream
+            kb = kernel_bytes(name, counts, p.n_scan, p.horizon_scan, rb)
+            if not kb:
+                continue
+            ach = kb * per / (kern[name]["avg_us"] * 1e-6)
+            r = dict(bound="hbm", kernel=name, achieved=round(ach / 1e9, 3), peak=HBM_PEAK / 1e9, unit="GB/s", frac=round(ach / HBM_PEAK, 6),
+                     traffic=pmc_traffic(name, per), algorithmic_bytes_per_launch=int(kb * per), streams_per_launch=per,
+                     concurrent_stream_groups=groups, avg_launch_us=kern[name]["avg_us"], share_of_device_time=kern[name]["share"])
+            if iso is not None and name in iso:
+                r.update(isolated_launch_us=iso[name]["avg_us"], achieved_isolated=round(kb * per / (iso[name]["avg_us"] * 1e-6) / 1e9, 3),
+                         frac_isolated=round(kb * per / (iso[name]["avg_us"] * 1e-6) / HBM_PEAK, 6))
+            roofs.append(r)
+            if len(roofs) == 3:
+                break
+        if roofs:
+            out["roofline"] = dict(roofs[0], map_rebuilds_per_launch=round(rebuilds / max(kern[roofs[0]["kernel"]]["launches"], 1), 2))
+            out["roofline_top3"] = roofs
     # RCCL prints its version banner through C stdio, which is buffered when stdout is a pipe / file: every rank pushes it out,
     # then rank 0 prints the JSON line after the barrier, so that it is the last line of the job's stdout
     try:

@@ -295,12 +295,29 @@ int alego_dist_shutdown(alego_handle* h);
 
 /* ---- sensor_msgs/PointCloud2 to alego_point: pcl::fromROSMsg<PointXYZI>, imageProjection.cpp:54-55, IP.cpp:109-110 ----
  * ROS-free mirror of sensor_msgs/PointField + the PointCloud2 layout fields.  Fields are matched by name ("x", "y", "z",
- * "intensity") and must be FLOAT32 (datatype 7) with count 1, as PCL's field mapper requires; a missing intensity gives 0.
+ * "intensity") and must be FLOAT32 (datatype 7) with count 1 (or 0: unset), as PCL's field mapper requires; a missing intensity gives 0.
  * Returns the number of points written (width * height), or ALEGO_ERR_ARG / ALEGO_ERR_CAPACITY. */
 typedef struct alego_pc2_field { const char* name; uint32_t offset; uint8_t datatype; uint32_t count; } alego_pc2_field;
 int alego_pc2_to_points(const uint8_t* data, uint64_t data_len, uint32_t width, uint32_t height, uint32_t point_step,
                         uint32_t row_step, int is_bigendian, const alego_pc2_field* fields, int n_fields,
                         alego_point* out, int32_t cap);
+
+/* ---- rosbag format 2.0 reader (host side, no ROS / libbz2 / liblz4 needed; csrc/rosbag.cpp) -------------------------------
+ * Replaces `rosbag play <file>.bag` + the `/lslidar_point_cloud` subscription + pcl::fromROSMsg at the head of ImageProjection
+ * (README.md:33-37, launch/test2.launch:6-14, src/IP.cpp:106-133, src/imageProjection.cpp:45,49-55): open the bag, hand out the
+ * messages of a topic in time order, deserialise sensor_msgs/PointCloud2 and run it through alego_pc2_to_points.  Chunks may be
+ * uncompressed, bz2 or lz4; a bag without index records (never closed) is scanned.  Errors: ALEGO_ERR_ARG (+ alego_bag_last_error). */
+typedef struct alego_bag alego_bag;
+int alego_bag_open(const char* path, alego_bag** out);
+void alego_bag_close(alego_bag* b);
+const char* alego_bag_last_error(const alego_bag* b);
+int alego_bag_topic_count(const alego_bag* b);
+int alego_bag_topic_info(const alego_bag* b, int i, const char** topic, const char** datatype, int64_t* n_messages);
+int64_t alego_bag_message_count(const alego_bag* b, const char* topic);
+/* serialized message `index` of `topic` (pointer valid until the next read / close); bag_time = the record's receive time */
+int alego_bag_read_raw(alego_bag* b, const char* topic, int64_t index, const uint8_t** data, uint64_t* len, double* bag_time);
+/* PointCloud2 message `index` of `topic` -> points (returns their number); header_stamp = msg.header.stamp, is_dense = msg.is_dense */
+int alego_bag_read_pc2(alego_bag* b, const char* topic, int64_t index, alego_point* out, int32_t cap, double* header_stamp, int32_t* is_dense);
 
 #ifdef __cplusplus
 }

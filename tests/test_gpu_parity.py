@@ -1614,3 +1614,90 @@ def test_loop_closure_icp_device_vs_oracle(params_a, standalone):
         assert np.abs(got["T"] - want["T"]).max() < 1e-5, (tag, got["T"], want["T"])
         assert abs(got["fitness"] - want["fitness"]) < 1e-6 * max(1.0, want["fitness"]), (tag, got["fitness"], want["fitness"])
     h.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# round 3: the handle shape bench.py times (>= 1024 slots, four stream groups, bag replay), and config 5's sharded
+# registration at its own geometry
+# ---------------------------------------------------------------------------------------------------------------------
+def test_timed_handle_shape_1024_slots_four_groups_bag_replay(params_a):
+    """bench.py's handle shape: 1024 slots in the default four stream groups replaying shared HBM-resident bags from their own
+    start scans, with every CU busy (every other batch test uses <= 9 slots, i.e. an empty chip; the ip_front halo
+    race of DESIGN.md 7 only fired under load).  Run three times: the poses of ALL slots and the heavy arrays of 32 sampled
+    slots repeat bit for bit, and 16 slots spread over the four groups (first / last of each included) equal one-slot
+    handles replaying the same (bag, start) sequence alone on the chip."""
+    p = params_a
+    n_slots, n_bags, bag_len, steps = 1024, 4, 14, 30
+    bags = [[synth.scan(p, k, stream=b) for k in range(bag_len)] for b in range(n_bags)]
+    src = lambda s: (s % n_bags, ((s // n_bags) * 5) % bag_len)
+    st = 7 | binding.REPLAY_BAG
+    arrays = ("seg_cloud", "seg_col", "less_sharp", "less_flat", "lm_corner_map_ds", "lm_surf_map_ds")
+    sample = list(range(0, n_slots, 32))
+    runs = []
+    for rep in range(3):
+        hb = binding.Handle(p, n_slots=n_slots, ring_len=1)
+        groups, per = hb.stream_groups()
+        assert (groups, per) == (4, 256)
+        hb.replay_create(n_bags, bag_len)
+        for b in range(n_bags):
+            for k in range(bag_len):
+                hb.replay_load(b, k, bags[b][k])
+        for s in range(n_slots):
+            hb.replay_assign(s, *src(s))
+        hb.batch_run(0, steps, st, sync=False)
+        hb.synchronize()
+        poses = []
+        for s in range(n_slots):
+            f, o, m = hb.batch_get_pose(s)
+            poses.append(np.concatenate([[f], o["t"], o["q"], o["params"], m["t"], m["q"], m["params"]]))
+        heavy = {s: [hb.debug_get(a, slot=s) for a in arrays] for s in sample}
+        checked = [g * per + j for g in range(groups) for j in (0, 85, 170, per - 1)]
+        if rep == 0:
+            for s in checked:
+                b, start = src(s)
+                h1 = binding.Handle(p)
+                for i in range(steps):
+                    f1, o1, m1 = h1.scan_process(bags[b][(start + i) % bag_len], stages=7)
+                fb, ob, mb = hb.batch_get_pose(s)
+                for k in ("t", "q", "params"):
+                    assert_bit_equal(ob[k], o1[k], f"slot {s} odometry {k}")
+                    assert_bit_equal(mb[k], m1[k], f"slot {s} map {k}")
+                for a in arrays:
+                    assert_bit_equal(hb.debug_get(a, slot=s), h1.debug_get(a), f"slot {s} {a}")
+                h1.close()
+        hb.close()
+        runs.append((np.array(poses), heavy))
+    for rep in (1, 2):
+        assert_bit_equal(runs[rep][0], runs[0][0], f"run {rep}: poses of all {n_slots} slots")
+        for s in sample:
+            for a, x, y in zip(arrays, runs[rep][1][s], runs[0][1][s]):
+                assert_bit_equal(x, y, f"run {rep} slot {s} {a}")
+    assert len(np.unique(runs[0][0][:, 1:4].round(6), axis=0)) > 40, "the slots are supposed to be in different places"
+
+
+def test_sharded_registration_world1_config5_geometry_vs_oracle():
+    """BASELINE config 5 at its own shape — 64 x 2048, recent_keyframe_num = 200 — with the registration on the RCCL-sharded kernel
+    sequence (alego_dist_init, world = 1: pack / evaluate / ncclAllReduce / step per solver evaluation) against the ORACLE, every
+    mapping frame teacher-forced: filtered maps, accepted queries, solver summaries, params_ per outer iteration, map pose.
+    min_keyframe_dist is lowered so that the window takes a key frame on every mapping frame."""
+    p = synth.default_params(64, 2048)
+    p.recent_keyframe_num = 200
+    p.min_keyframe_dist = 0.0004
+    h, o = binding.Handle(p), O.Oracle(p)
+    h.dist_init(0, 1, binding.dist_unique_id())
+    optimised = 0
+    for k in range(40):
+        pts = synth.scan(p, k)
+        h.set_lo_params(o.get("lo_params"))
+        h.set_lm_params(o.get("lm_params"))
+        o.process_scan(pts)
+        flags, odom, mp = h.scan_process(pts, stages=7)
+        if k == 0:
+            continue
+        _lm_compare(h, o, k, f"sharded 64x2048/K=200 scan {k}")
+        optimised += int(o.get("lm_info")[1])
+        want = o.get("map_pose")
+        assert np.abs(mp["t"] - want[:3]).max() < POSE_TOL and quat_angle(mp["q"], want[3:]) < POSE_TOL, k
+    assert optimised >= 15 and o.get("lm_info")[11] >= 18
+    h.dist_shutdown()
+    h.close()

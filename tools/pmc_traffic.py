@@ -1,6 +1,6 @@
 """Build profiles/r01_pmc_traffic.json from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE).
 
-usage: pmc_traffic.py <dir_fetch> <dir_write> <streams_per_launch> [tail]
+usage: pmc_traffic.py <dir_fetch> <dir_write> <streams_per_launch> [tail] [scan_launches]
 HBM bytes per launch = mean over the last `tail` dispatches of each kernel (steady state: the local map is full).
 Units as prescribed by MI355X_MICROARCH.md (HBM / rocprofv3 section): on gfx950 FETCH_SIZE counts 64 B per request
 where the requests are 128 B wide, so it is doubled; WRITE_SIZE is reported in KB like FETCH_SIZE and left uncorrected.
@@ -20,6 +20,7 @@ def load(d, counter):
 
 fd, wd, spl = sys.argv[1], sys.argv[2], int(sys.argv[3])
 tail = int(sys.argv[4]) if len(sys.argv) > 4 else 16
+scan_launches = int(sys.argv[5]) if len(sys.argv) > 5 else 0   # (steps of the run) x (stream groups): launches of a once-per-scan kernel
 F, W = load(fd, "FETCH_SIZE"), load(wd, "WRITE_SIZE")
 out = {"note": "steady-state mean per launch; FETCH_SIZE (KB) doubled per MI355X_MICROARCH.md HBM section (gfx950 counts 64 B per 128 B request), "
                "WRITE_SIZE (KB) uncorrected; kernels serialised by the counter collection",
@@ -29,4 +30,18 @@ for k in sorted(set(F) | set(W)):
     w = W.get(k, [0.0])[-tail:]
     fb, wb = 2.0 * 1024.0 * sum(f) / len(f), 1024.0 * sum(w) / len(w)
     out["kernels"][k] = {"fetch_bytes": round(fb), "write_bytes": round(wb), "hbm_bytes_per_launch": round(fb + wb), "dispatches": len(F.get(k, []))}
+if not scan_launches:
+    scan_launches = max(v["dispatches"] for k, v in out["kernels"].items() if not k.startswith("__amd"))
+# whole pipeline per scan of one stream: every kernel's steady-state bytes per launch x its launches per scan / streams per launch
+cor = unc = 0.0
+for k, v in out["kernels"].items():
+    if k.startswith("__amd"):
+        continue
+    w = v["dispatches"] / scan_launches / spl
+    cor += v["hbm_bytes_per_launch"] * w
+    unc += (v["fetch_bytes"] / 2.0 + v["write_bytes"]) * w
+    v["bytes_per_scan"] = round(v["hbm_bytes_per_launch"] * w)
+out["scan_launches"] = scan_launches
+out["hbm_bytes_per_scan"] = round(cor)
+out["hbm_bytes_per_scan_uncorrected"] = round(unc)
 json.dump(out, sys.stdout, indent=1)
