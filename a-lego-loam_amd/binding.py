@@ -28,7 +28,7 @@ EXPORTS = [
     "alego_dist_unique_id", "alego_dist_init", "alego_dist_shutdown", "alego_stream_setup", "alego_stream_run",
     "alego_loop_detect", "alego_loop_closure_icp",
     "alego_bag_open", "alego_bag_close", "alego_bag_last_error", "alego_bag_topic_count", "alego_bag_topic_info", "alego_bag_message_count",
-    "alego_bag_read_raw", "alego_bag_read_pc2",
+    "alego_bag_read_raw", "alego_bag_read_pc2", "alego_handle_lock", "alego_handle_unlock",
 ]
 
 REPLAY_PINGPONG = 0x100
@@ -195,6 +195,10 @@ def lib():
         L.alego_loop_detect.argtypes = [C.POINTER(AlegoParams), C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
         L.alego_loop_closure_icp.restype = C.c_int
         L.alego_loop_closure_icp.argtypes = [C.c_void_p, C.POINTER(KfIn), C.POINTER(KfIn), C.c_int32, C.POINTER(IcpResult), C.c_void_p, C.c_int32]
+        L.alego_handle_lock.restype = C.c_int
+        L.alego_handle_lock.argtypes = [C.c_void_p]
+        L.alego_handle_unlock.restype = C.c_int
+        L.alego_handle_unlock.argtypes = [C.c_void_p]
         L.alego_bag_open.restype = C.c_int
         L.alego_bag_open.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
         L.alego_bag_close.restype = None

@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <algorithm>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -37,6 +38,7 @@ int lo_configure();
 int lm_configure();
 
 struct alego_handle {
+  std::recursive_mutex host_lock;   // alego_handle_lock / alego_handle_unlock: for hosts that drive ONE handle from several threads (the three nodelets)
   alego_params P;
   int device = 0;
   hipStream_t stream = nullptr;       // = streams[0]
@@ -128,6 +130,8 @@ int alego_device_count(void) {
   return n;
 }
 int alego_params_sizeof(void) { return (int)sizeof(alego_params); }
+int alego_handle_lock(alego_handle* h) { if (!h) return ALEGO_ERR_ARG; h->host_lock.lock(); return 0; }
+int alego_handle_unlock(alego_handle* h) { if (!h) return ALEGO_ERR_ARG; h->host_lock.unlock(); return 0; }
 const char* alego_last_error(const alego_handle* h) { return h ? h->err.c_str() : "null handle"; }
 void* alego_stream(alego_handle* h) { return h ? (void*)h->stream : nullptr; }
 int alego_stream_groups(const alego_handle* h, int* slots_per_group) {

@@ -163,13 +163,14 @@ __global__ void icp_step(IcpState* S, const double* partial, int nwg, alego_para
   for (int k = 0; k < 16; ++k) { S->M[k] = M[k]; S->Tf[k] = Nf[k]; }
   S->apply = 1;
   const int it = ++S->iter;
-  // DefaultConvergenceCriteria::hasConverged (rotation threshold 0.99999 and absolute MSE 1e-12 are PCL's defaults)
+  // DefaultConvergenceCriteria::hasConverged (absolute MSE 1e-12 is PCL's default; IterativeClosestPoint::computeTransformation sets the
+  // rotation threshold to 1 - transformation_epsilon_ (PCL 1.8: setRotationThreshold(1.0 - transformation_epsilon_)), i.e. 0.999999 with laserMapping.cpp:673)
   bool conv = false;
   if (it >= P.icp_max_iters) conv = true;
   else {
     const double cos_angle = 0.5 * ((double)M[0] + (double)M[5] + (double)M[10] - 1.0);
     const double tr2 = (double)M[3] * M[3] + (double)M[7] * M[7] + (double)M[11] * M[11];
-    if (cos_angle >= 0.99999 && tr2 <= P.icp_trans_eps) conv = true;
+    if (cos_angle >= 1.0 - P.icp_trans_eps && tr2 <= P.icp_trans_eps) conv = true;
     else if (fabs(mse - S->prev_mse) < 1e-12) conv = true;
     else if (fabs(mse - S->prev_mse) / S->prev_mse < P.icp_fitness_eps) conv = true;
     else S->prev_mse = mse;

@@ -958,7 +958,9 @@ void launch_lm_grid(const DevCtx& d, const LmCtx& L, hipStream_t st) {
   ALEGO_LAUNCH(lm_grid_build, dim3(2, d.n_launch), dim3(LM_BLOCK), 0, st, d, L);
 }
 // allreduce(buffer, count of doubles, stream): sums shard_part over the ranks in place (RCCL, lm_host.hip); nullptr = not sharded
-void launch_lm_register(const DevCtx& d, const LmCtx& L, hipStream_t st, int (*allreduce)(void*, double*, size_t, hipStream_t), void* ar_ctx) {
+// Returns the first non-zero allreduce code: a failed collective (communicator aborted, peer gone) would leave the ranks stepping on
+// un-summed partials and hanging in the next one, so nothing further of this frame is enqueued and the caller reports the error.
+int launch_lm_register(const DevCtx& d, const LmCtx& L, hipStream_t st, int (*allreduce)(void*, double*, size_t, hipStream_t), void* ar_ctx) {
   ALEGO_LAUNCH(lm_knn, dim3(d.n_launch, 2, LM_ASSOC_GX), dim3(128), 0, st, d, L);
   ALEGO_LAUNCH(lm_fit, dim3(d.n_launch, 2, LM_FIT_GX), dim3(128), 0, st, d, L);
   if (allreduce) {
@@ -969,11 +971,11 @@ void launch_lm_register(const DevCtx& d, const LmCtx& L, hipStream_t st, int (*a
     for (int outer = 0; outer < d.P.lm_outer_iters; ++outer) {
       if (outer) ALEGO_LAUNCH(lm_shard_next_outer, g1, b1, 0, st, d, L);
       ALEGO_LAUNCH(lm_shard_eval, dim3(d.n_launch), dim3(LM_SOLVE_BLOCK), LM_SOLVE_LDS, st, d, L, 0);
-      (void)allreduce(ar_ctx, part, cnt, st);
+      if (int rc = allreduce(ar_ctx, part, cnt, st)) return rc;
       ALEGO_LAUNCH(lm_shard_step, g1, b1, 0, st, d, L, 1);
       for (int it = 0; it < d.P.lm_max_iters; ++it) {
         ALEGO_LAUNCH(lm_shard_eval, dim3(d.n_launch), dim3(LM_SOLVE_BLOCK), LM_SOLVE_LDS, st, d, L, 1);
-        (void)allreduce(ar_ctx, part, cnt, st);
+        if (int rc = allreduce(ar_ctx, part, cnt, st)) return rc;
         ALEGO_LAUNCH(lm_shard_step, g1, b1, 0, st, d, L, 0);
       }
     }
@@ -982,6 +984,7 @@ void launch_lm_register(const DevCtx& d, const LmCtx& L, hipStream_t st, int (*a
   }
   ALEGO_LAUNCH(lm_finish, dim3((d.n_launch + 63) / 64), dim3(64), 0, st, d, L);
   ALEGO_LAUNCH(lm_store_kf, dim3(8, 3, d.n_launch), dim3(LM_BLOCK), 0, st, d, L, -1);
+  return 0;
 }
 void launch_lm_retransform(const DevCtx& d, const LmCtx& L, int ring, hipStream_t st) {
   ALEGO_LAUNCH(lm_store_kf, dim3(8, 3, d.n_launch), dim3(LM_BLOCK), 0, st, d, L, ring);

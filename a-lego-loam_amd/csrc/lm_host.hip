@@ -17,7 +17,7 @@ void launch_lm_prepare(const DevCtx& d, const LmCtx& L, int stage, int run_hint,
 void launch_lm_concat(const DevCtx& d, const LmCtx& L, hipStream_t st);
 void launch_lm_total(const DevCtx& d, const LmCtx& L, hipStream_t st);
 void launch_lm_grid(const DevCtx& d, const LmCtx& L, hipStream_t st);
-void launch_lm_register(const DevCtx& d, const LmCtx& L, hipStream_t st, int (*allreduce)(void*, double*, size_t, hipStream_t), void* ar_ctx);
+int launch_lm_register(const DevCtx& d, const LmCtx& L, hipStream_t st, int (*allreduce)(void*, double*, size_t, hipStream_t), void* ar_ctx);
 void launch_lm_retransform(const DevCtx& d, const LmCtx& L, int ring, hipStream_t st);
 struct MapWork { int* items; int* count; int cap; };   // kernels_map.hip
 void launch_map_update(const DevCtx& d, const LmCtx& L, const MapWork& W, hipStream_t st);
@@ -239,7 +239,7 @@ static int lm_sequence(LmHost* lm, const DevCtx& d, int stage, const std::vector
   launch_lm_total(d, L, st);
   if (int r = vox_run(lm->v2[g], st, err)) return r;
   if (!dbg_sync(st, "vox total", err)) return ALEGO_ERR_HIP;
-  launch_lm_register(d, L, st, lm->comm ? &lm_allreduce : nullptr, lm);
+  if (int r = launch_lm_register(d, L, st, lm->comm ? &lm_allreduce : nullptr, lm)) { *err = "sharded registration: " + lm->dist_err; return r; }
   if (!dbg_sync(st, "lm_register", err)) return ALEGO_ERR_HIP;
   return 0;
 }

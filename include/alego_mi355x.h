@@ -105,6 +105,12 @@ const char* alego_last_error(const alego_handle* h);
 int alego_device_count(void);
 /* size of alego_params this library was built with (binding sanity check) */
 int alego_params_sizeof(void);
+/* A handle is single-threaded: one caller at a time.  A host that drives ONE handle from several threads — the three nodelets of
+ * launch/test.launch:6-10 share a process, the reference serialises them with per-node mutexes (laserOdometry.cpp:93,548;
+ * laserMapping.cpp:114,729,769) — brackets every call (and every group of calls that must see a consistent handle) with this
+ * recursive lock, which lives in the handle so that all users of the handle share it. */
+int alego_handle_lock(alego_handle* h);
+int alego_handle_unlock(alego_handle* h);
 
 /* ---- nodelet-equivalent single-scan entry points (host buffers, slot 0) --- */
 int alego_ip_process(alego_handle* h, const alego_scan_in* in, alego_seg_out* out);

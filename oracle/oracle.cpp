@@ -1891,11 +1891,12 @@ int oracle_loop_icp(const alego_params* P, const float* poses6, const alego_poin
     for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) N[r * 4 + c] = M[r * 4 + 0] * Tf[0 * 4 + c] + M[r * 4 + 1] * Tf[1 * 4 + c] + M[r * 4 + 2] * Tf[2 * 4 + c] + M[r * 4 + 3] * Tf[3 * 4 + c];
     std::memcpy(Tf, N, sizeof(N));
     ++it;
-    // DefaultConvergenceCriteria::hasConverged (rotation threshold 0.99999, absolute MSE 1e-12: PCL's defaults)
+    // DefaultConvergenceCriteria::hasConverged (absolute MSE 1e-12: PCL's default; rotation threshold = 1 - transformation_epsilon_ as
+    // IterativeClosestPoint::computeTransformation sets it in PCL 1.8, 0.999999 with laserMapping.cpp:673)
     if (it >= P->icp_max_iters) { converged = 1; break; }
     const double cos_angle = 0.5 * ((double)M[0] + (double)M[5] + (double)M[10] - 1.0);
     const double tr2 = (double)M[3] * M[3] + (double)M[7] * M[7] + (double)M[11] * M[11];
-    if (cos_angle >= 0.99999 && tr2 <= P->icp_trans_eps) { converged = 1; break; }
+    if (cos_angle >= 1.0 - P->icp_trans_eps && tr2 <= P->icp_trans_eps) { converged = 1; break; }
     if (std::fabs(mse - prev_mse) < 1e-12) { converged = 1; break; }
     if (std::fabs(mse - prev_mse) / prev_mse < P->icp_fitness_eps) { converged = 1; break; }
     prev_mse = mse;

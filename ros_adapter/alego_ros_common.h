@@ -49,6 +49,18 @@ inline alego_handle* shared_handle(ros::NodeHandle& pnh) {
   return h;
 }
 
+// The shared handle is single-threaded by contract, but ImageProjection's callback, LaserOdometry's main loop + IMU handler and
+// LaserMapping's main loop run on different threads of the nodelet manager: every alego_* call on the handle is bracketed by
+// the handle's own lock (alego_handle_lock: one mutex per handle, whoever the caller is — a mutex that is a member of one
+// nodelet would not exclude the other two).
+struct HandleLock {
+  alego_handle* h;
+  explicit HandleLock(alego_handle* handle) : h(handle) { if (h) alego_handle_lock(h); }
+  ~HandleLock() { if (h) alego_handle_unlock(h); }
+  HandleLock(const HandleLock&) = delete;
+  HandleLock& operator=(const HandleLock&) = delete;
+};
+
 // pcl::fromROSMsg<PointXYZI> without PCL (imageProjection.cpp:54-55)
 inline int from_ros(const sensor_msgs::PointCloud2& msg, std::vector<alego_point>& out) {
   std::vector<alego_pc2_field> f(msg.fields.size());

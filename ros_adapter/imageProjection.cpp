@@ -34,7 +34,10 @@ class ImageProjection : public nodelet::Nodelet {
     out.seg = seg_.data(); out.seg_cap = n_; out.outlier = outlier_.data(); out.outlier_cap = n_;
     out.ground = info_->segmentedCloudGroundFlag.data(); out.col = info_->segmentedCloudColInd.data(); out.range = info_->segmentedCloudRange.data();
     out.ring_start = info_->startRingIndex.data(); out.ring_end = info_->endRingIndex.data();
-    if (alego_ip_process(h_, &in, &out) < 0) { NODELET_ERROR("alego_ip_process: %s", alego_last_error(h_)); return; }
+    {
+      alego_ros::HandleLock lock(h_);   // LaserOdometry / LaserMapping drive the same handle from their own threads
+      if (alego_ip_process(h_, &in, &out) < 0) { NODELET_ERROR("alego_ip_process: %s", alego_last_error(h_)); return; }
+    }
     info_->header = msg->header;
     info_->startOrientation = out.orientation[0]; info_->endOrientation = out.orientation[1]; info_->orientationDiff = out.orientation[2];
     if (pub_info_.getNumSubscribers() > 0) pub_info_.publish(info_);                    // :320-335: only with subscribers

@@ -49,6 +49,7 @@ class LaserMapping : public nodelet::Nodelet {
       new_surf_ = new_corner_ = new_outlier_ = new_odom_ = false;
       if (!h_) continue;
       alego_pose mapped;
+      alego_ros::HandleLock lock(h_);   // until the end of this iteration: alego_lm_process and the key-frame fetch see one handle state
       const int flags = alego_lm_process(h_, corner_.data(), (int32_t)corner_.size(), surf_.data(), (int32_t)surf_.size(), outlier_.data(),
                                          (int32_t)outlier_.size(), &odom_, &mapped);
       if (flags < 0) { NODELET_ERROR("alego_lm_process: %s", alego_last_error(h_)); continue; }

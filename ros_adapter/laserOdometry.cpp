@@ -48,7 +48,7 @@ class LaserOdometry : public nodelet::Nodelet {
     s.orientation[0] = m->orientation.w; s.orientation[1] = m->orientation.x; s.orientation[2] = m->orientation.y; s.orientation[3] = m->orientation.z;
     s.linear_acceleration[0] = m->linear_acceleration.x; s.linear_acceleration[1] = m->linear_acceleration.y; s.linear_acceleration[2] = m->linear_acceleration.z;
     s.angular_velocity[0] = m->angular_velocity.x; s.angular_velocity[1] = m->angular_velocity.y; s.angular_velocity[2] = m->angular_velocity.z;
-    std::lock_guard<std::mutex> l(m_lib_);   // a handle is single-threaded: the main loop takes the same lock around alego_lo_process
+    alego_ros::HandleLock lock(h_);   // a handle is single-threaded: the main loop, ImageProjection and LaserMapping take the same lock
     if (alego_lo_push_imu(h_, 0, &s, 1) < 0) NODELET_WARN_THROTTLE(1.0, "alego_lo_push_imu: %s", alego_last_error(h_));
   }
 
@@ -84,8 +84,11 @@ class LaserOdometry : public nodelet::Nodelet {
       in.stamp = seg->header.stamp.toSec();   // t1 (:111)
       alego_pose odom;
       int flags;
-      { std::lock_guard<std::mutex> l(m_lib_); flags = alego_lo_process(h_, &in, &f, &odom); }
-      if (flags < 0) { NODELET_ERROR("alego_lo_process: %s", alego_last_error(h_)); continue; }
+      {
+        alego_ros::HandleLock lock(h_);
+        flags = alego_lo_process(h_, &in, &f, &odom);
+        if (flags < 0) { NODELET_ERROR("alego_lo_process: %s", alego_last_error(h_)); continue; }
+      }
       std_msgs::Header hd = seg->header;
       hd.frame_id = "/laser";
       auto pub = [&](ros::Publisher& p, const alego_point* pts, int n) {
@@ -117,7 +120,7 @@ class LaserOdometry : public nodelet::Nodelet {
   ros::Subscriber sub_seg_, sub_info_, sub_outlier_, sub_imu_;
   ros::Publisher pub_corner_, pub_corner_less_, pub_surf_, pub_surf_less_, pub_odom_, pub_surf_last_, pub_corner_last_;
   tf::TransformBroadcaster tf_;
-  std::mutex m_buf_, m_lib_;
+  std::mutex m_buf_;
   std::queue<sensor_msgs::PointCloud2ConstPtr> seg_buf_, outlier_buf_;
   std::queue<alego::cloud_infoConstPtr> info_buf_;
   alego_handle* h_ = nullptr;
