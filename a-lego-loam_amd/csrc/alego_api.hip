@@ -217,6 +217,7 @@ int alego_create(const alego_params* params, int device, int n_slots, int ring_l
   d.h_magic = (unsigned)((1ull << 32) / (unsigned long long)d.H) + 1u;
   d.inv_res_x = 1.0 / params->ang_res_x; d.inv_res_y = 1.0 / params->ang_res_y;
   d.tan_theta = (params->seg_theta > 0.0 && params->seg_theta < 1.5) ? std::tan(params->seg_theta) : std::nan("");
+  d.opt_ip_fused = env_int("ALEGO_IP_FUSED", 1) != 0;
   d.opt_cc_fused = env_int("ALEGO_CC_FUSED", 1) != 0;
   d.opt_cc_tile = env_int("ALEGO_CC_TILE", 1) != 0;
   d.opt_fe_pick1 = env_int("ALEGO_FE_PICK1", 0) != 0;
@@ -870,6 +871,7 @@ int alego_debug_set_option(alego_handle* h, const char* name, int value) {
   const std::string s(name);
   DevCtx& d = h->d;
   if (s == "ALEGO_CC_FUSED") d.opt_cc_fused = value != 0;
+  else if (s == "ALEGO_IP_FUSED") d.opt_ip_fused = value != 0;
   else if (s == "ALEGO_CC_TILE") d.opt_cc_tile = value != 0;
   else if (s == "ALEGO_FE_PICK1") d.opt_fe_pick1 = value != 0;
   else if (s == "ALEGO_LO_BOX_LDS") d.opt_lo_box_lds = value;

@@ -56,6 +56,7 @@ struct DevCtx {
   double tan_g_lo, tan_g_hi;              // tan of (sensor_mount_ang -/+ ground_angle_thres) (ground test shortcut; NaN disables)
   double tan_theta;                       // tan(seg_theta) for the edge predicate shortcut; NaN disables the shortcut
   // ---- kernel-variant switches (read once from the environment by alego_create, alego_debug_set_option overrides) ----
+  int opt_ip_fused;     // ALEGO_IP_FUSED   1: ImageProjection as one launch, one workgroup per stream (ip_fused; <= 16 rings, <= 32768 cells); 0: ip_project + ip_front + cc_*
   int opt_cc_fused;     // ALEGO_CC_FUSED   1: cc_lds16 also compacts; 0: ip_rowcount + ip_compact
   int opt_cc_tile;      // ALEGO_CC_TILE    1: images beyond the LDS paths are labelled band by band in LDS (cc_tile + cc_seam); 0: cc_runs + cc_link
   int opt_fe_pick1;     // ALEGO_FE_PICK1   1: one ring per wavefront (fe_pick) instead of fe_pick4

@@ -18,6 +18,7 @@
 // in between (owner, range, flags, parent: 13 B/cell) stay L2-resident.
 #include <cstdlib>
 #include "dev_common.h"
+#include "ip_common.h"
 #include "prof.h"
 
 #define IP_BLOCK 256
@@ -39,95 +40,10 @@ __global__ void __launch_bounds__(IP_BLOCK) ip_project(DevCtx d, int ring_pos) {
   bool valid = false;
   if (i < n) {
     const float4 p = pin[u];
-    // pcl::removeNaNFromPointCloud only filters when the message is not dense (alego_params.input_is_dense); an unfiltered
-    // non-finite point still counts as first / last point of the scan and is rejected by the row test (int(NaN) < 0)
-    const bool finite = isfinite(p.x) && isfinite(p.y) && isfinite(p.z);
-    valid = finite || P.input_is_dense != 0;
-    if (valid && P.near_filter) {
-      const float th = (float)P.near_thres;
-      if (p.x * p.x + p.y * p.y + p.z * p.z < th * th) valid = false;  // IP.cpp:91
-    }
-    if (valid && finite) {
-      // ---- fast path: cell from the boundary tables.  The reference rounds atan2f / hypotf to f32 before it divides by the
-      // angular resolution, so its row / column is the cell of the TRUE angle unless that angle lies within ~7e-5 cells of a
-      // boundary.  A polynomial estimate (good to 0.03 cells) picks a boundary, the exact offset to it comes from one
-      // cross / dot product against the boundary's (cos, sin) (fp64 products, f32 quotient: error < 1e-6 cells), and a point
-      // closer than 2.5e-4 columns / 1e-4 rows to any boundary takes the reference expressions below.  Every comparison is
-      // written so that a NaN or an out-of-range estimate also lands there.
-      int row = -1, col = -1;
-      bool slow = true;
-      {
-        const float h2 = p.x * p.x + p.y * p.y, hf = __builtin_amdgcn_sqrtf(h2);   // (v_sqrt_f32 / v_rcp_f32: 1 ulp is plenty here)
-        bool okr = (d.ip_fast & 1) && hf > 1e-3f && hf < 1e6f && fabsf(p.z) < 1e6f;
-        const float t = p.z * __builtin_amdgcn_rcpf(hf), t2 = t * t;
-        okr = okr && fabsf(t) < 0.6f;
-        const float a = t * (0.99997726f + t2 * (-0.33262347f + t2 * (0.19354346f + t2 * (-0.11643287f + t2 * (0.05265332f + t2 * -0.01172120f)))));
-        const float r0 = (a * 57.29577951f + (float)P.ang_bottom) * (float)d.inv_res_y + 0.5f;
-        const float kf = floorf(r0);
-        okr = okr && kf >= -3.0f && kf <= (float)(d.NS + 1);
-        const int kk = okr ? (int)kf : 0;
-        const double2 cs = d.ip_rowtab[kk + 3];
-        const float cr = (float)((double)p.z * cs.x - (double)hf * cs.y), dt = (float)((double)hf * cs.x + (double)p.z * cs.y);
-        const float q = cr * __builtin_amdgcn_rcpf(dt);
-        const float frac = q * (1.0f - q * q * 0.33333333f) * (57.29577951f * (float)d.inv_res_y);
-        const float fl = floorf(frac), dlo = frac - fl, dhi = 1.0f - dlo;
-        const int rfl = kk + (int)fl;   // floor of the reference's r; (int)r truncates: r in (-1, 1) is row 0, so 0 is no boundary
-        okr = okr && dt > 0.0f && frac > -1.0f && frac < 2.0f && (dlo >= 1e-4f || rfl == 0) && (dhi >= 1e-4f || rfl + 1 == 0);
-        // columns
-        const float ax = fabsf(p.x), ay = fabsf(p.y), mn = fminf(ax, ay), mx = fmaxf(ax, ay);
-        bool okc = (d.ip_fast & 2) && mx > 1e-3f && mx < 1e6f;
-        const float u = mn * __builtin_amdgcn_rcpf(mx), u2 = u * u;
-        float b = u * (0.99997726f + u2 * (-0.33262347f + u2 * (0.19354346f + u2 * (-0.11643287f + u2 * (0.05265332f + u2 * -0.01172120f)))));
-        b = ay > ax ? 1.57079633f - b : b;
-        b = p.x < 0.0f ? 3.14159265f - b : b;
-        b = p.y < 0.0f ? -b : b;
-        const float cf = floorf((6.28318531f - b) * (57.29577951f * (float)d.inv_res_x)) - (float)d.ip_cmin;
-        okc = okc && cf >= 0.0f && cf <= (float)(d.ip_ncb - 1);
-        const int ci = okc ? (int)cf : 0;
-        const double2 cc = d.ip_coltab[ci];
-        const float crc = (float)(-(double)p.y * cc.x - (double)p.x * cc.y), dtc = (float)((double)p.x * cc.x - (double)p.y * cc.y);
-        const float qc = crc * __builtin_amdgcn_rcpf(dtc);
-        const float fc = qc * (1.0f - qc * qc * 0.33333333f) * (57.29577951f * (float)d.inv_res_x);
-        const float flc = floorf(fc), dloc = fc - flc;
-        okc = okc && dtc > 0.0f && fc > -1.0f && fc < 2.0f && dloc >= 2.5e-4f && 1.0f - dloc >= 2.5e-4f;
-        if (okr && okc) {
-          slow = false;
-          row = rfl >= 0 ? rfl : (rfl == -1 ? 0 : -1);
-          col = d.ip_cmin + ci + (int)flc;
-          if (col >= d.H) col -= d.H;
-        }
-      }
-      if (slow) {
-      // imageProjection.cpp:79-80 (IP.cpp:142-172 for the RFANS table)
-      // (a * 180.0) / M_PI and x / ang_res are IEEE fp64 divisions in the reference (~35 instructions each here).  The
-      // integer part of the result only depends on the exact quotient when it lies within rounding error of an
-      // integer: multiply by the reciprocals first and redo the reference expression only in that case.
-      const double va = (double)d_atan2f(p.z, d_hypotf(p.x, p.y)) * 180.0;
-      if (P.laser_type == ALEGO_LASER_UNIFORM) {
-        const double r = (va * (1.0 / M_PI) + P.ang_bottom) * d.inv_res_y + 0.5;
-        row = (int)r;
-        if (fabs(r - rint(r)) < 1e-9 * (1.0 + fabs(r))) row = (int)((va / M_PI + P.ang_bottom) / P.ang_res_y + 0.5);
-      } else {  // RFANS ring table (IP.cpp:142-172)
-        const double vertical_ang = va / M_PI;
-        if (vertical_ang > 4.5) row = (int)(13 + (vertical_ang - 5.) / 3 + 0.5);
-        else if (vertical_ang > 0.5) row = (int)(11 + (vertical_ang - 1.0) / 2 + 0.5);
-        else if (vertical_ang > -7.) row = (int)(10.5 + vertical_ang);
-        else if (vertical_ang > -8.5) row = 3;
-        else if (vertical_ang > -10.5) row = 2;
-        else if (vertical_ang > -13.5) row = 1;
-        else row = 0;
-      }
-      // :87-97
-      const double ha = ((double)(-d_atan2f(p.y, p.x)) + 2 * M_PI) * 180.0;
-      const double cfast = ha * (1.0 / M_PI) * d.inv_res_x;
-      col = (int)cfast;
-      if (fabs(cfast - rint(cfast)) < 1e-9 * (1.0 + fabs(cfast))) col = (int)((ha / M_PI) / P.ang_res_x);
-      if (col >= d.H) col -= d.H;
-      }
-      if (row >= 0 && row < d.NS && col >= 0 && col < d.H)
-        atomicMax(&d.owner[(size_t)slot * d.N + col + row * d.H], IP_OWNER_TAG | i);  // later points overwrite earlier ones (:102-103);
+    const int cell = ip_point_cell(d, p, &valid);
+    if (cell >= 0)
+      atomicMax(&d.owner[(size_t)slot * d.N + cell], IP_OWNER_TAG | i);  // later points overwrite earlier ones (:102-103);
         // whatever the previous scan left in the cell (a plain index or -1, see ip_front) loses against a tagged entry: no reset pass
-    }
   }
   if (valid) { vmin = min(vmin, i); vmax = max(vmax, i); ++nvalid; }
   }
@@ -148,16 +64,6 @@ __global__ void __launch_bounds__(IP_BLOCK) ip_project(DevCtx d, int ring_pos) {
 
 DEV_INLINE int ld_agent(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 DEV_INLINE void st_agent(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
-// atan2(y, x) > theta for y > 0, x > 0 (y = d2 sin a, x = d1 - d2 cos a with d1 >= d2 > 0 and 0 < a < pi/2).
-// tan is monotone on (0, pi/2): the comparison is decided by the sign of y - x tan(theta) whenever that difference is
-// far (1e-9 relative) from zero — rounding errors of either form are ~1e-16 — and by the reference expression itself
-// otherwise.  Saves two fp64 atan2 per cell on all but a vanishing fraction of the edges.
-DEV_INLINE bool edge_angle_gt(double y, double x, double theta, double tan_theta) {
-  const double xt = x * tan_theta, m = y - xt;
-  if (fabs(m) > 1e-9 * (y + fabs(xt))) return m > 0.0;
-  return atan2(y, x) > theta;
-}
 
 // ip_front = range image + ground labelling + edge predicates in one launch (imageProjection.cpp:62-72,:107-143,:255-270).
 // A workgroup takes IPF_W - 1 consecutive columns plus the column to their right (halo, with wrap-around): one thread per
@@ -239,19 +145,7 @@ __global__ void __launch_bounds__(IPF_W) ip_front(DevCtx d, int ring_pos, int in
       s_r[row * IPF_W + tid] = r;
       if (mine && (init & 8)) rimg[row * d.H + col] = r;
       if (row >= 1 && row - 1 < P.ground_scan_id && ok && lower_ok) {  // :111-131, pair (row-1,row)
-        const double dx = (double)(x - lx), dy = (double)(y - ly), dz = (double)(z - lz);
-        // |deg(atan2(dz, hypot(dx, dy))) - mount| < thres  <=>  tan(lo) h < dz < tan(hi) h; decided by the two signed
-        // margins unless one of them is within 1e-9 (relative) of zero, where the reference expression decides
-        const double hq = sqrt(dx * dx + dy * dy);
-        const double m1 = dz - d.tan_g_lo * hq, m2 = d.tan_g_hi * hq - dz, tol = 1e-9 * (fabs(dz) + hq);
-        bool is_ground;
-        if (m1 > tol && m2 > tol) is_ground = true;
-        else if (m1 < -tol || m2 < -tol) is_ground = false;
-        else {
-          const double angle = (atan2(dz, hypot(dx, dy)) * 180.0) / M_PI;
-          is_ground = fabs(angle - P.sensor_mount_ang) < P.ground_angle_thres;
-        }
-        if (is_ground) ground |= 3ull << (row - 1);
+        if (ip_is_ground(d, x - lx, y - ly, z - lz)) ground |= 3ull << (row - 1);
       }
       lx = x; ly = y; lz = z; lower_ok = ok;
     }
@@ -551,48 +445,6 @@ __global__ void __launch_bounds__(CC_LDS_THREADS) cc_lds(DevCtx d, int ring_pos,
     // label_cnt_ numbering (:303-306); 0 for the root of an infeasible component (ip_labels turns it into 999999)
     if (rt[k] == v) d.cc_label[base + v] = fr ? s_cnt[2][k * NW + wave] + (int)__popcll(bf & below) + 1 : 0;
   }
-}
-
-// 16-bit variant for n_scan <= 16 (every such image has < 65536 cells): the parent array takes 2 B/cell (58 KB at 16x1800
-// instead of 115 KB), so that two of these workgroups — or one of them and the other stream groups' workgroups — fit a CU;
-// under load the kernel's duration is decided by that, not by its instruction count.  LDS has no 16-bit atomics: the union's
-// compare-and-swap goes through the aligned 32-bit word (a concurrent change of the other half makes it retry), the
-// path-halving stores are plain 16-bit stores (parents only ever decrease, any ancestor is a valid parent).  Component size
-// and row mask are accumulated one after the other in the ROOTS' OWN parent entries with 32-bit atomics on the packed
-// halves (sizes < 65536 cannot carry into the neighbour; OR is bit-local): 2 B/cell of LDS in total.
-DEV_INLINE int ccl16_find(uint16_t* par, int v) {
-  int curr = par[v];
-  if (curr != v) {
-    int prev = v, next;
-    while (curr > (next = par[curr])) { par[prev] = (uint16_t)next; prev = curr; curr = next; }
-  }
-  return curr;
-}
-// compare-and-swap of entry idx (expect -> val); returns the entry's previous value
-DEV_INLINE int ccl16_cas(uint16_t* par, int idx, int expect, int val) {
-  unsigned* w = reinterpret_cast<unsigned*>(par) + (idx >> 1);
-  const int sh = (idx & 1) * 16;
-  unsigned old = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  while (true) {
-    const int cur = (int)((old >> sh) & 0xFFFFu);
-    if (cur != expect) return cur;
-    const unsigned nw = (old & ~(0xFFFFu << sh)) | ((unsigned)val << sh);
-    const unsigned got = atomicCAS(w, old, nw);
-    if (got == old) return expect;
-    old = got;
-  }
-}
-DEV_INLINE void ccl16_union(uint16_t* par, int a, int b) {
-  int ra = ccl16_find(par, a), rb = ccl16_find(par, b);
-  bool repeat;
-  do {
-    repeat = false;
-    if (ra != rb) {
-      int ret;
-      if (ra < rb) { if ((ret = ccl16_cas(par, rb, rb, ra)) != rb) { rb = ret; repeat = true; } }
-      else { if ((ret = ccl16_cas(par, ra, ra, rb)) != ra) { ra = ret; repeat = true; } }
-    }
-  } while (repeat);
 }
 
 // Images too large for one workgroup's LDS (more than 16 rings with more than CC_LDS_MAXN cells: 64x2048): two-level labelling.
@@ -1088,7 +940,16 @@ __global__ void atan2f_probe(const float* y, const float* x, float* out, int n, 
 }
 
 // ---- host-side launchers -------------------------------------------------------
+bool ipf_eligible(const DevCtx& d);
+void launch_ip_fused(const DevCtx& d, int ring_pos, bool keep_images, hipStream_t st);
+int ipf_configure(const DevCtx& d);
+
 void launch_ip(const DevCtx& d, int ring_pos, bool want_labels, hipStream_t st) {
+  if (d.opt_ip_fused && ipf_eligible(d)) {   // one workgroup per stream, everything between the input points and cloud_info on chip (kernels_ipf.hip)
+    launch_ip_fused(d, ring_pos, want_labels || d.n_launch == 1, st);
+    if (want_labels) hipLaunchKernelGGL(ip_labels, dim3((d.N + IP_BLOCK - 1) / IP_BLOCK, d.n_launch), dim3(IP_BLOCK), 0, st, d);
+    return;
+  }
   const bool lds16 = d.NS <= 16 && d.N <= CC_LDS16_MAXN;
   const bool fused = d.opt_cc_fused && lds16;   // cc_lds16 also does the compaction
   const dim3 gN((d.N + IP_BLOCK - 1) / IP_BLOCK, d.n_launch);
@@ -1127,6 +988,7 @@ void launch_atan2f_probe(const float* y, const float* x, float* out, int n, int 
 
 // dynamic LDS above 64 KB has to be requested explicitly
 int ip_configure(const DevCtx& d) {
+  if (ipf_configure(d) != 0) return -1;
   if (d.N <= CC_LDS_MAXN && hipFuncSetAttribute(reinterpret_cast<const void*>(cc_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * d.N) != hipSuccess) return -1;
   if (d.NS <= 16 && d.N <= CC_LDS16_MAXN &&
       hipFuncSetAttribute(reinterpret_cast<const void*>(cc_lds16), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * ((d.N + 1) / 2)) != hipSuccess) return -1;   // <= 126 KB

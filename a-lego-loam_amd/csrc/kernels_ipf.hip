@@ -1,0 +1,426 @@
+// kernels_ipf.hip — ImageProjection as ONE launch: a workgroup per stream keeps the whole range-image pipeline on chip
+// (replaces src/imageProjection.cpp:49-316 for sensors of up to 16 rings and 32 768 cells; larger images and odd widths take the
+// multi-kernel path of kernels_ip.hip, which also stays available as the cross-check: ALEGO_IP_FUSED=0).
+//
+//   phase A  a1-a3  every thread projects n / 1024 input points (ip_point_cell, shared with ip_project); last writer wins by
+//                   ds_max_u32 on a 32-bit owner image in LDS (4 B / cell: 115 KB at 16 x 1800)                    (:58-104)
+//   phase B  a2-a4  a thread takes two adjacent columns: owner -> point gather (the only re-read of the input, mostly
+//                   coalesced), ranges in registers, ground test on consecutive rows, right- / down-edge predicates with the
+//                   right neighbour's column through a lane shift (LDS only at wavefront boundaries and for the wrap-around)
+//                   (:62-72,:107-143,:255-270).  The owner image shrinks to 2 B / cell in place; per-column state is four
+//                   16-bit row masks (ground, active, edge->right, edge->down)
+//   phase C  a5     vertical runs from the masks (no memory traffic), 16-bit lock-free union-find in LDS over the right-edges that
+//                   connect different run pairs, flatten, component size and row mask accumulated PER RUN in the roots' own
+//                   entries (2 B / cell of LDS for the parents: owner 2 N + parents 2 N + masks 8 H = 130 KB)      (:210-316)
+//   phase D  a6     ordered compaction: per row and wavefront ballots -> one 256-entry scan -> every kept cell's output line;
+//                   second (and last) gather of the kept cells' points, cloud_info arrays written once              (:158-191)
+//
+// Against ip_project + ip_front + cc_lds16: no owner / flag images in HBM, no tag reset protocol between workgroups, one launch
+// instead of three, and the per-cell passes of cc_lds16 (29 cells x 10 passes per thread) become bit operations on 16-bit
+// row masks.  HBM traffic: 16 P in, one gather of the filled cells, one of the kept cells, 25 M + 16 O out.
+#include <cstdlib>
+#include "dev_common.h"
+#include "ip_common.h"
+#include "prof.h"
+
+#define IPF2_T 1024
+#define IPF2_NW (IPF2_T / 64)
+#define IPF2_ROWS 16
+
+struct IpfShared {
+  float first_r[IPF2_NW][IPF2_ROWS];   // ranges of the first column of every wavefront (right neighbour of the previous wavefront's last column)
+  unsigned first_act[IPF2_NW];
+  int red[3][IPF2_NW];
+  int cnt[3][IPF2_ROWS * IPF2_NW];     // per (row, wavefront): kept cells, outliers, feasible roots -> exclusive prefix in row-major order
+  int wtot[3][4];
+  int tot[3];
+};
+
+#ifdef ALEGO_TIMING
+__device__ long long ipf_times[16];
+#define IPF_TICK(k) do { if (threadIdx.x == 0 && blockIdx.x == 0) ipf_times[k] = wall_clock64(); } while (0)
+extern "C" void alego_ipf_times(long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(ipf_times), sizeof(long long) * 16); }
+#else
+#define IPF_TICK(k)
+#endif
+
+DEV_INLINE int ipf_run_start(unsigned rs, int row) { return 31 - __clz((int)(rs & ((2u << row) - 1u))); }       // highest run start at or below row
+DEV_INLINE int ipf_run_end(unsigned down, int s) { return s + __ffs((int)~(down >> s)) - 1; }                    // s + number of consecutive down-edges from s
+
+bool ipf_eligible(const DevCtx& d) { return d.NS <= IPF2_ROWS && (d.H & 1) == 0 && d.H >= 64 && d.H <= 2 * IPF2_T && d.N <= 32768; }
+size_t ipf_lds_bytes(const DevCtx& d) { return (size_t)4 * d.N + (size_t)8 * d.H; }
+
+// keep bit 0: the single-scan entry points / tests read the range, flag, root and label images back
+__global__ void __launch_bounds__(IPF2_T) ip_fused(DevCtx d, int ring_pos, int keep) {
+  const int slot = blockIdx.x + d.slot0;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int N = d.N, H = d.H, NS = d.NS;
+  const size_t base = (size_t)slot * N;
+  const alego_params& P = d.P;
+  extern __shared__ __attribute__((aligned(16))) unsigned char ipf_smem[];
+  unsigned* own32 = reinterpret_cast<unsigned*>(ipf_smem);                                   // [N] phases A, B
+  uint16_t* own16 = reinterpret_cast<uint16_t*>(ipf_smem);                                   // [N] from phase C on: index + 1, 0 = empty
+  uint16_t* par = own16 + N;                                                                 // [N]
+  unsigned long long* fcol = reinterpret_cast<unsigned long long*>(ipf_smem + (size_t)4 * N);   // [H] ground | active << 16 | right << 32 | down << 48
+  __shared__ IpfShared S;
+
+  // ---------------- phase A: projection ----------------
+  IPF_TICK(0);
+  for (int v = tid; v < N; v += IPF2_T) own32[v] = 0u;
+  __syncthreads();
+  const int n = scan_count(d, slot, ring_pos);
+  const float4* pts = scan_pts(d, slot, ring_pos);
+  int vmin = 0x7fffffff, vmax = -1, nvalid = 0;
+#pragma unroll 1
+  for (int i0 = tid; i0 < n; i0 += IPF2_T * 4) {
+    float4 pin[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) pin[u] = pts[min(i0 + u * IPF2_T, n - 1)];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * IPF2_T;
+      if (i < n) {
+        bool valid;
+        const int cell = ip_point_cell(d, pin[u], &valid);
+        if (cell >= 0) atomicMax(&own32[cell], (unsigned)(i + 1));   // later points overwrite earlier ones (:102-103)
+        if (valid) { vmin = min(vmin, i); vmax = max(vmax, i); ++nvalid; }
+      }
+    }
+  }
+  IPF_TICK(1);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    vmin = min(vmin, __shfl_xor(vmin, o, 64));
+    vmax = max(vmax, __shfl_xor(vmax, o, 64));
+    nvalid += __shfl_xor(nvalid, o, 64);
+  }
+  if (lane == 0) { S.red[0][wave] = vmin; S.red[1][wave] = vmax; S.red[2][wave] = nvalid; }
+  __syncthreads();
+  if (tid == 0) {   // orientation block (:62-72)
+    int first = 0x7fffffff, last = -1, pv = 0;
+    for (int w = 0; w < IPF2_NW; ++w) { first = min(first, S.red[0][w]); last = max(last, S.red[1][w]); pv += S.red[2][w]; }
+    d.scal[slot * SC_COUNT + SC_PVALID_OUT] = pv;
+    if (last >= 0) {
+      float* ori = d.ori + slot * 4;
+      const float4 p0 = pts[first], p1 = pts[last];
+      float so = -d_atan2f(p0.y, p0.x);
+      float eo = (float)((double)(-d_atan2f(p1.y, p1.x)) + 2 * M_PI);
+      if ((double)(eo - so) > 3 * M_PI) eo = (float)((double)eo - 2 * M_PI);
+      else if ((double)(eo - so) < M_PI) eo = (float)((double)eo + 2 * M_PI);
+      ori[0] = so; ori[1] = eo; ori[2] = eo - so;
+    }
+  }
+
+  IPF_TICK(2);
+  // ---------------- phase B: ranges, ground, edges (two adjacent columns per thread) ----------------
+  const int c0 = 2 * tid, c1 = c0 + 1;
+  const bool colv = c0 < H;
+  float rng0[IPF2_ROWS], rng1[IPF2_ROWS];
+  unsigned opk[IPF2_ROWS];
+  unsigned filled0 = 0, filled1 = 0, ground0 = 0, ground1 = 0;
+  {
+    float lx0 = 0, ly0 = 0, lz0 = 0, lx1 = 0, ly1 = 0, lz1 = 0;
+    bool lok0 = false, lok1 = false;
+#pragma unroll
+    for (int row0 = 0; row0 < IPF2_ROWS; row0 += 4) {
+      uint2 ob[4];
+      float4 pa[4], pb[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) ob[u] = (colv && row0 + u < NS) ? *reinterpret_cast<const uint2*>(&own32[(row0 + u) * H + c0]) : make_uint2(0u, 0u);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { pa[u] = pts[max((int)ob[u].x - 1, 0)]; pb[u] = pts[max((int)ob[u].y - 1, 0)]; }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int row = row0 + u;
+        opk[row] = (ob[u].x & 0xFFFFu) | (ob[u].y << 16);
+        {
+          const bool ok = ob[u].x != 0u;
+          const float x = pa[u].x, y = pa[u].y, z = pa[u].z;
+          rng0[row] = ok ? sqrtf(x * x + y * y + z * z) : -1.0f;   // :99
+          if (ok) filled0 |= 1u << row;
+          if (row >= 1 && row - 1 < P.ground_scan_id && ok && lok0 && ip_is_ground(d, x - lx0, y - ly0, z - lz0)) ground0 |= 3u << (row - 1);   // :111-131
+          lx0 = x; ly0 = y; lz0 = z; lok0 = ok;
+        }
+        {
+          const bool ok = ob[u].y != 0u;
+          const float x = pb[u].x, y = pb[u].y, z = pb[u].z;
+          rng1[row] = ok ? sqrtf(x * x + y * y + z * z) : -1.0f;
+          if (ok) filled1 |= 1u << row;
+          if (row >= 1 && row - 1 < P.ground_scan_id && ok && lok1 && ip_is_ground(d, x - lx1, y - ly1, z - lz1)) ground1 |= 3u << (row - 1);
+          lx1 = x; ly1 = y; lz1 = z; lok1 = ok;
+        }
+      }
+    }
+  }
+  IPF_TICK(3);
+  const unsigned act0 = filled0 & ~ground0, act1 = filled1 & ~ground1;
+  if (lane == 0) {
+#pragma unroll
+    for (int r = 0; r < IPF2_ROWS; ++r) S.first_r[wave][r] = rng0[r];
+    S.first_act[wave] = act0;
+  }
+  __syncthreads();   // every read of the 32-bit owner image has happened
+  // the column to the right of c1: the next thread's first column, column 0 behind the last one (:241-248)
+  const int tlast = H / 2 - 1;
+  float nbr[IPF2_ROWS];
+  unsigned nb_act = (unsigned)__shfl_down((int)act0, 1, 64);
+#pragma unroll
+  for (int r = 0; r < IPF2_ROWS; ++r) nbr[r] = __shfl_down(rng0[r], 1, 64);
+  if (lane == 63 || tid == tlast) {
+    const int sw = tid == tlast ? 0 : min(wave + 1, IPF2_NW - 1);
+#pragma unroll
+    for (int r = 0; r < IPF2_ROWS; ++r) nbr[r] = S.first_r[sw][r];
+    nb_act = S.first_act[sw];
+  }
+  unsigned redge0 = 0, redge1 = 0, down0 = 0, down1 = 0;
+  if (colv) {
+#pragma unroll
+    for (int row = 0; row < IPF2_ROWS; ++row) {
+      if (row < NS) {
+        if ((act0 >> row) & 1u) {
+          const double r0 = (double)rng0[row];
+          if ((act1 >> row) & 1u) {   // same row, seg_alpha_x (:258-261)
+            const double r1 = (double)rng1[row], d1 = fmax(r0, r1), d2 = fmin(r0, r1);
+            if (edge_angle_gt(d2 * d.sin_ax, d1 - d2 * d.cos_ax, P.seg_theta, d.tan_theta)) redge0 |= 1u << row;
+          }
+          if (row + 1 < NS && ((act0 >> (row + 1)) & 1u)) {   // same column, seg_alpha_y (:262-265)
+            const double r1 = (double)rng0[row + 1 < IPF2_ROWS ? row + 1 : row], d1 = fmax(r0, r1), d2 = fmin(r0, r1);
+            if (edge_angle_gt(d2 * d.sin_ay, d1 - d2 * d.cos_ay, P.seg_theta, d.tan_theta)) down0 |= 1u << row;
+          }
+        }
+        if ((act1 >> row) & 1u) {
+          const double r0 = (double)rng1[row];
+          if ((nb_act >> row) & 1u) {
+            const double r1 = (double)nbr[row], d1 = fmax(r0, r1), d2 = fmin(r0, r1);
+            if (edge_angle_gt(d2 * d.sin_ax, d1 - d2 * d.cos_ax, P.seg_theta, d.tan_theta)) redge1 |= 1u << row;
+          }
+          if (row + 1 < NS && ((act1 >> (row + 1)) & 1u)) {
+            const double r1 = (double)rng1[row + 1 < IPF2_ROWS ? row + 1 : row], d1 = fmax(r0, r1), d2 = fmin(r0, r1);
+            if (edge_angle_gt(d2 * d.sin_ay, d1 - d2 * d.cos_ay, P.seg_theta, d.tan_theta)) down1 |= 1u << row;
+          }
+        }
+      }
+    }
+    fcol[c0] = (unsigned long long)ground0 | ((unsigned long long)act0 << 16) | ((unsigned long long)redge0 << 32) | ((unsigned long long)down0 << 48);
+    fcol[c1] = (unsigned long long)ground1 | ((unsigned long long)act1 << 16) | ((unsigned long long)redge1 << 32) | ((unsigned long long)down1 << 48);
+    if (keep & 1) {
+      float* rimg = d.range_img + base;
+      uint8_t* fimg = d.flag_img + base;
+#pragma unroll
+      for (int row = 0; row < IPF2_ROWS; ++row) {
+        if (row < NS) {
+          rimg[row * H + c0] = rng0[row]; rimg[row * H + c1] = rng1[row];
+          fimg[row * H + c0] = (uint8_t)(((ground0 >> row) & 1u) | (((act0 >> row) & 1u) << 1) | (((redge0 >> row) & 1u) << 2) | (((down0 >> row) & 1u) << 3));
+          fimg[row * H + c1] = (uint8_t)(((ground1 >> row) & 1u) | (((act1 >> row) & 1u) << 1) | (((redge1 >> row) & 1u) << 2) | (((down1 >> row) & 1u) << 3));
+        }
+      }
+    }
+  }
+
+  IPF_TICK(4);
+  // ---------------- phase C: connected components over vertical runs ----------------
+  // a cell starts a run when it is active and no down-edge reaches it from below; a run's representative is its first (lowest) cell
+  const unsigned rs0 = act0 & ~(down0 << 1), rs1 = act1 & ~(down1 << 1);
+  if (colv) {
+    unsigned* own16w = reinterpret_cast<unsigned*>(own16);
+    unsigned* parw0 = reinterpret_cast<unsigned*>(par);
+#pragma unroll
+    for (int row = 0; row < IPF2_ROWS; ++row) {
+      if (row < NS) {
+        const int v0 = row * H + c0;
+        own16w[v0 >> 1] = opk[row];
+        const int s0 = ((act0 >> row) & 1u) ? ipf_run_start(rs0, row) : row, s1 = ((act1 >> row) & 1u) ? ipf_run_start(rs1, row) : row;
+        parw0[v0 >> 1] = (unsigned)(s0 * H + c0) | ((unsigned)(s1 * H + c1) << 16);
+      }
+    }
+  }
+  __syncthreads();
+  IPF_TICK(5);
+  const int cn = c0 + 2 == H ? 0 : c0 + 2;
+  if (colv) {
+    // right-edges between the runs; one is skipped when the cell below already links the same pair of runs
+    const unsigned down_nb = (unsigned)(fcol[cn] >> 48) & 0xFFFFu;
+    unsigned m0 = redge0 & ~((redge0 & down0 & down1) << 1);
+    unsigned m1 = redge1 & ~((redge1 & down1 & down_nb) << 1);
+    while (m0) { const int row = __ffs((int)m0) - 1; m0 &= m0 - 1; ccl16_union(par, row * H + c0, row * H + c1); }
+    while (m1) { const int row = __ffs((int)m1) - 1; m1 &= m1 - 1; ccl16_union(par, row * H + c1, row * H + cn); }
+  }
+  __syncthreads();
+  IPF_TICK(6);
+  // flatten the run starts; root = minimum linear index of the component = BFS discovery order (:147-156)
+  unsigned root0 = 0, root1 = 0;
+  if (colv) {
+    for (unsigned m = rs0; m; m &= m - 1) { const int row = __ffs((int)m) - 1, s = row * H + c0; int r = par[s], nx; while (r > (nx = par[r])) r = nx; par[s] = (uint16_t)r; if (r == s) root0 |= 1u << row; }
+    for (unsigned m = rs1; m; m &= m - 1) { const int row = __ffs((int)m) - 1, s = row * H + c1; int r = par[s], nx; while (r > (nx = par[r])) r = nx; par[s] = (uint16_t)r; if (r == s) root1 |= 1u << row; }
+  }
+  __syncthreads();
+  IPF_TICK(7);
+  // A root's own entry is free from here on (its owner knows it through root0 / root1): it becomes the component's 16-bit
+  // accumulator, first for the size (:282), then for the row mask (:283-294).  One atomic per RUN.
+  unsigned* parw = reinterpret_cast<unsigned*>(par);
+  auto zero_roots = [&]() {
+    for (unsigned m = root0; m; m &= m - 1) par[(__ffs((int)m) - 1) * H + c0] = 0;
+    for (unsigned m = root1; m; m &= m - 1) par[(__ffs((int)m) - 1) * H + c1] = 0;
+    __syncthreads();
+  };
+  auto root_of = [&](unsigned rootm, int row, int c) -> int { const int s = row * H + c; return ((rootm >> row) & 1u) ? s : (int)par[s]; };
+  zero_roots();
+  if (colv) {
+    for (unsigned m = rs0; m; m &= m - 1) { const int row = __ffs((int)m) - 1, r = root_of(root0, row, c0); atomicAdd(&parw[r >> 1], (unsigned)(ipf_run_end(down0, row) - row + 1) << ((r & 1) * 16)); }
+    for (unsigned m = rs1; m; m &= m - 1) { const int row = __ffs((int)m) - 1, r = root_of(root1, row, c1); atomicAdd(&parw[r >> 1], (unsigned)(ipf_run_end(down1, row) - row + 1) << ((r & 1) * 16)); }
+  }
+  __syncthreads();
+  unsigned big0 = 0, big1 = 0, mid0 = 0, mid1 = 0;   // per run (bit at its start row): size >= 30 / 5 <= size < 30
+  if (colv) {
+    for (unsigned m = rs0; m; m &= m - 1) { const int row = __ffs((int)m) - 1, sz = (int)par[root_of(root0, row, c0)]; if (sz >= P.seg_big_num) big0 |= 1u << row; else if (sz >= P.seg_valid_point_num) mid0 |= 1u << row; }
+    for (unsigned m = rs1; m; m &= m - 1) { const int row = __ffs((int)m) - 1, sz = (int)par[root_of(root1, row, c1)]; if (sz >= P.seg_big_num) big1 |= 1u << row; else if (sz >= P.seg_valid_point_num) mid1 |= 1u << row; }
+  }
+  __syncthreads();
+  zero_roots();
+  if (colv) {   // rows touched by the mid-sized components
+    for (unsigned m = mid0; m; m &= m - 1) { const int row = __ffs((int)m) - 1, r = root_of(root0, row, c0), e = ipf_run_end(down0, row); atomicOr(&parw[r >> 1], (((2u << e) - 1u) & ~((1u << row) - 1u)) << ((r & 1) * 16)); }
+    for (unsigned m = mid1; m; m &= m - 1) { const int row = __ffs((int)m) - 1, r = root_of(root1, row, c1), e = ipf_run_end(down1, row); atomicOr(&parw[r >> 1], (((2u << e) - 1u) & ~((1u << row) - 1u)) << ((r & 1) * 16)); }
+  }
+  __syncthreads();
+  unsigned feas0 = 0, feas1 = 0;   // cells of feasible components
+  if (colv) {
+    for (unsigned m = big0 | mid0; m; m &= m - 1) {
+      const int row = __ffs((int)m) - 1, e = ipf_run_end(down0, row);
+      if (((big0 >> row) & 1u) || __popc((unsigned)par[root_of(root0, row, c0)]) >= P.seg_valid_line_num) feas0 |= ((2u << e) - 1u) & ~((1u << row) - 1u);
+    }
+    for (unsigned m = big1 | mid1; m; m &= m - 1) {
+      const int row = __ffs((int)m) - 1, e = ipf_run_end(down1, row);
+      if (((big1 >> row) & 1u) || __popc((unsigned)par[root_of(root1, row, c1)]) >= P.seg_valid_line_num) feas1 |= ((2u << e) - 1u) & ~((1u << row) - 1u);
+    }
+  }
+
+  IPF_TICK(8);
+  // ---------------- phase D: ordered compaction (:158-191) ----------------
+  const unsigned all16 = 0xFFFFu;
+  const unsigned rowgt = P.ground_scan_id >= 15 ? 0u : (P.ground_scan_id < 0 ? all16 : (all16 & ~((2u << P.ground_scan_id) - 1u)));   // rows > ground_scan_id
+  const bool gk0 = c0 % 5 == 0 || c0 <= 4 || c0 >= H - 5, gk1 = c1 % 5 == 0 || c1 <= 4 || c1 >= H - 5;
+  const unsigned keep0 = colv ? ((gk0 ? ground0 : 0u) | feas0) : 0u, keep1 = colv ? ((gk1 ? ground1 : 0u) | feas1) : 0u;
+  const unsigned outl0 = (colv && c0 % 5 == 0) ? (act0 & ~feas0 & rowgt) : 0u, outl1 = (colv && c1 % 5 == 0) ? (act1 & ~feas1 & rowgt) : 0u;
+  const unsigned fr0 = colv ? (root0 & feas0) : 0u, fr1 = colv ? (root1 & feas1) : 0u;   // roots of feasible components: label_cnt_ numbering (:303-306)
+#pragma unroll
+  for (int row = 0; row < IPF2_ROWS; ++row) {
+    const unsigned long long bk0 = __ballot((keep0 >> row) & 1u), bk1 = __ballot((keep1 >> row) & 1u);
+    const unsigned long long bo0 = __ballot((outl0 >> row) & 1u), bo1 = __ballot((outl1 >> row) & 1u);
+    const unsigned long long bf0 = __ballot((fr0 >> row) & 1u), bf1 = __ballot((fr1 >> row) & 1u);
+    if (lane == 0) {
+      S.cnt[0][row * IPF2_NW + wave] = (int)(__popcll(bk0) + __popcll(bk1));
+      S.cnt[1][row * IPF2_NW + wave] = (int)(__popcll(bo0) + __popcll(bo1));
+      S.cnt[2][row * IPF2_NW + wave] = (int)(__popcll(bf0) + __popcll(bf1));
+    }
+  }
+  __syncthreads();
+  {   // exclusive scan of the three 256-entry tables by the first four wavefronts
+    int v3[3] = {0, 0, 0}, in3[3] = {0, 0, 0};
+    if (tid < IPF2_ROWS * IPF2_NW) {
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        v3[a] = S.cnt[a][tid];
+        int incl = v3[a];
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+        in3[a] = incl;
+        if (lane == 63) S.wtot[a][wave] = incl;
+      }
+    }
+    __syncthreads();
+    if (tid < IPF2_ROWS * IPF2_NW) {
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        int woff = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) if (w < wave) woff += S.wtot[a][w];
+        S.cnt[a][tid] = woff + in3[a] - v3[a];
+        if (tid == IPF2_ROWS * IPF2_NW - 1) S.tot[a] = woff + in3[a];
+      }
+    }
+  }
+  __syncthreads();
+  if (tid < NS) {   // startRingIndex / endRingIndex (:161,:190)
+    const int row = tid;
+    d.ring_start[slot * NS + row] = S.cnt[0][row * IPF2_NW] + 5;
+    d.ring_end[slot * NS + row] = (row + 1 < IPF2_ROWS ? S.cnt[0][(row + 1) * IPF2_NW] : S.tot[0]) - 1 - 5;
+  }
+  if (tid == 0) {
+    int* sc = d.scal + slot * SC_COUNT;
+    sc[SC_M] = S.tot[0]; sc[SC_NOUT] = S.tot[1]; sc[SC_NFEAS] = S.tot[2];
+  }
+  IPF_TICK(9);
+  const unsigned long long below = (1ull << lane) - 1ull;
+  const unsigned* own16w = reinterpret_cast<const unsigned*>(own16);
+#pragma unroll
+  for (int row0 = 0; row0 < IPF2_ROWS; row0 += 4) {
+    float4 qa[4], qb[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int row = row0 + u;
+      const unsigned ow = (colv && row < NS) ? own16w[(row * H + c0) >> 1] : 0u;
+      const bool e0 = ((keep0 | outl0) >> row) & 1u, e1 = ((keep1 | outl1) >> row) & 1u;
+      qa[u] = pts[e0 ? (int)(ow & 0xFFFFu) - 1 : 0];   // (clamped address instead of a branch: the eight gathers are in flight together)
+      qb[u] = pts[e1 ? (int)(ow >> 16) - 1 : 0];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int row = row0 + u;
+      const bool k0 = (keep0 >> row) & 1u, k1 = (keep1 >> row) & 1u, o0 = (outl0 >> row) & 1u, o1 = (outl1 >> row) & 1u;
+      const unsigned long long bk0 = __ballot(k0), bk1 = __ballot(k1), bo0 = __ballot(o0), bo1 = __ballot(o1);
+      const int lk = S.cnt[0][row * IPF2_NW + wave] + (int)(__popcll(bk0 & below) + __popcll(bk1 & below));
+      const int lo = S.cnt[1][row * IPF2_NW + wave] + (int)(__popcll(bo0 & below) + __popcll(bo1 & below));
+      if (k0 | o0) {
+        const float4 q = qa[u];
+        const float4 p = make_float4(q.x, q.y, q.z, (float)(row + c0 / 10000.0));   // :101
+        if (k0) {
+          d.seg_pts[base + lk] = p;
+          d.seg_ground[base + lk] = (uint8_t)((ground0 >> row) & 1u);
+          d.seg_col[base + lk] = c0;
+          d.seg_range[base + lk] = sqrtf(q.x * q.x + q.y * q.y + q.z * q.z);   // = the range image's value (:99,:184)
+        } else {
+          d.outlier[base + lo] = p;
+        }
+      }
+      if (k1 | o1) {
+        const float4 q = qb[u];
+        const float4 p = make_float4(q.x, q.y, q.z, (float)(row + c1 / 10000.0));
+        const int l1 = lk + (k0 ? 1 : 0), lo1 = lo + (o0 ? 1 : 0);
+        if (k1) {
+          d.seg_pts[base + l1] = p;
+          d.seg_ground[base + l1] = (uint8_t)((ground1 >> row) & 1u);
+          d.seg_col[base + l1] = c1;
+          d.seg_range[base + l1] = sqrtf(q.x * q.x + q.y * q.y + q.z * q.z);
+        } else {
+          d.outlier[base + lo1] = p;
+        }
+      }
+    }
+  }
+  IPF_TICK(10);
+  if (keep & 1) {   // root image + label_cnt_ numbers for ip_labels (:303-314)
+#pragma unroll
+    for (int row = 0; row < IPF2_ROWS; ++row) {
+      const unsigned long long bf0 = __ballot((fr0 >> row) & 1u), bf1 = __ballot((fr1 >> row) & 1u);
+      if (colv && row < NS) {
+        const int v0 = row * H + c0, v1 = row * H + c1;
+        const int s0 = ((act0 >> row) & 1u) ? ipf_run_start(rs0, row) : row, s1 = ((act1 >> row) & 1u) ? ipf_run_start(rs1, row) : row;
+        d.parent[base + v0] = ((act0 >> row) & 1u) ? root_of(root0, s0, c0) : -1;
+        d.parent[base + v1] = ((act1 >> row) & 1u) ? root_of(root1, s1, c1) : -1;
+        const int nf = S.cnt[2][row * IPF2_NW + wave] + (int)(__popcll(bf0 & below) + __popcll(bf1 & below));
+        if ((root0 >> row) & 1u) d.cc_label[base + v0] = ((fr0 >> row) & 1u) ? nf + 1 : 0;
+        if ((root1 >> row) & 1u) d.cc_label[base + v1] = ((fr1 >> row) & 1u) ? nf + ((fr0 >> row) & 1u) + 1 : 0;
+      }
+    }
+  }
+}
+
+void launch_ip_fused(const DevCtx& d, int ring_pos, bool keep_images, hipStream_t st) {
+  ALEGO_LAUNCH(ip_fused, dim3(d.n_launch), dim3(IPF2_T), ipf_lds_bytes(d), st, d, ring_pos, keep_images ? 1 : 0);
+}
+
+// dynamic LDS above 64 KB has to be requested explicitly
+int ipf_configure(const DevCtx& d) {
+  if (!ipf_eligible(d)) return 0;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(ip_fused), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ipf_lds_bytes(d)) == hipSuccess ? 0 : -1;
+}

@@ -31,18 +31,21 @@ def _ip_compare(h, o, pts, tag):
     return seg
 
 
-@pytest.mark.parametrize("geom,variant", [((16, 1800), None), ((16, 1800), "ALEGO_CC_FUSED"), ((16, 1800), "ALEGO_IP_FAST"),
+@pytest.mark.parametrize("geom,variant", [((16, 1800), None), ((16, 1800), "ALEGO_IP_FUSED"), ((16, 1800), "ALEGO_IP_FUSED,ALEGO_CC_FUSED"), ((16, 1800), "ALEGO_IP_FAST"),
+                                          ((16, 1024), None), ((12, 2048), None), ((5, 64), None), ((16, 1800), "ALEGO_IP_FUSED,ALEGO_IP_FAST"),
                                           ((16, 4000), None), ((64, 2048), None), ((64, 2048), "ALEGO_CC_TILE"),
                                           ((32, 2048), None), ((40, 1800), None)])
 def test_ip_bit_exact(geom, variant, monkeypatch):
-    """ImageProjection bit for bit.  16x1800 runs the fused LDS kernel (cc_lds16); ALEGO_CC_FUSED=0 keeps its union-find but
+    """ImageProjection bit for bit.  Up to 16 rings / 32768 cells / an even width run ip_fused (one workgroup per stream, one launch:
+    16x1800, 16x1024, 12x2048, 5x64); ALEGO_IP_FUSED=0 selects the multi-kernel path: 16x1800 then runs cc_lds16; ALEGO_CC_FUSED=0 keeps its union-find but
     compacts with the separate ip_rowcount + ip_compact kernels; 16x4000 runs cc_lds16 at 126 KB of LDS; 64x2048, 32x2048 and 40x1800
     (bands of 256 / 512 / 409 + 164 columns) are labelled band by band in LDS and stitched at the seams (cc_tile + cc_seam +
     cc_stats), ALEGO_CC_TILE=0 keeps the global-memory union-find (cc_runs + cc_link).
     ALEGO_IP_FAST=0 projects every point with the reference expressions (normally only the points within 2.5e-4 cells of a
     cell boundary take them; the rest are placed by the boundary tables)."""
-    if variant:
-        monkeypatch.setenv(variant, "0")
+    for v in (variant or "").split(","):
+        if v:
+            monkeypatch.setenv(v, "0")
     p = synth.default_params(*geom)
     h, o = binding.Handle(p), O.Oracle(p)
     for k in (0, 1, 150):
