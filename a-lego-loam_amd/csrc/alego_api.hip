@@ -21,8 +21,8 @@
 
 thread_local Profiler* g_prof = nullptr;
 
-void launch_ip(const DevCtx& d, int ring_pos, bool want_labels, hipStream_t st);
-void launch_fe(const DevCtx& d, hipStream_t st);
+bool launch_ip(const DevCtx& d, int ring_pos, bool want_labels, hipStream_t st);
+void launch_fe(const DevCtx& d, hipStream_t st, bool curv_done);
 void launch_lo(const DevCtx& d, hipStream_t st);
 void launch_atan2f_probe(const float* y, const float* x, float* out, int n, int mode, hipStream_t st);
 int launch_stdsort_probe(const uint32_t* keys, int n, int depth_limit, int* pos_out, hipStream_t st);
@@ -234,7 +234,7 @@ int alego_create(const alego_params* params, int device, int n_slots, int ring_l
   rc |= dalloc(h, &d.seg_pts, B * N); rc |= dalloc(h, &d.seg_ground, B * N); rc |= dalloc(h, &d.seg_col, B * N);
   rc |= dalloc(h, &d.seg_range, B * N); rc |= dalloc(h, &d.ring_start, B * NS); rc |= dalloc(h, &d.ring_end, B * NS);
   rc |= dalloc(h, &d.ori, B * 4); rc |= dalloc(h, &d.outlier, B * N);
-  rc |= dalloc(h, &d.cd, B * N); rc |= dalloc(h, &d.picked0, B * N); rc |= dalloc(h, &d.plabel, B * N);
+  rc |= dalloc(h, &d.cd, B * N); rc |= dalloc(h, &d.picked0, B * N); rc |= dalloc(h, &d.fe_flag, B * N); rc |= dalloc(h, &d.plabel, B * N);
   rc |= dalloc(h, &d.st_idx, B * NS * d.st_stride); rc |= dalloc(h, &d.st_cnt, B * NS * 8);
   rc |= dalloc(h, &d.st_lfds, B * NS * d.H);
   d.fcap[F_SHARP] = d.cap_sharp * d.NS; d.fcap[F_LSHARP] = d.cap_lsharp * d.NS; d.fcap[F_FLAT] = d.cap_flat * d.NS; d.fcap[F_LFLAT] = d.N;
@@ -413,8 +413,8 @@ int alego_stream_run(alego_handle* h, int first_step, int n_scans, int stages, i
     DevCtx dl = view(h, lane0, w);
     dl.replay_bag = 1;
     const int pos = (int)(((long long)first_step + base) % h->d.bag_len);
-    if (stages & 1) launch_ip(dl, pos, false, sA);
-    if (do_lo) launch_fe(dl, sA);
+    const bool curv_done = (stages & 1) && launch_ip(dl, pos, false, sA);
+    if (do_lo) launch_fe(dl, sA, curv_done);
     hipEvent_t fe_done = ev();
     HIP_TRY(h, hipEventRecord(fe_done, sA));
     if (!do_lo) { h->pose_slot = lane0 + w - 1; continue; }
@@ -453,10 +453,11 @@ static int enqueue_scan(alego_handle* h, int slot0, int n, int pos, int stages, 
   g_prof = &h->prof;
   static const bool dbg = getenv("ALEGO_DEBUG_SYNC") != nullptr;
   auto chk = [&](const char* what) { if (dbg) { hipError_t e = hipStreamSynchronize(S); fprintf(stderr, "[alego dbg] %s: %s\n", what, hipGetErrorString(e)); } };
-  if (stages & 1) { launch_ip(d, pos, want_labels, S); chk("ip"); }
+  bool curv_done = false;
+  if (stages & 1) { curv_done = launch_ip(d, pos, want_labels, S); chk("ip"); }
   if (stages & 2) {
     if (d.P.deskew_mode) { launch_lo_deskew(d, S); chk("deskew"); }   // adjustDistortion(segmented_cloud, t1), laserOdometry.cpp:115
-    launch_fe(d, S); chk("fe");
+    launch_fe(d, S, curv_done); chk("fe");
     launch_lo(d, S); chk("lo");
     std::vector<char> odom_valid(n);
     for (int i = 0; i < n; ++i) odom_valid[i] = h->lo_scans[slot0 + i]++ > 0;

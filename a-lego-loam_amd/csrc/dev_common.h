@@ -99,7 +99,8 @@ struct DevCtx {
   float4* outlier;      // [slot][N]
   // ---- feature extraction ----
   float* cd;            // [slot][N] f32 11-tap sum (curvature = (double)cd^2)
-  uint8_t* picked0;     // [slot][N] cloud_neighbor_picked_ after occlusion marking
+  uint8_t* picked0;     // [slot][N] cloud_neighbor_picked_ after occlusion marking (single-scan entry points / tests only)
+  uint8_t* fe_flag;     // [slot][N] per-point flag byte of the feature pick (fe_common.h)
   int* plabel;          // [slot][N] cloud_label_
   int* st_idx;          // [slot][NS][st_stride] per-ring staging: sharp | less_sharp | flat | less_flat_scan indices
   int* st_cnt;          // [slot][NS][8]  counts: sharp, less_sharp, flat, less_flat_scan, less_flat voxels
@@ -115,7 +116,7 @@ struct DevCtx {
   int* lo_corr;         // [slot][qcap][4]  surf rows then corner rows: (query, closest, idx2, idx3) ; closest<0 = none
   int lo_qcap_surf, lo_qcap_corner;
   float4* lo_box;       // [slot][2 buffers][2 kinds][lo_box_cap][2]: min / max corner of every LO_CH consecutive targets
-  int lo_box_cap;       //   (kind 0: less_flat, 1: less_sharp), written by fe_boxes next to the feature clouds
+  int lo_box_cap;       //   (kind 0: less_flat, 1: less_sharp), written by fe_collect next to the feature clouds
   double* lo_state;     // [slot][LO_STATE_N]
   // ---- motion de-skew (adjustDistortion, laserOdometry.cpp:557-726; alego_params.deskew_mode) ----
   double* imu_ring;     // [slot][ALEGO_IMU_Q][10]: time, roll, pitch, yaw, shift xyz, velo xyz (imu_time_ ... imu_velo_z_)
@@ -160,7 +161,7 @@ DEV_INLINE int scan_count(const DevCtx& d, int slot, int pos) { return (d.replay
 // row of a cell index without an integer division (exact for v < 2^32 / H, i.e. for every supported image)
 DEV_INLINE int cell_row(const DevCtx& d, int v) { return (int)__umulhi((unsigned)v, d.h_magic); }
 
-// buffer written by the scan in flight (valid from fe_gather until lo_solve phase 1 flips SC_CUR)
+// buffer written by the scan in flight (valid from fe_collect until lo_solve phase 1 flips SC_CUR)
 DEV_INLINE int cur_in_flight(const DevCtx& d, int slot) { return d.scal[slot * SC_COUNT + SC_CUR] ^ 1; }
 // index into the [slot][2] feature arrays of the scan in flight / of the previous scan, as LaserOdometry sees them.  A lane never
 // runs lo_solve, so its SC_CUR stays at its initial 1 and feature extraction always fills its buffer 0.

@@ -1,7 +1,8 @@
 // kernels_fe.hip — feature extraction on gfx950 (replaces src/laserOdometry.cpp:122-293).
 //
 //   fe_curv    a7,a8: 11-tap f32 curvature sum through an LDS window + occlusion / parallel-beam
-//              marking written as a gather (no atomics)                         (:122-159)
+//              marking written as a gather (no atomics) (:122-159); the body (fe_common.h) is also the last phase of ip_fused,
+//              in which case this launch is skipped
 //   fe_pick4   a9: four rings per wavefront (one 16-lane DPP row each); the reference's "sort, then scan
 //              descending/ascending" is evaluated as repeated row-wide arg-max / arg-min over the
 //              not-yet-picked candidates of the sector (identical result for the total order
@@ -9,16 +10,16 @@
 //   fe_pick    the same with one ring per wavefront (suppress_radius > 7, very long sectors)
 //   fe_voxel   a10: per-ring pcl::VoxelGrid(0.4): runs of consecutive equal voxel ids ordered through
 //              monotone buckets in LDS, centroid in sorted (= original) order    (:288-293)
-//   fe_gather  ring-ascending concatenation into the four feature clouds       (:199-205,:245,:293)
-//   fe_boxes   bounding boxes of 32 consecutive less_flat / less_sharp points for the next scan's LaserOdometry
+//   fe_collect ring-ascending concatenation into the four feature clouds (:199-205,:245,:293) + bounding boxes of 32 consecutive
+//              less_flat / less_sharp points for the next scan's LaserOdometry
 #include <cstdlib>
 #include <type_traits>
 #include "dev_common.h"
+#include "fe_common.h"
 #include "prof.h"
 #include "stdsort_emu.h"
 
 #define FE_BLOCK 256
-#define FE_HALO 6
 #define FE_CW 1024   // points per fe_curv workgroup
 #define FE_MAXH 4096  // largest horizon_scan supported by the per-ring LDS staging
 // fe_pick<FE_T>: sector elements per lane kept in registers (sector length <= 64*FE_T): 6 covers 16x1800
@@ -29,66 +30,10 @@ __global__ void __launch_bounds__(FE_BLOCK) fe_curv(DevCtx d) {
   const int M = d.scal[slot * SC_COUNT + SC_M];
   const int t0 = blockIdx.x * FE_CW;   // FE_CW points per workgroup, FE_CW / FE_BLOCK per thread
   if (t0 >= M) return;
-  const size_t base = (size_t)slot * d.N;
-  const float* rng = d.seg_range + base;
-  const int* colv = d.seg_col + base;
-  const alego_params& P = d.P;
   __shared__ float s_r[FE_CW + 2 * FE_HALO];
   __shared__ int s_c[FE_CW + 2 * FE_HALO];
   __shared__ uint8_t s_f[FE_CW + 2 * FE_HALO];
-  #pragma unroll 5
-  for (int j = threadIdx.x; j < FE_CW + 2 * FE_HALO; j += FE_BLOCK) {
-    const int i = t0 - FE_HALO + j;
-    const bool in = i >= 0 && i < M;
-    s_r[j] = in ? rng[i] : 0.f;
-    s_c[j] = in ? colv[i] : 0;
-  }
-  __syncthreads();
-  // per-point conditions of markOccludedPoints for i = t0-5 .. t0+FE_BLOCK+4
-  for (int j = threadIdx.x + 1; j < FE_CW + 2 * FE_HALO - 1; j += FE_BLOCK) {
-    const int i = t0 - FE_HALO + j;
-    uint8_t f = 0;
-    if (i >= 5 && i < M - 5) {
-      const float r0 = s_r[j], r1 = s_r[j + 1], rm = s_r[j - 1];
-      int cdiff = s_c[j] - s_c[j + 1];
-      cdiff = cdiff < 0 ? -cdiff : cdiff;
-      bool c1, c2;
-      double diff1, diff2;
-      if (P.occl_f32) {  // LO.cpp:203-204
-        c1 = (double)(r0 - r1) > P.occl_depth; c2 = (double)(r1 - r0) > P.occl_depth;
-        diff1 = (double)fabsf(rm - r0); diff2 = (double)fabsf(r1 - r0);
-      } else {           // laserOdometry.cpp:134-135
-        const double d1 = (double)r0, d2 = (double)r1;
-        c1 = d1 - d2 > P.occl_depth; c2 = d2 - d1 > P.occl_depth;
-        diff1 = fabs((double)rm - d1); diff2 = fabs(d2 - d1);
-      }
-      const bool near = cdiff < P.occl_col_diff;
-      const bool A = near && c1;            // marks i-5..i and skips the rest (:142-144)
-      const bool B = near && !c1 && c2;     // marks i+1..i+5 (:148)
-      const bool C = !A && diff1 > P.parallel_ratio * (double)r0 && diff2 > P.parallel_ratio * (double)r0;  // (:154-157)
-      f = (uint8_t)((A ? 1 : 0) | (B ? 2 : 0) | (C ? 4 : 0));
-    }
-    s_f[j] = f;
-  }
-  __syncthreads();
-#pragma unroll
-  for (int u = 0; u < FE_CW / FE_BLOCK; ++u) {
-    const int i = t0 + u * FE_BLOCK + threadIdx.x;
-    if (i >= M) break;
-    const int j = u * FE_BLOCK + threadIdx.x + FE_HALO;
-    float cdv = 0.f;
-    if (i >= 5 && i < M - 5) {
-      // strictly left-to-right f32 sum (:124); built with -ffp-contract=off
-      cdv = s_r[j - 5] + s_r[j - 4] + s_r[j - 3] + s_r[j - 2] + s_r[j - 1] - s_r[j] * 10 + s_r[j + 1] + s_r[j + 2] + s_r[j + 3] + s_r[j + 4] + s_r[j + 5];
-    }
-    uint8_t pk = (s_f[j] & 4) ? 1 : 0;
-#pragma unroll
-    for (int l = 0; l <= 5; ++l) pk |= (s_f[j + l] & 1);       // A(i'), i' in [i, i+5]
-#pragma unroll
-    for (int l = 1; l <= 5; ++l) pk |= (s_f[j - l] & 2) >> 1;  // B(i'), i' in [i-5, i-1]
-    d.cd[base + i] = cdv;
-    d.picked0[base + i] = pk;
-  }
+  fe_curv_chunk<FE_BLOCK, FE_CW>(d, slot, M, t0, s_r, s_c, s_f);
 }
 
 // one wavefront per (ring, slot).  Dynamic LDS: 3 bytes per ring point (column u16, flags + label u8); the
@@ -117,7 +62,7 @@ __global__ void __launch_bounds__(64) fe_pick(DevCtx d) {
     const double ad = (double)a;
     const double curv = ad * ad;  // (double)diff_range * diff_range, exact (:125)
     s_col[k] = (uint16_t)d.seg_col[base + rf + k];
-    s_flag[k] = (uint8_t)((d.picked0[base + rf + k] & 1) | (d.seg_ground[base + rf + k] ? 2 : 0) |
+    s_flag[k] = (uint8_t)((d.fe_flag[base + rf + k] & 1) | (d.seg_ground[base + rf + k] ? 2 : 0) |
                           (curv > P.edge_thres ? 4 : 0) | (curv < P.surf_thres ? 8 : 0) | (1 << 4));  // bits 4-5: label + 1
   }
   __syncthreads();
@@ -313,15 +258,12 @@ __global__ void __launch_bounds__(64) fe_pick4(DevCtx d) {
     const int Sr = d.ring_start[slot * d.NS + ring0 + r], Er = d.ring_end[slot * d.NS + ring0 + r];
     const int rfr = Sr - 5, cntr = Er - Sr + 11;
     uint8_t* sf = s_flag + (size_t)r * d.H;
+    // the flag byte of every point comes ready from fe_curv_chunk (picked | ground << 1 | curvature > edge_thres << 2 | curvature <
+    // surf_thres << 3 | label 0 << 4 | column jump to the next point << 6); the jump bit of the ring's last point compares with
+    // the point itself in the reference's suppression loop (clamped index): cleared here
+    const uint8_t* ff = d.fe_flag + base + rfr;
 #pragma unroll 8
-    for (int k = lane; k < cntr; k += 64) {
-      const float a = fabsf(d.cd[base + rfr + k]);
-      const double ad = (double)a;
-      const double curv = ad * ad;  // (double)diff_range * diff_range, exact (:125)
-      const int dc = d.seg_col[base + rfr + min(k + 1, cntr - 1)] - d.seg_col[base + rfr + k];
-      sf[k] = (uint8_t)((d.picked0[base + rfr + k] & 1) | (d.seg_ground[base + rfr + k] ? 2 : 0) |
-                        (curv > P.edge_thres ? 4 : 0) | (curv < P.surf_thres ? 8 : 0) | (1 << 4) | ((dc < 0 ? -dc : dc) > P.suppress_col_diff ? 64 : 0));
-    }
+    for (int k = lane; k < cntr; k += 64) sf[k] = k == cntr - 1 ? (uint8_t)(ff[k] & ~64) : ff[k];
   }
   __syncthreads();
   const int S = rv ? d.ring_start[slot * d.NS + ring] : 0, E = rv ? d.ring_end[slot * d.NS + ring] : 0;
@@ -531,6 +473,12 @@ extern "C" void alego_fv_times(long long* out) { (void)hipMemcpyFromSymbol(out, 
 #define FV_TICK(k)
 #endif
 #define FV_NB 512
+#ifndef FV_STAGE
+#define FV_STAGE 1     // 1: the ring's candidate points are gathered once into LDS (26 B per column); 0: every pass gathers them from HBM / L2 (10 B per column)
+#endif
+// (ranking the ~300 runs of a ring by counting — every run sweeps all runs in LDS — was measured: 346 k -> 317 k scans/s.  The
+//  pipeline as a whole is VALU-issue bound; 90 k compares per ring cost more than the bucket tables' latency.)
+#define FV_LDS_PER_COL (FV_STAGE ? 26 : 10)
 #define FV_U 4    // gathers kept in flight per thread
 __global__ void __launch_bounds__(FE_BLOCK) fe_voxel(DevCtx d) {
   const int slot = blockIdx.y + d.slot0, ring = blockIdx.x, tid = threadIdx.x;
@@ -541,11 +489,14 @@ __global__ void __launch_bounds__(FE_BLOCK) fe_voxel(DevCtx d) {
   float4* out = d.st_lfds + ((size_t)slot * d.NS + ring) * d.H;
   const float4* seg = d.seg_lo + base;
   extern __shared__ __attribute__((aligned(16))) unsigned char fv_smem[];
-  uint32_t* s_key = reinterpret_cast<uint32_t*>(fv_smem);                       // voxel id per point      [H]
+  float4* s_pt = reinterpret_cast<float4*>(fv_smem);                            // the ring's less_flat_scan points, gathered ONCE [H] (FV_STAGE)
+  unsigned char* fv2 = fv_smem + (FV_STAGE ? 16 : 0) * (size_t)d.H;
+  auto point = [&](int i) -> float4 { if (FV_STAGE) return s_pt[i]; return seg[lfs[i]]; };
+  uint32_t* s_key = reinterpret_cast<uint32_t*>(fv2);                           // voxel id per point      [H]
   uint32_t* s_rvid = s_key;                                                     // voxel id per run, compacted in place (run r <= its first point)
-  uint16_t* s_rstart = reinterpret_cast<uint16_t*>(fv_smem + 4 * (size_t)d.H);  // first point of the run  [H]
-  uint16_t* s_order = reinterpret_cast<uint16_t*>(fv_smem + 6 * (size_t)d.H);   // runs sorted by (voxel id, run) [H]
-  uint16_t* s_tmp = reinterpret_cast<uint16_t*>(fv_smem + 8 * (size_t)d.H);     // runs dealt into buckets [H]
+  uint16_t* s_rstart = reinterpret_cast<uint16_t*>(fv2 + 4 * (size_t)d.H);      // first point of the run  [H]
+  uint16_t* s_order = reinterpret_cast<uint16_t*>(fv2 + 6 * (size_t)d.H);       // runs sorted by (voxel id, run) [H]
+  uint16_t* s_tmp = reinterpret_cast<uint16_t*>(fv2 + 8 * (size_t)d.H);         // runs dealt into buckets [H]
   __shared__ float s_red[6][FE_BLOCK / 64];
   __shared__ int s_scan[FE_BLOCK / 64];
   __shared__ int s_boff[FV_NB + 1], s_bcur[FV_NB + 1];
@@ -564,6 +515,7 @@ __global__ void __launch_bounds__(FE_BLOCK) fe_voxel(DevCtx d) {
     for (int u = 0; u < FV_U; ++u) pt[u] = seg[ix[u]];
 #pragma unroll
     for (int u = 0; u < FV_U; ++u) {   // (a clamped duplicate of the last point does not change min / max)
+      if (FV_STAGE && i0 + u * FE_BLOCK < n) s_pt[i0 + u * FE_BLOCK] = pt[u];   // every later pass reads the point from LDS: one global round trip instead of three
       mn[0] = fminf(mn[0], pt[u].x); mn[1] = fminf(mn[1], pt[u].y); mn[2] = fminf(mn[2], pt[u].z);
       mx[0] = fmaxf(mx[0], pt[u].x); mx[1] = fmaxf(mx[1], pt[u].y); mx[2] = fmaxf(mx[2], pt[u].z);
     }
@@ -583,7 +535,7 @@ __global__ void __launch_bounds__(FE_BLOCK) fe_voxel(DevCtx d) {
   }
   const long long dx = (long long)((mx[0] - mn[0]) * inv) + 1, dy = (long long)((mx[1] - mn[1]) * inv) + 1, dz = (long long)((mx[2] - mn[2]) * inv) + 1;
   if (dx * dy * dz > 2147483647LL) {  // "leaf size too small": the input is returned unchanged
-    for (int i = tid; i < n; i += FE_BLOCK) out[i] = seg[lfs[i]];
+    for (int i = tid; i < n; i += FE_BLOCK) out[i] = point(i);
     if (tid == 0) cnts[4] = n;
     return;
   }
@@ -595,23 +547,13 @@ __global__ void __launch_bounds__(FE_BLOCK) fe_voxel(DevCtx d) {
     divb[a] = (int)floorf(mx[a] * inv) - minb[a] + 1;
   }
   const int mul1 = divb[0], mul2 = divb[0] * divb[1];
-  for (int ib = tid; ib < n; ib += FE_BLOCK * FV_U) {
-    int ix[FV_U];
-    float4 pt[FV_U];
-#pragma unroll
-    for (int u = 0; u < FV_U; ++u) ix[u] = lfs[min(ib + u * FE_BLOCK, n - 1)];
-#pragma unroll
-    for (int u = 0; u < FV_U; ++u) pt[u] = seg[ix[u]];
-#pragma unroll
-    for (int u = 0; u < FV_U; ++u) {
-      const int i = ib + u * FE_BLOCK;
-      if (i < n) {
-        const int i0 = (int)(floorf(pt[u].x * inv) - (float)minb[0]);
-        const int i1 = (int)(floorf(pt[u].y * inv) - (float)minb[1]);
-        const int i2 = (int)(floorf(pt[u].z * inv) - (float)minb[2]);
-        s_key[i] = (uint32_t)(i0 + i1 * mul1 + i2 * mul2);
-      }
-    }
+#pragma unroll 4
+  for (int i = tid; i < n; i += FE_BLOCK) {
+    const float4 q = point(i);
+    const int i0 = (int)(floorf(q.x * inv) - (float)minb[0]);
+    const int i1 = (int)(floorf(q.y * inv) - (float)minb[1]);
+    const int i2 = (int)(floorf(q.z * inv) - (float)minb[2]);
+    s_key[i] = (uint32_t)(i0 + i1 * mul1 + i2 * mul2);
   }
   __syncthreads();
   FV_TICK(2);
@@ -703,16 +645,7 @@ __global__ void __launch_bounds__(FE_BLOCK) fe_voxel(DevCtx d) {
       int c = 0;
       for (int jj = j; jj < nruns && s_rvid[s_order[jj]] == vid; ++jj) {
         const int r = s_order[jj], i0 = s_rstart[r], len = (r + 1 < nruns ? (int)s_rstart[r + 1] : n) - i0;
-        for (int i = i0; i < i0 + len; i += 4) {   // four gathers in flight, added strictly in order
-          int ix[4];
-          float4 pt[4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) ix[u] = lfs[min(i + u, i0 + len - 1)];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) pt[u] = seg[ix[u]];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) if (i + u < i0 + len) { sx += pt[u].x; sy += pt[u].y; sz += pt[u].z; si += pt[u].w; ++c; }
-        }
+        for (int i = i0; i < i0 + len; ++i) { const float4 q = point(i); sx += q.x; sy += q.y; sz += q.z; si += q.w; ++c; }   // strictly in order
       }
       const float fn = (float)c;
       out[rank] = make_float4(sx / fn, sy / fn, sz / fn, si / fn);
@@ -724,98 +657,85 @@ __global__ void __launch_bounds__(FE_BLOCK) fe_voxel(DevCtx d) {
   FV_TICK(5);
 }
 
-// ring-ascending concatenation.  grid (NS, slots)
-__global__ void __launch_bounds__(FE_BLOCK) fe_gather(DevCtx d) {
-  const int slot = blockIdx.y + d.slot0, ring = blockIdx.x, tid = threadIdx.x;
+// fe_collect = ring-ascending concatenation of the four feature clouds (:199-205,:245,:293) + the bounding boxes of every LO_CH
+// consecutive less_flat / less_sharp points for the next scan's LaserOdometry (kernels_lo.hip), one workgroup per stream (was
+// fe_gather + fe_boxes: 16 + 48 workgroups per stream in two launches, the second one re-reading what the first had written).
+// Output point i of a cloud belongs to the ring r with off[r] <= i < off[r + 1] (binary search in the per-ring prefix, LDS);
+// 32 consecutive threads hold the 32 points of a box.
+#define FC_T 512
+__global__ void __launch_bounds__(FC_T) fe_collect(DevCtx d) {
+  const int slot = blockIdx.x + d.slot0, tid = threadIdx.x, lane = tid & 63;
   const int cur = cur_in_flight(d, slot);
   const size_t base = (size_t)slot * d.N;
-  __shared__ int s_off[4], s_tot[4];
-  const int* allc = d.st_cnt + (size_t)slot * d.NS * 8;
+  const int NS = d.NS;
+  __shared__ int s_off[4][65];
+  const int* allc = d.st_cnt + (size_t)slot * NS * 8;
   if (tid < 64) {
     const int r = tid;
-    int c[4], p[4];
-    c[0] = r < d.NS ? allc[r * 8 + 0] : 0; c[1] = r < d.NS ? allc[r * 8 + 1] : 0;
-    c[2] = r < d.NS ? allc[r * 8 + 2] : 0; c[3] = r < d.NS ? allc[r * 8 + 4] : 0;
+    int c[4];
+    c[0] = r < NS ? allc[r * 8 + 0] : 0; c[1] = r < NS ? allc[r * 8 + 1] : 0;
+    c[2] = r < NS ? allc[r * 8 + 2] : 0; c[3] = r < NS ? allc[r * 8 + 4] : 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      p[k] = r < ring ? c[k] : 0;
+      int incl = c[k];
 #pragma unroll
-      for (int o = 32; o > 0; o >>= 1) { p[k] += __shfl_xor(p[k], o, 64); c[k] += __shfl_xor(c[k], o, 64); }
-    }
-    if (tid == 0) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) { s_off[k] = p[k]; s_tot[k] = c[k]; }
+      for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+      s_off[k][r] = incl - c[k];
+      if (r == 63) s_off[k][64] = incl;
     }
   }
   __syncthreads();
-  const int* st = d.st_idx + ((size_t)slot * d.NS + ring) * d.st_stride;
-  const int* stk[3] = {st, st + d.cap_sharp, st + d.cap_sharp + d.cap_lsharp};
-  const int* myc = allc + ring * 8;
-  const float4* seg = d.seg_lo + base;
-  // A ring contributes at most a few hundred points per cloud: the first FE_BLOCK entries of the three index lists and
-  // the first 2 FE_BLOCK less_flat points are loaded together (one latency for all the indices, one for all the points);
-  // the loops behind only run for unusually large rings.
-  float4* dstk[3];
-  int* dstik[3];
-  int ixk[3];
-  float4 ptk[3], lf[2];
-  float4* dst_lf = d.feat[F_LFLAT] + ((size_t)slot * 2 + cur) * d.fcap[F_LFLAT] + s_off[3];
-  const float4* src_lf = d.st_lfds + ((size_t)slot * d.NS + ring) * d.H;
-  const int n_lf = myc[4];
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    dstk[k] = d.feat[k] + ((size_t)slot * 2 + cur) * d.fcap[k] + s_off[k];
-    dstik[k] = d.feat_idx[k] + ((size_t)slot * 2 + cur) * d.fcap[k] + s_off[k];
-    ixk[k] = tid < myc[k] ? stk[k][tid] : 0;
+  const int tot[4] = {s_off[0][64], s_off[1][64], s_off[2][64], s_off[3][64]};
+  if (tid <= NS) {
+    int* ro = d.ring_off + (((size_t)slot * 2 + cur) * 2) * (NS + 1);
+    ro[tid] = tid < NS ? s_off[1][tid] : tot[1];
+    ro[(NS + 1) + tid] = tid < NS ? s_off[3][tid] : tot[3];
   }
-#pragma unroll
-  for (int u = 0; u < 2; ++u) lf[u] = tid + u * FE_BLOCK < n_lf ? src_lf[tid + u * FE_BLOCK] : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-  for (int k = 0; k < 3; ++k) ptk[k] = seg[ixk[k]];
-#pragma unroll
-  for (int k = 0; k < 3; ++k) if (tid < myc[k]) { dstk[k][tid] = ptk[k]; dstik[k][tid] = ixk[k]; }
-#pragma unroll
-  for (int u = 0; u < 2; ++u) if (tid + u * FE_BLOCK < n_lf) dst_lf[tid + u * FE_BLOCK] = lf[u];
-#pragma unroll
-  for (int k = 0; k < 3; ++k)
-    for (int i = tid + FE_BLOCK; i < myc[k]; i += FE_BLOCK) { const int idx = stk[k][i]; dstk[k][i] = seg[idx]; dstik[k][i] = idx; }
-  for (int i = tid + 2 * FE_BLOCK; i < n_lf; i += FE_BLOCK) dst_lf[i] = src_lf[i];
   if (tid == 0) {
-    int* ro = d.ring_off + (((size_t)slot * 2 + cur) * 2) * (d.NS + 1);
-    ro[ring] = s_off[1];
-    ro[(d.NS + 1) + ring] = s_off[3];
-    if (ring == d.NS - 1) {
-      ro[d.NS] = s_tot[1];
-      ro[(d.NS + 1) + d.NS] = s_tot[3];
-      int* fc = d.feat_cnt + ((size_t)slot * 2 + cur) * 4;
-      fc[0] = s_tot[0]; fc[1] = s_tot[1]; fc[2] = s_tot[2]; fc[3] = s_tot[3];
-    }
+    int* fc = d.feat_cnt + ((size_t)slot * 2 + cur) * 4;
+    fc[0] = tot[0]; fc[1] = tot[1]; fc[2] = tot[2]; fc[3] = tot[3];
   }
-}
-
-// Bounding boxes of every LO_CH consecutive points of the less_flat / less_sharp clouds: next scan's LaserOdometry
-// prunes its exact nearest-neighbour searches with them (kernels_lo.hip).  Consecutive points are neighbours on a
-// ring, so the boxes are small.  grid (24, 2, slots), 256 threads = 8 boxes of 32 lanes, grid-stride.
-__global__ void __launch_bounds__(FE_BLOCK) fe_boxes(DevCtx d) {
-  const int slot = blockIdx.z + d.slot0, kind = blockIdx.y;
-  const int cur = cur_in_flight(d, slot);
-  const int tk = kind == 0 ? F_LFLAT : F_LSHARP;
-  const int nt = d.feat_cnt[((size_t)slot * 2 + cur) * 4 + tk];
-  const float4* tg = d.feat[tk] + ((size_t)slot * 2 + cur) * d.fcap[tk];
-  float4* bx = d.lo_box + (((size_t)slot * 2 + cur) * 2 + kind) * d.lo_box_cap * 2;
-  // whole workgroups stride over the boxes, so every lane of a 32-lane group stays in the loop together
-  for (int c0 = blockIdx.x * (FE_BLOCK / LO_CH); c0 * LO_CH < nt; c0 += gridDim.x * (FE_BLOCK / LO_CH)) {
-    const int c = c0 + threadIdx.x / LO_CH;
-    const int t = c * LO_CH + (threadIdx.x % LO_CH);
-    float mn[3] = {3.402823466e+38f, 3.402823466e+38f, 3.402823466e+38f}, mx[3] = {-3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f};
-    if (t < nt) { const float4 p = tg[t]; mn[0] = mx[0] = p.x; mn[1] = mx[1] = p.y; mn[2] = mx[2] = p.z; }
+  const float4* seg = d.seg_lo + base;
+  auto ring_of = [&](int k, int i) -> int {   // largest r with s_off[k][r] <= i (rings beyond NS hold the total: never chosen for i < total)
+    int lo = 0, hi = NS - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (s_off[k][mid] <= i) lo = mid; else hi = mid - 1; }
+    return lo;
+  };
 #pragma unroll
-    for (int a = 0; a < 3; ++a)
+  for (int k = 0; k < 4; ++k) {
+    float4* dst = d.feat[k] + ((size_t)slot * 2 + cur) * d.fcap[k];
+    int* dsti = k < 3 ? d.feat_idx[k] + ((size_t)slot * 2 + cur) * d.fcap[k] : nullptr;
+    const bool boxes = k == F_LSHARP || k == F_LFLAT;
+    float4* bx = boxes ? d.lo_box + (((size_t)slot * 2 + cur) * 2 + (k == F_LFLAT ? 0 : 1)) * d.lo_box_cap * 2 : nullptr;
+    const int stoff = k == 0 ? 0 : (k == 1 ? d.cap_sharp : d.cap_sharp + d.cap_lsharp);
+    for (int i0 = 0; i0 < tot[k]; i0 += FC_T) {
+      const int i = i0 + tid;
+      const bool v = i < tot[k];
+      float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (v) {
+        const int r = ring_of(k, i), j = i - s_off[k][r];
+        if (k < 3) {
+          const int idx = d.st_idx[((size_t)slot * NS + r) * d.st_stride + stoff + j];
+          p = seg[idx];
+          dsti[i] = idx;
+        } else {
+          p = d.st_lfds[((size_t)slot * NS + r) * d.H + j];
+        }
+        dst[i] = p;
+      }
+      if (boxes) {
+        float mn[3] = {3.402823466e+38f, 3.402823466e+38f, 3.402823466e+38f}, mx[3] = {-3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f};
+        if (v) { mn[0] = mx[0] = p.x; mn[1] = mx[1] = p.y; mn[2] = mx[2] = p.z; }
 #pragma unroll
-      for (int o = LO_CH / 2; o > 0; o >>= 1) { mn[a] = fminf(mn[a], __shfl_xor(mn[a], o, 64)); mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], o, 64)); }
-    if ((threadIdx.x % LO_CH) == 0 && c * LO_CH < nt) {
-      bx[2 * c] = make_float4(mn[0], mn[1], mn[2], 0.f);
-      bx[2 * c + 1] = make_float4(mx[0], mx[1], mx[2], 0.f);
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+          for (int o = LO_CH / 2; o > 0; o >>= 1) { mn[a] = fminf(mn[a], __shfl_xor(mn[a], o, 64)); mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], o, 64)); }
+        if ((tid % LO_CH) == 0 && v) {
+          const int c = i / LO_CH;
+          bx[2 * c] = make_float4(mn[0], mn[1], mn[2], 0.f);
+          bx[2 * c + 1] = make_float4(mx[0], mx[1], mx[2], 0.f);
+        }
+      }
     }
   }
 }
@@ -835,8 +755,11 @@ int launch_stdsort_probe(const uint32_t* keys, int n, int depth_limit, int* pos_
   return 0;
 }
 
-void launch_fe(const DevCtx& d, hipStream_t st) {
-  ALEGO_LAUNCH(fe_curv, dim3((d.N + FE_CW - 1) / FE_CW, d.n_launch), dim3(FE_BLOCK), 0, st, d);
+void launch_fe(const DevCtx& d, hipStream_t st, bool curv_done) {
+  // dynamic LDS above 64 KB has to be requested explicitly (fe_voxel: 26 B per column, horizon_scan <= 4096)
+  static const bool cfg = hipFuncSetAttribute(reinterpret_cast<const void*>(fe_voxel), hipFuncAttributeMaxDynamicSharedMemorySize, FV_LDS_PER_COL * FE_MAXH) == hipSuccess;
+  (void)cfg;
+  if (!curv_done) ALEGO_LAUNCH(fe_curv, dim3((d.N + FE_CW - 1) / FE_CW, d.n_launch), dim3(FE_BLOCK), 0, st, d);   // (ip_fused leaves cd / fe_flag behind)
   // the longest sector holds at most ceil(H / n_sectors) + 1 points
   const int sector_max = (d.H + d.P.n_sectors - 1) / (d.P.n_sectors > 0 ? d.P.n_sectors : 1) + 2;
   // (padding this allocation by 16 KB cost 7 % of the whole pipeline: the LDS footprint decides how many rings share a CU)
@@ -855,7 +778,6 @@ void launch_fe(const DevCtx& d, hipStream_t st) {
   else if (d.P.sort_mode == 2) { ALEGO_LAUNCH((fe_pick<12, true>), dim3(d.NS, d.n_launch), dim3(64), (size_t)3 * d.H, st, d); }
   else if (sector_max <= 64 * 6) { ALEGO_LAUNCH((fe_pick<6, false>), dim3(d.NS, d.n_launch), dim3(64), (size_t)3 * d.H + extra, st, d); }
   else { ALEGO_LAUNCH((fe_pick<12, false>), dim3(d.NS, d.n_launch), dim3(64), (size_t)3 * d.H, st, d); }
-  ALEGO_LAUNCH(fe_voxel, dim3(d.NS, d.n_launch), dim3(FE_BLOCK), (size_t)10 * d.H, st, d);
-  ALEGO_LAUNCH(fe_gather, dim3(d.NS, d.n_launch), dim3(FE_BLOCK), 0, st, d);
-  ALEGO_LAUNCH(fe_boxes, dim3(24, 2, d.n_launch), dim3(FE_BLOCK), 0, st, d);  // 24 x 8 boxes = 6144 targets per sweep
+  ALEGO_LAUNCH(fe_voxel, dim3(d.NS, d.n_launch), dim3(FE_BLOCK), (size_t)FV_LDS_PER_COL * d.H, st, d);
+  ALEGO_LAUNCH(fe_collect, dim3(d.n_launch), dim3(FC_T), 0, st, d);
 }

@@ -62,10 +62,11 @@ def kernel_bytes(name, c, NS, H, rebuilds_per_launch=0.0):
     rb = rebuilds_per_launch
     t = {
         # B_IP = 16 P (in) + 25 M + 16 O + 8 NS + 12 (out)
+        "ip_fused": 16 * P + 25 * M + 16 * O + 8 * NS + 12 + 8 * M,   # B_IP + the range / column re-read of B_FE (curvature phase)
         "ip_project": 16 * P, "ip_front": 12, "cc_lds16": 25 * M + 16 * O + 8 * NS, "cc_lds": 25 * M + 16 * O + 8 * NS,
         "ip_compact": 25 * M + 16 * O + 8 * NS,
         # B_FE = 9 M (range, col, ground in) + 16 feats (out)
-        "fe_curv": 8 * M, "fe_pick4": M, "fe_pick": M, "fe_gather": 16 * feats,
+        "fe_curv": 8 * M, "fe_pick4": M, "fe_pick": M, "fe_gather": 16 * feats, "fe_collect": 16 * feats,
         # B_LO = 16 (F' + Q) + 104
         "lo_assoc": 16 * (c["Fc"] + c["Fs"] + c["Qc"] + c["Qs"]) / 2, "lo_solve": 104 / 2, "lo_solve_t": 104 / 2,
         # B_LM = 16 Kraw + 32 Kds + 16 L + 104 per mapping frame
