@@ -21,6 +21,11 @@
 
 thread_local Profiler* g_prof = nullptr;
 
+// A handle of several stream groups drives two HIP streams per group (front end + LaserMapping); the runtime's default of 4 hardware
+// queues would make pairs of them share a queue and serialise.  Only effective when this library is loaded before the process's
+// first HIP call (bench.py / tests/conftest.py also export it); never overrides the user's setting.
+namespace { struct HwQueueEnv { HwQueueEnv() { setenv("GPU_MAX_HW_QUEUES", "8", 0); } } g_hw_queue_env; }
+
 bool launch_ip(const DevCtx& d, int ring_pos, bool want_labels, hipStream_t st);
 void launch_fe(const DevCtx& d, hipStream_t st, bool curv_done);
 void launch_lo(const DevCtx& d, hipStream_t st);
@@ -28,7 +33,8 @@ void launch_atan2f_probe(const float* y, const float* x, float* out, int n, int 
 int launch_stdsort_probe(const uint32_t* keys, int n, int depth_limit, int* pos_out, hipStream_t st);
 void launch_lo_imu_push(const DevCtx& d, int slot, const double* smp_dev, int n, hipStream_t st);
 void launch_lo_deskew(const DevCtx& d, hipStream_t st);
-void launch_traj_log(const DevCtx& d, hipStream_t st);
+void launch_traj_log(const DevCtx& d, hipStream_t st, const double* staged_odom = nullptr, int par = 0);
+const double* lm_host_stage_odom(LmHost* lm);
 void launch_dbg_eval_blocks(int type, int n, const double* geom13, const double* params6, double* res, double* jac6, hipStream_t st);
 int icp_run(const alego_params& P, const alego_kf_in* latest, const alego_kf_in* history, int n_history, alego_icp_result* out,
             alego_point* target_out, int target_cap, hipStream_t st, std::string* err);
@@ -46,6 +52,13 @@ struct alego_handle {
   // LmHost), so the latency-bound kernels of one group overlap with the kernels of the others.  Slots never interact.
   std::vector<hipStream_t> streams;
   int gsize = 1;
+  // alego_batch_run: LaserMapping of scan k runs on a second HIP stream of the group (back[g]) while the group's front end (ImageProjection,
+  // feature extraction, LaserOdometry — none of which reads anything LaserMapping writes) already works on scans k + 1, k + 2.  lm_stage
+  // hands a scan over (odometry + the three clouds, double-buffered by scan parity); ev_back[g][p] = LaserMapping of the last scan of parity p done.
+  bool lm_async = false;
+  std::vector<hipStream_t> back;
+  std::vector<hipEvent_t> ev_stage, ev_back;   // [group][2]
+  std::vector<long> grp_scans;                  // scans handed over per group
   DevCtx d;
   std::vector<void*> allocs;
   std::string err;
@@ -101,6 +114,7 @@ hipStream_t stream_of(const alego_handle* h, int slot) { return h->streams[slot 
 hipError_t sync_all(const alego_handle* h) {
   hipError_t r = hipSuccess;
   for (hipStream_t s : h->streams) { hipError_t e = hipStreamSynchronize(s); if (e != hipSuccess) r = e; }
+  for (hipStream_t s : h->back) { hipError_t e = hipStreamSynchronize(s); if (e != hipSuccess) r = e; }
   for (hipStream_t s : {h->s_lo, h->s_lm}) if (s) { hipError_t e = hipStreamSynchronize(s); if (e != hipSuccess) r = e; }
   return r;
 }
@@ -114,9 +128,12 @@ struct DevTemps {
 
 int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
 
+// LaserMapping work still in flight on the groups' back streams (alego_batch_run without sync): every other entry point waits for it first
+void drain_back(alego_handle* h) { for (hipStream_t s : h->back) (void)hipStreamSynchronize(s); }
 int check_slot(alego_handle* h, int slot) {
   if (!h) return ALEGO_ERR_ARG;
   if (slot < 0 || slot >= h->d.n_slots) { h->err = "slot out of range"; return ALEGO_ERR_ARG; }
+  drain_back(h);
   return 0;
 }
 
@@ -195,6 +212,19 @@ int alego_create(const alego_params* params, int device, int n_slots, int ring_l
       h->streams.push_back(s);
     }
     h->stream = h->streams[0];
+    h->lm_async = env_int("ALEGO_LM_ASYNC", 1) != 0;
+    if (h->lm_async) {
+      for (int g = 0; g < G; ++g) {
+        hipStream_t s = nullptr;
+        hipEvent_t e[4] = {nullptr, nullptr, nullptr, nullptr};
+        bool ok = hipStreamCreate(&s) == hipSuccess;
+        for (int k = 0; k < 4 && ok; ++k) ok = hipEventCreateWithFlags(&e[k], hipEventDisableTiming) == hipSuccess;
+        if (!ok) { h->lm_async = false; break; }
+        h->back.push_back(s);
+        h->ev_stage.push_back(e[0]); h->ev_stage.push_back(e[1]); h->ev_back.push_back(e[2]); h->ev_back.push_back(e[3]);
+      }
+      h->grp_scans.assign(G, 0);
+    }
   }
   DevCtx& d = h->d;
   std::memset(&d, 0, sizeof(d));
@@ -312,6 +342,9 @@ void alego_destroy(alego_handle* h) {
   if (h->lm) lm_host_destroy(h->lm);
   for (void* p : h->allocs) (void)guard_free(p);
   for (hipStream_t s : h->streams) hipStreamDestroy(s);
+  for (hipStream_t s : h->back) hipStreamDestroy(s);
+  for (hipEvent_t e : h->ev_stage) (void)hipEventDestroy(e);
+  for (hipEvent_t e : h->ev_back) (void)hipEventDestroy(e);
   if (h->s_lo) hipStreamDestroy(h->s_lo);
   if (h->s_lm) hipStreamDestroy(h->s_lm);
   for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
@@ -385,6 +418,7 @@ int alego_stream_run(alego_handle* h, int first_step, int n_scans, int stages, i
   if (!h) return ALEGO_ERR_ARG;
   if (!h->stream_mode) { h->err = "alego_stream_run: call alego_stream_setup first"; return ALEGO_ERR_ARG; }
   hipSetDevice(h->device);
+  drain_back(h);
   g_prof = &h->prof;
   const int W = h->lanes;
   hipStream_t sA = h->streams[0], sB = h->s_lo, sC = h->s_lm;
@@ -446,7 +480,7 @@ int alego_stream_run(alego_handle* h, int first_step, int n_scans, int stages, i
 }
 
 // enqueue IP -> FE -> LO -> LM for slots [slot0, slot0+n) on ring position `pos`
-static int enqueue_scan(alego_handle* h, int slot0, int n, int pos, int stages, bool want_labels) {
+static int enqueue_scan(alego_handle* h, int slot0, int n, int pos, int stages, bool want_labels, bool async_lm = false) {
   DevCtx d = view(h, slot0, n);
   d.replay_bag = (stages & ALEGO_REPLAY_BAG) ? 1 : 0;
   hipStream_t S = stream_of(h, slot0);  // [slot0, slot0+n) lies inside one stream group
@@ -461,8 +495,19 @@ static int enqueue_scan(alego_handle* h, int slot0, int n, int pos, int stages, 
     launch_lo(d, S); chk("lo");
     std::vector<char> odom_valid(n);
     for (int i = 0; i < n; ++i) odom_valid[i] = h->lo_scans[slot0 + i]++ > 0;
-    if (stages & 4) { if (int r = lm_host_enqueue(h->lm, d, odom_valid, &h->err)) return r; }
-    if (d.traj) launch_traj_log(d, S);
+    if ((stages & 4) && async_lm && h->lm_async) {
+      // LaserMapping of this scan on the group's back stream, behind the hand-over kernel on S (lm_host.hip)
+      const int g = slot0 / h->gsize;
+      hipStream_t B = h->back[g];
+      const long k = h->grp_scans[g]++;
+      const int par = (int)(k & 1);
+      if (int r = lm_host_enqueue_async(h->lm, d, odom_valid, &h->err, S, B, h->ev_stage[g * 2 + par], h->ev_back[g * 2 + par], h->ev_back[g * 2 + (par ^ 1)], k)) return r;
+      if (d.traj) launch_traj_log(d, B, lm_host_stage_odom(h->lm), par);
+      HIP_TRY(h, hipEventRecord(h->ev_back[g * 2 + par], B));
+    } else {
+      if (stages & 4) { if (int r = lm_host_enqueue(h->lm, d, odom_valid, &h->err)) return r; }
+      if (d.traj) launch_traj_log(d, S);
+    }
   }
   HIP_TRY(h, hipGetLastError());
   return 0;
@@ -486,7 +531,7 @@ int alego_batch_run(alego_handle* h, int first_pos, int n_scans, int stages, int
       pos = ((first_pos + s) % R + R) % R;
     }
     for (int s0 = 0; s0 < h->d.n_slots; s0 += h->gsize)
-      if (int r = enqueue_scan(h, s0, std::min(h->gsize, h->d.n_slots - s0), pos, stages & (7 | ALEGO_REPLAY_BAG), false)) return r;
+      if (int r = enqueue_scan(h, s0, std::min(h->gsize, h->d.n_slots - s0), pos, stages & (7 | ALEGO_REPLAY_BAG), false, /*async_lm=*/true)) return r;
   }
   if (sync) HIP_TRY(h, sync_all(h));
   return 0;

@@ -57,12 +57,14 @@ DEV_INLINE void lm_map_update(const LmCtx& L, int slot, int* li, int merge) {
 
 
 // grid (8, 3, slots).  stage: copy /corner_last, /surf_last, /outlier of this scan into the LM inputs.
-__global__ void __launch_bounds__(LM_BLOCK) lm_prepare(DevCtx d, LmCtx L, int stage, int run_hint) {
+// stage 0: inputs uploaded by the host (alego_lm_process); 1: copy this scan's clouds and read its odometry from the front end's
+// buffers; 2: lm_stage (below) has copied both — LaserMapping runs on its own HIP stream while the front end works on later scans.
+__global__ void __launch_bounds__(LM_BLOCK) lm_prepare(DevCtx d, LmCtx L, int stage, int run_hint, int par) {
   const int slot = blockIdx.z + d.slot0, kind = blockIdx.y;
   const int cur = d.scal[slot * SC_COUNT + SC_CUR];  // LO has completed: features of this scan
   const int sslot = scan_slot_of(d, slot);           // where this scan's features, outliers and odometry hand-over live (its lane, or the slot itself)
   int* li = lip(L, slot);
-  if (stage && run_hint != 0) {   // run_hint == 0: the host knows that no slot of this launch maps this scan (odd frame)
+  if (stage == 1 && run_hint != 0) {   // run_hint == 0: the host knows that no slot of this launch maps this scan (odd frame)
     // (written with unconditional loads + selects: a 3-way if/else chain here was lowered by hipcc 7.2 into
     //  a scalar switch that left the count pointer of the last arm undefined)
     const size_t fb = d.fs_cur >= 0 ? (size_t)d.fs_cur * 2 : (size_t)slot * 2 + cur;
@@ -81,11 +83,12 @@ __global__ void __launch_bounds__(LM_BLOCK) lm_prepare(DevCtx d, LmCtx L, int st
   if (blockIdx.x != 0 || kind != 0 || threadIdx.x != 0) return;
   double* ld = ldp(L, slot);
   double* po = d.poses + (size_t)sslot * 16;
+  const double* pin = stage == 2 ? L.stage_odom + ((size_t)slot * 2 + par) * 8 : po;   // this scan's /odom/lidar
   li[LI_RUN] = 0; li[LI_REBUILD] = 0; li[LI_REBUILD_FB] = 0; li[LI_KF_ADDED] = 0; li[LI_OPTIMIZED] = 0; li[LI_FLAGS] = 0;
-  if (!d.scal[sslot * SC_COUNT + SC_ODOM_VALID]) return;  // no /odom/lidar on the initialising scan -> no mapping frame
+  if (stage == 2 ? pin[7] == 0.0 : !d.scal[sslot * SC_COUNT + SC_ODOM_VALID]) return;  // no /odom/lidar on the initialising scan -> no mapping frame
   // laserOdomHandler :154-166
-  for (int k = 0; k < 3; ++k) ld[LD_T_O2L + k] = po[k];
-  for (int k = 0; k < 4; ++k) ld[LD_Q_O2L + k] = po[3 + k];
+  for (int k = 0; k < 3; ++k) ld[LD_T_O2L + k] = pin[k];
+  for (int k = 0; k < 4; ++k) ld[LD_Q_O2L + k] = pin[3 + k];
   const DQuat qm2o = ldq(ld + LD_Q_M2O), qo2l = ldq(ld + LD_Q_O2L);
   double r[3];
   dq_rotate(qm2o, ld + LD_T_O2L, r);
@@ -101,6 +104,33 @@ __global__ void __launch_bounds__(LM_BLOCK) lm_prepare(DevCtx d, LmCtx L, int st
   if (!run) { li[LI_FLAGS] = 8; return; }
   lm_map_update(L, slot, li, d.opt_map_merge);
   li[LI_REBUILD_FB] = li[LI_REBUILD] && !d.opt_map_merge;
+}
+
+
+// grid (8, 3, slots) on the FRONT END's stream: hands this scan over to a LaserMapping that runs on a stream of its own — /odom/lidar
+// and its validity into stage_odom[par], and (mapping frames, run_hint != 0) /corner_last, /surf_last, /outlier into the LM inputs.
+// After it the front end may overwrite its per-scan buffers; lm_prepare(stage 2) reads only what was staged here.
+__global__ void __launch_bounds__(LM_BLOCK) lm_stage(DevCtx d, LmCtx L, int run_hint, int par) {
+  const int slot = blockIdx.z + d.slot0, kind = blockIdx.y;
+  const int cur = d.scal[slot * SC_COUNT + SC_CUR];  // LO has completed: features of this scan
+  int* li = lip(L, slot);
+  if (run_hint != 0) {
+    const size_t fb = (size_t)slot * 2 + cur;
+    const int n_c = d.feat_cnt[fb * 4 + F_LSHARP], n_s = d.feat_cnt[fb * 4 + F_LFLAT], n_o = d.scal[slot * SC_COUNT + SC_NOUT];
+    const float4* src_c = d.feat[F_LSHARP] + fb * d.fcap[F_LSHARP];
+    const float4* src_s = d.feat[F_LFLAT] + fb * d.fcap[F_LFLAT];
+    const float4* src_o = d.outlier + (size_t)slot * d.N;
+    const float4* src = kind == 0 ? src_c : (kind == 1 ? src_s : src_o);
+    float4* dst = kind == 0 ? L.in_corner + (size_t)slot * L.in_cap_c : (kind == 1 ? L.in_surf + (size_t)slot * L.in_cap_s : L.in_outl + (size_t)slot * L.in_cap_o);
+    const int cap = kind == 0 ? L.in_cap_c : (kind == 1 ? L.in_cap_s : L.in_cap_o);
+    int n = kind == 0 ? n_c : (kind == 1 ? n_s : n_o);
+    if (n > cap) { n = cap; if (threadIdx.x == 0 && blockIdx.x == 0) li[LI_OVERFLOW] = 1; }
+    for (int i = blockIdx.x * LM_BLOCK + threadIdx.x; i < n; i += gridDim.x * LM_BLOCK) dst[i] = src[i];
+    if (blockIdx.x == 0 && threadIdx.x == 0) li[LI_NIN_C + kind] = n;
+  }
+  if (blockIdx.x != 0 || kind != 0 || threadIdx.x >= 8) return;
+  double* so = L.stage_odom + ((size_t)slot * 2 + par) * 8;
+  so[threadIdx.x] = threadIdx.x < 7 ? d.poses[(size_t)slot * 16 + threadIdx.x] : (d.scal[slot * SC_COUNT + SC_ODOM_VALID] ? 1.0 : 0.0);
 }
 
 
@@ -943,10 +973,15 @@ int lm_configure() {
 }
 
 // ---- launchers ---------------------------------------------------------------------
-void launch_lm_prepare(const DevCtx& d, const LmCtx& L, int stage, int run_hint, hipStream_t st) {
-  // a frame that is not mapped only needs the odometry hand-over (one thread per slot)
+void launch_lm_prepare(const DevCtx& d, const LmCtx& L, int stage, int run_hint, int par, hipStream_t st) {
+  // a frame that is not mapped only needs the odometry hand-over (one thread per slot); so does every frame whose clouds lm_stage copied
+  const bool small = run_hint == 0 || stage == 2;
+  const dim3 grid = small ? dim3(1, 1, d.n_launch) : dim3(8, 3, d.n_launch);
+  ALEGO_LAUNCH(lm_prepare, grid, dim3(small ? 64 : LM_BLOCK), 0, st, d, L, stage, run_hint, par);
+}
+void launch_lm_stage(const DevCtx& d, const LmCtx& L, int run_hint, int par, hipStream_t st) {
   const dim3 grid = run_hint == 0 ? dim3(1, 1, d.n_launch) : dim3(8, 3, d.n_launch);
-  ALEGO_LAUNCH(lm_prepare, grid, dim3(run_hint == 0 ? 64 : LM_BLOCK), 0, st, d, L, stage, run_hint);
+  ALEGO_LAUNCH(lm_stage, grid, dim3(run_hint == 0 ? 64 : LM_BLOCK), 0, st, d, L, run_hint, par);
 }
 void launch_lm_concat(const DevCtx& d, const LmCtx& L, hipStream_t st) {
   ALEGO_LAUNCH(lm_concat, dim3(2, L.K, d.n_launch), dim3(LM_BLOCK), 0, st, d, L);

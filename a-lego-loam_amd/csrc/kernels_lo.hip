@@ -676,7 +676,9 @@ __global__ void __launch_bounds__(DSK_T) lo_deskew(DevCtx d) {
 
 // per-scan pose log (alego_trajectory_*): what a bag replay publishes on /odom/lidar and /odom_aft_mapped, kept on the device so that
 // a batch replay needs no host synchronisation per scan
-__global__ void traj_log(DevCtx d) {
+// staged_odom != null: LaserMapping runs behind the front end on its own stream (alego_batch_run); the scan's /odom/lidar is then taken
+// from the hand-over buffer (LaserOdometry may already have written a later scan's pose into `poses`)
+__global__ void traj_log(DevCtx d, const double* staged_odom, int par) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= d.n_launch) return;
   const int slot = i + d.slot0;
@@ -684,12 +686,15 @@ __global__ void traj_log(DevCtx d) {
   d.traj_n[slot] = k + 1;
   if (k >= d.traj_cap) return;
   const double* po = d.poses + (size_t)slot * 16;
+  const double* od = staged_odom ? staged_odom + ((size_t)slot * 2 + par) * 8 : po;
   double* o = d.traj + ((size_t)slot * d.traj_cap + k) * 14;
 #pragma unroll
-  for (int j = 0; j < 14; ++j) o[j] = po[j];
+  for (int j = 0; j < 7; ++j) o[j] = od[j];
+#pragma unroll
+  for (int j = 7; j < 14; ++j) o[j] = po[j];
 }
-void launch_traj_log(const DevCtx& d, hipStream_t st) {
-  hipLaunchKernelGGL(traj_log, dim3((d.n_launch + 63) / 64), dim3(64), 0, st, d);
+void launch_traj_log(const DevCtx& d, hipStream_t st, const double* staged_odom, int par) {
+  hipLaunchKernelGGL(traj_log, dim3((d.n_launch + 63) / 64), dim3(64), 0, st, d, staged_odom, par);
 }
 
 void launch_lo_imu_push(const DevCtx& d, int slot, const double* smp_dev, int n, hipStream_t st) {

@@ -109,6 +109,8 @@ struct LmCtx {
   double* ld;                    // [slot][LD_COUNT]
   // staged inputs
   float4 *in_corner, *in_surf, *in_outl;          // [slot][in_cap_*]
+  double* stage_odom;                             // [slot][2][8] /odom/lidar of a scan (t 3, q 4, valid) handed over by lm_stage when LaserMapping runs on a
+                                                  // HIP stream of its own behind the front end (double-buffered by scan parity)
   // key-frame ring (clouds already transformed into the map frame, laserMapping.cpp:216-218) and SORTED by voxel key of the
   // map's leaf size (stable: input order inside a voxel): corner, and surf followed by outlier (:240-242) as one run
   float4 *kfs_c, *kfs_s;                          // [slot][KR][kf_cap_c] / [slot][KR][total_cap]

@@ -15,6 +15,10 @@ void lm_host_destroy(LmHost* lm);
 // LaserMapping for the scan just processed by LO, for the slots of view `d`
 // st_override: enqueue on this stream instead of the slot's group stream (alego_stream_run pipelines LaserMapping on a stream of its own)
 int lm_host_enqueue(LmHost* lm, const DevCtx& d, const std::vector<char>& odom_valid, std::string* err, hipStream_t st_override = nullptr);
+// the batch path: LaserMapping of this scan on `back`, behind the hand-over kernel (lm_stage) on `front`; k = scans handed over so far for
+// this stream group, back_same / back_other = events recorded on `back` after the LaserMapping of scans k - 2 / k - 1
+int lm_host_enqueue_async(LmHost* lm, const DevCtx& d, const std::vector<char>& odom_valid, std::string* err, hipStream_t front, hipStream_t back,
+                          hipEvent_t staged, hipEvent_t back_same, hipEvent_t back_other, long k);
 int lm_host_get_flags(LmHost* lm, int slot);
 int lm_host_process_host(LmHost* lm, const DevCtx& d, const alego_point* corner_last, int n_corner, const alego_point* surf_last,
                          int n_surf, const alego_point* outlier, int n_outlier, const alego_pose* odom, alego_pose* map_pose,

@@ -13,7 +13,8 @@
 #include "lm_ctx.h"
 #include "voxel.h"
 
-void launch_lm_prepare(const DevCtx& d, const LmCtx& L, int stage, int run_hint, hipStream_t st);
+void launch_lm_prepare(const DevCtx& d, const LmCtx& L, int stage, int run_hint, int par, hipStream_t st);
+void launch_lm_stage(const DevCtx& d, const LmCtx& L, int run_hint, int par, hipStream_t st);
 void launch_lm_concat(const DevCtx& d, const LmCtx& L, hipStream_t st);
 void launch_lm_total(const DevCtx& d, const LmCtx& L, hipStream_t st);
 void launch_lm_grid(const DevCtx& d, const LmCtx& L, hipStream_t st);
@@ -83,6 +84,7 @@ LmHost* lm_host_create(const alego_params& P, const DevCtx& d, int n_slots, int 
   const size_t B = n_slots;
   bool ok = true;
   ok = ok && A(lm, &L.li, B * LI_COUNT, err) && A(lm, &L.ld, B * LD_COUNT, err);
+  ok = ok && A(lm, &L.stage_odom, B * 2 * 8, err);
   ok = ok && A(lm, &L.in_corner, B * L.in_cap_c, err) && A(lm, &L.in_surf, B * L.in_cap_s, err) && A(lm, &L.in_outl, B * L.in_cap_o, err);
   ok = ok && A(lm, &L.kfs_c, B * L.KR * L.kf_cap_c, err) && A(lm, &L.kfs_s, B * L.KR * L.total_cap, err);
   ok = ok && A(lm, &L.kfs_n, B * 2 * L.KR, err) && A(lm, &L.kfs_box, B * 2 * L.KR * 8, err);
@@ -218,10 +220,12 @@ static int lm_allreduce(void* ctx, double* buf, size_t count, hipStream_t st) {
 }
 
 // odom_valid[s - slot0]: whether slot s has an /odom/lidar message for this scan (false on its first scan)
-static int lm_sequence(LmHost* lm, const DevCtx& d, int stage, const std::vector<char>& odom_valid, std::string* err, hipStream_t st_override = nullptr) {
+// A (optional): LaserMapping of this scan runs on A->back, behind the hand-over kernel lm_stage on the front end's stream.
+struct LmAsync { hipStream_t front, back; hipEvent_t staged, back_same, back_other; long k; };   // k: scans handed over before this one (its parity picks the staging buffer)
+static int lm_sequence(LmHost* lm, const DevCtx& d, int stage, const std::vector<char>& odom_valid, std::string* err, hipStream_t st_override = nullptr, const LmAsync* A = nullptr) {
   // the slots of one launch view always belong to one stream group
   const int g = d.slot0 / lm->gsize;
-  hipStream_t st = st_override ? st_override : lm->st[g];
+  hipStream_t st = A ? A->back : (st_override ? st_override : lm->st[g]);
   LmCtx L = lm->L;
   L.vox_bbox = lm->vm[g].bbox; L.vox_slot0 = g * lm->gsize;
   int n_run = 0, n_norun = 0;
@@ -232,7 +236,17 @@ static int lm_sequence(LmHost* lm, const DevCtx& d, int stage, const std::vector
     run ? ++n_run : ++n_norun;
   }
   const int hint = n_run == 0 ? 0 : (n_norun == 0 ? 1 : -1);  // -1: slots out of phase, no launch skipping
-  launch_lm_prepare(d, L, stage, hint, st);
+  int par = 0;
+  if (A) {
+    par = (int)(A->k & 1);
+    // stage_odom[par] was last read by the LaserMapping of scan k - 2; the cloud inputs by the last mapping frame (k - 1 at the latest)
+    if (A->k >= 2 && hipStreamWaitEvent(A->front, A->back_same, 0) != hipSuccess) { *err = "hipStreamWaitEvent failed"; return ALEGO_ERR_HIP; }
+    if (hint != 0 && A->k >= 1 && hipStreamWaitEvent(A->front, A->back_other, 0) != hipSuccess) { *err = "hipStreamWaitEvent failed"; return ALEGO_ERR_HIP; }
+    launch_lm_stage(d, L, hint, par, A->front);
+    if (hipEventRecord(A->staged, A->front) != hipSuccess || hipStreamWaitEvent(st, A->staged, 0) != hipSuccess) { *err = "event hand-over to the LaserMapping stream failed"; return ALEGO_ERR_HIP; }
+    stage = 2;
+  }
+  launch_lm_prepare(d, L, stage, hint, par, st);
   if (!dbg_sync(st, "lm_prepare", err)) return ALEGO_ERR_HIP;
   if (n_run == 0) return 0;
   if (int r = map_sequence(lm, d, L, g, st, err)) return r;   // (includes the VoxelGrid filters of the scan's three clouds)
@@ -260,6 +274,12 @@ static void clear_run_flags_outside(LmHost* lm, const DevCtx& d) {
 int lm_host_enqueue(LmHost* lm, const DevCtx& d, const std::vector<char>& odom_valid, std::string* err, hipStream_t st_override) {
   if (!st_override) clear_run_flags_outside(lm, d);   // (alego_stream_run: the other slots of the group are look-ahead lanes, LaserMapping never ran on them)
   return lm_sequence(lm, d, 1, odom_valid, err, st_override);
+}
+// The batch path: the view covers a whole stream group; LaserMapping of the scan goes to `back`, lm_stage to `front`.
+int lm_host_enqueue_async(LmHost* lm, const DevCtx& d, const std::vector<char>& odom_valid, std::string* err, hipStream_t front, hipStream_t back,
+                          hipEvent_t staged, hipEvent_t back_same, hipEvent_t back_other, long k) {
+  const LmAsync A{front, back, staged, back_same, back_other, k};
+  return lm_sequence(lm, d, 1, odom_valid, err, nullptr, &A);
 }
 
 int lm_host_process_host(LmHost* lm, const DevCtx& dfull, const alego_point* corner_last, int n_corner, const alego_point* surf_last,
@@ -308,6 +328,7 @@ int lm_host_process_host(LmHost* lm, const DevCtx& dfull, const alego_point* cor
   return li[LI_FLAGS];
 }
 
+const double* lm_host_stage_odom(LmHost* lm) { return lm->L.stage_odom; }
 void lm_host_get_params(LmHost* lm, int slot, double* p6) {
   (void)hipMemcpy(p6, lm->L.ld + (size_t)slot * LD_COUNT + LD_PARAMS, 48, hipMemcpyDeviceToHost);
 }

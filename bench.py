@@ -27,6 +27,8 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# two HIP streams per stream group (front end + LaserMapping) + RCCL's own: the runtime's default of 4 hardware queues would alias them
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 from alego_loader import load_package  # noqa: E402
 
 load_package()
