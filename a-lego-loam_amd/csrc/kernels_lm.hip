@@ -408,11 +408,14 @@ __global__ void __launch_bounds__(128) lm_knn(DevCtx d, LmCtx L) {
   double r[3];
   dq_rotate(qm, vin, r);
   const float sx = (float)(r[0] + ld[LD_T_M2L + 0]), sy = (float)(r[1] + ld[LD_T_M2L + 1]), sz = (float)(r[2] + ld[LD_T_M2L + 2]);
-  // exact 5-NN among all points with d^2 < knn_max_dist: they all lie in the 27 surrounding cells
-  float bd[5];
-  int bi[5];
-#pragma unroll
-  for (int k = 0; k < 5; ++k) { bd[k] = 3.402823466e+38f; bi[k] = 0x7fffffff; }
+  // exact 5-NN among all points with d^2 < knn_max_dist: they all lie in the 27 surrounding cells.
+  // A lane's five best candidates are an UNSORTED set of 64-bit keys (f32 distance bits << 32 | map index: the lexicographic
+  // (distance, index) order is the integer order) with the set's maximum tracked next to it: a candidate that beats the maximum
+  // replaces it (five compare-selects) and the maximum is recomputed (four), instead of a five-step insertion sort — the kernel is
+  // VALU-bound and the insertion ran for every candidate of every lane (any lane of the wavefront inserting makes all of them pay).
+  typedef unsigned long long u64k;
+  const u64k KNONE = ~0ull;
+  u64k k0 = KNONE, k1 = KNONE, k2 = KNONE, k3 = KNONE, k4 = KNONE, kmax = KNONE;
   if (nmap >= 5 && q >= qlo && q < qhi) {   // (another rank's query: nothing to search, the row stays empty)
     int cx, cy, cz;
     grid_cell(g, sx, sy, sz, &cx, &cy, &cz);
@@ -430,20 +433,17 @@ __global__ void __launch_bounds__(128) lm_knn(DevCtx d, LmCtx L) {
       re[r] = in ? a1 : 0;
     }
     auto consider = [&](const float4& a) {
-      const int idx = __float_as_int(a.w);
       float dist = 0.f, df;
       df = sx - a.x; dist += df * df;
       df = sy - a.y; dist += df * df;
       df = sz - a.z; dist += df * df;
-      if (dist < bd[4] || (dist == bd[4] && idx < bi[4])) {
-        bd[4] = dist; bi[4] = idx;
-#pragma unroll
-        for (int k = 4; k > 0; --k) {
-          if (bd[k] < bd[k - 1] || (bd[k] == bd[k - 1] && bi[k] < bi[k - 1])) {
-            const float td = bd[k]; bd[k] = bd[k - 1]; bd[k - 1] = td;
-            const int ti = bi[k]; bi[k] = bi[k - 1]; bi[k - 1] = ti;
-          }
-        }
+      const u64k key = ((u64k)(uint32_t)d_f2i(dist) << 32) | (uint32_t)__float_as_int(a.w);   // dist >= 0: its bit pattern orders like its value
+      if (key < kmax) {
+        // (a set that is not full yet holds KNONE entries, which are its maximum; equal KNONE entries are all "the maximum": only one may be replaced)
+        const bool e0 = k0 == kmax, e1 = !e0 && k1 == kmax, e2 = !e0 && !e1 && k2 == kmax, e3 = !e0 && !e1 && !e2 && k3 == kmax, e4 = !e0 && !e1 && !e2 && !e3;
+        k0 = e0 ? key : k0; k1 = e1 ? key : k1; k2 = e2 ? key : k2; k3 = e3 ? key : k3; k4 = e4 ? key : k4;
+        const u64k m01 = k0 > k1 ? k0 : k1, m23 = k2 > k3 ? k2 : k3, m03 = m01 > m23 ? m01 : m23;
+        kmax = m03 > k4 ? m03 : k4;
       }
     };
     // the first candidate of each of the nine runs: nine independent loads (a run is usually exhausted by one or two turns)
@@ -462,27 +462,24 @@ __global__ void __launch_bounds__(128) lm_knn(DevCtx d, LmCtx L) {
       }
     }
   }
-  // merge the 16 private lists: five rounds of "smallest head of the row"
+  // merge the private sets of the query's lanes: five rounds of "smallest key of the group"; the lane that holds it drops it
+  float bd[5];
+  int bi[5];
   {
-    float rd[5];
-    int ri[5];
 #pragma unroll
     for (int k = 0; k < 5; ++k) {
-      const unsigned long long head = ((unsigned long long)(uint32_t)d_f2i(bd[0]) << 32) | (uint32_t)bi[0];
-      const unsigned long long m = row_min_u64(head);
-      rd[k] = d_i2f((int32_t)(m >> 32)); ri[k] = (int)(uint32_t)m;
-      if (head == m && bi[0] != 0x7fffffff) {  // the winner pops its head
-        bd[0] = bd[1]; bd[1] = bd[2]; bd[2] = bd[3]; bd[3] = bd[4]; bd[4] = 3.402823466e+38f;
-        bi[0] = bi[1]; bi[1] = bi[2]; bi[2] = bi[3]; bi[3] = bi[4]; bi[4] = 0x7fffffff;
+      const u64k m01 = k0 < k1 ? k0 : k1, m23 = k2 < k3 ? k2 : k3, m03 = m01 < m23 ? m01 : m23, mine = m03 < k4 ? m03 : k4;
+      const u64k m = row_min_u64(mine);
+      bd[k] = d_i2f((int32_t)(m >> 32)); bi[k] = (int)(uint32_t)m;   // (KNONE: distance bits 0xFFFFFFFF = NaN, index 0xFFFFFFFF — see `ok` below)
+      if (mine == m && m != KNONE) {   // keys are unique (one per map point): exactly one lane of the group, exactly one of its entries
+        k0 = k0 == m ? KNONE : k0; k1 = k1 == m ? KNONE : k1; k2 = k2 == m ? KNONE : k2; k3 = k3 == m ? KNONE : k3; k4 = k4 == m ? KNONE : k4;
       }
     }
-#pragma unroll
-    for (int k = 0; k < 5; ++k) { bd[k] = rd[k]; bi[k] = ri[k]; }
   }
   // neighbour indices (ascending distance) for lm_fit; idx[0] < 0 = rejected (:376,:426)
   if (sub == 0 && qq < nq) {
     int* kn = L.knn + ((size_t)slot * L.qcap + (kind == 0 ? 0 : L.kf_cap_c) + q) * 5;
-    const bool ok = bi[4] != 0x7fffffff && (double)bd[4] < P.knn_max_dist && q >= qlo && q < qhi;   // (queries of other ranks' slices give no row here)
+    const bool ok = bi[4] != -1 && (double)bd[4] < P.knn_max_dist && q >= qlo && q < qhi;   // (queries of other ranks' slices give no row here)
 #pragma unroll
     for (int k = 0; k < 5; ++k) kn[k] = ok ? bi[k] : -1;
   }
