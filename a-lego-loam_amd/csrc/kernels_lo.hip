@@ -10,6 +10,7 @@
 //              Cholesky by one lane, step acceptance, and (second call) the pose integration
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 #include "dev_cost.h"
 #include "lm_ctx.h"
 #include "prof.h"
@@ -355,7 +356,45 @@ extern "C" void alego_lo_times(long long* out) { (void)hipMemcpyFromSymbol(out, 
 #define LO_T0
 #define LO_ACC(k)
 #endif
+// The correspondence rows of a solve do not change between its evaluations (six per ceres::Solve): the points of the rows are
+// gathered ONCE into LDS (structure of arrays: lane-consecutive rows read consecutive words) instead of from HBM / L2 on every
+// evaluation (four dependent loads per row and evaluation: 20 of lo_solve's 53 us for one stream).  Rows keep their order, so
+// every thread sums the same rows in the same order as lo_eval_rows does.  Problems with more than LO_LDS_ROWS rows stream.
+#define LO_LDS_ROWS 640   // >= n_flat * n_sectors * 16 rings + n_sharp * n_sectors * 16 rings at the reference's parameters (576)
+struct LoRowsLds { float v[12][LO_LDS_ROWS]; };   // c xyz, a xyz, b xyz, m xyz
 template <int BLK>
+DEV_INLINE void lo_stage_rows(const DevCtx& d, int slot, int kind, int n, int off, LoRowsLds& R, unsigned& okm) {
+  const int qk = kind == 0 ? F_FLAT : F_SHARP, tk = kind == 0 ? F_LFLAT : F_LSHARP;
+  const float4* qpts = d.feat[qk] + fidx_cur(d, slot) * d.fcap[qk];
+  const float4* tg = d.feat[tk] + fidx_last(d, slot) * d.fcap[tk];
+  const int* rows = d.lo_corr + ((size_t)slot * (d.lo_qcap_surf + d.lo_qcap_corner) + (kind == 0 ? 0 : d.lo_qcap_surf)) * 4;
+  okm = 0;
+  int k = 0;
+  for (int i = threadIdx.x; i < n; i += BLK, ++k) {
+    const int4 r = *reinterpret_cast<const int4*>(rows + (size_t)i * 4);
+    const bool ok = r.y >= 0;
+    const float4 pc = qpts[ok ? r.x : 0], pa = tg[ok ? r.y : 0], pb = tg[ok ? r.z : 0], pm = tg[(ok && kind == 0) ? r.w : 0];
+    const int j = off + i;
+    R.v[0][j] = pc.x; R.v[1][j] = pc.y; R.v[2][j] = pc.z; R.v[3][j] = pa.x; R.v[4][j] = pa.y; R.v[5][j] = pa.z;
+    R.v[6][j] = pb.x; R.v[7][j] = pb.y; R.v[8][j] = pb.z; R.v[9][j] = pm.x; R.v[10][j] = pm.y; R.v[11][j] = pm.z;
+    if (ok) okm |= 1u << k;
+  }
+}
+template <int BLK, int kind>
+DEV_INLINE void lo_eval_staged(int n, int off, const LoRowsLds& R, unsigned okm, const PoseTerms& T, double huber, double acc[28]) {
+  int k = 0;
+  for (int i = threadIdx.x; i < n; i += BLK, ++k) {
+    if (!((okm >> k) & 1u)) continue;
+    const int j = off + i;
+    const double cp[3] = {R.v[0][j], R.v[1][j], R.v[2][j]}, a[3] = {R.v[3][j], R.v[4][j], R.v[5][j]}, b[3] = {R.v[6][j], R.v[7][j], R.v[8][j]};
+    const double c[3] = {kind == 0 ? (double)R.v[9][j] : 0.0, kind == 0 ? (double)R.v[10][j] : 0.0, kind == 0 ? (double)R.v[11][j] : 0.0};
+    double res, J[6];
+    eval_block(kind == 0 ? BLK_SURF : BLK_CORNER, cp, a, b, c, 0.0, T, &res, J);
+    accumulate_block(res, J, huber, acc);
+  }
+}
+
+template <int BLK, bool STAGED = false>   // STAGED: the handle's row capacities fit LO_LDS_ROWS (decided at launch: fixed by the geometry / parameters)
 __global__ void __launch_bounds__(BLK) lo_solve_t(DevCtx d, int phase) {
   const int slot = blockIdx.x + d.slot0;
   const int cur = cur_in_flight(d, slot);
@@ -367,6 +406,7 @@ __global__ void __launch_bounds__(BLK) lo_solve_t(DevCtx d, int phase) {
   __shared__ double s_out[28], s_trig[12];
   __shared__ LmState S;
   __shared__ int s_action, s_cnt[BLK / 64];
+  __shared__ typename std::conditional<STAGED, LoRowsLds, char>::type s_rows;
   if (!sc[SC_LO_INIT]) {  // :316-324
     if (phase == 1 && threadIdx.x == 0) {
       sc[SC_LO_INIT] = 1; sc[SC_LO_FLAGS] = 1; sc[SC_LO_NSURF] = 0; sc[SC_LO_NCORNER] = 0; sc[SC_CUR] = cur;
@@ -403,13 +443,28 @@ __global__ void __launch_bounds__(BLK) lo_solve_t(DevCtx d, int phase) {
   const bool do_solve = s_cnt[0] >= d.P.lo_min_corr;
   if (do_solve) {
     double acc[28];
+    unsigned oks = 0, okc = 0;
+    if constexpr (STAGED) {
+      LO_T0;
+      lo_stage_rows<BLK>(d, slot, 0, nq_s, 0, s_rows, oks);
+      if (phase == 1) lo_stage_rows<BLK>(d, slot, 1, nq_c, nq_s, s_rows, okc);
+      LO_ACC(1);
+      // (every thread reads back only what it wrote itself: no barrier needed)
+    }
     auto evaluate = [&](const double* x) {
 #pragma unroll
       for (int k = 0; k < 28; ++k) acc[k] = 0;
       PoseTerms T;
       { LO_T0; T = pose_terms_coop(x, s_trig); LO_ACC(0); }
-      { LO_T0; lo_eval_rows<BLK>(d, slot, 0, nq_s, T, acc);
-        if (phase == 1) lo_eval_rows<BLK>(d, slot, 1, nq_c, T, acc); LO_ACC(1); }
+      { LO_T0;
+        if constexpr (STAGED) {
+          lo_eval_staged<BLK, 0>(nq_s, 0, s_rows, oks, T, d.P.huber_delta, acc);
+          if (phase == 1) lo_eval_staged<BLK, 1>(nq_c, nq_s, s_rows, okc, T, d.P.huber_delta, acc);
+        } else {
+          lo_eval_rows<BLK>(d, slot, 0, nq_s, T, acc);
+          if (phase == 1) lo_eval_rows<BLK>(d, slot, 1, nq_c, T, acc);
+        }
+        LO_ACC(1); }
       { LO_T0; block_reduce28_lds<BLK>(acc, s_acc, s_seg, s_out); LO_ACC(2); }
     };
     double x0[6];
@@ -513,6 +568,7 @@ void launch_dbg_transform_to_start(const double* params6, const float4* pts, int
 #define LO_WIDE_ROWS 1024
 int lo_configure() {
   return (hipFuncSetAttribute(reinterpret_cast<const void*>(lo_solve_t<LO_SOLVE_BLOCK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LO_SOLVE_LDS_OF(LO_SOLVE_BLOCK)) == hipSuccess &&
+          hipFuncSetAttribute(reinterpret_cast<const void*>(lo_solve_t<LO_SOLVE_BLOCK, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LO_SOLVE_LDS_OF(LO_SOLVE_BLOCK)) == hipSuccess &&
           hipFuncSetAttribute(reinterpret_cast<const void*>(lo_solve_t<LO_SOLVE_WIDE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LO_SOLVE_LDS_OF(LO_SOLVE_WIDE)) == hipSuccess) ? 0 : -1;
 }
 
@@ -708,8 +764,11 @@ void launch_lo(const DevCtx& d, hipStream_t st) {
   const int box_lds_max = std::min(d.opt_lo_box_lds, (int)LO_BOX_LDS);
   ALEGO_LAUNCH(lo_assoc<0>, dim3(d.n_launch, std::min((d.lo_qcap_surf + LO_QPB - 1) / LO_QPB, 8)), dim3(LO_BLOCK), 0, st, d, box_lds_max);
   const bool wide = d.lo_qcap_surf + d.lo_qcap_corner > LO_WIDE_ROWS;   // (fixed by the geometry: every handle of a sensor sums its rows in the same order)
+  // the rows of a solve staged in LDS: only when every possible row count fits (capacities, not counts: the variant is a property of the handle)
+  const bool staged = !wide && d.lo_qcap_surf + d.lo_qcap_corner <= LO_LDS_ROWS && d.lo_qcap_surf <= 32 * LO_SOLVE_BLOCK && d.lo_qcap_corner <= 32 * LO_SOLVE_BLOCK;
   auto solve = [&](int phase) {
     if (wide) { ALEGO_LAUNCH(lo_solve_t<LO_SOLVE_WIDE>, dim3(d.n_launch), dim3(LO_SOLVE_WIDE), LO_SOLVE_LDS_OF(LO_SOLVE_WIDE), st, d, phase); }
+    else if (staged) { ALEGO_LAUNCH((lo_solve_t<LO_SOLVE_BLOCK, true>), dim3(d.n_launch), dim3(LO_SOLVE_BLOCK), LO_SOLVE_LDS_OF(LO_SOLVE_BLOCK), st, d, phase); }
     else { ALEGO_LAUNCH(lo_solve_t<LO_SOLVE_BLOCK>, dim3(d.n_launch), dim3(LO_SOLVE_BLOCK), LO_SOLVE_LDS_OF(LO_SOLVE_BLOCK), st, d, phase); }
   };
   solve(0);
