@@ -1,0 +1,1 @@
+#include "../mock_ros_core.h"
