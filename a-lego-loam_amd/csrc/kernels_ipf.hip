@@ -107,7 +107,8 @@ __global__ void __launch_bounds__(IPF2_T) ip_fused(DevCtx d, int ring_pos, int k
   }
   if (lane == 0) { S.red[0][wave] = vmin; S.red[1][wave] = vmax; S.red[2][wave] = nvalid; }
   __syncthreads();
-  if (tid == 0) {   // orientation block (:62-72)
+  if (tid == IPF2_T - 1) {   // orientation block (:62-72): two dependent loads + two atan2f by ONE thread — the last one, whose wavefront has no columns
+                             // in phase B at 16 x 1800, so that the other fifteen do not wait for it at their next barrier
     int first = 0x7fffffff, last = -1, pv = 0;
     for (int w = 0; w < IPF2_NW; ++w) { first = min(first, S.red[0][w]); last = max(last, S.red[1][w]); pv += S.red[2][w]; }
     d.scal[slot * SC_COUNT + SC_PVALID_OUT] = pv;

@@ -71,7 +71,7 @@ DEV_INLINE WalkBest walk_reduce(WalkBest b) {
 //   ring walk (:344-373,:433-475): the reference walks up and down from the closest point inside +-2.5 rings and keeps
 //             the minimum of the double-precision distance per class, first visited on ties; here a lexicographic
 //             (distance, visiting rank) arg-min over the surviving boxes of the ring interval
-#define LO_QPB (LO_BLOCK / 16)
+#define LO_QPB_OF(B) ((B) / 16)
 #ifndef LO_NB
 #define LO_NB 2       // surviving boxes evaluated per turn (2 x LO_NB loads in flight per lane); 3: same, 4: slower
 #endif
@@ -91,15 +91,18 @@ DEV_INLINE uint32_t row_bits(unsigned long long ballot, int lane) { return (uint
 #ifdef ALEGO_TIMING
 __device__ long long la_times[12];
 extern "C" void alego_la_times(long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(la_times), sizeof(long long) * 12); }
-#define LA_TICK(k) do { if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && kind == 0) la_times[k] = wall_clock64(); } while (0)
+#define LA_TICK(k) do { if (threadIdx.x == 0 && slot == d.slot0 && qb0 == 0 && kind == 0) la_times[k] = wall_clock64(); } while (0)
 #else
 #define LA_TICK(k)
 #endif
-template <int kind>   // compile-time: the corner association has one class of second points, the surf one two
-__global__ void __launch_bounds__(LO_BLOCK) lo_assoc(DevCtx d, int box_lds_max) {
+// kind (compile-time): the corner association has one class of second points, the surf one two.  BLKA threads per workgroup, BLKA / 16
+// queries at a time; workgroup qb0 of qbn of the stream takes the query blocks qb0, qb0 + qbn, ...  (A device function: the batch path
+// launches it as lo_assoc, one stream's chain kernel lo_chain calls it between its grid barriers.)
+template <int kind, int BLKA>
+DEV_INLINE void lo_assoc_body(const DevCtx& d, int box_lds_max, int slot, int qb0, int qbn) {
   static_assert(LO_CH % 16 == 0, "a box is evaluated as LO_CH / 16 targets per lane of a 16-lane row");
   constexpr int TPL = LO_CH / 16;
-  const int slot = blockIdx.x + d.slot0, qb0 = blockIdx.y, qbn = gridDim.y;   // slot fastest: a stream's workgroups share an XCD / L2 (see lm_knn)
+  constexpr int LO_QPB = BLKA / 16;
   const size_t fc = fidx_cur(d, slot), fl = fidx_last(d, slot);
   const int* sc = d.scal + slot * SC_COUNT;
   if (!sc[SC_LO_INIT]) return;
@@ -119,8 +122,8 @@ __global__ void __launch_bounds__(LO_BLOCK) lo_assoc(DevCtx d, int box_lds_max) 
   __shared__ float4 s_box[2 * LO_BOX_LDS];   // the boxes are read by every query of the workgroup: LDS when they fit
   __shared__ int s_roff[65];
   const bool box_lds = nch <= box_lds_max;   // (<= LO_BOX_LDS; the parity tests also run with 0 = boxes straight from HBM)
-  if (box_lds) for (int i = threadIdx.x; i < 2 * nch; i += LO_BLOCK) s_box[i] = bx[i];
-  for (int i = threadIdx.x; i <= d.NS; i += LO_BLOCK) s_roff[i] = roff[i];
+  if (box_lds) for (int i = threadIdx.x; i < 2 * nch; i += BLKA) s_box[i] = bx[i];
+  for (int i = threadIdx.x; i <= d.NS; i += BLKA) s_roff[i] = roff[i];
   if (threadIdx.x == 0) {
     bool same = true;   // NaN (nothing cached yet) or a pose written by alego_set_lo_params compares unequal
 #pragma unroll
@@ -325,6 +328,11 @@ __global__ void __launch_bounds__(LO_BLOCK) lo_assoc(DevCtx d, int box_lds_max) 
   }
 }
 
+template <int kind>
+__global__ void __launch_bounds__(LO_BLOCK) lo_assoc(DevCtx d, int box_lds_max) {
+  lo_assoc_body<kind, LO_BLOCK>(d, box_lds_max, blockIdx.x + d.slot0, blockIdx.y, gridDim.y);   // slot fastest: a stream's workgroups share an XCD / L2 (see lm_knn)
+}
+
 // evaluate every valid correspondence row of [row0, row0+n) at pose p
 template <int BLK>
 DEV_INLINE void lo_eval_rows(const DevCtx& d, int slot, int kind, int n, const PoseTerms& T, double acc[28]) {
@@ -351,7 +359,7 @@ DEV_INLINE void lo_eval_rows(const DevCtx& d, int slot, int kind, int n, const P
 __device__ long long lo_times[8];
 extern "C" void alego_lo_times(long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(lo_times), sizeof(long long) * 8); }
 #define LO_T0 const long long t0_ = wall_clock64()
-#define LO_ACC(k) do { if (threadIdx.x == 0 && blockIdx.x == 0) lo_times[k] += wall_clock64() - t0_; } while (0)
+#define LO_ACC(k) do { if (threadIdx.x == 0 && slot == d.slot0) lo_times[k] += wall_clock64() - t0_; } while (0)
 #else
 #define LO_T0
 #define LO_ACC(k)
@@ -394,9 +402,8 @@ DEV_INLINE void lo_eval_staged(int n, int off, const LoRowsLds& R, unsigned okm,
   }
 }
 
-template <int BLK, bool STAGED = false>   // STAGED: the handle's row capacities fit LO_LDS_ROWS (decided at launch: fixed by the geometry / parameters)
-__global__ void __launch_bounds__(BLK) lo_solve_t(DevCtx d, int phase) {
-  const int slot = blockIdx.x + d.slot0;
+template <int BLK, bool STAGED>   // STAGED: the handle's row capacities fit LO_LDS_ROWS (decided at launch: fixed by the geometry / parameters)
+DEV_INLINE void lo_solve_body(const DevCtx& d, int phase, int slot) {
   const int cur = cur_in_flight(d, slot);
   int* sc = d.scal + slot * SC_COUNT;
   double* st = d.lo_state + (size_t)slot * LO_STATE_N;
@@ -416,7 +423,7 @@ __global__ void __launch_bounds__(BLK) lo_solve_t(DevCtx d, int phase) {
   }
 #ifdef ALEGO_TIMING
   const long long tk0_ = wall_clock64();
-  if (threadIdx.x == 0 && blockIdx.x == 0) lo_times[7] += 1;
+  if (threadIdx.x == 0 && slot == d.slot0) lo_times[7] += 1;
 #endif
   const int nq_s = d.feat_cnt[fidx_cur(d, slot) * 4 + F_FLAT];
   const int nq_c = d.feat_cnt[fidx_cur(d, slot) * 4 + F_SHARP];
@@ -529,9 +536,17 @@ __global__ void __launch_bounds__(BLK) lo_solve_t(DevCtx d, int phase) {
     }
   }
 #ifdef ALEGO_TIMING
-  if (threadIdx.x == 0 && blockIdx.x == 0) lo_times[6] += wall_clock64() - tk0_;
+  if (threadIdx.x == 0 && slot == d.slot0) lo_times[6] += wall_clock64() - tk0_;
 #endif
 }
+
+template <int BLK, bool STAGED = false>
+__global__ void __launch_bounds__(BLK) lo_solve_t(DevCtx d, int phase) { lo_solve_body<BLK, STAGED>(d, phase, blockIdx.x + d.slot0); }
+
+// (One stream, alego_stream_run: the four dependent launches of a scan's LaserOdometry were also tried as ONE launch of 48 one-wavefront
+//  workgroups separated by grid barriers on a counter in HBM — bit-identical, and no faster: 5.60 k against 5.66 k scans/s.  The scan's
+//  critical path is shared between this chain and LaserMapping's ~14 dependent launches on its own stream; removing three dispatch
+//  gaps here moves nothing while that chain is as long.  Removed again.)
 
 // ---- debug entries (alego_debug_eval_blocks / alego_debug_transform_to_start): the device functions the solvers and the
 // association kernel call, on caller-provided data, for direct parity tests against the oracle
@@ -762,16 +777,16 @@ void launch_lo_deskew(const DevCtx& d, hipStream_t st) {
 
 void launch_lo(const DevCtx& d, hipStream_t st) {
   const int box_lds_max = std::min(d.opt_lo_box_lds, (int)LO_BOX_LDS);
-  ALEGO_LAUNCH(lo_assoc<0>, dim3(d.n_launch, std::min((d.lo_qcap_surf + LO_QPB - 1) / LO_QPB, 8)), dim3(LO_BLOCK), 0, st, d, box_lds_max);
   const bool wide = d.lo_qcap_surf + d.lo_qcap_corner > LO_WIDE_ROWS;   // (fixed by the geometry: every handle of a sensor sums its rows in the same order)
   // the rows of a solve staged in LDS: only when every possible row count fits (capacities, not counts: the variant is a property of the handle)
   const bool staged = !wide && d.lo_qcap_surf + d.lo_qcap_corner <= LO_LDS_ROWS && d.lo_qcap_surf <= 32 * LO_SOLVE_BLOCK && d.lo_qcap_corner <= 32 * LO_SOLVE_BLOCK;
+  ALEGO_LAUNCH(lo_assoc<0>, dim3(d.n_launch, std::min((d.lo_qcap_surf + LO_QPB_OF(LO_BLOCK) - 1) / LO_QPB_OF(LO_BLOCK), 8)), dim3(LO_BLOCK), 0, st, d, box_lds_max);
   auto solve = [&](int phase) {
     if (wide) { ALEGO_LAUNCH(lo_solve_t<LO_SOLVE_WIDE>, dim3(d.n_launch), dim3(LO_SOLVE_WIDE), LO_SOLVE_LDS_OF(LO_SOLVE_WIDE), st, d, phase); }
     else if (staged) { ALEGO_LAUNCH((lo_solve_t<LO_SOLVE_BLOCK, true>), dim3(d.n_launch), dim3(LO_SOLVE_BLOCK), LO_SOLVE_LDS_OF(LO_SOLVE_BLOCK), st, d, phase); }
     else { ALEGO_LAUNCH(lo_solve_t<LO_SOLVE_BLOCK>, dim3(d.n_launch), dim3(LO_SOLVE_BLOCK), LO_SOLVE_LDS_OF(LO_SOLVE_BLOCK), st, d, phase); }
   };
   solve(0);
-  ALEGO_LAUNCH(lo_assoc<1>, dim3(d.n_launch, std::min((d.lo_qcap_corner + LO_QPB - 1) / LO_QPB, 12)), dim3(LO_BLOCK), 0, st, d, box_lds_max);
+  ALEGO_LAUNCH(lo_assoc<1>, dim3(d.n_launch, std::min((d.lo_qcap_corner + LO_QPB_OF(LO_BLOCK) - 1) / LO_QPB_OF(LO_BLOCK), 12)), dim3(LO_BLOCK), 0, st, d, box_lds_max);
   solve(1);
 }

@@ -27,6 +27,7 @@
 #include <climits>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <condition_variable>
@@ -678,6 +679,72 @@ struct CeresLike {
       for (int i = 0; i < R; ++i) { rhs[i] = residuals[i]; for (int k = 0; k < 6; ++k) A[(size_t)k * m + i] = jac[(size_t)i * 6 + k]; }
       for (int k = 0; k < 6; ++k) A[(size_t)k * m + R + k] = std::sqrt(diagonal[k] / radius);
       double step[6];
+      // ORACLE_SOLVER=normal (diagnostic, tests/diagnostics/solver_family.py): the same damped least-squares step through the normal
+      // equations + Cholesky (what the device's lm_propose does) instead of Householder QR of the stacked system (Ceres DENSE_QR).
+      // Mathematically the same step; the two differ by rounding only — the experiment asks how far that alone moves a free run.
+      static const int normal_eq = [] { const char* e = std::getenv("ORACLE_SOLVER"); return !e ? 0 : std::strcmp(e, "normal") == 0 ? 1 : std::strcmp(e, "normal_ld") == 0 ? 2 : std::strcmp(e, "normal_ld_lo") == 0 ? 3 : std::strcmp(e, "tsqr") == 0 ? 4 : 0; }();
+      // 2: the same in extended precision (x87 long double, 64-bit mantissa) — a proxy for "normal equations formed and factored more
+      // accurately than fp64" (double-double on the device); 3: extended only for problems of LaserOdometry's size (R < 1000)
+      const bool ext = normal_eq == 2 || (normal_eq == 3 && R < 1000);
+      if (normal_eq == 4) {
+        // 4: what a QR solve ON THE DEVICE would be — TSQR: the rows split into 64 strided blocks (one per thread), a Householder QR per block,
+        // then a binary tree of QRs of stacked 6 x 6 triangles.  Same family as DENSE_QR, another order of operations.
+        const int NB = 64;
+        std::vector<std::vector<double>> Rk(NB, std::vector<double>(36, 0.0)), qk(NB, std::vector<double>(6, 0.0));
+        for (int t = 0; t < NB; ++t) {
+          std::vector<int> rows;
+          for (int i = t; i < m; i += NB) rows.push_back(i);
+          const int mb = std::max((int)rows.size(), 6);
+          std::vector<double> Ab((size_t)mb * 6, 0.0), bb(mb, 0.0);
+          for (size_t r = 0; r < rows.size(); ++r) { bb[r] = rhs[rows[r]]; for (int k = 0; k < 6; ++k) Ab[(size_t)k * mb + r] = A[(size_t)k * m + rows[r]]; }
+          double dummy[6];
+          qr_solve(Ab, bb, mb, 6, dummy);   // leaves R in the upper triangle of Ab and Q^T b in bb
+          for (int r = 0; r < 6; ++r) { qk[t][r] = bb[r]; for (int k = r; k < 6; ++k) Rk[t][r * 6 + k] = Ab[(size_t)k * mb + r]; }
+        }
+        for (int stride = 1; stride < NB; stride *= 2)
+          for (int t = 0; t + stride < NB; t += 2 * stride) {
+            std::vector<double> Ab(12 * 6, 0.0), bb(12, 0.0);
+            for (int r = 0; r < 6; ++r) { bb[r] = qk[t][r]; bb[6 + r] = qk[t + stride][r]; for (int k = 0; k < 6; ++k) { Ab[(size_t)k * 12 + r] = Rk[t][r * 6 + k]; Ab[(size_t)k * 12 + 6 + r] = Rk[t + stride][r * 6 + k]; } }
+            double dummy[6];
+            qr_solve(Ab, bb, 12, 6, dummy);
+            for (int r = 0; r < 6; ++r) { qk[t][r] = bb[r]; for (int k = 0; k < 6; ++k) Rk[t][r * 6 + k] = k >= r ? Ab[(size_t)k * 12 + r] : 0.0; }
+          }
+        for (int k = 5; k >= 0; --k) { double sacc = qk[0][k]; for (int j = k + 1; j < 6; ++j) sacc -= Rk[0][k * 6 + j] * step[j]; step[k] = sacc / Rk[0][k * 6 + k]; }
+      } else if (normal_eq && ext) {
+        long double H[6][6] = {{0}}, g[6] = {0};
+        for (int i = 0; i < R; ++i)
+          for (int a = 0; a < 6; ++a) { g[a] += (long double)jac[(size_t)i * 6 + a] * residuals[i]; for (int b2_ = 0; b2_ <= a; ++b2_) H[a][b2_] += (long double)jac[(size_t)i * 6 + a] * jac[(size_t)i * 6 + b2_]; }
+        for (int a = 0; a < 6; ++a) { for (int b2_ = a + 1; b2_ < 6; ++b2_) H[a][b2_] = H[b2_][a]; H[a][a] += (long double)diagonal[a] / radius; }
+        long double L[6][6] = {{0}}, y[6];
+        bool ok = true;
+        for (int j = 0; j < 6; ++j) {
+          long double sj = H[j][j];
+          for (int k = 0; k < j; ++k) sj -= L[j][k] * L[j][k];
+          if (!(sj > 0)) { ok = false; sj = 1; }
+          L[j][j] = sqrtl(sj);
+          for (int i = j + 1; i < 6; ++i) { long double t = H[i][j]; for (int k = 0; k < j; ++k) t -= L[i][k] * L[j][k]; L[i][j] = t / L[j][j]; }
+        }
+        for (int i = 0; i < 6; ++i) { long double t = g[i]; for (int k = 0; k < i; ++k) t -= L[i][k] * y[k]; y[i] = t / L[i][i]; }
+        for (int i = 5; i >= 0; --i) { long double t = y[i]; for (int k = i + 1; k < 6; ++k) t -= L[k][i] * y[k]; y[i] = t / L[i][i]; }
+        for (int k = 0; k < 6; ++k) step[k] = ok ? (double)y[k] : NAN;
+      } else if (normal_eq) {
+        double H[6][6] = {{0}}, g[6] = {0};
+        for (int i = 0; i < R; ++i)
+          for (int a = 0; a < 6; ++a) { g[a] += jac[(size_t)i * 6 + a] * residuals[i]; for (int b2_ = 0; b2_ <= a; ++b2_) H[a][b2_] += jac[(size_t)i * 6 + a] * jac[(size_t)i * 6 + b2_]; }
+        for (int a = 0; a < 6; ++a) { for (int b2_ = a + 1; b2_ < 6; ++b2_) H[a][b2_] = H[b2_][a]; H[a][a] += diagonal[a] / radius; }
+        double L[6][6] = {{0}}, y[6];
+        bool ok = true;
+        for (int j = 0; j < 6; ++j) {
+          double sj = H[j][j];
+          for (int k = 0; k < j; ++k) sj -= L[j][k] * L[j][k];
+          if (!(sj > 0)) { ok = false; sj = 1; }
+          L[j][j] = std::sqrt(sj);
+          for (int i = j + 1; i < 6; ++i) { double t = H[i][j]; for (int k = 0; k < j; ++k) t -= L[i][k] * L[j][k]; L[i][j] = t / L[j][j]; }
+        }
+        for (int i = 0; i < 6; ++i) { double t = g[i]; for (int k = 0; k < i; ++k) t -= L[i][k] * y[k]; y[i] = t / L[i][i]; }
+        for (int i = 5; i >= 0; --i) { double t = y[i]; for (int k = i + 1; k < 6; ++k) t -= L[k][i] * y[k]; y[i] = t / L[i][i]; }
+        for (int k = 0; k < 6; ++k) step[k] = ok ? y[k] : NAN;
+      } else
       qr_solve(A, rhs, m, 6, step);
       reuse_diagonal = true;
       bool finite = true;
