@@ -34,7 +34,7 @@ def worker(mode, stream, scans, device):
 
 def run(mode, stream, scans):
     env = dict(os.environ)
-    if mode.startswith("normal"):
+    if mode not in ("qr", "device"):
         env["ORACLE_SOLVER"] = mode
     else:
         env.pop("ORACLE_SOLVER", None)

@@ -9,14 +9,14 @@
 #                                  priming scans: around scan 560 every stream fills its 50-key-frame window and rebuilds its map at once
 set -u
 R=${1:-r03}
-MODE=${2:-all}    # all | traffic (only the two --pmc passes; needs gpurun_out/${R}_bench.json from an earlier run or a previous call)
+MODE=${2:-all}    # all | traffic (only the two --pmc traffic passes) | pmc (traffic + SQ counters); the last two need gpurun_out/${R}_bench.json from an earlier call
 cd /tmp && export TMPDIR=/tmp
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out
 rm -rf /tmp/prof_stats /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE
 if [ "$MODE" = "all" ]; then
 timeout 900 python bench.py < /dev/null > gpurun_out/${R}_bench.json 2> gpurun_out/${R}_bench.err
-timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/prof_stats -o st --output-format csv -- python bench.py --no-cpu < /dev/null > gpurun_out/${R}_bench_under_rocprof.json 2> /tmp/st.log
+timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/prof_stats -o st --output-format csv -- python bench.py --no-cpu --no-check --no-isolated < /dev/null > gpurun_out/${R}_bench_under_rocprof.json 2> /tmp/st.log
 find /tmp/prof_stats -name "*kernel_stats.csv" -exec cp {} gpurun_out/${R}_bench_kernel_stats.csv \;
 python tools/trace_tail_stats.py /tmp/prof_stats gpurun_out/${R}_bench_under_rocprof.json > gpurun_out/${R}_bench_kernel_stats_steady.csv
 fi
@@ -28,12 +28,12 @@ print(d["roofline"]["streams_per_launch"])
 PY
 )
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 900 rocprofv3 --pmc $c --kernel-trace -d /tmp/pmc_$c -o p --output-format csv -- python bench.py --steps 8 --warmup 0 --prime 700 --no-cpu --no-profile < /dev/null > /tmp/pmc_$c.log 2>&1
+  timeout 900 rocprofv3 --pmc $c --kernel-trace -d /tmp/pmc_$c -o p --output-format csv -- python bench.py --steps 8 --warmup 0 --prime 700 --no-cpu --no-profile --no-check --no-isolated < /dev/null > /tmp/pmc_$c.log 2>&1
 done
 python tools/pmc_traffic.py /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE "$PER" 16 > gpurun_out/${R}_pmc_traffic.json
-[ "$MODE" = "all" ] || { ls -la gpurun_out/${R}_*; exit 0; }
+[ "$MODE" = "traffic" ] && { ls -la gpurun_out/${R}_*; exit 0; }
 # SQ counters (occupancy / issue statistics quoted in DESIGN.md section 4): one stream group, 512 streams
 rm -rf /tmp/pmc_sq
-ALEGO_STREAM_GROUPS=1 timeout 1500 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU GRBM_GUI_ACTIVE --kernel-trace -d /tmp/pmc_sq -o sq --output-format csv -- python bench.py --streams 512 --steps 6 --warmup 0 --prime 700 --no-cpu --no-profile < /dev/null > /tmp/pmc_sq.log 2>&1
+ALEGO_STREAM_GROUPS=1 timeout 1500 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD GRBM_GUI_ACTIVE --kernel-trace -d /tmp/pmc_sq -o sq --output-format csv -- python bench.py --streams 512 --steps 6 --warmup 0 --prime 700 --no-cpu --no-profile --no-check --no-isolated < /dev/null > /tmp/pmc_sq.log 2>&1
 python tools/pmc_agg.py /tmp/pmc_sq 12 > gpurun_out/${R}_pmc_sq.json
 ls -la gpurun_out/${R}_*
