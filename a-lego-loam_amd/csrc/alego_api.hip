@@ -26,8 +26,8 @@ thread_local Profiler* g_prof = nullptr;
 // first HIP call (bench.py / tests/conftest.py also export it); never overrides the user's setting.
 namespace { struct HwQueueEnv { HwQueueEnv() { setenv("GPU_MAX_HW_QUEUES", "8", 0); } } g_hw_queue_env; }
 
-bool launch_ip(const DevCtx& d, int ring_pos, bool want_labels, hipStream_t st);
-void launch_fe(const DevCtx& d, hipStream_t st, bool curv_done);
+void launch_ip(const DevCtx& d, int ring_pos, bool want_labels, hipStream_t st);
+void launch_fe(const DevCtx& d, hipStream_t st);
 void launch_lo(const DevCtx& d, hipStream_t st);
 void launch_atan2f_probe(const float* y, const float* x, float* out, int n, int mode, hipStream_t st);
 int launch_stdsort_probe(const uint32_t* keys, int n, int depth_limit, int* pos_out, hipStream_t st);
@@ -447,8 +447,8 @@ int alego_stream_run(alego_handle* h, int first_step, int n_scans, int stages, i
     DevCtx dl = view(h, lane0, w);
     dl.replay_bag = 1;
     const int pos = (int)(((long long)first_step + base) % h->d.bag_len);
-    const bool curv_done = (stages & 1) && launch_ip(dl, pos, false, sA);
-    if (do_lo) launch_fe(dl, sA, curv_done);
+    if (stages & 1) launch_ip(dl, pos, false, sA);
+    if (do_lo) launch_fe(dl, sA);
     hipEvent_t fe_done = ev();
     HIP_TRY(h, hipEventRecord(fe_done, sA));
     if (!do_lo) { h->pose_slot = lane0 + w - 1; continue; }
@@ -487,11 +487,10 @@ static int enqueue_scan(alego_handle* h, int slot0, int n, int pos, int stages, 
   g_prof = &h->prof;
   static const bool dbg = getenv("ALEGO_DEBUG_SYNC") != nullptr;
   auto chk = [&](const char* what) { if (dbg) { hipError_t e = hipStreamSynchronize(S); fprintf(stderr, "[alego dbg] %s: %s\n", what, hipGetErrorString(e)); } };
-  bool curv_done = false;
-  if (stages & 1) { curv_done = launch_ip(d, pos, want_labels, S); chk("ip"); }
+  if (stages & 1) { launch_ip(d, pos, want_labels, S); chk("ip"); }
   if (stages & 2) {
     if (d.P.deskew_mode) { launch_lo_deskew(d, S); chk("deskew"); }   // adjustDistortion(segmented_cloud, t1), laserOdometry.cpp:115
-    launch_fe(d, S, curv_done); chk("fe");
+    launch_fe(d, S); chk("fe");
     launch_lo(d, S); chk("lo");
     std::vector<char> odom_valid(n);
     for (int i = 0; i < n; ++i) odom_valid[i] = h->lo_scans[slot0 + i]++ > 0;

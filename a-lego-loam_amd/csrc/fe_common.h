@@ -1,5 +1,4 @@
-// fe_common.h — curvature + occlusion marks of a chunk of the segmented cloud (src/laserOdometry.cpp:122-159), shared by the
-// stand-alone fe_curv kernel and by ip_fused, which runs it on its own output while that is still in the L2.
+// fe_common.h — curvature + occlusion marks of a chunk of the segmented cloud (src/laserOdometry.cpp:122-159): the body of fe_curv.
 #ifndef ALEGO_FE_COMMON_H_
 #define ALEGO_FE_COMMON_H_
 #include "dev_common.h"

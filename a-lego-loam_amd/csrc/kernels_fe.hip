@@ -1,8 +1,7 @@
 // kernels_fe.hip — feature extraction on gfx950 (replaces src/laserOdometry.cpp:122-293).
 //
 //   fe_curv    a7,a8: 11-tap f32 curvature sum through an LDS window + occlusion / parallel-beam
-//              marking written as a gather (no atomics) (:122-159); the body (fe_common.h) is also the last phase of ip_fused,
-//              in which case this launch is skipped
+//              marking written as a gather (no atomics) (:122-159), and the flag byte of every point for the pick
 //   fe_pick4   a9: four rings per wavefront (one 16-lane DPP row each); the reference's "sort, then scan
 //              descending/ascending" is evaluated as repeated row-wide arg-max / arg-min over the
 //              not-yet-picked candidates of the sector (identical result for the total order
@@ -755,11 +754,11 @@ int launch_stdsort_probe(const uint32_t* keys, int n, int depth_limit, int* pos_
   return 0;
 }
 
-void launch_fe(const DevCtx& d, hipStream_t st, bool curv_done) {
+void launch_fe(const DevCtx& d, hipStream_t st) {
   // dynamic LDS above 64 KB has to be requested explicitly (fe_voxel: 26 B per column, horizon_scan <= 4096)
   static const bool cfg = hipFuncSetAttribute(reinterpret_cast<const void*>(fe_voxel), hipFuncAttributeMaxDynamicSharedMemorySize, FV_LDS_PER_COL * FE_MAXH) == hipSuccess;
   (void)cfg;
-  if (!curv_done) ALEGO_LAUNCH(fe_curv, dim3((d.N + FE_CW - 1) / FE_CW, d.n_launch), dim3(FE_BLOCK), 0, st, d);   // (ip_fused leaves cd / fe_flag behind)
+  ALEGO_LAUNCH(fe_curv, dim3((d.N + FE_CW - 1) / FE_CW, d.n_launch), dim3(FE_BLOCK), 0, st, d);
   // the longest sector holds at most ceil(H / n_sectors) + 1 points
   const int sector_max = (d.H + d.P.n_sectors - 1) / (d.P.n_sectors > 0 ? d.P.n_sectors : 1) + 2;
   // (padding this allocation by 16 KB cost 7 % of the whole pipeline: the LDS footprint decides how many rings share a CU)

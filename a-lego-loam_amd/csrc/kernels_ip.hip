@@ -943,14 +943,12 @@ __global__ void atan2f_probe(const float* y, const float* x, float* out, int n, 
 bool ipf_eligible(const DevCtx& d);
 void launch_ip_fused(const DevCtx& d, int ring_pos, bool keep_images, hipStream_t st);
 int ipf_configure(const DevCtx& d);
-bool ipf_does_curvature();
 
-// returns true when the launch also left the curvature sums / feature flags of the segmented cloud (ip_fused's last phase): launch_fe then skips fe_curv
-bool launch_ip(const DevCtx& d, int ring_pos, bool want_labels, hipStream_t st) {
+void launch_ip(const DevCtx& d, int ring_pos, bool want_labels, hipStream_t st) {
   if (d.opt_ip_fused && ipf_eligible(d)) {   // one workgroup per stream, everything between the input points and cloud_info on chip (kernels_ipf.hip)
     launch_ip_fused(d, ring_pos, want_labels || d.n_launch == 1, st);
     if (want_labels) hipLaunchKernelGGL(ip_labels, dim3((d.N + IP_BLOCK - 1) / IP_BLOCK, d.n_launch), dim3(IP_BLOCK), 0, st, d);
-    return ipf_does_curvature();
+    return;
   }
   const bool lds16 = d.NS <= 16 && d.N <= CC_LDS16_MAXN;
   const bool fused = d.opt_cc_fused && lds16;   // cc_lds16 also does the compaction
@@ -982,7 +980,6 @@ bool launch_ip(const DevCtx& d, int ring_pos, bool want_labels, hipStream_t st) 
     ALEGO_LAUNCH(ip_compact, dim3(d.NS, d.n_launch), dim3(IP_BLOCK), 0, st, d, ring_pos);
   }
   if (want_labels) hipLaunchKernelGGL(ip_labels, gN, dim3(IP_BLOCK), 0, st, d);
-  return false;
 }
 
 void launch_atan2f_probe(const float* y, const float* x, float* out, int n, int mode, hipStream_t st) {

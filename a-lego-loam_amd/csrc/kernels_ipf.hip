@@ -12,8 +12,6 @@
 //   phase C  a5     vertical runs from the masks (no memory traffic), 16-bit lock-free union-find in LDS over the right-edges that
 //                   connect different run pairs, flatten, component size and row mask accumulated PER RUN in the roots' own
 //                   entries (2 B / cell of LDS for the parents: owner 2 N + parents 2 N + masks 8 H = 130 KB)      (:210-316)
-//   phase E  a7-a8  curvature sums and occlusion marks of the segmented cloud (fe_common.h) while it is still in the L2: replaces the
-//                   fe_curv launch (laserOdometry.cpp:122-159)
 //   phase D  a6     ordered compaction: per row and wavefront ballots -> one 256-entry scan -> every kept cell's output line;
 //                   second (and last) gather of the kept cells' points, cloud_info arrays written once              (:158-191)
 //
@@ -23,17 +21,13 @@
 #include <algorithm>
 #include <cstdlib>
 #include "dev_common.h"
-#include "fe_common.h"
 #include "ip_common.h"
 #include "prof.h"
 
 #define IPF2_T 1024
-#ifndef IPF_CURV
-// 1: curvature + occlusion marks as a last phase of ip_fused.  Measured: it re-reads cloud_info through the L2 in a workgroup that
-// owns its CU alone (16 wavefronts, nothing to hide the round trips behind): 29 us per stream against 24 us of CU time for the
-// stand-alone fe_curv launch, which runs at full occupancy.  Off.
-#define IPF_CURV 0
-#endif
+// (Curvature + occlusion marks as a last phase of this kernel was measured and removed: the phase re-reads cloud_info through the L2 in a
+//  workgroup that owns its CU alone — 16 wavefronts, nothing to hide the round trips behind — 29 us per stream against 24 us of CU time
+//  for the stand-alone fe_curv launch, which runs at full occupancy.  A fat workgroup must not wait on global memory.)
 #define IPF2_NW (IPF2_T / 64)
 #define IPF2_ROWS 16
 
@@ -58,10 +52,11 @@ DEV_INLINE int ipf_run_start(unsigned rs, int row) { return 31 - __clz((int)(rs 
 DEV_INLINE int ipf_run_end(unsigned down, int s) { return s + __ffs((int)~(down >> s)) - 1; }                    // s + number of consecutive down-edges from s
 
 bool ipf_eligible(const DevCtx& d) { return d.NS <= IPF2_ROWS && (d.H & 1) == 0 && d.H >= 64 && d.H <= 2 * IPF2_T && d.N <= 32768; }
-#define IPF2_CW_BIG 8192    // points per curvature chunk when the image's LDS allows it (9 B per point), else IPF2_T
-size_t ipf_lds_bytes(const DevCtx& d) { return std::max((size_t)4 * d.N + (size_t)8 * d.H, (size_t)9 * (IPF2_T + 2 * FE_HALO) + 64); }
+size_t ipf_lds_bytes(const DevCtx& d) { return (size_t)4 * d.N + (size_t)8 * d.H; }
 
 // keep bit 0: the single-scan entry points / tests read the range, flag, root and label images back
+// (128 VGPRs x 1024 threads = the CU's whole register file.  Capping the kernel at 96 / 80 VGPRs (amdgpu_waves_per_eu 5 / 6) so that other
+//  streams' wavefronts could share the CU was measured: 348.5 k / 334.9 k against 349.9 k scans/s — the spills cost what the sharing gains.)
 __global__ void __launch_bounds__(IPF2_T) ip_fused(DevCtx d, int ring_pos, int keep) {
   const int slot = blockIdx.x + d.slot0;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -426,29 +421,8 @@ __global__ void __launch_bounds__(IPF2_T) ip_fused(DevCtx d, int ring_pos, int k
     }
   }
 
-#if IPF_CURV
-  // ---------------- phase E: curvature + occlusion marks of the segmented cloud (laserOdometry.cpp:122-159) ----------------
-  // cloud_info has just been written by this workgroup and is re-read through the L2 in chunks; the image's LDS is free again.
-  IPF_TICK(11);
-  __syncthreads();
-  {
-    const int M = S.tot[0];
-    float* s_r = reinterpret_cast<float*>(ipf_smem);
-    if ((size_t)4 * N + (size_t)8 * H >= (size_t)9 * (IPF2_CW_BIG + 2 * FE_HALO) + 64) {
-      int* s_c = reinterpret_cast<int*>(s_r + IPF2_CW_BIG + 2 * FE_HALO);
-      uint8_t* s_f = reinterpret_cast<uint8_t*>(s_c + IPF2_CW_BIG + 2 * FE_HALO);
-      for (int t0 = 0; t0 < M; t0 += IPF2_CW_BIG) { fe_curv_chunk<IPF2_T, IPF2_CW_BIG>(d, slot, M, t0, s_r, s_c, s_f); __syncthreads(); }
-    } else {
-      int* s_c = reinterpret_cast<int*>(s_r + IPF2_T + 2 * FE_HALO);
-      uint8_t* s_f = reinterpret_cast<uint8_t*>(s_c + IPF2_T + 2 * FE_HALO);
-      for (int t0 = 0; t0 < M; t0 += IPF2_T) { fe_curv_chunk<IPF2_T, IPF2_T>(d, slot, M, t0, s_r, s_c, s_f); __syncthreads(); }
-    }
-  }
-  IPF_TICK(12);
-#endif
 }
 
-bool ipf_does_curvature() { return IPF_CURV != 0; }
 void launch_ip_fused(const DevCtx& d, int ring_pos, bool keep_images, hipStream_t st) {
   ALEGO_LAUNCH(ip_fused, dim3(d.n_launch), dim3(IPF2_T), ipf_lds_bytes(d), st, d, ring_pos, keep_images ? 1 : 0);
 }
