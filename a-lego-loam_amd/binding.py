@@ -98,7 +98,7 @@ def lib():
                                "there is no CPU fallback")
         # a handle drives two HIP streams per stream group (+ three for alego_stream_run): with the runtime's default of 4 hardware queues
         # pairs of them share a queue and serialise (measured: one stream 5.7 k -> 3.0 k scans/s).  Read by the HIP runtime when it initialises.
-        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
         L = C.CDLL(path)
         L.alego_create.restype = C.c_int
         L.alego_create.argtypes = [C.POINTER(AlegoParams), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]

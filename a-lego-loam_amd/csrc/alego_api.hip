@@ -24,7 +24,7 @@ thread_local Profiler* g_prof = nullptr;
 // A handle of several stream groups drives two HIP streams per group (front end + LaserMapping); the runtime's default of 4 hardware
 // queues would make pairs of them share a queue and serialise.  Only effective when this library is loaded before the process's
 // first HIP call (bench.py / tests/conftest.py also export it); never overrides the user's setting.
-namespace { struct HwQueueEnv { HwQueueEnv() { setenv("GPU_MAX_HW_QUEUES", "8", 0); } } g_hw_queue_env; }
+namespace { struct HwQueueEnv { HwQueueEnv() { setenv("GPU_MAX_HW_QUEUES", "16", 0); } } g_hw_queue_env; }
 
 void launch_ip(const DevCtx& d, int ring_pos, bool want_labels, hipStream_t st);
 void launch_fe(const DevCtx& d, hipStream_t st);

@@ -472,6 +472,9 @@ extern "C" void alego_fv_times(long long* out) { (void)hipMemcpyFromSymbol(out, 
 #define FV_TICK(k)
 #endif
 #define FV_NB 512
+#ifndef FV_BLOCK
+#define FV_BLOCK 256   // threads per ring
+#endif
 #ifndef FV_STAGE
 #define FV_STAGE 1     // 1: the ring's candidate points are gathered once into LDS (26 B per column); 0: every pass gathers them from HBM / L2 (10 B per column)
 #endif
@@ -479,7 +482,7 @@ extern "C" void alego_fv_times(long long* out) { (void)hipMemcpyFromSymbol(out, 
 //  pipeline as a whole is VALU-issue bound; 90 k compares per ring cost more than the bucket tables' latency.)
 #define FV_LDS_PER_COL (FV_STAGE ? 26 : 10)
 #define FV_U 4    // gathers kept in flight per thread
-__global__ void __launch_bounds__(FE_BLOCK) fe_voxel(DevCtx d) {
+__global__ void __launch_bounds__(FV_BLOCK) fe_voxel(DevCtx d) {
   const int slot = blockIdx.y + d.slot0, ring = blockIdx.x, tid = threadIdx.x;
   const size_t base = (size_t)slot * d.N;
   int* cnts = d.st_cnt + ((size_t)slot * d.NS + ring) * 8;
@@ -496,8 +499,8 @@ __global__ void __launch_bounds__(FE_BLOCK) fe_voxel(DevCtx d) {
   uint16_t* s_rstart = reinterpret_cast<uint16_t*>(fv2 + 4 * (size_t)d.H);      // first point of the run  [H]
   uint16_t* s_order = reinterpret_cast<uint16_t*>(fv2 + 6 * (size_t)d.H);       // runs sorted by (voxel id, run) [H]
   uint16_t* s_tmp = reinterpret_cast<uint16_t*>(fv2 + 8 * (size_t)d.H);         // runs dealt into buckets [H]
-  __shared__ float s_red[6][FE_BLOCK / 64];
-  __shared__ int s_scan[FE_BLOCK / 64];
+  __shared__ float s_red[6][FV_BLOCK / 64];
+  __shared__ int s_scan[FV_BLOCK / 64];
   __shared__ int s_boff[FV_NB + 1], s_bcur[FV_NB + 1];
   if (n == 0) { if (tid == 0) cnts[4] = 0; return; }
   const float inv = 1.0f / d.P.less_flat_leaf;
@@ -505,16 +508,16 @@ __global__ void __launch_bounds__(FE_BLOCK) fe_voxel(DevCtx d) {
   // getMinMax3D
   float mn[3] = {3.402823466e+38f, 3.402823466e+38f, 3.402823466e+38f}, mx[3] = {-3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f};
   // gathers through the index list: FV_U index loads, then FV_U point loads in flight together
-  for (int i0 = tid; i0 < n; i0 += FE_BLOCK * FV_U) {
+  for (int i0 = tid; i0 < n; i0 += FV_BLOCK * FV_U) {
     int ix[FV_U];
     float4 pt[FV_U];
 #pragma unroll
-    for (int u = 0; u < FV_U; ++u) ix[u] = lfs[min(i0 + u * FE_BLOCK, n - 1)];
+    for (int u = 0; u < FV_U; ++u) ix[u] = lfs[min(i0 + u * FV_BLOCK, n - 1)];
 #pragma unroll
     for (int u = 0; u < FV_U; ++u) pt[u] = seg[ix[u]];
 #pragma unroll
     for (int u = 0; u < FV_U; ++u) {   // (a clamped duplicate of the last point does not change min / max)
-      if (FV_STAGE && i0 + u * FE_BLOCK < n) s_pt[i0 + u * FE_BLOCK] = pt[u];   // every later pass reads the point from LDS: one global round trip instead of three
+      if (FV_STAGE && i0 + u * FV_BLOCK < n) s_pt[i0 + u * FV_BLOCK] = pt[u];   // every later pass reads the point from LDS: one global round trip instead of three
       mn[0] = fminf(mn[0], pt[u].x); mn[1] = fminf(mn[1], pt[u].y); mn[2] = fminf(mn[2], pt[u].z);
       mx[0] = fmaxf(mx[0], pt[u].x); mx[1] = fmaxf(mx[1], pt[u].y); mx[2] = fmaxf(mx[2], pt[u].z);
     }
@@ -530,11 +533,11 @@ __global__ void __launch_bounds__(FE_BLOCK) fe_voxel(DevCtx d) {
   for (int a = 0; a < 3; ++a) {
     mn[a] = s_red[a][0]; mx[a] = s_red[3 + a][0];
 #pragma unroll
-    for (int w = 1; w < FE_BLOCK / 64; ++w) { mn[a] = fminf(mn[a], s_red[a][w]); mx[a] = fmaxf(mx[a], s_red[3 + a][w]); }
+    for (int w = 1; w < FV_BLOCK / 64; ++w) { mn[a] = fminf(mn[a], s_red[a][w]); mx[a] = fmaxf(mx[a], s_red[3 + a][w]); }
   }
   const long long dx = (long long)((mx[0] - mn[0]) * inv) + 1, dy = (long long)((mx[1] - mn[1]) * inv) + 1, dz = (long long)((mx[2] - mn[2]) * inv) + 1;
   if (dx * dy * dz > 2147483647LL) {  // "leaf size too small": the input is returned unchanged
-    for (int i = tid; i < n; i += FE_BLOCK) out[i] = point(i);
+    for (int i = tid; i < n; i += FV_BLOCK) out[i] = point(i);
     if (tid == 0) cnts[4] = n;
     return;
   }
@@ -547,7 +550,7 @@ __global__ void __launch_bounds__(FE_BLOCK) fe_voxel(DevCtx d) {
   }
   const int mul1 = divb[0], mul2 = divb[0] * divb[1];
 #pragma unroll 4
-  for (int i = tid; i < n; i += FE_BLOCK) {
+  for (int i = tid; i < n; i += FV_BLOCK) {
     const float4 q = point(i);
     const int i0 = (int)(floorf(q.x * inv) - (float)minb[0]);
     const int i1 = (int)(floorf(q.y * inv) - (float)minb[1]);
@@ -558,7 +561,7 @@ __global__ void __launch_bounds__(FE_BLOCK) fe_voxel(DevCtx d) {
   FV_TICK(2);
   // runs of consecutive equal voxel ids
   int nruns = 0;
-  for (int c0 = 0; c0 < n; c0 += FE_BLOCK) {
+  for (int c0 = 0; c0 < n; c0 += FV_BLOCK) {
     const int i = c0 + tid;
     const uint32_t mykey = i < n ? s_key[i] : 0u;   // read before the barrier: the run ids are compacted into the same array
     const bool head = i < n && (i == 0 || mykey != s_key[i - 1]);
@@ -567,7 +570,7 @@ __global__ void __launch_bounds__(FE_BLOCK) fe_voxel(DevCtx d) {
     __syncthreads();
     int woff = 0, tot = 0;
 #pragma unroll
-    for (int w = 0; w < FE_BLOCK / 64; ++w) { if (w < (tid >> 6)) woff += s_scan[w]; tot += s_scan[w]; }
+    for (int w = 0; w < FV_BLOCK / 64; ++w) { if (w < (tid >> 6)) woff += s_scan[w]; tot += s_scan[w]; }
     if (head) {
       const int r = nruns + woff + (int)__popcll(m & ((1ull << (tid & 63)) - 1ull));
       s_rvid[r] = mykey;
@@ -586,13 +589,13 @@ __global__ void __launch_bounds__(FE_BLOCK) fe_voxel(DevCtx d) {
     int shift = 0;
     while (((T - 1) >> shift) >= (unsigned)FV_NB) ++shift;
     const int nb = (int)((T - 1) >> shift) + 1;
-    for (int b = tid; b <= nb; b += FE_BLOCK) s_boff[b] = 0;
+    for (int b = tid; b <= nb; b += FV_BLOCK) s_boff[b] = 0;
     __syncthreads();
-    for (int r = tid; r < nruns; r += FE_BLOCK) atomicAdd(&s_boff[min((int)(s_rvid[r] >> shift), nb - 1) + 1], 1);
+    for (int r = tid; r < nruns; r += FV_BLOCK) atomicAdd(&s_boff[min((int)(s_rvid[r] >> shift), nb - 1) + 1], 1);
     __syncthreads();
-    // inclusive scan of s_boff[1..nb] (FV_NB / FE_BLOCK consecutive entries per thread) -> bucket b = [s_boff[b], s_boff[b+1])
+    // inclusive scan of s_boff[1..nb] (FV_NB / FV_BLOCK consecutive entries per thread) -> bucket b = [s_boff[b], s_boff[b+1])
     {
-      constexpr int PER = FV_NB / FE_BLOCK;
+      constexpr int PER = FV_NB / FV_BLOCK;
       int v[PER], sum = 0;
 #pragma unroll
       for (int k = 0; k < PER; ++k) { const int b = tid * PER + k; v[k] = b < nb ? s_boff[b + 1] : 0; sum += v[k]; }
@@ -603,18 +606,18 @@ __global__ void __launch_bounds__(FE_BLOCK) fe_voxel(DevCtx d) {
       __syncthreads();
       int run = incl - sum;
 #pragma unroll
-      for (int w = 0; w < FE_BLOCK / 64; ++w) if (w < (tid >> 6)) run += s_scan[w];
+      for (int w = 0; w < FV_BLOCK / 64; ++w) if (w < (tid >> 6)) run += s_scan[w];
 #pragma unroll
       for (int k = 0; k < PER; ++k) { const int b = tid * PER + k; run += v[k]; if (b < nb) { s_boff[b + 1] = run; s_bcur[b + 1] = run; } }
       if (tid == 0) s_bcur[0] = 0;
     }
     __syncthreads();
-    for (int r = tid; r < nruns; r += FE_BLOCK) {
+    for (int r = tid; r < nruns; r += FV_BLOCK) {
       const int b = min((int)(s_rvid[r] >> shift), nb - 1);
       s_tmp[atomicAdd(&s_bcur[b], 1)] = (uint16_t)r;  // s_bcur[b] starts at s_boff[b] (written one slot up, read one down)
     }
     __syncthreads();
-    for (int t = tid; t < nruns; t += FE_BLOCK) {
+    for (int t = tid; t < nruns; t += FV_BLOCK) {
       const int r = s_tmp[t];
       const uint32_t v = s_rvid[r];
       const int b = min((int)(v >> shift), nb - 1);
@@ -628,7 +631,7 @@ __global__ void __launch_bounds__(FE_BLOCK) fe_voxel(DevCtx d) {
   FV_TICK(4);
   // first run of every voxel -> output rank; it accumulates all runs of the voxel in order
   int nvox = 0;
-  for (int c0 = 0; c0 < nruns; c0 += FE_BLOCK) {
+  for (int c0 = 0; c0 < nruns; c0 += FV_BLOCK) {
     const int j = c0 + tid;
     const bool head = j < nruns && (j == 0 || s_rvid[s_order[j]] != s_rvid[s_order[j - 1]]);
     const unsigned long long m = __ballot(head);
@@ -636,7 +639,7 @@ __global__ void __launch_bounds__(FE_BLOCK) fe_voxel(DevCtx d) {
     __syncthreads();
     int woff = 0, tot = 0;
 #pragma unroll
-    for (int w = 0; w < FE_BLOCK / 64; ++w) { if (w < (tid >> 6)) woff += s_scan[w]; tot += s_scan[w]; }
+    for (int w = 0; w < FV_BLOCK / 64; ++w) { if (w < (tid >> 6)) woff += s_scan[w]; tot += s_scan[w]; }
     if (head) {
       const int rank = nvox + woff + (int)__popcll(m & ((1ull << (tid & 63)) - 1ull));
       const uint32_t vid = s_rvid[s_order[j]];
@@ -777,6 +780,6 @@ void launch_fe(const DevCtx& d, hipStream_t st) {
   else if (d.P.sort_mode == 2) { ALEGO_LAUNCH((fe_pick<12, true>), dim3(d.NS, d.n_launch), dim3(64), (size_t)3 * d.H, st, d); }
   else if (sector_max <= 64 * 6) { ALEGO_LAUNCH((fe_pick<6, false>), dim3(d.NS, d.n_launch), dim3(64), (size_t)3 * d.H + extra, st, d); }
   else { ALEGO_LAUNCH((fe_pick<12, false>), dim3(d.NS, d.n_launch), dim3(64), (size_t)3 * d.H, st, d); }
-  ALEGO_LAUNCH(fe_voxel, dim3(d.NS, d.n_launch), dim3(FE_BLOCK), (size_t)FV_LDS_PER_COL * d.H, st, d);
+  ALEGO_LAUNCH(fe_voxel, dim3(d.NS, d.n_launch), dim3(FV_BLOCK), (size_t)FV_LDS_PER_COL * d.H, st, d);
   ALEGO_LAUNCH(fe_collect, dim3(d.n_launch), dim3(FC_T), 0, st, d);
 }

@@ -28,7 +28,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 # two HIP streams per stream group (front end + LaserMapping) + RCCL's own: the runtime's default of 4 hardware queues would alias them
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 from alego_loader import load_package  # noqa: E402
 
 load_package()
@@ -350,7 +350,7 @@ def main():
         # An RCCL communicator brings HIP streams of its own.  With the runtime's default of 4 hardware queues they alias with the
         # handle's 4 stream groups, two of which then share a queue and serialise: 293 k instead of 329 k scans/s with the communicator
         # merely alive (measured at N = 1 under the launcher; 8 queues: 329.7 k).  Must be set before the HIP runtime initialises.
-        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the product path")

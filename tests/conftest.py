@@ -7,7 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # before the first HIP call: the handles drive two HIP streams per stream group
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")   # before the first HIP call: the handles drive two HIP streams per stream group
 from alego_loader import load_package  # noqa: E402
 
 load_package()

@@ -21,7 +21,7 @@ def _setup(rank, world, port):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                       HSA_ENABLE_IPC_MODE_LEGACY="0")
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # RCCL's streams next to the handle's
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")   # RCCL's streams next to the handle's
     import torch
     torch.cuda.set_device(rank)
     from alego_loader import load_package
