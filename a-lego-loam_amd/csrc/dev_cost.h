@@ -223,6 +223,36 @@ DEV_INLINE void block_reduce28_lds(const double acc[28], double* s_acc /*[28*T/4
   __syncthreads();
 }
 
+// The same with a third DPP step (row_half_mirror: the two quads of eight lanes) before LDS: 28 x T/8 doubles of scratch (14 KB for
+// 512 threads).  lm_solve keeps its residual rows in LDS, so every KB of reduction scratch is 20 rows streamed from the L2 instead.
+template <int T>
+DEV_INLINE void block_reduce28_oct(const double acc[28], double* s_acc /*[28*T/8]*/, double* s_out /*[28]*/) {
+  constexpr int Q = T / 8, G = Q / 8;
+  static_assert(G == 2 || G == 4 || G == 8 || G == 16, "128, 256, 512 or 1024 threads");
+  static_assert(28 * G <= T, "one lane group per scalar");
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int k = 0; k < 28; ++k) {
+    double v = dpp_add_f64<0xB1>(acc[k]);
+    v = dpp_add_f64<0x4E>(v);
+    v = dpp_add_f64<0x141>(v);              // all eight lanes hold ((a + b) + (c + d)) + ((e + f) + (g + h))
+    if ((tid & 7) == 0) s_acc[k * Q + (tid >> 3)] = v;
+  }
+  __syncthreads();
+  if (tid < 28 * G) {
+    const int k = tid / G, g = tid - k * G;
+    double t = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) t += s_acc[k * Q + j * G + g];
+    t = dpp_add_f64<0xB1>(t);
+    if (G >= 4) t = dpp_add_f64<0x4E>(t);
+    if (G >= 8) t = dpp_add_f64<0x141>(t);
+    if (G == 16) t = dpp_add_f64<0x140>(t);
+    if (g == 0) s_out[k] = t;
+  }
+  __syncthreads();
+}
+
 // ---------------------------------------------------------------------------
 // Trust-region Levenberg-Marquardt control (Ceres TrustRegionMinimizer +
 // LevenbergMarquardtStrategy defaults) driven by one thread; the

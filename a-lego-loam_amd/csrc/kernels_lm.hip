@@ -15,9 +15,6 @@
 #include "lm_ctx.h"
 
 #define LM_BLOCK 256
-#ifndef LM_SOLVE_BLOCK
-#define LM_SOLVE_BLOCK 256
-#endif
 
 DEV_INLINE double* ldp(const LmCtx& L, int slot) { return L.ld + (size_t)slot * LD_COUNT; }
 DEV_INLINE int* lip(const LmCtx& L, int slot) { return L.li + (size_t)slot * LI_COUNT; }
@@ -398,6 +395,11 @@ __global__ void __launch_bounds__(128) lm_knn(DevCtx d, LmCtx L) {
   const DQuat qm = ldq(ld + LD_Q_M2L);
   constexpr int QPB = 128 / LM_KNN_LANES;
   const int sub = threadIdx.x & (LM_KNN_LANES - 1);
+  // bit pattern of the smallest f32 f with (double)f >= knn_max_dist: dist < f  <=>  (double)dist < knn_max_dist (:376,:426 accept a query only
+  // when its FIFTH neighbour is closer than that, so farther candidates need not enter the top-5 sets at all)
+  float flim = (float)P.knn_max_dist;
+  if ((double)flim < P.knn_max_dist) flim = __int_as_float(__float_as_int(flim) + 1);
+  const uint32_t limbits = P.knn_max_dist > 0.0 ? (uint32_t)__float_as_int(flim) : 0u;
   // every lane of a wavefront runs the same number of iterations (DPP reads neighbours' registers): clamp, don't exit
   const int nq_round = (nq + QPB - 1) / QPB * QPB;
   for (int qq = bx * QPB + threadIdx.x / LM_KNN_LANES; qq < nq_round; qq += gx * QPB) {
@@ -438,7 +440,7 @@ __global__ void __launch_bounds__(128) lm_knn(DevCtx d, LmCtx L) {
       df = sy - a.y; dist += df * df;
       df = sz - a.z; dist += df * df;
       const u64k key = ((u64k)(uint32_t)d_f2i(dist) << 32) | (uint32_t)__float_as_int(a.w);   // dist >= 0: its bit pattern orders like its value
-      if (key < kmax) {
+      if (key < kmax && (uint32_t)d_f2i(dist) < limbits) {   // (limbits: a neighbour at knn_max_dist or beyond can never be part of an ACCEPTED query — see `ok` below)
         // (a set that is not full yet holds KNONE entries, which are its maximum; equal KNONE entries are all "the maximum": only one may be replaced)
         const bool e0 = k0 == kmax, e1 = !e0 && k1 == kmax, e2 = !e0 && !e1 && k2 == kmax, e3 = !e0 && !e1 && !e2 && k3 == kmax, e4 = !e0 && !e1 && !e2 && !e3;
         k0 = e0 ? key : k0; k1 = e1 ? key : k1; k2 = e2 ? key : k2; k3 = e3 ? key : k3; k4 = e4 ? key : k4;
@@ -562,8 +564,141 @@ __global__ void __launch_bounds__(128) lm_fit(DevCtx d, LmCtx L) {
   }
 }
 
+// ---- the accepted residual rows of one registration --------------------------------------------------------------------------
+// Round 3: lm_solve used to pack its ~2.9 k accepted rows (80 B each = 230 KB per stream) into HBM and stream them through every one
+// of the ~30 evaluations of a mapping frame: 512 streams x 230 KB x 30 = 3.5 GB per launch out of the L2 / Infinity Cache, which is what
+// bounded the kernel (514 us per launch with the rows, 0.94 MB of HBM traffic per scan).  Now the rows live in LDS for the whole solve,
+// structure of arrays, edges (a, b: 6 f64 + the query point 3 f32 = 60 B) apart from planes (normal, d: 4 f64 + 3 f32 = 44 B): 143 KB
+// at 16 x 1800.  Rows beyond the workgroup's LDS budget stay in `crows` (80 B rows, edges at [0, Rc), planes behind them) and are read
+// from there — same arithmetic, same order.  The compaction is STABLE in the query index (every thread takes a contiguous range of
+// queries), thread t evaluates edges t, t + T, ... and then planes t, t + T, ...: the summation order of the normal equations is a
+// function of the accepted-query lists alone, and lm_shard_eval (all rows in `crows`) follows the same order.
+// Measured on the 2048-stream bench (four stream groups share the chip), T threads x LDS for the rows: 512 x 158 KB 348 k scans/s (a single
+// stream's solve: 94 us against 150 us before), 512 x 48 KB 345 k, 256 x 158 KB 347 k, 256 x 96 KB 355 k, 256 x 48 KB 357 k, 256 x 0 354 k,
+// 1024 x any 287 k (128 VGPRs: spills); the old kernel 349 k.  Under load the footprint decides — 256 threads x 254 VGPRs is half a CU's
+// register file, and a workgroup that needs the whole CU's LDS waits for every other LDS user to leave — so the default keeps two thirds of the
+// rows on chip (96 KB) and streams the rest.
+#ifndef LM_SOLVE_T
+#define LM_SOLVE_T 256
+#endif
+#define LM_SOLVE_RED_BYTES ((size_t)28 * (LM_SOLVE_T / 8) * sizeof(double))
+#define LM_SOLVE_DYN_BYTES ((size_t)158 * 1024)   // upper limit (ALEGO_LM_ROW_LDS): of the CU's 160 KB; the kernel's static LDS (solver state, scan tables) is < 2 KB
+#define LM_SOLVE_ROW_BYTES_DEFAULT ((size_t)96 * 1024)
+struct LmRows {
+  int Rc, Rs;             // accepted corner (edge) / surf (plane) rows
+  int Ce, Cp;             // the first Ce edges / Cp planes are resident in LDS
+  double *ea, *eb, *pn;   // LDS: ea[k * Ce + i], eb[k * Ce + i] (k < 3); pn[k * Cp + j] (k < 4: normal, negative_OA_dot_norm)
+  float *ep, *pp;         // LDS: query points ep[k * Ce + i], pp[k * Cp + j] (k < 3)
+  double* crows;          // HBM: rows that do not fit (all of them on the sharded path)
+};
+
+template <int T>
+DEV_INLINE void lm_pack_rows(const LmCtx& L, int slot, int nqc, int nqs, unsigned char* row_lds, size_t row_budget, int (*s_cnt)[T / 64], LmRows& W) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const double* blocks = L.blocks + (size_t)slot * L.qcap * 8;
+  const float4* qc = L.cur_corner_ds + (size_t)slot * L.kf_cap_c;
+  const float4* qs = L.cur_total_ds + (size_t)slot * L.total_cap;
+  const int n_all = nqc + nqs, per = (n_all + T - 1) / T;
+  const int lo = min(tid * per, n_all), hi = min(lo + per, n_all);
+  auto qrow = [&](int i) -> size_t { return (size_t)(i < nqc ? i : L.kf_cap_c + (i - nqc)); };
+  constexpr int U = 4;   // loads in flight per thread
+  int cc = 0, cs = 0;
+  for (int i0 = lo; i0 < hi; i0 += U) {
+    double ty[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) ty[u] = blocks[qrow(min(i0 + u, n_all - 1)) * 8 + 7];
+#pragma unroll
+    for (int u = 0; u < U; ++u) if (i0 + u < hi && ty[u] != 0.0) { if (i0 + u < nqc) ++cc; else ++cs; }
+  }
+  int ic = cc, is = cs;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const int tc = __shfl_up(ic, o, 64), ts = __shfl_up(is, o, 64); if (lane >= o) { ic += tc; is += ts; } }
+  if (lane == 63) { s_cnt[0][wave] = ic; s_cnt[1][wave] = is; }
+  __syncthreads();
+  int epos = ic - cc, ppos = is - cs, Rc = 0, Rs = 0;
+#pragma unroll
+  for (int w = 0; w < T / 64; ++w) { const int a = s_cnt[0][w], b = s_cnt[1][w]; if (w < wave) { epos += a; ppos += b; } Rc += a; Rs += b; }
+  W.Rc = Rc; W.Rs = Rs;
+  W.Ce = (int)min((size_t)Rc, row_budget / 60);
+  W.Cp = (int)min((size_t)Rs, (row_budget - (size_t)60 * W.Ce) / 44);
+  W.ea = reinterpret_cast<double*>(row_lds); W.eb = W.ea + 3 * (size_t)W.Ce; W.pn = W.eb + 3 * (size_t)W.Ce;
+  W.ep = reinterpret_cast<float*>(W.pn + 4 * (size_t)W.Cp); W.pp = W.ep + 3 * (size_t)W.Ce;
+  W.crows = L.crows + (size_t)slot * L.qcap * 10;
+  for (int i0 = lo; i0 < hi; i0 += U) {
+    double4 blo[U], bhi[U];
+    float4 pt[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = min(i0 + u, n_all - 1);
+      const double4* b = reinterpret_cast<const double4*>(blocks + qrow(i) * 8);
+      blo[u] = b[0]; bhi[u] = b[1];
+      pt[u] = i < nqc ? qc[i] : qs[i - nqc];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = i0 + u;
+      if (i < hi && bhi[u].w != 0.0) {
+        const bool is_c = i < nqc;
+        const int r = is_c ? epos++ : ppos++;
+        if (is_c && r < W.Ce) {
+          W.ea[r] = blo[u].x; W.ea[W.Ce + r] = blo[u].y; W.ea[2 * W.Ce + r] = blo[u].z;
+          W.eb[r] = blo[u].w; W.eb[W.Ce + r] = bhi[u].x; W.eb[2 * W.Ce + r] = bhi[u].y;
+          W.ep[r] = pt[u].x; W.ep[W.Ce + r] = pt[u].y; W.ep[2 * W.Ce + r] = pt[u].z;
+        } else if (!is_c && r < W.Cp) {
+          W.pn[r] = blo[u].x; W.pn[W.Cp + r] = blo[u].y; W.pn[2 * W.Cp + r] = blo[u].z; W.pn[3 * W.Cp + r] = bhi[u].z;
+          W.pp[r] = pt[u].x; W.pp[W.Cp + r] = pt[u].y; W.pp[2 * W.Cp + r] = pt[u].z;
+        } else {
+          double2* o = reinterpret_cast<double2*>(W.crows + (size_t)(is_c ? r : Rc + r) * 10);   // 80 B rows: 16-byte aligned
+          o[0] = make_double2(blo[u].x, blo[u].y); o[1] = make_double2(blo[u].z, blo[u].w);
+          o[2] = make_double2(bhi[u].x, bhi[u].y); o[3] = make_double2(bhi[u].z, bhi[u].w);
+          *reinterpret_cast<float4*>(o + 4) = pt[u];
+        }
+      }
+    }
+  }
+  __threadfence_block();
+  __syncthreads();
+}
+
+// residuals + Jacobians of all rows at the pose of Tm, accumulated into this thread's 28 normal-equation scalars
+template <int T>
+DEV_INLINE void lm_eval_rows(const LmRows& W, const PoseTerms& Tm, double huber, double acc[28]) {
+  const double c3[3] = {0, 0, 0};
+  for (int i = threadIdx.x; i < W.Rc; i += T) {   // EdgeCostFunction (utility.h:242-297)
+    double a3[3], b3[3], cp[3];
+    if (i < W.Ce) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { a3[k] = W.ea[k * W.Ce + i]; b3[k] = W.eb[k * W.Ce + i]; cp[k] = (double)W.ep[k * W.Ce + i]; }
+    } else {
+      const double2* b = reinterpret_cast<const double2*>(W.crows + (size_t)i * 10);
+      const double2 q0 = b[0], q1 = b[1], q2 = b[2];
+      const float4 pc = *reinterpret_cast<const float4*>(b + 4);
+      a3[0] = q0.x; a3[1] = q0.y; a3[2] = q1.x; b3[0] = q1.y; b3[1] = q2.x; b3[2] = q2.y; cp[0] = pc.x; cp[1] = pc.y; cp[2] = pc.z;
+    }
+    double res, J[6];
+    eval_block(BLK_EDGE, cp, a3, b3, c3, 0.0, Tm, &res, J);
+    accumulate_block(res, J, huber, acc);
+  }
+  for (int j = threadIdx.x; j < W.Rs; j += T) {   // PlaneCostFunction (utility.h:299-349)
+    double a3[3], cp[3], dd;
+    if (j < W.Cp) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { a3[k] = W.pn[k * W.Cp + j]; cp[k] = (double)W.pp[k * W.Cp + j]; }
+      dd = W.pn[3 * W.Cp + j];
+    } else {
+      const double2* b = reinterpret_cast<const double2*>(W.crows + (size_t)(W.Rc + j) * 10);
+      const double2 q0 = b[0], q1 = b[1], q3 = b[3];
+      const float4 pc = *reinterpret_cast<const float4*>(b + 4);
+      a3[0] = q0.x; a3[1] = q0.y; a3[2] = q1.x; dd = q3.x; cp[0] = pc.x; cp[1] = pc.y; cp[2] = pc.z;
+    }
+    double res, J[6];
+    eval_block(BLK_PLANE, cp, a3, c3, c3, dd, Tm, &res, J);
+    accumulate_block(res, J, huber, acc);
+  }
+}
+
 // grid (slots): scan2MapOptimization's solver part
-__global__ void __launch_bounds__(LM_SOLVE_BLOCK) lm_solve(DevCtx d, LmCtx L) {
+__global__ void __launch_bounds__(LM_SOLVE_T) lm_solve(DevCtx d, LmCtx L) {
   const int slot = blockIdx.x + d.slot0;
   int* li = lip(L, slot);
   if (!li[LI_RUN]) return;
@@ -574,68 +709,21 @@ __global__ void __launch_bounds__(LM_SOLVE_BLOCK) lm_solve(DevCtx d, LmCtx L) {
     return;
   }
   extern __shared__ __attribute__((aligned(16))) unsigned char lm_smem[];
-  double* s_acc = reinterpret_cast<double*>(lm_smem);                // [28][LM_SOLVE_BLOCK]
-  double* s_seg = s_acc + 28 * (LM_SOLVE_BLOCK / 4);                  // [28][LM_SOLVE_BLOCK/128]
+  double* s_acc = reinterpret_cast<double*>(lm_smem);                // [28][LM_SOLVE_T / 8]
   __shared__ double s_out[28], s_trig[12];
   __shared__ LmState S;
-  __shared__ int s_action, s_cnt[2][LM_SOLVE_BLOCK / 64];
-  const int nqc = li[LI_NCUR_C], nqs = li[LI_NTOTAL_DS];
-  const double* blocks = L.blocks + (size_t)slot * L.qcap * 8;
-  const float4* qc = L.cur_corner_ds + (size_t)slot * L.kf_cap_c;
-  const float4* qs = L.cur_total_ds + (size_t)slot * L.total_cap;
-  // ---- correspondence counts (:465) and the packed list of accepted rows.  About half of the queries have no
-  // correspondence; every solver evaluation streams the rows once, so they are packed once (thread-major order: the
-  // summation order of the normal equations is fixed by it, like before by the query index) and the ~30 evaluations of a
-  // mapping frame read half as much.
-  double* crows = L.crows + (size_t)slot * L.qcap * 10;
-  const int nrows_all = nqc + nqs;
-  {
-    constexpr int CU_ = 4;   // type flags of four rows in flight
-    int cc = 0, cs = 0;
-    for (int i0 = threadIdx.x; i0 < nrows_all; i0 += LM_SOLVE_BLOCK * CU_) {
-      double ty[CU_];
-#pragma unroll
-      for (int u = 0; u < CU_; ++u) { const int i = min(i0 + u * LM_SOLVE_BLOCK, nrows_all - 1); ty[u] = blocks[(size_t)(i < nqc ? i : L.kf_cap_c + (i - nqc)) * 8 + 7]; }
-#pragma unroll
-      for (int u = 0; u < CU_; ++u) { const int i = i0 + u * LM_SOLVE_BLOCK; if (i < nrows_all && ty[u] != 0.0) { if (i < nqc) ++cc; else ++cs; } }
-    }
-    // exclusive scan of (cc + cs) over the threads: wavefront scan, then the wavefront totals
-    const int mine = cc + cs;
-    int incl = mine;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane_id() >= o) incl += t; }
-    int wc = cc, ws = cs;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { wc += __shfl_xor(wc, o, 64); ws += __shfl_xor(ws, o, 64); }
-    if (lane_id() == 0) { s_cnt[0][threadIdx.x >> 6] = wc; s_cnt[1][threadIdx.x >> 6] = ws; }
-    __syncthreads();
-    int woff = 0, ta = 0, tb = 0;
-    for (int w = 0; w < LM_SOLVE_BLOCK / 64; ++w) { const int c = s_cnt[0][w] + s_cnt[1][w]; if (w < (int)(threadIdx.x >> 6)) woff += c; ta += s_cnt[0][w]; tb += s_cnt[1][w]; }
-    int pos = woff + incl - mine;
-    for (int i = threadIdx.x; i < nrows_all; i += LM_SOLVE_BLOCK) {
-      const bool is_c = i < nqc;
-      const double4* b = reinterpret_cast<const double4*>(blocks + (size_t)(is_c ? i : L.kf_cap_c + (i - nqc)) * 8);
-      const double4 lo = b[0], hi = b[1];
-      if (hi.w != 0.0) {
-        const float4 pc = is_c ? qc[i] : qs[i - nqc];
-        double2* o = reinterpret_cast<double2*>(crows + (size_t)pos * 10);   // 80 B rows: 16-byte aligned (not 32: no double4 here)
-        o[0] = make_double2(lo.x, lo.y); o[1] = make_double2(lo.z, lo.w); o[2] = make_double2(hi.x, hi.y); o[3] = make_double2(hi.z, hi.w);
-        *reinterpret_cast<float4*>(o + 4) = pc;
-        ++pos;
-      }
-    }
-    __threadfence_block();
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      li[LI_NCC] = ta; li[LI_NSC] = tb; li[LI_OPTIMIZED] = 1;
-      s_cnt[0][0] = ta + tb;
-    }
-    __syncthreads();
-  }
-  const int R = s_cnt[0][0];
+  __shared__ int s_action, s_cnt[2][LM_SOLVE_T / 64];
+  // ---- correspondence counts (:465) and the accepted rows, into LDS ----
+  LmRows W;
+#ifdef ALEGO_TIMING
+  const long long cpack_ = clock64();
+#endif
+  lm_pack_rows<LM_SOLVE_T>(L, slot, li[LI_NCUR_C], li[LI_NTOTAL_DS], lm_smem + LM_SOLVE_RED_BYTES, L.solve_row_bytes, s_cnt, W);
+  if (threadIdx.x == 0) { li[LI_NCC] = W.Rc; li[LI_NSC] = W.Rs; li[LI_OPTIMIZED] = 1; }
+  const int R = W.Rc + W.Rs;
   double acc[28];
 #ifdef ALEGO_TIMING
-  long long tm[5] = {0, 0, 0, 0, 0};
+  long long tm[5] = {0, 0, 0, 0, clock64() - cpack_};   // pose terms, rows, reduction, trust-region control (one thread), pack
 #define TM(k, expr) { const long long c_ = clock64(); expr; tm[k] += clock64() - c_; }
 #else
 #define TM(k, expr) { expr; }
@@ -645,37 +733,8 @@ __global__ void __launch_bounds__(LM_SOLVE_BLOCK) lm_solve(DevCtx d, LmCtx L) {
     for (int k = 0; k < 28; ++k) acc[k] = 0;
     PoseTerms T;
     TM(0, T = pose_terms_coop(x, s_trig));
-#ifdef ALEGO_TIMING
-    const long long c1_ = clock64();
-#endif
-    // software-pipelined: the loads of row i+1 are issued before row i is evaluated
-    struct Row { double2 q0, q1, q2, q3; float4 pc; };   // a.xy | a.z b.x | b.yz | d, type
-    auto load_row = [&](int i) {
-      Row r;
-      const double2* b = reinterpret_cast<const double2*>(crows + (size_t)i * 10);
-      r.q0 = b[0]; r.q1 = b[1]; r.q2 = b[2]; r.q3 = b[3];
-      r.pc = *reinterpret_cast<const float4*>(b + 4);
-      return r;
-    };
-    int i = threadIdx.x;
-    Row cur;
-    if (i < R) cur = load_row(i);
-    while (i < R) {
-      const int inext = i + LM_SOLVE_BLOCK;
-      Row nxt = cur;
-      if (inext < R) nxt = load_row(inext);
-      const double ty = cur.q3.y;
-      const double cp[3] = {cur.pc.x, cur.pc.y, cur.pc.z}, a3[3] = {cur.q0.x, cur.q0.y, cur.q1.x}, b3[3] = {cur.q1.y, cur.q2.x, cur.q2.y}, c3[3] = {0, 0, 0};
-      double res, J[6];
-      eval_block(ty == 2.0 ? BLK_EDGE : BLK_PLANE, cp, a3, b3, c3, cur.q3.x, T, &res, J);
-      accumulate_block(res, J, P.huber_delta, acc);
-      cur = nxt;
-      i = inext;
-    }
-#ifdef ALEGO_TIMING
-    tm[1] += clock64() - c1_;
-#endif
-    TM(2, block_reduce28_lds<LM_SOLVE_BLOCK>(acc, s_acc, s_seg, s_out));
+    TM(1, lm_eval_rows<LM_SOLVE_T>(W, T, P.huber_delta, acc));
+    TM(2, block_reduce28_oct<LM_SOLVE_T>(acc, s_acc, s_out));
   };
   for (int outer = 0; outer < P.lm_outer_iters; ++outer) {  // :360 — identical correspondences both times
     if (R == 0) {  // ceres::Solve on an empty problem is a no-op
@@ -700,14 +759,14 @@ __global__ void __launch_bounds__(LM_SOLVE_BLOCK) lm_solve(DevCtx d, LmCtx L) {
 #pragma unroll
         for (int k = 0; k < 6; ++k) xc[k] = S.cand[k];
         evaluate(xc);
-        TM(4, if (threadIdx.x == 0) s_action = lm_consume(S, s_out); __syncthreads());
+        TM(3, if (threadIdx.x == 0) s_action = lm_consume(S, s_out); __syncthreads());
         if (s_action == LM_STOP) break;
       }
       __syncthreads();
     }
     if (threadIdx.x == 0) {
 #ifdef ALEGO_TIMING
-      for (int k = 0; k < 5; ++k) ld[43 + k] = (outer == 0 ? 0.0 : ld[43 + k]) + (double)tm[k];
+      for (int k = 0; k < 5; ++k) ld[43 + k] = (double)tm[k];   // (accumulated over both outer iterations)
 #endif
 #pragma unroll
       for (int k = 0; k < 6; ++k) ld[LD_PARAMS + k] = S.x[k];
@@ -823,91 +882,50 @@ __global__ void lm_apply_correction(DevCtx d, LmCtx L, int slot, const double* r
 // The host enqueues the worst-case sequence (lm_outer_iters x (1 + lm_max_iters) evaluations); kernels of a finished solve return at once.
 // Same evaluation code, same row order and same reduction as lm_solve: with one rank the result is bit-identical to it.
 static_assert(sizeof(LmState) <= 64 * sizeof(double), "LmHost allocates 64 doubles per slot for the sharded solve's state");
-__global__ void __launch_bounds__(LM_SOLVE_BLOCK) lm_shard_pack(DevCtx d, LmCtx L) {
+__global__ void __launch_bounds__(LM_SOLVE_T) lm_shard_pack(DevCtx d, LmCtx L) {
   const int slot = blockIdx.x + d.slot0;
   int* li = lip(L, slot);
   int* ctl = L.shard_ctl + (size_t)slot * 8;
   double* part = L.shard_part + (size_t)slot * 32;
   if (threadIdx.x < 32) part[threadIdx.x] = 0.0;
-  if (threadIdx.x == 0) { ctl[0] = 0; ctl[1] = LM_STOP; ctl[2] = 1; ctl[3] = 0; ctl[4] = 1; }
+  if (threadIdx.x == 0) { ctl[0] = 0; ctl[1] = LM_STOP; ctl[2] = 1; ctl[3] = 0; ctl[4] = 1; ctl[5] = 0; }
   if (!li[LI_RUN]) return;
   const alego_params& P = d.P;
   if (li[LI_NCUR_C] < P.lm_min_corner || li[LI_NTOTAL] < P.lm_min_surf || li[LI_KDS_C] < P.lm_min_map_corner || li[LI_NKF] == 0) {
     if (threadIdx.x == 0) { li[LI_FLAGS] |= 16; li[LI_NCC] = 0; li[LI_NSC] = 0; li[LI_SUM0] = 0; li[LI_SUM1] = 0; }
     return;
   }
-  __shared__ int s_cnt[2][LM_SOLVE_BLOCK / 64];
-  const int nqc = li[LI_NCUR_C], nqs = li[LI_NTOTAL_DS];
-  const double* blocks = L.blocks + (size_t)slot * L.qcap * 8;
-  const float4* qc = L.cur_corner_ds + (size_t)slot * L.kf_cap_c;
-  const float4* qs = L.cur_total_ds + (size_t)slot * L.total_cap;
-  double* crows = L.crows + (size_t)slot * L.qcap * 10;
-  const int nrows_all = nqc + nqs;
-  int cc = 0, cs = 0;
-  for (int i = threadIdx.x; i < nrows_all; i += LM_SOLVE_BLOCK) {
-    const double ty = blocks[(size_t)(i < nqc ? i : L.kf_cap_c + (i - nqc)) * 8 + 7];
-    if (ty != 0.0) { if (i < nqc) ++cc; else ++cs; }
-  }
-  const int mine = cc + cs;
-  int incl = mine;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane_id() >= o) incl += t; }
-  int wc = cc, ws = cs;
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) { wc += __shfl_xor(wc, o, 64); ws += __shfl_xor(ws, o, 64); }
-  if (lane_id() == 0) { s_cnt[0][threadIdx.x >> 6] = wc; s_cnt[1][threadIdx.x >> 6] = ws; }
-  __syncthreads();
-  int woff = 0, ta = 0, tb = 0;
-  for (int w = 0; w < LM_SOLVE_BLOCK / 64; ++w) { const int c = s_cnt[0][w] + s_cnt[1][w]; if (w < (int)(threadIdx.x >> 6)) woff += c; ta += s_cnt[0][w]; tb += s_cnt[1][w]; }
-  int pos = woff + incl - mine;
-  for (int i = threadIdx.x; i < nrows_all; i += LM_SOLVE_BLOCK) {   // thread-major order, as lm_solve packs them
-    const bool is_c = i < nqc;
-    const double4* b = reinterpret_cast<const double4*>(blocks + (size_t)(is_c ? i : L.kf_cap_c + (i - nqc)) * 8);
-    const double4 lo = b[0], hi = b[1];
-    if (hi.w != 0.0) {
-      const float4 pc = is_c ? qc[i] : qs[i - nqc];
-      double2* o = reinterpret_cast<double2*>(crows + (size_t)pos * 10);
-      o[0] = make_double2(lo.x, lo.y); o[1] = make_double2(lo.z, lo.w); o[2] = make_double2(hi.x, hi.y); o[3] = make_double2(hi.z, hi.w);
-      *reinterpret_cast<float4*>(o + 4) = pc;
-      ++pos;
-    }
-  }
+  __shared__ int s_cnt[2][LM_SOLVE_T / 64];
+  LmRows W;
+  lm_pack_rows<LM_SOLVE_T>(L, slot, li[LI_NCUR_C], li[LI_NTOTAL_DS], nullptr, 0, s_cnt, W);   // every row to HBM, in lm_solve's order
   if (threadIdx.x == 0) {
-    ctl[0] = ta + tb; ctl[1] = LM_EVAL; ctl[2] = 0; ctl[4] = 0;
-    part[28] = (double)ta; part[29] = (double)tb;   // summed over the ranks with the first evaluation
+    ctl[0] = W.Rc + W.Rs; ctl[5] = W.Rc; ctl[1] = LM_EVAL; ctl[2] = 0; ctl[4] = 0;
+    part[28] = (double)W.Rc; part[29] = (double)W.Rs;   // summed over the ranks with the first evaluation
     li[LI_OPTIMIZED] = 1;
   }
 }
 
-__global__ void __launch_bounds__(LM_SOLVE_BLOCK) lm_shard_eval(DevCtx d, LmCtx L, int which) {
+__global__ void __launch_bounds__(LM_SOLVE_T) lm_shard_eval(DevCtx d, LmCtx L, int which) {
   const int slot = blockIdx.x + d.slot0;
   const int* ctl = L.shard_ctl + (size_t)slot * 8;
   if (ctl[2] || ctl[4] || ctl[1] != LM_EVAL) return;   // solve finished / guard failed: the all-reduce still runs, on stale partials nobody reads
   extern __shared__ __attribute__((aligned(16))) unsigned char lm_smem[];
   double* s_acc = reinterpret_cast<double*>(lm_smem);
-  double* s_seg = s_acc + 28 * (LM_SOLVE_BLOCK / 4);
   __shared__ double s_out[28], s_trig[12];
   const LmState* S = reinterpret_cast<const LmState*>(L.shard_state) + slot;
   const double* ld = ldp(L, slot);
   double x[6];
 #pragma unroll
   for (int k = 0; k < 6; ++k) x[k] = which == 0 ? ld[LD_PARAMS + k] : S->cand[k];
-  const double* crows = L.crows + (size_t)slot * L.qcap * 10;
-  const int R = ctl[0];
+  LmRows W{};
+  W.Rc = ctl[5]; W.Rs = ctl[0] - ctl[5];
+  W.crows = L.crows + (size_t)slot * L.qcap * 10;
   double acc[28];
 #pragma unroll
   for (int k = 0; k < 28; ++k) acc[k] = 0;
   const PoseTerms T = pose_terms_coop(x, s_trig);
-  for (int i = threadIdx.x; i < R; i += LM_SOLVE_BLOCK) {
-    const double2* b = reinterpret_cast<const double2*>(crows + (size_t)i * 10);
-    const double2 q0 = b[0], q1 = b[1], q2 = b[2], q3 = b[3];
-    const float4 pc = *reinterpret_cast<const float4*>(b + 4);
-    const double cp[3] = {pc.x, pc.y, pc.z}, a3[3] = {q0.x, q0.y, q1.x}, b3[3] = {q1.y, q2.x, q2.y}, c3[3] = {0, 0, 0};
-    double res, J[6];
-    eval_block(q3.y == 2.0 ? BLK_EDGE : BLK_PLANE, cp, a3, b3, c3, q3.x, T, &res, J);
-    accumulate_block(res, J, d.P.huber_delta, acc);
-  }
-  block_reduce28_lds<LM_SOLVE_BLOCK>(acc, s_acc, s_seg, s_out);
+  lm_eval_rows<LM_SOLVE_T>(W, T, d.P.huber_delta, acc);
+  block_reduce28_oct<LM_SOLVE_T>(acc, s_acc, s_out);
   double* part = L.shard_part + (size_t)slot * 32;
   if (threadIdx.x < 28) part[threadIdx.x] = s_out[threadIdx.x];
   if (threadIdx.x == 0 && which == 1) { part[28] = 0.0; part[29] = 0.0; }
@@ -963,10 +981,10 @@ __global__ void lm_shard_next_outer(DevCtx d, LmCtx L) {
   ctl[3] += 1; ctl[2] = 0; ctl[1] = LM_EVAL;
 }
 
-#define LM_SOLVE_LDS ((size_t)(28 * (LM_SOLVE_BLOCK / 4) + 28 * (LM_SOLVE_BLOCK / 128)) * sizeof(double))
+size_t lm_solve_row_bytes_max() { return LM_SOLVE_DYN_BYTES - LM_SOLVE_RED_BYTES; }
+size_t lm_solve_row_bytes_default() { return LM_SOLVE_ROW_BYTES_DEFAULT; }
 int lm_configure() {
-  if (hipFuncSetAttribute(reinterpret_cast<const void*>(lm_shard_eval), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LM_SOLVE_LDS) != hipSuccess) return -1;
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(lm_solve), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LM_SOLVE_LDS) == hipSuccess ? 0 : -1;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(lm_solve), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LM_SOLVE_DYN_BYTES) == hipSuccess ? 0 : -1;
 }
 
 // ---- launchers ---------------------------------------------------------------------
@@ -999,20 +1017,20 @@ int launch_lm_register(const DevCtx& d, const LmCtx& L, hipStream_t st, int (*al
     double* part = L.shard_part + (size_t)d.slot0 * 32;
     const size_t cnt = (size_t)d.n_launch * 32;
     const dim3 g1((d.n_launch + 63) / 64), b1(64);
-    ALEGO_LAUNCH(lm_shard_pack, dim3(d.n_launch), dim3(LM_SOLVE_BLOCK), 0, st, d, L);
+    ALEGO_LAUNCH(lm_shard_pack, dim3(d.n_launch), dim3(LM_SOLVE_T), 0, st, d, L);
     for (int outer = 0; outer < d.P.lm_outer_iters; ++outer) {
       if (outer) ALEGO_LAUNCH(lm_shard_next_outer, g1, b1, 0, st, d, L);
-      ALEGO_LAUNCH(lm_shard_eval, dim3(d.n_launch), dim3(LM_SOLVE_BLOCK), LM_SOLVE_LDS, st, d, L, 0);
+      ALEGO_LAUNCH(lm_shard_eval, dim3(d.n_launch), dim3(LM_SOLVE_T), LM_SOLVE_RED_BYTES, st, d, L, 0);
       if (int rc = allreduce(ar_ctx, part, cnt, st)) return rc;
       ALEGO_LAUNCH(lm_shard_step, g1, b1, 0, st, d, L, 1);
       for (int it = 0; it < d.P.lm_max_iters; ++it) {
-        ALEGO_LAUNCH(lm_shard_eval, dim3(d.n_launch), dim3(LM_SOLVE_BLOCK), LM_SOLVE_LDS, st, d, L, 1);
+        ALEGO_LAUNCH(lm_shard_eval, dim3(d.n_launch), dim3(LM_SOLVE_T), LM_SOLVE_RED_BYTES, st, d, L, 1);
         if (int rc = allreduce(ar_ctx, part, cnt, st)) return rc;
         ALEGO_LAUNCH(lm_shard_step, g1, b1, 0, st, d, L, 0);
       }
     }
   } else {
-  ALEGO_LAUNCH(lm_solve, dim3(d.n_launch), dim3(LM_SOLVE_BLOCK), LM_SOLVE_LDS, st, d, L);
+  ALEGO_LAUNCH(lm_solve, dim3(d.n_launch), dim3(LM_SOLVE_T), LM_SOLVE_RED_BYTES + L.solve_row_bytes, st, d, L);
   }
   ALEGO_LAUNCH(lm_finish, dim3((d.n_launch + 63) / 64), dim3(64), 0, st, d, L);
   ALEGO_LAUNCH(lm_store_kf, dim3(8, 3, d.n_launch), dim3(LM_BLOCK), 0, st, d, L, -1);

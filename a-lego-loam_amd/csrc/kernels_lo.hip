@@ -75,7 +75,11 @@ DEV_INLINE WalkBest walk_reduce(WalkBest b) {
 #ifndef LO_NB
 #define LO_NB 2       // surviving boxes evaluated per turn (2 x LO_NB loads in flight per lane); 3: same, 4: slower
 #endif
-#define LO_BOX_LDS (16384 / LO_CH)   // boxes (of LO_CH targets) staged in LDS: 512 boxes = 16 KB at 32 targets per box
+#ifndef LO_BOX_LDS
+#define LO_BOX_LDS_BIG 512   // sensors with more than 16 rings (64 x 2048: ~430 less_flat boxes)
+#define LO_BOX_LDS 160   // boxes (of LO_CH targets) staged in LDS: 5 KB (16 x 1800 has ~135 less_flat boxes; larger feature sets read the boxes from the L2).
+                         // 512 boxes = 16 KB made eight of these workgroups fill a CU's LDS: 351 k -> 354 k scans/s with 160
+#endif
 DEV_INLINE WalkBest walk_reduce_row(WalkBest b) {
   const unsigned long long bits = (unsigned long long)__double_as_longlong(b.dist);
   const unsigned long long mn = row16_min_u64(bits);
@@ -98,7 +102,7 @@ extern "C" void alego_la_times(long long* out) { (void)hipMemcpyFromSymbol(out, 
 // kind (compile-time): the corner association has one class of second points, the surf one two.  BLKA threads per workgroup, BLKA / 16
 // queries at a time; workgroup qb0 of qbn of the stream takes the query blocks qb0, qb0 + qbn, ...  (A device function: the batch path
 // launches it as lo_assoc, one stream's chain kernel lo_chain calls it between its grid barriers.)
-template <int kind, int BLKA>
+template <int kind, int BLKA, int BOXCAP = LO_BOX_LDS>
 DEV_INLINE void lo_assoc_body(const DevCtx& d, int box_lds_max, int slot, int qb0, int qbn) {
   static_assert(LO_CH % 16 == 0, "a box is evaluated as LO_CH / 16 targets per lane of a 16-lane row");
   constexpr int TPL = LO_CH / 16;
@@ -119,7 +123,7 @@ DEV_INLINE void lo_assoc_body(const DevCtx& d, int box_lds_max, int slot, int qb
   LA_TICK(0);
   __shared__ float s_sel[LO_QPB][4];
   __shared__ double s_pose[12];
-  __shared__ float4 s_box[2 * LO_BOX_LDS];   // the boxes are read by every query of the workgroup: LDS when they fit
+  __shared__ float4 s_box[2 * BOXCAP];   // the boxes are read by every query of the workgroup: LDS when they fit
   __shared__ int s_roff[65];
   const bool box_lds = nch <= box_lds_max;   // (<= LO_BOX_LDS; the parity tests also run with 0 = boxes straight from HBM)
   if (box_lds) for (int i = threadIdx.x; i < 2 * nch; i += BLKA) s_box[i] = bx[i];
@@ -328,9 +332,9 @@ DEV_INLINE void lo_assoc_body(const DevCtx& d, int box_lds_max, int slot, int qb
   }
 }
 
-template <int kind>
+template <int kind, int BOXCAP = LO_BOX_LDS>
 __global__ void __launch_bounds__(LO_BLOCK) lo_assoc(DevCtx d, int box_lds_max) {
-  lo_assoc_body<kind, LO_BLOCK>(d, box_lds_max, blockIdx.x + d.slot0, blockIdx.y, gridDim.y);   // slot fastest: a stream's workgroups share an XCD / L2 (see lm_knn)
+  lo_assoc_body<kind, LO_BLOCK, BOXCAP>(d, box_lds_max, blockIdx.x + d.slot0, blockIdx.y, gridDim.y);   // slot fastest: a stream's workgroups share an XCD / L2 (see lm_knn)
 }
 
 // evaluate every valid correspondence row of [row0, row0+n) at pose p
@@ -776,17 +780,21 @@ void launch_lo_deskew(const DevCtx& d, hipStream_t st) {
 }
 
 void launch_lo(const DevCtx& d, hipStream_t st) {
-  const int box_lds_max = std::min(d.opt_lo_box_lds, (int)LO_BOX_LDS);
+  const bool big_boxes = d.NS > 16;   // (which instantiation holds the boxes does not change a result: the boxes only prune)
+  const int box_lds_max = std::min(d.opt_lo_box_lds, big_boxes ? (int)LO_BOX_LDS_BIG : (int)LO_BOX_LDS);
   const bool wide = d.lo_qcap_surf + d.lo_qcap_corner > LO_WIDE_ROWS;   // (fixed by the geometry: every handle of a sensor sums its rows in the same order)
   // the rows of a solve staged in LDS: only when every possible row count fits (capacities, not counts: the variant is a property of the handle)
   const bool staged = !wide && d.lo_qcap_surf + d.lo_qcap_corner <= LO_LDS_ROWS && d.lo_qcap_surf <= 32 * LO_SOLVE_BLOCK && d.lo_qcap_corner <= 32 * LO_SOLVE_BLOCK;
-  ALEGO_LAUNCH(lo_assoc<0>, dim3(d.n_launch, std::min((d.lo_qcap_surf + LO_QPB_OF(LO_BLOCK) - 1) / LO_QPB_OF(LO_BLOCK), 8)), dim3(LO_BLOCK), 0, st, d, box_lds_max);
+  const dim3 g0(d.n_launch, std::min((d.lo_qcap_surf + LO_QPB_OF(LO_BLOCK) - 1) / LO_QPB_OF(LO_BLOCK), 8)), g1(d.n_launch, std::min((d.lo_qcap_corner + LO_QPB_OF(LO_BLOCK) - 1) / LO_QPB_OF(LO_BLOCK), 12));
+  if (big_boxes) { ALEGO_LAUNCH((lo_assoc<0, LO_BOX_LDS_BIG>), g0, dim3(LO_BLOCK), 0, st, d, box_lds_max); }
+  else { ALEGO_LAUNCH(lo_assoc<0>, g0, dim3(LO_BLOCK), 0, st, d, box_lds_max); }
   auto solve = [&](int phase) {
     if (wide) { ALEGO_LAUNCH(lo_solve_t<LO_SOLVE_WIDE>, dim3(d.n_launch), dim3(LO_SOLVE_WIDE), LO_SOLVE_LDS_OF(LO_SOLVE_WIDE), st, d, phase); }
     else if (staged) { ALEGO_LAUNCH((lo_solve_t<LO_SOLVE_BLOCK, true>), dim3(d.n_launch), dim3(LO_SOLVE_BLOCK), LO_SOLVE_LDS_OF(LO_SOLVE_BLOCK), st, d, phase); }
     else { ALEGO_LAUNCH(lo_solve_t<LO_SOLVE_BLOCK>, dim3(d.n_launch), dim3(LO_SOLVE_BLOCK), LO_SOLVE_LDS_OF(LO_SOLVE_BLOCK), st, d, phase); }
   };
   solve(0);
-  ALEGO_LAUNCH(lo_assoc<1>, dim3(d.n_launch, std::min((d.lo_qcap_corner + LO_QPB_OF(LO_BLOCK) - 1) / LO_QPB_OF(LO_BLOCK), 12)), dim3(LO_BLOCK), 0, st, d, box_lds_max);
+  if (big_boxes) { ALEGO_LAUNCH((lo_assoc<1, LO_BOX_LDS_BIG>), g1, dim3(LO_BLOCK), 0, st, d, box_lds_max); }
+  else { ALEGO_LAUNCH(lo_assoc<1>, g1, dim3(LO_BLOCK), 0, st, d, box_lds_max); }
   solve(1);
 }

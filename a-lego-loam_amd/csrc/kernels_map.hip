@@ -13,12 +13,13 @@
 //               left, binary-search increment + ordered insertion of the new voxels for the run that entered, empty voxels dropped.
 //               (Any other change — first use, pose corrections, a cleared window — rebuilds U by inserting the runs one by one.)
 //               The last workgroup of the launch writes the work list of map_accum.
-//   map_accum   one workgroup per 1024 consecutive voxels of a map: the runs are visited in window order; a run's points
-//               of the chunk are one contiguous piece (found by binary search), each point finds its voxel by binary search in
-//               the chunk's keys (LDS) and the head of every voxel-run of the piece adds its points to the accumulator (LDS).
+//   map_accum   one workgroup per 512 consecutive voxels of a map: a run's points of the chunk are one contiguous piece (found by
+//               binary search); the pieces are staged in LDS batch by batch in window order, each point finds its voxel by binary
+//               search in the chunk's keys (LDS), and one thread per voxel adds its points in order (registers).
 //
 // HBM traffic per rebuild: the window's points once (16 B each) + the new / old run twice + the output, against ~21x that for the
 // radix sort of the concatenation (rocprofv3 FETCH/WRITE counters, round 1).
+#include <cstdlib>
 #include "dev_common.h"
 #include "lm_ctx.h"
 #include "prof.h"
@@ -27,10 +28,10 @@ typedef unsigned long long u64;
 
 #define MU_T 512          // threads of map_update
 #ifndef MA_T
-#define MA_T 512          // threads of map_accum: a run's piece of a chunk (a few hundred points) in one prefetched sweep (256: two or three dependent sweeps per run)
+#define MA_T 512          // threads of map_accum = voxels per work item
 #endif
 #ifndef MAP_R
-#define MAP_R 1024        // voxels per map_accum work item
+#define MAP_R 512         // voxels per map_accum work item (= MA_T: one thread per voxel in its accumulation phase)
 #endif
 #define MAP_KMAX 512      // window entries held in LDS (alego_create refuses a larger recent_keyframe_num)
 
@@ -87,14 +88,20 @@ DEV_INLINE int block_excl_scan(int v, int* s_w /*[MU_T/64 + 1]*/, int* total) {
 
 // grid (2, slots); dynamic LDS: 2 * MU_FCAP * 8 bytes
 __global__ void __launch_bounds__(MU_T) map_update(DevCtx d, LmCtx L, MapWork W) {
-  const int m = blockIdx.x, slot = blockIdx.y + d.slot0, tid = threadIdx.x;
-  int* li = lipm(L, slot);
+  const int m = blockIdx.x, tid = threadIdx.x;
   __shared__ int s_rem[MAP_KMAX], s_add[MAP_KMAX], s_nrem, s_nadd, s_nU, s_nnew, s_err;
   __shared__ int s_w[MU_T / 64 + 1];
   __shared__ int s_last;
   __shared__ float s_box[6][MU_T / 64];
   __shared__ int s_kr_tot[MU_T / 64];
   extern __shared__ __attribute__((aligned(16))) unsigned char mu_smem[];
+  // A workgroup takes the slots blockIdx.y, blockIdx.y + gridDim.y, ...: only every sixth mapping frame changes its window, and a workgroup
+  // that has nothing to do still has to wait for 68 KB of LDS to start.  A quarter of the workgroups, each looking at four slots, leaves the
+  // LDS to the other stream groups' kernels.
+  for (int sl = blockIdx.y; sl < d.n_launch; sl += gridDim.y) {
+  const int slot = sl + d.slot0;
+  int* li = lipm(L, slot);
+  __syncthreads();   // LDS of the previous slot is reused
   const bool active = li[LI_REBUILD] && d.opt_map_merge;
   if (active) {
     const float inv = 1.0f / (m == 0 ? d.P.lm_leaf_corner : d.P.lm_leaf_surf);
@@ -341,6 +348,7 @@ __global__ void __launch_bounds__(MU_T) map_update(DevCtx d, LmCtx L, MapWork W)
       for (int a = 0; a < 3; ++a) { bb[a] = vbox_enc(mn[a]); bb[4 + a] = ~vbox_enc(mx[a]); }
     }
   }
+  }   // slots of this workgroup
   // ---- the last workgroup of the launch plans map_accum and closes the bookkeeping of every slot
   __threadfence();
   __syncthreads();
@@ -385,14 +393,35 @@ __global__ void __launch_bounds__(MU_T) map_update(DevCtx d, LmCtx L, MapWork W)
   }
 }
 
-// persistent workgroups over the work list
+// persistent workgroups over the work list.
+// Round 3 rewrite.  The first version visited the window's runs one after the other — a barrier per run, a run's piece of the chunk
+// (a few hundred points) on 512 threads, the followers of a voxel-run added by up to 63 dependent wave shuffles: 50 (K = 200: 200) serial
+// rounds of ~6 us per work item, 23 % VALU-busy, 8.7 % of the whole pipeline's time for a kernel that runs on every sixth mapping
+// frame.  Now the pieces of several runs form a BATCH (<= MA_JB sub-pieces, <= MA_BCAP points) that is staged in LDS in one sweep:
+//   1   every point of the batch is loaded once into LDS (s_pts); the first point of every (sub-piece, voxel) pair finds its voxel by
+//       binary search in the chunk's keys (LDS) and writes its position to s_start[sub][voxel]; followers are marked in s_rank
+//   2   one THREAD PER VOXEL walks the sub-pieces in window order and adds its points in order, accumulator in registers
+// Same additions in the same order as before (run after run, input order inside a run, starting from 0): bit-identical sums.
+#ifndef MA_JB
+#define MA_JB 8           // sub-pieces per batch.  (12 x 2048 points = 62 KB of LDS: 351 k scans/s; 8 x 1024 = 38 KB: 362 k; 6 x 512: the same)
+#endif
+#ifndef MA_PT
+#define MA_PT 2           // consecutive points of a batch per thread
+#endif
+#define MA_BCAP (MA_PT * MA_T)   // points per batch (a longer piece is cut into sub-pieces; they stay in order)
+static_assert(MAP_R == MA_T, "phase 2: one thread per voxel of the chunk");
 __global__ void __launch_bounds__(MA_T) map_accum(DevCtx d, LmCtx L, MapWork W) {
   __shared__ u64 s_key[MAP_R];
-  __shared__ float4 s_acc[MAP_R];
-  __shared__ int s_cnt[MAP_R];
+  __shared__ float4 s_pts[MA_BCAP];
+  __shared__ unsigned short s_rank[MA_BCAP];
+  __shared__ unsigned short s_start[MA_JB * MAP_R];   // [sub-piece][voxel]: position + 1 of the pair's first point in the batch (valid where s_mask has the bit)
+  __shared__ unsigned s_mask[MAP_R];                  // per voxel: the sub-pieces of the batch that hold points of it
   __shared__ int s_lo[MAP_KMAX], s_hi[MAP_KMAX], s_ent[MAP_KMAX];
-  const int tid = threadIdx.x, lane = tid & 63;
+  __shared__ int s_sub_ent[MA_JB], s_sub_lo[MA_JB], s_sub_off[MA_JB + 1];
+  __shared__ int s_nsub, s_next_j, s_next_pos;
+  const int tid = threadIdx.x;
   const int nitems = W.count[0];
+  for (int i = tid; i < MAP_R; i += MA_T) s_mask[i] = 0u;   // phase 2 leaves every entry it used at 0 again
   for (int it = blockIdx.x; it < nitems; it += gridDim.x) {
     const int item = W.items[it];
     const int slot = (item >> 12) + d.slot0, m = (item >> 11) & 1, chunk = item & 2047;
@@ -404,7 +433,7 @@ __global__ void __launch_bounds__(MA_T) map_accum(DevCtx d, LmCtx L, MapWork W) 
     const int* rec = L.rec + (size_t)slot * L.K;
     const int nwin = li[LI_REC_CNT];
     __syncthreads();   // LDS of the previous item is reused
-    for (int r = tid; r < nr; r += MA_T) { s_key[r] = U[r0 + r]; s_acc[r] = make_float4(0.f, 0.f, 0.f, 0.f); s_cnt[r] = 0; }
+    if (tid < nr) s_key[tid] = U[r0 + tid];
     __syncthreads();
     const u64 key_lo = s_key[0], key_hi = s_key[nr - 1];
     for (int j = tid; j < nwin; j += MA_T) {   // the piece of every run that falls into this chunk's key range
@@ -415,66 +444,99 @@ __global__ void __launch_bounds__(MA_T) map_accum(DevCtx d, LmCtx L, MapWork W) 
       s_lo[j] = bound_run(pts, n, inv, key_lo, false);
       s_hi[j] = bound_run(pts, n, inv, key_hi, true);
     }
-    __syncthreads();
-    // Runs in window order = the reference's summation order.  One barrier per run; the first MA_T points of the next run's
-    // piece (with the point before each, for the run-head test) are loaded before the barrier of the current one.
-    auto fetch = [&](int j, float4& p, float4& pp) {
-      const int lo = s_lo[j], hi = s_hi[j], i = lo + tid;
-      const float4* pts = run_pts(L, slot, m, s_ent[j]);
-      const int ic = hi > lo ? min(i, hi - 1) : 0;
-      p = pts[ic]; pp = pts[max(ic - 1, 0)];
-    };
-    float4 np_ = make_float4(0.f, 0.f, 0.f, 0.f), npp_ = np_;
-    if (nwin > 0) fetch(0, np_, npp_);
-    for (int j = 0; j < nwin; ++j) {
-      const int lo = s_lo[j], hi = s_hi[j];
-      const float4* pts = run_pts(L, slot, m, s_ent[j]);
-      float4 p = np_, pp = npp_;
-      if (j + 1 < nwin) fetch(j + 1, np_, npp_);
-      for (int i0 = lo; i0 < hi; i0 += MA_T) {
-        const int i = i0 + tid;
-        if (i0 > lo) { const int ic = min(i, hi - 1); p = pts[ic]; pp = pts[max(ic - 1, 0)]; }
-        const bool valid = i < hi;
-        // (lanes past the piece carry a key no voxel has, different per lane, so that they neither start nor extend a run)
-        const u64 key = valid ? vkey_of(p, inv) : (~0ull - (u64)lane);
-        const bool head = valid && (i == lo || vkey_of(pp, inv) != key);
-        int a = 0;
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        int c = 0;
-        if (head) {   // the first point of a voxel-run adds the whole run, in order, to what the earlier runs left
-          int b = nr;
-          while (a < b) { const int mid = (a + b) >> 1; if (s_key[mid] < key) a = mid + 1; else b = mid; }
-          if (a >= nr || s_key[a] != key) { li[LI_OVERFLOW] = 4; a = min(a, nr - 1); }   // voxel list out of sync (internal error)
-          acc = s_acc[a];
-          acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w; c = 1;
+    if (tid == 0) { s_next_j = 0; s_next_pos = -1; }
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    int cnt = 0;
+    while (true) {
+      __syncthreads();
+      if (tid == 0) {   // the next batch: sub-pieces in window order
+        int j = s_next_j, pos = s_next_pos, ns = 0, tot = 0;
+        while (j < nwin && ns < MA_JB && tot < MA_BCAP) {
+          const int lo = pos >= 0 ? pos : s_lo[j], hi = s_hi[j];
+          if (hi <= lo) { ++j; pos = -1; continue; }
+          const int take = min(hi - lo, MA_BCAP - tot);
+          s_sub_ent[ns] = s_ent[j]; s_sub_lo[ns] = lo; s_sub_off[ns] = tot;
+          tot += take; ++ns;
+          if (lo + take < hi) pos = lo + take; else { ++j; pos = -1; }
         }
-        // the followers of a run sit in the next lanes: wave shuffles instead of dependent loads
-        bool cont = head;
-        for (int sft = 1; sft < 64; ++sft) {
-          const u64 ks = __shfl_down(key, sft, 64);
-          const bool inwave = lane + sft < 64;
-          const bool more = cont && inwave && ks == key;
-          if (!__any(more)) break;
-          const float qx = __shfl_down(p.x, sft, 64), qy = __shfl_down(p.y, sft, 64), qz = __shfl_down(p.z, sft, 64), qw = __shfl_down(p.w, sft, 64);
-          if (more) { acc.x += qx; acc.y += qy; acc.z += qz; acc.w += qw; ++c; } else if (inwave) cont = false;   // the run ended inside the wavefront
-        }
-        if (head) {
-          int i2 = i + c;
-          if (cont && lane + c >= 64) {   // the run reached the edge of the wavefront: the rest one by one
-            while (i2 < hi) { const float4 q = pts[i2]; if (vkey_of(q, inv) != key) break; acc.x += q.x; acc.y += q.y; acc.z += q.z; acc.w += q.w; ++c; ++i2; }
+        s_sub_off[ns] = tot;
+        s_nsub = ns; s_next_j = j; s_next_pos = pos;
+      }
+      __syncthreads();
+      const int nsub = s_nsub;
+      if (nsub == 0) break;
+      const int btot = s_sub_off[nsub];
+      // ---- 1: stage the batch; thread t takes the MA_PT consecutive points from t * MA_PT (their loads are issued together).  Only the
+      // first point of a voxel-run looks its voxel up (the runs are sorted: the followers have the same key)
+      {
+        const int idx0 = tid * MA_PT;
+        int jj = 0;
+#pragma unroll
+        for (int u = 1; u < MA_JB; ++u) jj += (u < nsub && s_sub_off[u] <= idx0) ? 1 : 0;
+        float4 p[MA_PT], pprev;
+        int sj[MA_PT];
+        {
+          int j2 = jj;
+#pragma unroll
+          for (int u = 0; u < MA_PT; ++u) {
+            const int idx = min(idx0 + u, btot - 1);
+            while (j2 + 1 < nsub && idx >= s_sub_off[j2 + 1]) ++j2;
+            sj[u] = j2;
+            p[u] = run_pts(L, slot, m, s_sub_ent[j2])[s_sub_lo[j2] + (idx - s_sub_off[j2])];
           }
-          s_acc[a] = acc;
-          s_cnt[a] += c;
+          const int ip = min(idx0, btot - 1);
+          pprev = run_pts(L, slot, m, s_sub_ent[jj])[s_sub_lo[jj] + max(ip - s_sub_off[jj] - 1, 0)];
+        }
+        u64 kprev = vkey_of(pprev, inv);
+        int jprev = idx0 > s_sub_off[jj] ? jj : -1;   // -1: the thread's first point opens its sub-piece
+#pragma unroll
+        for (int u = 0; u < MA_PT; ++u) {
+          const int idx = idx0 + u;
+          if (idx < btot) {
+            const u64 key = vkey_of(p[u], inv);
+            const bool head = sj[u] != jprev || key != kprev;
+            int a = 0xFFFF;
+            if (head) {
+              int lo2 = 0, hi2 = nr;
+              while (lo2 < hi2) { const int mid = (lo2 + hi2) >> 1; if (s_key[mid] < key) lo2 = mid + 1; else hi2 = mid; }
+              if (lo2 >= nr || s_key[lo2] != key) { li[LI_OVERFLOW] = 4; lo2 = min(lo2, nr - 1); }   // voxel list out of sync (internal error)
+              a = lo2;
+              s_start[sj[u] * MAP_R + a] = (unsigned short)(idx + 1);
+              atomicOr(&s_mask[a], 1u << sj[u]);
+            }
+            s_pts[idx] = p[u];
+            s_rank[idx] = (unsigned short)a;
+            kprev = key; jprev = sj[u];
+          }
         }
       }
       __syncthreads();
+      // ---- 2: thread tid = voxel tid of the chunk.  ONE loop, one point per iteration; a thread moves on to its next sub-piece (the set bits
+      // of s_mask) inside the same iteration, so a wavefront runs max-over-lanes(points of the voxel in this batch) iterations — not the sum
+      // over the sub-pieces of the longest voxel-run in each.
+      if (tid < nr) {
+        unsigned msk = s_mask[tid];
+        s_mask[tid] = 0u;
+        int k = -1, end = 0;
+        while (true) {
+          if (k < 0) {
+            if (!msk) break;
+            const int jj = __ffs((int)msk) - 1;
+            msk &= msk - 1;
+            k = (int)s_start[jj * MAP_R + tid] - 1;
+            end = s_sub_off[jj + 1];
+          }
+          const float4 q = s_pts[k];
+          acc.x += q.x; acc.y += q.y; acc.z += q.z; acc.w += q.w; ++cnt; ++k;
+          if (!(k < end && s_rank[k] == 0xFFFFu)) k = -1;
+        }
+      }
     }
     float4* out = map_out(L, slot, m);
     const int cap = m == 0 ? L.map_cap_c : L.map_cap_s;
-    for (int r = tid; r < nr; r += MA_T) {
-      const float4 a = s_acc[r];
-      const float fn = (float)s_cnt[r];
-      if (r0 + r < cap) out[r0 + r] = make_float4(a.x / fn, a.y / fn, a.z / fn, a.w / fn);
+    if (tid < nr && r0 + tid < cap) {
+      const float fn = (float)cnt;
+      out[r0 + tid] = make_float4(acc.x / fn, acc.y / fn, acc.z / fn, acc.w / fn);
     }
   }
 }
@@ -482,9 +544,11 @@ __global__ void __launch_bounds__(MA_T) map_accum(DevCtx d, LmCtx L, MapWork W) 
 void launch_map_update(const DevCtx& d, const LmCtx& L, const MapWork& W, hipStream_t st) {
   static const bool cfg = hipFuncSetAttribute(reinterpret_cast<const void*>(map_update), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * MU_FCAP * 8) == hipSuccess;
   (void)cfg;
-  ALEGO_LAUNCH(map_update, dim3(2, d.n_launch), dim3(MU_T), (size_t)2 * MU_FCAP * 8, st, d, L, W);
+  static const int div = []() { const char* e = getenv("ALEGO_MU_DIV"); return e && atoi(e) > 0 ? atoi(e) : 4; }();   // slots per workgroup
+  ALEGO_LAUNCH(map_update, dim3(2, (d.n_launch + div - 1) / div), dim3(MU_T), (size_t)2 * MU_FCAP * 8, st, d, L, W);
 }
 void launch_map_accum(const DevCtx& d, const LmCtx& L, const MapWork& W, hipStream_t st) {
-  const int grid = std::min(1024, std::max(16, 4 * d.n_launch));
+  static const int gmax = []() { const char* e = getenv("ALEGO_MA_GRID"); return e && atoi(e) > 0 ? atoi(e) : 1024; }();
+  const int grid = std::min(gmax, std::max(16, 4 * d.n_launch));
   ALEGO_LAUNCH(map_accum, dim3(grid), dim3(MA_T), 0, st, d, L, W);
 }

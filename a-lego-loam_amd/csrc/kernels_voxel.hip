@@ -30,7 +30,9 @@ __device__ __forceinline__ unsigned vx_enc(float f) {
 }
 __device__ __forceinline__ bool vx_enabled(const VoxJob& J) { return J.enable == nullptr || *J.enable != 0; }
 
+#ifndef VX_SMALL_MAX
 #define VX_SMALL_MAX 8192      // jobs up to this many points are done by vox_small
+#endif
 
 // ---------------------------------------------------------------------------------------------------------
 // vox_big: one 1024-thread workgroup per job.

@@ -105,6 +105,7 @@ struct LmCtx {
   int total_cap;                 // kf_cap_s + kf_cap_o
   int gcap;                      // grid cells capacity per map
   int qcap;                      // residual rows capacity: kf_cap_c + total_cap
+  int solve_row_bytes;           // LDS lm_solve keeps its accepted rows in (ALEGO_LM_ROW_LDS overrides; rows beyond it are read from crows)
   int* li;                       // [slot][LI_COUNT]
   double* ld;                    // [slot][LD_COUNT]
   // staged inputs
@@ -147,7 +148,7 @@ struct LmCtx {
   int* knn;                                       // [slot][qcap][5] neighbour indices of every query (lm_knn -> lm_fit)
   // residual blocks
   double* blocks;                                 // [slot][qcap][8]: a/normal (3), b (3), d, type (0 = none)
-  double* crows;                                  // [slot][qcap][10]: the accepted rows only, packed for lm_solve: the 8 doubles above + the query point (float4)
+  double* crows;                                  // [slot][qcap][10]: accepted rows that do not fit lm_solve's LDS (all rows on the sharded path): the 8 doubles above + the query point (float4)
 };
 
 #endif

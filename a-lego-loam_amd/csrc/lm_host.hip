@@ -19,6 +19,8 @@ void launch_lm_concat(const DevCtx& d, const LmCtx& L, hipStream_t st);
 void launch_lm_total(const DevCtx& d, const LmCtx& L, hipStream_t st);
 void launch_lm_grid(const DevCtx& d, const LmCtx& L, hipStream_t st);
 int launch_lm_register(const DevCtx& d, const LmCtx& L, hipStream_t st, int (*allreduce)(void*, double*, size_t, hipStream_t), void* ar_ctx);
+size_t lm_solve_row_bytes_max();
+size_t lm_solve_row_bytes_default();
 void launch_lm_retransform(const DevCtx& d, const LmCtx& L, int ring, hipStream_t st);
 struct MapWork { int* items; int* count; int cap; };   // kernels_map.hip
 void launch_map_update(const DevCtx& d, const LmCtx& L, const MapWork& W, hipStream_t st);
@@ -81,6 +83,11 @@ LmHost* lm_host_create(const alego_params& P, const DevCtx& d, int n_slots, int 
   L.map_cap_c = L.K * L.kf_cap_c; L.map_cap_s = L.K * L.total_cap;
   L.gcap = n_slots <= 64 ? (1 << 20) : (1 << 18);
   L.qcap = L.kf_cap_c + L.total_cap;
+  {
+    const size_t mx = lm_solve_row_bytes_max();
+    const char* e = getenv("ALEGO_LM_ROW_LDS");   // development: a smaller budget sends rows through crows (tests: 0 = all of them)
+    L.solve_row_bytes = (int)(e ? std::min(mx, (size_t)std::max(0, atoi(e))) : std::min(mx, lm_solve_row_bytes_default()));
+  }
   const size_t B = n_slots;
   bool ok = true;
   ok = ok && A(lm, &L.li, B * LI_COUNT, err) && A(lm, &L.ld, B * LD_COUNT, err);
@@ -148,11 +155,12 @@ LmHost* lm_host_create(const alego_params& P, const DevCtx& d, int n_slots, int 
   //  mapping frames are expected per round, instead of a handful for the rare one — 64x2048: 1.85 -> see profiles/r02_geo_64x2048*)
   const bool big_scans = d.N > 8 * 8192;
   lm->vm[g].grid_small = 3 * ns + std::max(2, ns / 2);
+  if (const char* e = getenv("ALEGO_VOX_GRID_DIV")) { const int dv = std::max(1, atoi(e)); lm->vm[g].grid_small = std::max(2, lm->vm[g].grid_small / dv); lm->v2[g].grid_small = std::max(1, lm->v2[g].grid_small / dv); }
   lm->vm[g].grid_big = (!d.opt_map_merge || big_scans) ? std::max(2, ns / 2) : std::min(8, std::max(2, ns / 2));
   lm->v2[g].grid_big = big_scans ? std::max(2, ns / 2) : std::max(1, ns / 16);
   lm->vk[g].grid_small = 2; lm->vk[g].grid_big = 2;
   MapWork& W = lm->work[g];
-  W.cap = std::max(4096, 32 * ns);
+  W.cap = std::max(4096, 64 * ns);
   if (!A(lm, &W.items, (size_t)W.cap, err) || !A(lm, &W.count, 2, err)) { lm_host_destroy(lm); return nullptr; }
   }
   return lm;

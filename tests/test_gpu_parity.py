@@ -1506,6 +1506,32 @@ def test_sharded_registration_single_rank_equals_fused_solver(params_a):
     ha.close(); hb.close()
 
 
+def test_lm_solve_rows_in_lds_or_hbm_are_bit_identical(params_a, monkeypatch):
+    """lm_solve keeps the accepted residual rows in LDS up to a budget and reads the rest from HBM (`crows`).  Where a row lives must not
+    change a bit: the summation order is a function of the accepted-query lists alone.  Budgets 0 (every row from HBM), 20 000 B (a few
+    hundred rows on chip, the split inside both the edge and the plane list at some frames), the default and the whole CU."""
+    p = params_a
+    hs = []
+    for budget in ("0", "20000", None, "200000"):
+        if budget is None:
+            monkeypatch.delenv("ALEGO_LM_ROW_LDS", raising=False)
+        else:
+            monkeypatch.setenv("ALEGO_LM_ROW_LDS", budget)
+        hs.append(binding.Handle(p))
+    for k in range(30):
+        pts = synth.scan(p, k)
+        outs = [h.scan_process(pts, stages=7)[2] for h in hs]
+        infos = [h.debug_get("lm_info") for h in hs]
+        states = [h.debug_get("lm_state") for h in hs]
+        for j in range(1, len(hs)):
+            assert_bit_equal(outs[j]["params"], outs[0]["params"], f"scan {k} handle {j} LM params_")
+            assert_bit_equal(infos[j][6:12], infos[0][6:12], f"scan {k} handle {j} correspondences / solver summaries")
+            assert_bit_equal(states[j][27:43], states[0][27:43], f"scan {k} handle {j} params_ per outer iteration and costs")
+    assert infos[0][6] + infos[0][7] > 500, "the frames of this test have too few rows to split"
+    for h in hs:
+        h.close()
+
+
 def test_sharded_registration_slices_partition_the_queries(params_a):
     """The query slices of two ranks (contiguous slices of laser_corner_ds_ ++ laser_surf_total_ds_) are disjoint and
     cover what one rank accepts: the rows a rank contributes to the all-reduce are exactly its share of the unsharded rows."""

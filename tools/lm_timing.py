@@ -12,4 +12,4 @@ h.batch_run(0, 561, st)
 for i in range(4):
     h.batch_run(561 + i, 1, st)
     li = h.debug_get("lm_info"); ld = h.debug_get("lm_state")
-    print("run", li[2], "sum", hex(li[8]), hex(li[9]), "cycles pose/eval/reduce/propose/consume", ld[43:48].astype(np.int64))
+    print("run", li[2], "sum", hex(li[8]), hex(li[9]), "rows", li[6], li[7], "cycles (100 MHz wall clock ticks x ?; clock64) pose/rows/reduce/control/pack", ld[43:48].astype(np.int64))
