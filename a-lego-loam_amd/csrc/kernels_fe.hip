@@ -471,7 +471,9 @@ extern "C" void alego_fv_times(long long* out) { (void)hipMemcpyFromSymbol(out, 
 #else
 #define FV_TICK(k)
 #endif
-#define FV_NB 512
+#ifndef FV_NB
+#define FV_NB 256
+#endif
 #ifndef FV_BLOCK
 #define FV_BLOCK 256   // threads per ring
 #endif
@@ -481,6 +483,15 @@ extern "C" void alego_fv_times(long long* out) { (void)hipMemcpyFromSymbol(out, 
 // (ranking the ~300 runs of a ring by counting — every run sweeps all runs in LDS — was measured: 346 k -> 317 k scans/s.  The
 //  pipeline as a whole is VALU-issue bound; 90 k compares per ring cost more than the bucket tables' latency.)
 #define FV_LDS_PER_COL (FV_STAGE ? 26 : 10)
+// Points staged in LDS per ring: a ring of H columns holds ~0.6 H less_flat_scan points (the rest are empty, ground-only or picked cells); the
+// staging area is sized for 0.72 H of them and a fuller ring reads its tail from the L2 on every pass.  10 H + 16 x 0.72 H + 2.2 KB = 40.9 KB at
+// H = 1800: FOUR rings per CU instead of three (26 H + 4.2 KB = 51 KB).  Same run, scans/s: 512 buckets + everything staged 395 k; 512 buckets +
+// 0.64 H staged 406 k; 256 buckets + 0.72 H staged 407 k; nothing staged (three gathers through the L2 per point) 402 k.
+#ifndef FV_CAP_PCT
+#define FV_CAP_PCT 72
+#endif
+__host__ __device__ inline int fv_stage_cap(int H) { return FV_STAGE ? ((H * FV_CAP_PCT / 100 + 15) & ~15) : 0; }
+static size_t fv_lds_bytes(int H) { return (size_t)10 * H + (size_t)16 * fv_stage_cap(H); }
 #define FV_U 4    // gathers kept in flight per thread
 __global__ void __launch_bounds__(FV_BLOCK) fe_voxel(DevCtx d) {
   const int slot = blockIdx.y + d.slot0, ring = blockIdx.x, tid = threadIdx.x;
@@ -491,9 +502,10 @@ __global__ void __launch_bounds__(FV_BLOCK) fe_voxel(DevCtx d) {
   float4* out = d.st_lfds + ((size_t)slot * d.NS + ring) * d.H;
   const float4* seg = d.seg_lo + base;
   extern __shared__ __attribute__((aligned(16))) unsigned char fv_smem[];
-  float4* s_pt = reinterpret_cast<float4*>(fv_smem);                            // the ring's less_flat_scan points, gathered ONCE [H] (FV_STAGE)
-  unsigned char* fv2 = fv_smem + (FV_STAGE ? 16 : 0) * (size_t)d.H;
-  auto point = [&](int i) -> float4 { if (FV_STAGE) return s_pt[i]; return seg[lfs[i]]; };
+  float4* s_pt = reinterpret_cast<float4*>(fv_smem);                            // the ring's less_flat_scan points, gathered ONCE [cap] (FV_STAGE)
+  const int cap = fv_stage_cap(d.H);
+  unsigned char* fv2 = fv_smem + (size_t)16 * cap;
+  auto point = [&](int i) -> float4 { if (i < cap) return s_pt[i]; return seg[lfs[i]]; };
   uint32_t* s_key = reinterpret_cast<uint32_t*>(fv2);                           // voxel id per point      [H]
   uint32_t* s_rvid = s_key;                                                     // voxel id per run, compacted in place (run r <= its first point)
   uint16_t* s_rstart = reinterpret_cast<uint16_t*>(fv2 + 4 * (size_t)d.H);      // first point of the run  [H]
@@ -517,7 +529,7 @@ __global__ void __launch_bounds__(FV_BLOCK) fe_voxel(DevCtx d) {
     for (int u = 0; u < FV_U; ++u) pt[u] = seg[ix[u]];
 #pragma unroll
     for (int u = 0; u < FV_U; ++u) {   // (a clamped duplicate of the last point does not change min / max)
-      if (FV_STAGE && i0 + u * FV_BLOCK < n) s_pt[i0 + u * FV_BLOCK] = pt[u];   // every later pass reads the point from LDS: one global round trip instead of three
+      if (i0 + u * FV_BLOCK < min(n, cap)) s_pt[i0 + u * FV_BLOCK] = pt[u];   // every later pass reads the point from LDS: one global round trip instead of three
       mn[0] = fminf(mn[0], pt[u].x); mn[1] = fminf(mn[1], pt[u].y); mn[2] = fminf(mn[2], pt[u].z);
       mx[0] = fmaxf(mx[0], pt[u].x); mx[1] = fmaxf(mx[1], pt[u].y); mx[2] = fmaxf(mx[2], pt[u].z);
     }
@@ -759,7 +771,7 @@ int launch_stdsort_probe(const uint32_t* keys, int n, int depth_limit, int* pos_
 
 void launch_fe(const DevCtx& d, hipStream_t st) {
   // dynamic LDS above 64 KB has to be requested explicitly (fe_voxel: 26 B per column, horizon_scan <= 4096)
-  static const bool cfg = hipFuncSetAttribute(reinterpret_cast<const void*>(fe_voxel), hipFuncAttributeMaxDynamicSharedMemorySize, FV_LDS_PER_COL * FE_MAXH) == hipSuccess;
+  static const bool cfg = hipFuncSetAttribute(reinterpret_cast<const void*>(fe_voxel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fv_lds_bytes(FE_MAXH)) == hipSuccess;
   (void)cfg;
   ALEGO_LAUNCH(fe_curv, dim3((d.N + FE_CW - 1) / FE_CW, d.n_launch), dim3(FE_BLOCK), 0, st, d);
   // the longest sector holds at most ceil(H / n_sectors) + 1 points
@@ -780,6 +792,6 @@ void launch_fe(const DevCtx& d, hipStream_t st) {
   else if (d.P.sort_mode == 2) { ALEGO_LAUNCH((fe_pick<12, true>), dim3(d.NS, d.n_launch), dim3(64), (size_t)3 * d.H, st, d); }
   else if (sector_max <= 64 * 6) { ALEGO_LAUNCH((fe_pick<6, false>), dim3(d.NS, d.n_launch), dim3(64), (size_t)3 * d.H + extra, st, d); }
   else { ALEGO_LAUNCH((fe_pick<12, false>), dim3(d.NS, d.n_launch), dim3(64), (size_t)3 * d.H, st, d); }
-  ALEGO_LAUNCH(fe_voxel, dim3(d.NS, d.n_launch), dim3(FV_BLOCK), (size_t)FV_LDS_PER_COL * d.H, st, d);
+  ALEGO_LAUNCH(fe_voxel, dim3(d.NS, d.n_launch), dim3(FV_BLOCK), fv_lds_bytes(d.H), st, d);
   ALEGO_LAUNCH(fe_collect, dim3(d.n_launch), dim3(FC_T), 0, st, d);
 }

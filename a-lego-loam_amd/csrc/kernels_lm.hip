@@ -573,11 +573,13 @@ __global__ void __launch_bounds__(128) lm_fit(DevCtx d, LmCtx L) {
 // from there — same arithmetic, same order.  The compaction is STABLE in the query index (every thread takes a contiguous range of
 // queries), thread t evaluates edges t, t + T, ... and then planes t, t + T, ...: the summation order of the normal equations is a
 // function of the accepted-query lists alone, and lm_shard_eval (all rows in `crows`) follows the same order.
-// Measured on the 2048-stream bench (four stream groups share the chip), T threads x LDS for the rows: 512 x 158 KB 348 k scans/s (a single
-// stream's solve: 94 us against 150 us before), 512 x 48 KB 345 k, 256 x 158 KB 347 k, 256 x 96 KB 355 k, 256 x 48 KB 357 k, 256 x 0 354 k,
-// 1024 x any 287 k (128 VGPRs: spills); the old kernel 349 k.  Under load the footprint decides — 256 threads x 254 VGPRs is half a CU's
-// register file, and a workgroup that needs the whole CU's LDS waits for every other LDS user to leave — so the default keeps two thirds of the
-// rows on chip (96 KB) and streams the rest.
+// Measured on the 2048-stream bench (four stream groups share the chip), T threads x LDS for the rows, always against the other variants in
+// the same run (runs on different boxes differ by +-3 %).  While map_update still flooded the chip with empty 68 KB workgroups: 512 x 158 KB 348 k
+// scans/s, 256 x 158 KB 347 k, 256 x 96 KB 355 k, 256 x 48 KB 357 k, 256 x 0 354 k, 1024 x any 287 k (128 VGPRs: spills); the old kernel 349 k.
+// After that fix: 256 x 96 KB 408 k, 256 x 32 KB 410 k, 256 x 0 409 k, 256 x 158 KB 399 k; 512 x 96 KB against 256 x 96 KB: 396 k / 404 k.
+// The row budget does not matter except for the variant that needs a CU's whole LDS (it has to wait for every other LDS user to leave);
+// 256 threads x 254 VGPRs leave half a CU's register file to the other stream groups.  A single stream's solve takes 94 us with 512 threads,
+// ~130 us with 256, 150 us before.  Two thirds of the rows on chip remove two thirds of the kernel's HBM traffic: 256 threads, 96 KB.
 #ifndef LM_SOLVE_T
 #define LM_SOLVE_T 256
 #endif

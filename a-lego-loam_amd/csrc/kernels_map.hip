@@ -19,6 +19,7 @@
 //
 // HBM traffic per rebuild: the window's points once (16 B each) + the new / old run twice + the output, against ~21x that for the
 // radix sort of the concatenation (rocprofv3 FETCH/WRITE counters, round 1).
+#include <algorithm>
 #include <cstdlib>
 #include "dev_common.h"
 #include "lm_ctx.h"
@@ -96,8 +97,8 @@ __global__ void __launch_bounds__(MU_T) map_update(DevCtx d, LmCtx L, MapWork W)
   __shared__ int s_kr_tot[MU_T / 64];
   extern __shared__ __attribute__((aligned(16))) unsigned char mu_smem[];
   // A workgroup takes the slots blockIdx.y, blockIdx.y + gridDim.y, ...: only every sixth mapping frame changes its window, and a workgroup
-  // that has nothing to do still has to wait for 68 KB of LDS to start.  A quarter of the workgroups, each looking at four slots, leaves the
-  // LDS to the other stream groups' kernels.
+  // that has nothing to do still has to wait for 68 KB of LDS before it can start — 1024 of them per launch held the back stream of their
+  // group for 1.2 ms and took LDS from everybody else: 367 k -> 409 k scans/s with 32 slots per workgroup (launch_map_update).
   for (int sl = blockIdx.y; sl < d.n_launch; sl += gridDim.y) {
   const int slot = sl + d.slot0;
   int* li = lipm(L, slot);
@@ -544,8 +545,11 @@ __global__ void __launch_bounds__(MA_T) map_accum(DevCtx d, LmCtx L, MapWork W) 
 void launch_map_update(const DevCtx& d, const LmCtx& L, const MapWork& W, hipStream_t st) {
   static const bool cfg = hipFuncSetAttribute(reinterpret_cast<const void*>(map_update), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * MU_FCAP * 8) == hipSuccess;
   (void)cfg;
-  static const int div = []() { const char* e = getenv("ALEGO_MU_DIV"); return e && atoi(e) > 0 ? atoi(e) : 4; }();   // slots per workgroup
-  ALEGO_LAUNCH(map_update, dim3(2, (d.n_launch + div - 1) / div), dim3(MU_T), (size_t)2 * MU_FCAP * 8, st, d, L, W);
+  // slots per workgroup (2048-stream bench, scans/s): 1: 367 k, 2: 388 k, 4: 396 k, 8: 403 k, 16: 405-408 k, 32: 409 k, 64: 409 k; at least 16 workgroups
+  // per map where there are that many slots, so that a small handle's rebuilds are not serialised
+  static const int div = []() { const char* e = getenv("ALEGO_MU_DIV"); return e && atoi(e) > 0 ? atoi(e) : 32; }();
+  const int gy = std::max(std::min(d.n_launch, 16), (d.n_launch + div - 1) / div);
+  ALEGO_LAUNCH(map_update, dim3(2, gy), dim3(MU_T), (size_t)2 * MU_FCAP * 8, st, d, L, W);
 }
 void launch_map_accum(const DevCtx& d, const LmCtx& L, const MapWork& W, hipStream_t st) {
   static const int gmax = []() { const char* e = getenv("ALEGO_MA_GRID"); return e && atoi(e) > 0 ? atoi(e) : 1024; }();
