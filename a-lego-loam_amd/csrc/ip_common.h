@@ -103,6 +103,62 @@ DEV_INLINE int ip_point_cell(const DevCtx& d, const float4 p, bool* valid_out) {
   return cell;
 }
 
+// Quick decision for ip_fused's first pass.  The row / column of a point is the cell of its TRUE elevation / azimuth unless that angle lies
+// within the reference's own rounding (~3e-5 cells) of a cell boundary, so a cheap estimate of both angles whose error is bounded decides every
+// point that is not NEAR a boundary; the others (a few per cent of a real scan) are deferred to ip_point_cell (table refinement or the
+// reference expressions).  Error budget of the estimate: the odd degree-11 polynomial for atan on [0, 1] is within 1.8e-6 rad of atan in f32
+// (tests/test_oracle.py::test_quick_projection_polynomial_bound evaluates it on 2M arguments), v_rcp / v_sqrt (1 ulp) and the quadrant fix-ups
+// add < 1.5e-6 rad, the product with 180 / (pi res) two roundings of a value <= 1.5 H: 4e-6 rad and 4e-7 H cells in total are charged, twice
+// over, in the margins below (at least 0.02 columns / 0.005 rows).  Nothing here has to be bit-exact, so FMA contraction is allowed.
+// Returns true when decided: *cell_out = row * H + col, or -1 when the point has no cell (filtered, non-finite, outside the image).
+DEV_INLINE bool ip_point_quick(const DevCtx& d, const float4 p, float mr, float mc, bool* valid_out, int* cell_out) {
+  const alego_params& P = d.P;
+  const bool finite = isfinite(p.x) && isfinite(p.y) && isfinite(p.z);
+  bool valid = finite || P.input_is_dense != 0;
+  if (valid && P.near_filter) {
+    const float th = (float)P.near_thres;
+    if (p.x * p.x + p.y * p.y + p.z * p.z < th * th) valid = false;  // IP.cpp:91 (same expression as ip_point_cell)
+  }
+  *valid_out = valid;
+  *cell_out = -1;
+  if (!(valid && finite)) return true;
+  if ((d.ip_fast & 3) != 3) return false;
+  bool ok;
+  int rfl, col;
+  {
+#pragma clang fp contract(fast)
+    const float h2 = p.x * p.x + p.y * p.y, hf = __builtin_amdgcn_sqrtf(h2);
+    const float t = p.z * __builtin_amdgcn_rcpf(hf), t2 = t * t;
+    ok = hf > 1e-3f && hf < 1e6f && fabsf(t) < 0.6f;
+    const float a = t * (0.99997726f + t2 * (-0.33262347f + t2 * (0.19354346f + t2 * (-0.11643287f + t2 * (0.05265332f + t2 * -0.01172120f)))));
+    const float r0 = (a * 57.29577951f + (float)P.ang_bottom) * (float)d.inv_res_y + 0.5f;
+    const float rf = floorf(r0), fr = r0 - rf;
+    ok = ok && fr >= mr && fr <= 1.0f - mr && rf >= -64.0f && rf <= 4096.0f;
+    rfl = (int)rf;
+    const float ax = fabsf(p.x), ay = fabsf(p.y), mn = fminf(ax, ay), mx = fmaxf(ax, ay);
+    ok = ok && mx > 1e-3f && mx < 1e6f;
+    const float u = mn * __builtin_amdgcn_rcpf(mx), u2 = u * u;
+    float b = u * (0.99997726f + u2 * (-0.33262347f + u2 * (0.19354346f + u2 * (-0.11643287f + u2 * (0.05265332f + u2 * -0.01172120f)))));
+    b = ay > ax ? 1.57079633f - b : b;
+    b = p.x < 0.0f ? 3.14159265f - b : b;
+    b = p.y < 0.0f ? -b : b;
+    const float c0 = (6.28318531f - b) * (57.29577951f * (float)d.inv_res_x);   // (-atan2f(y, x) + 2 pi) * 180 / pi / ang_res_x (:87-95)
+    const float cf = floorf(c0), fc = c0 - cf;
+    ok = ok && fc >= mc && fc <= 1.0f - mc && cf >= 0.0f && cf < (float)(2 * d.H);
+    col = (int)cf;
+  }
+  if (!ok) return false;   // (a NaN anywhere fails a comparison above)
+  const int row = rfl >= 0 ? rfl : (rfl == -1 ? 0 : -1);   // (int)r truncates: r in (-1, 1) is row 0
+  if (col >= d.H) col -= d.H;
+  if (row >= 0 && row < d.NS && col >= 0 && col < d.H) *cell_out = col + row * d.H;
+  return true;
+}
+// the margins of ip_point_quick (cells) for this sensor
+DEV_INLINE void ip_quick_margins(const DevCtx& d, float* mr, float* mc) {
+  *mr = fmaxf(0.005f, 8e-6f * 57.29577951f * (float)d.inv_res_y + 1e-5f);
+  *mc = fmaxf(0.02f, 8e-6f * 57.29577951f * (float)d.inv_res_x + 8e-7f * (float)d.H);
+}
+
 // ground test of two vertically adjacent cells (imageProjection.cpp:111-131): |deg(atan2(dz, hypot(dx, dy))) - mount| < thres
 // <=> tan(lo) h < dz < tan(hi) h; decided by the two signed margins unless one of them is within 1e-9 (relative) of zero, where
 // the reference expression decides.  fx, fy, fz = the f32 differences upper - lower.

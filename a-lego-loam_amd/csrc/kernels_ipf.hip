@@ -25,6 +25,9 @@
 #include "prof.h"
 
 #define IPF2_T 1024
+#ifndef IPF_QUICK
+#define IPF_QUICK 1   // 0: every point through ip_point_cell in the first pass (the round-3 kernel before the two-pass projection)
+#endif
 // (Curvature + occlusion marks as a last phase of this kernel was measured and removed: the phase re-reads cloud_info through the L2 in a
 //  workgroup that owns its CU alone — 16 wavefronts, nothing to hide the round trips behind — 29 us per stream against 24 us of CU time
 //  for the stand-alone fe_curv launch, which runs at full occupancy.  A fat workgroup must not wait on global memory.)
@@ -38,6 +41,7 @@ struct IpfShared {
   int cnt[3][IPF2_ROWS * IPF2_NW];     // per (row, wavefront): kept cells, outliers, feasible roots -> exclusive prefix in row-major order
   int wtot[3][4];
   int tot[3];
+  int nlist;                            // phase A: points deferred to the exact projection
 };
 
 #ifdef ALEGO_TIMING
@@ -71,11 +75,19 @@ __global__ void __launch_bounds__(IPF2_T) ip_fused(DevCtx d, int ring_pos, int k
   __shared__ IpfShared S;
 
   // ---------------- phase A: projection ----------------
+  // Pass 1 decides every point that is not near a cell boundary from a cheap estimate of its two angles (ip_point_quick: ~70 instructions
+  // against ~160 for ip_point_cell) and defers the others to a list in LDS (the column-mask area, free until phase B); pass 2 runs
+  // ip_point_cell on the list with all lanes busy.  Last writer wins by atomicMax on the point index, so the order of the passes is immaterial.
   IPF_TICK(0);
   for (int v = tid; v < N; v += IPF2_T) own32[v] = 0u;
+  if (tid == 0) S.nlist = 0;
   __syncthreads();
   const int n = scan_count(d, slot, ring_pos);
   const float4* pts = scan_pts(d, slot, ring_pos);
+  int* s_list = reinterpret_cast<int*>(fcol);
+  const int list_cap = 2 * H;   // 8 H bytes
+  float qmr, qmc;
+  ip_quick_margins(d, &qmr, &qmc);
   int vmin = 0x7fffffff, vmax = -1, nvalid = 0;
 #pragma unroll 1
   for (int i0 = tid; i0 < n; i0 += IPF2_T * 4) {
@@ -85,12 +97,39 @@ __global__ void __launch_bounds__(IPF2_T) ip_fused(DevCtx d, int ring_pos, int k
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int i = i0 + u * IPF2_T;
-      if (i < n) {
-        bool valid;
-        const int cell = ip_point_cell(d, pin[u], &valid);
-        if (cell >= 0) atomicMax(&own32[cell], (unsigned)(i + 1));   // later points overwrite earlier ones (:102-103)
-        if (valid) { vmin = min(vmin, i); vmax = max(vmax, i); ++nvalid; }
+      bool valid = false, defer = false;
+      int cell = -1;
+#if IPF_QUICK
+      if (i < n) defer = !ip_point_quick(d, pin[u], qmr, qmc, &valid, &cell);
+#else
+      if (i < n) cell = ip_point_cell(d, pin[u], &valid);
+#endif
+      if (cell >= 0) atomicMax(&own32[cell], (unsigned)(i + 1));   // later points overwrite earlier ones (:102-103)
+      if (valid) { vmin = min(vmin, i); vmax = max(vmax, i); ++nvalid; }
+      const unsigned long long dm = __ballot(defer);
+      if (dm) {   // wavefront-aggregated append
+        int base = 0;
+        if (lane == 0) base = atomicAdd(&S.nlist, (int)__popcll(dm));
+        base = __shfl(base, 0, 64);
+        if (defer) {
+          const int pos = base + (int)__popcll(dm & ((1ull << lane) - 1ull));
+          if (pos < list_cap) s_list[pos] = i;   // (a full list is dealt with below)
+        }
       }
+    }
+  }
+  __syncthreads();
+  {
+    // the deferred points; when the list overflowed (a scan with more than an eighth of its points on cell boundaries) every point is projected
+    // again, exactly — atomicMax makes that idempotent for the ones pass 1 had decided
+    const bool all = S.nlist > list_cap;
+    const int nl = all ? n : S.nlist;
+#pragma unroll 1
+    for (int j = tid; j < nl; j += IPF2_T) {
+      const int i = all ? j : s_list[j];
+      bool v2;
+      const int c2 = ip_point_cell(d, pts[i], &v2);
+      if (c2 >= 0) atomicMax(&own32[c2], (unsigned)(i + 1));
     }
   }
   IPF_TICK(1);

@@ -110,7 +110,8 @@ void alego_synth_pose(int stream, long scan_index, double* pose4) {
 
 // flags: bit0 = azimuth jitter U(-0.45,0.45)*ang_res_x (stresses the atan2f cell
 // assignment); bit1 = emit NaN points for rays without a return (exercises the
-// NaN filter, imageProjection.cpp:58-59) instead of dropping them.
+// NaN filter, imageProjection.cpp:58-59) instead of dropping them; bit2 = azimuth uniform over the whole column (what a real
+// spinning sensor delivers: ip_fused's quick projection defers the points near a column boundary to the exact one).
 // Output order: ring-major (ring 0 all columns, ring 1 ...).  Returns the point count.
 int alego_synth_scan(const alego_params* P, int stream, long scan_index, int flags,
                      alego_point* out, int cap) {
@@ -127,6 +128,7 @@ int alego_synth_scan(const alego_params* P, int stream, long scan_index, int fla
       double u1 = rng.uniform(), u2 = rng.uniform(), u3 = rng.uniform();
       double az = -(j + 0.5) * P->ang_res_x;
       if (flags & 1) az += (u3 - 0.5) * 0.9 * P->ang_res_x;
+      if (flags & 4) az += (u3 - 0.5) * P->ang_res_x;   // azimuth anywhere in the column: ~4 % of the points within 0.02 columns of a boundary
       az *= (kPi / 180.0);
       const double ds[3] = {cphi * std::cos(az), cphi * std::sin(az), sphi};  // sensor frame
       const double dw[3] = {cyaw * ds[0] - syaw * ds[1], syaw * ds[0] + cyaw * ds[1], ds[2]};

@@ -106,12 +106,12 @@ def pmc_traffic(kernel, streams_per_launch):
         return None
 
 
-def make_bags(p, n_bags, first_stream):
+def make_bags(p, n_bags, first_stream, flags=0):
     """One T0 lap (560 scans) of each of `n_bags` streams, on the host."""
     jobs = [(b, k) for b in range(n_bags) for k in range(LAP)]
     bags = [[None] * LAP for _ in range(n_bags)]
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
-        for (b, k), a in zip(jobs, ex.map(lambda bk: synth.scan(p, bk[1], stream=first_stream + bk[0]), jobs)):
+        for (b, k), a in zip(jobs, ex.map(lambda bk: synth.scan(p, bk[1], stream=first_stream + bk[0], flags=flags), jobs)):
             bags[b][k] = a
     return bags
 
@@ -338,6 +338,7 @@ def main():
     ap.add_argument("--shard-registration", action="store_true",
                     help="BASELINE config 5: every rank replays the SAME streams and each scan-to-map registration is split over the ranks "
                          "(alego_dist_init: query slices + one ncclAllReduce of the normal equations per solver evaluation); strong scaling")
+    ap.add_argument("--scan-flags", type=int, default=0, help="synthetic scan generator flags (synth.cpp): 1 azimuth jitter +-0.45 column, 2 NaN returns, 4 azimuth uniform over the column")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-check", action="store_true", help="skip timed_handle_check (slots of the timed handle against one-slot replicas)")
@@ -368,7 +369,7 @@ def main():
         p.kf_cap_surf, p.kf_cap_outlier = args.kf_cap, max(256, args.kf_cap // 4)
     B = args.streams
     shard = args.shard_registration
-    bags = make_bags(p, args.bags, first_stream=0 if shard else rank * args.bags)   # config 5: every rank holds the same streams
+    bags = make_bags(p, args.bags, first_stream=0 if shard else rank * args.bags, flags=args.scan_flags)   # config 5: every rank holds the same streams
     if shard:
         os.environ["ALEGO_STREAM_GROUPS"] = "1"   # the collectives of one communicator must not overlap: one stream group
     h = binding.Handle(p, device=local, n_slots=B, ring_len=1)
@@ -420,7 +421,8 @@ def main():
         "config": {"workload": f"{ns}x{hs} S0/T0 bag-equivalent replay (one 560-scan lap per bag, replayed cyclically), IP->LO->LM with a "
                                f"{p.recent_keyframe_num}-key-frame local map, {B} independent streams per GPU on {args.bags} resident bags "
                                f"(one scan per stream per step)",
-                   "streams_per_gpu": B, "bags_per_gpu": args.bags, "bag_scans": LAP, "primed_scans": args.prime, "parallelism": (f"registration sharded x{world} (RCCL all-reduce of the normal equations)" if shard else f"streams x{world}")},
+                   "streams_per_gpu": B, "bags_per_gpu": args.bags, "bag_scans": LAP, "primed_scans": args.prime, "parallelism": (f"registration sharded x{world} (RCCL all-reduce of the normal equations)" if shard else f"streams x{world}"),
+                   "scan_flags": args.scan_flags},
     }
     # every rank reports its own rate; rank 0 prints them (the driver computes scaling from `value`, this is for the reader)
     per_rank = D.gather_floats(B * args.steps / dt_local, dist, device="cuda")

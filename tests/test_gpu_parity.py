@@ -94,6 +94,38 @@ def test_ip_points_on_cell_boundaries(params_a):
     h.close()
 
 
+@pytest.mark.parametrize("geom", [(16, 1800), (16, 1024), (12, 2048)])
+def test_ip_quick_projection_margins(geom):
+    """ip_fused decides a point's cell from a cheap estimate of its angles unless the estimate lies within a margin (0.02 columns / 0.005
+    rows at 16 x 1800) of a cell boundary; those points are deferred to the exact projection.  Points spread over both sides of the margins,
+    points anywhere in a column (what a spinning sensor delivers), random directions (most rows off-centre, outside the image, near the poles)
+    and huge / tiny ranges must all land in the reference's cell."""
+    p = synth.default_params(*geom)
+    h, o = binding.Handle(p), O.Oracle(p)
+    rng = np.random.default_rng(23)
+    n = p.n_scan * p.horizon_scan
+    _ip_compare(h, o, synth.scan(p, 9, flags=4), "azimuth uniform over the column")
+    # fractional positions concentrated around the margins on either side of a boundary
+    fc = rng.choice([0.0, 1.0], n) + rng.choice([-1.0, 1.0], n) * rng.uniform(0.0, 0.06, n)
+    fr = rng.choice([0.0, 1.0], n) + rng.choice([-1.0, 1.0], n) * rng.uniform(0.0, 0.02, n)
+    cols = rng.integers(0, 2 * p.horizon_scan, n) + fc
+    rows = rng.integers(-1, p.n_scan + 1, n) + fr
+    half = n // 2
+    fr2 = rows.copy(); fr2[:half] = rng.integers(0, p.n_scan, half) + 0.5       # first half: rows at the beam centres, columns near the margins
+    fc2 = cols.copy(); fc2[half:] = rng.integers(0, p.horizon_scan, n - half) + 0.5
+    az = -(fc2 * p.ang_res_x * np.pi / 180.0 - 2 * np.pi)
+    el = ((fr2 - 0.5) * p.ang_res_y - p.ang_bottom) * np.pi / 180.0
+    r = rng.uniform(1.0, 80.0, n)
+    pts = np.zeros((n, 4), np.float32)
+    pts[:, 0] = r * np.cos(el) * np.cos(az); pts[:, 1] = r * np.cos(el) * np.sin(az); pts[:, 2] = r * np.sin(el)
+    _ip_compare(h, o, pts, "either side of the margins")
+    v = rng.normal(size=(n, 3)); v /= np.linalg.norm(v, axis=1, keepdims=True)
+    rr = np.exp(rng.uniform(np.log(1e-3), np.log(1e5), n))                      # 1 mm .. 100 km
+    pts = np.zeros((n, 4), np.float32); pts[:, :3] = (v * rr[:, None]).astype(np.float32)
+    _ip_compare(h, o, pts, "random directions, ranges over eight decades")
+    h.close()
+
+
 def test_ip_options(params_a):
     p = params_a.copy()
     p.near_filter, p.laser_type = 1, 1  # IP.cpp: removeClosedPointCloud + RFANS ring table

@@ -324,3 +324,55 @@ def test_motion_deskew_restatement(params_a):
     assert err < 2e-3, err                 # the IMU's yaw is linear between 100 Hz samples; f32 rotation of points up to 50 m away
     assert np.abs(und[:, :3] - seg[:, :3]).max() > 0.05, "the cloud did move"
     assert_bit_equal(und[0], seg[0], "the first point defines the start pose and is not touched (:641-647)")
+
+
+def test_quick_projection_polynomial_bound(params_a):
+    """The error budget of ip_fused's quick projection (csrc/ip_common.h: ip_point_quick): the f32 evaluation of its odd degree-11 polynomial is
+    within 1.8e-6 rad of atan on [0, 1], and the whole angle estimate — reduction to [0, 1], quadrant fix-ups, f32 roundings; 1 ulp is charged for
+    the hardware's rcp / sqrt — stays inside the 4e-6 rad the margins are built from (twice over).  With that budget a point whose estimated
+    column / row lies outside the margins lands in the reference's cell: checked here against the oracle's projection on random directions."""
+    c = [np.float32(v) for v in (0.99997726, -0.33262347, 0.19354346, -0.11643287, 0.05265332, -0.01172120)]
+    def poly(u):
+        u2 = u * u
+        return u * (c[0] + u2 * (c[1] + u2 * (c[2] + u2 * (c[3] + u2 * (c[4] + u2 * c[5])))))
+    u = np.linspace(0.0, 1.0, 2_000_001).astype(np.float32)
+    assert np.abs(poly(u).astype(np.float64) - np.arctan(u.astype(np.float64))).max() < 1.8e-6
+    rng = np.random.default_rng(5)
+    n = 1_000_000
+    v = rng.normal(size=(n, 3)); v /= np.linalg.norm(v, axis=1, keepdims=True)
+    pts = (v * rng.uniform(1.0, 100.0, n)[:, None]).astype(np.float32)
+    x, y, z = pts[:, 0], pts[:, 1], pts[:, 2]
+    one = np.float32(1.0)
+    ax, ay = np.abs(x), np.abs(y)
+    mn, mx = np.minimum(ax, ay), np.maximum(ax, ay)
+    b = poly(mn * (one / mx))
+    b = np.where(ay > ax, np.float32(1.57079633) - b, b)
+    b = np.where(x < 0, np.float32(3.14159265) - b, b)
+    b = np.where(y < 0, -b, b)
+    az = np.arctan2(y.astype(np.float64), x.astype(np.float64))
+    assert np.abs(b.astype(np.float64) - az).max() < 3.0e-6            # azimuth estimate (before the 1 ulp of rcp: 1.2e-7 relative)
+    hf = np.sqrt(x * x + y * y)
+    ok = np.abs(z) < np.float32(0.6) * hf
+    t = (z * (one / hf))[ok]
+    el = np.arctan2(z.astype(np.float64), np.hypot(x.astype(np.float64), y.astype(np.float64)))[ok]
+    assert np.abs(poly(t).astype(np.float64) - el).max() < 2.5e-6      # elevation estimate where the quick path is taken (|t| < 0.6)
+    # end to end against the oracle's cells: quick decision = floor of the estimated (row + 0.5, column) outside the margins
+    p = params_a
+    H, NS = p.horizon_scan, p.n_scan
+    mr = max(0.005, 8e-6 * 57.29577951 / p.ang_res_y + 1e-5); mc = max(0.02, 8e-6 * 57.29577951 / p.ang_res_x + 8e-7 * H)
+    r0 = (poly(z * (one / hf)) * np.float32(57.29577951) + np.float32(p.ang_bottom)) * np.float32(1.0 / p.ang_res_y) + np.float32(0.5)
+    c0 = (np.float32(6.28318531) - b) * (np.float32(57.29577951) * np.float32(1.0 / p.ang_res_x))
+    fr, fc = r0 - np.floor(r0), c0 - np.floor(c0)
+    decided = ok & (fr >= mr) & (fr <= 1 - mr) & (fc >= mc) & (fc <= 1 - mc)
+    rfl = np.nan_to_num(np.floor(r0), nan=-100.0, posinf=1e6, neginf=-1e6).astype(np.int64)
+    row = np.where(rfl >= 0, rfl, np.where(rfl == -1, 0, -1))
+    col = np.nan_to_num(np.floor(c0), nan=-100.0, posinf=1e6, neginf=-1e6).astype(np.int64); col = np.where(col >= H, col - H, col)
+    quick = np.where((row >= 0) & (row < NS) & (col >= 0) & (col < H), col + row * H, -1)
+    # the reference expressions (imageProjection.cpp:79-97) in double on the f32-rounded libm results, as the oracle evaluates them
+    va = np.arctan2(z, np.sqrt(x.astype(np.float64) ** 2 + y.astype(np.float64) ** 2).astype(np.float32)).astype(np.float32).astype(np.float64) * 180.0
+    rr = ((va / np.pi + p.ang_bottom) / p.ang_res_y + 0.5); rrow = np.trunc(rr).astype(np.int64)
+    ha = (-(np.arctan2(y, x).astype(np.float32)).astype(np.float64) + 2 * np.pi) * 180.0
+    rcol = np.trunc((ha / np.pi) / p.ang_res_x).astype(np.int64); rcol = np.where(rcol >= H, rcol - H, rcol)
+    ref = np.where((rrow >= 0) & (rrow < NS) & (rr > -1) & (rcol >= 0) & (rcol < H), rcol + rrow * H, -1)
+    assert decided.mean() > 0.3
+    assert np.array_equal(quick[decided], ref[decided])
