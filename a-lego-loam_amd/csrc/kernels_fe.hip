@@ -490,7 +490,13 @@ extern "C" void alego_fv_times(long long* out) { (void)hipMemcpyFromSymbol(out, 
 #ifndef FV_CAP_PCT
 #define FV_CAP_PCT 72
 #endif
-__host__ __device__ inline int fv_stage_cap(int H) { return FV_STAGE ? ((H * FV_CAP_PCT / 100 + 15) & ~15) : 0; }
+// Wide images (H = 4000: the key arrays alone are 40 KB) stage less or nothing, so that the workgroup stays near 40 KB: a ring of 16 x 4000 with
+// everything staged took 88 KB — one workgroup per CU, fe_voxel a quarter of that geometry's device time.
+__host__ __device__ inline int fv_stage_cap(int H) {
+  if (!FV_STAGE) return 0;
+  const int by_pct = (H * FV_CAP_PCT / 100 + 15) & ~15, by_lds = (40960 - 2200 - 10 * H) / 16;
+  return by_lds <= 0 ? 0 : (by_pct < by_lds ? by_pct : (by_lds & ~15));
+}
 static size_t fv_lds_bytes(int H) { return (size_t)10 * H + (size_t)16 * fv_stage_cap(H); }
 #define FV_U 4    // gathers kept in flight per thread
 __global__ void __launch_bounds__(FV_BLOCK) fe_voxel(DevCtx d) {
