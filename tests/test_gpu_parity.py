@@ -210,6 +210,30 @@ def test_fe_lo_teacher_forced(geom, nscan, box_lds, monkeypatch):
     h.close()
 
 
+@pytest.mark.parametrize("geom", [(16, 1800), (16, 1024), (6, 256)])
+def test_fe_voxel_rings_fuller_than_the_lds_staging(geom):
+    """fe_voxel stages 0.72 H points of a ring in LDS and reads the rest of a fuller ring from the L2 on every pass.  A closed, bumpy
+    wall all around the sensor (no ground, no empty cells: every ring keeps all H columns) puts ~28 % of every ring's less_flat_scan
+    beyond the staging area; the per-ring VoxelGrid output, the picks and everything before them must still equal the oracle's, bit for bit."""
+    p = synth.default_params(*geom)
+    h, o = binding.Handle(p), O.Oracle(p)
+    n_scan, H = geom
+    rows, cols = np.meshgrid(np.arange(n_scan), np.arange(H), indexing="ij")
+    for k in range(2):
+        el = np.deg2rad(-p.ang_bottom + rows * p.ang_res_y)
+        az = -np.deg2rad((cols + 0.5) * p.ang_res_x)
+        r = 12.0 + 0.8 * np.sin(cols / 60.0 + k) + 0.3 * np.cos(rows * 0.4) + 0.004 * ((cols * 7 + rows * 3) % 5)   # smooth enough to stay ONE segment
+        pts = np.zeros((n_scan * H, 4), np.float32)
+        pts[:, 0] = (r * np.cos(el) * np.cos(az)).ravel(); pts[:, 1] = (r * np.cos(el) * np.sin(az)).ravel(); pts[:, 2] = (r * np.sin(el)).ravel()
+        seg = _ip_compare(h, o, pts, f"{geom} wall {k}")
+        assert seg["seg"].shape[0] > 0.9 * n_scan * H, "the wall was meant to keep (almost) every cell"
+        h.set_lo_params(o.get("lo_params"))
+        o.lo()
+        flags, feat, odom = h.lo_process(seg)
+        _fe_compare(h, o, feat, f"{geom} wall {k}")
+    h.close()
+
+
 def test_fe_lo_standalone_node_variants(params_a):
     """LO.cpp's variants of the nodelet code: f32 occlusion test (LO.cpp:203-204) and the other sector split (:245-249)."""
     p = params_a.copy()
