@@ -498,6 +498,17 @@ def main():
         if roofs:
             out["roofline"] = dict(roofs[0], map_rebuilds_per_launch=round(rebuilds / max(kern[roofs[0]["kernel"]]["launches"], 1), 2))
             out["roofline_top3"] = roofs
+        # the device's counterpart of cpu_baseline.lo_opt_ms_per_frame (the reference README's "optimisation" time per frame, README.md:50,54):
+        # LaserOdometry's two ceres::Solve calls = two lo_solve launches per scan, each advancing `per` streams
+        los = [k for k in kern if k.startswith("(lo_solve_t") or k.startswith("lo_solve_t")]
+        if los:
+            name = los[0]
+            lo = {"kernel": name, "launches_per_frame": 2, "streams_per_launch": per,
+                  "ms_per_launch_under_load": round(kern[name]["avg_us"] / 1e3, 4),
+                  "ms_per_frame_amortised": round(2 * kern[name]["avg_us"] / 1e3 / per, 6)}
+            if iso is not None and name in iso:
+                lo["ms_per_launch_isolated"] = round(iso[name]["avg_us"] / 1e3, 4)
+            out["lo_opt_device"] = lo
     # RCCL prints its version banner through C stdio, which is buffered when stdout is a pipe / file: every rank pushes it out,
     # then rank 0 prints the JSON line after the barrier, so that it is the last line of the job's stdout
     try:
