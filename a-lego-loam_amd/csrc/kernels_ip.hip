@@ -28,24 +28,44 @@ __global__ void __launch_bounds__(IP_BLOCK) ip_project(DevCtx d, int ring_pos) {
   const int slot = blockIdx.y + d.slot0;
   const int i0 = blockIdx.x * IP_BLOCK * IP_PW + threadIdx.x;   // IP_PW points per thread, their loads in flight together
   const int n = scan_count(d, slot, ring_pos);
-  const alego_params& P = d.P;
   const float4* in = scan_pts(d, slot, ring_pos);
   float4 pin[IP_PW];
 #pragma unroll
   for (int u = 0; u < IP_PW; ++u) pin[u] = in[min(i0 + u * IP_BLOCK, max(n - 1, 0))];
   int vmin = 0x7fffffff, vmax = -1, nvalid = 0;
+  // Two passes, as in ip_fused: ip_point_quick decides the points away from cell boundaries from an estimate of their angles, the others go
+  // onto the workgroup's list in LDS and through ip_point_cell afterwards, all lanes busy (last writer wins by atomicMax: order immaterial).
+  __shared__ int s_def[IP_BLOCK * IP_PW];
+  __shared__ int s_ndef;
+  if (threadIdx.x == 0) s_ndef = 0;
+  __syncthreads();
+  float qmr, qmc;
+  ip_quick_margins(d, &qmr, &qmc);
+  const int lane = lane_id();
 #pragma unroll
   for (int u = 0; u < IP_PW; ++u) {
-  const int i = i0 + u * IP_BLOCK;
-  bool valid = false;
-  if (i < n) {
-    const float4 p = pin[u];
-    const int cell = ip_point_cell(d, p, &valid);
+    const int i = i0 + u * IP_BLOCK;
+    bool valid = false, defer = false;
+    int cell = -1;
+    if (i < n) defer = !ip_point_quick(d, pin[u], qmr, qmc, &valid, &cell);
     if (cell >= 0)
       atomicMax(&d.owner[(size_t)slot * d.N + cell], IP_OWNER_TAG | i);  // later points overwrite earlier ones (:102-103);
         // whatever the previous scan left in the cell (a plain index or -1, see ip_front) loses against a tagged entry: no reset pass
+    if (valid) { vmin = min(vmin, i); vmax = max(vmax, i); ++nvalid; }
+    const unsigned long long dm = __ballot(defer);
+    if (dm) {
+      int b0 = 0;
+      if (lane == 0) b0 = atomicAdd(&s_ndef, (int)__popcll(dm));
+      b0 = __shfl(b0, 0, 64);
+      if (defer) s_def[b0 + (int)__popcll(dm & ((1ull << lane) - 1ull))] = i;   // (at most IP_BLOCK * IP_PW entries: one per point of the workgroup)
+    }
   }
-  if (valid) { vmin = min(vmin, i); vmax = max(vmax, i); ++nvalid; }
+  __syncthreads();
+  for (int j = threadIdx.x; j < s_ndef; j += IP_BLOCK) {
+    const int i = s_def[j];
+    bool v2;
+    const int cell = ip_point_cell(d, in[i], &v2);
+    if (cell >= 0) atomicMax(&d.owner[(size_t)slot * d.N + cell], IP_OWNER_TAG | i);
   }
   // first / last valid point for the orientation block (:62-63): one atomic per wavefront
 #pragma unroll
