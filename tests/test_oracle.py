@@ -376,3 +376,54 @@ def test_quick_projection_polynomial_bound(params_a):
     ref = np.where((rrow >= 0) & (rrow < NS) & (rr > -1) & (rcol >= 0) & (rcol < H), rcol + rrow * H, -1)
     assert decided.mean() > 0.3
     assert np.array_equal(quick[decided], ref[decided])
+
+
+def test_solver_agrees_with_scipy_least_squares_on_noisy_data_with_outliers():
+    """An independent trust-region solver (scipy.optimize.least_squares, method 'trf', loss 'huber' with f_scale = the Huber delta: the same
+    robust cost as ceres::HuberLoss, 0.5 * sum rho(r^2)) on the SAME residual / Jacobian functions (the oracle's cost functors, typos included)
+    must end where the oracle's restatement of ceres::Solve ends, up to Ceres' default function tolerance: noisy point-to-plane / point-to-line data with 10 %
+    gross outliers, so that the loss function and its corrector matter."""
+    from scipy.optimize import least_squares
+    rng = np.random.default_rng(12)
+    true = np.array([0.25, -0.15, 0.08, 0.01, -0.015, 0.035])
+
+    def rot(p):
+        cr, sr, cp, sp, cy, sy = np.cos(p[3]), np.sin(p[3]), np.cos(p[4]), np.sin(p[4]), np.cos(p[5]), np.sin(p[5])
+        rz = np.array([[cy, -sy, 0], [sy, cy, 0], [0, 0, 1.0]]); ry = np.array([[cp, 0, sp], [0, 1, 0], [-sp, 0, cp]]); rx = np.array([[1, 0, 0], [0, cr, -sr], [0, sr, cr]])
+        return rz @ ry @ rx
+
+    blocks = []
+    for i in range(400):
+        cp = rng.normal(size=3) * 8
+        lp = rot(true) @ cp + true[:3] + rng.normal(size=3) * 0.02
+        if i % 10 == 0:
+            lp += rng.normal(size=3) * 1.5          # gross outlier: far beyond the Huber delta of 0.1
+        n = rng.normal(size=3); n /= np.linalg.norm(n)
+        if i % 3:
+            blocks.append([3, *cp, *n, 0, 0, 0, 0, 0, 0, -float(n @ lp)])
+        else:
+            blocks.append([2, *cp, *(lp + 0.1 * n), *(lp - 0.1 * n), 0, 0, 0, 0])
+    blocks = np.array(blocks)
+    huber = 0.1
+
+    def geom(b):
+        g = np.zeros(13); g[0:12] = b[1:13]; g[12] = b[13]
+        return g
+
+    def res(x):
+        return np.array([O.eval_block(int(b[0]), geom(b), x)[0] for b in blocks])
+
+    def jac(x):
+        return np.array([O.eval_block(int(b[0]), geom(b), x)[1] for b in blocks])
+
+    x0 = np.zeros(6)
+    x, info = O.solve(blocks, x0, 50, huber)
+    for _ in range(3):                              # (ceres::Solve is restarted from its own result, as scan2MapOptimization does twice)
+        x, info = O.solve(blocks, x, 50, huber)
+    ref = least_squares(res, x0, jac=jac, method="trf", loss="huber", f_scale=huber, xtol=1e-15, ftol=1e-15, gtol=1e-15, max_nfev=500)
+    assert ref.success
+    # ceres::Solve stops at its default function_tolerance (relative cost change <= 1e-6), scipy was asked for 1e-15: the two end points
+    # differ by what that tolerance leaves (measured 7e-5 in the pose, 1e-7 relative in the cost), not by more
+    assert np.abs(x - ref.x).max() < 3e-4, (x, ref.x)
+    assert abs(info["final_cost"] - ref.cost) < 5e-6 * ref.cost, (info["final_cost"], ref.cost)
+    assert np.abs(x - true)[[0, 1, 2, 5]].max() < 0.02   # and both are near the truth despite the outliers
