@@ -22,9 +22,8 @@
 thread_local Profiler* g_prof = nullptr;
 
 // A handle of several stream groups drives two HIP streams per group (front end + LaserMapping); the runtime's default of 4 hardware
-// queues would make pairs of them share a queue and serialise.  Only effective when this library is loaded before the process's
-// first HIP call (bench.py / tests/conftest.py also export it); never overrides the user's setting.
-namespace { struct HwQueueEnv { HwQueueEnv() { setenv("GPU_MAX_HW_QUEUES", "16", 0); } } g_hw_queue_env; }
+// queues makes pairs of them share a queue and serialise.  The host process exports GPU_MAX_HW_QUEUES=16 before its first HIP call
+// (bench.py, tests/conftest.py, binding.py do; include/alego_mi355x.h documents it) — the library does not touch the environment.
 
 void launch_ip(const DevCtx& d, int ring_pos, bool want_labels, hipStream_t st);
 void launch_fe(const DevCtx& d, hipStream_t st);
@@ -128,12 +127,18 @@ struct DevTemps {
 
 int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
 
-// LaserMapping work still in flight on the groups' back streams (alego_batch_run without sync): every other entry point waits for it first
-void drain_back(alego_handle* h) { for (hipStream_t s : h->back) (void)hipStreamSynchronize(s); }
-int check_slot(alego_handle* h, int slot) {
+// LaserMapping work still in flight on the groups' back streams (alego_batch_run without sync): every entry point that reads or writes
+// LaserOdometry / LaserMapping state waits for it first — per-slot calls for their own group's back stream (check_slot), whole-handle
+// calls (alego_lo_process, alego_lm_process, alego_stream_run, alego_dist_*) for all of them.  alego_batch_load only writes the
+// front end's input ring and does not wait (a host-fed batch_load + batch_run(sync = 0) loop keeps its overlap).
+void drain_back(alego_handle* h, int slot = -1) {
+  if (slot >= 0 && !h->back.empty()) { (void)hipStreamSynchronize(h->back[std::min<size_t>((size_t)(slot / h->gsize), h->back.size() - 1)]); return; }
+  for (hipStream_t s : h->back) (void)hipStreamSynchronize(s);
+}
+int check_slot(alego_handle* h, int slot, bool drain = true) {
   if (!h) return ALEGO_ERR_ARG;
   if (slot < 0 || slot >= h->d.n_slots) { h->err = "slot out of range"; return ALEGO_ERR_ARG; }
-  drain_back(h);
+  if (drain) drain_back(h, slot);
   return 0;
 }
 
@@ -358,7 +363,7 @@ int alego_synchronize(alego_handle* h) {
 }
 
 int alego_batch_load(alego_handle* h, int slot, int ring_pos, const alego_point* pts, int32_t n) {
-  if (int r = check_slot(h, slot)) return r;
+  if (int r = check_slot(h, slot, false)) return r;
   if (ring_pos < 0 || ring_pos >= h->d.ring_len || n < 0 || (n > 0 && !pts)) { h->err = "ring_pos / n out of range or null points"; return ALEGO_ERR_ARG; }
   if (n > h->d.Pcap) { h->err = "scan larger than n_scan*horizon_scan"; return ALEGO_ERR_CAPACITY; }
   hipSetDevice(h->device);
@@ -671,6 +676,7 @@ int alego_ip_process(alego_handle* h, const alego_scan_in* in, alego_seg_out* ou
 int alego_lo_process(alego_handle* h, const alego_seg_out* in, alego_feat_out* feat, alego_pose* odom) {
   if (!h || !in) return ALEGO_ERR_ARG;
   hipSetDevice(h->device);
+  drain_back(h);
   const DevCtx& d = h->d;
   if (in->m < 0 || in->m > d.N) { h->err = "segmented cloud larger than n_scan*horizon_scan"; return ALEGO_ERR_CAPACITY; }
   if (!in->ring_start || !in->ring_end || (in->m > 0 && (!in->seg || !in->ground || !in->col || !in->range))) { h->err = "alego_lo_process: null input array"; return ALEGO_ERR_ARG; }
@@ -695,6 +701,7 @@ int alego_lm_process(alego_handle* h, const alego_point* corner_last, int32_t n_
                      int32_t n_surf, const alego_point* outlier, int32_t n_outlier, const alego_pose* odom, alego_pose* map_pose) {
   if (!h || !odom) return ALEGO_ERR_ARG;
   hipSetDevice(h->device);
+  drain_back(h);
   g_prof = &h->prof;
   return lm_host_process_host(h->lm, h->d, corner_last, n_corner, surf_last, n_surf, outlier, n_outlier, odom, map_pose, &h->err);
 }
@@ -958,11 +965,13 @@ int alego_dist_unique_id(char id[ALEGO_DIST_ID_BYTES]) { return id ? lm_host_dis
 int alego_dist_init(alego_handle* h, int rank, int world, const char id[ALEGO_DIST_ID_BYTES]) {
   if (!h || !id) return ALEGO_ERR_ARG;
   hipSetDevice(h->device);
+  drain_back(h);
   return lm_host_dist_init(h->lm, rank, world, id, &h->err);
 }
 int alego_dist_shutdown(alego_handle* h) {
   if (!h) return ALEGO_ERR_ARG;
   hipSetDevice(h->device);
+  drain_back(h);
   return lm_host_dist_shutdown(h->lm);
 }
 

@@ -47,7 +47,8 @@ struct BzCrc {
   BzCrc() { for (uint32_t i = 0; i < 256; ++i) { uint32_t c = i << 24; for (int k = 0; k < 8; ++k) c = (c & 0x80000000u) ? (c << 1) ^ 0x04c11db7u : (c << 1); t[i] = c; } }
 };
 
-bool bunzip2(const uint8_t* in, size_t n, std::vector<uint8_t>& out, std::string* err) {
+// `cap`: the uncompressed size the chunk header declares — output beyond it is refused (an untrusted file must not make the reader allocate without bound)
+bool bunzip2(const uint8_t* in, size_t n, std::vector<uint8_t>& out, size_t cap, std::string* err) {
   static const BzCrc crc_tab;
   BitReader br(in, n);
   if (br.bits(8) != 'B' || br.bits(8) != 'Z' || br.bits(8) != 'h') { *err = "bz2: bad stream magic"; return false; }
@@ -185,10 +186,12 @@ bool bunzip2(const uint8_t* in, size_t n, std::vector<uint8_t>& out, std::string
       const uint8_t ch = (uint8_t)(tpos & 0xff);
       tpos >>= 8;
       if (same == 4) {   // count byte after four equal bytes
+        if (out.size() + ch > cap) { *err = "bz2: output exceeds the chunk's declared size"; return false; }
         for (int k = 0; k < ch; ++k) { out.push_back((uint8_t)prev); crc = (crc << 8) ^ crc_tab.t[(crc >> 24) ^ (uint8_t)prev]; }
         same = 0; prev = -1;
         continue;
       }
+      if (out.size() >= cap) { *err = "bz2: output exceeds the chunk's declared size"; return false; }
       out.push_back(ch);
       crc = (crc << 8) ^ crc_tab.t[(crc >> 24) ^ ch];
       if ((int)ch == prev) ++same; else { same = 1; prev = ch; }
@@ -202,7 +205,7 @@ bool bunzip2(const uint8_t* in, size_t n, std::vector<uint8_t>& out, std::string
 // ---------------------------------------------------------------------------------------------------------------------
 // LZ4 frame format (what rosbag's "lz4" compression writes); checksums are not verified
 // ---------------------------------------------------------------------------------------------------------------------
-bool unlz4_frame(const uint8_t* in, size_t n, std::vector<uint8_t>& out, std::string* err) {
+bool unlz4_frame(const uint8_t* in, size_t n, std::vector<uint8_t>& out, size_t cap, std::string* err) {
   size_t p = 0;
   auto need = [&](size_t k) { return p + k <= n; };
   if (!need(7) || in[0] != 0x04 || in[1] != 0x22 || in[2] != 0x4D || in[3] != 0x18) { *err = "lz4: bad frame magic"; return false; }
@@ -220,7 +223,7 @@ bool unlz4_frame(const uint8_t* in, size_t n, std::vector<uint8_t>& out, std::st
     const bool raw = bs & 0x80000000u;
     bs &= 0x7fffffffu;
     if (!need(bs)) { *err = "lz4: truncated block"; return false; }
-    if (raw) { out.insert(out.end(), in + p, in + p + bs); }
+    if (raw) { if (out.size() + bs > cap) { *err = "lz4: output exceeds the chunk's declared size"; return false; } out.insert(out.end(), in + p, in + p + bs); }
     else {
       size_t q = p; const size_t end = p + bs;
       while (q < end) {
@@ -228,6 +231,7 @@ bool unlz4_frame(const uint8_t* in, size_t n, std::vector<uint8_t>& out, std::st
         size_t lit = tok >> 4;
         if (lit == 15) { uint8_t b; do { if (q >= end) { *err = "lz4: bad literal length"; return false; } b = in[q++]; lit += b; } while (b == 255); }
         if (q + lit > end) { *err = "lz4: literals beyond the block"; return false; }
+        if (out.size() + lit > cap) { *err = "lz4: output exceeds the chunk's declared size"; return false; }
         out.insert(out.end(), in + q, in + q + lit); q += lit;
         if (q >= end) break;   // the last sequence has no match
         if (q + 2 > end) { *err = "lz4: truncated match"; return false; }
@@ -236,6 +240,7 @@ bool unlz4_frame(const uint8_t* in, size_t n, std::vector<uint8_t>& out, std::st
         if (ml == 15) { uint8_t b; do { if (q >= end) { *err = "lz4: bad match length"; return false; } b = in[q++]; ml += b; } while (b == 255); }
         ml += 4;
         if (off == 0 || off > out.size()) { *err = "lz4: bad match offset"; return false; }
+        if (out.size() + ml > cap) { *err = "lz4: output exceeds the chunk's declared size"; return false; }
         const size_t s = out.size() - off;
         for (size_t k = 0; k < ml; ++k) out.push_back(out[s + k]);   // (overlapping copies are the format's run-length idiom)
       }
@@ -315,9 +320,9 @@ struct alego_bag {
     const Chunk& c = chunks[ci];
     if (c.comp == 0) { *n = c.clen; return base + c.pos; }
     if (cached != (int)ci) {
-      cache.clear(); cache.reserve(c.size);
+      cache.clear(); cache.reserve(std::min<size_t>(c.size, (size_t)64 << 20));   // (header-controlled: grown on demand beyond 64 MiB, never past c.size)
       cached = -1;
-      const bool ok = c.comp == 1 ? bunzip2(base + c.pos, c.clen, cache, &err) : unlz4_frame(base + c.pos, c.clen, cache, &err);
+      const bool ok = c.comp == 1 ? bunzip2(base + c.pos, c.clen, cache, c.size, &err) : unlz4_frame(base + c.pos, c.clen, cache, c.size, &err);
       if (!ok) return nullptr;
       if (cache.size() != c.size) { err = "chunk: uncompressed size differs from the header's"; return nullptr; }
       cached = (int)ci;
@@ -373,10 +378,8 @@ void alego_bag_close(alego_bag* b) {
   delete b;
 }
 
-int alego_bag_open(const char* path, alego_bag** out) {
-  if (!path || !out) return ALEGO_ERR_ARG;
-  *out = nullptr;
-  alego_bag* b = new alego_bag();
+static int bag_open_impl(const char* path, alego_bag** out, alego_bag*& b) {
+  b = new alego_bag();
   auto fail = [&](const char* why) { std::fprintf(stderr, "alego_bag_open(%s): %s%s%s\n", path, why, b->err.empty() ? "" : ": ", b->err.c_str()); alego_bag_close(b); return ALEGO_ERR_ARG; };
   b->fd = open(path, O_RDONLY);
   if (b->fd < 0) return fail("cannot open the file");
@@ -417,12 +420,13 @@ int alego_bag_open(const char* path, alego_bag** out) {
     }
     pos = r.next;
   }
-  for (uint32_t ci = 0; ci < b->chunks.size(); ++ci) {
-    bool conn_known = true;
-    if (b->chunks[ci].indexed) for (auto& f : found) if (f.second.chunk == ci && !b->conns.count(f.first)) { conn_known = false; break; }
-    if (!b->chunks[ci].indexed || !conn_known)
-      if (!scan_chunk(b, ci, !b->chunks[ci].indexed, &found)) return fail("unreadable chunk");
-  }
+  // chunks to walk record by record: those without index records, and those an index entry of which names a connection no record
+  // outside the chunks declared (one pass over the index entries, not one per chunk)
+  std::vector<uint8_t> needs_scan(b->chunks.size(), 0);
+  for (uint32_t ci = 0; ci < b->chunks.size(); ++ci) needs_scan[ci] = !b->chunks[ci].indexed;
+  for (auto& f : found) if (!needs_scan[f.second.chunk] && !b->conns.count(f.first)) needs_scan[f.second.chunk] = 1;
+  for (uint32_t ci = 0; ci < b->chunks.size(); ++ci)
+    if (needs_scan[ci] && !scan_chunk(b, ci, !b->chunks[ci].indexed, &found)) return fail("unreadable chunk");
   uint64_t seq = 0;
   for (auto& f : found) {
     auto it = b->conns.find(f.first);
@@ -437,6 +441,15 @@ int alego_bag_open(const char* path, alego_bag** out) {
   }
   *out = b;
   return ALEGO_OK;
+}
+
+int alego_bag_open(const char* path, alego_bag** out) {
+  if (!path || !out) return ALEGO_ERR_ARG;
+  *out = nullptr;
+  alego_bag* b = nullptr;
+  // nothing may unwind through the C ABI: allocation failures on a hostile or damaged file become an error code
+  try { return bag_open_impl(path, out, b); }
+  catch (...) { std::fprintf(stderr, "alego_bag_open(%s): out of memory or malformed file\n", path); if (b && *out != b) alego_bag_close(b); *out = nullptr; return ALEGO_ERR_ARG; }
 }
 
 int alego_bag_topic_count(const alego_bag* b) { return b ? (int)b->topic_names.size() : ALEGO_ERR_ARG; }
@@ -456,8 +469,7 @@ int64_t alego_bag_message_count(const alego_bag* b, const char* topic) {
   return it == b->topics.end() ? 0 : (int64_t)it->second.size();
 }
 
-int alego_bag_read_raw(alego_bag* b, const char* topic, int64_t index, const uint8_t** data, uint64_t* len, double* bag_time) {
-  if (!b || !topic || !data || !len) return ALEGO_ERR_ARG;
+static int bag_read_raw_impl(alego_bag* b, const char* topic, int64_t index, const uint8_t** data, uint64_t* len, double* bag_time) {
   auto it = b->topics.find(topic);
   if (it == b->topics.end() || index < 0 || index >= (int64_t)it->second.size()) { b->err = "no such topic / message index"; return ALEGO_ERR_ARG; }
   const Msg& m = it->second[(size_t)index];
@@ -471,9 +483,15 @@ int alego_bag_read_raw(alego_bag* b, const char* topic, int64_t index, const uin
   return ALEGO_OK;
 }
 
+int alego_bag_read_raw(alego_bag* b, const char* topic, int64_t index, const uint8_t** data, uint64_t* len, double* bag_time) {
+  if (!b || !topic || !data || !len) return ALEGO_ERR_ARG;
+  try { return bag_read_raw_impl(b, topic, index, data, len, bag_time); }
+  catch (...) { b->cached = -1; b->err = "out of memory while reading a chunk"; return ALEGO_ERR_ARG; }
+}
+
 // sensor_msgs/PointCloud2 in ROS1 serialisation: Header (seq u32, stamp sec u32 nsec u32, frame_id string), height u32, width u32,
 // PointField[] (name string, offset u32, datatype u8, count u32), is_bigendian u8, point_step u32, row_step u32, data u8[], is_dense u8
-int alego_bag_read_pc2(alego_bag* b, const char* topic, int64_t index, alego_point* out, int32_t cap, double* header_stamp, int32_t* is_dense) {
+static int bag_read_pc2_impl(alego_bag* b, const char* topic, int64_t index, alego_point* out, int32_t cap, double* header_stamp, int32_t* is_dense) {
   const uint8_t* d = nullptr; uint64_t n = 0;
   if (int rc = alego_bag_read_raw(b, topic, index, &d, &n, nullptr)) return rc;
   uint64_t p = 0;
@@ -503,6 +521,12 @@ int alego_bag_read_pc2(alego_bag* b, const char* topic, int64_t index, alego_poi
   const int rc = alego_pc2_to_points(payload, dlen, width, height, point_step, row_step, big, b->fields_tmp.data(), (int)nf, out, cap);
   if (rc < 0) b->err = rc == ALEGO_ERR_CAPACITY ? "cloud larger than the output capacity" : "PointCloud2 layout rejected (x / y / z FLOAT32 fields, steps, data length)";
   return rc;
+}
+
+int alego_bag_read_pc2(alego_bag* b, const char* topic, int64_t index, alego_point* out, int32_t cap, double* header_stamp, int32_t* is_dense) {
+  if (!b) return ALEGO_ERR_ARG;
+  try { return bag_read_pc2_impl(b, topic, index, out, cap, header_stamp, is_dense); }
+  catch (...) { b->err = "out of memory while parsing a PointCloud2 message"; return ALEGO_ERR_ARG; }
 }
 
 }  // extern "C"

@@ -64,7 +64,7 @@ def kernel_bytes(name, c, NS, H, rebuilds_per_launch=0.0):
     rb = rebuilds_per_launch
     t = {
         # B_IP = 16 P (in) + 25 M + 16 O + 8 NS + 12 (out)
-        "ip_fused": 16 * P + 25 * M + 16 * O + 8 * NS + 12 + 8 * M,   # B_IP + the range / column re-read of B_FE (curvature phase)
+        "ip_fused": 16 * P + 25 * M + 16 * O + 8 * NS + 12,   # = B_IP (the curvature phase left the kernel in round 3; fe_* are charged B_FE)
         "ip_project": 16 * P, "ip_front": 12, "cc_lds16": 25 * M + 16 * O + 8 * NS, "cc_lds": 25 * M + 16 * O + 8 * NS,
         "ip_compact": 25 * M + 16 * O + 8 * NS,
         # B_FE = 9 M (range, col, ground in) + 16 feats (out)
@@ -222,7 +222,7 @@ def quat_angle(q1, q2):
     return 2.0 * float(np.arccos(min(1.0, abs(float(np.dot(q1, q2))))))
 
 
-def cpu_legs(p, bags, prime, seconds=10.0, device=None):
+def cpu_legs(p, bags, prime, seconds=10.0, device=None, n_streams=2048):
     """BASELINE.md §2 on the host cores of this box, on the scan sequences the GPU streams replay (slot 0 = bag 0 from scan 0):
     cpu_seq (1 thread, timed after `prime` scans), cpu_pipe3 (IP || LO || LM threads), cpu_replicas (one oracle per core on the
     sequences of slots 0..C-1).  While cpu_seq primes, one-stream device handles process the same scans: SURVEY.md 8(d)'s pose
@@ -293,7 +293,7 @@ def cpu_legs(p, bags, prime, seconds=10.0, device=None):
     n3 = max(50, int(seconds * seq_rate * 1.2))
     t3 = o3.run_pipelined([seq_of(0, prime + k) for k in range(n3)])
     # ---- cpu_replicas: one oracle per host core on the sequences of slots 0..C-1
-    C = max(1, min(os.cpu_count() or 1, 64))
+    C = max(1, min(os.cpu_count() or 1, n_streams))   # min(n_streams, host_cores)
     reps = [oracle_py.Oracle(p) for _ in range(C)]
 
     def prime_rep(c):
@@ -462,7 +462,7 @@ def main():
         omt = None
         if world == 1 and not args.no_cpu:
             out.update(single_stream(p, bags[0], local, args.prime, max(args.steps, 200)))
-            out["cpu_baseline"], out["parity"], omt = cpu_legs(p, bags, args.prime, device=local)
+            out["cpu_baseline"], out["parity"], omt = cpu_legs(p, bags, args.prime, device=local, n_streams=B)
         if not args.no_check and not shard:
             out["timed_handle_check"] = timed_handle_check(h, p, bags, B, step, local, omt)
     h.close()

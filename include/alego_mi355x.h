@@ -129,7 +129,12 @@ int alego_scan_process(alego_handle* h, int slot, const alego_scan_in* in, int s
 /* copy one scan into ring position `ring_pos` of `slot` (host -> HBM, outside the timed region) */
 int alego_batch_load(alego_handle* h, int slot, int ring_pos, const alego_point* pts, int32_t n);
 /* advance every slot by n_scans scans (ring positions first_pos, first_pos+1, ... mod ring_len),
- * all kernels enqueued on the handle's stream; returns without synchronising when sync == 0 */
+ * all kernels enqueued on the handle's streams; returns without synchronising when sync == 0.  With sync == 0 LaserMapping of the
+ * last scans may still be in flight on the stream groups' second ("back") HIP streams when the call returns: every entry point that
+ * touches LaserOdometry / LaserMapping state waits for it first (per-slot calls for their own group, alego_lo_process /
+ * alego_lm_process / alego_stream_run / alego_dist_init / alego_dist_shutdown for all groups); alego_batch_load, which only writes the
+ * input ring, does not.  A handle of G stream groups drives 2 G HIP streams: export GPU_MAX_HW_QUEUES=16 in the host process before
+ * its first HIP call (the runtime's default of 4 hardware queues makes pairs of streams serialise); the library never sets it. */
 int alego_batch_run(alego_handle* h, int first_pos, int n_scans, int stages, int sync);
 int alego_synchronize(alego_handle* h);
 /* OR into `stages` of alego_batch_run: replay the resident ring back and forth (0..R-1,R-2..0,1..)
