@@ -256,6 +256,8 @@ int alego_create(const alego_params* params, int device, int n_slots, int ring_l
   d.opt_cc_fused = env_int("ALEGO_CC_FUSED", 1) != 0;
   d.opt_cc_tile = env_int("ALEGO_CC_TILE", 1) != 0;
   d.opt_fe_pick1 = env_int("ALEGO_FE_PICK1", 0) != 0;
+  d.opt_fe_fused = env_int("ALEGO_FE_FUSED", 0) != 0;
+  d.opt_fe_cand = env_int("ALEGO_FE_CAND", 0);
   d.opt_lo_box_lds = env_int("ALEGO_LO_BOX_LDS", 1 << 20);
   d.opt_map_merge = env_int("ALEGO_MAP_MERGE", 1) != 0;
   const size_t B = n_slots, N = d.N, NS = d.NS;
@@ -275,10 +277,11 @@ int alego_create(const alego_params* params, int device, int n_slots, int ring_l
   d.fcap[F_SHARP] = d.cap_sharp * d.NS; d.fcap[F_LSHARP] = d.cap_lsharp * d.NS; d.fcap[F_FLAT] = d.cap_flat * d.NS; d.fcap[F_LFLAT] = d.N;
   for (int k = 0; k < 4; ++k) rc |= dalloc(h, &d.feat[k], B * 2 * d.fcap[k]);
   for (int k = 0; k < 3; ++k) rc |= dalloc(h, &d.feat_idx[k], B * 2 * d.fcap[k]);
-  rc |= dalloc(h, &d.feat_cnt, B * 2 * 4); rc |= dalloc(h, &d.ring_off, B * 2 * 2 * (NS + 1));
+  rc |= dalloc(h, &d.feat_cnt, B * 2 * 4); rc |= dalloc(h, &d.ring_off, B * 2 * 2 * (NS + 1)); rc |= dalloc(h, &d.ring_boff, B * 2 * 2 * (NS + 1));
+  rc |= dalloc(h, &d.fe_sync, B * NS);
   d.lo_qcap_surf = d.fcap[F_FLAT]; d.lo_qcap_corner = d.fcap[F_SHARP];
   rc |= dalloc(h, &d.lo_corr, B * (d.lo_qcap_surf + d.lo_qcap_corner) * 4);
-  d.lo_box_cap = (d.N + LO_CH - 1) / LO_CH;
+  d.lo_box_cap = (d.N + LO_CH - 1) / LO_CH + d.NS;   // boxes never straddle rings: up to one partly filled box per ring
   rc |= dalloc(h, &d.lo_box, B * 2 * 2 * d.lo_box_cap * 2);
   rc |= dalloc(h, &d.lo_state, B * LO_STATE_N);
   rc |= dalloc(h, &d.poses, B * 16);
@@ -926,6 +929,8 @@ int alego_debug_set_option(alego_handle* h, const char* name, int value) {
   else if (s == "ALEGO_IP_FUSED") d.opt_ip_fused = value != 0;
   else if (s == "ALEGO_CC_TILE") d.opt_cc_tile = value != 0;
   else if (s == "ALEGO_FE_PICK1") d.opt_fe_pick1 = value != 0;
+  else if (s == "ALEGO_FE_FUSED") d.opt_fe_fused = value != 0;
+  else if (s == "ALEGO_FE_CAND") d.opt_fe_cand = value;
   else if (s == "ALEGO_LO_BOX_LDS") d.opt_lo_box_lds = value;
   else if (s == "ALEGO_MAP_MERGE") { if (int r = lm_host_set_map_merge(h->lm, value != 0, &h->err)) return r; d.opt_map_merge = value != 0; }
   else if (s == "ALEGO_IP_FAST") d.ip_fast = h->ip_fast_capable & value;

@@ -30,6 +30,8 @@ enum {
   SC_LM_FRAME,    // LaserMapping frame_cnt (laserMapping.cpp:111)
   SC_LM_FLAGS,
   SC_PVALID_OUT,  // valid input points of the last projected scan (SC_PVALID is an accumulator, cleared by ip_front)
+  SC_FE_EPOCH,    // feature-extraction launches of this slot so far (fe_front increments it; tags the ring counts fe_ring_out's workgroups publish to each other)
+  SC_FE_ERR,      // != 0: a workgroup of fe_ring_out gave up waiting for the counts of the rings below it (never expected; surfaces as ALEGO_ERR_HIP)
   SC_COUNT = 32
 };
 
@@ -60,6 +62,8 @@ struct DevCtx {
   int opt_cc_fused;     // ALEGO_CC_FUSED   1: cc_lds16 also compacts; 0: ip_rowcount + ip_compact
   int opt_cc_tile;      // ALEGO_CC_TILE    1: images beyond the LDS paths are labelled band by band in LDS (cc_tile + cc_seam); 0: cc_runs + cc_link
   int opt_fe_pick1;     // ALEGO_FE_PICK1   1: one ring per wavefront (fe_pick) instead of fe_pick4
+  int opt_fe_fused;     // ALEGO_FE_FUSED   1: feature extraction as fe_front + fe_ring_out (kernels_fe2.hip); 0: fe_curv + fe_pick* + fe_voxel + fe_collect
+  int opt_fe_cand;      // ALEGO_FE_CAND    sharp candidates of a ring sector kept in LDS by fe_front (0: by geometry; the tests set 8 to drive the overflow path)
   int opt_lo_box_lds;   // ALEGO_LO_BOX_LDS boxes staged in LDS by lo_assoc (0: straight from HBM)
   int opt_map_merge;    // ALEGO_MAP_MERGE  1: local map from the pre-sorted key frames; 0: concat + radix VoxelGrid
   // ---- input ring ----
@@ -112,11 +116,13 @@ struct DevCtx {
   int fcap[4];
   int* feat_cnt;        // [slot][2][4]
   int* ring_off;        // [slot][2][2][NS+1] ring offsets of less_sharp ([..][0]) and less_flat ([..][1])
+  int* ring_boff;       // [slot][2][2][NS+1] the same for their bounding boxes: ring r owns the boxes [ring_boff[r], ring_boff[r+1]) of lo_box
+  unsigned* fe_sync;    // [slot][NS] fe_ring_out: (SC_FE_EPOCH << 16 | less_flat voxels of the ring), published for the rings above
   // ---- laser odometry ----
   int* lo_corr;         // [slot][qcap][4]  surf rows then corner rows: (query, closest, idx2, idx3) ; closest<0 = none
   int lo_qcap_surf, lo_qcap_corner;
-  float4* lo_box;       // [slot][2 buffers][2 kinds][lo_box_cap][2]: min / max corner of every LO_CH consecutive targets
-  int lo_box_cap;       //   (kind 0: less_flat, 1: less_sharp), written by fe_collect next to the feature clouds
+  float4* lo_box;       // [slot][2 buffers][2 kinds][lo_box_cap][2]: min / max corner of up to LO_CH consecutive targets of one ring; .w of the
+  int lo_box_cap;       //   corners = first target / number of targets (int bits); kind 0: less_flat, 1: less_sharp; written by feature extraction
   double* lo_state;     // [slot][LO_STATE_N]
   // ---- motion de-skew (adjustDistortion, laserOdometry.cpp:557-726; alego_params.deskew_mode) ----
   double* imu_ring;     // [slot][ALEGO_IMU_Q][10]: time, roll, pitch, yaw, shift xyz, velo xyz (imu_time_ ... imu_velo_z_)

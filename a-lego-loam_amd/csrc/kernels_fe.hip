@@ -688,7 +688,7 @@ __global__ void __launch_bounds__(FC_T) fe_collect(DevCtx d) {
   const int cur = cur_in_flight(d, slot);
   const size_t base = (size_t)slot * d.N;
   const int NS = d.NS;
-  __shared__ int s_off[4][65];
+  __shared__ int s_off[4][65], s_boff[2][65];   // s_boff: first box of every ring (less_sharp, less_flat): boxes never straddle rings
   const int* allc = d.st_cnt + (size_t)slot * NS * 8;
   if (tid < 64) {
     const int r = tid;
@@ -702,6 +702,14 @@ __global__ void __launch_bounds__(FC_T) fe_collect(DevCtx d) {
       for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
       s_off[k][r] = incl - c[k];
       if (r == 63) s_off[k][64] = incl;
+      if (k == 1 || k == 3) {
+        const int nb = (c[k] + LO_CH - 1) / LO_CH;
+        int bi = nb;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(bi, o, 64); if (lane >= o) bi += t; }
+        s_boff[k == 1 ? 0 : 1][r] = bi - nb;
+        if (r == 63) s_boff[k == 1 ? 0 : 1][64] = bi;
+      }
     }
   }
   __syncthreads();
@@ -710,6 +718,9 @@ __global__ void __launch_bounds__(FC_T) fe_collect(DevCtx d) {
     int* ro = d.ring_off + (((size_t)slot * 2 + cur) * 2) * (NS + 1);
     ro[tid] = tid < NS ? s_off[1][tid] : tot[1];
     ro[(NS + 1) + tid] = tid < NS ? s_off[3][tid] : tot[3];
+    int* rb = d.ring_boff + (((size_t)slot * 2 + cur) * 2) * (NS + 1);
+    rb[tid] = tid < NS ? s_boff[0][tid] : s_boff[0][64];
+    rb[(NS + 1) + tid] = tid < NS ? s_boff[1][tid] : s_boff[1][64];
   }
   if (tid == 0) {
     int* fc = d.feat_cnt + ((size_t)slot * 2 + cur) * 4;
@@ -728,12 +739,23 @@ __global__ void __launch_bounds__(FC_T) fe_collect(DevCtx d) {
     const bool boxes = k == F_LSHARP || k == F_LFLAT;
     float4* bx = boxes ? d.lo_box + (((size_t)slot * 2 + cur) * 2 + (k == F_LFLAT ? 0 : 1)) * d.lo_box_cap * 2 : nullptr;
     const int stoff = k == 0 ? 0 : (k == 1 ? d.cap_sharp : d.cap_sharp + d.cap_lsharp);
-    for (int i0 = 0; i0 < tot[k]; i0 += FC_T) {
-      const int i = i0 + tid;
-      const bool v = i < tot[k];
+    // clouds with boxes are walked box by box (LO_CH consecutive threads = the up to LO_CH points of one ring's box), the others point by point
+    const int kb = k == F_LSHARP ? 0 : 1;
+    const int nwork = boxes ? s_boff[kb][64] * LO_CH : tot[k];
+    for (int i0 = 0; i0 < nwork; i0 += FC_T) {
+      int i = i0 + tid, r = 0, j = 0, bxi = 0;
+      bool v = i < nwork;
+      if (boxes) {
+        bxi = min(i / LO_CH, s_boff[kb][64] - 1);
+        int lo = 0, hi = NS - 1;   // largest r with s_boff[r] <= bxi
+        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (s_boff[kb][mid] <= bxi) lo = mid; else hi = mid - 1; }
+        r = lo; j = (bxi - s_boff[kb][r]) * LO_CH + (tid % LO_CH);
+        v = v && j < s_off[k][r + 1] - s_off[k][r];
+        i = s_off[k][r] + j;
+      }
       float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
       if (v) {
-        const int r = ring_of(k, i), j = i - s_off[k][r];
+        if (!boxes) { r = ring_of(k, i); j = i - s_off[k][r]; }
         if (k < 3) {
           const int idx = d.st_idx[((size_t)slot * NS + r) * d.st_stride + stoff + j];
           p = seg[idx];
@@ -750,10 +772,10 @@ __global__ void __launch_bounds__(FC_T) fe_collect(DevCtx d) {
         for (int a = 0; a < 3; ++a)
 #pragma unroll
           for (int o = LO_CH / 2; o > 0; o >>= 1) { mn[a] = fminf(mn[a], __shfl_xor(mn[a], o, 64)); mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], o, 64)); }
-        if ((tid % LO_CH) == 0 && v) {
-          const int c = i / LO_CH;
-          bx[2 * c] = make_float4(mn[0], mn[1], mn[2], 0.f);
-          bx[2 * c + 1] = make_float4(mx[0], mx[1], mx[2], 0.f);
+        if ((tid % LO_CH) == 0 && v) {   // (thread 0 of a box holds its first point: every box has one)
+          const int len = min(LO_CH, s_off[k][r + 1] - i);
+          bx[2 * bxi] = make_float4(mn[0], mn[1], mn[2], __int_as_float(i));
+          bx[2 * bxi + 1] = make_float4(mx[0], mx[1], mx[2], __int_as_float(len));
         }
       }
     }
@@ -775,7 +797,12 @@ int launch_stdsort_probe(const uint32_t* keys, int n, int depth_limit, int* pos_
   return 0;
 }
 
+bool fe_fused_eligible(const DevCtx& d);                    // kernels_fe2.hip
+void launch_fe_fused(const DevCtx& d, hipStream_t st);
+void launch_fe_curv_debug(const DevCtx& d, hipStream_t st) { ALEGO_LAUNCH(fe_curv, dim3((d.N + FE_CW - 1) / FE_CW, d.n_launch), dim3(FE_BLOCK), 0, st, d); }
+
 void launch_fe(const DevCtx& d, hipStream_t st) {
+  if (fe_fused_eligible(d)) { launch_fe_fused(d, st); return; }   // fe_front + fe_ring_out; below: the four-kernel path (ALEGO_FE_FUSED=0, sort_mode 2)
   // dynamic LDS above 64 KB has to be requested explicitly (fe_voxel: 26 B per column, horizon_scan <= 4096)
   static const bool cfg = hipFuncSetAttribute(reinterpret_cast<const void*>(fe_voxel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fv_lds_bytes(FE_MAXH)) == hipSuccess;
   (void)cfg;

@@ -61,7 +61,10 @@ DEV_INLINE WalkBest walk_reduce(WalkBest b) {
 // One DPP row (16 lanes) per query, four queries per wavefront in lock-step, LO_QPB per workgroup: the kernel is
 // instruction-issue bound, and every reduction below is four row-local DPP steps shared by the four queries.
 //
-// Both searches of a query are exact and pruned with the bounding boxes of LO_CH consecutive targets (fe_boxes):
+// Both searches of a query are exact and pruned with bounding boxes of up to LO_CH consecutive targets OF ONE RING (written by feature
+// extraction next to the clouds: box c covers the targets [start, start + len), start / len carried in the .w fields of its two corners;
+// ring r owns the boxes [ring_boff[r], ring_boff[r + 1]) — a ring's feature-extraction workgroup writes its own boxes without waiting for
+// any other ring, and a ring window is a contiguous range of boxes):
 // a box is skipped when its lower bound exceeds the best distance found so far.  The lower bound is evaluated with
 // the same operations, in the same order and precision as the distance itself (clamped per-axis difference, squares,
 // left-to-right sum), and IEEE rounding is monotone, so bound <= distance of every point of the box: no candidate
@@ -117,17 +120,18 @@ DEV_INLINE void lo_assoc_body(const DevCtx& d, int box_lds_max, int slot, int qb
   const int nt = d.feat_cnt[fl * 4 + tk];
   const float4* tg = d.feat[tk] + fl * d.fcap[tk];
   const float4* bx = d.lo_box + (fl * 2 + kind) * d.lo_box_cap * 2;
-  const int nch = (nt + LO_CH - 1) / LO_CH;
   const int* roff = d.ring_off + (fl * 2 + (kind == 0 ? 1 : 0)) * (d.NS + 1);
+  const int* boff = d.ring_boff + (fl * 2 + (kind == 0 ? 1 : 0)) * (d.NS + 1);
+  const int nch = nt > 0 ? boff[d.NS] : 0;
   const double* st = d.lo_state + (size_t)slot * LO_STATE_N;
   LA_TICK(0);
   __shared__ float s_sel[LO_QPB][4];
   __shared__ double s_pose[12];
   __shared__ float4 s_box[2 * BOXCAP];   // the boxes are read by every query of the workgroup: LDS when they fit
-  __shared__ int s_roff[65];
+  __shared__ int s_roff[65], s_boff[65];
   const bool box_lds = nch <= box_lds_max;   // (<= LO_BOX_LDS; the parity tests also run with 0 = boxes straight from HBM)
   if (box_lds) for (int i = threadIdx.x; i < 2 * nch; i += BLKA) s_box[i] = bx[i];
-  for (int i = threadIdx.x; i <= d.NS; i += BLKA) s_roff[i] = roff[i];
+  for (int i = threadIdx.x; i <= d.NS; i += BLKA) { s_roff[i] = roff[i]; s_boff[i] = boff[i]; }
   if (threadIdx.x == 0) {
     bool same = true;   // NaN (nothing cached yet) or a pose written by alego_set_lo_params compares unequal
 #pragma unroll
@@ -171,6 +175,13 @@ DEV_INLINE void lo_assoc_body(const DevCtx& d, int box_lds_max, int slot, int qb
       dy = fmaxf(fmaxf(lo.y - sy, sy - hi.y), 0.f);
       dz = fmaxf(fmaxf(lo.z - sz, sz - hi.z), 0.f);
     };
+    // first target and number of targets of box c (< 0: none)
+    auto box_span = [&](int c, int& start, int& len) {
+      const int cc = max(c, 0);
+      float ws, wl;
+      if (box_lds) { ws = s_box[2 * cc].w; wl = s_box[2 * cc + 1].w; } else { ws = bx[2 * cc].w; wl = bx[2 * cc + 1].w; }
+      start = __float_as_int(ws); len = c >= 0 ? __float_as_int(wl) : 0;
+    };
     auto lb_f32 = [&](int c) -> float {
       if (c >= nch) return INF;
       float dx, dy, dz;
@@ -182,11 +193,13 @@ DEV_INLINE void lo_assoc_body(const DevCtx& d, int box_lds_max, int slot, int qb
     // this lane's two targets of each of the boxes ca, cb (< 0: none) folded into its running (distance, index) minimum;
     // the four loads are issued together
     auto nn_eval = [&](const int (&cb)[LO_NB], unsigned long long best) -> unsigned long long {
-      int t[TPL * LO_NB];
+      int t[TPL * LO_NB], bs[LO_NB], bl[LO_NB];
       bool v[TPL * LO_NB];
       float4 a[TPL * LO_NB];
 #pragma unroll
-      for (int u = 0; u < TPL * LO_NB; ++u) { t[u] = cb[u / TPL] * LO_CH + l16 + 16 * (u % TPL); v[u] = cb[u / TPL] >= 0 && t[u] < nt; }
+      for (int u = 0; u < LO_NB; ++u) box_span(cb[u], bs[u], bl[u]);
+#pragma unroll
+      for (int u = 0; u < TPL * LO_NB; ++u) { t[u] = bs[u / TPL] + l16 + 16 * (u % TPL); v[u] = l16 + 16 * (u % TPL) < bl[u / TPL]; }
 #pragma unroll
       for (int u = 0; u < TPL * LO_NB; ++u) a[u] = tg[v[u] ? t[u] : 0];
 #pragma unroll
@@ -253,22 +266,25 @@ DEV_INLINE void lo_assoc_body(const DevCtx& d, int box_lds_max, int slot, int qb
       b3.dist = w3 ? pd : b3.dist; b3.rank = w3 ? rank : b3.rank; b3.idx = w3 ? k : b3.idx;
     };
     auto walk_eval = [&](const int (&cb)[LO_NB]) {   // boxes cb[] (< 0: none): all their loads in flight together
-      int k[TPL * LO_NB];
+      int k[TPL * LO_NB], bs[LO_NB], bl[LO_NB];
       bool v[TPL * LO_NB];
       float4 a[TPL * LO_NB];
 #pragma unroll
-      for (int u = 0; u < TPL * LO_NB; ++u) { k[u] = cb[u / TPL] * LO_CH + l16 + 16 * (u % TPL); v[u] = cb[u / TPL] >= 0 && k[u] < nt; }
+      for (int u = 0; u < LO_NB; ++u) box_span(cb[u], bs[u], bl[u]);
+#pragma unroll
+      for (int u = 0; u < TPL * LO_NB; ++u) { k[u] = bs[u / TPL] + l16 + 16 * (u % TPL); v[u] = l16 + 16 * (u % TPL) < bl[u / TPL]; }
 #pragma unroll
       for (int u = 0; u < TPL * LO_NB; ++u) a[u] = tg[v[u] ? k[u] : 0];
 #pragma unroll
       for (int u = 0; u < TPL * LO_NB; ++u) walk_one(k[u], v[u], a[u]);
     };
-    // class S: same ring (surf only); class O: the other rings of the window.  A box may overlap both.
-    const int cw0 = lo / LO_CH, cw1 = hi > lo ? (hi - 1) / LO_CH : -1;   // empty window: no box
+    // class S: same ring (surf only); class O: the other rings of the window.  A box belongs to one ring.
+    const int cw0 = found ? s_boff[rlo] : 0, cw1 = found ? s_boff[rhi + 1] - 1 : -1;   // empty window: no box
+    const int same_b0 = s_boff[crc], same_b1 = s_boff[crc + 1];
     auto box_class = [&](int c, bool& inS, bool& inO) {
-      const int k0 = max(c * LO_CH, lo), k1 = min(c * LO_CH + LO_CH, hi);   // [k0, k1) inside the window
-      inS = kind == 0 && k0 < same_hi && k1 > same_lo;
-      inO = k0 < same_lo || k1 > same_hi;
+      const bool own = c >= same_b0 && c < same_b1;
+      inS = kind == 0 && own;
+      inO = !own;
     };
     auto lb_f64 = [&](int c) -> double {
       float dx, dy, dz;
@@ -291,7 +307,7 @@ DEV_INLINE void lo_assoc_body(const DevCtx& d, int box_lds_max, int slot, int qb
     }
     mo = row16_min_u64(mo);
     LA_TICK(5);
-    const int cseedS = cw1 >= 0 ? closest / LO_CH : -1, cseedO = mo == ~0ull ? -1 : (int)(uint32_t)mo;
+    const int cseedS = cw1 >= cw0 ? min(max(same_b0 + (closest - same_lo) / LO_CH, cw0), cw1) : -1, cseedO = mo == ~0ull ? -1 : (int)(uint32_t)mo;
     { int cb[LO_NB]; for (int u = 0; u < LO_NB; ++u) cb[u] = -1; cb[0] = cseedS; cb[1] = cseedO != cseedS ? cseedO : -1; walk_eval(cb); }
     // class bounds after the seeds (an upper bound of the final minimum; nfd when nothing was found)
     // (values, not a conditional on the two structs: `c ? b3.dist : b2.dist` is a select of addresses and sent both structs

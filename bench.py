@@ -479,6 +479,7 @@ def main():
             hi.batch_run(args.prime + args.warmup, args.steps, stages)
             iso = kernel_table(hi.profile_report())
             hi.close()
+            out["kernels_isolated"] = {k: v["avg_us"] for k, v in iso.items()}   # one stream group alone on the chip: every launch by itself
         roofs = []
         for name in kern:  # kernels in the order of their share of the device time; those with a §8(d) term of their own
             rb = rebuilds / max(kern[name]["launches"], 1) / per  # map rebuilds per launch and stream

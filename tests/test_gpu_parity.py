@@ -163,17 +163,25 @@ def _fe_compare(h, o, feat, tag):
         assert_bit_equal(h.debug_get(name), o.get(name), f"{tag} {name}")
     for name in ("sharp", "less_sharp", "flat", "less_flat"):
         assert_bit_equal(feat[name], o.get(name), f"{tag} {name} cloud")
+    assert h.debug_get("scal")[18] == 0, f"{tag}: fe_ring_out gave up waiting for a lower ring's count (SC_FE_ERR)"
 
 
 @pytest.mark.parametrize("geom,nscan,box_lds", [((16, 1800), 6, None), ((16, 1800), 3, 0), ((16, 1800), 3, "pick1"),
-                                                 ((16, 4000), 3, None), ((64, 2048), 3, None)])
+                                                 ((16, 4000), 3, None), ((64, 2048), 3, None),
+                                                 ((16, 1800), 3, "unfused"), ((16, 4000), 2, "unfused"), ((64, 2048), 2, "unfused"),
+                                                 ((16, 1800), 3, "cand8"), ((16, 4000), 2, "cand8"), ((64, 2048), 2, "cand8")])
 def test_fe_lo_teacher_forced(geom, nscan, box_lds, monkeypatch):
     """Each scan starts from the oracle's params_ (teacher forcing): indices exact, pose 1e-4.  box_lds = 0 makes lo_assoc
-    read its bounding boxes from HBM (the path of feature clouds too large for the LDS staging); "pick1" runs the
-    one-ring-per-wavefront fe_pick (the path of suppress_radius > 7) instead of fe_pick4.  The three geometries cover
-    fe_pick4<19>, <43> and <24>."""
+    read its bounding boxes from HBM (the path of feature clouds too large for the LDS staging).  Feature extraction runs as
+    fe_front + fe_ring_out (kernels_fe2.hip); "cand8" leaves it 8 sharp + 4 flat candidate slots per ring sector in LDS, so that most
+    sectors spill to HBM and are picked by ff_pick_mem; "unfused" is the four-kernel path (ALEGO_FE_FUSED=0: fe_pick4<19>, <43>, <24> on the
+    three geometries), "pick1" that path with the one-ring-per-wavefront fe_pick."""
     if box_lds == "pick1":
         monkeypatch.setenv("ALEGO_FE_PICK1", "1")
+    elif box_lds == "unfused":
+        monkeypatch.setenv("ALEGO_FE_FUSED", "0")
+    elif box_lds == "cand8":
+        monkeypatch.setenv("ALEGO_FE_CAND", "8")
     elif box_lds is not None:
         monkeypatch.setenv("ALEGO_LO_BOX_LDS", str(box_lds))
     p = synth.default_params(*geom)
@@ -259,10 +267,15 @@ def test_fe_lo_standalone_node_variants(params_a):
                                        ((32, 1024), dict(n_sectors=3)),
                                        ((16, 1800), dict(ang_res_x=0.21)),                    # H * res != 360: no column table
                                        ((16, 1800), dict(ang_bottom=11.3, ang_res_y=1.33))])  # other row boundaries
-def test_feature_pick_parameter_variants(geom, mods):
-    """Other ring counts (not a multiple of the four rings a wavefront of fe_pick4 takes), sector counts, pick counts,
-    suppression radii and angular resolutions than the reference's literals: segmentation, feature lists and the LO pose
-    against the oracle."""
+@pytest.mark.parametrize("fe", ["fused", "cand8", "unfused"])
+def test_feature_pick_parameter_variants(geom, mods, fe, monkeypatch):
+    """Other ring counts (not a multiple of the eight rings a wavefront of fe_front / the four of fe_pick4 takes), sector counts, pick
+    counts, suppression radii and angular resolutions than the reference's literals: segmentation, feature lists and the LO pose
+    against the oracle — on the two-kernel path, on it with most candidate lists spilled, and on the four-kernel path."""
+    if fe == "cand8":
+        monkeypatch.setenv("ALEGO_FE_CAND", "8")
+    elif fe == "unfused":
+        monkeypatch.setenv("ALEGO_FE_FUSED", "0")
     p = synth.default_params(*geom)
     for k, v in mods.items():
         setattr(p, k, v)
@@ -277,6 +290,42 @@ def test_feature_pick_parameter_variants(geom, mods):
         if k:
             np.testing.assert_allclose(odom["params"], o.get("lo_params"), rtol=0, atol=1e-7)
     h.close()
+
+
+@pytest.mark.parametrize("geom,fe", [((16, 1800), "fused"), ((16, 1800), "cand8"), ((16, 1800), "unfused"), ((16, 4000), "fused"), ((12, 640), "fused")])
+def test_fe_dense_candidates_and_tied_curvatures(geom, fe, monkeypatch):
+    """Ranges quantised to 1/8 m on a rough surface: nearly every point of a sector is a sharp or flat candidate (more than the LDS lists
+    hold: the spill path without any option) and the 11-tap sums take few distinct values, so that most picks are decided by the tie rule
+    (sharp: larger index, flat: smaller index).  Two parameter sets: the reference's, and thresholds / pick counts that keep the lists
+    long (edge_thres 0, 40 less-sharp picks per sector)."""
+    if fe == "cand8":
+        monkeypatch.setenv("ALEGO_FE_CAND", "8")
+    elif fe == "unfused":
+        monkeypatch.setenv("ALEGO_FE_FUSED", "0")
+    n_scan, H = geom
+    for variant in range(2):
+        p = synth.default_params(*geom)
+        if variant:
+            p.edge_thres, p.surf_thres, p.n_sharp, p.n_less_sharp, p.n_flat = 0.0, 5.0, 4, 40, 9
+        h, o = binding.Handle(p), O.Oracle(p)
+        rng = np.random.default_rng(7 + variant)
+        rows, cols = np.meshgrid(np.arange(n_scan), np.arange(H), indexing="ij")
+        for k in range(2):
+            el = np.deg2rad(-p.ang_bottom + rows * p.ang_res_y)
+            az = -np.deg2rad((cols + 0.5) * p.ang_res_x)
+            r = 9.0 + 0.5 * np.sin(cols / 40.0 + k) + rng.integers(0, 4, size=rows.shape) * 0.125
+            r = np.round(r * 8.0) / 8.0
+            r = np.where(el < np.deg2rad(-3.0), np.minimum(r, 1.9 / np.maximum(np.sin(-el), 1e-3)), r)   # a floor 1.9 m below the sensor: ground points
+            keep = rng.random(rows.shape) > 0.03
+            pts = np.zeros((n_scan * H, 4), np.float32)
+            pts[:, 0] = (r * np.cos(el) * np.cos(az)).ravel(); pts[:, 1] = (r * np.cos(el) * np.sin(az)).ravel(); pts[:, 2] = (r * np.sin(el)).ravel()
+            pts = pts[keep.ravel()]
+            seg = _ip_compare(h, o, pts, f"{geom} rough {k}")
+            h.set_lo_params(o.get("lo_params"))
+            o.lo()
+            flags, feat, odom = h.lo_process(seg)
+            _fe_compare(h, o, feat, f"{geom} {fe} rough variant {variant} scan {k}")
+        h.close()
 
 
 def test_create_rejects_out_of_range_pick_parameters(params_a):

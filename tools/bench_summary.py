@@ -8,5 +8,6 @@ print("counts", d.get("counts"))
 cb = d.get("cpu_baseline") or {}
 print("cpu_pipe3", cb.get("cpu_pipe3"), "cpu_replicas", cb.get("cpu_replicas"))
 print("parity", d.get("parity"))
+iso = d.get("kernels_isolated", {})
 for k, v in list(d.get("kernels", {}).items())[:40]:
-    print("%-28s %9.1f us x%4d %5.1f%%" % (k, v["avg_us"], v["launches"], 100 * v["share"]))
+    print("%-28s %9.1f us x%4d %5.1f%%   alone %8.1f us" % (k, v["avg_us"], v["launches"], 100 * v["share"], iso.get(k, float("nan"))))
