@@ -256,7 +256,7 @@ int alego_create(const alego_params* params, int device, int n_slots, int ring_l
   d.opt_cc_fused = env_int("ALEGO_CC_FUSED", 1) != 0;
   d.opt_cc_tile = env_int("ALEGO_CC_TILE", 1) != 0;
   d.opt_fe_pick1 = env_int("ALEGO_FE_PICK1", 0) != 0;
-  d.opt_fe_fused = env_int("ALEGO_FE_FUSED", 0) != 0;
+  d.opt_fe_fused = env_int("ALEGO_FE_FUSED", 1) != 0;
   d.opt_fe_cand = env_int("ALEGO_FE_CAND", 0);
   d.opt_lo_box_lds = env_int("ALEGO_LO_BOX_LDS", 1 << 20);
   d.opt_map_merge = env_int("ALEGO_MAP_MERGE", 1) != 0;

@@ -1,14 +1,15 @@
 // kernels_fe2.hip — feature extraction in two launches (round 4; replaces fe_curv + fe_pick4 + fe_voxel + fe_collect of kernels_fe.hip,
 // which stay behind ALEGO_FE_FUSED=0 as the cross-check and as the path of sort_mode 2).  src/laserOdometry.cpp:122-293.
 //
-//   fe_front     a7-a9: one wavefront group per EIGHT rings of a stream walks the rings sector by sector.  For a sector the ring's ranges /
-//                columns are staged once in LDS; the 11-tap curvature sum (:122-129), the occlusion / parallel-beam marks (:131-159, as
-//                ballot masks — no per-point flag array), the thresholds and each point's suppression reach (how far the +-5 marking of
-//                :211-234 gets before a column jump stops it) are evaluated with all 64 lanes, and the sector's sharp / flat CANDIDATES
-//                are compacted into a list in LDS.  The greedy pick (:189-277) then only ever looks at candidates — a 16 x 1800 sector has
-//                ~190 points and ~32 sharp candidates — in registers, eight rings in lock-step, eight lanes per ring: arg-max by three DPP
-//                steps, suppression = an index-range test on the registers.  Nothing per point goes to HBM: the kernel reads range /
-//                column / ground (9 B per point) and writes the picked indices.
+//   fe_cand      a7-a8 + candidates: one wavefront per (stream, ring, sector), all of them at once.  The sector's ranges / columns are staged
+//                once in LDS; the 11-tap curvature sum (:122-129), the occlusion / parallel-beam marks (:131-159, as ballot masks — no
+//                per-point flag array), the thresholds and each point's suppression reach (how far the +-5 marking of :211-234 gets before a
+//                column jump stops it) are evaluated per point, and the sector's sharp / flat CANDIDATES — a 16 x 1800 sector has ~190 points,
+//                ~32 sharp and ~12 flat candidates — go to a short list (8 B per candidate; it stays in the L2).  Reads range / column /
+//                ground (9 B per point); no curvature or flag array is written.
+//   fe_pick8     a9: the greedy pick (:189-277) is sequential per ring and only ever asks for the best remaining candidate: one wavefront per
+//                EIGHT rings of a stream, eight lanes per ring, the sector's candidates in registers, arg-max by three DPP steps,
+//                suppression = an index-range test on the registers; writes the picked indices.
 //   fe_ring_out  a10 + the clouds: one workgroup per (stream, ring).  pcl::VoxelGrid(0.4) on the ring's less_flat_scan (:288-293) straight
 //                from the segmented cloud — the points of a ring are contiguous, the few labelled ones are holes in a bitmap — then the
 //                ring writes its part of all four feature clouds, its index lists, ring offsets and bounding boxes in place.  The less_flat
@@ -23,29 +24,21 @@
 #define FE_MAXH 4096   // largest horizon_scan (as kernels_fe.hip)
 
 // ---------------------------------------------------------------------------------------------------------------------------------
-// fe_front
+// fe_cand + fe_pick8
 // ---------------------------------------------------------------------------------------------------------------------------------
-#define FF_G 8        // rings per workgroup (8 lanes of the picking wavefront each)
+#define FF_G 8        // rings per picking wavefront (8 lanes each)
 #define FF_HALO 8     // staged points either side of a sector (11-tap sum: 5, occlusion marks of the neighbours: 6)
 #define FF_Q0 64      // staging position of a sector's first point: the sector's 64-point chunks are the ballot masks' chunks
+#define FC_NW 4       // ring sectors (wavefronts) per fe_cand workgroup
 
-struct FfLayout {     // dynamic LDS of one workgroup, in bytes from its start
-  int scap, mch, ct, mw;          // staged positions per wavefront (multiple of 64), mask chunks, list entries per ring, mark words per ring
-  int off_key, off_pay, off_mark, off_misc, off_wave, wave_bytes, total;
+struct FfLayout {     // dynamic LDS of one fe_cand wavefront, in bytes
+  int scap, mch, wave_bytes;      // staged positions (multiple of 64), mask chunks
 };
-__host__ __device__ inline FfLayout ff_layout(int sector_cap, int CS, int CF, int NW) {
+__host__ __device__ inline FfLayout ff_layout(int sector_cap) {
   FfLayout L;
   L.scap = (FF_Q0 + sector_cap + FF_HALO + 63) & ~63;
   L.mch = L.scap / 64 + 1;
-  L.ct = CS + CF;
-  L.mw = (sector_cap + FF_HALO + 31) / 32 + 1;
-  L.off_key = 0;
-  L.off_pay = L.off_key + 4 * FF_G * L.ct;
-  L.off_mark = (L.off_pay + 2 * FF_G * L.ct + 3) & ~3;
-  L.off_misc = L.off_mark + 4 * FF_G * L.mw;
-  L.off_wave = (L.off_misc + 4 * FF_G * 4 + 7) & ~7;
-  L.wave_bytes = (8 * 4 * L.mch + 4 * L.scap + 2 * L.scap + 7) & ~7;   // masks u64 [4][mch], ranges f32 [scap], columns u16 [scap]
-  L.total = L.off_wave + NW * L.wave_bytes;
+  L.wave_bytes = (8 * 4 * L.mch + 4 * L.scap + 2 * L.scap + 7) & ~7;   // masks u64 [4][mch], ranges f32 [scap], columns | ground << 15 u16 [scap]
   return L;
 }
 
@@ -60,12 +53,28 @@ DEV_INLINE uint32_t grp8_max_u32(uint32_t v) {
 // bits [pos, pos + 64) of the 128-bit value hi:lo
 DEV_INLINE unsigned long long ext128(unsigned long long lo, unsigned long long hi, int pos) { return (lo >> pos) | (pos ? hi << (64 - pos) : 0ull); }
 
-// One sector [sp, ep] of one ring, all 64 lanes of the calling wavefront: candidates -> keyl / payl (sharp from entry 0, flat from entry CS;
-// entries beyond CS / CF go to the overflow lists in HBM).  carry = largest index already marked by the picks of the ring's previous sector.
+DEV_INLINE void ff_sector(const alego_params& P, int S, int E, int j, int& sp, int& ep) {
+  const int NSEC = P.n_sectors;
+  if (P.sector_formula == 0) { sp = (S * (NSEC - j) + E * j) / NSEC; ep = (S * (NSEC - 1 - j) + E * (j + 1)) / NSEC - 1; }   // laserOdometry.cpp:177-178
+  else { const int diff = E - S; sp = S + j * diff / NSEC; ep = S + (j + 1) * diff / NSEC - 1; }                               // LO.cpp:245-249
+}
+
+// The candidate list of one ring sector, in HBM (it stays in the L2 between fe_cand and fe_pick8): `sector_cap` entries (key, pay); the sharp
+// candidates fill it from the front, the flat ones from the back — a point is one or the other (not ground / ground), so they never meet.
 //   key  sharp: |cd| bits + 1, flat: ~|cd| bits (0 = no candidate; the pick is an arg-MAX for both; curvature = (double)cd^2 orders like |cd|)
-//   pay  sharp: (index in sector) << 6 | reach forward << 3 | reach backward; flat: 0xFFFF - that (ties: sharp -> larger index, flat -> smaller)
-DEV_INLINE void ff_wide(const DevCtx& d, size_t base, int M, int sp, int ep, int carry, unsigned char* wl, const FfLayout& L, uint32_t* keyl, uint16_t* payl,
-                        int CS, int CF, uint2* ovf_s, uint2* ovf_f, int& ns_out, int& nf_out, bool dbg) {
+//   pay  sharp: (index in sector) << 6 | reach forward << 3 | reach backward; flat: ~ of that (ties: sharp -> larger index, flat -> smaller)
+DEV_INLINE uint2* ff_list(const DevCtx& d, int slot, int ring, int j, int sector_cap) {
+  return reinterpret_cast<uint2*>(d.st_lfds + ((size_t)slot * d.NS + ring) * d.H) + (size_t)j * sector_cap;   // (the filtered-ring staging of the four-kernel path: 2 H entries per ring)
+}
+DEV_INLINE int* ff_counts(const DevCtx& d, int slot, int ring) {   // [sector][2]: sharp, flat candidates (the less_flat_scan index list of the four-kernel path)
+  return d.st_idx + ((size_t)slot * d.NS + ring) * d.st_stride + d.cap_sharp + d.cap_lsharp + d.cap_flat;
+}
+
+// One sector [sp, ep] of one ring, all 64 lanes of the calling wavefront: the ring's ranges / columns are staged once in LDS; the 11-tap
+// curvature sum (:122-129), the occlusion / parallel-beam marks (:131-159) as ballot masks — no per-point flag array — the thresholds and each
+// point's suppression reach (how far the +-5 marking of :211-234 gets before a column jump stops it) are evaluated per point, and the
+// sector's sharp / flat candidates are compacted into `list`.  Two workgroup barriers (matched by callers that skip a sector).
+DEV_INLINE void ff_wide(const DevCtx& d, size_t base, int M, int sp, int ep, unsigned char* wl, const FfLayout& L, uint2* list, int sector_cap, int& ns_out, int& nf_out, bool dbg) {
   const int lane = threadIdx.x & 63;
   const alego_params& P = d.P;
   unsigned long long* mA = reinterpret_cast<unsigned long long*>(wl);
@@ -74,6 +83,7 @@ DEV_INLINE void ff_wide(const DevCtx& d, size_t base, int M, int sp, int ep, int
   uint16_t* scl = reinterpret_cast<uint16_t*>(wl + 8 * 4 * L.mch + 4 * L.scap);
   const float* rng = d.seg_range + base;
   const int* colv = d.seg_col + base;
+  const uint8_t* gndv = d.seg_ground + base;
   const int len = ep - sp + 1;
   const int q0 = FF_Q0 - FF_HALO, q1 = FF_Q0 + len + FF_HALO;   // staged positions [q0, q1): point k sits at q = k - sp + FF_Q0
 #pragma unroll 2
@@ -82,8 +92,9 @@ DEV_INLINE void ff_wide(const DevCtx& d, size_t base, int M, int sp, int ep, int
     const bool in = k >= 0 && k < M;
     const float r = rng[in ? k : 0];
     const int c = colv[in ? k : 0];
+    const uint8_t g = gndv[in ? k : 0];
     sr[q] = in ? r : 0.f;
-    scl[q] = in ? (uint16_t)c : (uint16_t)0;
+    scl[q] = in ? (uint16_t)((c & 0x7fff) | (g ? 0x8000 : 0)) : (uint16_t)0;
   }
   __syncthreads();
   // per-point predicates of markOccludedPoints (:131-159) and the column jumps of the suppression (:214,:226) as one bit per point
@@ -93,7 +104,7 @@ DEV_INLINE void ff_wide(const DevCtx& d, size_t base, int M, int sp, int ep, int
     const bool inr = q > q0 && q < q1 - 1;
     const int qa = min(max(q, q0 + 1), q1 - 2);
     const float r0 = sr[qa], r1 = sr[qa + 1], rm = sr[qa - 1];
-    const int c0 = scl[qa], c1 = scl[qa + 1];
+    const int c0 = scl[qa] & 0x7fff, c1 = scl[qa + 1] & 0x7fff;
     int cdiff = c0 - c1;
     cdiff = cdiff < 0 ? -cdiff : cdiff;
     bool c1b, c2b;
@@ -121,7 +132,7 @@ DEV_INLINE void ff_wide(const DevCtx& d, size_t base, int M, int sp, int ep, int
   for (int it = 0; it * 64 < len; ++it) {
     const int ch = it + 1, q = ch * 64 + lane, loc = it * 64 + lane, k = sp + loc;
     const bool own = loc < len;
-    const uint8_t gnd = d.seg_ground[base + (own ? k : sp)];
+    const bool gnd = (scl[q] & 0x8000) != 0;
     // strictly left-to-right f32 sum (:124); built with -ffp-contract=off
     const float cdv = sr[q - 5] + sr[q - 4] + sr[q - 3] + sr[q - 2] + sr[q - 1] - sr[q] * 10 + sr[q + 1] + sr[q + 2] + sr[q + 3] + sr[q + 4] + sr[q + 5];
     const unsigned long long a0 = mA[ch], a1 = ch + 1 < nch ? mA[ch + 1] : 0ull;
@@ -134,24 +145,35 @@ DEV_INLINE void ff_wide(const DevCtx& d, size_t base, int M, int sp, int ep, int
     const unsigned w5 = (unsigned)(ext128((jp >> 59) | (j0 << 5), j0 >> 59, lane) & 0x1full);  // jumps at i-5 .. i-1 (bit 4 = i-1)
     const int rf = min(SR, __ffs((int)(f5 | 0x20u)) - 1), rb = min(SR, __clz((int)(w5 << 27)));
     const double ad = (double)fabsf(cdv), curv = ad * ad;                                       // (double)diff_range * diff_range, exact (:125)
-    const bool free_ = own && !pk && k > carry;
+    const bool free_ = own && !pk;
     const bool cs = free_ && !gnd && curv > P.edge_thres;
     const bool cf = free_ && gnd && curv < P.surf_thres;
     const uint32_t kb = (uint32_t)d_f2i(fabsf(cdv));
     const uint32_t pay = ((uint32_t)loc << 6) | ((uint32_t)rf << 3) | (uint32_t)rb;
     const unsigned long long ms = __ballot(cs), mf = __ballot(cf), below = (1ull << lane) - 1ull;
-    if (cs) {
-      const int pos = ns + (int)__popcll(ms & below);
-      if (pos < CS) { keyl[pos] = kb + 1u; payl[pos] = (uint16_t)pay; } else ovf_s[pos - CS] = make_uint2(kb + 1u, pay);
-    }
-    if (cf) {
-      const int pos = nf + (int)__popcll(mf & below);
-      if (pos < CF) { keyl[CS + pos] = ~kb; payl[CS + pos] = (uint16_t)(0xFFFFu - pay); } else ovf_f[pos - CF] = make_uint2(~kb, 0xFFFFu - pay);
-    }
+    if (cs) list[ns + (int)__popcll(ms & below)] = make_uint2(kb + 1u, pay);
+    if (cf) list[sector_cap - 1 - (nf + (int)__popcll(mf & below))] = make_uint2(~kb, ~pay);
     ns += (int)__popcll(ms); nf += (int)__popcll(mf);
     if (dbg && own) { d.cd[base + k] = cdv; d.picked0[base + k] = pk ? 1 : 0; }
   }
   ns_out = ns; nf_out = nf;
+}
+
+// one wavefront per (ring, sector) — every sector of every ring of every stream at once, nothing sequential
+__global__ void __launch_bounds__(64 * FC_NW) fe_cand(DevCtx d, int sector_cap) {
+  const int slot = blockIdx.y + d.slot0, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int NS = d.NS, NSEC = d.P.n_sectors;
+  const int item = blockIdx.x * FC_NW + wave, ring = item / NSEC, j = item - ring * NSEC;
+  const size_t base = (size_t)slot * d.N;
+  const int M = d.scal[slot * SC_COUNT + SC_M];
+  extern __shared__ __attribute__((aligned(16))) unsigned char ff_smem[];
+  const FfLayout L = ff_layout(sector_cap);
+  int sp = 0, ep = -1;
+  if (ring < NS) ff_sector(d.P, d.ring_start[slot * NS + ring], d.ring_end[slot * NS + ring], j, sp, ep);
+  int ns = 0, nf = 0;
+  if (sp < ep) ff_wide(d, base, M, sp, ep, ff_smem + wave * L.wave_bytes, L, ff_list(d, slot, ring, j, sector_cap), sector_cap, ns, nf, d.n_launch == 1);
+  else { __syncthreads(); __syncthreads(); }
+  if (ring < NS && lane == 0) { int* cc = ff_counts(d, slot, ring); cc[2 * j] = ns; cc[2 * j + 1] = nf; }
 }
 
 // what the eight ring groups of the picking wavefront carry from sector to sector
@@ -159,29 +181,53 @@ struct FfPick {
   bool act0;            // the ring exists and the sector has at least two points (:181)
   int sp;               // first point of the sector
   int carry;            // largest index marked so far
+  int carry_in;         // ... when the sector began: its candidates at or below it are gone (the marks of a pick are contiguous from the
+                        // pick, so everything between the sector's start and carry_in is marked; inside a sector the bitmap / registers decide)
   int n_sharp, n_ls, n_flat;
   int* st_sharp; int* st_lsharp; int* st_flat;
 };
 
+// label / continuation of the pick that has just been counted (:196-210, :245-251), shared by the two pick loops
+template <bool FLAT>
+DEV_INLINE void ff_label(const alego_params& P, int picked, int nmax, int& lab, bool& spread, bool& more) {
+  if (FLAT) { lab = -1; more = picked < P.n_flat; spread = more; }                       // the n_flat-th pick breaks before the suppression (:248-251)
+  else { lab = picked <= P.n_sharp ? 2 : (picked <= P.n_less_sharp ? 1 : 0); spread = lab != 0; more = lab != 0 && picked < nmax; }
+}
+// a pick's bookkeeping: sharp picks set their reach in the sector's mark bitmap (the flat candidates are tested against it when they are
+// loaded), every pick raises `carry`, lane 0 of the group appends the index to the ring's lists
+template <bool FLAT>
+DEV_INLINE void ff_commit(FfPick& R, bool rem, int lab, int c, int lo, int hi, uint32_t* mark, int mw, int gl) {
+  if (!FLAT) {   // the reach as bits of the sector's mark bitmap: at most two words, lanes 0 and 1 of the group
+    const int w = (lo >> 5) + (gl & 1), wl = max(lo, 32 * w), wh = min(hi, 32 * w + 31);
+    const uint32_t bits = (rem && gl < 2 && wh >= wl) ? (((2u << (wh - 32 * w)) - 1u) & ~((1u << (wl - 32 * w)) - 1u)) : 0u;
+    atomicOr(&mark[min(w, mw - 1)], bits);
+  }
+  if (rem) R.carry = max(R.carry, R.sp + hi);
+  if (rem && gl == 0) {
+    if (FLAT) R.st_flat[R.n_flat] = R.sp + c;
+    else { if (lab == 2) R.st_sharp[R.n_sharp] = R.sp + c; R.st_lsharp[R.n_ls] = R.sp + c; }
+  }
+  if (FLAT) R.n_flat += rem ? 1 : 0;
+  else { R.n_sharp += (rem && lab == 2) ? 1 : 0; R.n_ls += rem ? 1 : 0; }
+}
+DEV_INLINE bool ff_marked(const uint32_t* mark, int mw, uint32_t loc) { return (mark[min((int)(loc >> 5), mw - 1)] >> (loc & 31u)) & 1u; }
+
 // The greedy pick of one sector for the eight rings of the wavefront, candidates in registers: lane gl of a group holds the list entries
-// gl, gl + 8, ... (K of them).  FLAT = false: sharp / less-sharp (:189-236), FLAT = true: flat (:238-277).  Every pick: arg-max of (key, pay)
-// over the group (ties: see ff_wide), label by count, then every candidate inside the picked point's reach leaves the registers; sharp
-// picks also set their reach in the sector's mark bitmap (the flat candidates are tested against it when they are loaded) and every pick
-// raises `carry`, the marks that reach into the next sector.  The (n_less_sharp + 1)-th sharp pick of the reference (:207-210: marked, not
-// labelled, break) has no effect on any output — it marks a non-ground point of its own sector, and only ground points are flat candidates — and
-// is not taken.
+// gl, gl + 8, ... (K of them; lp[t * dir] = entry t).  FLAT = false: sharp / less-sharp (:189-236), FLAT = true: flat (:238-277).  Every pick:
+// arg-max of (key, pay) over the group, label by count, then every candidate inside the picked point's reach leaves the registers.  The
+// (n_less_sharp + 1)-th sharp pick of the reference (:207-210: marked, not labelled, break) has no effect on any output — it marks a non-ground
+// point of its own sector, and only ground points are flat candidates — and is not taken.
 template <int K, bool FLAT>
-DEV_INLINE void ff_pick_regs(const alego_params& P, FfPick& R, int ncand, const uint32_t* keyl, const uint16_t* payl, uint32_t* mark, int mw, int gl) {
+DEV_INLINE void ff_pick_regs(const alego_params& P, FfPick& R, int ncand, const uint2* lp, int dir, uint32_t* mark, int mw, int gl) {
   uint32_t key[K], pay[K];
 #pragma unroll
-  for (int t = 0; t < K; ++t) {
+  for (int t = 0; t < K; ++t) {   // unconditional loads from clamped addresses: all K in flight together
     const int idx = gl + 8 * t;
     const bool ok = R.act0 && idx < ncand;
-    const int ia = ok ? idx : 0;
-    uint32_t kv = keyl[ia];
-    const uint32_t pv = payl[ia];
-    if (FLAT) { const uint32_t loc = (0xFFFFu - pv) >> 6; if ((mark[min((int)(loc >> 5), mw - 1)] >> (loc & 31u)) & 1u) kv = 0u; }
-    key[t] = ok ? kv : 0u; pay[t] = pv;
+    const uint2 e = lp[(ok ? idx : 0) * dir];
+    const uint32_t pv = FLAT ? ~e.y : e.y, loc = pv >> 6;
+    const bool gone = R.sp + (int)loc <= R.carry_in || (FLAT && ff_marked(mark, mw, loc));
+    key[t] = (ok && !gone) ? e.x : 0u; pay[t] = e.y;
   }
   const int nmax = FLAT ? 0x7fffffff : max(P.n_sharp, P.n_less_sharp);
   int picked = 0;
@@ -198,51 +244,32 @@ DEV_INLINE void ff_pick_regs(const alego_params& P, FfPick& R, int ncand, const 
     act = act && kmax != 0u;
     if (!__any(act)) break;
     uint32_t pm = grp8_max_u32(bk == kmax ? bp : 0u);
-    if (FLAT) pm = 0xFFFFu - pm;
+    if (FLAT) pm = ~pm;
     const int c = (int)(pm >> 6), rf = (int)((pm >> 3) & 7u), rb = (int)(pm & 7u);
     picked += act ? 1 : 0;
     int lab;
     bool spread, more;
-    if (FLAT) { lab = -1; more = picked < P.n_flat; spread = more; }                       // the n_flat-th pick breaks before the suppression (:248-251)
-    else { lab = picked <= P.n_sharp ? 2 : (picked <= P.n_less_sharp ? 1 : 0); spread = lab != 0; more = lab != 0 && picked < nmax; }
+    ff_label<FLAT>(P, picked, nmax, lab, spread, more);
     const int lo = max(c - (spread ? rb : 0), 0), hi = c + (spread ? rf : 0);
     const bool rem = act && (FLAT || lab != 0);
 #pragma unroll
     for (int t = 0; t < K; ++t) {
-      const uint32_t loc = (FLAT ? 0xFFFFu - pay[t] : pay[t]) >> 6;
+      const uint32_t loc = (FLAT ? ~pay[t] : pay[t]) >> 6;
       if (rem && loc - (uint32_t)lo <= (uint32_t)(hi - lo)) key[t] = 0u;
     }
-    if (!FLAT) {   // the reach as bits of the sector's mark bitmap: at most two words, lanes 0 and 1 of the group
-      const int w = (lo >> 5) + (gl & 1), wl = max(lo, 32 * w), wh = min(hi, 32 * w + 31);
-      const uint32_t bits = (rem && gl < 2 && wh >= wl) ? (((2u << (wh - 32 * w)) - 1u) & ~((1u << (wl - 32 * w)) - 1u)) : 0u;
-      atomicOr(&mark[min(w, mw - 1)], bits);
-    }
-    if (rem) R.carry = max(R.carry, R.sp + hi);
-    if (rem && gl == 0) {
-      if (FLAT) R.st_flat[R.n_flat] = R.sp + c;
-      else { if (lab == 2) R.st_sharp[R.n_sharp] = R.sp + c; R.st_lsharp[R.n_ls] = R.sp + c; }
-    }
-    if (FLAT) R.n_flat += rem ? 1 : 0;
-    else { R.n_sharp += (rem && lab == 2) ? 1 : 0; R.n_ls += rem ? 1 : 0; }
+    ff_commit<FLAT>(R, rem, lab, c, lo, hi, mark, mw, gl);
     act = act && more;
   }
 }
 
-// the same pick with the candidates left where ff_wide put them (LDS, overflow in HBM): any number of candidates, any sector length
+// the same pick with the candidates left in their list: any number of candidates, any sector length
 template <bool FLAT>
-DEV_INLINE void ff_pick_mem(const alego_params& P, FfPick& R, int ncand, int nwave, uint32_t* keyl, const uint16_t* payl, int cap, uint2* ovf, uint32_t* mark, int mw, int gl) {
-  auto load = [&](int t, uint32_t& kv, uint32_t& pv) {
-    if (t < cap) { kv = keyl[t]; pv = payl[t]; } else { const uint2 e = ovf[t - cap]; kv = e.x; pv = e.y; }
-  };
-  auto kill = [&](int t) { if (t < cap) keyl[t] = 0u; else ovf[t - cap].x = 0u; };
-  if (FLAT) {
-    for (int t = gl; t < nwave; t += 8) {
-      if (R.act0 && t < ncand) {
-        uint32_t kv, pv;
-        load(t, kv, pv);
-        const uint32_t loc = (0xFFFFu - pv) >> 6;
-        if ((mark[min((int)(loc >> 5), mw - 1)] >> (loc & 31u)) & 1u) kill(t);
-      }
+DEV_INLINE void ff_pick_mem(const alego_params& P, FfPick& R, int ncand, int nwave, uint2* lp, int dir, uint32_t* mark, int mw, int gl) {
+  for (int t = gl; t < nwave; t += 8) {   // what the earlier sectors' picks (and, for flat, this sector's sharp picks) have marked
+    if (R.act0 && t < ncand) {
+      const uint2 e = lp[t * dir];
+      const uint32_t loc = (FLAT ? ~e.y : e.y) >> 6;
+      if (R.sp + (int)loc <= R.carry_in || (FLAT && ff_marked(mark, mw, loc))) lp[t * dir].x = 0u;
     }
   }
   const int nmax = FLAT ? 0x7fffffff : max(P.n_sharp, P.n_less_sharp);
@@ -252,128 +279,78 @@ DEV_INLINE void ff_pick_mem(const alego_params& P, FfPick& R, int ncand, int nwa
     uint32_t bk = 0u, bp = 0u;
     for (int t = gl; t < nwave; t += 8) {
       if (act && t < ncand) {
-        uint32_t kv, pv;
-        load(t, kv, pv);
-        const bool take = FLAT ? kv > bk : kv >= bk;
-        bk = take ? kv : bk; bp = take ? pv : bp;
+        const uint2 e = lp[t * dir];
+        const bool take = FLAT ? e.x > bk : e.x >= bk;
+        bk = take ? e.x : bk; bp = take ? e.y : bp;
       }
     }
     const uint32_t kmax = grp8_max_u32(bk);
     act = act && kmax != 0u;
     if (!__any(act)) break;
     uint32_t pm = grp8_max_u32(bk == kmax ? bp : 0u);
-    if (FLAT) pm = 0xFFFFu - pm;
+    if (FLAT) pm = ~pm;
     const int c = (int)(pm >> 6), rf = (int)((pm >> 3) & 7u), rb = (int)(pm & 7u);
     picked += act ? 1 : 0;
     int lab;
     bool spread, more;
-    if (FLAT) { lab = -1; more = picked < P.n_flat; spread = more; }
-    else { lab = picked <= P.n_sharp ? 2 : (picked <= P.n_less_sharp ? 1 : 0); spread = lab != 0; more = lab != 0 && picked < nmax; }
+    ff_label<FLAT>(P, picked, nmax, lab, spread, more);
     const int lo = max(c - (spread ? rb : 0), 0), hi = c + (spread ? rf : 0);
     const bool rem = act && (FLAT || lab != 0);
     for (int t = gl; t < nwave; t += 8) {
       if (rem && t < ncand) {
-        uint32_t kv, pv;
-        load(t, kv, pv);
-        const uint32_t loc = (FLAT ? 0xFFFFu - pv : pv) >> 6;
-        if (loc - (uint32_t)lo <= (uint32_t)(hi - lo)) kill(t);
+        const uint32_t pv = lp[t * dir].y, loc = (FLAT ? ~pv : pv) >> 6;
+        if (loc - (uint32_t)lo <= (uint32_t)(hi - lo)) lp[t * dir].x = 0u;
       }
     }
-    if (!FLAT) {
-      const int w = (lo >> 5) + (gl & 1), wl = max(lo, 32 * w), wh = min(hi, 32 * w + 31);
-      const uint32_t bits = (rem && gl < 2 && wh >= wl) ? (((2u << (wh - 32 * w)) - 1u) & ~((1u << (wl - 32 * w)) - 1u)) : 0u;
-      atomicOr(&mark[min(w, mw - 1)], bits);
-    }
-    if (rem) R.carry = max(R.carry, R.sp + hi);
-    if (rem && gl == 0) {
-      if (FLAT) R.st_flat[R.n_flat] = R.sp + c;
-      else { if (lab == 2) R.st_sharp[R.n_sharp] = R.sp + c; R.st_lsharp[R.n_ls] = R.sp + c; }
-    }
-    if (FLAT) R.n_flat += rem ? 1 : 0;
-    else { R.n_sharp += (rem && lab == 2) ? 1 : 0; R.n_ls += rem ? 1 : 0; }
+    ff_commit<FLAT>(R, rem, lab, c, lo, hi, mark, mw, gl);
     act = act && more;
   }
 }
 
-DEV_INLINE void ff_sector(const alego_params& P, int S, int E, int j, int& sp, int& ep) {
-  const int NSEC = P.n_sectors;
-  if (P.sector_formula == 0) { sp = (S * (NSEC - j) + E * j) / NSEC; ep = (S * (NSEC - 1 - j) + E * (j + 1)) / NSEC - 1; }   // laserOdometry.cpp:177-178
-  else { const int diff = E - S; sp = S + j * diff / NSEC; ep = S + (j + 1) * diff / NSEC - 1; }                               // LO.cpp:245-249
-}
-
-// NW wavefronts: the staging / candidate part of a sector step is shared ring by ring among them, wavefront 0 picks
-// BIG: sectors of more than 400 points (16 x 4000), candidate lists of up to 192 + 64 per ring sector in registers
-template <int NW, bool BIG>
-__global__ void __launch_bounds__(64 * NW) fe_front(DevCtx d, int sector_cap, int CS, int CF) {
-  const int slot = blockIdx.y + d.slot0, ring0 = blockIdx.x * FF_G, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+// One wavefront per EIGHT rings of a stream (eight lanes each), sector by sector in lock-step: the greedy pick only ever looks at the
+// candidates fe_cand left — a 16 x 1800 sector has ~190 points and ~32 sharp candidates — in registers; arg-max by three DPP steps, suppression =
+// an index-range test on the registers.  BIG: sectors of more than 400 points (16 x 4000: up to ~140 sharp / ~200 flat candidates).
+#define FF_MW_MAX 28   // mark words per ring: sectors of up to 768 points (alego_create) + reach
+template <bool BIG>
+__global__ void __launch_bounds__(64) fe_pick8(DevCtx d, int sector_cap) {
+  const int slot = blockIdx.y + d.slot0, ring0 = blockIdx.x * FF_G, lane = threadIdx.x;
   const int g = lane >> 3, gl = lane & 7;
   const int NS = d.NS;
-  const size_t base = (size_t)slot * d.N;
   const alego_params& P = d.P;
   int* sc = d.scal + slot * SC_COUNT;
-  const int M = sc[SC_M];
-  const bool dbg = d.n_launch == 1;
-  extern __shared__ __attribute__((aligned(16))) unsigned char ff_smem[];
-  const FfLayout L = ff_layout(sector_cap, CS, CF, NW);
-  uint32_t* s_key = reinterpret_cast<uint32_t*>(ff_smem + L.off_key);     // [FF_G][ct]
-  uint16_t* s_pay = reinterpret_cast<uint16_t*>(ff_smem + L.off_pay);     // [FF_G][ct]
-  uint32_t* s_mark = reinterpret_cast<uint32_t*>(ff_smem + L.off_mark);   // [FF_G][mw]
-  int* s_misc = reinterpret_cast<int*>(ff_smem + L.off_misc);             // [FF_G][4]: sharp candidates, flat candidates, carry
-  unsigned char* wl = ff_smem + L.off_wave + wave * L.wave_bytes;
-  if (blockIdx.x == 0 && threadIdx.x == 0) sc[SC_FE_EPOCH] = sc[SC_FE_EPOCH] + 1;   // (fe_ring_out of this launch tags its ring counts with it)
-  // the picking wavefront's ring of this lane
+  __shared__ uint32_t s_mark[FF_G][FF_MW_MAX];
+  const int mw = min((sector_cap + FF_HALO + 31) / 32 + 1, FF_MW_MAX);
+  if (blockIdx.x == 0 && lane == 0) sc[SC_FE_EPOCH] = sc[SC_FE_EPOCH] + 1;   // (fe_ring_out of this launch tags its ring counts with it)
   const int ring = ring0 + g;
   const bool rv = ring < NS;
+  const int rc = rv ? ring : 0;
   const int S = rv ? d.ring_start[slot * NS + ring] : 0, E = rv ? d.ring_end[slot * NS + ring] : 0;
-  int* st = d.st_idx + ((size_t)slot * NS + (rv ? ring : 0)) * d.st_stride;
+  int* st = d.st_idx + ((size_t)slot * NS + rc) * d.st_stride;
+  const int* cc = ff_counts(d, slot, rc);
   FfPick R;
-  R.act0 = false; R.sp = 0; R.carry = -1; R.n_sharp = 0; R.n_ls = 0; R.n_flat = 0;
+  R.act0 = false; R.sp = 0; R.carry = -1; R.carry_in = -1; R.n_sharp = 0; R.n_ls = 0; R.n_flat = 0;
   R.st_sharp = st; R.st_lsharp = st + d.cap_sharp; R.st_flat = st + d.cap_sharp + d.cap_lsharp;
-  if (threadIdx.x < FF_G) s_misc[threadIdx.x * 4 + 2] = -1;
-  __syncthreads();
+  uint32_t* mk = s_mark[g];
   const int NSEC = P.n_sectors;
   for (int j = 0; j < NSEC; ++j) {
-    // ---- candidates of sector j, ring by ring
-    for (int r0 = 0; r0 < FF_G; r0 += NW) {
-      const int rr = r0 + wave, rg = ring0 + rr;
-      int sp = 0, ep = -1;
-      if (rr < FF_G && rg < NS) ff_sector(P, d.ring_start[slot * NS + rg], d.ring_end[slot * NS + rg], j, sp, ep);
-      int ns = 0, nf = 0;
-      if (sp < ep) {   // (wavefront-uniform; the barriers inside ff_wide are matched by the two below)
-        uint2* ovf = reinterpret_cast<uint2*>(d.st_lfds + ((size_t)slot * NS + rg) * d.H);   // the filtered-ring staging of the four-kernel path: free here
-        ff_wide(d, base, M, sp, ep, s_misc[rr * 4 + 2], wl, L, s_key + rr * L.ct, s_pay + rr * L.ct, CS, CF, ovf, ovf + sector_cap, ns, nf, dbg);
-      } else { __syncthreads(); __syncthreads(); }
-      if (rr < FF_G && lane == 0) { s_misc[rr * 4 + 0] = ns; s_misc[rr * 4 + 1] = nf; }
-      if (wave == 0) for (int w = lane; w < NW * L.mw; w += 64) s_mark[min(r0 * L.mw + w, FF_G * L.mw - 1)] = 0u;   // this step's rings' mark bitmaps
-      __syncthreads();
-    }
-    // ---- the picks, eight rings in lock-step
-    if (wave == 0) {
-      int sp = 0, ep = -1;
-      if (rv) ff_sector(P, S, E, j, sp, ep);
-      R.act0 = rv && sp < ep; R.sp = sp;
-      const int ns = R.act0 ? s_misc[g * 4 + 0] : 0, nf = R.act0 ? s_misc[g * 4 + 1] : 0;
-      const uint32_t* kl = s_key + g * L.ct;
-      const uint16_t* pl = s_pay + g * L.ct;
-      uint32_t* mk = s_mark + g * L.mw;
-      uint2* ovf = reinterpret_cast<uint2*>(d.st_lfds + ((size_t)slot * NS + (rv ? ring : 0)) * d.H);
-      const int nsw = (int)wave_max_u32((uint32_t)ns), nfw = (int)wave_max_u32((uint32_t)nf);
-      if (nsw > CS) ff_pick_mem<false>(P, R, ns, nsw, s_key + g * L.ct, pl, CS, ovf, mk, L.mw, gl);
-      else if (nsw <= (BIG ? 64 : 32)) ff_pick_regs<(BIG ? 8 : 4), false>(P, R, ns, kl, pl, mk, L.mw, gl);
-      else if (nsw <= (BIG ? 128 : 64)) ff_pick_regs<(BIG ? 16 : 8), false>(P, R, ns, kl, pl, mk, L.mw, gl);
-      else if (nsw <= (BIG ? 192 : 96)) ff_pick_regs<(BIG ? 24 : 12), false>(P, R, ns, kl, pl, mk, L.mw, gl);
-      else ff_pick_mem<false>(P, R, ns, nsw, s_key + g * L.ct, pl, CS, ovf, mk, L.mw, gl);
-      __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the sharp picks' marks are in LDS before the flat candidates are tested against them
-      __builtin_amdgcn_wave_barrier();
-      if (nfw > CF) ff_pick_mem<true>(P, R, nf, nfw, s_key + g * L.ct + CS, pl + CS, CF, ovf + sector_cap, mk, L.mw, gl);
-      else if (nfw <= 32) ff_pick_regs<4, true>(P, R, nf, kl + CS, pl + CS, mk, L.mw, gl);
-      else if (BIG && nfw <= 64) ff_pick_regs<8, true>(P, R, nf, kl + CS, pl + CS, mk, L.mw, gl);
-      else ff_pick_mem<true>(P, R, nf, nfw, s_key + g * L.ct + CS, pl + CS, CF, ovf + sector_cap, mk, L.mw, gl);
-      if (gl == 0) s_misc[g * 4 + 2] = R.carry;
-    }
-    __syncthreads();
+    int sp = 0, ep = -1;
+    if (rv) ff_sector(P, S, E, j, sp, ep);
+    R.act0 = rv && sp < ep; R.sp = sp; R.carry_in = R.carry;
+    const int ns = R.act0 ? cc[2 * j] : 0, nf = R.act0 ? cc[2 * j + 1] : 0;
+    uint2* lst = ff_list(d, slot, rc, j, sector_cap);
+    for (int w = gl; w < mw; w += 8) mk[w] = 0u;
+    const int nsw = (int)wave_max_u32((uint32_t)ns), nfw = (int)wave_max_u32((uint32_t)nf);
+    if (nsw <= (BIG ? 64 : 32)) ff_pick_regs<(BIG ? 8 : 4), false>(P, R, ns, lst, 1, mk, mw, gl);
+    else if (nsw <= (BIG ? 128 : 64)) ff_pick_regs<(BIG ? 16 : 8), false>(P, R, ns, lst, 1, mk, mw, gl);
+    else if (nsw <= (BIG ? 192 : 96) && !d.opt_fe_cand) ff_pick_regs<(BIG ? 24 : 12), false>(P, R, ns, lst, 1, mk, mw, gl);
+    else ff_pick_mem<false>(P, R, ns, nsw, lst, 1, mk, mw, gl);
+    __builtin_amdgcn_wave_barrier();   // (LDS is in order per wavefront: the sharp picks' marks are there before the flat candidates are tested against them)
+    if (nfw <= 32 && !(d.opt_fe_cand && nfw > 8)) ff_pick_regs<4, true>(P, R, nf, lst + sector_cap - 1, -1, mk, mw, gl);
+    else if (BIG && nfw <= 64 && !d.opt_fe_cand) ff_pick_regs<8, true>(P, R, nf, lst + sector_cap - 1, -1, mk, mw, gl);
+    else ff_pick_mem<true>(P, R, nf, nfw, lst + sector_cap - 1, -1, mk, mw, gl);
+    __builtin_amdgcn_wave_barrier();
   }
-  if (wave == 0 && rv && gl == 0) {
+  if (rv && gl == 0) {
     int* c = d.st_cnt + ((size_t)slot * NS + ring) * 8;
     c[0] = R.n_sharp; c[1] = R.n_ls; c[2] = R.n_flat;
   }
@@ -388,17 +365,121 @@ __global__ void __launch_bounds__(64 * NW) fe_front(DevCtx d, int sector_cap, in
 #define FO_CAP_PCT 72
 #define FO_INVALID 0xFFFFFFFFu
 #define FO_SPIN_LIMIT (1 << 22)
-// points of the ring staged in LDS (by position in the ring): the rest is read from the L2 on every pass (fe_voxel's budget: the workgroup stays
-// at ~40 KB so that four rings share a CU)
+#define FO_STATIC_LDS 3744 // static LDS of fe_ring_out (bitmap, the aliased bucket / box area, reduction scratch), rounded up
+// points of the ring staged in LDS (by position in the ring): the rest is read from the L2 on every pass.  The workgroup stays within 40 KB
+// — FOUR rings per CU; one byte more and it is three (fe_voxel's budget)
 __host__ __device__ inline int fo_stage_cap(int H) {
-  const int by_pct = (H * FO_CAP_PCT / 100 + 15) & ~15, by_lds = (40960 - 2200 - 10 * H) / 16;
+  const int by_pct = (H * FO_CAP_PCT / 100 + 15) & ~15, by_lds = (40960 - FO_STATIC_LDS - 10 * H) / 16;
   return by_lds <= 0 ? 0 : (by_pct < by_lds ? by_pct : (by_lds & ~15));
 }
-static size_t fo_lds_bytes(int H) { return (size_t)10 * H + (size_t)16 * fo_stage_cap(H); }
+static size_t fo_lds_bytes(int H) { return std::max((size_t)10 * H + (size_t)16 * fo_stage_cap(H), (size_t)6 * 65 * 4); }
 
+// order-preserving map float -> u32 (for LDS atomic min / max) and back
+DEV_INLINE uint32_t fo_ord(float f) { const uint32_t b = (uint32_t)d_f2i(f); return b ^ ((b >> 31) ? 0xFFFFFFFFu : 0x80000000u); }
+DEV_INLINE float fo_unord(uint32_t u) { return d_i2f((int32_t)(u ^ ((u >> 31) ? 0x80000000u : 0xFFFFFFFFu))); }
+
+#ifdef ALEGO_TIMING
+__device__ long long fo_times[12];
+extern "C" void alego_fo_times(long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(fo_times), sizeof(long long) * 12); }
+#define FO_TICK(k) do { if (threadIdx.x == 0 && blockIdx.y == 8 && blockIdx.x == 0) fo_times[k] = wall_clock64(); } while (0)
+#else
+#define FO_TICK(k)
+#endif
+
+// the workgroup of row NS: the stream's sharp / less_sharp / flat clouds (ring-ascending concatenation of the picks, :199-205,:245), their
+// index lists, the less_sharp ring offsets and bounding boxes (everything fe_pick8 counted; no ring has to wait for this)
+DEV_INLINE void fo_picks_out(const DevCtx& d, int slot, unsigned char* smem) {
+  const int tid = threadIdx.x, lane = tid & 63, NS = d.NS;
+  const size_t base = (size_t)slot * d.N;
+  const size_t fb = (size_t)slot * 2 + cur_in_flight(d, slot);
+  const int* allc = d.st_cnt + (size_t)slot * NS * 8;
+  const float4* seg = d.seg_lo + base;
+  int (*s_off)[65] = reinterpret_cast<int (*)[65]>(smem);   // [0..2]: first pick of every ring in the three clouds, [3]: first less_sharp box
+  if (tid < 64) {
+    const int r = tid;
+    int c[4];
+    c[0] = r < NS ? allc[r * 8 + 0] : 0; c[1] = r < NS ? allc[r * 8 + 1] : 0; c[2] = r < NS ? allc[r * 8 + 2] : 0;
+    c[3] = (c[1] + LO_CH - 1) / LO_CH;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      int incl = c[k];
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+      s_off[k][r] = incl - c[k];
+      if (r == 63) s_off[k][64] = incl;
+    }
+  }
+  __syncthreads();
+  if (tid <= NS) {
+    d.ring_off[(fb * 2) * (NS + 1) + tid] = tid < NS ? s_off[1][tid] : s_off[1][64];
+    d.ring_boff[(fb * 2) * (NS + 1) + tid] = tid < NS ? s_off[3][tid] : s_off[3][64];
+  }
+  if (tid < 3) d.feat_cnt[fb * 4 + tid] = s_off[tid][64];
+  auto ring_of = [&](int k, int i) -> int {   // largest r with s_off[k][r] <= i (rings beyond NS hold the total: never chosen for i < total)
+    int lo = 0, hi = NS - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (s_off[k][mid] <= i) lo = mid; else hi = mid - 1; }
+    return lo;
+  };
+  const int stoff[3] = {0, d.cap_sharp, d.cap_sharp + d.cap_lsharp};
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    float4* dst = d.feat[k] + fb * d.fcap[k];
+    int* dsti = d.feat_idx[k] + fb * d.fcap[k];
+    float4* bx = d.lo_box + (fb * 2 + 1) * d.lo_box_cap * 2;
+    const bool boxes = k == F_LSHARP;
+    // less_sharp is walked box by box (LO_CH consecutive threads = the up to LO_CH picks of one ring's box), the others pick by pick
+    const int nwork = boxes ? s_off[3][64] * LO_CH : s_off[k][64];
+    for (int i0 = 0; i0 < nwork; i0 += FO_BLOCK) {
+      int i = i0 + tid, r = 0, j = 0, bxi = 0;
+      bool v = i < nwork;
+      if (boxes) {
+        bxi = min(i / LO_CH, s_off[3][64] - 1);
+        r = ring_of(3, bxi); j = (bxi - s_off[3][r]) * LO_CH + (tid % LO_CH);
+        v = v && j < s_off[k][r + 1] - s_off[k][r];
+        i = s_off[k][r] + j;
+      } else if (v) { r = ring_of(k, i); j = i - s_off[k][r]; }
+      float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (v) {
+        const int idx = d.st_idx[((size_t)slot * NS + r) * d.st_stride + stoff[k] + j];
+        p = seg[idx];
+        dsti[i] = idx; dst[i] = p;
+      }
+      if (boxes) {
+        float mn[3] = {3.402823466e+38f, 3.402823466e+38f, 3.402823466e+38f}, mx[3] = {-3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f};
+        if (v) { mn[0] = mx[0] = p.x; mn[1] = mx[1] = p.y; mn[2] = mx[2] = p.z; }
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+          for (int o = LO_CH / 2; o > 0; o >>= 1) { mn[a] = fminf(mn[a], __shfl_xor(mn[a], o, 64)); mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], o, 64)); }
+        if ((tid % LO_CH) == 0 && v) {   // (thread 0 of a box holds its first pick: every box has one)
+          bx[2 * bxi] = make_float4(mn[0], mn[1], mn[2], __int_as_float(i));
+          bx[2 * bxi + 1] = make_float4(mx[0], mx[1], mx[2], __int_as_float(min(LO_CH, s_off[k][r + 1] - i)));
+        }
+      }
+    }
+  }
+  // cloud_label_ for the single-scan entry points / tests (:196-204,:245): 2 sharp, 1 less sharp, -1 flat, 0 otherwise
+  if (d.n_launch == 1) {
+    const int M = d.scal[slot * SC_COUNT + SC_M];
+    for (int k = tid; k < M; k += FO_BLOCK) d.plabel[base + k] = 0;
+    __syncthreads();
+    for (int pass = 0; pass < 3; ++pass) {   // less sharp first: a sharp pick is on both lists
+      const int k = pass == 0 ? 1 : (pass == 1 ? 0 : 2), lab = pass == 0 ? 1 : (pass == 1 ? 2 : -1);
+      for (int i = tid; i < s_off[k][64]; i += FO_BLOCK) {
+        const int r = ring_of(k, i);
+        d.plabel[base + d.st_idx[((size_t)slot * NS + r) * d.st_stride + stoff[k] + i - s_off[k][r]]] = lab;
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// grid (streams, NS + 1): row r < NS = ring r of the stream, row NS = fo_picks_out
 __global__ void __launch_bounds__(FO_BLOCK) fe_ring_out(DevCtx d) {
   const int slot = blockIdx.x + d.slot0, ring = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
   const int NS = d.NS, H = d.H;
+  extern __shared__ __attribute__((aligned(16))) unsigned char fo_smem[];
+  if (ring == NS) { fo_picks_out(d, slot, fo_smem); return; }
   const size_t base = (size_t)slot * d.N;
   const alego_params& P = d.P;
   int* scv = d.scal + slot * SC_COUNT;
@@ -407,43 +488,30 @@ __global__ void __launch_bounds__(FO_BLOCK) fe_ring_out(DevCtx d) {
   const unsigned epoch = (unsigned)scv[SC_FE_EPOCH] & 0xFFFFu;
   const int S = d.ring_start[slot * NS + ring], E = d.ring_end[slot * NS + ring];
   const int n_all = min(max(E - S, 0), H);               // the sectors of a ring cover [S, E - 1] (:177-178)
-  const int* allc = d.st_cnt + (size_t)slot * NS * 8;
-  const int* st = d.st_idx + ((size_t)slot * NS + ring) * d.st_stride;
+  const int n_ls = d.st_cnt[((size_t)slot * NS + ring) * 8 + 1];
+  const int* st_ls = d.st_idx + ((size_t)slot * NS + ring) * d.st_stride + d.cap_sharp;
   const float4* seg = d.seg_lo + base;
-  extern __shared__ __attribute__((aligned(16))) unsigned char fo_smem[];
   float4* s_pt = reinterpret_cast<float4*>(fo_smem);                            // the ring's points [cap]
   const int cap = fo_stage_cap(H);
   unsigned char* fv2 = fo_smem + (size_t)16 * cap;
-  uint32_t* s_key = reinterpret_cast<uint32_t*>(fv2);                           // voxel id per point (FO_INVALID: not in less_flat_scan)   [H]
+  uint32_t* s_key = reinterpret_cast<uint32_t*>(fv2);                           // voxel id per point (a hole carries the id of the point before it)   [H]
   uint32_t* s_rvid = s_key;                                                     // voxel id per run, compacted in place (run r <= its first point)
   uint16_t* s_rstart = reinterpret_cast<uint16_t*>(fv2 + 4 * (size_t)H);        // first point of the run  [H]
   uint16_t* s_order = reinterpret_cast<uint16_t*>(fv2 + 6 * (size_t)H);         // valid runs sorted by (voxel id, run) [H]
   uint16_t* s_tmp = reinterpret_cast<uint16_t*>(fv2 + 8 * (size_t)H);           // valid runs dealt into buckets [H]
-  __shared__ uint32_t s_bm[FE_MAXH / 32 + 1];     // holes of less_flat_scan: the ring's less-sharp picks (label > 0, :284) and points of skipped sectors (:181)
-  __shared__ int s_wpre[FE_MAXH / 32 + 1];
+  __shared__ uint32_t s_bm[FE_MAXH / 32 + 2];     // holes of less_flat_scan: the ring's less-sharp picks (label > 0, :284) and points of skipped sectors (:181)
+  __shared__ int s_alias[768];                    // bucket offsets / cursors while the runs are ordered; hole prefix counts of the pass-through; box corners afterwards
+  int* s_boff = s_alias; int* s_bcur = s_alias + FO_NB + 1; int* s_wpre = s_alias;
+  uint32_t* s_bx = reinterpret_cast<uint32_t*>(s_alias);                        // [box][6]: min xyz, max xyz as ordered u32
   __shared__ float s_red[6][FO_BLOCK / 64];
   __shared__ int s_scan[FO_BLOCK / 64], s_cntv[FO_BLOCK / 64];
-  __shared__ int s_boff[FO_NB + 1], s_bcur[FO_NB + 1];
-  __shared__ int s_pre[8], s_look[3];
-  // ---- offsets of the ring's sharp / less_sharp / flat picks and of its less_sharp boxes (everything fe_front counted)
-  if (tid < 64) {
-    const int r = tid;
-    const int c0 = r < NS ? allc[r * 8 + 0] : 0, c1 = r < NS ? allc[r * 8 + 1] : 0, c2 = r < NS ? allc[r * 8 + 2] : 0;
-    const int b1 = (c1 + LO_CH - 1) / LO_CH;
-    int v[8] = {r < ring ? c0 : 0, r < ring ? c1 : 0, r < ring ? c2 : 0, r < ring ? b1 : 0, c0, c1, c2, b1};
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) v[k] += __shfl_xor(v[k], o, 64);
-      if (lane == 0) s_pre[k] = v[k];
-    }
-  }
+  __shared__ int s_look[3];
+  FO_TICK(0);
   const int BW = (n_all + 31) / 32;
-  for (int w = tid; w <= BW; w += FO_BLOCK) s_bm[w] = 0u;
+  for (int w = tid; w <= BW + 1 && w <= FE_MAXH / 32 + 1; w += FO_BLOCK) s_bm[w] = 0u;
   __syncthreads();
-  const int cnt3[3] = {allc[ring * 8 + 0], allc[ring * 8 + 1], allc[ring * 8 + 2]};
-  for (int t = tid; t < cnt3[1]; t += FO_BLOCK) {
-    const int i = st[d.cap_sharp + t] - S;
+  for (int t = tid; t < n_ls; t += FO_BLOCK) {
+    const int i = st_ls[t] - S;
     if (i >= 0 && i < n_all) atomicOr(&s_bm[i >> 5], 1u << (i & 31));
   }
   if (tid < P.n_sectors) {
@@ -452,48 +520,13 @@ __global__ void __launch_bounds__(FO_BLOCK) fe_ring_out(DevCtx d) {
     const int i = sp - S;
     if (sp == ep && i >= 0 && i < n_all) atomicOr(&s_bm[i >> 5], 1u << (i & 31));   // a one-point sector is skipped (sp >= ep)
   }
-  // ---- the ring's part of the sharp / less_sharp / flat clouds, its less_sharp boxes, its offsets
-  {
-    const int stoff[3] = {0, d.cap_sharp, d.cap_sharp + d.cap_lsharp};
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      float4* dst = d.feat[k] + fb * d.fcap[k] + s_pre[k];
-      int* dsti = d.feat_idx[k] + fb * d.fcap[k] + s_pre[k];
-      for (int t = tid; t < cnt3[k]; t += FO_BLOCK) { const int idx = st[stoff[k] + t]; dst[t] = seg[idx]; dsti[t] = idx; }
-    }
-    float4* bx = d.lo_box + (fb * 2 + 1) * d.lo_box_cap * 2 + (size_t)2 * s_pre[3];
-    const int nb = (cnt3[1] + LO_CH - 1) / LO_CH;
-    for (int b0 = 0; b0 < nb; b0 += FO_BLOCK / LO_CH) {
-      const int b = b0 + tid / LO_CH, t = b * LO_CH + tid % LO_CH;
-      const bool v = b < nb && t < cnt3[1];
-      float mn[3] = {3.402823466e+38f, 3.402823466e+38f, 3.402823466e+38f}, mx[3] = {-3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f};
-      if (v) { const float4 p = seg[st[d.cap_sharp + t]]; mn[0] = mx[0] = p.x; mn[1] = mx[1] = p.y; mn[2] = mx[2] = p.z; }
-#pragma unroll
-      for (int a = 0; a < 3; ++a)
-#pragma unroll
-        for (int o = LO_CH / 2; o > 0; o >>= 1) { mn[a] = fminf(mn[a], __shfl_xor(mn[a], o, 64)); mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], o, 64)); }
-      if (tid % LO_CH == 0 && v) {
-        bx[2 * b] = make_float4(mn[0], mn[1], mn[2], __int_as_float(s_pre[1] + t));
-        bx[2 * b + 1] = make_float4(mx[0], mx[1], mx[2], __int_as_float(min(LO_CH, cnt3[1] - t)));
-      }
-    }
-    int* ro = d.ring_off + (fb * 2) * (NS + 1);
-    int* rb = d.ring_boff + (fb * 2) * (NS + 1);
-    if (tid == 0) {
-      ro[ring] = s_pre[1]; rb[ring] = s_pre[3];
-      if (ring == 0) {
-        ro[NS] = s_pre[5]; rb[NS] = s_pre[7];
-        int* fc = d.feat_cnt + fb * 4;
-        fc[0] = s_pre[4]; fc[1] = s_pre[5]; fc[2] = s_pre[6];
-      }
-    }
-  }
   __syncthreads();
+  FO_TICK(1);
   auto hole = [&](int i) -> bool { return (s_bm[i >> 5] >> (i & 31)) & 1u; };
   auto point = [&](int i) -> float4 { if (i < cap) return s_pt[i]; return seg[S + i]; };
   // ---- pcl::VoxelGrid on the ring's less_flat_scan: runs of consecutive equal voxel ids, ordered through monotone buckets,
-  // centroid in original order — fe_voxel's algorithm on positions of the ring instead of an index list; a hole is a run of its own that
-  // is never ordered
+  // centroid in original order — fe_voxel's algorithm on positions of the ring instead of an index list; a hole stays inside the run of the
+  // point before it and is skipped when the run is summed
   const float inv = 1.0f / P.less_flat_leaf;
   float mn[3] = {3.402823466e+38f, 3.402823466e+38f, 3.402823466e+38f}, mx[3] = {-3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f};
   int nval = 0;
@@ -505,7 +538,7 @@ __global__ void __launch_bounds__(FO_BLOCK) fe_ring_out(DevCtx d) {
     for (int u = 0; u < FO_U; ++u) {
       const int i = i0 + u * FO_BLOCK;
       if (i < min(n_all, cap)) s_pt[i] = pt[u];
-      const bool v = i < n_all && !hole(i);
+      const bool v = i < n_all && !hole(min(i, n_all - 1));
       nval += v ? 1 : 0;
       mn[0] = fminf(mn[0], v ? pt[u].x : 3.402823466e+38f); mn[1] = fminf(mn[1], v ? pt[u].y : 3.402823466e+38f); mn[2] = fminf(mn[2], v ? pt[u].z : 3.402823466e+38f);
       mx[0] = fmaxf(mx[0], v ? pt[u].x : -3.402823466e+38f); mx[1] = fmaxf(mx[1], v ? pt[u].y : -3.402823466e+38f); mx[2] = fmaxf(mx[2], v ? pt[u].z : -3.402823466e+38f);
@@ -530,6 +563,7 @@ __global__ void __launch_bounds__(FO_BLOCK) fe_ring_out(DevCtx d) {
 #pragma unroll
     for (int w = 1; w < FO_BLOCK / 64; ++w) { mn[a] = fminf(mn[a], s_red[a][w]); mx[a] = fmaxf(mx[a], s_red[3 + a][w]); }
   }
+  FO_TICK(2);
   bool passthrough = false;
   if (nval > 0) {
     const long long dx = (long long)((mx[0] - mn[0]) * inv) + 1, dy = (long long)((mx[1] - mn[1]) * inv) + 1, dz = (long long)((mx[2] - mn[2]) * inv) + 1;
@@ -547,13 +581,17 @@ __global__ void __launch_bounds__(FO_BLOCK) fe_ring_out(DevCtx d) {
       divb[a] = (int)floorf(mx[a] * inv) - minb[a] + 1;
     }
     const int mul1 = divb[0], mul2 = divb[0] * divb[1];
+    // a hole takes the id of the nearest non-hole before it (none: invalid, a leading run that is never ordered), so that the few
+    // labelled points do not cut the runs
 #pragma unroll 4
     for (int i = tid; i < n_all; i += FO_BLOCK) {
-      const float4 q = point(i);
+      int src = i;
+      while (src >= 0 && hole(src)) --src;
+      const float4 q = point(max(src, 0));
       const int i0 = (int)(floorf(q.x * inv) - (float)minb[0]);
       const int i1 = (int)(floorf(q.y * inv) - (float)minb[1]);
       const int i2 = (int)(floorf(q.z * inv) - (float)minb[2]);
-      s_key[i] = hole(i) ? FO_INVALID : (uint32_t)(i0 + i1 * mul1 + i2 * mul2);
+      s_key[i] = src < 0 ? FO_INVALID : (uint32_t)(i0 + i1 * mul1 + i2 * mul2);
     }
     __syncthreads();
     // runs of consecutive equal voxel ids
@@ -575,6 +613,7 @@ __global__ void __launch_bounds__(FO_BLOCK) fe_ring_out(DevCtx d) {
       nruns += tot;
       __syncthreads();
     }
+    FO_TICK(3);
     // order the valid runs by (voxel id, run index): dealt into <= FO_NB buckets monotone in the voxel id, ranked inside the bucket
     {
       unsigned T = (unsigned)divb[0] * (unsigned)divb[1] * (unsigned)divb[2];
@@ -621,6 +660,7 @@ __global__ void __launch_bounds__(FO_BLOCK) fe_ring_out(DevCtx d) {
       }
     }
     __syncthreads();
+    FO_TICK(4);
     // voxels = first runs of their id in the order
     int nh = 0;
     for (int j = tid; j < nrv; j += FO_BLOCK) nh += (j == 0 || s_rvid[s_order[j]] != s_rvid[s_order[j - 1]]) ? 1 : 0;
@@ -632,6 +672,7 @@ __global__ void __launch_bounds__(FO_BLOCK) fe_ring_out(DevCtx d) {
 #pragma unroll
     for (int w = 0; w < FO_BLOCK / 64; ++w) nout += s_cntv[w];
   }
+  FO_TICK(5);
   // ---- the ring's less_flat offset: its count for the rings above, the counts of the rings below
   if (tid == 0) __hip_atomic_store(&d.fe_sync[(size_t)slot * NS + ring], (epoch << 16) | (unsigned)nout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (tid < 64) {
@@ -652,18 +693,39 @@ __global__ void __launch_bounds__(FO_BLOCK) fe_ring_out(DevCtx d) {
     for (int o = 32; o > 0; o >>= 1) { c += __shfl_xor(c, o, 64); nbx += __shfl_xor(nbx, o, 64); bad += __shfl_xor(bad, o, 64); }
     if (lane == 0) { s_look[0] = c; s_look[1] = nbx; s_look[2] = bad; }
   }
-  __syncthreads();
+  const int nbox = (nout + LO_CH - 1) / LO_CH;
+  __syncthreads();   // (also: the bucket tables / the hole prefix of the pass-through are dead or read-only from here on... see below)
   const int off3 = s_look[0], boff3 = s_look[1];
   if (s_look[2]) {   // never expected (a lower ring's workgroup is dispatched before this one): nothing is written, the error surfaces on the host
     if (tid == 0) scv[SC_FE_ERR] = 1;
     return;
   }
+  FO_TICK(6);
   float4* out = d.feat[F_LFLAT] + fb * d.fcap[F_LFLAT] + off3;
-  if (passthrough) {
-    __syncthreads();
+  // box corners of every LO_CH consecutive output points, gathered with LDS atomics while the points are written
+  auto box_add = [&](int rank, const float4& p) {
+    uint32_t* b = s_bx + 6 * (rank / LO_CH);
+    atomicMin(&b[0], fo_ord(p.x)); atomicMin(&b[1], fo_ord(p.y)); atomicMin(&b[2], fo_ord(p.z));
+    atomicMax(&b[3], fo_ord(p.x)); atomicMax(&b[4], fo_ord(p.y)); atomicMax(&b[5], fo_ord(p.z));
+  };
+  if (passthrough) {   // (rare; the hole prefix shares its LDS with the box corners: the boxes are taken from the written points afterwards)
     for (int i = tid; i < n_all; i += FO_BLOCK)
       if (!hole(i)) out[i - (s_wpre[i >> 5] + __popc(s_bm[i >> 5] & ((1u << (i & 31)) - 1u)))] = point(i);
+    __syncthreads();
+    for (int bi = tid; bi < nbox; bi += FO_BLOCK) {
+      uint32_t* c = s_bx + 6 * bi;
+      float lo3[3] = {3.402823466e+38f, 3.402823466e+38f, 3.402823466e+38f}, hi3[3] = {-3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f};
+      for (int t = bi * LO_CH; t < min(nout, bi * LO_CH + LO_CH); ++t) {
+        const float4 q = out[t];
+        lo3[0] = fminf(lo3[0], q.x); lo3[1] = fminf(lo3[1], q.y); lo3[2] = fminf(lo3[2], q.z);
+        hi3[0] = fmaxf(hi3[0], q.x); hi3[1] = fmaxf(hi3[1], q.y); hi3[2] = fmaxf(hi3[2], q.z);
+      }
+      __builtin_amdgcn_s_waitcnt(0);   // (all of the thread's reads of s_wpre's area are long done: the barrier above)
+      c[0] = fo_ord(lo3[0]); c[1] = fo_ord(lo3[1]); c[2] = fo_ord(lo3[2]); c[3] = fo_ord(hi3[0]); c[4] = fo_ord(hi3[1]); c[5] = fo_ord(hi3[2]);
+    }
   } else {
+    for (int b = tid; b < 6 * nbox; b += FO_BLOCK) s_bx[b] = (b % 6) < 3 ? 0xFFFFFFFFu : 0u;
+    __syncthreads();
     // first run of every voxel -> output rank; it accumulates all runs of the voxel in order
     int nvox = 0;
     for (int c0 = 0; c0 < nrv; c0 += FO_BLOCK) {
@@ -682,51 +744,45 @@ __global__ void __launch_bounds__(FO_BLOCK) fe_ring_out(DevCtx d) {
         int c = 0;
         for (int jj = j; jj < nrv && s_rvid[s_order[jj]] == vid; ++jj) {
           const int r = s_order[jj], i0 = s_rstart[r], len = (r + 1 < nruns ? (int)s_rstart[r + 1] : n_all) - i0;
-          for (int i = i0; i < i0 + len; ++i) { const float4 q = point(i); sx += q.x; sy += q.y; sz += q.z; si += q.w; ++c; }   // strictly in order
+          // the holes of the run's first 32 points in one word (s_bm has a spare word at its end); a run rarely has any
+          const uint32_t hb = (uint32_t)((((unsigned long long)s_bm[(i0 >> 5) + 1] << 32) | s_bm[i0 >> 5]) >> (i0 & 31));
+          if (hb == 0u && len <= 32) {
+            for (int i = i0; i < i0 + len; ++i) { const float4 q = point(i); sx += q.x; sy += q.y; sz += q.z; si += q.w; }   // strictly in order
+            c += len;
+          } else {
+            for (int i = i0; i < i0 + len; ++i) {
+              if (hole(i)) continue;
+              const float4 q = point(i); sx += q.x; sy += q.y; sz += q.z; si += q.w; ++c;
+            }
+          }
         }
         const float fn = (float)c;
-        out[rank] = make_float4(sx / fn, sy / fn, sz / fn, si / fn);
+        const float4 ctr = make_float4(sx / fn, sy / fn, sz / fn, si / fn);
+        out[rank] = ctr;
+        box_add(rank, ctr);
       }
       nvox += tot;
       __syncthreads();
     }
   }
-  __syncthreads();   // the ring's part of less_flat is written: its boxes are taken from there (global memory written by this workgroup)
+  __syncthreads();
+  FO_TICK(7);
   {
     float4* bx = d.lo_box + (fb * 2 + 0) * d.lo_box_cap * 2 + (size_t)2 * boff3;
-    const int nb = (nout + LO_CH - 1) / LO_CH;
-    for (int b0 = 0; b0 < nb; b0 += FO_BLOCK / LO_CH) {
-      const int b = b0 + tid / LO_CH, t = b * LO_CH + tid % LO_CH;
-      const bool v = b < nb && t < nout;
-      float bn[3] = {3.402823466e+38f, 3.402823466e+38f, 3.402823466e+38f}, bxm[3] = {-3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f};
-      if (v) { const float4 p = out[t]; bn[0] = bxm[0] = p.x; bn[1] = bxm[1] = p.y; bn[2] = bxm[2] = p.z; }
-#pragma unroll
-      for (int a = 0; a < 3; ++a)
-#pragma unroll
-        for (int o = LO_CH / 2; o > 0; o >>= 1) { bn[a] = fminf(bn[a], __shfl_xor(bn[a], o, 64)); bxm[a] = fmaxf(bxm[a], __shfl_xor(bxm[a], o, 64)); }
-      if (tid % LO_CH == 0 && v) {
-        bx[2 * b] = make_float4(bn[0], bn[1], bn[2], __int_as_float(off3 + t));
-        bx[2 * b + 1] = make_float4(bxm[0], bxm[1], bxm[2], __int_as_float(min(LO_CH, nout - t)));
-      }
+    for (int b = tid; b < nbox; b += FO_BLOCK) {
+      const uint32_t* c = s_bx + 6 * b;
+      bx[2 * b] = make_float4(fo_unord(c[0]), fo_unord(c[1]), fo_unord(c[2]), __int_as_float(off3 + b * LO_CH));
+      bx[2 * b + 1] = make_float4(fo_unord(c[3]), fo_unord(c[4]), fo_unord(c[5]), __int_as_float(min(LO_CH, nout - b * LO_CH)));
     }
     if (tid == 0) {
       int* ro = d.ring_off + (fb * 2 + 1) * (NS + 1);
       int* rb = d.ring_boff + (fb * 2 + 1) * (NS + 1);
       ro[ring] = off3; rb[ring] = boff3;
-      if (ring == NS - 1) { ro[NS] = off3 + nout; rb[NS] = boff3 + nb; d.feat_cnt[fb * 4 + 3] = off3 + nout; }
+      if (ring == NS - 1) { ro[NS] = off3 + nout; rb[NS] = boff3 + nbox; d.feat_cnt[fb * 4 + 3] = off3 + nout; }
       d.st_cnt[((size_t)slot * NS + ring) * 8 + 4] = nout;
     }
   }
-  // ---- cloud_label_ of the ring's points for the single-scan entry points / tests (:196-204,:245): 2 sharp, 1 less sharp, -1 flat
-  if (d.n_launch == 1) {
-    const int rf = S - 5, cntr = E - S + 11;
-    for (int k = tid; k < cntr; k += FO_BLOCK) if (rf + k >= 0 && rf + k < d.N) d.plabel[base + rf + k] = 0;
-    __syncthreads();
-    for (int t = tid; t < cnt3[1]; t += FO_BLOCK) d.plabel[base + st[d.cap_sharp + t]] = 1;
-    for (int t = tid; t < cnt3[2]; t += FO_BLOCK) d.plabel[base + st[d.cap_sharp + d.cap_lsharp + t]] = -1;
-    __syncthreads();
-    for (int t = tid; t < cnt3[0]; t += FO_BLOCK) d.plabel[base + st[t]] = 2;
-  }
+  FO_TICK(8);
 }
 
 void launch_fe_curv_debug(const DevCtx& d, hipStream_t st);   // kernels_fe.hip: fe_curv alone (curvature sums / occlusion marks of the points outside every sector, tests only)
@@ -738,15 +794,13 @@ void launch_fe_fused(const DevCtx& d, hipStream_t st) {
   static const bool cfg = hipFuncSetAttribute(reinterpret_cast<const void*>(fe_ring_out), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fo_lds_bytes(FE_MAXH)) == hipSuccess;
   (void)cfg;
   const int sector_cap = (d.H + d.P.n_sectors - 1) / (d.P.n_sectors > 0 ? d.P.n_sectors : 1) + 2;
-  // candidates of a ring sector kept in LDS: 96 sharp + 32 flat cover every sector of the 16 x 1800 and 64 x 2048 streams (sharp: mean 32, max 93);
-  // a 16 x 4000 sector has up to ~140 sharp and ~200 flat candidates.  More than that spills to HBM and is picked from there.
-  int CS = sector_cap > 400 ? 192 : 96, CF = sector_cap > 400 ? 64 : 32;
-  if (d.opt_fe_cand > 0) { CS = std::min(d.opt_fe_cand, CS); CF = std::min((d.opt_fe_cand + 1) / 2, CF); }   // (tests: small lists drive the overflow path)
-  CS = (CS + 1) & ~1; CF = (CF + 1) & ~1;
   if (d.n_launch == 1) launch_fe_curv_debug(d, st);
-  const FfLayout L = ff_layout(sector_cap, CS, CF, 1);
-  const dim3 gf((d.NS + FF_G - 1) / FF_G, d.n_launch);
-  if (sector_cap > 400) { ALEGO_LAUNCH((fe_front<1, true>), gf, dim3(64), (size_t)L.total, st, d, sector_cap, CS, CF); }
-  else { ALEGO_LAUNCH((fe_front<1, false>), gf, dim3(64), (size_t)L.total, st, d, sector_cap, CS, CF); }
-  ALEGO_LAUNCH(fe_ring_out, dim3(d.n_launch, d.NS), dim3(FO_BLOCK), fo_lds_bytes(d.H), st, d);
+  const FfLayout L = ff_layout(sector_cap);
+  ALEGO_LAUNCH(fe_cand, dim3((d.NS * d.P.n_sectors + FC_NW - 1) / FC_NW, d.n_launch), dim3(64 * FC_NW), (size_t)FC_NW * L.wave_bytes, st, d, sector_cap);
+  // registers hold up to 96 sharp + 32 flat candidates of a ring sector (192 + 64 for sectors of more than 400 points: 16 x 4000 has up to ~140 /
+  // ~200); longer lists are picked from memory (ff_pick_mem; ALEGO_FE_CAND != 0 sends everything beyond 64 / 8 there: tests)
+  const dim3 gp((d.NS + FF_G - 1) / FF_G, d.n_launch);
+  if (sector_cap > 400) { ALEGO_LAUNCH(fe_pick8<true>, gp, dim3(64), 0, st, d, sector_cap); }
+  else { ALEGO_LAUNCH(fe_pick8<false>, gp, dim3(64), 0, st, d, sector_cap); }
+  ALEGO_LAUNCH(fe_ring_out, dim3(d.n_launch, d.NS + 1), dim3(FO_BLOCK), fo_lds_bytes(d.H), st, d);
 }
