@@ -25,7 +25,7 @@ EXPORTS = [
     "alego_lo_push_imu", "alego_trajectory_enable", "alego_trajectory_get", "alego_debug_check_guards", "alego_debug_math", "alego_debug_std_sort", "alego_debug_eval_blocks", "alego_debug_transform_to_start", "alego_debug_set_option",
     "alego_lm_keyframe_count", "alego_lm_get_keyframe", "alego_lm_set_keypose", "alego_lm_reset_window", "alego_lm_apply_correction",
     "alego_lm_add_keyframe", "alego_pc2_to_points", "alego_replay_create", "alego_replay_load", "alego_replay_assign",
-    "alego_dist_unique_id", "alego_dist_init", "alego_dist_shutdown", "alego_stream_setup", "alego_stream_run",
+    "alego_dist_unique_id", "alego_dist_init", "alego_dist_shutdown", "alego_dist_allreduce_probe", "alego_stream_setup", "alego_stream_run",
     "alego_loop_detect", "alego_loop_closure_icp",
     "alego_bag_open", "alego_bag_close", "alego_bag_last_error", "alego_bag_topic_count", "alego_bag_topic_info", "alego_bag_message_count",
     "alego_bag_read_raw", "alego_bag_read_pc2", "alego_handle_lock", "alego_handle_unlock",
@@ -190,6 +190,8 @@ def lib():
         L.alego_dist_init.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_char_p]
         L.alego_dist_shutdown.restype = C.c_int
         L.alego_dist_shutdown.argtypes = [C.c_void_p]
+        L.alego_dist_allreduce_probe.restype = C.c_int
+        L.alego_dist_allreduce_probe.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double)]
         L.alego_stream_setup.restype = C.c_int
         L.alego_stream_setup.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.alego_stream_run.restype = C.c_int
@@ -614,6 +616,12 @@ class Handle:
     # ---- one registration sharded over the ranks of an RCCL communicator (BASELINE config 5) ----
     def dist_init(self, rank, world, unique_id: bytes):
         self._check(lib().alego_dist_init(self._h, rank, world, C.create_string_buffer(unique_id, DIST_ID_BYTES)), "alego_dist_init")
+
+    def dist_allreduce_probe(self, iters=200):
+        """microseconds per ncclAllReduce of one solver evaluation's 32 doubles (a collective: every rank calls it)"""
+        us = C.c_double()
+        self._check(lib().alego_dist_allreduce_probe(self._h, iters, C.byref(us)), "alego_dist_allreduce_probe")
+        return float(us.value)
 
     def dist_shutdown(self):
         self._check(lib().alego_dist_shutdown(self._h), "alego_dist_shutdown")

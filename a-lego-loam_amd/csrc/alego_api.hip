@@ -973,6 +973,12 @@ int alego_dist_init(alego_handle* h, int rank, int world, const char id[ALEGO_DI
   drain_back(h);
   return lm_host_dist_init(h->lm, rank, world, id, &h->err);
 }
+int alego_dist_allreduce_probe(alego_handle* h, int iters, double* usec_per_allreduce) {
+  if (!h) return ALEGO_ERR_ARG;
+  hipSetDevice(h->device);
+  drain_back(h);
+  return lm_host_dist_probe(h->lm, iters, usec_per_allreduce, &h->err);
+}
 int alego_dist_shutdown(alego_handle* h) {
   if (!h) return ALEGO_ERR_ARG;
   hipSetDevice(h->device);

@@ -36,6 +36,7 @@ int lm_host_add_keyframe(LmHost* lm, const DevCtx& d, int slot, const float* pos
 int lm_host_dist_unique_id(char* id128);
 int lm_host_dist_init(LmHost* lm, int rank, int world, const char* id128, std::string* err);
 int lm_host_dist_shutdown(LmHost* lm);
+int lm_host_dist_probe(LmHost* lm, int iters, double* usec, std::string* err);
 int lm_host_debug_slice(LmHost* lm, int rank, int world, std::string* err);
 int lm_host_set_map_merge(LmHost* lm, int on, std::string* err);
 int lm_host_debug_get(LmHost* lm, int slot, const char* name, void* out, int cap_bytes, int* count, int* dtype, std::string* err);

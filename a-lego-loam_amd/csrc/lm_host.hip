@@ -494,6 +494,30 @@ int lm_host_dist_init(LmHost* lm, int rank, int world, const char* id128, std::s
   lm->L.shard_rank = rank; lm->L.shard_world = world;
   return 0;
 }
+// the collective of one solver evaluation on its own: `iters` in-place ncclAllReduce(sum, 32 doubles) back to back on the registration's
+// stream between two events (every rank has to call it: it IS a collective); microseconds per all-reduce, enqueue + completion included
+int lm_host_dist_probe(LmHost* lm, int iters, double* usec, std::string* err) {
+  if (!lm->comm) { *err = "alego_dist_allreduce_probe: no communicator (alego_dist_init first)"; return ALEGO_ERR_ARG; }
+  if (iters < 1 || !usec) { *err = "alego_dist_allreduce_probe: iters / output"; return ALEGO_ERR_ARG; }
+  hipStream_t st = lm->st[0];
+  double* buf = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (hipMalloc(&buf, 32 * sizeof(double)) != hipSuccess || hipMemsetAsync(buf, 0, 32 * sizeof(double), st) != hipSuccess ||
+      hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { *err = "alego_dist_allreduce_probe: allocation failed"; if (buf) (void)hipFree(buf); return ALEGO_ERR_HIP; }
+  int rc = 0;
+  for (int i = 0; i < 8 && !rc; ++i) rc = lm_allreduce(lm, buf, 32, st);   // warm the channels
+  (void)hipEventRecord(e0, st);
+  for (int i = 0; i < iters && !rc; ++i) rc = lm_allreduce(lm, buf, 32, st);
+  (void)hipEventRecord(e1, st);
+  const hipError_t se = hipStreamSynchronize(st);
+  float ms = 0.f;
+  if (!rc && se == hipSuccess) (void)hipEventElapsedTime(&ms, e0, e1);
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipFree(buf);
+  if (rc) { *err = lm->dist_err; return rc; }
+  if (se != hipSuccess) { *err = std::string("alego_dist_allreduce_probe: ") + hipGetErrorString(se); return ALEGO_ERR_HIP; }
+  *usec = 1e3 * (double)ms / iters;
+  return 0;
+}
 int lm_host_dist_shutdown(LmHost* lm) {
   if (!lm->comm) return 0;
   for (hipStream_t s : lm->st) (void)hipStreamSynchronize(s);

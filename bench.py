@@ -323,6 +323,43 @@ def cpu_legs(p, bags, prime, seconds=10.0, device=None, n_streams=2048):
                 host_cores=os.cpu_count()), parity, oracle_map_t
 
 
+def rank_self_check(p, h, args, rank, world, dist, device, steps_done, stages):
+    """Every rank's slot 0 against a ONE-slot handle on rank 0 that replays the same (bag, start scan) for the same number of steps:
+    odometry + map pose bit for bit (what tests/test_multi_gpu.py asserts).  Streams never interact and the result of a stream does not
+    depend on which GPU, which slot or how many neighbours it ran with, so any difference is an error of the sharding, not noise."""
+    import torch
+    _, odom, mp = h.batch_get_pose(0)
+    mine = np.concatenate([odom["t"], odom["q"], mp["t"], mp["q"]]).astype(np.float64)
+    if dist is not None:
+        t = torch.tensor(mine, dtype=torch.float64, device="cuda")
+        allp = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allp, t)
+        allp = [a.cpu().numpy() for a in allp]
+    else:
+        allp = [mine]
+    res = None
+    if rank == 0:
+        bad, worst = [], 0.0
+        for r in range(world):
+            bag = make_bags(p, 1, first_stream=r * args.bags, flags=args.scan_flags)   # bag 0 of rank r = the bag of its slot 0 (slot_source(0, .) = (0, 0))
+            os.environ["ALEGO_STREAM_GROUPS"] = "1"
+            h1 = binding.Handle(p, device=device, n_slots=1, ring_len=1)
+            os.environ.pop("ALEGO_STREAM_GROUPS")
+            setup_replay(h1, bag, 1)
+            h1.batch_run(0, steps_done, stages)
+            _, o1, m1 = h1.batch_get_pose(0)
+            h1.close()
+            ref = np.concatenate([o1["t"], o1["q"], m1["t"], m1["q"]]).astype(np.float64)
+            if not np.array_equal(ref.view(np.uint64), allp[r].view(np.uint64)):
+                bad.append(r)
+                worst = max(worst, float(np.abs(ref - allp[r]).max()))
+        res = dict(ranks_checked=world, steps=steps_done, bit_equal=not bad, ranks_differing=bad, max_abs_diff=worst,
+                   what="slot 0 of every rank vs a one-slot handle on rank 0 replaying the same bag: odometry and map pose (t, q), 14 doubles")
+        if bad:
+            print(f"bench.py: SELF-CHECK FAILED: ranks {bad} differ from rank 0's replay of their stream (max |diff| {worst:g})", file=sys.stderr)
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -343,6 +380,9 @@ def main():
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-check", action="store_true", help="skip timed_handle_check (slots of the timed handle against one-slot replicas)")
     ap.add_argument("--no-isolated", action="store_true", help="skip the one-group pass that gives the kernels' isolated durations")
+    ap.add_argument("--self-check", action="store_true", help="after the timed region rank 0 replays, on its own GPU, the stream every rank's slot 0 ran and compares the poses "
+                                                              "bit for bit; always on at N > 1 (--no-self-check turns it off)")
+    ap.add_argument("--no-self-check", action="store_true")
     args = ap.parse_args()
 
     rank, local, world = D.env()
@@ -400,6 +440,12 @@ def main():
     cs = [h.batch_get_counts(s) for s in sample]
     counts = {k: int(round(float(np.mean([c[k] for c in cs])))) for k in cs[0]}      # mean over a sample of streams (they are at different places)
     flags, odom, mp = h.batch_get_pose(0)
+    self_check = None
+    if (args.self_check or world > 1) and not args.no_self_check and not shard:
+        self_check = rank_self_check(p, h, args, rank, world, dist, local, step, stages)
+    allreduce_us = None
+    if shard:
+        allreduce_us = D.gather_floats(h.dist_allreduce_probe(200), dist, device="cuda")   # (a collective: every rank takes part)
     rebuilds0 = sum(h.batch_get_counts(s)["n_rebuild"] for s in range(B))
 
     roof, kern, rebuilds, per, groups = None, None, 0, B, 1
@@ -438,6 +484,12 @@ def main():
             except binding.AlegoError:
                 trunc += 1
         out["truncated_streams"] = trunc
+        if self_check is not None:
+            out["self_check"] = self_check
+        if allreduce_us is not None:
+            # config 5's only data-path collective: one in-place ncclAllReduce(sum, 32 f64) per solver evaluation (~42 per mapping frame)
+            out["shard_allreduce"] = dict(usec_per_allreduce_by_rank=[round(v, 2) for v in allreduce_us], doubles=32, per_mapping_frame=42,
+                                          note="200 back-to-back all-reduces on the registration's stream, enqueue + completion included")
         ab = algorithmic_bytes(counts, p.n_scan)
         # the device rebuilds a local map only when the stream's key-frame set changed; SURVEY 8(d)'s B_LM charges the map terms on
         # every mapping frame (the reference re-concatenates every time).  Both figures are reported.
@@ -524,6 +576,8 @@ def main():
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+    if rank == 0 and (out.get("self_check") or {}).get("bit_equal") is False:
+        sys.exit(3)   # the line is printed (with self_check.bit_equal = false) and the job fails
 
 
 if __name__ == "__main__":

@@ -303,6 +303,9 @@ int alego_loop_closure_icp(alego_handle* h, const alego_kf_in* latest, const ale
 int alego_dist_unique_id(char id[ALEGO_DIST_ID_BYTES]);   /* rank 0: ncclGetUniqueId; distribute the bytes to every rank */
 int alego_dist_init(alego_handle* h, int rank, int world, const char id[ALEGO_DIST_ID_BYTES]);
 int alego_dist_shutdown(alego_handle* h);
+/* the collective of ONE solver evaluation measured on its own (a mapping frame has ~42 of them): `iters` in-place all-reduces of 32 doubles
+ * back to back on the registration's stream; microseconds each.  A collective: every rank of the communicator calls it. */
+int alego_dist_allreduce_probe(alego_handle* h, int iters, double* usec_per_allreduce);
 
 /* ---- sensor_msgs/PointCloud2 to alego_point: pcl::fromROSMsg<PointXYZI>, imageProjection.cpp:54-55, IP.cpp:109-110 ----
  * ROS-free mirror of sensor_msgs/PointField + the PointCloud2 layout fields.  Fields are matched by name ("x", "y", "z",

@@ -233,3 +233,63 @@ def test_replay_example_lists_a_bag_without_a_gpu(tmp_path):
     out = subprocess.run([exe, "--bag", path, "--list"], capture_output=True, text=True, timeout=60)
     assert out.returncode == 0, out.stderr
     assert "/lslidar_point_cloud" in out.stdout and "sensor_msgs/PointCloud2" in out.stdout and " 3" in out.stdout
+
+
+# ---- -m gpu: from bag bytes to poses on the device (README.md:33-37: `rosbag play` + the nodelets; IP.cpp:106-133) ----
+@pytest.mark.gpu
+@pytest.mark.parametrize("compression,dense", [("bz2", True), ("lz4", False)])
+def test_bag_bytes_to_device_poses_vs_oracle(tmp_path, compression, dense):
+    """A bag written here (bz2 / lz4 chunks; PointCloud2 messages in PCL's padded 32-byte point_step, a driver's 22-byte layout and rows
+    with padding; is_dense both ways, the non-dense bag carrying NaN returns) -> alego_bag_read_pc2 -> alego_scan_process on the MI355X,
+    against the oracle fed the same parsed points: segmentation and feature outputs bit-exact, poses within 1e-4.  Then the plain C++
+    host program (`examples/replay --bag`) on the same file: its final poses must be the binding's, digit for digit."""
+    import json
+    from alego_amd import synth
+    from oracle import oracle_py as O
+    p = synth.default_params(16, 1800)
+    p.input_is_dense = 1 if dense else 0
+    n_scans = 8
+    msgs, sent = [], []
+    for k in range(n_scans):
+        pts = synth.scan(p, k)
+        pts = pts[: (len(pts) // 4) * 4].copy()       # (height = 4 rows in one of the layouts)
+        if not dense:
+            pts[37 + k, 0] = np.nan; pts[1000 + 3 * k, 2] = np.nan
+        kw = [dict(), dict(layout="driver"), dict(height=4, pad=24)][k % 3]
+        msgs.append(("/lslidar_point_cloud", 50.0 + 0.1 * k, pc2_message(pts, k, 49.9 + 0.1 * k, dense=dense, **kw)))
+        if k % 3 == 0:
+            msgs.append(("/imu/data", 50.0 + 0.1 * k + 0.02, b"\x00" * 40))
+        sent.append(pts)
+    path = str(tmp_path / f"dev_{compression}.bag")
+    write_bag(path, msgs, compression=compression, chunk_msgs=3, topics_types={"/imu/data": "sensor_msgs/Imu"})
+    bag = binding.Bag(path)
+    assert bag.message_count("/lslidar_point_cloud") == n_scans
+    h, o = binding.Handle(p), O.Oracle(p)
+    last = None
+    for k in range(n_scans):
+        pts, stamp, is_dense = bag.read_pc2("/lslidar_point_cloud", k, cap=p.n_scan * p.horizon_scan)
+        assert is_dense == dense and abs(stamp - (49.9 + 0.1 * k)) < 1e-6
+        assert_bit_equal(pts, sent[k], f"message {k} as parsed")
+        o.process_scan(pts)
+        flags, odom, mp, seg, feat = h.scan_process(pts, stages=7, want_outputs=True)
+        assert_bit_equal(seg["label_image"], o.get("label_img"), f"scan {k} label image")
+        for name, key in (("seg", "seg_cloud"), ("col", "seg_col"), ("ground", "seg_ground"), ("range", "seg_range")):
+            assert_bit_equal(seg[name], o.get(key), f"scan {k} {key}")
+        for name in ("sharp", "less_sharp", "flat", "less_flat"):
+            assert_bit_equal(feat[name], o.get(name), f"scan {k} {name}")
+        for name in ("sharp_idx", "less_sharp_idx", "flat_idx"):
+            assert_bit_equal(h.debug_get(name), o.get(name), f"scan {k} {name}")
+        if k > 0:
+            assert np.abs(odom["t"] - o.get("odom_pose")[:3]).max() < 1e-4
+            assert np.abs(mp["t"] - o.get("map_pose")[:3]).max() < 1e-4
+        last = (odom, mp)
+    h.close(); bag.close()
+    exe = os.path.join(ROOT, "examples", "replay")
+    if not os.path.exists(exe):
+        pytest.skip("examples/replay not built")
+    out = subprocess.run([exe, "--bag", path, "--n-scan", "16", "--horizon", "1800"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    j = json.loads(out.stdout.strip().splitlines()[-1])
+    assert j["scans"] == n_scans and j["dropped"] == 0
+    assert j["odom_t"] == [float(v) for v in last[0]["t"]], (j["odom_t"], last[0]["t"])
+    assert j["map_t"] == [float(v) for v in last[1]["t"]], (j["map_t"], last[1]["t"])
