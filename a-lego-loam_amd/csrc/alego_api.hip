@@ -253,6 +253,7 @@ int alego_create(const alego_params* params, int device, int n_slots, int ring_l
   d.inv_res_x = 1.0 / params->ang_res_x; d.inv_res_y = 1.0 / params->ang_res_y;
   d.tan_theta = (params->seg_theta > 0.0 && params->seg_theta < 1.5) ? std::tan(params->seg_theta) : std::nan("");
   d.opt_ip_fused = env_int("ALEGO_IP_FUSED", 1) != 0;
+  d.opt_ip_half = env_int("ALEGO_IP_HALF", 1) != 0;
   d.opt_cc_fused = env_int("ALEGO_CC_FUSED", 1) != 0;
   d.opt_cc_tile = env_int("ALEGO_CC_TILE", 1) != 0;
   d.opt_fe_pick1 = env_int("ALEGO_FE_PICK1", 0) != 0;
@@ -268,6 +269,8 @@ int alego_create(const alego_params* params, int device, int n_slots, int ring_l
   rc |= dalloc(h, &d.parent, B * N); rc |= dalloc(h, &d.cc_size, B * N); rc |= dalloc(h, &d.cc_rows, B * N);
   rc |= dalloc(h, &d.label_img, B * N); rc |= dalloc(h, &d.cc_label, B * N); rc |= dalloc(h, &d.row_cnt, B * NS * 4);
   rc |= dalloc(h, &d.scal, B * SC_COUNT);
+  d.ipf_own = nullptr;
+  if (d.NS <= 16 && d.N <= 32768 && (d.H & 1) == 0) rc |= dalloc(h, &d.ipf_own, B * (N / 2), false);
   rc |= dalloc(h, &d.seg_pts, B * N); rc |= dalloc(h, &d.seg_ground, B * N); rc |= dalloc(h, &d.seg_col, B * N);
   rc |= dalloc(h, &d.seg_range, B * N); rc |= dalloc(h, &d.ring_start, B * NS); rc |= dalloc(h, &d.ring_end, B * NS);
   rc |= dalloc(h, &d.ori, B * 4); rc |= dalloc(h, &d.outlier, B * N);
@@ -927,6 +930,7 @@ int alego_debug_set_option(alego_handle* h, const char* name, int value) {
   DevCtx& d = h->d;
   if (s == "ALEGO_CC_FUSED") d.opt_cc_fused = value != 0;
   else if (s == "ALEGO_IP_FUSED") d.opt_ip_fused = value != 0;
+  else if (s == "ALEGO_IP_HALF") d.opt_ip_half = value != 0;
   else if (s == "ALEGO_CC_TILE") d.opt_cc_tile = value != 0;
   else if (s == "ALEGO_FE_PICK1") d.opt_fe_pick1 = value != 0;
   else if (s == "ALEGO_FE_FUSED") d.opt_fe_fused = value != 0;

@@ -59,6 +59,7 @@ struct DevCtx {
   double tan_theta;                       // tan(seg_theta) for the edge predicate shortcut; NaN disables the shortcut
   // ---- kernel-variant switches (read once from the environment by alego_create, alego_debug_set_option overrides) ----
   int opt_ip_fused;     // ALEGO_IP_FUSED   1: ImageProjection as one launch, one workgroup per stream (ip_fused; <= 16 rings, <= 32768 cells); 0: ip_project + ip_front + cc_*
+  int opt_ip_half;      // ALEGO_IP_HALF    1: ip_fused_h (512 threads, 2 N + 8 H bytes of LDS: two workgroups per CU) where it applies; 0: ip_fused
   int opt_cc_fused;     // ALEGO_CC_FUSED   1: cc_lds16 also compacts; 0: ip_rowcount + ip_compact
   int opt_cc_tile;      // ALEGO_CC_TILE    1: images beyond the LDS paths are labelled band by band in LDS (cc_tile + cc_seam); 0: cc_runs + cc_link
   int opt_fe_pick1;     // ALEGO_FE_PICK1   1: one ring per wavefront (fe_pick) instead of fe_pick4
@@ -89,6 +90,7 @@ struct DevCtx {
   int* parent;          // [slot][N] union-find parent (root = min linear index of the component)
   int* cc_size;         // [slot][N] per-root size, later per-root label
   unsigned long long* cc_rows;  // [slot][N] per-root row bitmask
+  unsigned* ipf_own;    // [slot][N / 2] ip_fused_h: the packed 16-bit owners of two adjacent columns between its phases B and D (null: not allocated)
   int* label_img;       // [slot][N] label_mat_
   int* cc_label;        // [slot][N] per-root label_cnt_ number (0 = infeasible)
   int* row_cnt;         // [slot][NS][4] per-row kept / outlier / feasible-root counts

@@ -162,14 +162,21 @@ DEV_INLINE void ip_quick_margins(const DevCtx& d, float* mr, float* mc) {
 // ground test of two vertically adjacent cells (imageProjection.cpp:111-131): |deg(atan2(dz, hypot(dx, dy))) - mount| < thres
 // <=> tan(lo) h < dz < tan(hi) h; decided by the two signed margins unless one of them is within 1e-9 (relative) of zero, where
 // the reference expression decides.  fx, fy, fz = the f32 differences upper - lower.
+// (the reference expressions themselves are real calls, not inlined: they are taken by a vanishing fraction of the cells, and inlined into
+//  the unrolled per-row code of ip_fused / ip_front their fp64 atan2 / hypot bodies were 90 % of those kernels' instructions and the
+//  source of their register spills)
+__device__ __attribute__((noinline)) inline bool ip_is_ground_ref(double dx, double dy, double dz, double mount, double thres) {
+  const double angle = (atan2(dz, hypot(dx, dy)) * 180.0) / M_PI;
+  return fabs(angle - mount) < thres;
+}
+__device__ __attribute__((noinline)) inline bool edge_angle_ref(double y, double x, double theta) { return atan2(y, x) > theta; }
 DEV_INLINE bool ip_is_ground(const DevCtx& d, float fx, float fy, float fz) {
   const double dx = (double)fx, dy = (double)fy, dz = (double)fz;
   const double hq = sqrt(dx * dx + dy * dy);
   const double m1 = dz - d.tan_g_lo * hq, m2 = d.tan_g_hi * hq - dz, tol = 1e-9 * (fabs(dz) + hq);
   if (m1 > tol && m2 > tol) return true;
   if (m1 < -tol || m2 < -tol) return false;
-  const double angle = (atan2(dz, hypot(dx, dy)) * 180.0) / M_PI;
-  return fabs(angle - d.P.sensor_mount_ang) < d.P.ground_angle_thres;
+  return ip_is_ground_ref(dx, dy, dz, d.P.sensor_mount_ang, d.P.ground_angle_thres);
 }
 
 // atan2(y, x) > theta for y > 0, x > 0 (y = d2 sin a, x = d1 - d2 cos a with d1 >= d2 > 0 and 0 < a < pi/2).
@@ -179,7 +186,7 @@ DEV_INLINE bool ip_is_ground(const DevCtx& d, float fx, float fy, float fz) {
 DEV_INLINE bool edge_angle_gt(double y, double x, double theta, double tan_theta) {
   const double xt = x * tan_theta, m = y - xt;
   if (fabs(m) > 1e-9 * (y + fabs(xt))) return m > 0.0;
-  return atan2(y, x) > theta;
+  return edge_angle_ref(y, x, theta);
 }
 
 

@@ -462,12 +462,538 @@ __global__ void __launch_bounds__(IPF2_T) ip_fused(DevCtx d, int ring_pos, int k
 
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// ip_fused_h — the same pipeline in HALF a CU (round 4).  ip_fused holds 16 wavefronts x 128 VGPRs and 130 KB of LDS: it can only be placed
+// on a CU that has drained completely, overlaps with nothing and — with four stream groups keeping every CU partly busy — waits five times its
+// own duration for such a CU.  Here: 512 threads (8 wavefronts x 128 VGPRs: half the register file) and 2 N + 8 H bytes of LDS (72 KB at
+// 16 x 1800), so that two of these workgroups share a CU, or one shares it with the other stream groups' work:
+//   * a thread takes its column pairs ONE AFTER THE OTHER (pair t, then pair t + 512); nothing of a pair stays in registers between the
+//     phases — the four 16-bit row masks of a column live in LDS (fcol: ground, active, right-edges -> roots, down-edges -> feasible cells);
+//   * the owner image is 2 B / cell from the start (point index + 1 <= 32768): "last writer wins" is a 16-bit maximum through a
+//     compare-and-swap on the aligned 32-bit word (LDS has no 16-bit atomics; adjacent cells of consecutive points retry once);
+//   * the parent array of phase C takes the owner image's place; the packed owners a pair needs again for the emit of phase D wait in
+//     an HBM scratch line of the stream (2 N bytes, written and read by this workgroup only: it stays in the L2).
+// Results are bit-identical to ip_fused (same arithmetic per cell, same ordered compaction); ALEGO_IP_HALF=0 selects ip_fused.
+#define IPH_T 512
+#define IPH_NW (IPH_T / 64)
+#define IPH_NP 2
+#ifndef IPH_GB
+#define IPH_GB 4   // rows gathered per batch in phase B / phase D (loads in flight against registers)
+#endif
+#ifndef IPH_GD
+#define IPH_GD 4
+#endif
+struct IphShared {
+  float first_r[IPH_NW][IPF2_ROWS];    // ranges of the first column of every wavefront of the pass in flight
+  unsigned first_act[IPH_NW];
+  float col0_r[IPF2_ROWS];             // column 0 (right neighbour of the last column, :241-248)
+  unsigned col0_act;
+  int red[3][IPH_NW];
+  int cnt[3][IPF2_ROWS * IPH_NP * IPH_NW];   // per (row, pass, wavefront) = column-ascending inside a row: kept cells, outliers, feasible roots
+  int wtot[3][4];
+  int tot[3];
+  int nlist;
+};
+bool iph_eligible(const DevCtx& d) { return ipf_eligible(d) && d.H <= 2 * IPH_NP * IPH_T && d.N <= 32768 && d.ipf_own != nullptr; }
+size_t iph_lds_bytes(const DevCtx& d) { return (size_t)2 * d.N + (size_t)8 * d.H; }
+
+// 16-bit maximum of own16[cell] and val through the aligned 32-bit word
+DEV_INLINE void iph_max16(unsigned* w32, int cell, unsigned val) {
+  unsigned* w = w32 + (cell >> 1);
+  const int sh = (cell & 1) * 16;
+  unsigned old = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  while (((old >> sh) & 0xFFFFu) < val) {
+    const unsigned nw = (old & ~(0xFFFFu << sh)) | (val << sh);
+    const unsigned got = atomicCAS(w, old, nw);
+    if (got == old) break;
+    old = got;
+  }
+}
+// the four row masks of a column
+struct IphCol { unsigned a, b, x, y; };   // a = ground, b = active, x = right-edges (phase C: roots), y = down-edges (after phase C: feasible cells)
+DEV_INLINE IphCol iph_load(const unsigned long long* fcol, int c) { const unsigned long long v = fcol[c]; IphCol m; m.a = (unsigned)v & 0xFFFFu; m.b = (unsigned)(v >> 16) & 0xFFFFu; m.x = (unsigned)(v >> 32) & 0xFFFFu; m.y = (unsigned)(v >> 48); return m; }
+DEV_INLINE void iph_store(unsigned long long* fcol, int c, const IphCol& m) { fcol[c] = (unsigned long long)m.a | ((unsigned long long)m.b << 16) | ((unsigned long long)m.x << 32) | ((unsigned long long)m.y << 48); }
+
+__global__ void __launch_bounds__(IPH_T, 4) ip_fused_h(DevCtx d, int ring_pos, int keep) {   // 4 wavefronts per SIMD = 128 VGPRs: two workgroups per CU
+  const int slot = blockIdx.x + d.slot0;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int N = d.N, H = d.H, NS = d.NS;
+  const size_t base = (size_t)slot * N;
+  const alego_params& P = d.P;
+  extern __shared__ __attribute__((aligned(16))) unsigned char ipf_smem[];
+  unsigned* own16w = reinterpret_cast<unsigned*>(ipf_smem);                                  // [N / 2] phases A, B: two 16-bit owners (index + 1, 0 = empty) per word
+  uint16_t* par = reinterpret_cast<uint16_t*>(ipf_smem);                                     // [N] from phase C on
+  unsigned long long* fcol = reinterpret_cast<unsigned long long*>(ipf_smem + (size_t)2 * N);   // [H] row masks of every column
+  unsigned* own_g = d.ipf_own + (size_t)slot * (N / 2);                                      // the packed owners between phase B and phase D
+  __shared__ IphShared S;
+  const int hpairs = H / 2;
+
+  // ---------------- phase A: projection (as ip_fused; 16-bit owners) ----------------
+  for (int v = tid; v < N / 2; v += IPH_T) own16w[v] = 0u;
+  if (tid == 0) S.nlist = 0;
+  __syncthreads();
+  const int n = scan_count(d, slot, ring_pos);
+  const float4* pts = scan_pts(d, slot, ring_pos);
+  {
+    int* s_list = reinterpret_cast<int*>(fcol);
+    const int list_cap = 2 * H;   // 8 H bytes
+    float qmr, qmc;
+    ip_quick_margins(d, &qmr, &qmc);
+    int vmin = 0x7fffffff, vmax = -1, nvalid = 0;
+#pragma unroll 1
+    for (int i0 = tid; i0 < n; i0 += IPH_T * 4) {
+      float4 pin[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) pin[u] = pts[min(i0 + u * IPH_T, n - 1)];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u * IPH_T;
+        bool valid = false, defer = false;
+        int cell = -1;
+        if (i < n) defer = !ip_point_quick(d, pin[u], qmr, qmc, &valid, &cell);
+        if (cell >= 0) iph_max16(own16w, cell, (unsigned)(i + 1));   // later points overwrite earlier ones (:102-103)
+        if (valid) { vmin = min(vmin, i); vmax = max(vmax, i); ++nvalid; }
+        const unsigned long long dm = __ballot(defer);
+        if (dm) {   // wavefront-aggregated append
+          int lb = 0;
+          if (lane == 0) lb = atomicAdd(&S.nlist, (int)__popcll(dm));
+          lb = __shfl(lb, 0, 64);
+          if (defer) {
+            const int pos = lb + (int)__popcll(dm & ((1ull << lane) - 1ull));
+            if (pos < list_cap) s_list[pos] = i;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    {
+      const bool all = S.nlist > list_cap;
+      const int nl = all ? n : S.nlist;
+#pragma unroll 1
+      for (int j = tid; j < nl; j += IPH_T) {
+        const int i = all ? j : s_list[j];
+        bool v2;
+        const int c2 = ip_point_cell(d, pts[i], &v2);
+        if (c2 >= 0) iph_max16(own16w, c2, (unsigned)(i + 1));
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      vmin = min(vmin, __shfl_xor(vmin, o, 64));
+      vmax = max(vmax, __shfl_xor(vmax, o, 64));
+      nvalid += __shfl_xor(nvalid, o, 64);
+    }
+    if (lane == 0) { S.red[0][wave] = vmin; S.red[1][wave] = vmax; S.red[2][wave] = nvalid; }
+  }
+  __syncthreads();
+  if (tid == IPH_T - 1) {   // orientation block (:62-72)
+    int first = 0x7fffffff, last = -1, pv = 0;
+    for (int w = 0; w < IPH_NW; ++w) { first = min(first, S.red[0][w]); last = max(last, S.red[1][w]); pv += S.red[2][w]; }
+    d.scal[slot * SC_COUNT + SC_PVALID_OUT] = pv;
+    if (last >= 0) {
+      float* ori = d.ori + slot * 4;
+      const float4 p0 = pts[first], p1 = pts[last];
+      float so = -d_atan2f(p0.y, p0.x);
+      float eo = (float)((double)(-d_atan2f(p1.y, p1.x)) + 2 * M_PI);
+      if ((double)(eo - so) > 3 * M_PI) eo = (float)((double)eo - 2 * M_PI);
+      else if ((double)(eo - so) < M_PI) eo = (float)((double)eo + 2 * M_PI);
+      ori[0] = so; ori[1] = eo; ori[2] = eo - so;
+    }
+  }
+
+  // ---------------- phase B: ranges, ground, edges — one column pair per thread and pass ----------------
+#pragma unroll 1
+  for (int p = 0; p < IPH_NP; ++p) {
+    const int pi = tid + p * IPH_T, c0 = 2 * pi, c1 = c0 + 1;
+    const bool colv = pi < hpairs;
+    float rng0[IPF2_ROWS], rng1[IPF2_ROWS];
+    unsigned filled0 = 0, filled1 = 0, ground0 = 0, ground1 = 0;
+    {
+      float lx0 = 0, ly0 = 0, lz0 = 0, lx1 = 0, ly1 = 0, lz1 = 0;
+      bool lok0 = false, lok1 = false;
+#pragma unroll
+      for (int row0 = 0; row0 < IPF2_ROWS; row0 += IPH_GB) {
+        unsigned ob[IPH_GB];
+        float4 pa[IPH_GB], pb[IPH_GB];
+#pragma unroll
+        for (int u = 0; u < IPH_GB; ++u) ob[u] = (colv && row0 + u < NS) ? own16w[((row0 + u) * H + c0) >> 1] : 0u;
+#pragma unroll
+        for (int u = 0; u < IPH_GB; ++u) { pa[u] = pts[max((int)(ob[u] & 0xFFFFu) - 1, 0)]; pb[u] = pts[max((int)(ob[u] >> 16) - 1, 0)]; }
+#pragma unroll
+        for (int u = 0; u < IPH_GB; ++u) {
+          const int row = row0 + u;
+          if (colv && row < NS) own_g[(row * H + c0) >> 1] = ob[u];
+          {
+            const bool ok = (ob[u] & 0xFFFFu) != 0u;
+            const float x = pa[u].x, y = pa[u].y, z = pa[u].z;
+            rng0[row] = ok ? sqrtf(x * x + y * y + z * z) : -1.0f;   // :99
+            if (ok) filled0 |= 1u << row;
+            if (row >= 1 && row - 1 < P.ground_scan_id && ok && lok0 && ip_is_ground(d, x - lx0, y - ly0, z - lz0)) ground0 |= 3u << (row - 1);   // :111-131
+            lx0 = x; ly0 = y; lz0 = z; lok0 = ok;
+          }
+          {
+            const bool ok = (ob[u] >> 16) != 0u;
+            const float x = pb[u].x, y = pb[u].y, z = pb[u].z;
+            rng1[row] = ok ? sqrtf(x * x + y * y + z * z) : -1.0f;
+            if (ok) filled1 |= 1u << row;
+            if (row >= 1 && row - 1 < P.ground_scan_id && ok && lok1 && ip_is_ground(d, x - lx1, y - ly1, z - lz1)) ground1 |= 3u << (row - 1);
+            lx1 = x; ly1 = y; lz1 = z; lok1 = ok;
+          }
+        }
+      }
+    }
+    const unsigned act0 = filled0 & ~ground0, act1 = filled1 & ~ground1;
+    __syncthreads();   // (the previous pass has read S.first_r)
+    if (lane == 0) {
+#pragma unroll
+      for (int r = 0; r < IPF2_ROWS; ++r) S.first_r[wave][r] = rng0[r];
+      S.first_act[wave] = act0;
+    }
+    if (p == 0 && tid == 0) {
+#pragma unroll
+      for (int r = 0; r < IPF2_ROWS; ++r) S.col0_r[r] = rng0[r];
+      S.col0_act = act0;
+    }
+    __syncthreads();
+    // the column to the right of c1: the next thread's first column; column 0 behind the last one (:241-248); the first column of the
+    // NEXT pass behind this pass's last thread, which gathers that one column itself
+    float nbr[IPF2_ROWS];
+    unsigned nb_act = (unsigned)__shfl_down((int)act0, 1, 64);
+#pragma unroll
+    for (int r = 0; r < IPF2_ROWS; ++r) nbr[r] = __shfl_down(rng0[r], 1, 64);
+    const bool wrap = pi == hpairs - 1;                                   // right neighbour = column 0
+    const bool nextpass = !wrap && tid == IPH_T - 1 && p + 1 < IPH_NP;   // right neighbour = first column of the next pass
+    if ((lane == 63 && !nextpass) || wrap) {
+      const int sw = min(wave + 1, IPH_NW - 1);
+#pragma unroll
+      for (int r = 0; r < IPF2_ROWS; ++r) nbr[r] = wrap ? S.col0_r[r] : S.first_r[sw][r];
+      nb_act = wrap ? S.col0_act : S.first_act[sw];
+    }
+    if (nextpass) {
+      const int cx = c0 + 2;   // (< H: not the wrap)
+      unsigned fl = 0, gd = 0;
+      float lx = 0, ly = 0, lz = 0;
+      bool lok = false;
+#pragma unroll
+      for (int row = 0; row < IPF2_ROWS; ++row) {
+        const unsigned ow = row < NS ? (own16w[(row * H + cx) >> 1] & 0xFFFFu) : 0u;
+        const float4 q = pts[max((int)ow - 1, 0)];
+        const bool ok = ow != 0u;
+        nbr[row] = ok ? sqrtf(q.x * q.x + q.y * q.y + q.z * q.z) : -1.0f;
+        if (ok) fl |= 1u << row;
+        if (row >= 1 && row - 1 < P.ground_scan_id && ok && lok && ip_is_ground(d, q.x - lx, q.y - ly, q.z - lz)) gd |= 3u << (row - 1);
+        lx = q.x; ly = q.y; lz = q.z; lok = ok;
+      }
+      nb_act = fl & ~gd;
+    }
+    unsigned redge0 = 0, redge1 = 0, down0 = 0, down1 = 0;
+    if (colv) {
+#pragma unroll
+      for (int row = 0; row < IPF2_ROWS; ++row) {
+        if (row < NS) {
+          if ((act0 >> row) & 1u) {
+            const double r0 = (double)rng0[row];
+            if ((act1 >> row) & 1u) {   // same row, seg_alpha_x (:258-261)
+              const double r1 = (double)rng1[row], d1 = fmax(r0, r1), d2 = fmin(r0, r1);
+              if (edge_angle_gt(d2 * d.sin_ax, d1 - d2 * d.cos_ax, P.seg_theta, d.tan_theta)) redge0 |= 1u << row;
+            }
+            if (row + 1 < NS && ((act0 >> (row + 1)) & 1u)) {   // same column, seg_alpha_y (:262-265)
+              const double r1 = (double)rng0[row + 1 < IPF2_ROWS ? row + 1 : row], d1 = fmax(r0, r1), d2 = fmin(r0, r1);
+              if (edge_angle_gt(d2 * d.sin_ay, d1 - d2 * d.cos_ay, P.seg_theta, d.tan_theta)) down0 |= 1u << row;
+            }
+          }
+          if ((act1 >> row) & 1u) {
+            const double r0 = (double)rng1[row];
+            if ((nb_act >> row) & 1u) {
+              const double r1 = (double)nbr[row], d1 = fmax(r0, r1), d2 = fmin(r0, r1);
+              if (edge_angle_gt(d2 * d.sin_ax, d1 - d2 * d.cos_ax, P.seg_theta, d.tan_theta)) redge1 |= 1u << row;
+            }
+            if (row + 1 < NS && ((act1 >> (row + 1)) & 1u)) {
+              const double r1 = (double)rng1[row + 1 < IPF2_ROWS ? row + 1 : row], d1 = fmax(r0, r1), d2 = fmin(r0, r1);
+              if (edge_angle_gt(d2 * d.sin_ay, d1 - d2 * d.cos_ay, P.seg_theta, d.tan_theta)) down1 |= 1u << row;
+            }
+          }
+        }
+      }
+      fcol[c0] = (unsigned long long)ground0 | ((unsigned long long)act0 << 16) | ((unsigned long long)redge0 << 32) | ((unsigned long long)down0 << 48);
+      fcol[c1] = (unsigned long long)ground1 | ((unsigned long long)act1 << 16) | ((unsigned long long)redge1 << 32) | ((unsigned long long)down1 << 48);
+      if (keep & 1) {
+        float* rimg = d.range_img + base;
+        uint8_t* fimg = d.flag_img + base;
+#pragma unroll
+        for (int row = 0; row < IPF2_ROWS; ++row) {
+          if (row < NS) {
+            rimg[row * H + c0] = rng0[row]; rimg[row * H + c1] = rng1[row];
+            fimg[row * H + c0] = (uint8_t)(((ground0 >> row) & 1u) | (((act0 >> row) & 1u) << 1) | (((redge0 >> row) & 1u) << 2) | (((down0 >> row) & 1u) << 3));
+            fimg[row * H + c1] = (uint8_t)(((ground1 >> row) & 1u) | (((act1 >> row) & 1u) << 1) | (((redge1 >> row) & 1u) << 2) | (((down1 >> row) & 1u) << 3));
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();   // every read of the owner image has happened: its LDS becomes the parent array
+
+  // ---------------- phase C: connected components over vertical runs (ip_fused's steps, column by column from the masks in LDS) ----------------
+  // a cell starts a run when it is active and no down-edge reaches it from below; a run's representative is its first (lowest) cell
+  const int ncol = IPH_NP * 2;   // columns of a thread: 2 (tid + p T) + k
+  auto col_of = [&](int q) -> int { return 2 * (tid + (q >> 1) * IPH_T) + (q & 1); };
+  unsigned* parw = reinterpret_cast<unsigned*>(par);
+#pragma unroll 1
+  for (int p = 0; p < IPH_NP; ++p) {
+    const int pi = tid + p * IPH_T, c0 = 2 * pi, c1 = c0 + 1;
+    if (pi < hpairs) {
+      const IphCol m0 = iph_load(fcol, c0), m1 = iph_load(fcol, c1);
+      const unsigned rs0 = m0.b & ~(m0.y << 1), rs1 = m1.b & ~(m1.y << 1);
+#pragma unroll
+      for (int row = 0; row < IPF2_ROWS; ++row) {
+        if (row < NS) {
+          const int s0 = ((m0.b >> row) & 1u) ? ipf_run_start(rs0, row) : row, s1 = ((m1.b >> row) & 1u) ? ipf_run_start(rs1, row) : row;
+          parw[(row * H + c0) >> 1] = (unsigned)(s0 * H + c0) | ((unsigned)(s1 * H + c1) << 16);
+        }
+      }
+    }
+  }
+  __syncthreads();
+#pragma unroll 1
+  for (int p = 0; p < IPH_NP; ++p) {
+    const int pi = tid + p * IPH_T, c0 = 2 * pi, c1 = c0 + 1;
+    if (pi < hpairs) {
+      const int cn = c0 + 2 == H ? 0 : c0 + 2;
+      const IphCol a0 = iph_load(fcol, c0), a1 = iph_load(fcol, c1);
+      // right-edges between the runs; one is skipped when the cell below already links the same pair of runs
+      const unsigned down_nb = (unsigned)(fcol[cn] >> 48) & 0xFFFFu;
+      unsigned m0 = a0.x & ~((a0.x & a0.y & a1.y) << 1);
+      unsigned m1 = a1.x & ~((a1.x & a1.y & down_nb) << 1);
+      while (m0) { const int row = __ffs((int)m0) - 1; m0 &= m0 - 1; ccl16_union(par, row * H + c0, row * H + c1); }
+      while (m1) { const int row = __ffs((int)m1) - 1; m1 &= m1 - 1; ccl16_union(par, row * H + c1, row * H + cn); }
+    }
+  }
+  __syncthreads();
+  // flatten the run starts; root = minimum linear index of the component = BFS discovery order (:147-156).  The roots take the right-edges' place in fcol.
+#pragma unroll 1
+  for (int q = 0; q < ncol; ++q) {
+    const int c = col_of(q);
+    if (c < H) {
+      IphCol m = iph_load(fcol, c);
+      unsigned root = 0;
+      for (unsigned rm = m.b & ~(m.y << 1); rm; rm &= rm - 1) { const int row = __ffs((int)rm) - 1, s = row * H + c; int r = par[s], nx; while (r > (nx = par[r])) r = nx; par[s] = (uint16_t)r; if (r == s) root |= 1u << row; }
+      m.x = root;
+      iph_store(fcol, c, m);
+    }
+  }
+  __syncthreads();
+  // A root's own entry is free from here on: the component's 16-bit accumulator, first for the size (:282), then for the row mask (:283-294)
+  auto zero_roots = [&]() {
+#pragma unroll 1
+    for (int q = 0; q < ncol; ++q) {
+      const int c = col_of(q);
+      if (c < H) for (unsigned m = (unsigned)(fcol[c] >> 32) & 0xFFFFu; m; m &= m - 1) par[(__ffs((int)m) - 1) * H + c] = 0;
+    }
+    __syncthreads();
+  };
+  auto root_of = [&](unsigned rootm, int row, int c) -> int { const int s = row * H + c; return ((rootm >> row) & 1u) ? s : (int)par[s]; };
+  zero_roots();
+#pragma unroll 1
+  for (int q = 0; q < ncol; ++q) {
+    const int c = col_of(q);
+    if (c < H) {
+      const IphCol m = iph_load(fcol, c);
+      for (unsigned rm = m.b & ~(m.y << 1); rm; rm &= rm - 1) { const int row = __ffs((int)rm) - 1, r = root_of(m.x, row, c); atomicAdd(&parw[r >> 1], (unsigned)(ipf_run_end(m.y, row) - row + 1) << ((r & 1) * 16)); }
+    }
+  }
+  __syncthreads();
+  unsigned bm[IPH_NP * 2];   // per column: runs of big components | runs of mid-sized ones << 16 (bit at the run's start row)
+#pragma unroll
+  for (int q = 0; q < IPH_NP * 2; ++q) {
+    const int c = col_of(q);
+    unsigned big = 0, mid = 0;
+    if (c < H) {
+      const IphCol m = iph_load(fcol, c);
+      for (unsigned rm = m.b & ~(m.y << 1); rm; rm &= rm - 1) { const int row = __ffs((int)rm) - 1, sz = (int)par[root_of(m.x, row, c)]; if (sz >= P.seg_big_num) big |= 1u << row; else if (sz >= P.seg_valid_point_num) mid |= 1u << row; }
+    }
+    bm[q] = big | (mid << 16);
+  }
+  __syncthreads();
+  zero_roots();
+#pragma unroll
+  for (int q = 0; q < IPH_NP * 2; ++q) {   // rows touched by the mid-sized components
+    const int c = col_of(q);
+    if (c < H && (bm[q] >> 16)) {
+      const IphCol m = iph_load(fcol, c);
+      for (unsigned rm = bm[q] >> 16; rm; rm &= rm - 1) { const int row = __ffs((int)rm) - 1, r = root_of(m.x, row, c), e = ipf_run_end(m.y, row); atomicOr(&parw[r >> 1], (((2u << e) - 1u) & ~((1u << row) - 1u)) << ((r & 1) * 16)); }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < IPH_NP * 2; ++q) {   // cells of feasible components: they take the down-edges' place in fcol
+    const int c = col_of(q);
+    if (c < H) {
+      IphCol m = iph_load(fcol, c);
+      const unsigned big = bm[q] & 0xFFFFu, mid = bm[q] >> 16;
+      unsigned feas = 0;
+      for (unsigned rm = big | mid; rm; rm &= rm - 1) {
+        const int row = __ffs((int)rm) - 1, e = ipf_run_end(m.y, row);
+        if (((big >> row) & 1u) || __popc((unsigned)par[root_of(m.x, row, c)]) >= P.seg_valid_line_num) feas |= ((2u << e) - 1u) & ~((1u << row) - 1u);
+      }
+      if (keep & 1) {   // root image for ip_labels / the tests (:303-314), while the down-edges are still there
+        const unsigned rs = m.b & ~(m.y << 1);
+#pragma unroll
+        for (int row = 0; row < IPF2_ROWS; ++row)
+          if (row < NS) d.parent[base + row * H + c] = ((m.b >> row) & 1u) ? root_of(m.x, ipf_run_start(rs, row), c) : -1;
+      }
+      m.y = feas;
+      iph_store(fcol, c, m);
+    }
+  }
+  // (fcol entries are read and written by their own thread only from here on: no barrier)
+
+  // ---------------- phase D: ordered compaction (:158-191) ----------------
+  const unsigned all16 = 0xFFFFu;
+  const unsigned rowgt = P.ground_scan_id >= 15 ? 0u : (P.ground_scan_id < 0 ? all16 : (all16 & ~((2u << P.ground_scan_id) - 1u)));   // rows > ground_scan_id
+  // keep | outliers << 16 of column c; feasible roots (label_cnt_ numbering, :303-306)
+  auto col_sets = [&](int c, const IphCol& m, unsigned& keepm, unsigned& outlm, unsigned& frm) {
+    const bool gk = c % 5 == 0 || c <= 4 || c >= H - 5;
+    keepm = (gk ? m.a : 0u) | m.y;
+    outlm = c % 5 == 0 ? (m.b & ~m.y & rowgt) : 0u;
+    frm = m.x & m.y;
+  };
+#pragma unroll 1
+  for (int p = 0; p < IPH_NP; ++p) {
+    const int pi = tid + p * IPH_T, c0 = 2 * pi, c1 = c0 + 1;
+    unsigned k0 = 0, k1 = 0, o0 = 0, o1 = 0, f0 = 0, f1 = 0;
+    if (pi < hpairs) { col_sets(c0, iph_load(fcol, c0), k0, o0, f0); col_sets(c1, iph_load(fcol, c1), k1, o1, f1); }
+#pragma unroll
+    for (int row = 0; row < IPF2_ROWS; ++row) {
+      const unsigned long long bk0 = __ballot((k0 >> row) & 1u), bk1 = __ballot((k1 >> row) & 1u);
+      const unsigned long long bo0 = __ballot((o0 >> row) & 1u), bo1 = __ballot((o1 >> row) & 1u);
+      const unsigned long long bf0 = __ballot((f0 >> row) & 1u), bf1 = __ballot((f1 >> row) & 1u);
+      if (lane == 0) {
+        const int e = (row * IPH_NP + p) * IPH_NW + wave;
+        S.cnt[0][e] = (int)(__popcll(bk0) + __popcll(bk1));
+        S.cnt[1][e] = (int)(__popcll(bo0) + __popcll(bo1));
+        S.cnt[2][e] = (int)(__popcll(bf0) + __popcll(bf1));
+      }
+    }
+  }
+  __syncthreads();
+  constexpr int NCNT = IPF2_ROWS * IPH_NP * IPH_NW;   // 256
+  {   // exclusive scan of the three 256-entry tables by the first four wavefronts
+    int v3[3] = {0, 0, 0}, in3[3] = {0, 0, 0};
+    if (tid < NCNT) {
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        v3[a] = S.cnt[a][tid];
+        int incl = v3[a];
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+        in3[a] = incl;
+        if (lane == 63) S.wtot[a][wave] = incl;
+      }
+    }
+    __syncthreads();
+    if (tid < NCNT) {
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        int woff = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) if (w < wave) woff += S.wtot[a][w];
+        S.cnt[a][tid] = woff + in3[a] - v3[a];
+        if (tid == NCNT - 1) S.tot[a] = woff + in3[a];
+      }
+    }
+  }
+  __syncthreads();
+  if (tid < NS) {   // startRingIndex / endRingIndex (:161,:190)
+    const int row = tid;
+    d.ring_start[slot * NS + row] = S.cnt[0][row * IPH_NP * IPH_NW] + 5;
+    d.ring_end[slot * NS + row] = (row + 1 < IPF2_ROWS ? S.cnt[0][(row + 1) * IPH_NP * IPH_NW] : S.tot[0]) - 1 - 5;
+  }
+  if (tid == 0) {
+    int* sc = d.scal + slot * SC_COUNT;
+    sc[SC_M] = S.tot[0]; sc[SC_NOUT] = S.tot[1]; sc[SC_NFEAS] = S.tot[2];
+  }
+  const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll 1
+  for (int p = 0; p < IPH_NP; ++p) {
+    const int pi = tid + p * IPH_T, c0 = 2 * pi, c1 = c0 + 1;
+    const bool colv = pi < hpairs;
+    unsigned keep0 = 0, keep1 = 0, outl0 = 0, outl1 = 0, fr0 = 0, fr1 = 0, ground0 = 0, ground1 = 0, root0 = 0, root1 = 0;
+    if (colv) {
+      const IphCol m0 = iph_load(fcol, c0), m1 = iph_load(fcol, c1);
+      col_sets(c0, m0, keep0, outl0, fr0); col_sets(c1, m1, keep1, outl1, fr1);
+      ground0 = m0.a; ground1 = m1.a; root0 = m0.x; root1 = m1.x;
+    }
+#pragma unroll
+    for (int row0 = 0; row0 < IPF2_ROWS; row0 += IPH_GD) {
+      unsigned ow[IPH_GD];
+      float4 qa[IPH_GD], qb[IPH_GD];
+#pragma unroll
+      for (int u = 0; u < IPH_GD; ++u) ow[u] = (colv && row0 + u < NS) ? own_g[((row0 + u) * H + c0) >> 1] : 0u;
+#pragma unroll
+      for (int u = 0; u < IPH_GD; ++u) {
+        const int row = row0 + u;
+        const bool e0 = ((keep0 | outl0) >> row) & 1u, e1 = ((keep1 | outl1) >> row) & 1u;
+        qa[u] = pts[e0 ? (int)(ow[u] & 0xFFFFu) - 1 : 0];   // (clamped address instead of a branch: the eight gathers are in flight together)
+        qb[u] = pts[e1 ? (int)(ow[u] >> 16) - 1 : 0];
+      }
+#pragma unroll
+      for (int u = 0; u < IPH_GD; ++u) {
+        const int row = row0 + u;
+        const bool k0 = (keep0 >> row) & 1u, k1 = (keep1 >> row) & 1u, o0 = (outl0 >> row) & 1u, o1 = (outl1 >> row) & 1u;
+        const unsigned long long bk0 = __ballot(k0), bk1 = __ballot(k1), bo0 = __ballot(o0), bo1 = __ballot(o1);
+        const int e = (row * IPH_NP + p) * IPH_NW + wave;
+        const int lk = S.cnt[0][e] + (int)(__popcll(bk0 & below) + __popcll(bk1 & below));
+        const int lo = S.cnt[1][e] + (int)(__popcll(bo0 & below) + __popcll(bo1 & below));
+        if (k0 | o0) {
+          const float4 q = qa[u];
+          const float4 pp = make_float4(q.x, q.y, q.z, (float)(row + c0 / 10000.0));   // :101
+          if (k0) {
+            d.seg_pts[base + lk] = pp;
+            d.seg_ground[base + lk] = (uint8_t)((ground0 >> row) & 1u);
+            d.seg_col[base + lk] = c0;
+            d.seg_range[base + lk] = sqrtf(q.x * q.x + q.y * q.y + q.z * q.z);   // = the range image's value (:99,:184)
+          } else {
+            d.outlier[base + lo] = pp;
+          }
+        }
+        if (k1 | o1) {
+          const float4 q = qb[u];
+          const float4 pp = make_float4(q.x, q.y, q.z, (float)(row + c1 / 10000.0));
+          const int l1 = lk + (k0 ? 1 : 0), lo1 = lo + (o0 ? 1 : 0);
+          if (k1) {
+            d.seg_pts[base + l1] = pp;
+            d.seg_ground[base + l1] = (uint8_t)((ground1 >> row) & 1u);
+            d.seg_col[base + l1] = c1;
+            d.seg_range[base + l1] = sqrtf(q.x * q.x + q.y * q.y + q.z * q.z);
+          } else {
+            d.outlier[base + lo1] = pp;
+          }
+        }
+      }
+    }
+    if (keep & 1) {   // label_cnt_ numbers of the feasible roots for ip_labels (:303-314)
+#pragma unroll
+      for (int row = 0; row < IPF2_ROWS; ++row) {
+        const unsigned long long bf0 = __ballot((fr0 >> row) & 1u), bf1 = __ballot((fr1 >> row) & 1u);
+        if (colv && row < NS) {
+          const int nf = S.cnt[2][(row * IPH_NP + p) * IPH_NW + wave] + (int)(__popcll(bf0 & below) + __popcll(bf1 & below));
+          if ((root0 >> row) & 1u) d.cc_label[base + row * H + c0] = ((fr0 >> row) & 1u) ? nf + 1 : 0;
+          if ((root1 >> row) & 1u) d.cc_label[base + row * H + c1] = ((fr1 >> row) & 1u) ? nf + ((fr0 >> row) & 1u) + 1 : 0;
+        }
+      }
+    }
+  }
+}
+
 void launch_ip_fused(const DevCtx& d, int ring_pos, bool keep_images, hipStream_t st) {
+  if (d.opt_ip_half && iph_eligible(d)) { ALEGO_LAUNCH(ip_fused_h, dim3(d.n_launch), dim3(IPH_T), iph_lds_bytes(d), st, d, ring_pos, keep_images ? 1 : 0); return; }
+
   ALEGO_LAUNCH(ip_fused, dim3(d.n_launch), dim3(IPF2_T), ipf_lds_bytes(d), st, d, ring_pos, keep_images ? 1 : 0);
 }
 
 // dynamic LDS above 64 KB has to be requested explicitly
 int ipf_configure(const DevCtx& d) {
   if (!ipf_eligible(d)) return 0;
+  if (iph_eligible(d) && hipFuncSetAttribute(reinterpret_cast<const void*>(ip_fused_h), hipFuncAttributeMaxDynamicSharedMemorySize, (int)iph_lds_bytes(d)) != hipSuccess) return -1;
   return hipFuncSetAttribute(reinterpret_cast<const void*>(ip_fused), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ipf_lds_bytes(d)) == hipSuccess ? 0 : -1;
 }
