@@ -29,7 +29,9 @@
 #define FF_G 8        // rings per picking wavefront (8 lanes each)
 #define FF_HALO 8     // staged points either side of a sector (11-tap sum: 5, occlusion marks of the neighbours: 6)
 #define FF_Q0 64      // staging position of a sector's first point: the sector's 64-point chunks are the ballot masks' chunks
+#ifndef FC_NW
 #define FC_NW 4       // ring sectors (wavefronts) per fe_cand workgroup
+#endif
 
 struct FfLayout {     // dynamic LDS of one fe_cand wavefront, in bytes
   int scap, mch, wave_bytes;      // staged positions (multiple of 64), mask chunks
@@ -359,7 +361,9 @@ __global__ void __launch_bounds__(64) fe_pick8(DevCtx d, int sector_cap) {
 // ---------------------------------------------------------------------------------------------------------------------------------
 // fe_ring_out
 // ---------------------------------------------------------------------------------------------------------------------------------
+#ifndef FO_BLOCK
 #define FO_BLOCK 256
+#endif
 #define FO_NB 256          // buckets of the run ordering (as fe_voxel)
 #define FO_U 4             // loads kept in flight per thread
 #define FO_CAP_PCT 72

@@ -37,7 +37,7 @@ from alego_amd import dist as D  # noqa: E402
 
 HBM_PEAK = 8.0e12  # B/s, MI355X spec (MI355X_MICROARCH.md)
 LAP = 560          # scans per T0 lap
-PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")
 
 
 def algorithmic_bytes(c, NS):
@@ -65,10 +65,12 @@ def kernel_bytes(name, c, NS, H, rebuilds_per_launch=0.0):
     t = {
         # B_IP = 16 P (in) + 25 M + 16 O + 8 NS + 12 (out)
         "ip_fused": 16 * P + 25 * M + 16 * O + 8 * NS + 12,   # = B_IP (the curvature phase left the kernel in round 3; fe_* are charged B_FE)
+        "ip_fused_h": 16 * P + 25 * M + 16 * O + 8 * NS + 12,
         "ip_project": 16 * P, "ip_front": 12, "cc_lds16": 25 * M + 16 * O + 8 * NS, "cc_lds": 25 * M + 16 * O + 8 * NS,
         "ip_compact": 25 * M + 16 * O + 8 * NS,
         # B_FE = 9 M (range, col, ground in) + 16 feats (out)
         "fe_curv": 8 * M, "fe_pick4": M, "fe_pick": M, "fe_gather": 16 * feats, "fe_collect": 16 * feats,
+        "fe_cand": 9 * M, "fe_ring_out": 16 * feats,   # (fe_pick8 works on the candidate lists: intermediates)
         # B_LO = 16 (F' + Q) + 104
         "lo_assoc": 16 * (c["Fc"] + c["Fs"] + c["Qc"] + c["Qs"]) / 2, "lo_solve": 104 / 2, "lo_solve_t": 104 / 2,
         # B_LM = 16 Kraw + 32 Kds + 16 L + 104 per mapping frame
@@ -82,6 +84,13 @@ def kernel_table(rep):
     tot = sum(v[0] for v in rep.values())
     return {k: dict(ms_total=round(v[0], 3), launches=v[1], avg_us=round(1e3 * v[0] / max(v[1], 1), 2),
                     share=round(v[0] / tot, 4)) for k, v in sorted(rep.items(), key=lambda kv: -kv[1][0])}
+
+
+def set_pmc_file(geometry, keyframes):
+    """the committed --pmc passes of this workload: profiles/r04_pmc_traffic.json (16x1800, the default) or profiles/r04_geo_<geometry>[_k<K>]_pmc_traffic.json"""
+    global PMC_FILE
+    if geometry.lower() != "16x1800":
+        PMC_FILE = os.path.join(ROOT, "profiles", "r04_geo_%s%s_pmc_traffic.json" % (geometry.lower(), ("_k%d" % keyframes) if keyframes > 0 else ""))
 
 
 def pmc_bytes_per_scan():
@@ -401,6 +410,7 @@ def main():
         dist = D.init("nccl", torch.device("cuda", local))  # RCCL: only the barrier + max-over-ranks use it
 
     ns, hs = (int(v) for v in args.geometry.lower().split("x"))
+    set_pmc_file(args.geometry, args.keyframes)
     p = synth.default_params(ns, hs)
     if args.keyframes > 0:
         p.recent_keyframe_num = args.keyframes

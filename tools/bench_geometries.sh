@@ -2,7 +2,7 @@
 # Run on the GPU box: bench lines + rocprofv3 kernel summaries for the reference geometry (16x4000, utility.h:50-55) and for config 5's
 # geometry (64x2048 with a 200-key-frame local map).  Outputs gpurun_out/<round>_geo_*; copy to profiles/ afterwards.
 set -u
-R=${1:-r02}
+R=${1:-r04}
 cd /tmp && export TMPDIR=/tmp
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out
@@ -12,6 +12,18 @@ run() {  # tag, bench args...
   rm -rf /tmp/prof_geo
   timeout 1200 rocprofv3 --kernel-trace --stats -d /tmp/prof_geo -o st --output-format csv -- python bench.py "$@" --no-cpu --no-profile < /dev/null > gpurun_out/${R}_geo_${tag}_under_rocprof.json 2> /tmp/geo.log
   find /tmp/prof_geo -name "*kernel_stats.csv" -exec cp {} gpurun_out/${R}_geo_${tag}_kernel_stats.csv \;
+  # HBM traffic per launch: two separate --pmc passes (FETCH_SIZE, WRITE_SIZE), as tools/refresh_profiles.sh does for the default workload
+  local per=$(python - <<PY
+import json
+d = json.loads(open("gpurun_out/${R}_geo_${tag}.json").read().strip().splitlines()[-1])
+print(d["roofline"]["streams_per_launch"])
+PY
+)
+  for c in FETCH_SIZE WRITE_SIZE; do
+    rm -rf /tmp/pmcg_$c
+    timeout 1200 rocprofv3 --pmc $c --kernel-trace -d /tmp/pmcg_$c -o p --output-format csv -- python bench.py "$@" --steps 8 --warmup 0 --no-cpu --no-profile --no-check --no-isolated < /dev/null > /tmp/pmcg_$c.log 2>&1
+  done
+  python tools/pmc_traffic.py /tmp/pmcg_FETCH_SIZE /tmp/pmcg_WRITE_SIZE "$per" 16 > gpurun_out/${R}_geo_${tag}_pmc_traffic.json
   tail -c 600 gpurun_out/${R}_geo_${tag}.json; echo; head -8 gpurun_out/${R}_geo_${tag}_kernel_stats.csv
 }
 run 16x4000 --geometry 16x4000 --streams 768 --steps 60 --warmup 10
