@@ -270,7 +270,7 @@ int alego_create(const alego_params* params, int device, int n_slots, int ring_l
   rc |= dalloc(h, &d.label_img, B * N); rc |= dalloc(h, &d.cc_label, B * N); rc |= dalloc(h, &d.row_cnt, B * NS * 4);
   rc |= dalloc(h, &d.scal, B * SC_COUNT);
   d.ipf_own = nullptr;
-  if (d.NS <= 16 && d.N <= 32768 && (d.H & 1) == 0) rc |= dalloc(h, &d.ipf_own, B * (N / 2), false);
+  if (d.NS <= 16 && d.N <= 65535 && (d.H & 1) == 0) rc |= dalloc(h, &d.ipf_own, B * (N / 2), false);
   rc |= dalloc(h, &d.seg_pts, B * N); rc |= dalloc(h, &d.seg_ground, B * N); rc |= dalloc(h, &d.seg_col, B * N);
   rc |= dalloc(h, &d.seg_range, B * N); rc |= dalloc(h, &d.ring_start, B * NS); rc |= dalloc(h, &d.ring_end, B * NS);
   rc |= dalloc(h, &d.ori, B * 4); rc |= dalloc(h, &d.outlier, B * N);

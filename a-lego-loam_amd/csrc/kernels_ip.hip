@@ -961,11 +961,12 @@ __global__ void atan2f_probe(const float* y, const float* x, float* out, int n, 
 
 // ---- host-side launchers -------------------------------------------------------
 bool ipf_eligible(const DevCtx& d);
+bool ipw_eligible(const DevCtx& d);
 void launch_ip_fused(const DevCtx& d, int ring_pos, bool keep_images, hipStream_t st);
 int ipf_configure(const DevCtx& d);
 
 void launch_ip(const DevCtx& d, int ring_pos, bool want_labels, hipStream_t st) {
-  if (d.opt_ip_fused && ipf_eligible(d)) {   // one workgroup per stream, everything between the input points and cloud_info on chip (kernels_ipf.hip)
+  if (d.opt_ip_fused && (ipf_eligible(d) || (d.opt_ip_half && ipw_eligible(d)))) {   // one workgroup per stream, everything between the input points and cloud_info on chip (kernels_ipf.hip)
     launch_ip_fused(d, ring_pos, want_labels || d.n_launch == 1, st);
     if (want_labels) hipLaunchKernelGGL(ip_labels, dim3((d.N + IP_BLOCK - 1) / IP_BLOCK, d.n_launch), dim3(IP_BLOCK), 0, st, d);
     return;

@@ -474,27 +474,36 @@ __global__ void __launch_bounds__(IPF2_T) ip_fused(DevCtx d, int ring_pos, int k
 //   * the parent array of phase C takes the owner image's place; the packed owners a pair needs again for the emit of phase D wait in
 //     an HBM scratch line of the stream (2 N bytes, written and read by this workgroup only: it stays in the L2).
 // Results are bit-identical to ip_fused (same arithmetic per cell, same ordered compaction); ALEGO_IP_HALF=0 selects ip_fused.
-#define IPH_T 512
-#define IPH_NW (IPH_T / 64)
+#define IPH_T 512     // ip_fused_h: 8 wavefronts, two column pairs per thread: H <= 2048, N <= 32768
 #define IPH_NP 2
+#define IPW_T 1024    // ip_fused_w (round 4): the same kernel with 16 wavefronts for the images only a whole CU can hold — 16 x 4000, the reference's own
+#define IPW_NP 2      //   geometry (utility.h:50-55): 2 N + 8 H = 160 000 B of the CU's 163 840 B of LDS, H <= 4096, N <= 65 535 (16-bit owners / prefixes)
 #ifndef IPH_GB
 #define IPH_GB 4   // rows gathered per batch in phase B / phase D (loads in flight against registers)
 #endif
 #ifndef IPH_GD
 #define IPH_GD 4
 #endif
+// first_r / first_act (phase B) and the count tables (phase D) are never live together: one area (the wide instantiation has 16 bytes of
+// LDS to spare at 16 x 4000)
+template <int NW, int NP>
 struct IphShared {
-  float first_r[IPH_NW][IPF2_ROWS];    // ranges of the first column of every wavefront of the pass in flight
-  unsigned first_act[IPH_NW];
+  union {
+    struct { float first_r[NW][IPF2_ROWS]; unsigned first_act[NW]; } b;   // ranges / active mask of the first column of every wavefront of the pass in flight
+    unsigned short cnt[3][IPF2_ROWS * NP * NW];   // per (row, pass, wavefront) = column-ascending inside a row: kept cells, outliers, feasible roots -> exclusive prefixes (< 65536)
+  } u;
   float col0_r[IPF2_ROWS];             // column 0 (right neighbour of the last column, :241-248)
   unsigned col0_act;
-  int red[3][IPH_NW];
-  int cnt[3][IPF2_ROWS * IPH_NP * IPH_NW];   // per (row, pass, wavefront) = column-ascending inside a row: kept cells, outliers, feasible roots
-  int wtot[3][4];
+  int red[3][NW];
+  int wtot[3][IPF2_ROWS * NP * NW / 64];
   int tot[3];
   int nlist;
 };
 bool iph_eligible(const DevCtx& d) { return ipf_eligible(d) && d.H <= 2 * IPH_NP * IPH_T && d.N <= 32768 && d.ipf_own != nullptr; }
+bool ipw_eligible(const DevCtx& d) {
+  return d.NS <= IPF2_ROWS && (d.H & 1) == 0 && d.H >= 64 && d.H <= 2 * IPW_NP * IPW_T && d.N <= 65535 && d.ipf_own != nullptr &&
+         (size_t)2 * d.N + (size_t)8 * d.H + sizeof(IphShared<IPW_T / 64, IPW_NP>) <= 163840;
+}
 size_t iph_lds_bytes(const DevCtx& d) { return (size_t)2 * d.N + (size_t)8 * d.H; }
 
 // 16-bit maximum of own16[cell] and val through the aligned 32-bit word
@@ -514,7 +523,9 @@ struct IphCol { unsigned a, b, x, y; };   // a = ground, b = active, x = right-e
 DEV_INLINE IphCol iph_load(const unsigned long long* fcol, int c) { const unsigned long long v = fcol[c]; IphCol m; m.a = (unsigned)v & 0xFFFFu; m.b = (unsigned)(v >> 16) & 0xFFFFu; m.x = (unsigned)(v >> 32) & 0xFFFFu; m.y = (unsigned)(v >> 48); return m; }
 DEV_INLINE void iph_store(unsigned long long* fcol, int c, const IphCol& m) { fcol[c] = (unsigned long long)m.a | ((unsigned long long)m.b << 16) | ((unsigned long long)m.x << 32) | ((unsigned long long)m.y << 48); }
 
-__global__ void __launch_bounds__(IPH_T, 4) ip_fused_h(DevCtx d, int ring_pos, int keep) {   // 4 wavefronts per SIMD = 128 VGPRs: two workgroups per CU
+template <int T, int NP>
+__global__ void __launch_bounds__(T, 4) ip_fused_t(DevCtx d, int ring_pos, int keep) {   // 4 wavefronts per SIMD = 128 VGPRs: two workgroups of 512 threads per CU
+  constexpr int NW = T / 64;
   const int slot = blockIdx.x + d.slot0;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int N = d.N, H = d.H, NS = d.NS;
@@ -525,11 +536,11 @@ __global__ void __launch_bounds__(IPH_T, 4) ip_fused_h(DevCtx d, int ring_pos, i
   uint16_t* par = reinterpret_cast<uint16_t*>(ipf_smem);                                     // [N] from phase C on
   unsigned long long* fcol = reinterpret_cast<unsigned long long*>(ipf_smem + (size_t)2 * N);   // [H] row masks of every column
   unsigned* own_g = d.ipf_own + (size_t)slot * (N / 2);                                      // the packed owners between phase B and phase D
-  __shared__ IphShared S;
+  __shared__ IphShared<NW, NP> S;
   const int hpairs = H / 2;
 
   // ---------------- phase A: projection (as ip_fused; 16-bit owners) ----------------
-  for (int v = tid; v < N / 2; v += IPH_T) own16w[v] = 0u;
+  for (int v = tid; v < N / 2; v += T) own16w[v] = 0u;
   if (tid == 0) S.nlist = 0;
   __syncthreads();
   const int n = scan_count(d, slot, ring_pos);
@@ -541,13 +552,13 @@ __global__ void __launch_bounds__(IPH_T, 4) ip_fused_h(DevCtx d, int ring_pos, i
     ip_quick_margins(d, &qmr, &qmc);
     int vmin = 0x7fffffff, vmax = -1, nvalid = 0;
 #pragma unroll 1
-    for (int i0 = tid; i0 < n; i0 += IPH_T * 4) {
+    for (int i0 = tid; i0 < n; i0 += T * 4) {
       float4 pin[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) pin[u] = pts[min(i0 + u * IPH_T, n - 1)];
+      for (int u = 0; u < 4; ++u) pin[u] = pts[min(i0 + u * T, n - 1)];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const int i = i0 + u * IPH_T;
+        const int i = i0 + u * T;
         bool valid = false, defer = false;
         int cell = -1;
         if (i < n) defer = !ip_point_quick(d, pin[u], qmr, qmc, &valid, &cell);
@@ -570,7 +581,7 @@ __global__ void __launch_bounds__(IPH_T, 4) ip_fused_h(DevCtx d, int ring_pos, i
       const bool all = S.nlist > list_cap;
       const int nl = all ? n : S.nlist;
 #pragma unroll 1
-      for (int j = tid; j < nl; j += IPH_T) {
+      for (int j = tid; j < nl; j += T) {
         const int i = all ? j : s_list[j];
         bool v2;
         const int c2 = ip_point_cell(d, pts[i], &v2);
@@ -586,9 +597,9 @@ __global__ void __launch_bounds__(IPH_T, 4) ip_fused_h(DevCtx d, int ring_pos, i
     if (lane == 0) { S.red[0][wave] = vmin; S.red[1][wave] = vmax; S.red[2][wave] = nvalid; }
   }
   __syncthreads();
-  if (tid == IPH_T - 1) {   // orientation block (:62-72)
+  if (tid == T - 1) {   // orientation block (:62-72)
     int first = 0x7fffffff, last = -1, pv = 0;
-    for (int w = 0; w < IPH_NW; ++w) { first = min(first, S.red[0][w]); last = max(last, S.red[1][w]); pv += S.red[2][w]; }
+    for (int w = 0; w < NW; ++w) { first = min(first, S.red[0][w]); last = max(last, S.red[1][w]); pv += S.red[2][w]; }
     d.scal[slot * SC_COUNT + SC_PVALID_OUT] = pv;
     if (last >= 0) {
       float* ori = d.ori + slot * 4;
@@ -603,8 +614,8 @@ __global__ void __launch_bounds__(IPH_T, 4) ip_fused_h(DevCtx d, int ring_pos, i
 
   // ---------------- phase B: ranges, ground, edges — one column pair per thread and pass ----------------
 #pragma unroll 1
-  for (int p = 0; p < IPH_NP; ++p) {
-    const int pi = tid + p * IPH_T, c0 = 2 * pi, c1 = c0 + 1;
+  for (int p = 0; p < NP; ++p) {
+    const int pi = tid + p * T, c0 = 2 * pi, c1 = c0 + 1;
     const bool colv = pi < hpairs;
     float rng0[IPF2_ROWS], rng1[IPF2_ROWS];
     unsigned filled0 = 0, filled1 = 0, ground0 = 0, ground1 = 0;
@@ -643,11 +654,11 @@ __global__ void __launch_bounds__(IPH_T, 4) ip_fused_h(DevCtx d, int ring_pos, i
       }
     }
     const unsigned act0 = filled0 & ~ground0, act1 = filled1 & ~ground1;
-    __syncthreads();   // (the previous pass has read S.first_r)
+    __syncthreads();   // (the previous pass has read S.u.b.first_r)
     if (lane == 0) {
 #pragma unroll
-      for (int r = 0; r < IPF2_ROWS; ++r) S.first_r[wave][r] = rng0[r];
-      S.first_act[wave] = act0;
+      for (int r = 0; r < IPF2_ROWS; ++r) S.u.b.first_r[wave][r] = rng0[r];
+      S.u.b.first_act[wave] = act0;
     }
     if (p == 0 && tid == 0) {
 #pragma unroll
@@ -662,12 +673,12 @@ __global__ void __launch_bounds__(IPH_T, 4) ip_fused_h(DevCtx d, int ring_pos, i
 #pragma unroll
     for (int r = 0; r < IPF2_ROWS; ++r) nbr[r] = __shfl_down(rng0[r], 1, 64);
     const bool wrap = pi == hpairs - 1;                                   // right neighbour = column 0
-    const bool nextpass = !wrap && tid == IPH_T - 1 && p + 1 < IPH_NP;   // right neighbour = first column of the next pass
+    const bool nextpass = !wrap && tid == T - 1 && p + 1 < NP;   // right neighbour = first column of the next pass
     if ((lane == 63 && !nextpass) || wrap) {
-      const int sw = min(wave + 1, IPH_NW - 1);
+      const int sw = min(wave + 1, NW - 1);
 #pragma unroll
-      for (int r = 0; r < IPF2_ROWS; ++r) nbr[r] = wrap ? S.col0_r[r] : S.first_r[sw][r];
-      nb_act = wrap ? S.col0_act : S.first_act[sw];
+      for (int r = 0; r < IPF2_ROWS; ++r) nbr[r] = wrap ? S.col0_r[r] : S.u.b.first_r[sw][r];
+      nb_act = wrap ? S.col0_act : S.u.b.first_act[sw];
     }
     if (nextpass) {
       const int cx = c0 + 2;   // (< H: not the wrap)
@@ -735,12 +746,12 @@ __global__ void __launch_bounds__(IPH_T, 4) ip_fused_h(DevCtx d, int ring_pos, i
 
   // ---------------- phase C: connected components over vertical runs (ip_fused's steps, column by column from the masks in LDS) ----------------
   // a cell starts a run when it is active and no down-edge reaches it from below; a run's representative is its first (lowest) cell
-  const int ncol = IPH_NP * 2;   // columns of a thread: 2 (tid + p T) + k
-  auto col_of = [&](int q) -> int { return 2 * (tid + (q >> 1) * IPH_T) + (q & 1); };
+  const int ncol = NP * 2;   // columns of a thread: 2 (tid + p T) + k
+  auto col_of = [&](int q) -> int { return 2 * (tid + (q >> 1) * T) + (q & 1); };
   unsigned* parw = reinterpret_cast<unsigned*>(par);
 #pragma unroll 1
-  for (int p = 0; p < IPH_NP; ++p) {
-    const int pi = tid + p * IPH_T, c0 = 2 * pi, c1 = c0 + 1;
+  for (int p = 0; p < NP; ++p) {
+    const int pi = tid + p * T, c0 = 2 * pi, c1 = c0 + 1;
     if (pi < hpairs) {
       const IphCol m0 = iph_load(fcol, c0), m1 = iph_load(fcol, c1);
       const unsigned rs0 = m0.b & ~(m0.y << 1), rs1 = m1.b & ~(m1.y << 1);
@@ -755,8 +766,8 @@ __global__ void __launch_bounds__(IPH_T, 4) ip_fused_h(DevCtx d, int ring_pos, i
   }
   __syncthreads();
 #pragma unroll 1
-  for (int p = 0; p < IPH_NP; ++p) {
-    const int pi = tid + p * IPH_T, c0 = 2 * pi, c1 = c0 + 1;
+  for (int p = 0; p < NP; ++p) {
+    const int pi = tid + p * T, c0 = 2 * pi, c1 = c0 + 1;
     if (pi < hpairs) {
       const int cn = c0 + 2 == H ? 0 : c0 + 2;
       const IphCol a0 = iph_load(fcol, c0), a1 = iph_load(fcol, c1);
@@ -802,9 +813,9 @@ __global__ void __launch_bounds__(IPH_T, 4) ip_fused_h(DevCtx d, int ring_pos, i
     }
   }
   __syncthreads();
-  unsigned bm[IPH_NP * 2];   // per column: runs of big components | runs of mid-sized ones << 16 (bit at the run's start row)
+  unsigned bm[NP * 2];   // per column: runs of big components | runs of mid-sized ones << 16 (bit at the run's start row)
 #pragma unroll
-  for (int q = 0; q < IPH_NP * 2; ++q) {
+  for (int q = 0; q < NP * 2; ++q) {
     const int c = col_of(q);
     unsigned big = 0, mid = 0;
     if (c < H) {
@@ -816,7 +827,7 @@ __global__ void __launch_bounds__(IPH_T, 4) ip_fused_h(DevCtx d, int ring_pos, i
   __syncthreads();
   zero_roots();
 #pragma unroll
-  for (int q = 0; q < IPH_NP * 2; ++q) {   // rows touched by the mid-sized components
+  for (int q = 0; q < NP * 2; ++q) {   // rows touched by the mid-sized components
     const int c = col_of(q);
     if (c < H && (bm[q] >> 16)) {
       const IphCol m = iph_load(fcol, c);
@@ -825,7 +836,7 @@ __global__ void __launch_bounds__(IPH_T, 4) ip_fused_h(DevCtx d, int ring_pos, i
   }
   __syncthreads();
 #pragma unroll
-  for (int q = 0; q < IPH_NP * 2; ++q) {   // cells of feasible components: they take the down-edges' place in fcol
+  for (int q = 0; q < NP * 2; ++q) {   // cells of feasible components: they take the down-edges' place in fcol
     const int c = col_of(q);
     if (c < H) {
       IphCol m = iph_load(fcol, c);
@@ -858,8 +869,8 @@ __global__ void __launch_bounds__(IPH_T, 4) ip_fused_h(DevCtx d, int ring_pos, i
     frm = m.x & m.y;
   };
 #pragma unroll 1
-  for (int p = 0; p < IPH_NP; ++p) {
-    const int pi = tid + p * IPH_T, c0 = 2 * pi, c1 = c0 + 1;
+  for (int p = 0; p < NP; ++p) {
+    const int pi = tid + p * T, c0 = 2 * pi, c1 = c0 + 1;
     unsigned k0 = 0, k1 = 0, o0 = 0, o1 = 0, f0 = 0, f1 = 0;
     if (pi < hpairs) { col_sets(c0, iph_load(fcol, c0), k0, o0, f0); col_sets(c1, iph_load(fcol, c1), k1, o1, f1); }
 #pragma unroll
@@ -868,21 +879,21 @@ __global__ void __launch_bounds__(IPH_T, 4) ip_fused_h(DevCtx d, int ring_pos, i
       const unsigned long long bo0 = __ballot((o0 >> row) & 1u), bo1 = __ballot((o1 >> row) & 1u);
       const unsigned long long bf0 = __ballot((f0 >> row) & 1u), bf1 = __ballot((f1 >> row) & 1u);
       if (lane == 0) {
-        const int e = (row * IPH_NP + p) * IPH_NW + wave;
-        S.cnt[0][e] = (int)(__popcll(bk0) + __popcll(bk1));
-        S.cnt[1][e] = (int)(__popcll(bo0) + __popcll(bo1));
-        S.cnt[2][e] = (int)(__popcll(bf0) + __popcll(bf1));
+        const int e = (row * NP + p) * NW + wave;
+        S.u.cnt[0][e] = (unsigned short)(__popcll(bk0) + __popcll(bk1));
+        S.u.cnt[1][e] = (unsigned short)(__popcll(bo0) + __popcll(bo1));
+        S.u.cnt[2][e] = (unsigned short)(__popcll(bf0) + __popcll(bf1));
       }
     }
   }
   __syncthreads();
-  constexpr int NCNT = IPF2_ROWS * IPH_NP * IPH_NW;   // 256
-  {   // exclusive scan of the three 256-entry tables by the first four wavefronts
+  constexpr int NCNT = IPF2_ROWS * NP * NW;   // 256 (ip_fused_h) / 512 (ip_fused_w) <= T
+  {   // exclusive scan of the three tables by the first NCNT threads
     int v3[3] = {0, 0, 0}, in3[3] = {0, 0, 0};
     if (tid < NCNT) {
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
-        v3[a] = S.cnt[a][tid];
+        v3[a] = S.u.cnt[a][tid];
         int incl = v3[a];
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
@@ -896,8 +907,8 @@ __global__ void __launch_bounds__(IPH_T, 4) ip_fused_h(DevCtx d, int ring_pos, i
       for (int a = 0; a < 3; ++a) {
         int woff = 0;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) if (w < wave) woff += S.wtot[a][w];
-        S.cnt[a][tid] = woff + in3[a] - v3[a];
+        for (int w = 0; w < NCNT / 64; ++w) if (w < wave) woff += S.wtot[a][w];
+        S.u.cnt[a][tid] = (unsigned short)(woff + in3[a] - v3[a]);
         if (tid == NCNT - 1) S.tot[a] = woff + in3[a];
       }
     }
@@ -905,8 +916,8 @@ __global__ void __launch_bounds__(IPH_T, 4) ip_fused_h(DevCtx d, int ring_pos, i
   __syncthreads();
   if (tid < NS) {   // startRingIndex / endRingIndex (:161,:190)
     const int row = tid;
-    d.ring_start[slot * NS + row] = S.cnt[0][row * IPH_NP * IPH_NW] + 5;
-    d.ring_end[slot * NS + row] = (row + 1 < IPF2_ROWS ? S.cnt[0][(row + 1) * IPH_NP * IPH_NW] : S.tot[0]) - 1 - 5;
+    d.ring_start[slot * NS + row] = (int)S.u.cnt[0][row * NP * NW] + 5;
+    d.ring_end[slot * NS + row] = (row + 1 < IPF2_ROWS ? (int)S.u.cnt[0][(row + 1) * NP * NW] : S.tot[0]) - 1 - 5;
   }
   if (tid == 0) {
     int* sc = d.scal + slot * SC_COUNT;
@@ -914,8 +925,8 @@ __global__ void __launch_bounds__(IPH_T, 4) ip_fused_h(DevCtx d, int ring_pos, i
   }
   const unsigned long long below = (1ull << lane) - 1ull;
 #pragma unroll 1
-  for (int p = 0; p < IPH_NP; ++p) {
-    const int pi = tid + p * IPH_T, c0 = 2 * pi, c1 = c0 + 1;
+  for (int p = 0; p < NP; ++p) {
+    const int pi = tid + p * T, c0 = 2 * pi, c1 = c0 + 1;
     const bool colv = pi < hpairs;
     unsigned keep0 = 0, keep1 = 0, outl0 = 0, outl1 = 0, fr0 = 0, fr1 = 0, ground0 = 0, ground1 = 0, root0 = 0, root1 = 0;
     if (colv) {
@@ -941,9 +952,9 @@ __global__ void __launch_bounds__(IPH_T, 4) ip_fused_h(DevCtx d, int ring_pos, i
         const int row = row0 + u;
         const bool k0 = (keep0 >> row) & 1u, k1 = (keep1 >> row) & 1u, o0 = (outl0 >> row) & 1u, o1 = (outl1 >> row) & 1u;
         const unsigned long long bk0 = __ballot(k0), bk1 = __ballot(k1), bo0 = __ballot(o0), bo1 = __ballot(o1);
-        const int e = (row * IPH_NP + p) * IPH_NW + wave;
-        const int lk = S.cnt[0][e] + (int)(__popcll(bk0 & below) + __popcll(bk1 & below));
-        const int lo = S.cnt[1][e] + (int)(__popcll(bo0 & below) + __popcll(bo1 & below));
+        const int e = (row * NP + p) * NW + wave;
+        const int lk = (int)S.u.cnt[0][e] + (int)(__popcll(bk0 & below) + __popcll(bk1 & below));
+        const int lo = (int)S.u.cnt[1][e] + (int)(__popcll(bo0 & below) + __popcll(bo1 & below));
         if (k0 | o0) {
           const float4 q = qa[u];
           const float4 pp = make_float4(q.x, q.y, q.z, (float)(row + c0 / 10000.0));   // :101
@@ -976,7 +987,7 @@ __global__ void __launch_bounds__(IPH_T, 4) ip_fused_h(DevCtx d, int ring_pos, i
       for (int row = 0; row < IPF2_ROWS; ++row) {
         const unsigned long long bf0 = __ballot((fr0 >> row) & 1u), bf1 = __ballot((fr1 >> row) & 1u);
         if (colv && row < NS) {
-          const int nf = S.cnt[2][(row * IPH_NP + p) * IPH_NW + wave] + (int)(__popcll(bf0 & below) + __popcll(bf1 & below));
+          const int nf = (int)S.u.cnt[2][(row * NP + p) * NW + wave] + (int)(__popcll(bf0 & below) + __popcll(bf1 & below));
           if ((root0 >> row) & 1u) d.cc_label[base + row * H + c0] = ((fr0 >> row) & 1u) ? nf + 1 : 0;
           if ((root1 >> row) & 1u) d.cc_label[base + row * H + c1] = ((fr1 >> row) & 1u) ? nf + ((fr0 >> row) & 1u) + 1 : 0;
         }
@@ -985,15 +996,22 @@ __global__ void __launch_bounds__(IPH_T, 4) ip_fused_h(DevCtx d, int ring_pos, i
   }
 }
 
+static constexpr auto ip_fused_h = ip_fused_t<IPH_T, IPH_NP>;
+static constexpr auto ip_fused_w = ip_fused_t<IPW_T, IPW_NP>;
+
 void launch_ip_fused(const DevCtx& d, int ring_pos, bool keep_images, hipStream_t st) {
   if (d.opt_ip_half && iph_eligible(d)) { ALEGO_LAUNCH(ip_fused_h, dim3(d.n_launch), dim3(IPH_T), iph_lds_bytes(d), st, d, ring_pos, keep_images ? 1 : 0); return; }
+  if (!ipf_eligible(d)) { ALEGO_LAUNCH(ip_fused_w, dim3(d.n_launch), dim3(IPW_T), iph_lds_bytes(d), st, d, ring_pos, keep_images ? 1 : 0); return; }   // (the caller checked ipw_eligible)
 
   ALEGO_LAUNCH(ip_fused, dim3(d.n_launch), dim3(IPF2_T), ipf_lds_bytes(d), st, d, ring_pos, keep_images ? 1 : 0);
 }
 
 // dynamic LDS above 64 KB has to be requested explicitly
 int ipf_configure(const DevCtx& d) {
-  if (!ipf_eligible(d)) return 0;
+  if (!ipf_eligible(d)) {
+    if (ipw_eligible(d) && hipFuncSetAttribute(reinterpret_cast<const void*>(ip_fused_w), hipFuncAttributeMaxDynamicSharedMemorySize, (int)iph_lds_bytes(d)) != hipSuccess) return -1;
+    return 0;
+  }
   if (iph_eligible(d) && hipFuncSetAttribute(reinterpret_cast<const void*>(ip_fused_h), hipFuncAttributeMaxDynamicSharedMemorySize, (int)iph_lds_bytes(d)) != hipSuccess) return -1;
   return hipFuncSetAttribute(reinterpret_cast<const void*>(ip_fused), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ipf_lds_bytes(d)) == hipSuccess ? 0 : -1;
 }

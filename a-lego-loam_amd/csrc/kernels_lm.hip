@@ -466,10 +466,17 @@ __global__ void __launch_bounds__(128) lm_knn(DevCtx d, LmCtx L) {
     float4 first[9];
 #pragma unroll
     for (int r = 0; r < 9; ++r) first[r] = cp[rs[r] + sub < re[r] ? rs[r] + sub : 0];
+    // the query's own row of cells first, then the rows that share a face with it, the four diagonal ones last: the sets' maxima fall early and
+    // fewer of the later candidates enter a set at all (the result does not depend on the order: a set of unique keys)
+#ifndef LM_KNN_ORDER
+#define LM_KNN_ORDER 1
+#endif
+    constexpr int ord[9] = {4, 1, 3, 5, 7, 0, 2, 6, 8};
 #pragma unroll
-    for (int r = 0; r < 9; ++r) if (rs[r] + sub < re[r]) consider(first[r]);
+    for (int k = 0; k < 9; ++k) { const int r = LM_KNN_ORDER ? ord[k] : k; if (rs[r] + sub < re[r]) consider(first[r]); }
 #pragma unroll
-    for (int r = 0; r < 9; ++r) {
+    for (int k = 0; k < 9; ++k) {
+      const int r = LM_KNN_ORDER ? ord[k] : k;
       for (int t = rs[r] + sub + LM_KNN_LANES; t < re[r]; t += 2 * LM_KNN_LANES) {  // an x-run of cells is contiguous in the cell-sorted copy
         const int t1 = t + LM_KNN_LANES;
         const float4 a0 = cp[t], a1 = cp[t1 < re[r] ? t1 : t];

@@ -36,10 +36,12 @@ def _ip_compare(h, o, pts, tag):
                                           ((16, 4000), None), ((64, 2048), None), ((64, 2048), "ALEGO_CC_TILE"),
                                           ((32, 2048), None), ((40, 1800), None),
                                           ((16, 1800), "ALEGO_IP_HALF"), ((16, 1024), "ALEGO_IP_HALF"), ((12, 2048), "ALEGO_IP_HALF"), ((5, 64), "ALEGO_IP_HALF"),
-                                          ((16, 1800), "ALEGO_IP_HALF,ALEGO_IP_FAST")])
+                                          ((16, 1800), "ALEGO_IP_HALF,ALEGO_IP_FAST"), ((16, 4000), "ALEGO_IP_HALF"), ((16, 4094), None), ((14, 3000), None)])
 def test_ip_bit_exact(geom, variant, monkeypatch):
     """ImageProjection bit for bit.  Up to 16 rings / 32768 cells / an even width run ip_fused_h (one 512-thread workgroup per stream in half
-    a CU, one launch: 16x1800, 16x1024, 12x2048, 5x64; ALEGO_IP_HALF=0: ip_fused, the same pipeline with 1024 threads and the whole CU); ALEGO_IP_FUSED=0 selects the multi-kernel path: 16x1800 then runs cc_lds16; ALEGO_CC_FUSED=0 keeps its union-find but
+    a CU, one launch: 16x1800, 16x1024, 12x2048, 5x64; ALEGO_IP_HALF=0: ip_fused, the same pipeline with 1024 threads and the whole CU); wider images of up to
+    16 rings and 65 535 cells (16x4000 — the reference's own geometry —, 16x4094, 14x3000) run the same kernel with 1024 threads and all of a CU's LDS
+    (ip_fused_w; ALEGO_IP_HALF=0 sends them down the multi-kernel path); ALEGO_IP_FUSED=0 selects the multi-kernel path: 16x1800 then runs cc_lds16; ALEGO_CC_FUSED=0 keeps its union-find but
     compacts with the separate ip_rowcount + ip_compact kernels; 16x4000 runs cc_lds16 at 126 KB of LDS; 64x2048, 32x2048 and 40x1800
     (bands of 256 / 512 / 409 + 164 columns) are labelled band by band in LDS and stitched at the seams (cc_tile + cc_seam +
     cc_stats), ALEGO_CC_TILE=0 keeps the global-memory union-find (cc_runs + cc_link).
