@@ -28,6 +28,7 @@ thread_local Profiler* g_prof = nullptr;
 void launch_ip(const DevCtx& d, int ring_pos, bool want_labels, hipStream_t st);
 void launch_fe(const DevCtx& d, hipStream_t st);
 void launch_lo(const DevCtx& d, hipStream_t st);
+void launch_lo_grid(const DevCtx& d, hipStream_t st);
 void launch_atan2f_probe(const float* y, const float* x, float* out, int n, int mode, hipStream_t st);
 int launch_stdsort_probe(const uint32_t* keys, int n, int depth_limit, int* pos_out, hipStream_t st);
 void launch_lo_imu_push(const DevCtx& d, int slot, const double* smp_dev, int n, hipStream_t st);
@@ -260,6 +261,7 @@ int alego_create(const alego_params* params, int device, int n_slots, int ring_l
   d.opt_fe_fused = env_int("ALEGO_FE_FUSED", 1) != 0;
   d.opt_fe_cand = env_int("ALEGO_FE_CAND", 0);
   d.opt_lo_box_lds = env_int("ALEGO_LO_BOX_LDS", 1 << 20);
+  d.opt_lo_grid = env_int("ALEGO_LO_GRID", 1) != 0;
   d.opt_map_merge = env_int("ALEGO_MAP_MERGE", 1) != 0;
   const size_t B = n_slots, N = d.N, NS = d.NS;
   int rc = 0;
@@ -286,6 +288,8 @@ int alego_create(const alego_params* params, int device, int n_slots, int ring_l
   rc |= dalloc(h, &d.lo_corr, B * (d.lo_qcap_surf + d.lo_qcap_corner) * 4);
   d.lo_box_cap = (d.N + LO_CH - 1) / LO_CH + d.NS;   // boxes never straddle rings: up to one partly filled box per ring
   rc |= dalloc(h, &d.lo_box, B * 2 * 2 * d.lo_box_cap * 2);
+  rc |= dalloc(h, &d.lo_cpts[0], B * 2 * d.fcap[F_LFLAT], false); rc |= dalloc(h, &d.lo_cpts[1], B * 2 * d.fcap[F_LSHARP], false);
+  rc |= dalloc(h, &d.lo_cell, B * 2 * 2 * (LO_GC + 2)); rc |= dalloc(h, &d.lo_geom, B * 2 * 2 * 8);
   rc |= dalloc(h, &d.lo_state, B * LO_STATE_N);
   rc |= dalloc(h, &d.poses, B * 16);
   rc |= dalloc(h, &d.imu_ring, B * ALEGO_IMU_Q * 10); rc |= dalloc(h, &d.imu_ptr, B * 4); rc |= dalloc(h, &d.scan_stamp, B);
@@ -936,6 +940,7 @@ int alego_debug_set_option(alego_handle* h, const char* name, int value) {
   else if (s == "ALEGO_FE_FUSED") d.opt_fe_fused = value != 0;
   else if (s == "ALEGO_FE_CAND") d.opt_fe_cand = value;
   else if (s == "ALEGO_LO_BOX_LDS") d.opt_lo_box_lds = value;
+  else if (s == "ALEGO_LO_GRID") d.opt_lo_grid = value != 0;
   else if (s == "ALEGO_MAP_MERGE") { if (int r = lm_host_set_map_merge(h->lm, value != 0, &h->err)) return r; d.opt_map_merge = value != 0; }
   else if (s == "ALEGO_IP_FAST") d.ip_fast = h->ip_fast_capable & value;
   else if (s == "ALEGO_POKE_GUARD") { HIP_TRY(h, hipMemset(d.scal + (size_t)d.n_slots * SC_COUNT + value, 0xFF, 4)); }   // tests of the guard pages: a write `value` ints past the end of an array

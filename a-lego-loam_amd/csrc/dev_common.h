@@ -124,6 +124,12 @@ struct DevCtx {
   int* lo_corr;         // [slot][qcap][4]  surf rows then corner rows: (query, closest, idx2, idx3) ; closest<0 = none
   int lo_qcap_surf, lo_qcap_corner;
   float4* lo_box;       // [slot][2 buffers][2 kinds][lo_box_cap][2]: min / max corner of up to LO_CH consecutive targets of one ring; .w of the
+  // the previous scan's target clouds once more, sorted by the cells of a 2-D (x, y) grid of >= 1 m (lo_grid_build, kernels_lo.hip): the exact 1-NN of almost
+  // every query is settled by the 3 x 3 cells around it; the boxes remain for the ring walks and for the queries whose neighbour is farther than a cell
+  float4* lo_cpts[2];   // [slot][2 buffers][fcap]: kind 0 less_flat, 1 less_sharp; .w = the target's index (int bits)
+  unsigned short* lo_cell;   // [slot][2 buffers][2 kinds][LO_GC + 2]: first sorted point of every cell (exclusive prefix, row-major in x)
+  float* lo_geom;       // [slot][2 buffers][2 kinds][8]: origin x, y, 1 / cell size, settle threshold (0.999 cell^2), gx, gy (int bits; gx = 0: no grid), -, -
+  int opt_lo_grid;      // ALEGO_LO_GRID    1: lo_assoc takes the 1-NN from the grid where that is exact; 0: boxes only
   int lo_box_cap;       //   corners = first target / number of targets (int bits); kind 0: less_flat, 1: less_sharp; written by feature extraction
   double* lo_state;     // [slot][LO_STATE_N]
   // ---- motion de-skew (adjustDistortion, laserOdometry.cpp:557-726; alego_params.deskew_mode) ----
@@ -156,6 +162,11 @@ enum {
 #ifndef LO_CH
 #define LO_CH 32
 #endif
+#ifndef LO_GC
+#define LO_GC 4096
+#endif
+// LO_GC: cells of the LaserOdometry target grid (64 x 64; the cell size starts at 1 m and doubles until the cloud's bounding box fits: 2 m for a 100 m scene.  16384 cells
+// were measured: the 1 m cells halve lo_assoc's candidates, but lo_grid_build's scan and table are four times as long: 418 k against 425 k scans/s; 1024 cells: 420 k)
 // LO_CH: targets per bounding box of the LaserOdometry 1-NN / ring-walk pruning
 
 // the input scan of `slot` at ring position / replay step `pos`

@@ -797,12 +797,13 @@ int launch_stdsort_probe(const uint32_t* keys, int n, int depth_limit, int* pos_
   return 0;
 }
 
+void launch_lo_grid(const DevCtx& d, hipStream_t st);        // kernels_lo.hip: the target grid of the clouds just written, for the next scan's LaserOdometry
 bool fe_fused_eligible(const DevCtx& d);                    // kernels_fe2.hip
 void launch_fe_fused(const DevCtx& d, hipStream_t st);
 void launch_fe_curv_debug(const DevCtx& d, hipStream_t st) { ALEGO_LAUNCH(fe_curv, dim3((d.N + FE_CW - 1) / FE_CW, d.n_launch), dim3(FE_BLOCK), 0, st, d); }
 
 void launch_fe(const DevCtx& d, hipStream_t st) {
-  if (fe_fused_eligible(d)) { launch_fe_fused(d, st); return; }   // fe_front + fe_ring_out; below: the four-kernel path (ALEGO_FE_FUSED=0, sort_mode 2)
+  if (fe_fused_eligible(d)) { launch_fe_fused(d, st); launch_lo_grid(d, st); return; }   // fe_cand + fe_pick8 + fe_ring_out; below: the four-kernel path (ALEGO_FE_FUSED=0, sort_mode 2)
   // dynamic LDS above 64 KB has to be requested explicitly (fe_voxel: 26 B per column, horizon_scan <= 4096)
   static const bool cfg = hipFuncSetAttribute(reinterpret_cast<const void*>(fe_voxel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fv_lds_bytes(FE_MAXH)) == hipSuccess;
   (void)cfg;
@@ -827,4 +828,5 @@ void launch_fe(const DevCtx& d, hipStream_t st) {
   else { ALEGO_LAUNCH((fe_pick<12, false>), dim3(d.NS, d.n_launch), dim3(64), (size_t)3 * d.H, st, d); }
   ALEGO_LAUNCH(fe_voxel, dim3(d.NS, d.n_launch), dim3(FV_BLOCK), fv_lds_bytes(d.H), st, d);
   ALEGO_LAUNCH(fe_collect, dim3(d.n_launch), dim3(FC_T), 0, st, d);
+  launch_lo_grid(d, st);
 }

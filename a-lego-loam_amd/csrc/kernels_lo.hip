@@ -102,6 +102,102 @@ extern "C" void alego_la_times(long long* out) { (void)hipMemcpyFromSymbol(out, 
 #else
 #define LA_TICK(k)
 #endif
+// ---- the target grid (round 4) ----------------------------------------------------------------------------------------------------
+// pcl::KdTreeFLANN::nearestKSearch(sel, 1, ...) (:341,:430) is an EXACT nearest neighbour; the boxes answer it with ~12 boxes of 32 targets per
+// query whatever the bound (a box is a 43-degree arc of one ring: every ring has one that contains the query's (x, y)).  The neighbour a
+// LiDAR feature had a tenth of a second ago is almost always within a metre: lo_grid_build sorts a scan's less_flat / less_sharp clouds by the
+// cells of a 2-D grid over (x, y) — cell size 1 m, doubled until the cloud's bounding box fits LO_GC cells (2 m for a 100 m scene) — as soon as feature extraction has
+// written them, and lo_assoc looks at the 3 x 3 cells around the query first: every target closer than a cell size lies there, so a best
+// candidate closer than that IS the nearest neighbour (ties: lowest index, as before); only a query without one takes the box search.
+// One workgroup per (stream, cloud): counts packed two cells per LDS word (a cloud has < 65536 points: otherwise no grid, gx = 0), exclusive
+// scan, scatter; the order inside a cell is whatever the atomics give and does not matter (the key is (distance, index)).
+#define LG_T 256
+__global__ void __launch_bounds__(LG_T) lo_grid_build(DevCtx d) {
+  const int slot = blockIdx.x + d.slot0, kind = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const size_t fb = (size_t)slot * 2 + cur_in_flight(d, slot);
+  const int tk = kind == 0 ? F_LFLAT : F_LSHARP;
+  const int n = d.feat_cnt[fb * 4 + tk];
+  const float4* pts = d.feat[tk] + fb * d.fcap[tk];
+  float4* cp = d.lo_cpts[kind] + fb * d.fcap[tk];
+  unsigned short* cell = d.lo_cell + (fb * 2 + kind) * (LO_GC + 2);
+  float* geom = d.lo_geom + (fb * 2 + kind) * 8;
+  __shared__ unsigned s_cnt[LO_GC / 2];
+  __shared__ float s_red[4][LG_T / 64];
+  __shared__ int s_tot[LG_T / 64];
+  if (n <= 0 || n > 65535) { if (tid == 0) geom[4] = __int_as_float(0); return; }
+  float mn[2] = {3.402823466e+38f, 3.402823466e+38f}, mx[2] = {-3.402823466e+38f, -3.402823466e+38f};
+  for (int i = tid; i < n; i += LG_T) { const float4 p = pts[i]; mn[0] = fminf(mn[0], p.x); mn[1] = fminf(mn[1], p.y); mx[0] = fmaxf(mx[0], p.x); mx[1] = fmaxf(mx[1], p.y); }
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { mn[a] = fminf(mn[a], __shfl_xor(mn[a], o, 64)); mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], o, 64)); }
+    if (lane == 0) { s_red[a][wave] = mn[a]; s_red[2 + a][wave] = mx[a]; }
+  }
+  for (int w = tid; w < LO_GC / 2; w += LG_T) s_cnt[w] = 0u;
+  __syncthreads();
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    mn[a] = s_red[a][0]; mx[a] = s_red[2 + a][0];
+#pragma unroll
+    for (int w = 1; w < LG_T / 64; ++w) { mn[a] = fminf(mn[a], s_red[a][w]); mx[a] = fmaxf(mx[a], s_red[2 + a][w]); }
+  }
+  float csz = 1.0f;
+  int gx = 0, gy = 0;
+  bool ok = mx[0] - mn[0] < 1e6f && mx[1] - mn[1] < 1e6f;   // (also false for NaN / infinite extents)
+  for (int it = 0; ok && it < 24; ++it) {
+    gx = (int)floorf((mx[0] - mn[0]) / csz) + 2; gy = (int)floorf((mx[1] - mn[1]) / csz) + 2;
+    if ((long long)gx * gy <= LO_GC) break;
+    csz *= 2.0f;
+  }
+  ok = ok && (long long)gx * gy <= LO_GC;
+  if (!ok) { if (tid == 0) geom[4] = __int_as_float(0); return; }
+  const float inv = 1.0f / csz;   // (csz is a power of two: exact)
+  const int ncell = gx * gy;
+  auto cell_of = [&](const float4& p) -> int {
+    const int ix = min(max((int)floorf((p.x - mn[0]) * inv), 0), gx - 1), iy = min(max((int)floorf((p.y - mn[1]) * inv), 0), gy - 1);
+    return ix + gx * iy;
+  };
+  for (int i = tid; i < n; i += LG_T) { const int c = cell_of(pts[i]); atomicAdd(&s_cnt[c >> 1], 1u << ((c & 1) * 16)); }
+  __syncthreads();
+  // exclusive scan: thread t owns the cells [64 t, 64 t + 64) (32 words)
+  constexpr int WPT = LO_GC / 2 / LG_T;
+  int tsum = 0;
+#pragma unroll 4
+  for (int k = 0; k < WPT; ++k) { const unsigned w = s_cnt[tid * WPT + k]; tsum += (int)(w & 0xFFFFu) + (int)(w >> 16); }
+  int incl = tsum;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+  if (lane == 63) s_tot[wave] = incl;
+  __syncthreads();
+  int run = incl - tsum;
+#pragma unroll
+  for (int w = 0; w < LG_T / 64; ++w) if (w < wave) run += s_tot[w];
+  for (int k = 0; k < WPT; ++k) {
+    const int c0 = 2 * (tid * WPT + k);
+    const unsigned w = s_cnt[tid * WPT + k];
+    const int a = run, b = run + (int)(w & 0xFFFFu);
+    run = b + (int)(w >> 16);
+    s_cnt[tid * WPT + k] = (unsigned)a | ((unsigned)b << 16);   // the counts become the cells' cursors
+    if (c0 <= ncell) cell[c0] = (unsigned short)a;
+    if (c0 + 1 <= ncell) cell[c0 + 1] = (unsigned short)b;
+  }
+  __syncthreads();
+  for (int i = tid; i < n; i += LG_T) {
+    const float4 p = pts[i];
+    const int c = cell_of(p);
+    const unsigned old = atomicAdd(&s_cnt[c >> 1], 1u << ((c & 1) * 16));
+    cp[(old >> ((c & 1) * 16)) & 0xFFFFu] = make_float4(p.x, p.y, p.z, __int_as_float(i));
+  }
+  if (tid == 0) {
+    geom[0] = mn[0]; geom[1] = mn[1]; geom[2] = inv; geom[3] = 0.999f * csz * csz;
+    geom[4] = __int_as_float(gx); geom[5] = __int_as_float(gy);
+  }
+}
+void launch_lo_grid(const DevCtx& d, hipStream_t st) {
+  if (!d.opt_lo_grid) return;
+  ALEGO_LAUNCH(lo_grid_build, dim3(d.n_launch, 2), dim3(LG_T), 0, st, d);
+}
+
 // kind (compile-time): the corner association has one class of second points, the surf one two.  BLKA threads per workgroup, BLKA / 16
 // queries at a time; workgroup qb0 of qbn of the stream takes the query blocks qb0, qb0 + qbn, ...  (A device function: the batch path
 // launches it as lo_assoc, one stream's chain kernel lo_chain calls it between its grid barriers.)
@@ -129,9 +225,13 @@ DEV_INLINE void lo_assoc_body(const DevCtx& d, int box_lds_max, int slot, int qb
   __shared__ double s_pose[12];
   __shared__ float4 s_box[2 * BOXCAP];   // the boxes are read by every query of the workgroup: LDS when they fit
   __shared__ int s_roff[65], s_boff[65];
+  __shared__ float s_geom[8];
   const bool box_lds = nch <= box_lds_max;   // (<= LO_BOX_LDS; the parity tests also run with 0 = boxes straight from HBM)
   if (box_lds) for (int i = threadIdx.x; i < 2 * nch; i += BLKA) s_box[i] = bx[i];
   for (int i = threadIdx.x; i <= d.NS; i += BLKA) { s_roff[i] = roff[i]; s_boff[i] = boff[i]; }
+  if (threadIdx.x < 8) s_geom[threadIdx.x] = d.opt_lo_grid ? d.lo_geom[(fl * 2 + kind) * 8 + threadIdx.x] : 0.f;
+  const float4* gpts = d.lo_cpts[kind] + fl * d.fcap[tk];
+  const unsigned short* gcell = d.lo_cell + (fl * 2 + kind) * (LO_GC + 2);
   if (threadIdx.x == 0) {
     bool same = true;   // NaN (nothing cached yet) or a pose written by alego_set_lo_params compares unequal
 #pragma unroll
@@ -216,6 +316,39 @@ DEV_INLINE void lo_assoc_body(const DevCtx& d, int box_lds_max, int slot, int qb
 #pragma unroll
       for (int u = 0; u < LO_NB; ++u) { cb[u] = surv ? c0 + __ffs((int)surv) - 1 : -1; surv &= surv - 1; }   // 0 stays 0
     };
+    // ---- the 3 x 3 grid cells around the query first: a candidate closer than (almost) a cell size is the nearest neighbour
+    unsigned long long gbest = ~0ull;
+    bool settled = false;
+    {
+      const int ggx = __float_as_int(s_geom[4]), ggy = __float_as_int(s_geom[5]);
+      if (ggx > 0) {
+        const int cx = (int)floorf((sx - s_geom[0]) * s_geom[2]), cy = (int)floorf((sy - s_geom[1]) * s_geom[2]);
+        const int x0 = max(cx - 1, 0), x1 = min(cx + 1, ggx - 1);
+        int a0[3], a1[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {   // unconditional loads from clamped addresses: all six in flight together
+          const int y = cy + r - 1;
+          const bool in = y >= 0 && y < ggy && x0 <= x1 && cx >= -1 && cx <= ggx;
+          const int b0 = gcell[in ? y * ggx + x0 : 0], b1 = gcell[in ? y * ggx + x1 + 1 : 0];
+          a0[r] = in ? b0 : 0; a1[r] = in ? b1 : 0;
+        }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          for (int t = a0[r] + l16; __ballot(t < a1[r]); t += 16) {
+            const bool v = t < a1[r];
+            const float4 a = gpts[v ? t : 0];
+            float r2 = 0.f, df;
+            df = a.x - sx; r2 += df * df; df = a.y - sy; r2 += df * df; df = a.z - sz; r2 += df * df;
+            const unsigned long long k = ((unsigned long long)(uint32_t)d_f2i(r2) << 32) | (uint32_t)__float_as_int(a.w);
+            if (v) gbest = k < gbest ? k : gbest;
+          }
+        }
+        gbest = row16_min_u64(gbest);
+        settled = gbest != ~0ull && d_i2f((int32_t)(gbest >> 32)) < s_geom[3];
+      }
+    }
+    unsigned long long bj = gbest;
+    if (__ballot(!settled)) {   // (rare: a query with no target within a cell size — its row, and with it the wavefront's other rows, search the boxes; both answers are exact)
     unsigned long long m1 = ~0ull;
     for (int c = l16; c < nch; c += 16) {
       const unsigned long long k = ((unsigned long long)(uint32_t)d_f2i(lb_f32(c)) << 32) | (uint32_t)c;
@@ -236,7 +369,8 @@ DEV_INLINE void lo_assoc_body(const DevCtx& d, int box_lds_max, int slot, int qb
         best = nn_eval(cb, best);
       }
     }
-    const unsigned long long bj = row16_min_u64(best);
+    bj = row16_min_u64(best);
+    }
     LA_TICK(4);
     const bool found = (double)d_i2f((int32_t)(bj >> 32)) < nfd;
     if (found) closest = (int)(uint32_t)bj;

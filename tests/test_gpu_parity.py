@@ -175,7 +175,8 @@ def _fe_compare(h, o, feat, tag):
 @pytest.mark.parametrize("geom,nscan,box_lds", [((16, 1800), 6, None), ((16, 1800), 3, 0), ((16, 1800), 3, "pick1"),
                                                  ((16, 4000), 3, None), ((64, 2048), 3, None),
                                                  ((16, 1800), 3, "unfused"), ((16, 4000), 2, "unfused"), ((64, 2048), 2, "unfused"),
-                                                 ((16, 1800), 3, "cand8"), ((16, 4000), 2, "cand8"), ((64, 2048), 2, "cand8")])
+                                                 ((16, 1800), 3, "cand8"), ((16, 4000), 2, "cand8"), ((64, 2048), 2, "cand8"),
+                                                 ((16, 1800), 4, "nogrid"), ((64, 2048), 3, "nogrid"), ((16, 1800), 4, "leaf2")])
 def test_fe_lo_teacher_forced(geom, nscan, box_lds, monkeypatch):
     """Each scan starts from the oracle's params_ (teacher forcing): indices exact, pose 1e-4.  box_lds = 0 makes lo_assoc
     read its bounding boxes from HBM (the path of feature clouds too large for the LDS staging).  Feature extraction runs as
@@ -188,9 +189,13 @@ def test_fe_lo_teacher_forced(geom, nscan, box_lds, monkeypatch):
         monkeypatch.setenv("ALEGO_FE_FUSED", "0")
     elif box_lds == "cand8":
         monkeypatch.setenv("ALEGO_FE_CAND", "8")
+    elif box_lds == "nogrid":
+        monkeypatch.setenv("ALEGO_LO_GRID", "0")   # the 1-NN of LaserOdometry from the boxes alone (otherwise: the 3 x 3 cells of the target grid first)
     elif box_lds is not None:
         monkeypatch.setenv("ALEGO_LO_BOX_LDS", str(box_lds))
     p = synth.default_params(*geom)
+    if box_lds == "leaf2":
+        p.less_flat_leaf = 2.5   # a less_flat cloud so thin that most queries have no target within a grid cell: the box search behind the grid
     h, o = binding.Handle(p), O.Oracle(p)
     for k in range(nscan):
         pts = synth.scan(p, k)
