@@ -112,6 +112,7 @@ extern "C" void alego_la_times(long long* out) { (void)hipMemcpyFromSymbol(out, 
 // One workgroup per (stream, cloud): counts packed two cells per LDS word (a cloud has < 65536 points: otherwise no grid, gx = 0), exclusive
 // scan, scatter; the order inside a cell is whatever the atomics give and does not matter (the key is (distance, index)).
 #define LG_T 256
+#define LG_KEEP 20   // 5120 points: every cloud of a 16-ring sensor
 __global__ void __launch_bounds__(LG_T) lo_grid_build(DevCtx d) {
   const int slot = blockIdx.x + d.slot0, kind = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const size_t fb = (size_t)slot * 2 + cur_in_flight(d, slot);
@@ -125,8 +126,13 @@ __global__ void __launch_bounds__(LG_T) lo_grid_build(DevCtx d) {
   __shared__ float s_red[4][LG_T / 64];
   __shared__ int s_tot[LG_T / 64];
   if (n <= 0 || n > 65535) { if (tid == 0) geom[4] = __int_as_float(0); return; }
+  // the cloud's (x, y) extent from its bounding boxes (feature extraction wrote them next to the cloud: ~150 boxes instead of every point once more)
   float mn[2] = {3.402823466e+38f, 3.402823466e+38f}, mx[2] = {-3.402823466e+38f, -3.402823466e+38f};
-  for (int i = tid; i < n; i += LG_T) { const float4 p = pts[i]; mn[0] = fminf(mn[0], p.x); mn[1] = fminf(mn[1], p.y); mx[0] = fmaxf(mx[0], p.x); mx[1] = fmaxf(mx[1], p.y); }
+  {
+    const float4* bx = d.lo_box + (fb * 2 + kind) * d.lo_box_cap * 2;
+    const int nbox = d.ring_boff[(fb * 2 + (kind == 0 ? 1 : 0)) * (d.NS + 1) + d.NS];
+    for (int b = tid; b < nbox; b += LG_T) { const float4 l = bx[2 * b], u = bx[2 * b + 1]; mn[0] = fminf(mn[0], l.x); mn[1] = fminf(mn[1], l.y); mx[0] = fmaxf(mx[0], u.x); mx[1] = fmaxf(mx[1], u.y); }
+  }
 #pragma unroll
   for (int a = 0; a < 2; ++a) {
 #pragma unroll
@@ -157,7 +163,15 @@ __global__ void __launch_bounds__(LG_T) lo_grid_build(DevCtx d) {
     const int ix = min(max((int)floorf((p.x - mn[0]) * inv), 0), gx - 1), iy = min(max((int)floorf((p.y - mn[1]) * inv), 0), gy - 1);
     return ix + gx * iy;
   };
-  for (int i = tid; i < n; i += LG_T) { const int c = cell_of(pts[i]); atomicAdd(&s_cnt[c >> 1], 1u << ((c & 1) * 16)); }
+  // the points stay in registers between the count and the scatter (LG_KEEP per thread; a larger cloud reads the rest again)
+  float4 keep[LG_KEEP];
+#pragma unroll
+  for (int u = 0; u < LG_KEEP; ++u) {
+    const int i = tid + u * LG_T;
+    keep[u] = pts[min(i, n - 1)];
+    if (i < n) { const int c = cell_of(keep[u]); atomicAdd(&s_cnt[c >> 1], 1u << ((c & 1) * 16)); }
+  }
+  for (int i = tid + LG_KEEP * LG_T; i < n; i += LG_T) { const int c = cell_of(pts[i]); atomicAdd(&s_cnt[c >> 1], 1u << ((c & 1) * 16)); }
   __syncthreads();
   // exclusive scan: thread t owns the cells [64 t, 64 t + 64) (32 words)
   constexpr int WPT = LO_GC / 2 / LG_T;
@@ -182,12 +196,14 @@ __global__ void __launch_bounds__(LG_T) lo_grid_build(DevCtx d) {
     if (c0 + 1 <= ncell) cell[c0 + 1] = (unsigned short)b;
   }
   __syncthreads();
-  for (int i = tid; i < n; i += LG_T) {
-    const float4 p = pts[i];
+  auto place = [&](int i, const float4& p) {
     const int c = cell_of(p);
     const unsigned old = atomicAdd(&s_cnt[c >> 1], 1u << ((c & 1) * 16));
     cp[(old >> ((c & 1) * 16)) & 0xFFFFu] = make_float4(p.x, p.y, p.z, __int_as_float(i));
-  }
+  };
+#pragma unroll
+  for (int u = 0; u < LG_KEEP; ++u) { const int i = tid + u * LG_T; if (i < n) place(i, keep[u]); }
+  for (int i = tid + LG_KEEP * LG_T; i < n; i += LG_T) place(i, pts[i]);
   if (tid == 0) {
     geom[0] = mn[0]; geom[1] = mn[1]; geom[2] = inv; geom[3] = 0.999f * csz * csz;
     geom[4] = __int_as_float(gx); geom[5] = __int_as_float(gy);

@@ -65,7 +65,7 @@ def kernel_bytes(name, c, NS, H, rebuilds_per_launch=0.0):
     t = {
         # B_IP = 16 P (in) + 25 M + 16 O + 8 NS + 12 (out)
         "ip_fused": 16 * P + 25 * M + 16 * O + 8 * NS + 12,   # = B_IP (the curvature phase left the kernel in round 3; fe_* are charged B_FE)
-        "ip_fused_h": 16 * P + 25 * M + 16 * O + 8 * NS + 12,
+        "ip_fused_h": 16 * P + 25 * M + 16 * O + 8 * NS + 12, "ip_fused_w": 16 * P + 25 * M + 16 * O + 8 * NS + 12,
         "ip_project": 16 * P, "ip_front": 12, "cc_lds16": 25 * M + 16 * O + 8 * NS, "cc_lds": 25 * M + 16 * O + 8 * NS,
         "ip_compact": 25 * M + 16 * O + 8 * NS,
         # B_FE = 9 M (range, col, ground in) + 16 feats (out)
