@@ -803,7 +803,7 @@ void launch_fe_fused(const DevCtx& d, hipStream_t st);
 void launch_fe_curv_debug(const DevCtx& d, hipStream_t st) { ALEGO_LAUNCH(fe_curv, dim3((d.N + FE_CW - 1) / FE_CW, d.n_launch), dim3(FE_BLOCK), 0, st, d); }
 
 void launch_fe(const DevCtx& d, hipStream_t st) {
-  if (fe_fused_eligible(d)) { launch_fe_fused(d, st); launch_lo_grid(d, st); return; }   // fe_cand + fe_pick8 + fe_ring_out; below: the four-kernel path (ALEGO_FE_FUSED=0, sort_mode 2)
+  if (fe_fused_eligible(d)) { launch_fe_fused(d, st); launch_lo_grid(d, st); return; }   // fe_cand + fe_pickc + fe_ring_out; below: the four-kernel path (ALEGO_FE_FUSED=0, sort_mode 2)
   // dynamic LDS above 64 KB has to be requested explicitly (fe_voxel: 26 B per column, horizon_scan <= 4096)
   static const bool cfg = hipFuncSetAttribute(reinterpret_cast<const void*>(fe_voxel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fv_lds_bytes(FE_MAXH)) == hipSuccess;
   (void)cfg;

@@ -7,8 +7,8 @@
 //                column jump stops it) are evaluated per point, and the sector's sharp / flat CANDIDATES — a 16 x 1800 sector has ~190 points,
 //                ~32 sharp and ~12 flat candidates — go to a short list (8 B per candidate; it stays in the L2).  Reads range / column /
 //                ground (9 B per point); no curvature or flag array is written.
-//   fe_pick8     a9: the greedy pick (:189-277) is sequential per ring and only ever asks for the best remaining candidate: one wavefront per
-//                EIGHT rings of a stream, eight lanes per ring, the sector's candidates in registers, arg-max by three DPP steps,
+//   fe_pickc     a9: the greedy pick (:189-277) is sequential per ring and only ever asks for the best remaining candidate: one wavefront per
+//                FOUR rings of a stream, sixteen lanes (one DPP row) per ring, the sector's candidates in registers, arg-max by four DPP steps,
 //                suppression = an index-range test on the registers; writes the picked indices.
 //   fe_ring_out  a10 + the clouds: one workgroup per (stream, ring).  pcl::VoxelGrid(0.4) on the ring's less_flat_scan (:288-293) straight
 //                from the segmented cloud — the points of a ring are contiguous, the few labelled ones are holes in a bitmap — then the
@@ -24,9 +24,13 @@
 #define FE_MAXH 4096   // largest horizon_scan (as kernels_fe.hip)
 
 // ---------------------------------------------------------------------------------------------------------------------------------
-// fe_cand + fe_pick8
+// fe_cand + fe_pickc
 // ---------------------------------------------------------------------------------------------------------------------------------
-#define FF_G 8        // rings per picking wavefront (8 lanes each)
+#ifndef FF_G
+#define FF_G 4        // rings per picking wavefront (64 / FF_G lanes each): 4 (default) or 8 — eight rings per wavefront issue a quarter fewer instructions, but the
+                      // kernel is a latency chain: four rings finish in 166 instead of 292 us alone and the bench gains 1.1 % (424.9 k -> 429.4 k scans/s, same box)
+#endif
+#define FF_LPR (64 / FF_G)
 #define FF_HALO 8     // staged points either side of a sector (11-tap sum: 5, occlusion marks of the neighbours: 6)
 #define FF_Q0 64      // staging position of a sector's first point: the sector's 64-point chunks are the ballot masks' chunks
 #ifndef FC_NW
@@ -44,12 +48,15 @@ __host__ __device__ inline FfLayout ff_layout(int sector_cap) {
   return L;
 }
 
-// max over the 8 lanes of a ring group (quad_perm xor 1, xor 2, row_half_mirror), result in every lane of the group
+// max over the 64 / FF_G lanes of a ring group (quad_perm xor 1, xor 2, row_half_mirror; row_mirror for 16 lanes), result in every lane of the group
 DEV_INLINE uint32_t grp8_max_u32(uint32_t v) {
   int x = (int)v, t;
   t = __builtin_amdgcn_update_dpp(x, x, 0xB1, 0xF, 0xF, false); x = (uint32_t)t > (uint32_t)x ? t : x;
   t = __builtin_amdgcn_update_dpp(x, x, 0x4E, 0xF, 0xF, false); x = (uint32_t)t > (uint32_t)x ? t : x;
   t = __builtin_amdgcn_update_dpp(x, x, 0x141, 0xF, 0xF, false); x = (uint32_t)t > (uint32_t)x ? t : x;
+#if FF_G == 4   // 16 lanes per ring: one more step (row_mirror) = row16_max_u32
+  t = __builtin_amdgcn_update_dpp(x, x, 0x140, 0xF, 0xF, false); x = (uint32_t)t > (uint32_t)x ? t : x;
+#endif
   return (uint32_t)x;
 }
 // bits [pos, pos + 64) of the 128-bit value hi:lo
@@ -61,7 +68,7 @@ DEV_INLINE void ff_sector(const alego_params& P, int S, int E, int j, int& sp, i
   else { const int diff = E - S; sp = S + j * diff / NSEC; ep = S + (j + 1) * diff / NSEC - 1; }                               // LO.cpp:245-249
 }
 
-// The candidate list of one ring sector, in HBM (it stays in the L2 between fe_cand and fe_pick8): `sector_cap` entries (key, pay); the sharp
+// The candidate list of one ring sector, in HBM (it stays in the L2 between fe_cand and fe_pickc): `sector_cap` entries (key, pay); the sharp
 // candidates fill it from the front, the flat ones from the back — a point is one or the other (not ground / ground), so they never meet.
 //   key  sharp: |cd| bits + 1, flat: ~|cd| bits (0 = no candidate; the pick is an arg-MAX for both; curvature = (double)cd^2 orders like |cd|)
 //   pay  sharp: (index in sector) << 6 | reach forward << 3 | reach backward; flat: ~ of that (ties: sharp -> larger index, flat -> smaller)
@@ -214,8 +221,8 @@ DEV_INLINE void ff_commit(FfPick& R, bool rem, int lab, int c, int lo, int hi, u
 }
 DEV_INLINE bool ff_marked(const uint32_t* mark, int mw, uint32_t loc) { return (mark[min((int)(loc >> 5), mw - 1)] >> (loc & 31u)) & 1u; }
 
-// The greedy pick of one sector for the eight rings of the wavefront, candidates in registers: lane gl of a group holds the list entries
-// gl, gl + 8, ... (K of them; lp[t * dir] = entry t).  FLAT = false: sharp / less-sharp (:189-236), FLAT = true: flat (:238-277).  Every pick:
+// The greedy pick of one sector for the FF_G rings of the wavefront, candidates in registers: lane gl of a group holds the list entries
+// gl, gl + FF_LPR, ... (K of them; lp[t * dir] = entry t).  FLAT = false: sharp / less-sharp (:189-236), FLAT = true: flat (:238-277).  Every pick:
 // arg-max of (key, pay) over the group, label by count, then every candidate inside the picked point's reach leaves the registers.  The
 // (n_less_sharp + 1)-th sharp pick of the reference (:207-210: marked, not labelled, break) has no effect on any output — it marks a non-ground
 // point of its own sector, and only ground points are flat candidates — and is not taken.
@@ -224,7 +231,7 @@ DEV_INLINE void ff_pick_regs(const alego_params& P, FfPick& R, int ncand, const 
   uint32_t key[K], pay[K];
 #pragma unroll
   for (int t = 0; t < K; ++t) {   // unconditional loads from clamped addresses: all K in flight together
-    const int idx = gl + 8 * t;
+    const int idx = gl + FF_LPR * t;
     const bool ok = R.act0 && idx < ncand;
     const uint2 e = lp[(ok ? idx : 0) * dir];
     const uint32_t pv = FLAT ? ~e.y : e.y, loc = pv >> 6;
@@ -267,7 +274,7 @@ DEV_INLINE void ff_pick_regs(const alego_params& P, FfPick& R, int ncand, const 
 // the same pick with the candidates left in their list: any number of candidates, any sector length
 template <bool FLAT>
 DEV_INLINE void ff_pick_mem(const alego_params& P, FfPick& R, int ncand, int nwave, uint2* lp, int dir, uint32_t* mark, int mw, int gl) {
-  for (int t = gl; t < nwave; t += 8) {   // what the earlier sectors' picks (and, for flat, this sector's sharp picks) have marked
+  for (int t = gl; t < nwave; t += FF_LPR) {   // what the earlier sectors' picks (and, for flat, this sector's sharp picks) have marked
     if (R.act0 && t < ncand) {
       const uint2 e = lp[t * dir];
       const uint32_t loc = (FLAT ? ~e.y : e.y) >> 6;
@@ -279,7 +286,7 @@ DEV_INLINE void ff_pick_mem(const alego_params& P, FfPick& R, int ncand, int nwa
   bool act = R.act0 && (FLAT || nmax > 0);
   while (true) {
     uint32_t bk = 0u, bp = 0u;
-    for (int t = gl; t < nwave; t += 8) {
+    for (int t = gl; t < nwave; t += FF_LPR) {
       if (act && t < ncand) {
         const uint2 e = lp[t * dir];
         const bool take = FLAT ? e.x > bk : e.x >= bk;
@@ -298,7 +305,7 @@ DEV_INLINE void ff_pick_mem(const alego_params& P, FfPick& R, int ncand, int nwa
     ff_label<FLAT>(P, picked, nmax, lab, spread, more);
     const int lo = max(c - (spread ? rb : 0), 0), hi = c + (spread ? rf : 0);
     const bool rem = act && (FLAT || lab != 0);
-    for (int t = gl; t < nwave; t += 8) {
+    for (int t = gl; t < nwave; t += FF_LPR) {
       if (rem && t < ncand) {
         const uint32_t pv = lp[t * dir].y, loc = (FLAT ? ~pv : pv) >> 6;
         if (loc - (uint32_t)lo <= (uint32_t)(hi - lo)) lp[t * dir].x = 0u;
@@ -309,14 +316,14 @@ DEV_INLINE void ff_pick_mem(const alego_params& P, FfPick& R, int ncand, int nwa
   }
 }
 
-// One wavefront per EIGHT rings of a stream (eight lanes each), sector by sector in lock-step: the greedy pick only ever looks at the
-// candidates fe_cand left — a 16 x 1800 sector has ~190 points and ~32 sharp candidates — in registers; arg-max by three DPP steps, suppression =
+// One wavefront per FF_G = 4 rings of a stream (16 lanes each), sector by sector in lock-step: the greedy pick only ever looks at the
+// candidates fe_cand left — a 16 x 1800 sector has ~190 points and ~32 sharp candidates — in registers; arg-max by four DPP steps, suppression =
 // an index-range test on the registers.  BIG: sectors of more than 400 points (16 x 4000: up to ~140 sharp / ~200 flat candidates).
 #define FF_MW_MAX 28   // mark words per ring: sectors of up to 768 points (alego_create) + reach
 template <bool BIG>
-__global__ void __launch_bounds__(64) fe_pick8(DevCtx d, int sector_cap) {
+__global__ void __launch_bounds__(64) fe_pickc(DevCtx d, int sector_cap) {
   const int slot = blockIdx.y + d.slot0, ring0 = blockIdx.x * FF_G, lane = threadIdx.x;
-  const int g = lane >> 3, gl = lane & 7;
+  const int g = lane / FF_LPR, gl = lane % FF_LPR;
   const int NS = d.NS;
   const alego_params& P = d.P;
   int* sc = d.scal + slot * SC_COUNT;
@@ -340,15 +347,16 @@ __global__ void __launch_bounds__(64) fe_pick8(DevCtx d, int sector_cap) {
     R.act0 = rv && sp < ep; R.sp = sp; R.carry_in = R.carry;
     const int ns = R.act0 ? cc[2 * j] : 0, nf = R.act0 ? cc[2 * j + 1] : 0;
     uint2* lst = ff_list(d, slot, rc, j, sector_cap);
-    for (int w = gl; w < mw; w += 8) mk[w] = 0u;
+    for (int w = gl; w < mw; w += FF_LPR) mk[w] = 0u;
     const int nsw = (int)wave_max_u32((uint32_t)ns), nfw = (int)wave_max_u32((uint32_t)nf);
-    if (nsw <= (BIG ? 64 : 32)) ff_pick_regs<(BIG ? 8 : 4), false>(P, R, ns, lst, 1, mk, mw, gl);
-    else if (nsw <= (BIG ? 128 : 64)) ff_pick_regs<(BIG ? 16 : 8), false>(P, R, ns, lst, 1, mk, mw, gl);
-    else if (nsw <= (BIG ? 192 : 96) && !d.opt_fe_cand) ff_pick_regs<(BIG ? 24 : 12), false>(P, R, ns, lst, 1, mk, mw, gl);
+    constexpr int KU = 32 / FF_LPR;   // registers per lane for 32 candidates of a ring
+    if (nsw <= (BIG ? 64 : 32)) ff_pick_regs<(BIG ? 2 : 1) * KU, false>(P, R, ns, lst, 1, mk, mw, gl);
+    else if (nsw <= (BIG ? 128 : 64)) ff_pick_regs<(BIG ? 4 : 2) * KU, false>(P, R, ns, lst, 1, mk, mw, gl);
+    else if (nsw <= (BIG ? 192 : 96) && !d.opt_fe_cand) ff_pick_regs<(BIG ? 6 : 3) * KU, false>(P, R, ns, lst, 1, mk, mw, gl);
     else ff_pick_mem<false>(P, R, ns, nsw, lst, 1, mk, mw, gl);
     __builtin_amdgcn_wave_barrier();   // (LDS is in order per wavefront: the sharp picks' marks are there before the flat candidates are tested against them)
-    if (nfw <= 32 && !(d.opt_fe_cand && nfw > 8)) ff_pick_regs<4, true>(P, R, nf, lst + sector_cap - 1, -1, mk, mw, gl);
-    else if (BIG && nfw <= 64 && !d.opt_fe_cand) ff_pick_regs<8, true>(P, R, nf, lst + sector_cap - 1, -1, mk, mw, gl);
+    if (nfw <= 32 && !(d.opt_fe_cand && nfw > 8)) ff_pick_regs<KU, true>(P, R, nf, lst + sector_cap - 1, -1, mk, mw, gl);
+    else if (BIG && nfw <= 64 && !d.opt_fe_cand) ff_pick_regs<2 * KU, true>(P, R, nf, lst + sector_cap - 1, -1, mk, mw, gl);
     else ff_pick_mem<true>(P, R, nf, nfw, lst + sector_cap - 1, -1, mk, mw, gl);
     __builtin_amdgcn_wave_barrier();
   }
@@ -391,7 +399,7 @@ extern "C" void alego_fo_times(long long* out) { (void)hipMemcpyFromSymbol(out, 
 #endif
 
 // the workgroup of row NS: the stream's sharp / less_sharp / flat clouds (ring-ascending concatenation of the picks, :199-205,:245), their
-// index lists, the less_sharp ring offsets and bounding boxes (everything fe_pick8 counted; no ring has to wait for this)
+// index lists, the less_sharp ring offsets and bounding boxes (everything fe_pickc counted; no ring has to wait for this)
 DEV_INLINE void fo_picks_out(const DevCtx& d, int slot, unsigned char* smem) {
   const int tid = threadIdx.x, lane = tid & 63, NS = d.NS;
   const size_t base = (size_t)slot * d.N;
@@ -804,7 +812,7 @@ void launch_fe_fused(const DevCtx& d, hipStream_t st) {
   // registers hold up to 96 sharp + 32 flat candidates of a ring sector (192 + 64 for sectors of more than 400 points: 16 x 4000 has up to ~140 /
   // ~200); longer lists are picked from memory (ff_pick_mem; ALEGO_FE_CAND != 0 sends everything beyond 64 / 8 there: tests)
   const dim3 gp((d.NS + FF_G - 1) / FF_G, d.n_launch);
-  if (sector_cap > 400) { ALEGO_LAUNCH(fe_pick8<true>, gp, dim3(64), 0, st, d, sector_cap); }
-  else { ALEGO_LAUNCH(fe_pick8<false>, gp, dim3(64), 0, st, d, sector_cap); }
+  if (sector_cap > 400) { ALEGO_LAUNCH(fe_pickc<true>, gp, dim3(64), 0, st, d, sector_cap); }
+  else { ALEGO_LAUNCH(fe_pickc<false>, gp, dim3(64), 0, st, d, sector_cap); }
   ALEGO_LAUNCH(fe_ring_out, dim3(d.n_launch, d.NS + 1), dim3(FO_BLOCK), fo_lds_bytes(d.H), st, d);
 }

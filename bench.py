@@ -70,7 +70,7 @@ def kernel_bytes(name, c, NS, H, rebuilds_per_launch=0.0):
         "ip_compact": 25 * M + 16 * O + 8 * NS,
         # B_FE = 9 M (range, col, ground in) + 16 feats (out)
         "fe_curv": 8 * M, "fe_pick4": M, "fe_pick": M, "fe_gather": 16 * feats, "fe_collect": 16 * feats,
-        "fe_cand": 9 * M, "fe_ring_out": 16 * feats,   # (fe_pick8 works on the candidate lists: intermediates)
+        "fe_cand": 9 * M, "fe_ring_out": 16 * feats,   # (fe_pickc works on the candidate lists: intermediates)
         # B_LO = 16 (F' + Q) + 104
         "lo_assoc": 16 * (c["Fc"] + c["Fs"] + c["Qc"] + c["Qs"]) / 2, "lo_solve": 104 / 2, "lo_solve_t": 104 / 2,
         # B_LM = 16 Kraw + 32 Kds + 16 L + 104 per mapping frame
