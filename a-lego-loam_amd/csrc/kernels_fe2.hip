@@ -491,6 +491,7 @@ __global__ void __launch_bounds__(FO_BLOCK) fe_ring_out(DevCtx d) {
   const int slot = blockIdx.x + d.slot0, ring = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
   const int NS = d.NS, H = d.H;
   extern __shared__ __attribute__((aligned(16))) unsigned char fo_smem[];
+  if ((int)blockIdx.x >= d.n_launch) return;   // (the grid's x extent is padded to a multiple of 8, see launch_fe_fused)
   if (ring == NS) { fo_picks_out(d, slot, fo_smem); return; }
   const size_t base = (size_t)slot * d.N;
   const alego_params& P = d.P;
@@ -814,5 +815,8 @@ void launch_fe_fused(const DevCtx& d, hipStream_t st) {
   const dim3 gp((d.NS + FF_G - 1) / FF_G, d.n_launch);
   if (sector_cap > 400) { ALEGO_LAUNCH(fe_pickc<true>, gp, dim3(64), 0, st, d, sector_cap); }
   else { ALEGO_LAUNCH(fe_pickc<false>, gp, dim3(64), 0, st, d, sector_cap); }
-  ALEGO_LAUNCH(fe_ring_out, dim3(d.n_launch, d.NS + 1), dim3(FO_BLOCK), fo_lds_bytes(d.H), st, d);
+  // x padded to a multiple of 8: workgroup b runs on XCD b mod 8, so every ring of a stream lands on the stream's XCD and the workgroups of its lower
+  // rings are dispatched before it by the same dispatcher — what the ring-count look-back relies on.  (With 683 streams per launch — three stream groups — the
+  // rings of a stream sat on different XCDs and the bench workload died with a memory access fault after a few hundred scans; 512 and 256 per launch never did.)
+  ALEGO_LAUNCH(fe_ring_out, dim3((d.n_launch + 7) / 8 * 8, d.NS + 1), dim3(FO_BLOCK), fo_lds_bytes(d.H), st, d);
 }
