@@ -112,7 +112,10 @@ extern "C" void alego_la_times(long long* out) { (void)hipMemcpyFromSymbol(out, 
 // One workgroup per (stream, cloud): counts packed two cells per LDS word (a cloud has < 65536 points: otherwise no grid, gx = 0), exclusive
 // scan, scatter; the order inside a cell is whatever the atomics give and does not matter (the key is (distance, index)).
 #define LG_T 256
-#define LG_KEEP 20   // 5120 points: every cloud of a 16-ring sensor
+#ifndef LG_KEEP
+#define LG_KEEP 20
+#endif
+// LG_KEEP:  // 5120 points: every cloud of a 16-ring sensor
 __global__ void __launch_bounds__(LG_T) lo_grid_build(DevCtx d) {
   const int slot = blockIdx.x + d.slot0, kind = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const size_t fb = (size_t)slot * 2 + cur_in_flight(d, slot);
