@@ -572,6 +572,7 @@ static int fetch_pose(alego_handle* h, int slot, alego_pose* odom, alego_pose* m
     lm_host_get_params(h->lm, slot, map_pose->params);
     map_pose->valid = sc[SC_ODOM_VALID];
   }
+  if (sc[SC_FE_ERR]) { h->err = "feature extraction: a ring's workgroup gave up waiting for the voxel counts of the rings below it (fe_ring_out); the slot's feature clouds are incomplete"; return ALEGO_ERR_HIP; }
   const int lmf = lm_host_get_flags(h->lm, slot);
   if (lmf < 0) { h->err = "LaserMapping device capacity exceeded / launch logic out of sync"; return lmf; }
   return sc[SC_LO_FLAGS] | lmf;
