@@ -814,8 +814,10 @@ __global__ void __launch_bounds__(IP_BLOCK) cc_stats(DevCtx d) {
     const bool same = active && root == lroot;
     const unsigned long long m = __ballot(same);
     unsigned long long rb = same ? (1ull << row) : 0ull;
+    if (d.H & 63) {   // (a wavefront's 64 consecutive cells share a row when the width is a multiple of 64 — 64 x 2048 —: nothing to combine)
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) rb |= __shfl_xor(rb, o, 64);
+      for (int o = 32; o > 0; o >>= 1) rb |= __shfl_xor(rb, o, 64);
+    }
     if (lane == leader) {
       atomicAdd(&d.cc_size[base + lroot], (int)__popcll(m));
       atomicOr(&d.cc_rows[base + lroot], rb);
