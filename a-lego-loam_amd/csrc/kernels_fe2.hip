@@ -380,8 +380,12 @@ __global__ void __launch_bounds__(64) fe_pickc(DevCtx d, int sector_cap) {
 #define FO_STATIC_LDS 3744 // static LDS of fe_ring_out (bitmap, the aliased bucket / box area, reduction scratch), rounded up
 // points of the ring staged in LDS (by position in the ring): the rest is read from the L2 on every pass.  The workgroup stays within 40 KB
 // — FOUR rings per CU; one byte more and it is three (fe_voxel's budget)
+#ifndef FO_BUDGET_BIG
+#define FO_BUDGET_BIG 53248   // LDS budget of a ring too wide for four workgroups per CU anyway (10 H + static > 40 KB: H = 4000): what three per CU leave, i.e. 600 staged points (80 KB / two per CU: 216 k against 224 k scans/s)
+#endif
 __host__ __device__ inline int fo_stage_cap(int H) {
-  const int by_pct = (H * FO_CAP_PCT / 100 + 15) & ~15, by_lds = (40960 - FO_STATIC_LDS - 10 * H) / 16;
+  const int budget = 10 * H + FO_STATIC_LDS > 40960 ? FO_BUDGET_BIG : 40960;
+  const int by_pct = (H * FO_CAP_PCT / 100 + 15) & ~15, by_lds = (budget - FO_STATIC_LDS - 10 * H) / 16;
   return by_lds <= 0 ? 0 : (by_pct < by_lds ? by_pct : (by_lds & ~15));
 }
 static size_t fo_lds_bytes(int H) { return std::max((size_t)10 * H + (size_t)16 * fo_stage_cap(H), (size_t)6 * 65 * 4); }
