@@ -855,8 +855,12 @@ __global__ void __launch_bounds__(IP_BLOCK) ip_rowcount(DevCtx d) {
   int nk = 0, no = 0, nf = 0;
   for (int col = threadIdx.x; col < d.H; col += IP_BLOCK) {
     bool fr;
-    const int c = ip_classify(d, base, row * d.H + col, row, col, &fr);
+    const int v = row * d.H + col;
+    const int c = ip_classify(d, base, v, row, col, &fr);
     nk += c == 1; no += c == 2; nf += fr;
+    // the class of the cell for ip_compact (bits 4-5, bit 6: feasible root): the sweep that follows asks the flag byte instead of walking
+    // flag -> root -> size -> row mask again (every other reader of the flag image masks the low bits; ip_front rewrites the image every scan)
+    d.flag_img[base + v] = (uint8_t)((d.flag_img[base + v] & 0x0F) | (c << 4) | (fr ? 0x40 : 0));
   }
   __shared__ int s[3][IP_BLOCK / 64];
 #pragma unroll
@@ -908,7 +912,8 @@ __global__ void __launch_bounds__(IP_BLOCK) ip_compact(DevCtx d, int ring_pos) {
     int c = 0;
     bool fr = false;
     const int v = row * d.H + col;
-    if (col < d.H) c = ip_classify(d, base, v, row, col, &fr);
+    uint8_t fl = 0;
+    if (col < d.H) { fl = d.flag_img[base + v]; c = (fl >> 4) & 3; fr = (fl & 0x40) != 0; }   // (classified by ip_rowcount)
     const unsigned long long bk = __ballot(c == 1), bo = __ballot(c == 2), bf = __ballot(fr);
     const unsigned long long below = (1ull << lane) - 1ull;
     if (lane == 0) { s_wave[0][wave] = (int)__popcll(bk); s_wave[1][wave] = (int)__popcll(bo); s_wave[2][wave] = (int)__popcll(bf); }
@@ -927,7 +932,7 @@ __global__ void __launch_bounds__(IP_BLOCK) ip_compact(DevCtx d, int ring_pos) {
       if (c == 1) {
         const int line = run_k + wk + (int)__popcll(bk & below);
         d.seg_pts[base + line] = p;
-        d.seg_ground[base + line] = d.flag_img[base + v] & 1;
+        d.seg_ground[base + line] = fl & 1;
         d.seg_col[base + line] = col;
         d.seg_range[base + line] = sqrtf(p.x * p.x + p.y * p.y + p.z * p.z);   // = the range image's value (:99)
       } else {
