@@ -376,28 +376,44 @@ __global__ void __launch_bounds__(64) fe_pickc(DevCtx d, int sector_cap) {
 #define FO_U 4             // loads kept in flight per thread
 #define FO_CAP_PCT 72
 #define FO_INVALID 0xFFFFFFFFu
+#define FO_END 0xFFFFu
 #define FO_SPIN_LIMIT (1 << 22)
-#define FO_STATIC_LDS 3744 // static LDS of fe_ring_out (bitmap, the aliased bucket / box area, reduction scratch), rounded up
+#define FO_STATIC_LDS 4000 // static LDS of fe_ring_out (bitmap, the aliased bucket / box area, reduction scratch), rounded up
 // points of the ring staged in LDS (by position in the ring): the rest is read from the L2 on every pass.  The workgroup stays within 40 KB
 // — FOUR rings per CU; one byte more and it is three (fe_voxel's budget)
 #ifndef FO_BUDGET_BIG
 #define FO_BUDGET_BIG 53248   // LDS budget of a ring too wide for four workgroups per CU anyway (10 H + static > 40 KB: H = 4000): what three per CU leave, i.e. 600 staged points (80 KB / two per CU: 216 k against 224 k scans/s)
 #endif
-__host__ __device__ inline int fo_stage_cap(int H) {
-  const int budget = 10 * H + FO_STATIC_LDS > 40960 ? FO_BUDGET_BIG : 40960;
-  const int by_pct = (H * FO_CAP_PCT / 100 + 15) & ~15, by_lds = (budget - FO_STATIC_LDS - 10 * H) / 16;
-  return by_lds <= 0 ? 0 : (by_pct < by_lds ? by_pct : (by_lds & ~15));
+// dynamic LDS of a ring: 12 bytes per column for the run tables, 4 more for the bucket-ordered keys of the run ordering where they fit ("keyed"),
+// the rest of the budget for staged points
+#ifndef FO_KEYED
+#define FO_KEYED 1
+#endif
+struct FoLayout { int cap; int keyed; };
+__host__ __device__ inline FoLayout fo_layout(int H) {
+  const int budget = 12 * H + FO_STATIC_LDS > 40960 ? FO_BUDGET_BIG : 40960;
+  FoLayout L;
+  L.keyed = FO_KEYED && 16 * H + FO_STATIC_LDS <= budget;
+  const int by_pct = (H * FO_CAP_PCT / 100 + 15) & ~15, by_lds = (budget - FO_STATIC_LDS - (L.keyed ? 16 : 12) * H) / 16;
+  L.cap = by_lds <= 0 ? 0 : (by_pct < by_lds ? by_pct : (by_lds & ~15));
+  return L;
 }
-static size_t fo_lds_bytes(int H) { return std::max((size_t)10 * H + (size_t)16 * fo_stage_cap(H), (size_t)6 * 65 * 4); }
+static size_t fo_lds_bytes(int H) { const FoLayout L = fo_layout(H); return std::max((size_t)(L.keyed ? 16 : 12) * H + (size_t)16 * L.cap, (size_t)6 * 65 * 4); }
 
 // order-preserving map float -> u32 (for LDS atomic min / max) and back
 DEV_INLINE uint32_t fo_ord(float f) { const uint32_t b = (uint32_t)d_f2i(f); return b ^ ((b >> 31) ? 0xFFFFFFFFu : 0x80000000u); }
 DEV_INLINE float fo_unord(uint32_t u) { return d_i2f((int32_t)(u ^ ((u >> 31) ? 0x80000000u : 0xFFFFFFFFu))); }
 
 #ifdef ALEGO_TIMING
-__device__ long long fo_times[12];
-extern "C" void alego_fo_times(long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(fo_times), sizeof(long long) * 12); }
-#define FO_TICK(k) do { if (threadIdx.x == 0 && blockIdx.y == 8 && blockIdx.x == 0) fo_times[k] = wall_clock64(); } while (0)
+__device__ long long fo_times[24];
+extern "C" void alego_fo_times(long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(fo_times), sizeof(long long) * 24); }
+#ifndef FO_TICK_RING
+#define FO_TICK_RING 8
+#endif
+#define FO_TICK(k) do { if (threadIdx.x == 0 && blockIdx.y == FO_TICK_RING && blockIdx.x == 0) fo_times[k] = wall_clock64(); } while (0)
+#elif defined(FO_STOP_AFTER)
+// development (instruction counts per phase, tools/fo_phase_counts.sh): the ring stops after phase FO_STOP_AFTER — its count is published first so that no ring above it spins
+#define FO_TICK(k) do { if ((k) == FO_STOP_AFTER) { if (threadIdx.x == 0) __hip_atomic_store(&d.fe_sync[(size_t)slot * NS + ring], (epoch << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; } } while (0)
 #else
 #define FO_TICK(k)
 #endif
@@ -509,13 +525,16 @@ __global__ void __launch_bounds__(FO_BLOCK) fe_ring_out(DevCtx d) {
   const int* st_ls = d.st_idx + ((size_t)slot * NS + ring) * d.st_stride + d.cap_sharp;
   const float4* seg = d.seg_lo + base;
   float4* s_pt = reinterpret_cast<float4*>(fo_smem);                            // the ring's points [cap]
-  const int cap = fo_stage_cap(H);
+  const FoLayout lay = fo_layout(H);
+  const int cap = lay.cap;
   unsigned char* fv2 = fo_smem + (size_t)16 * cap;
   uint32_t* s_key = reinterpret_cast<uint32_t*>(fv2);                           // voxel id per point (a hole carries the id of the point before it)   [H]
-  uint32_t* s_rvid = s_key;                                                     // voxel id per run, compacted in place (run r <= its first point)
-  uint16_t* s_rstart = reinterpret_cast<uint16_t*>(fv2 + 4 * (size_t)H);        // first point of the run  [H]
-  uint16_t* s_order = reinterpret_cast<uint16_t*>(fv2 + 6 * (size_t)H);         // valid runs sorted by (voxel id, run) [H]
-  uint16_t* s_tmp = reinterpret_cast<uint16_t*>(fv2 + 8 * (size_t)H);           // valid runs dealt into buckets [H]
+  uint16_t* s_tmp = reinterpret_cast<uint16_t*>(fv2);                           // (once the runs are found, in the keys' place) valid runs dealt into buckets [H]; then: first point | flags of the run at that place of the order
+  uint16_t* s_order = reinterpret_cast<uint16_t*>(fv2 + 2 * (size_t)H);         // valid runs sorted by (voxel id, run) [H]; then: length - 1 of the run at that place of the order
+  uint32_t* s_rvid = reinterpret_cast<uint32_t*>(fv2 + 4 * (size_t)H);          // voxel id per run [H]
+  uint16_t* s_rstart = reinterpret_cast<uint16_t*>(fv2 + 8 * (size_t)H);        // first point of the run  [H]
+  uint16_t* s_nxt = reinterpret_cast<uint16_t*>(fv2 + 10 * (size_t)H);          // per point: the next point of its voxel in summation order (FO_END: none) [H]
+  uint32_t* k_tmp = reinterpret_cast<uint32_t*>(fv2 + 12 * (size_t)H);          // (keyed) per place of the bucket lists: (voxel id within the bucket) << 12 | run [H]
   __shared__ uint32_t s_bm[FE_MAXH / 32 + 2];     // holes of less_flat_scan: the ring's less-sharp picks (label > 0, :284) and points of skipped sectors (:181)
   __shared__ int s_alias[768];                    // bucket offsets / cursors while the runs are ordered; hole prefix counts of the pass-through; box corners afterwards
   int* s_boff = s_alias; int* s_bcur = s_alias + FO_NB + 1; int* s_wpre = s_alias;
@@ -523,6 +542,19 @@ __global__ void __launch_bounds__(FO_BLOCK) fe_ring_out(DevCtx d) {
   __shared__ float s_red[6][FO_BLOCK / 64];
   __shared__ int s_scan[FO_BLOCK / 64], s_cntv[FO_BLOCK / 64];
   __shared__ int s_look[3];
+  __shared__ int s_rc[64];                        // heads per (chunk of FO_BLOCK, wavefront): every wavefront scans the 64 counts itself — one barrier for all chunks
+  static_assert(FE_MAXH / 64 <= 64 && FO_BLOCK % 64 == 0, "s_rc holds one count per 64 positions of a ring");
+  constexpr int NW = FO_BLOCK / 64;
+  const int wv = tid >> 6;
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  auto scan64 = [&](int cnt, int* total) -> int {   // exclusive prefix of one value per lane over the wavefront
+    int incl = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+    *total = __builtin_amdgcn_readlane(incl, 63);
+    return incl - cnt;
+  };
+  if (tid < 64) s_rc[tid] = 0;
   FO_TICK(0);
   const int BW = (n_all + 31) / 32;
   for (int w = tid; w <= BW + 1 && w <= FE_MAXH / 32 + 1; w += FO_BLOCK) s_bm[w] = 0u;
@@ -586,7 +618,7 @@ __global__ void __launch_bounds__(FO_BLOCK) fe_ring_out(DevCtx d) {
     const long long dx = (long long)((mx[0] - mn[0]) * inv) + 1, dy = (long long)((mx[1] - mn[1]) * inv) + 1, dz = (long long)((mx[2] - mn[2]) * inv) + 1;
     passthrough = dx * dy * dz > 2147483647LL;   // "leaf size too small": the input is returned unchanged
   }
-  int nout = 0, nrv = 0, nruns = 0;
+  int nout = 0, nrv = 0, nruns = 0, vex = 0;   // vex: voxels before every (chunk, wavefront) of the order, one per lane
   if (passthrough) {
     if (tid == 0) { int acc = 0; for (int w = 0; w <= BW; ++w) { s_wpre[w] = acc; acc += __popc(s_bm[w]); } }
     nout = nval;
@@ -611,25 +643,38 @@ __global__ void __launch_bounds__(FO_BLOCK) fe_ring_out(DevCtx d) {
       s_key[i] = src < 0 ? FO_INVALID : (uint32_t)(i0 + i1 * mul1 + i2 * mul2);
     }
     __syncthreads();
-    // runs of consecutive equal voxel ids
-    for (int c0 = 0; c0 < n_all; c0 += FO_BLOCK) {
-      const int i = c0 + tid;
-      const uint32_t mykey = i < n_all ? s_key[i] : 0u;   // read before the barrier: the run ids are compacted into the same array
-      const bool head = i < n_all && (i == 0 || mykey != s_key[i - 1]);
+    // runs of consecutive equal voxel ids: heads counted per (chunk, wavefront), one barrier, every wavefront scans the counts, heads written
+#pragma nounroll
+    for (int c = 0; c * FO_BLOCK < n_all; ++c) {
+      const int i = c * FO_BLOCK + tid;
+      const bool head = i < n_all && (i == 0 || s_key[i] != s_key[i - 1]);
       const unsigned long long m = __ballot(head);
-      if (lane == 0) s_scan[tid >> 6] = (int)__popcll(m);
-      __syncthreads();
-      int woff = 0, tot = 0;
-#pragma unroll
-      for (int w = 0; w < FO_BLOCK / 64; ++w) { if (w < (tid >> 6)) woff += s_scan[w]; tot += s_scan[w]; }
-      if (head) {
-        const int r = nruns + woff + (int)__popcll(m & ((1ull << lane) - 1ull));
-        s_rvid[r] = mykey;
-        s_rstart[r] = (uint16_t)i;
-      }
-      nruns += tot;
-      __syncthreads();
+      if (lane == 0) s_rc[c * NW + wv] = (int)__popcll(m);
     }
+    __syncthreads();
+    {
+      const int ex = scan64(s_rc[lane], &nruns);
+#pragma nounroll
+      for (int c = 0; c * FO_BLOCK < n_all; ++c) {
+        const int i = c * FO_BLOCK + tid;
+        const uint32_t mykey = i < n_all ? s_key[i] : 0u;
+        const bool head = i < n_all && (i == 0 || mykey != s_key[i - 1]);
+        const unsigned long long m = __ballot(head);
+        const int r0 = __builtin_amdgcn_readlane(ex, __builtin_amdgcn_readfirstlane(c * NW + wv));
+        if (head) {
+          const int r = r0 + (int)__popcll(m & lt);
+          s_rvid[r] = mykey;
+          s_rstart[r] = (uint16_t)i;
+        }
+        // the chain a voxel's sum follows: the next point of the run that is not a hole (a hole carries the key of the point before it, so it never ends a run)
+        if (i < n_all) {
+          int j = i + 1;
+          while (j < n_all && hole(j)) ++j;
+          s_nxt[i] = (uint16_t)((j < n_all && s_key[j] == mykey) ? j : FO_END);
+        }
+      }
+    }
+    __syncthreads();   // (the keys are dead from here on: the bucket lists take their place)
     FO_TICK(3);
     // order the valid runs by (voxel id, run index): dealt into <= FO_NB buckets monotone in the voxel id, ranked inside the bucket
     {
@@ -640,8 +685,10 @@ __global__ void __launch_bounds__(FO_BLOCK) fe_ring_out(DevCtx d) {
       const int nb = (int)((T - 1) >> shift) + 1;
       for (int b = tid; b <= nb; b += FO_BLOCK) s_boff[b] = 0;
       __syncthreads();
+      FO_TICK(9);
       for (int r = tid; r < nruns; r += FO_BLOCK) { const uint32_t v = s_rvid[r]; if (v != FO_INVALID) atomicAdd(&s_boff[min((int)(v >> shift), nb - 1) + 1], 1); }
       __syncthreads();
+      FO_TICK(10);
       {
         constexpr int PER = FO_NB / FO_BLOCK;
         int v[PER], sum = 0;
@@ -661,33 +708,74 @@ __global__ void __launch_bounds__(FO_BLOCK) fe_ring_out(DevCtx d) {
       }
       __syncthreads();
       nrv = s_boff[nb];
+      FO_TICK(11);
+      const bool keyed = lay.keyed && shift <= 20;   // (voxel id within a bucket: `shift` bits, run: 12)
+      const uint32_t lowmask = (1u << shift) - 1u;
       for (int r = tid; r < nruns; r += FO_BLOCK) {
         const uint32_t v = s_rvid[r];
-        if (v != FO_INVALID) s_tmp[atomicAdd(&s_bcur[min((int)(v >> shift), nb - 1)], 1)] = (uint16_t)r;  // s_bcur[b] starts at s_boff[b] (written one slot up, read one down)
+        if (v != FO_INVALID) {
+          const int pos = atomicAdd(&s_bcur[min((int)(v >> shift), nb - 1)], 1);   // s_bcur[b] starts at s_boff[b] (written one slot up, read one down)
+          s_tmp[pos] = (uint16_t)r;
+          if (keyed) k_tmp[pos] = ((v & lowmask) << 12) | (uint32_t)r;
+        }
       }
       __syncthreads();
+      FO_TICK(12);
+#ifdef ALEGO_TIMING
+      if (tid == 0 && blockIdx.y == FO_TICK_RING && blockIdx.x == 0) { int mxb = 0; for (int b = 0; b < nb; ++b) mxb = max(mxb, s_boff[b + 1] - s_boff[b]); fo_times[16] = n_all; fo_times[17] = nruns; fo_times[18] = nrv; fo_times[19] = nb; fo_times[20] = mxb; }
+#endif
       for (int t = tid; t < nrv; t += FO_BLOCK) {
         const int r = s_tmp[t];
         const uint32_t v = s_rvid[r];
         const int b = min((int)(v >> shift), nb - 1);
         const int bs = s_boff[b], be = s_boff[b + 1];
         int rank = bs;
-        for (int q = bs; q < be; ++q) { const int o = s_tmp[q]; const uint32_t u = s_rvid[o]; rank += (u < v) || (u == v && o < r); }
+        if (keyed) {   // one read and one compare per entry of the bucket: (id, run) order = order of the packed keys
+          const uint32_t mine = ((v & lowmask) << 12) | (uint32_t)r;
+#pragma nounroll
+          for (int q = bs; q < be; q += 4) {
+            uint32_t u[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) u[k] = k_tmp[min(q + k, be - 1)];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) rank += (u[k] < mine && q + k < be) ? 1 : 0;
+          }
+        } else {
+#pragma nounroll
+          for (int q = bs; q < be; ++q) { const int o = s_tmp[q]; const uint32_t u = s_rvid[o]; rank += (u < v) || (u == v && o < r); }
+        }
         s_order[rank] = (uint16_t)r;
       }
     }
+    if (tid < 64) s_rc[tid] = 0;   // (last read before the barrier that ended the runs)
     __syncthreads();
     FO_TICK(4);
-    // voxels = first runs of their id in the order
-    int nh = 0;
-    for (int j = tid; j < nrv; j += FO_BLOCK) nh += (j == 0 || s_rvid[s_order[j]] != s_rvid[s_order[j - 1]]) ? 1 : 0;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) nh += __shfl_xor(nh, o, 64);
-    if (lane == 0) s_cntv[tid >> 6] = nh;   // (s_cntv was last read before the barriers above)
+    // the first point of the run at every place of the order, with a mark where the run continues the voxel of the place before — there the chain of
+    // that voxel's previous run is linked to this one; voxels = places that do not continue: counted per (chunk, wavefront) like the runs
+#pragma nounroll
+    for (int c = 0; c * FO_BLOCK < nrv; ++c) {
+      const int j = c * FO_BLOCK + tid;
+      uint32_t st = 0x1000u;
+      if (j < nrv) {
+        const int r = s_order[j];
+        const int i0 = s_rstart[r];
+        st = (uint32_t)i0;
+        if (j > 0) {
+          const int rp = s_order[j - 1];
+          if (s_rvid[rp] == s_rvid[r]) {
+            int t = (rp + 1 < nruns ? (int)s_rstart[rp + 1] : n_all) - 1;
+            while (hole(t)) --t;   // (a run's first point is never a hole)
+            s_nxt[t] = (uint16_t)i0;
+            st |= 0x1000u;
+          }
+        }
+        s_tmp[j] = (uint16_t)st;
+      }
+      const unsigned long long m = __ballot(!(st & 0x1000u));
+      if (lane == 0) s_rc[c * NW + wv] = (int)__popcll(m);
+    }
     __syncthreads();
-    nout = 0;
-#pragma unroll
-    for (int w = 0; w < FO_BLOCK / 64; ++w) nout += s_cntv[w];
+    vex = scan64(s_rc[lane], &nout);
   }
   FO_TICK(5);
   // ---- the ring's less_flat offset: its count for the rings above, the counts of the rings below
@@ -743,43 +831,33 @@ __global__ void __launch_bounds__(FO_BLOCK) fe_ring_out(DevCtx d) {
   } else {
     for (int b = tid; b < 6 * nbox; b += FO_BLOCK) s_bx[b] = (b % 6) < 3 ? 0xFFFFFFFFu : 0u;
     __syncthreads();
-    // first run of every voxel -> output rank; it accumulates all runs of the voxel in order
-    int nvox = 0;
-    for (int c0 = 0; c0 < nrv; c0 += FO_BLOCK) {
-      const int j = c0 + tid;
-      const bool head = j < nrv && (j == 0 || s_rvid[s_order[j]] != s_rvid[s_order[j - 1]]);
+    FO_TICK(13);
+    // first run of every voxel -> output rank; it follows the voxel's chain through all its runs, one point per step
+#pragma nounroll
+    for (int c = 0; c * FO_BLOCK < nrv; ++c) {
+      const int j = c * FO_BLOCK + tid;
+      const uint32_t a0 = j < nrv ? s_tmp[j] : 0x1000u;
+      const bool head = !(a0 & 0x1000u);
       const unsigned long long m = __ballot(head);
-      if (lane == 0) s_scan[tid >> 6] = (int)__popcll(m);
-      __syncthreads();
-      int woff = 0, tot = 0;
-#pragma unroll
-      for (int w = 0; w < FO_BLOCK / 64; ++w) { if (w < (tid >> 6)) woff += s_scan[w]; tot += s_scan[w]; }
+      const int rank0 = __builtin_amdgcn_readlane(vex, __builtin_amdgcn_readfirstlane(c * NW + wv));
       if (head) {
-        const int rank = nvox + woff + (int)__popcll(m & ((1ull << lane) - 1ull));
-        const uint32_t vid = s_rvid[s_order[j]];
+        const int rank = rank0 + (int)__popcll(m & lt);
+        int i = (int)(a0 & 0xFFFu);
+        float4 q = point(i);
         float sx = 0.f, sy = 0.f, sz = 0.f, si = 0.f;
-        int c = 0;
-        for (int jj = j; jj < nrv && s_rvid[s_order[jj]] == vid; ++jj) {
-          const int r = s_order[jj], i0 = s_rstart[r], len = (r + 1 < nruns ? (int)s_rstart[r + 1] : n_all) - i0;
-          // the holes of the run's first 32 points in one word (s_bm has a spare word at its end); a run rarely has any
-          const uint32_t hb = (uint32_t)((((unsigned long long)s_bm[(i0 >> 5) + 1] << 32) | s_bm[i0 >> 5]) >> (i0 & 31));
-          if (hb == 0u && len <= 32) {
-            for (int i = i0; i < i0 + len; ++i) { const float4 q = point(i); sx += q.x; sy += q.y; sz += q.z; si += q.w; }   // strictly in order
-            c += len;
-          } else {
-            for (int i = i0; i < i0 + len; ++i) {
-              if (hole(i)) continue;
-              const float4 q = point(i); sx += q.x; sy += q.y; sz += q.z; si += q.w; ++c;
-            }
-          }
+        int cnt = 0;
+#pragma nounroll
+        for (;;) {
+          const int ni = s_nxt[i];
+          sx += q.x; sy += q.y; sz += q.z; si += q.w; ++cnt;   // strictly in order
+          if (ni == FO_END) break;
+          q = point(ni); i = ni;
         }
-        const float fn = (float)c;
+        const float fn = (float)cnt;
         const float4 ctr = make_float4(sx / fn, sy / fn, sz / fn, si / fn);
         out[rank] = ctr;
         box_add(rank, ctr);
       }
-      nvox += tot;
-      __syncthreads();
     }
   }
   __syncthreads();

@@ -505,6 +505,11 @@ bool ipw_eligible(const DevCtx& d) {
          (size_t)2 * d.N + (size_t)8 * d.H + sizeof(IphShared<IPW_T / 64, IPW_NP>) <= 163840;
 }
 size_t iph_lds_bytes(const DevCtx& d) { return (size_t)2 * d.N + (size_t)8 * d.H; }
+#ifdef ALEGO_DUP_HOOK
+static size_t iph_pad() { static const char* e = std::getenv("ALEGO_IPH_PAD"); return e ? (size_t)atoi(e) : 0; }   // development: unused LDS that keeps a second ip_fused_h off the CU
+#else
+static size_t iph_pad() { return 0; }
+#endif
 
 // 16-bit maximum of own16[cell] and val through the aligned 32-bit word
 DEV_INLINE void iph_max16(unsigned* w32, int cell, unsigned val) {
@@ -1000,7 +1005,7 @@ static constexpr auto ip_fused_h = ip_fused_t<IPH_T, IPH_NP>;
 static constexpr auto ip_fused_w = ip_fused_t<IPW_T, IPW_NP>;
 
 void launch_ip_fused(const DevCtx& d, int ring_pos, bool keep_images, hipStream_t st) {
-  if (d.opt_ip_half && iph_eligible(d)) { ALEGO_LAUNCH(ip_fused_h, dim3(d.n_launch), dim3(IPH_T), iph_lds_bytes(d), st, d, ring_pos, keep_images ? 1 : 0); return; }
+  if (d.opt_ip_half && iph_eligible(d)) { ALEGO_LAUNCH(ip_fused_h, dim3(d.n_launch), dim3(IPH_T), iph_lds_bytes(d) + iph_pad(), st, d, ring_pos, keep_images ? 1 : 0); return; }
   if (!ipf_eligible(d)) { ALEGO_LAUNCH(ip_fused_w, dim3(d.n_launch), dim3(IPW_T), iph_lds_bytes(d), st, d, ring_pos, keep_images ? 1 : 0); return; }   // (the caller checked ipw_eligible)
 
   ALEGO_LAUNCH(ip_fused, dim3(d.n_launch), dim3(IPF2_T), ipf_lds_bytes(d), st, d, ring_pos, keep_images ? 1 : 0);
@@ -1012,6 +1017,6 @@ int ipf_configure(const DevCtx& d) {
     if (ipw_eligible(d) && hipFuncSetAttribute(reinterpret_cast<const void*>(ip_fused_w), hipFuncAttributeMaxDynamicSharedMemorySize, (int)iph_lds_bytes(d)) != hipSuccess) return -1;
     return 0;
   }
-  if (iph_eligible(d) && hipFuncSetAttribute(reinterpret_cast<const void*>(ip_fused_h), hipFuncAttributeMaxDynamicSharedMemorySize, (int)iph_lds_bytes(d)) != hipSuccess) return -1;
+  if (iph_eligible(d) && hipFuncSetAttribute(reinterpret_cast<const void*>(ip_fused_h), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(iph_lds_bytes(d) + iph_pad())) != hipSuccess) return -1;
   return hipFuncSetAttribute(reinterpret_cast<const void*>(ip_fused), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ipf_lds_bytes(d)) == hipSuccess ? 0 : -1;
 }
