@@ -389,16 +389,38 @@ __global__ void __launch_bounds__(64) fe_pickc(DevCtx d, int sector_cap) {
 #ifndef FO_KEYED
 #define FO_KEYED 1
 #endif
+#ifndef FO_STAGE
+#define FO_STAGE 0   // 1: the first `cap` points of the ring wait in LDS between the passes (measured: nothing gained over reading them from the L2 again; every access pays for the choice)
+#endif
 struct FoLayout { int cap; int keyed; };
 __host__ __device__ inline FoLayout fo_layout(int H) {
   const int budget = 12 * H + FO_STATIC_LDS > 40960 ? FO_BUDGET_BIG : 40960;
   FoLayout L;
   L.keyed = FO_KEYED && 16 * H + FO_STATIC_LDS <= budget;
   const int by_pct = (H * FO_CAP_PCT / 100 + 15) & ~15, by_lds = (budget - FO_STATIC_LDS - (L.keyed ? 16 : 12) * H) / 16;
-  L.cap = by_lds <= 0 ? 0 : (by_pct < by_lds ? by_pct : (by_lds & ~15));
+  L.cap = !FO_STAGE || by_lds <= 0 ? 0 : (by_pct < by_lds ? by_pct : (by_lds & ~15));
   return L;
 }
 static size_t fo_lds_bytes(int H) { const FoLayout L = fo_layout(H); return std::max((size_t)(L.keyed ? 16 : 12) * H + (size_t)16 * L.cap, (size_t)6 * 65 * 4); }
+
+// reductions over the 64 lanes by DPP (quad, half row, row, then the row results passed on: row_bcast15 / row_bcast31): the result is in lane 63
+#define FO_DPP_F(x, ctrl, rmask) __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), ctrl, rmask, 0xF, false))
+DEV_INLINE float wave_min_f32(float x) {
+  x = fminf(x, FO_DPP_F(x, 0xB1, 0xF)); x = fminf(x, FO_DPP_F(x, 0x4E, 0xF)); x = fminf(x, FO_DPP_F(x, 0x141, 0xF)); x = fminf(x, FO_DPP_F(x, 0x140, 0xF));
+  x = fminf(x, FO_DPP_F(x, 0x142, 0xA)); x = fminf(x, FO_DPP_F(x, 0x143, 0xC));
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63));
+}
+DEV_INLINE float wave_max_f32(float x) {
+  x = fmaxf(x, FO_DPP_F(x, 0xB1, 0xF)); x = fmaxf(x, FO_DPP_F(x, 0x4E, 0xF)); x = fmaxf(x, FO_DPP_F(x, 0x141, 0xF)); x = fmaxf(x, FO_DPP_F(x, 0x140, 0xF));
+  x = fmaxf(x, FO_DPP_F(x, 0x142, 0xA)); x = fmaxf(x, FO_DPP_F(x, 0x143, 0xC));
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63));
+}
+DEV_INLINE int wave_sum_i32(int x) {   // (a disabled row keeps `old` = 0: nothing added)
+  x += __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, false); x += __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, false);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x141, 0xF, 0xF, false); x += __builtin_amdgcn_update_dpp(0, x, 0x140, 0xF, 0xF, false);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false); x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false);
+  return __builtin_amdgcn_readlane(x, 63);
+}
 
 // order-preserving map float -> u32 (for LDS atomic min / max) and back
 DEV_INLINE uint32_t fo_ord(float f) { const uint32_t b = (uint32_t)d_f2i(f); return b ^ ((b >> 31) ? 0xFFFFFFFFu : 0x80000000u); }
@@ -536,9 +558,11 @@ __global__ void __launch_bounds__(FO_BLOCK) fe_ring_out(DevCtx d) {
   uint16_t* s_nxt = reinterpret_cast<uint16_t*>(fv2 + 10 * (size_t)H);          // per point: the next point of its voxel in summation order (FO_END: none) [H]
   uint32_t* k_tmp = reinterpret_cast<uint32_t*>(fv2 + 12 * (size_t)H);          // (keyed) per place of the bucket lists: (voxel id within the bucket) << 12 | run [H]
   __shared__ uint32_t s_bm[FE_MAXH / 32 + 2];     // holes of less_flat_scan: the ring's less-sharp picks (label > 0, :284) and points of skipped sectors (:181)
+  constexpr int FO_MAXBOX = (FE_MAXH + LO_CH - 1) / LO_CH;
+  static_assert(6 * FO_MAXBOX <= 768 && 2 * (FO_NB + 1) <= 768 && FE_MAXH / 32 + 1 <= 768, "s_alias holds the bucket tables, the hole prefix or the box corners");
   __shared__ int s_alias[768];                    // bucket offsets / cursors while the runs are ordered; hole prefix counts of the pass-through; box corners afterwards
   int* s_boff = s_alias; int* s_bcur = s_alias + FO_NB + 1; int* s_wpre = s_alias;
-  uint32_t* s_bx = reinterpret_cast<uint32_t*>(s_alias);                        // [box][6]: min xyz, max xyz as ordered u32
+  uint32_t* s_bx = reinterpret_cast<uint32_t*>(s_alias);                        // [6][FO_MAXBOX]: min xyz, max xyz of every box as ordered u32
   __shared__ float s_red[6][FO_BLOCK / 64];
   __shared__ int s_scan[FO_BLOCK / 64], s_cntv[FO_BLOCK / 64];
   __shared__ int s_look[3];
@@ -572,51 +596,82 @@ __global__ void __launch_bounds__(FO_BLOCK) fe_ring_out(DevCtx d) {
   __syncthreads();
   FO_TICK(1);
   auto hole = [&](int i) -> bool { return (s_bm[i >> 5] >> (i & 31)) & 1u; };
-  auto point = [&](int i) -> float4 { if (i < cap) return s_pt[i]; return seg[S + i]; };
+  const float4* seg_ring = seg + S;   // (uniform base + 32-bit index: no 64-bit address arithmetic per access)
+#if FO_STAGE
+  auto point = [&](int i) -> float4 { if (i < cap) return s_pt[i]; return seg_ring[(unsigned)i]; };
+#else
+  auto point = [&](int i) -> float4 { return seg_ring[(unsigned)i]; };
+#endif
   // ---- pcl::VoxelGrid on the ring's less_flat_scan: runs of consecutive equal voxel ids, ordered through monotone buckets,
   // centroid in original order — fe_voxel's algorithm on positions of the ring instead of an index list; a hole stays inside the run of the
-  // point before it and is skipped when the run is summed
+  // point before it and is left out of the chain the run is summed along.
+  // The bounding box is taken over ALL points of the ring, holes included: which points share a voxel (floor(p / leaf)) and the order of the voxels
+  // (lexicographic in z, y, x) do not depend on it, only whether the linear ids fit — if they do for this box they do for the smaller one of the points
+  // that are left; if not, the exact box decides (bbox_exact: "leaf size too small" returns the input unchanged).
   const float inv = 1.0f / P.less_flat_leaf;
   float mn[3] = {3.402823466e+38f, 3.402823466e+38f, 3.402823466e+38f}, mx[3] = {-3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f};
-  int nval = 0;
-  for (int i0 = tid; i0 < n_all; i0 += FO_BLOCK * FO_U) {
-    float4 pt[FO_U];
+  auto wg_box = [&](int nv) -> int {   // workgroup-wide min / max / sum; ends with every thread holding the results
+    nv = wave_sum_i32(nv);
 #pragma unroll
-    for (int u = 0; u < FO_U; ++u) pt[u] = seg[S + min(i0 + u * FO_BLOCK, n_all - 1)];
+    for (int a = 0; a < 3; ++a) { mn[a] = wave_min_f32(mn[a]); mx[a] = wave_max_f32(mx[a]); }
+    __syncthreads();   // (s_red / s_cntv may still be read from an earlier call)
+    if (lane == 0) {
+      s_cntv[wv] = nv;
 #pragma unroll
-    for (int u = 0; u < FO_U; ++u) {
-      const int i = i0 + u * FO_BLOCK;
-      if (i < min(n_all, cap)) s_pt[i] = pt[u];
-      const bool v = i < n_all && !hole(min(i, n_all - 1));
-      nval += v ? 1 : 0;
-      mn[0] = fminf(mn[0], v ? pt[u].x : 3.402823466e+38f); mn[1] = fminf(mn[1], v ? pt[u].y : 3.402823466e+38f); mn[2] = fminf(mn[2], v ? pt[u].z : 3.402823466e+38f);
-      mx[0] = fmaxf(mx[0], v ? pt[u].x : -3.402823466e+38f); mx[1] = fmaxf(mx[1], v ? pt[u].y : -3.402823466e+38f); mx[2] = fmaxf(mx[2], v ? pt[u].z : -3.402823466e+38f);
+      for (int a = 0; a < 3; ++a) { s_red[a][wv] = mn[a]; s_red[3 + a][wv] = mx[a]; }
     }
-  }
+    __syncthreads();
+    nv = 0;
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) nval += __shfl_xor(nval, o, 64);
-  if (lane == 0) s_cntv[tid >> 6] = nval;
+    for (int w = 0; w < NW; ++w) nv += s_cntv[w];
 #pragma unroll
-  for (int a = 0; a < 3; ++a) {
+    for (int a = 0; a < 3; ++a) {
+      mn[a] = s_red[a][0]; mx[a] = s_red[3 + a][0];
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { mn[a] = fminf(mn[a], __shfl_xor(mn[a], o, 64)); mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], o, 64)); }
-    if (lane == 0) { s_red[a][tid >> 6] = mn[a]; s_red[3 + a][tid >> 6] = mx[a]; }
-  }
-  __syncthreads();
-  nval = 0;
+      for (int w = 1; w < NW; ++w) { mn[a] = fminf(mn[a], s_red[a][w]); mx[a] = fmaxf(mx[a], s_red[3 + a][w]); }
+    }
+    return nv;
+  };
+  auto bbox_exact = [&]() {
 #pragma unroll
-  for (int w = 0; w < FO_BLOCK / 64; ++w) nval += s_cntv[w];
+    for (int a = 0; a < 3; ++a) { mn[a] = 3.402823466e+38f; mx[a] = -3.402823466e+38f; }
+#pragma nounroll
+    for (int i = tid; i < n_all; i += FO_BLOCK) {
+      if (hole(i)) continue;
+      const float4 q = point(i);
+      mn[0] = fminf(mn[0], q.x); mn[1] = fminf(mn[1], q.y); mn[2] = fminf(mn[2], q.z);
+      mx[0] = fmaxf(mx[0], q.x); mx[1] = fmaxf(mx[1], q.y); mx[2] = fmaxf(mx[2], q.z);
+    }
+    (void)wg_box(0);
+  };
+  int nval = 0;
+  {
+    int nh = 0;
+    for (int w = tid; w <= BW; w += FO_BLOCK) nh += __popc(s_bm[w]);   // (bits are set for positions of the ring only)
+    for (int i0 = tid; i0 < n_all; i0 += FO_BLOCK * FO_U) {
+      float4 pt[FO_U];
 #pragma unroll
-  for (int a = 0; a < 3; ++a) {
-    mn[a] = s_red[a][0]; mx[a] = s_red[3 + a][0];
+      for (int u = 0; u < FO_U; ++u) pt[u] = seg_ring[(unsigned)min(i0 + u * FO_BLOCK, n_all - 1)];   // (clamped: a point taken twice changes no minimum)
 #pragma unroll
-    for (int w = 1; w < FO_BLOCK / 64; ++w) { mn[a] = fminf(mn[a], s_red[a][w]); mx[a] = fmaxf(mx[a], s_red[3 + a][w]); }
+      for (int u = 0; u < FO_U; ++u) {
+#if FO_STAGE
+        const int i = i0 + u * FO_BLOCK;
+        if (i < min(n_all, cap)) s_pt[i] = pt[u];
+#endif
+        mn[0] = fminf(mn[0], pt[u].x); mn[1] = fminf(mn[1], pt[u].y); mn[2] = fminf(mn[2], pt[u].z);
+        mx[0] = fmaxf(mx[0], pt[u].x); mx[1] = fmaxf(mx[1], pt[u].y); mx[2] = fmaxf(mx[2], pt[u].z);
+      }
+    }
+    nval = n_all - wg_box(nh);
   }
   FO_TICK(2);
   bool passthrough = false;
   if (nval > 0) {
-    const long long dx = (long long)((mx[0] - mn[0]) * inv) + 1, dy = (long long)((mx[1] - mn[1]) * inv) + 1, dz = (long long)((mx[2] - mn[2]) * inv) + 1;
-    passthrough = dx * dy * dz > 2147483647LL;   // "leaf size too small": the input is returned unchanged
+    auto too_many = [&]() -> bool {
+      const long long dx = (long long)((mx[0] - mn[0]) * inv) + 1, dy = (long long)((mx[1] - mn[1]) * inv) + 1, dz = (long long)((mx[2] - mn[2]) * inv) + 1;
+      return dx * dy * dz > 2147483647LL;
+    };
+    if (too_many()) { bbox_exact(); passthrough = too_many(); }   // "leaf size too small": the input is returned unchanged
   }
   int nout = 0, nrv = 0, nruns = 0, vex = 0;   // vex: voxels before every (chunk, wavefront) of the order, one per lane
   if (passthrough) {
@@ -632,28 +687,33 @@ __global__ void __launch_bounds__(FO_BLOCK) fe_ring_out(DevCtx d) {
     const int mul1 = divb[0], mul2 = divb[0] * divb[1];
     // a hole takes the id of the nearest non-hole before it (none: invalid, a leading run that is never ordered), so that the few
     // labelled points do not cut the runs
-#pragma unroll 4
-    for (int i = tid; i < n_all; i += FO_BLOCK) {
-      int src = i;
-      while (src >= 0 && hole(src)) --src;
-      const float4 q = point(max(src, 0));
-      const int i0 = (int)(floorf(q.x * inv) - (float)minb[0]);
-      const int i1 = (int)(floorf(q.y * inv) - (float)minb[1]);
-      const int i2 = (int)(floorf(q.z * inv) - (float)minb[2]);
-      s_key[i] = src < 0 ? FO_INVALID : (uint32_t)(i0 + i1 * mul1 + i2 * mul2);
-    }
-    __syncthreads();
-    // runs of consecutive equal voxel ids: heads counted per (chunk, wavefront), one barrier, every wavefront scans the counts, heads written
+    // (24-bit multiplies run at full rate, 32-bit ones at a quarter)
+    const bool u24 = (unsigned)divb[0] < (1u << 24) && (unsigned)divb[1] < (1u << 24) && (unsigned)divb[2] < (1u << 24) && (unsigned)mul2 < (1u << 24);
+    // runs of consecutive equal voxel ids: the heads inside a wavefront are counted per (chunk, wavefront) while the keys are written (the key of the
+    // lane before: DPP wave_shr); the first position of a wavefront is compared after the barrier, when every wavefront scans the counts
 #pragma nounroll
     for (int c = 0; c * FO_BLOCK < n_all; ++c) {
       const int i = c * FO_BLOCK + tid;
-      const bool head = i < n_all && (i == 0 || s_key[i] != s_key[i - 1]);
-      const unsigned long long m = __ballot(head);
+      uint32_t key = FO_INVALID;
+      if (i < n_all) {
+        int src = i;
+        while (src >= 0 && hole(src)) --src;
+        const float4 q = point(max(src, 0));
+        const int i0 = (int)(floorf(q.x * inv) - (float)minb[0]);
+        const int i1 = (int)(floorf(q.y * inv) - (float)minb[1]);
+        const int i2 = (int)(floorf(q.z * inv) - (float)minb[2]);
+        const uint32_t id = u24 ? (uint32_t)i0 + __umul24((unsigned)i1, (unsigned)mul1) + __umul24((unsigned)i2, (unsigned)mul2) : (uint32_t)(i0 + i1 * mul1 + i2 * mul2);
+        key = src < 0 ? FO_INVALID : id;
+        s_key[i] = key;
+      }
+      const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp((int)key, (int)key, 0x138, 0xF, 0xF, false);   // wave_shr:1 (lane 0 keeps its own: no head counted here)
+      const unsigned long long m = __ballot(i < n_all && key != prev);
       if (lane == 0) s_rc[c * NW + wv] = (int)__popcll(m);
     }
     __syncthreads();
     {
-      const int ex = scan64(s_rc[lane], &nruns);
+      const int p0 = lane * 64;   // (count `lane` belongs to the 64 positions from p0)
+      const int ex = scan64(s_rc[lane] + ((p0 < n_all && (p0 == 0 || s_key[p0] != s_key[p0 - 1])) ? 1 : 0), &nruns);
 #pragma nounroll
       for (int c = 0; c * FO_BLOCK < n_all; ++c) {
         const int i = c * FO_BLOCK + tid;
@@ -733,13 +793,7 @@ __global__ void __launch_bounds__(FO_BLOCK) fe_ring_out(DevCtx d) {
         if (keyed) {   // one read and one compare per entry of the bucket: (id, run) order = order of the packed keys
           const uint32_t mine = ((v & lowmask) << 12) | (uint32_t)r;
 #pragma nounroll
-          for (int q = bs; q < be; q += 4) {
-            uint32_t u[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) u[k] = k_tmp[min(q + k, be - 1)];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) rank += (u[k] < mine && q + k < be) ? 1 : 0;
-          }
+          for (int q = bs; q < be; ++q) rank += k_tmp[q] < mine ? 1 : 0;
         } else {
 #pragma nounroll
           for (int q = bs; q < be; ++q) { const int o = s_tmp[q]; const uint32_t u = s_rvid[o]; rank += (u < v) || (u == v && o < r); }
@@ -809,16 +863,17 @@ __global__ void __launch_bounds__(FO_BLOCK) fe_ring_out(DevCtx d) {
   float4* out = d.feat[F_LFLAT] + fb * d.fcap[F_LFLAT] + off3;
   // box corners of every LO_CH consecutive output points, gathered with LDS atomics while the points are written
   auto box_add = [&](int rank, const float4& p) {
-    uint32_t* b = s_bx + 6 * (rank / LO_CH);
-    atomicMin(&b[0], fo_ord(p.x)); atomicMin(&b[1], fo_ord(p.y)); atomicMin(&b[2], fo_ord(p.z));
-    atomicMax(&b[3], fo_ord(p.x)); atomicMax(&b[4], fo_ord(p.y)); atomicMax(&b[5], fo_ord(p.z));
+    uint32_t* b = s_bx + rank / LO_CH;
+    const uint32_t ox = fo_ord(p.x), oy = fo_ord(p.y), oz = fo_ord(p.z);
+    atomicMin(&b[0], ox); atomicMin(&b[FO_MAXBOX], oy); atomicMin(&b[2 * FO_MAXBOX], oz);
+    atomicMax(&b[3 * FO_MAXBOX], ox); atomicMax(&b[4 * FO_MAXBOX], oy); atomicMax(&b[5 * FO_MAXBOX], oz);
   };
   if (passthrough) {   // (rare; the hole prefix shares its LDS with the box corners: the boxes are taken from the written points afterwards)
     for (int i = tid; i < n_all; i += FO_BLOCK)
       if (!hole(i)) out[i - (s_wpre[i >> 5] + __popc(s_bm[i >> 5] & ((1u << (i & 31)) - 1u)))] = point(i);
     __syncthreads();
     for (int bi = tid; bi < nbox; bi += FO_BLOCK) {
-      uint32_t* c = s_bx + 6 * bi;
+      uint32_t* c = s_bx + bi;
       float lo3[3] = {3.402823466e+38f, 3.402823466e+38f, 3.402823466e+38f}, hi3[3] = {-3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f};
       for (int t = bi * LO_CH; t < min(nout, bi * LO_CH + LO_CH); ++t) {
         const float4 q = out[t];
@@ -826,10 +881,11 @@ __global__ void __launch_bounds__(FO_BLOCK) fe_ring_out(DevCtx d) {
         hi3[0] = fmaxf(hi3[0], q.x); hi3[1] = fmaxf(hi3[1], q.y); hi3[2] = fmaxf(hi3[2], q.z);
       }
       __builtin_amdgcn_s_waitcnt(0);   // (all of the thread's reads of s_wpre's area are long done: the barrier above)
-      c[0] = fo_ord(lo3[0]); c[1] = fo_ord(lo3[1]); c[2] = fo_ord(lo3[2]); c[3] = fo_ord(hi3[0]); c[4] = fo_ord(hi3[1]); c[5] = fo_ord(hi3[2]);
+      c[0] = fo_ord(lo3[0]); c[FO_MAXBOX] = fo_ord(lo3[1]); c[2 * FO_MAXBOX] = fo_ord(lo3[2]);
+      c[3 * FO_MAXBOX] = fo_ord(hi3[0]); c[4 * FO_MAXBOX] = fo_ord(hi3[1]); c[5 * FO_MAXBOX] = fo_ord(hi3[2]);
     }
   } else {
-    for (int b = tid; b < 6 * nbox; b += FO_BLOCK) s_bx[b] = (b % 6) < 3 ? 0xFFFFFFFFu : 0u;
+    for (int b = tid; b < 6 * FO_MAXBOX; b += FO_BLOCK) s_bx[b] = b < 3 * FO_MAXBOX ? 0xFFFFFFFFu : 0u;
     __syncthreads();
     FO_TICK(13);
     // first run of every voxel -> output rank; it follows the voxel's chain through all its runs, one point per step
@@ -865,9 +921,9 @@ __global__ void __launch_bounds__(FO_BLOCK) fe_ring_out(DevCtx d) {
   {
     float4* bx = d.lo_box + (fb * 2 + 0) * d.lo_box_cap * 2 + (size_t)2 * boff3;
     for (int b = tid; b < nbox; b += FO_BLOCK) {
-      const uint32_t* c = s_bx + 6 * b;
-      bx[2 * b] = make_float4(fo_unord(c[0]), fo_unord(c[1]), fo_unord(c[2]), __int_as_float(off3 + b * LO_CH));
-      bx[2 * b + 1] = make_float4(fo_unord(c[3]), fo_unord(c[4]), fo_unord(c[5]), __int_as_float(min(LO_CH, nout - b * LO_CH)));
+      const uint32_t* c = s_bx + b;
+      bx[2 * b] = make_float4(fo_unord(c[0]), fo_unord(c[FO_MAXBOX]), fo_unord(c[2 * FO_MAXBOX]), __int_as_float(off3 + b * LO_CH));
+      bx[2 * b + 1] = make_float4(fo_unord(c[3 * FO_MAXBOX]), fo_unord(c[4 * FO_MAXBOX]), fo_unord(c[5 * FO_MAXBOX]), __int_as_float(min(LO_CH, nout - b * LO_CH)));
     }
     if (tid == 0) {
       int* ro = d.ring_off + (fb * 2 + 1) * (NS + 1);
