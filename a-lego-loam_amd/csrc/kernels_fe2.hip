@@ -422,6 +422,10 @@ DEV_INLINE int wave_sum_i32(int x) {   // (a disabled row keeps `old` = 0: nothi
   return __builtin_amdgcn_readlane(x, 63);
 }
 
+// a * b + c on the low 24 bits of a and b, at full rate (a 32-bit multiply takes four times as long; written out because the compiler turns __umul24 of
+// values it cannot bound back into mask + 32-bit multiply)
+DEV_INLINE uint32_t mad_u24(uint32_t a, uint32_t b, uint32_t c) { uint32_t r; asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+
 // order-preserving map float -> u32 (for LDS atomic min / max) and back
 DEV_INLINE uint32_t fo_ord(float f) { const uint32_t b = (uint32_t)d_f2i(f); return b ^ ((b >> 31) ? 0xFFFFFFFFu : 0x80000000u); }
 DEV_INLINE float fo_unord(uint32_t u) { return d_i2f((int32_t)(u ^ ((u >> 31) ? 0x80000000u : 0xFFFFFFFFu))); }
@@ -596,6 +600,21 @@ __global__ void __launch_bounds__(FO_BLOCK) fe_ring_out(DevCtx d) {
   __syncthreads();
   FO_TICK(1);
   auto hole = [&](int i) -> bool { return (s_bm[i >> 5] >> (i & 31)) & 1u; };
+  // the nearest position at or before i (after i) that is not a hole, -1 (>= n_all) if there is none: one look at the bitmap word unless every position of
+  // the word on that side is a hole (bits beyond the ring are clear, s_bm has spare words at its end)
+  auto prev_kept = [&](int i) -> int {
+    uint32_t w = ~s_bm[i >> 5] & (0xFFFFFFFFu >> (31 - (i & 31)));
+    int k = i >> 5;
+    while (w == 0u && k > 0) { --k; w = ~s_bm[k]; }
+    return w ? k * 32 + 31 - __clz((int)w) : -1;
+  };
+  auto next_kept = [&](int i) -> int {
+    const int j = i + 1;
+    uint32_t w = ~s_bm[j >> 5] & (0xFFFFFFFFu << (j & 31));
+    int k = j >> 5;
+    while (w == 0u && k <= BW) { ++k; w = ~s_bm[k]; }
+    return w ? k * 32 + __ffs((int)w) - 1 : n_all;
+  };
   const float4* seg_ring = seg + S;   // (uniform base + 32-bit index: no 64-bit address arithmetic per access)
 #if FO_STAGE
   auto point = [&](int i) -> float4 { if (i < cap) return s_pt[i]; return seg_ring[(unsigned)i]; };
@@ -696,13 +715,12 @@ __global__ void __launch_bounds__(FO_BLOCK) fe_ring_out(DevCtx d) {
       const int i = c * FO_BLOCK + tid;
       uint32_t key = FO_INVALID;
       if (i < n_all) {
-        int src = i;
-        while (src >= 0 && hole(src)) --src;
+        const int src = prev_kept(i);
         const float4 q = point(max(src, 0));
         const int i0 = (int)(floorf(q.x * inv) - (float)minb[0]);
         const int i1 = (int)(floorf(q.y * inv) - (float)minb[1]);
         const int i2 = (int)(floorf(q.z * inv) - (float)minb[2]);
-        const uint32_t id = u24 ? (uint32_t)i0 + __umul24((unsigned)i1, (unsigned)mul1) + __umul24((unsigned)i2, (unsigned)mul2) : (uint32_t)(i0 + i1 * mul1 + i2 * mul2);
+        const uint32_t id = u24 ? mad_u24((uint32_t)i2, (uint32_t)mul2, mad_u24((uint32_t)i1, (uint32_t)mul1, (uint32_t)i0)) : (uint32_t)(i0 + i1 * mul1 + i2 * mul2);
         key = src < 0 ? FO_INVALID : id;
         s_key[i] = key;
       }
@@ -728,9 +746,8 @@ __global__ void __launch_bounds__(FO_BLOCK) fe_ring_out(DevCtx d) {
         }
         // the chain a voxel's sum follows: the next point of the run that is not a hole (a hole carries the key of the point before it, so it never ends a run)
         if (i < n_all) {
-          int j = i + 1;
-          while (j < n_all && hole(j)) ++j;
-          s_nxt[i] = (uint16_t)((j < n_all && s_key[j] == mykey) ? j : FO_END);
+          const int j = next_kept(i);
+          s_nxt[i] = (uint16_t)((j < n_all && s_key[min(j, n_all - 1)] == mykey) ? j : FO_END);
         }
       }
     }
