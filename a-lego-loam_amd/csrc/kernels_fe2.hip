@@ -384,7 +384,8 @@ __global__ void __launch_bounds__(64) fe_pickc(DevCtx d, int sector_cap) {
 #ifndef FO_BUDGET_BIG
 #define FO_BUDGET_BIG 53248   // LDS budget of a ring too wide for four workgroups per CU anyway (10 H + static > 40 KB: H = 4000): what three per CU leave, i.e. 600 staged points (80 KB / two per CU: 216 k against 224 k scans/s)
 #endif
-// dynamic LDS of a ring: 12 bytes per column for the run tables, 4 more for the bucket-ordered keys of the run ordering where they fit ("keyed"),
+// dynamic LDS of a ring: 12 bytes per column for the run tables, 2 more where they fit ("keyed": the bucket lists of the run ordering hold 32-bit keys instead of
+// 16-bit run numbers, in the place of the per-point keys, and the sorted order moves behind the tables),
 // the rest of the budget for staged points
 #ifndef FO_KEYED
 #define FO_KEYED 1
@@ -396,12 +397,12 @@ struct FoLayout { int cap; int keyed; };
 __host__ __device__ inline FoLayout fo_layout(int H) {
   const int budget = 12 * H + FO_STATIC_LDS > 40960 ? FO_BUDGET_BIG : 40960;
   FoLayout L;
-  L.keyed = FO_KEYED && 16 * H + FO_STATIC_LDS <= budget;
-  const int by_pct = (H * FO_CAP_PCT / 100 + 15) & ~15, by_lds = (budget - FO_STATIC_LDS - (L.keyed ? 16 : 12) * H) / 16;
+  L.keyed = FO_KEYED && 14 * H + FO_STATIC_LDS <= budget;
+  const int by_pct = (H * FO_CAP_PCT / 100 + 15) & ~15, by_lds = (budget - FO_STATIC_LDS - (L.keyed ? 14 : 12) * H) / 16;
   L.cap = !FO_STAGE || by_lds <= 0 ? 0 : (by_pct < by_lds ? by_pct : (by_lds & ~15));
   return L;
 }
-static size_t fo_lds_bytes(int H) { const FoLayout L = fo_layout(H); return std::max((size_t)(L.keyed ? 16 : 12) * H + (size_t)16 * L.cap, (size_t)6 * 65 * 4); }
+static size_t fo_lds_bytes(int H) { const FoLayout L = fo_layout(H); return std::max((size_t)(L.keyed ? 14 : 12) * H + (size_t)16 * L.cap, (size_t)6 * 65 * 4); }
 
 // reductions over the 64 lanes by DPP (quad, half row, row, then the row results passed on: row_bcast15 / row_bcast31): the result is in lane 63
 #define FO_DPP_F(x, ctrl, rmask) __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), ctrl, rmask, 0xF, false))
@@ -556,11 +557,11 @@ __global__ void __launch_bounds__(FO_BLOCK) fe_ring_out(DevCtx d) {
   unsigned char* fv2 = fo_smem + (size_t)16 * cap;
   uint32_t* s_key = reinterpret_cast<uint32_t*>(fv2);                           // voxel id per point (a hole carries the id of the point before it)   [H]
   uint16_t* s_tmp = reinterpret_cast<uint16_t*>(fv2);                           // (once the runs are found, in the keys' place) valid runs dealt into buckets [H]; then: first point | flags of the run at that place of the order
-  uint16_t* s_order = reinterpret_cast<uint16_t*>(fv2 + 2 * (size_t)H);         // valid runs sorted by (voxel id, run) [H]; then: length - 1 of the run at that place of the order
+  uint32_t* k_tmp = reinterpret_cast<uint32_t*>(fv2);                           // (keyed, in the keys' place as well) per place of the bucket lists: (voxel id within the bucket) << 12 | run [H]
+  uint16_t* s_order = reinterpret_cast<uint16_t*>(fv2 + (lay.keyed ? 12 : 2) * (size_t)H);   // valid runs sorted by (voxel id, run) [H]
   uint32_t* s_rvid = reinterpret_cast<uint32_t*>(fv2 + 4 * (size_t)H);          // voxel id per run [H]
   uint16_t* s_rstart = reinterpret_cast<uint16_t*>(fv2 + 8 * (size_t)H);        // first point of the run  [H]
   uint16_t* s_nxt = reinterpret_cast<uint16_t*>(fv2 + 10 * (size_t)H);          // per point: the next point of its voxel in summation order (FO_END: none) [H]
-  uint32_t* k_tmp = reinterpret_cast<uint32_t*>(fv2 + 12 * (size_t)H);          // (keyed) per place of the bucket lists: (voxel id within the bucket) << 12 | run [H]
   __shared__ uint32_t s_bm[FE_MAXH / 32 + 2];     // holes of less_flat_scan: the ring's less-sharp picks (label > 0, :284) and points of skipped sectors (:181)
   constexpr int FO_MAXBOX = (FE_MAXH + LO_CH - 1) / LO_CH;
   static_assert(6 * FO_MAXBOX <= 768 && 2 * (FO_NB + 1) <= 768 && FE_MAXH / 32 + 1 <= 768, "s_alias holds the bucket tables, the hole prefix or the box corners");
@@ -792,8 +793,8 @@ __global__ void __launch_bounds__(FO_BLOCK) fe_ring_out(DevCtx d) {
         const uint32_t v = s_rvid[r];
         if (v != FO_INVALID) {
           const int pos = atomicAdd(&s_bcur[min((int)(v >> shift), nb - 1)], 1);   // s_bcur[b] starts at s_boff[b] (written one slot up, read one down)
-          s_tmp[pos] = (uint16_t)r;
           if (keyed) k_tmp[pos] = ((v & lowmask) << 12) | (uint32_t)r;
+          else s_tmp[pos] = (uint16_t)r;
         }
       }
       __syncthreads();
@@ -802,13 +803,13 @@ __global__ void __launch_bounds__(FO_BLOCK) fe_ring_out(DevCtx d) {
       if (tid == 0 && blockIdx.y == FO_TICK_RING && blockIdx.x == 0) { int mxb = 0; for (int b = 0; b < nb; ++b) mxb = max(mxb, s_boff[b + 1] - s_boff[b]); fo_times[16] = n_all; fo_times[17] = nruns; fo_times[18] = nrv; fo_times[19] = nb; fo_times[20] = mxb; }
 #endif
       for (int t = tid; t < nrv; t += FO_BLOCK) {
-        const int r = s_tmp[t];
+        const uint32_t mine = keyed ? k_tmp[t] : 0u;
+        const int r = keyed ? (int)(mine & 0xFFFu) : (int)s_tmp[t];
         const uint32_t v = s_rvid[r];
         const int b = min((int)(v >> shift), nb - 1);
         const int bs = s_boff[b], be = s_boff[b + 1];
         int rank = bs;
         if (keyed) {   // one read and one compare per entry of the bucket: (id, run) order = order of the packed keys
-          const uint32_t mine = ((v & lowmask) << 12) | (uint32_t)r;
 #pragma nounroll
           for (int q = bs; q < be; ++q) rank += k_tmp[q] < mine ? 1 : 0;
         } else {
