@@ -528,8 +528,11 @@ struct IphCol { unsigned a, b, x, y; };   // a = ground, b = active, x = right-e
 DEV_INLINE IphCol iph_load(const unsigned long long* fcol, int c) { const unsigned long long v = fcol[c]; IphCol m; m.a = (unsigned)v & 0xFFFFu; m.b = (unsigned)(v >> 16) & 0xFFFFu; m.x = (unsigned)(v >> 32) & 0xFFFFu; m.y = (unsigned)(v >> 48); return m; }
 DEV_INLINE void iph_store(unsigned long long* fcol, int c, const IphCol& m) { fcol[c] = (unsigned long long)m.a | ((unsigned long long)m.b << 16) | ((unsigned long long)m.x << 32) | ((unsigned long long)m.y << 48); }
 
+#ifndef IPH_MINW
+#define IPH_MINW 4   // wavefronts per SIMD the register budget allows (4: 128 VGPRs)
+#endif
 template <int T, int NP>
-__global__ void __launch_bounds__(T, 4) ip_fused_t(DevCtx d, int ring_pos, int keep) {   // 4 wavefronts per SIMD = 128 VGPRs: two workgroups of 512 threads per CU
+__global__ void __launch_bounds__(T, IPH_MINW) ip_fused_t(DevCtx d, int ring_pos, int keep) {   // 4 wavefronts per SIMD = 128 VGPRs: two workgroups of 512 threads per CU
   constexpr int NW = T / 64;
   const int slot = blockIdx.x + d.slot0;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
