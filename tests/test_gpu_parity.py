@@ -339,6 +339,26 @@ def test_fe_dense_candidates_and_tied_curvatures(geom, fe, monkeypatch):
         h.close()
 
 
+@pytest.mark.parametrize("leaf", [0.05, 0.012, 0.002, 3.0e-4])
+@pytest.mark.parametrize("geom", [(16, 1800), (16, 4000)])
+def test_fe_less_flat_leaf_extremes(geom, leaf):
+    """The per-ring VoxelGrid of less_flat_scan at leaf sizes that leave fe_ring_out's usual path: 0.05 / 0.012 m — hundreds of millions of voxel ids in a
+    ring's box, the bucket lists fall back from packed 32-bit keys to run numbers — and 0.002 m / 0.3 mm, where the id range overflows for some or all
+    rings ("leaf size too small": pcl::VoxelGrid returns its input; the decision needs the exact box of the points that are left, not the
+    box of all the ring's points the ids are normally taken from).  less_flat and everything downstream bit-exact against the oracle."""
+    p = synth.default_params(*geom)
+    p.less_flat_leaf = leaf
+    h, o = binding.Handle(p), O.Oracle(p)
+    for k in range(3):
+        pts = synth.scan(p, 40 + k)
+        seg = _ip_compare(h, o, pts, f"{geom} leaf {leaf} scan {k}")
+        h.set_lo_params(o.get("lo_params"))
+        o.lo()
+        flags, feat, odom = h.lo_process(seg)
+        _fe_compare(h, o, feat, f"{geom} leaf {leaf} scan {k}")
+    h.close()
+
+
 def test_create_rejects_out_of_range_pick_parameters(params_a):
     """The pick marks suppress_radius neighbours on either side of a point and the segmented cloud only has the reference's
     5-point margin at the ends of a ring: a larger radius is refused, not clamped."""
