@@ -64,6 +64,11 @@ DEV_INLINE unsigned long long ext128(unsigned long long lo, unsigned long long h
 
 DEV_INLINE void ff_sector(const alego_params& P, int S, int E, int j, int& sp, int& ep) {
   const int NSEC = P.n_sectors;
+  if (NSEC == 6) {   // the reference's six sectors: divisions by a constant (a handful of instructions instead of ~35 each)
+    if (P.sector_formula == 0) { sp = (S * (6 - j) + E * j) / 6; ep = (S * (5 - j) + E * (j + 1)) / 6 - 1; }
+    else { const int diff = E - S; sp = S + j * diff / 6; ep = S + (j + 1) * diff / 6 - 1; }
+    return;
+  }
   if (P.sector_formula == 0) { sp = (S * (NSEC - j) + E * j) / NSEC; ep = (S * (NSEC - 1 - j) + E * (j + 1)) / NSEC - 1; }   // laserOdometry.cpp:177-178
   else { const int diff = E - S; sp = S + j * diff / NSEC; ep = S + (j + 1) * diff / NSEC - 1; }                               // LO.cpp:245-249
 }

@@ -339,11 +339,11 @@ def test_fe_dense_candidates_and_tied_curvatures(geom, fe, monkeypatch):
         h.close()
 
 
-@pytest.mark.parametrize("leaf", [0.05, 0.012, 0.002, 3.0e-4])
+@pytest.mark.parametrize("leaf", [0.05, 0.03, 0.022, 0.012, 3.0e-4])
 @pytest.mark.parametrize("geom", [(16, 1800), (16, 4000)])
 def test_fe_less_flat_leaf_extremes(geom, leaf):
-    """The per-ring VoxelGrid of less_flat_scan at leaf sizes that leave fe_ring_out's usual path: 0.05 / 0.012 m — hundreds of millions of voxel ids in a
-    ring's box, the bucket lists fall back from packed 32-bit keys to run numbers — and 0.002 m / 0.3 mm, where the id range overflows for some or all
+    """The per-ring VoxelGrid of less_flat_scan at leaf sizes that leave fe_ring_out's usual path: 0.05 ... 0.022 m — up to hundreds of millions of voxel ids in a
+    ring's box, the bucket lists fall back from packed 32-bit keys to run numbers — and 0.012 m / 0.3 mm, where the id range overflows for some or all
     rings ("leaf size too small": pcl::VoxelGrid returns its input; the decision needs the exact box of the points that are left, not the
     box of all the ring's points the ids are normally taken from).  less_flat and everything downstream bit-exact against the oracle."""
     p = synth.default_params(*geom)
