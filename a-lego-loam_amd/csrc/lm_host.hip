@@ -86,7 +86,12 @@ LmHost* lm_host_create(const alego_params& P, const DevCtx& d, int n_slots, int 
   {
     const size_t mx = lm_solve_row_bytes_max();
     const char* e = getenv("ALEGO_LM_ROW_LDS");   // development: a smaller budget sends rows through crows (tests: 0 = all of them)
-    L.solve_row_bytes = (int)(e ? std::min(mx, (size_t)std::max(0, atoi(e))) : std::min(mx, lm_solve_row_bytes_default()));
+    // more streams per launch than CUs: 72 KB, so that two lm_solve workgroups (254 VGPRs x 4 wavefronts each) share a CU and the few rows beyond the
+    // budget come from the L2 (measured at 512 per launch: 446 k -> 452 k scans/s for anything between 56 and 76 KB; at 192 / 128 per launch 96 KB is 1 % better)
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+    const size_t dflt = gsize > cus ? (size_t)72 * 1024 : lm_solve_row_bytes_default();
+    L.solve_row_bytes = (int)(e ? std::min(mx, (size_t)std::max(0, atoi(e))) : std::min(mx, dflt));
   }
   const size_t B = n_slots;
   bool ok = true;
