@@ -383,7 +383,8 @@ __global__ void __launch_bounds__(64) fe_pickc(DevCtx d, int sector_cap) {
 #define FO_INVALID 0xFFFFFFFFu
 #define FO_END 0xFFFFu
 #define FO_SPIN_LIMIT (1 << 22)
-#define FO_STATIC_LDS 4000 // static LDS of fe_ring_out (bitmap, the aliased bucket / box area, reduction scratch), rounded up
+#define FO_ALIAS_INTS (6 * ((FE_MAXH + LO_CH - 1) / LO_CH) > 768 ? 6 * ((FE_MAXH + LO_CH - 1) / LO_CH) : 768)   // bucket tables / hole prefix / box corners: 768 with boxes of 32 targets
+#define FO_STATIC_LDS (928 + 4 * FO_ALIAS_INTS) // static LDS of fe_ring_out (bitmap, the aliased bucket / box area, reduction scratch, count table), rounded up: 4000
 // points of the ring staged in LDS (by position in the ring): the rest is read from the L2 on every pass.  The workgroup stays within 40 KB
 // — FOUR rings per CU; one byte more and it is three (fe_voxel's budget)
 #ifndef FO_BUDGET_BIG
@@ -569,8 +570,9 @@ __global__ void __launch_bounds__(FO_BLOCK) fe_ring_out(DevCtx d) {
   uint16_t* s_nxt = reinterpret_cast<uint16_t*>(fv2 + 10 * (size_t)H);          // per point: the next point of its voxel in summation order (FO_END: none) [H]
   __shared__ uint32_t s_bm[FE_MAXH / 32 + 2];     // holes of less_flat_scan: the ring's less-sharp picks (label > 0, :284) and points of skipped sectors (:181)
   constexpr int FO_MAXBOX = (FE_MAXH + LO_CH - 1) / LO_CH;
-  static_assert(6 * FO_MAXBOX <= 768 && 2 * (FO_NB + 1) <= 768 && FE_MAXH / 32 + 1 <= 768, "s_alias holds the bucket tables, the hole prefix or the box corners");
-  __shared__ int s_alias[768];                    // bucket offsets / cursors while the runs are ordered; hole prefix counts of the pass-through; box corners afterwards
+  constexpr int FO_ALIAS = FO_ALIAS_INTS;
+  static_assert(6 * FO_MAXBOX <= FO_ALIAS && 2 * (FO_NB + 1) <= FO_ALIAS && FE_MAXH / 32 + 1 <= FO_ALIAS, "s_alias holds the bucket tables, the hole prefix or the box corners");
+  __shared__ int s_alias[FO_ALIAS];                    // bucket offsets / cursors while the runs are ordered; hole prefix counts of the pass-through; box corners afterwards
   int* s_boff = s_alias; int* s_bcur = s_alias + FO_NB + 1; int* s_wpre = s_alias;
   uint32_t* s_bx = reinterpret_cast<uint32_t*>(s_alias);                        // [6][FO_MAXBOX]: min xyz, max xyz of every box as ordered u32
   __shared__ float s_red[6][FO_BLOCK / 64];
