@@ -275,6 +275,9 @@ DEV_INLINE void d_eig3(const double Ain[9], double lam[3], double vmax[3], doubl
   for (int sweep = 0; sweep < 60; ++sweep) {
     const double off = A[1] * A[1] + A[2] * A[2] + A[5] * A[5];
     if (off < 1e-300) break;
+    // converged to working precision (round 4, oracle and device alike): the off-diagonal mass is below 1e-40 of the diagonal's, a further rotation moves no entry
+    // by more than 1e-20 of the largest.  The absolute test alone ran 8-9 sweeps where 5 suffice — lm_fit was 40 % shorter for it, the bench + 2.8 %.
+    if (off <= 1e-40 * (A[0] * A[0] + A[4] * A[4] + A[8] * A[8])) break;
 #pragma unroll
     for (int p = 0; p < 2; ++p)
 #pragma unroll

@@ -493,6 +493,9 @@ void eig3(const double Ain[9], double lam[3], double V[9]) {
   for (int sweep = 0; sweep < 60; ++sweep) {
     double off = A[1] * A[1] + A[2] * A[2] + A[5] * A[5];
     if (off < 1e-300) break;
+    // converged to working precision: the off-diagonal mass is below 1e-40 of the diagonal's (a further rotation moves no entry by more than 1e-20
+    // of the largest; Eigen's own solver stops on a relative test as well).  The device's d_eig3 has the same test in the same place.
+    if (off <= 1e-40 * (A[0] * A[0] + A[4] * A[4] + A[8] * A[8])) break;
     for (int p = 0; p < 2; ++p)
       for (int q = p + 1; q < 3; ++q) {
         double apq = A[p * 3 + q];
