@@ -198,6 +198,40 @@ def test_kdtree_knn_equals_brute_force():
         assert_bit_equal(dist[i], d[order], f"query {i} distances")
 
 
+def test_eig3_against_numpy_eigh():
+    """The oracle's eig3 (cyclic Jacobi with a relative stopping test, standing in for Eigen::SelfAdjointEigenSolver<Matrix3d>, laserMapping.cpp:394)
+    against numpy.linalg.eigh: scatter matrices of five near-collinear points (what lm_fit feeds it), generic ones, near-degenerate and zero ones.
+    Eigenvalues ascending to 1e-13 of the trace, V orthonormal, A V = V diag(lam), the dominant eigenvector aligned where it is separated."""
+    rng = np.random.default_rng(5)
+    L = O.lib()
+    mats = []
+    for k in range(4000):
+        if k % 4 == 0:      # five points along a line with small noise
+            d = rng.standard_normal(3); d /= np.linalg.norm(d)
+            pts = np.outer(np.linspace(-0.4, 0.4, 5) + rng.normal(0, 0.02, 5), d) + rng.normal(0, 10.0 ** rng.uniform(-6, -1), (5, 3)) + rng.normal(0, 30, 3)
+        elif k % 4 == 1:    # generic
+            pts = rng.standard_normal((5, 3)) * 10.0 ** rng.uniform(-3, 2)
+        elif k % 4 == 2:    # two nearly equal eigenvalues
+            pts = rng.standard_normal((5, 3)) * np.array([1.0, 1.0 + 10.0 ** rng.uniform(-12, -3), 0.1])
+        else:               # rank one / zero
+            pts = np.outer(rng.standard_normal(5), rng.standard_normal(3)) if k % 8 == 3 else np.zeros((5, 3))
+        z = pts - pts.mean(axis=0)
+        mats.append(z.T @ z)
+    for A in mats:
+        A = np.ascontiguousarray(0.5 * (A + A.T))
+        lam, V = np.empty(3), np.empty(9)
+        L.oracle_eig3(A.ctypes.data, lam.ctypes.data, V.ctypes.data)
+        V = V.reshape(3, 3)
+        w, U = np.linalg.eigh(A)
+        tr = max(np.trace(A), 1e-300)
+        assert np.all(np.diff(lam) >= 0)
+        np.testing.assert_allclose(lam, w, rtol=0, atol=1e-13 * tr)
+        np.testing.assert_allclose(V.T @ V, np.eye(3), rtol=0, atol=1e-14)
+        np.testing.assert_allclose(A @ V, V * lam, rtol=0, atol=1e-13 * tr)
+        if w[2] - w[1] > 1e-6 * tr:
+            assert abs(V[:, 2] @ U[:, 2]) > 1 - 1e-12
+
+
 def test_cost_functors_against_finite_differences():
     """Analytic Jacobians agree with central differences except where the reference deliberately does not:
     the LO functors zero most columns and mis-scale dz by 1/k (utility.h:226-231), the LM functors carry the
