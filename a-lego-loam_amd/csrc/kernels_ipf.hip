@@ -481,6 +481,9 @@ __global__ void __launch_bounds__(IPF2_T) ip_fused(DevCtx d, int ring_pos, int k
 #ifndef IPH_GB
 #define IPH_GB 4   // rows gathered per batch in phase B / phase D (loads in flight against registers)
 #endif
+#ifndef IPH_OWN_AHEAD
+#define IPH_OWN_AHEAD 1
+#endif
 #ifndef IPH_GD
 #define IPH_GD 4
 #endif
@@ -942,12 +945,21 @@ __global__ void __launch_bounds__(T, IPH_MINW) ip_fused_t(DevCtx d, int ring_pos
       col_sets(c0, m0, keep0, outl0, fr0); col_sets(c1, m1, keep1, outl1, fr1);
       ground0 = m0.a; ground1 = m1.a; root0 = m0.x; root1 = m1.x;
     }
+#if IPH_OWN_AHEAD
+    unsigned owa[IPF2_ROWS];   // the packed owners of all sixteen rows at once: one round trip in front of the gathers instead of one per group of rows
+#pragma unroll
+    for (int r = 0; r < IPF2_ROWS; ++r) owa[r] = (colv && r < NS) ? own_g[(r * H + c0) >> 1] : 0u;
+#endif
 #pragma unroll
     for (int row0 = 0; row0 < IPF2_ROWS; row0 += IPH_GD) {
       unsigned ow[IPH_GD];
       float4 qa[IPH_GD], qb[IPH_GD];
 #pragma unroll
+#if IPH_OWN_AHEAD
+      for (int u = 0; u < IPH_GD; ++u) ow[u] = owa[row0 + u];
+#else
       for (int u = 0; u < IPH_GD; ++u) ow[u] = (colv && row0 + u < NS) ? own_g[((row0 + u) * H + c0) >> 1] : 0u;
+#endif
 #pragma unroll
       for (int u = 0; u < IPH_GD; ++u) {
         const int row = row0 + u;
