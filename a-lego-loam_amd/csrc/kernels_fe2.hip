@@ -592,6 +592,11 @@ __global__ void __launch_bounds__(FO_BLOCK) fe_ring_out(DevCtx d) {
   };
   if (tid < 64) s_rc[tid] = 0;
   FO_TICK(0);
+  // the ring's first FO_U x FO_BLOCK points are fetched now, in front of the bitmap's own round trip (the pick list), and stay in registers for the
+  // bounding box and for the voxel ids (most rings have no more points than that)
+  float4 keep[FO_U];
+#pragma unroll
+  for (int u = 0; u < FO_U; ++u) keep[u] = (seg + S)[(unsigned)max(min(tid + u * FO_BLOCK, n_all - 1), 0)];
   const int BW = (n_all + 31) / 32;
   for (int w = tid; w <= BW + 1 && w <= FE_MAXH / 32 + 1; w += FO_BLOCK) s_bm[w] = 0u;
   __syncthreads();
@@ -678,7 +683,7 @@ __global__ void __launch_bounds__(FO_BLOCK) fe_ring_out(DevCtx d) {
     for (int i0 = tid; i0 < n_all; i0 += FO_BLOCK * FO_U) {
       float4 pt[FO_U];
 #pragma unroll
-      for (int u = 0; u < FO_U; ++u) pt[u] = seg_ring[(unsigned)min(i0 + u * FO_BLOCK, n_all - 1)];   // (clamped: a point taken twice changes no minimum)
+      for (int u = 0; u < FO_U; ++u) pt[u] = i0 == tid ? keep[u] : seg_ring[(unsigned)min(i0 + u * FO_BLOCK, n_all - 1)];   // (clamped: a point taken twice changes no minimum)
 #pragma unroll
       for (int u = 0; u < FO_U; ++u) {
 #if FO_STAGE
@@ -718,13 +723,13 @@ __global__ void __launch_bounds__(FO_BLOCK) fe_ring_out(DevCtx d) {
     const bool u24 = (unsigned)divb[0] < (1u << 24) && (unsigned)divb[1] < (1u << 24) && (unsigned)divb[2] < (1u << 24) && (unsigned)mul2 < (1u << 24);
     // runs of consecutive equal voxel ids: the heads inside a wavefront are counted per (chunk, wavefront) while the keys are written (the key of the
     // lane before: DPP wave_shr); the first position of a wavefront is compared after the barrier, when every wavefront scans the counts
-#pragma nounroll
-    for (int c = 0; c * FO_BLOCK < n_all; ++c) {
+    auto key_chunk = [&](int c, float4 own) {
       const int i = c * FO_BLOCK + tid;
       uint32_t key = FO_INVALID;
       if (i < n_all) {
         const int src = prev_kept(i);
-        const float4 q = point(max(src, 0));
+        float4 q = own;
+        if (src != i) q = point(max(src, 0));   // (a hole: the point it inherits from)
         const int i0 = (int)(floorf(q.x * inv) - (float)minb[0]);
         const int i1 = (int)(floorf(q.y * inv) - (float)minb[1]);
         const int i2 = (int)(floorf(q.z * inv) - (float)minb[2]);
@@ -735,7 +740,11 @@ __global__ void __launch_bounds__(FO_BLOCK) fe_ring_out(DevCtx d) {
       const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp((int)key, (int)key, 0x138, 0xF, 0xF, false);   // wave_shr:1 (lane 0 keeps its own: no head counted here)
       const unsigned long long m = __ballot(i < n_all && key != prev);
       if (lane == 0) s_rc[c * NW + wv] = (int)__popcll(m);
-    }
+    };
+#pragma unroll
+    for (int c = 0; c < FO_U; ++c) if (c * FO_BLOCK < n_all) key_chunk(c, keep[c]);
+#pragma nounroll
+    for (int c = FO_U; c * FO_BLOCK < n_all; ++c) key_chunk(c, seg_ring[(unsigned)min(c * FO_BLOCK + tid, n_all - 1)]);
     __syncthreads();
     {
       const int p0 = lane * 64;   // (count `lane` belongs to the 64 positions from p0)
