@@ -481,6 +481,9 @@ __global__ void __launch_bounds__(IPF2_T) ip_fused(DevCtx d, int ring_pos, int k
 #ifndef IPH_GB
 #define IPH_GB 4   // rows gathered per batch in phase B / phase D (loads in flight against registers)
 #endif
+#ifndef IPH_PREFETCH
+#define IPH_PREFETCH 1
+#endif
 #ifndef IPH_OWN_AHEAD
 #define IPH_OWN_AHEAD 1
 #endif
@@ -562,11 +565,25 @@ __global__ void __launch_bounds__(T, IPH_MINW) ip_fused_t(DevCtx d, int ring_pos
     float qmr, qmc;
     ip_quick_margins(d, &qmr, &qmc);
     int vmin = 0x7fffffff, vmax = -1, nvalid = 0;
+#if IPH_PREFETCH
+    float4 pnx[4];   // the next iteration's points are in flight while this one's are projected
+#pragma unroll
+    for (int u = 0; u < 4; ++u) pnx[u] = pts[max(min(tid + u * T, n - 1), 0)];
+#endif
 #pragma unroll 1
     for (int i0 = tid; i0 < n; i0 += T * 4) {
       float4 pin[4];
+#if IPH_PREFETCH
+#pragma unroll
+      for (int u = 0; u < 4; ++u) pin[u] = pnx[u];
+      if (i0 + T * 4 < n) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) pnx[u] = pts[min(i0 + T * 4 + u * T, n - 1)];
+      }
+#else
 #pragma unroll
       for (int u = 0; u < 4; ++u) pin[u] = pts[min(i0 + u * T, n - 1)];
+#endif
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int i = i0 + u * T;
