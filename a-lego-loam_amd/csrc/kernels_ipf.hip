@@ -534,6 +534,11 @@ struct IphCol { unsigned a, b, x, y; };   // a = ground, b = active, x = right-e
 DEV_INLINE IphCol iph_load(const unsigned long long* fcol, int c) { const unsigned long long v = fcol[c]; IphCol m; m.a = (unsigned)v & 0xFFFFu; m.b = (unsigned)(v >> 16) & 0xFFFFu; m.x = (unsigned)(v >> 32) & 0xFFFFu; m.y = (unsigned)(v >> 48); return m; }
 DEV_INLINE void iph_store(unsigned long long* fcol, int c, const IphCol& m) { fcol[c] = (unsigned long long)m.a | ((unsigned long long)m.b << 16) | ((unsigned long long)m.x << 32) | ((unsigned long long)m.y << 48); }
 
+#ifdef IPH_STOP_AFTER   // development (instruction counts per phase, profiles/r04_phase_counts.txt): the kernel ends after phase IPH_STOP_AFTER (1 = A ... 3 = C);
+#define IPH_STOP(k) do { if ((k) == IPH_STOP_AFTER) return; } while (0)   // nothing downstream may run (tools/kernel_times.py 512 1 ...: ImageProjection only)
+#else
+#define IPH_STOP(k)
+#endif
 #ifndef IPH_MINW
 #define IPH_MINW 4   // wavefronts per SIMD the register budget allows (4: 128 VGPRs)
 #endif
@@ -640,6 +645,7 @@ __global__ void __launch_bounds__(T, IPH_MINW) ip_fused_t(DevCtx d, int ring_pos
     }
   }
 
+  IPH_STOP(1);
   // ---------------- phase B: ranges, ground, edges — one column pair per thread and pass ----------------
 #pragma unroll 1
   for (int p = 0; p < NP; ++p) {
@@ -772,6 +778,7 @@ __global__ void __launch_bounds__(T, IPH_MINW) ip_fused_t(DevCtx d, int ring_pos
   }
   __syncthreads();   // every read of the owner image has happened: its LDS becomes the parent array
 
+  IPH_STOP(2);
   // ---------------- phase C: connected components over vertical runs (ip_fused's steps, column by column from the masks in LDS) ----------------
   // a cell starts a run when it is active and no down-edge reaches it from below; a run's representative is its first (lowest) cell
   const int ncol = NP * 2;   // columns of a thread: 2 (tid + p T) + k
@@ -886,6 +893,7 @@ __global__ void __launch_bounds__(T, IPH_MINW) ip_fused_t(DevCtx d, int ring_pos
   }
   // (fcol entries are read and written by their own thread only from here on: no barrier)
 
+  IPH_STOP(3);
   // ---------------- phase D: ordered compaction (:158-191) ----------------
   const unsigned all16 = 0xFFFFu;
   const unsigned rowgt = P.ground_scan_id >= 15 ? 0u : (P.ground_scan_id < 0 ? all16 : (all16 & ~((2u << P.ground_scan_id) - 1u)));   // rows > ground_scan_id
