@@ -104,9 +104,10 @@ DEV_INLINE void ff_wide(const DevCtx& d, size_t base, int M, int sp, int ep, uns
   for (int q = q0 + lane; q < q1; q += 64) {
     const int k = sp + q - FF_Q0;
     const bool in = k >= 0 && k < M;
-    const float r = rng[in ? k : 0];
-    const int c = colv[in ? k : 0];
-    const uint8_t g = gndv[in ? k : 0];
+    const unsigned ku = in ? (unsigned)k : 0u;   // (uniform base + unsigned 32-bit index: no 64-bit address arithmetic per lane)
+    const float r = rng[ku];
+    const int c = colv[ku];
+    const uint8_t g = gndv[ku];
     sr[q] = in ? r : 0.f;
     scl[q] = in ? (uint16_t)((c & 0x7fff) | (g ? 0x8000 : 0)) : (uint16_t)0;
   }
@@ -165,8 +166,8 @@ DEV_INLINE void ff_wide(const DevCtx& d, size_t base, int M, int sp, int ep, uns
     const uint32_t kb = (uint32_t)d_f2i(fabsf(cdv));
     const uint32_t pay = ((uint32_t)loc << 6) | ((uint32_t)rf << 3) | (uint32_t)rb;
     const unsigned long long ms = __ballot(cs), mf = __ballot(cf), below = (1ull << lane) - 1ull;
-    if (cs) list[ns + (int)__popcll(ms & below)] = make_uint2(kb + 1u, pay);
-    if (cf) list[sector_cap - 1 - (nf + (int)__popcll(mf & below))] = make_uint2(~kb, ~pay);
+    if (cs) list[(unsigned)(ns + (int)__popcll(ms & below))] = make_uint2(kb + 1u, pay);
+    if (cf) list[(unsigned)(sector_cap - 1 - (nf + (int)__popcll(mf & below)))] = make_uint2(~kb, ~pay);
     ns += (int)__popcll(ms); nf += (int)__popcll(mf);
     if (dbg && own) { d.cd[base + k] = cdv; d.picked0[base + k] = pk ? 1 : 0; }
   }
@@ -175,7 +176,9 @@ DEV_INLINE void ff_wide(const DevCtx& d, size_t base, int M, int sp, int ep, uns
 
 // one wavefront per (ring, sector) — every sector of every ring of every stream at once, nothing sequential
 __global__ void __launch_bounds__(64 * FC_NW) fe_cand(DevCtx d, int sector_cap) {
-  const int slot = blockIdx.y + d.slot0, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // (the wavefront's number through readfirstlane: ring, sector, their bounds and every pointer derived from them are then scalar — the compiler cannot
+  // know that threadIdx.x >> 6 is uniform, and computed all of it per lane with 64-bit vector arithmetic)
+  const int slot = blockIdx.y + d.slot0, lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int NS = d.NS, NSEC = d.P.n_sectors;
   const int item = blockIdx.x * FC_NW + wave, ring = item / NSEC, j = item - ring * NSEC;
   const size_t base = (size_t)slot * d.N;
