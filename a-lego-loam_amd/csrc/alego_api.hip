@@ -262,6 +262,8 @@ int alego_create(const alego_params* params, int device, int n_slots, int ring_l
   d.opt_fe_cand = env_int("ALEGO_FE_CAND", 0);
   d.opt_lo_box_lds = env_int("ALEGO_LO_BOX_LDS", 1 << 20);
   d.opt_lo_grid = env_int("ALEGO_LO_GRID", 1) != 0;
+  d.opt_fo_spin = env_int("ALEGO_FE_SPIN", 0);
+  d.opt_fo_pad8 = env_int("ALEGO_FE_PAD8", 0) != 0;
   d.opt_map_merge = env_int("ALEGO_MAP_MERGE", 1) != 0;
   const size_t B = n_slots, N = d.N, NS = d.NS;
   int rc = 0;
@@ -942,6 +944,8 @@ int alego_debug_set_option(alego_handle* h, const char* name, int value) {
   else if (s == "ALEGO_FE_CAND") d.opt_fe_cand = value;
   else if (s == "ALEGO_LO_BOX_LDS") d.opt_lo_box_lds = value;
   else if (s == "ALEGO_LO_GRID") d.opt_lo_grid = value != 0;
+  else if (s == "ALEGO_FE_SPIN") d.opt_fo_spin = value;
+  else if (s == "ALEGO_FE_PAD8") d.opt_fo_pad8 = value != 0;
   else if (s == "ALEGO_MAP_MERGE") { if (int r = lm_host_set_map_merge(h->lm, value != 0, &h->err)) return r; d.opt_map_merge = value != 0; }
   else if (s == "ALEGO_IP_FAST") d.ip_fast = h->ip_fast_capable & value;
   else if (s == "ALEGO_POKE_GUARD") { HIP_TRY(h, hipMemset(d.scal + (size_t)d.n_slots * SC_COUNT + value, 0xFF, 4)); }   // tests of the guard pages: a write `value` ints past the end of an array

@@ -31,7 +31,10 @@ enum {
   SC_LM_FLAGS,
   SC_PVALID_OUT,  // valid input points of the last projected scan (SC_PVALID is an accumulator, cleared by ip_front)
   SC_FE_EPOCH,    // feature-extraction launches of this slot so far (fe_front increments it; tags the ring counts fe_ring_out's workgroups publish to each other)
-  SC_FE_ERR,      // != 0: a workgroup of fe_ring_out gave up waiting for the counts of the rings below it (never expected; surfaces as ALEGO_ERR_HIP)
+  SC_FE_ERR,      // != 0 (sticky until the slot is reset): a workgroup of fe_ring_out gave up waiting for the counts of the rings below it; the slot's less_flat
+                  // cloud is then treated as EMPTY by everything that reads it (lo_grid_build, lo_assoc, lm_stage) and the host gets ALEGO_ERR_HIP (fetch_pose)
+  SC_FE_TICKET,   // fe_ring_out: rings of this launch handed out so far (a workgroup's ring = its ticket, so the rings it waits for belong to workgroups that
+                  // are already running whatever order the dispatchers place them in; fe_pickc resets it)
   SC_COUNT = 32
 };
 
@@ -130,6 +133,8 @@ struct DevCtx {
   unsigned short* lo_cell;   // [slot][2 buffers][2 kinds][LO_GC + 2]: first sorted point of every cell (exclusive prefix, row-major in x)
   float* lo_geom;       // [slot][2 buffers][2 kinds][8]: origin x, y, 1 / cell size, settle threshold (0.999 cell^2), gx, gy (int bits; gx = 0: no grid), -, -
   int opt_lo_grid;      // ALEGO_LO_GRID    1: lo_assoc takes the 1-NN from the grid where that is exact; 0: boxes only
+  int opt_fo_spin;      // ALEGO_FE_SPIN    development: polls a ring of fe_ring_out waits for a lower ring's count (0: FO_SPIN_LIMIT; the tests set 1 to drive the give-up path)
+  int opt_fo_pad8;      // ALEGO_FE_PAD8    development: 1 pads fe_ring_out's grid to a multiple of 8 streams (a stream's rings on one XCD, round 4's work-around; 0 = default since the ring tickets)
   int lo_box_cap;       //   corners = first target / number of targets (int bits); kind 0: less_flat, 1: less_sharp; written by feature extraction
   double* lo_state;     // [slot][LO_STATE_N]
   // ---- motion de-skew (adjustDistortion, laserOdometry.cpp:557-726; alego_params.deskew_mode) ----

@@ -14,8 +14,8 @@
 //                from the segmented cloud — the points of a ring are contiguous, the few labelled ones are holes in a bitmap — then the
 //                ring writes its part of all four feature clouds, its index lists, ring offsets and bounding boxes in place.  The less_flat
 //                offset of a ring needs the voxel counts of the rings below it: every workgroup publishes its count as soon as it is known
-//                (one agent-scope store) and reads the counts below it (workgroups of lower rings are dispatched earlier: slot-fastest
-//                grid).  No staging copy of the filtered rings, no collecting pass.
+//                (one agent-scope store) and reads the counts below it (a workgroup's ring is its per-stream ticket: the lower rings are
+//                always running already).  No staging copy of the filtered rings, no collecting pass.
 #include <algorithm>
 #include <cstdlib>
 #include "dev_common.h"
@@ -337,7 +337,7 @@ __global__ void __launch_bounds__(64) fe_pickc(DevCtx d, int sector_cap) {
   int* sc = d.scal + slot * SC_COUNT;
   __shared__ uint32_t s_mark[FF_G][FF_MW_MAX];
   const int mw = min((sector_cap + FF_HALO + 31) / 32 + 1, FF_MW_MAX);
-  if (blockIdx.x == 0 && lane == 0) sc[SC_FE_EPOCH] = sc[SC_FE_EPOCH] + 1;   // (fe_ring_out of this launch tags its ring counts with it)
+  if (blockIdx.x == 0 && lane == 0) { sc[SC_FE_EPOCH] = sc[SC_FE_EPOCH] + 1; sc[SC_FE_TICKET] = 0; }   // (fe_ring_out of this launch tags its ring counts with the epoch and hands out its rings by ticket)
   const int ring = ring0 + g;
   const bool rv = ring < NS;
   const int rc = rv ? ring : 0;
@@ -544,14 +544,22 @@ DEV_INLINE void fo_picks_out(const DevCtx& d, int slot, unsigned char* smem) {
 
 // grid (streams, NS + 1): row r < NS = ring r of the stream, row NS = fo_picks_out
 __global__ void __launch_bounds__(FO_BLOCK) fe_ring_out(DevCtx d) {
-  const int slot = blockIdx.x + d.slot0, ring = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+  const int slot = blockIdx.x + d.slot0, tid = threadIdx.x, lane = tid & 63;
   const int NS = d.NS, H = d.H;
   extern __shared__ __attribute__((aligned(16))) unsigned char fo_smem[];
-  if ((int)blockIdx.x >= d.n_launch) return;   // (the grid's x extent is padded to a multiple of 8, see launch_fe_fused)
-  if (ring == NS) { fo_picks_out(d, slot, fo_smem); return; }
+  if ((int)blockIdx.x >= d.n_launch) return;   // (ALEGO_FE_PAD8=1 pads the grid's x extent to a multiple of 8, see launch_fe_fused)
+  if ((int)blockIdx.y == NS) { fo_picks_out(d, slot, fo_smem); return; }
+  int* scv = d.scal + slot * SC_COUNT;
+  // Which ring this workgroup takes is decided by a per-stream TICKET, not by blockIdx.y: a ring waits for the voxel counts of the rings below it, and with
+  // tickets those rings belong to workgroups that took theirs earlier — they are running, and they in turn wait only for still earlier ones.  No assumption
+  // about the order in which the (per-XCD) dispatchers place the workgroups of a launch is left (round 4 relied on "lower blockIdx.y first on the stream's
+  // XCD", which three or six stream groups broke: DESIGN.md section 7).  fe_pickc of the same scan reset the counter.
+  __shared__ int s_ticket;
+  if (tid == 0) s_ticket = atomicAdd(&scv[SC_FE_TICKET], 1);
+  __syncthreads();
+  const int ring = min(s_ticket, NS - 1);   // (the clamp only matters if somebody launches the kernel without fe_pickc in front of it)
   const size_t base = (size_t)slot * d.N;
   const alego_params& P = d.P;
-  int* scv = d.scal + slot * SC_COUNT;
   const int cur = cur_in_flight(d, slot);
   const size_t fb = (size_t)slot * 2 + cur;
   const unsigned epoch = (unsigned)scv[SC_FE_EPOCH] & 0xFFFFu;
@@ -876,13 +884,14 @@ __global__ void __launch_bounds__(FO_BLOCK) fe_ring_out(DevCtx d) {
     if (tid < ring) {
       unsigned v = 0;
       int spins = 0;
+      const int limit = d.opt_fo_spin > 0 ? d.opt_fo_spin : FO_SPIN_LIMIT;
       while (true) {
         v = __hip_atomic_load(&d.fe_sync[(size_t)slot * NS + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if ((v >> 16) == epoch || ++spins > FO_SPIN_LIMIT) break;
+        if ((v >> 16) == epoch || ++spins > limit) break;
         __builtin_amdgcn_s_sleep(2);
       }
       bad = (v >> 16) != epoch;
-      c = (int)(v & 0xFFFFu);
+      c = bad ? 0 : (int)(v & 0xFFFFu);   // (a count that never came counts as 0: every offset below only shrinks, so whatever this ring still writes stays inside the slot's arrays)
       nbx = (c + LO_CH - 1) / LO_CH;
     }
 #pragma unroll
@@ -892,10 +901,10 @@ __global__ void __launch_bounds__(FO_BLOCK) fe_ring_out(DevCtx d) {
   const int nbox = (nout + LO_CH - 1) / LO_CH;
   __syncthreads();   // (also: the bucket tables / the hole prefix of the pass-through are dead or read-only from here on... see below)
   const int off3 = s_look[0], boff3 = s_look[1];
-  if (s_look[2]) {   // never expected (a lower ring's workgroup is dispatched before this one): nothing is written, the error surfaces on the host
-    if (tid == 0) scv[SC_FE_ERR] = 1;
-    return;
-  }
+  // Gave up on a lower ring (never expected: its workgroup holds an earlier ticket and is running — the limit is seconds).  The flag is sticky and
+  // makes every reader of the slot's less_flat cloud treat it as empty (lo_grid_build, lo_assoc, lm_stage) until the host, which gets ALEGO_ERR_HIP from
+  // fetch_pose, resets the slot; this ring still writes its (meaningless, in-bounds) part so that the tables of the scan are all written.
+  if (s_look[2] && tid == 0) scv[SC_FE_ERR] = 1;
   FO_TICK(6);
   float4* out = d.feat[F_LFLAT] + fb * d.fcap[F_LFLAT] + off3;
   // box corners of every LO_CH consecutive output points, gathered with LDS atomics while the points are written
@@ -976,7 +985,15 @@ __global__ void __launch_bounds__(FO_BLOCK) fe_ring_out(DevCtx d) {
 void launch_fe_curv_debug(const DevCtx& d, hipStream_t st);   // kernels_fe.hip: fe_curv alone (curvature sums / occlusion marks of the points outside every sector, tests only)
 
 // fused path: everything but alego_params.sort_mode = 2 (the libstdc++ tie order needs the whole sector's keys: four-kernel path)
-bool fe_fused_eligible(const DevCtx& d) { return d.opt_fe_fused && !d.opt_fe_pick1 && d.P.sort_mode != 2 && d.NS <= 64 && d.H <= FE_MAXH; }
+// (and only sector counts whose candidate lists fit where they are kept: n_sectors * sector_cap 8-byte entries in a ring's 16 H-byte staging row (ff_list),
+// 2 n_sectors counts in the H-int tail of its index row (ff_counts), one thread per sector for the one-point sectors (fe_ring_out) — anything else, e.g.
+// n_sectors > H / 3, takes the four-kernel path)
+bool fe_fused_eligible(const DevCtx& d) {
+  const int nsec = d.P.n_sectors;
+  if (!(d.opt_fe_fused && !d.opt_fe_pick1 && d.P.sort_mode != 2 && d.NS <= 64 && d.H <= FE_MAXH && nsec >= 1)) return false;
+  const long long sector_cap = (d.H + nsec - 1) / nsec + 2;
+  return nsec <= FO_BLOCK && (long long)nsec * sector_cap <= 2LL * d.H && 2LL * nsec <= d.H;
+}
 
 void launch_fe_fused(const DevCtx& d, hipStream_t st) {
   static const bool cfg = hipFuncSetAttribute(reinterpret_cast<const void*>(fe_ring_out), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fo_lds_bytes(FE_MAXH)) == hipSuccess;
@@ -990,8 +1007,8 @@ void launch_fe_fused(const DevCtx& d, hipStream_t st) {
   const dim3 gp((d.NS + FF_G - 1) / FF_G, d.n_launch);
   if (sector_cap > 400) { ALEGO_LAUNCH(fe_pickc<true>, gp, dim3(64), 0, st, d, sector_cap); }
   else { ALEGO_LAUNCH(fe_pickc<false>, gp, dim3(64), 0, st, d, sector_cap); }
-  // x padded to a multiple of 8: workgroup b runs on XCD b mod 8, so every ring of a stream lands on the stream's XCD and the workgroups of its lower
-  // rings are dispatched before it by the same dispatcher — what the ring-count look-back relies on.  (With 683 streams per launch — three stream groups — the
-  // rings of a stream sat on different XCDs and the bench workload died with a memory access fault after a few hundred scans; 512 and 256 per launch never did.)
-  ALEGO_LAUNCH(fe_ring_out, dim3((d.n_launch + 7) / 8 * 8, d.NS + 1), dim3(FO_BLOCK), fo_lds_bytes(d.H), st, d);
+  // Rings are handed out by ticket (fe_ring_out), so the look-back between the rings of a stream does not depend on where the dispatchers put the workgroups.
+  // Round 4 padded x to a multiple of 8 instead (workgroup b runs on XCD b mod 8: a stream's rings then share an XCD and its dispatcher's order) after 683
+  // streams per launch — three stream groups — had died with a memory access fault; ALEGO_FE_PAD8=1 still does that (a development switch, not needed).
+  ALEGO_LAUNCH(fe_ring_out, dim3(d.opt_fo_pad8 ? (d.n_launch + 7) / 8 * 8 : d.n_launch, d.NS + 1), dim3(FO_BLOCK), fo_lds_bytes(d.H), st, d);
 }

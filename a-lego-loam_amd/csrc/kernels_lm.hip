@@ -65,7 +65,7 @@ __global__ void __launch_bounds__(LM_BLOCK) lm_prepare(DevCtx d, LmCtx L, int st
     // (written with unconditional loads + selects: a 3-way if/else chain here was lowered by hipcc 7.2 into
     //  a scalar switch that left the count pointer of the last arm undefined)
     const size_t fb = d.fs_cur >= 0 ? (size_t)d.fs_cur * 2 : (size_t)slot * 2 + cur;
-    const int n_c = d.feat_cnt[fb * 4 + F_LSHARP], n_s = d.feat_cnt[fb * 4 + F_LFLAT], n_o = d.scal[sslot * SC_COUNT + SC_NOUT];
+    const int n_c = d.feat_cnt[fb * 4 + F_LSHARP], n_s = d.scal[sslot * SC_COUNT + SC_FE_ERR] ? 0 : d.feat_cnt[fb * 4 + F_LFLAT], n_o = d.scal[sslot * SC_COUNT + SC_NOUT];   // (SC_FE_ERR: dev_common.h)
     const float4* src_c = d.feat[F_LSHARP] + fb * d.fcap[F_LSHARP];
     const float4* src_s = d.feat[F_LFLAT] + fb * d.fcap[F_LFLAT];
     const float4* src_o = d.outlier + (size_t)sslot * d.N;
@@ -113,7 +113,7 @@ __global__ void __launch_bounds__(LM_BLOCK) lm_stage(DevCtx d, LmCtx L, int run_
   int* li = lip(L, slot);
   if (run_hint != 0) {
     const size_t fb = (size_t)slot * 2 + cur;
-    const int n_c = d.feat_cnt[fb * 4 + F_LSHARP], n_s = d.feat_cnt[fb * 4 + F_LFLAT], n_o = d.scal[slot * SC_COUNT + SC_NOUT];
+    const int n_c = d.feat_cnt[fb * 4 + F_LSHARP], n_s = d.scal[slot * SC_COUNT + SC_FE_ERR] ? 0 : d.feat_cnt[fb * 4 + F_LFLAT], n_o = d.scal[slot * SC_COUNT + SC_NOUT];
     const float4* src_c = d.feat[F_LSHARP] + fb * d.fcap[F_LSHARP];
     const float4* src_s = d.feat[F_LFLAT] + fb * d.fcap[F_LFLAT];
     const float4* src_o = d.outlier + (size_t)slot * d.N;

@@ -120,7 +120,7 @@ __global__ void __launch_bounds__(LG_T) lo_grid_build(DevCtx d) {
   const int slot = blockIdx.x + d.slot0, kind = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const size_t fb = (size_t)slot * 2 + cur_in_flight(d, slot);
   const int tk = kind == 0 ? F_LFLAT : F_LSHARP;
-  const int n = d.feat_cnt[fb * 4 + tk];
+  const int n = (kind == 0 && d.scal[slot * SC_COUNT + SC_FE_ERR]) ? 0 : d.feat_cnt[fb * 4 + tk];   // (a slot whose fe_ring_out gave up has no less_flat cloud: dev_common.h)
   const float4* pts = d.feat[tk] + fb * d.fcap[tk];
   float4* cp = d.lo_cpts[kind] + fb * d.fcap[tk];
   unsigned short* cell = d.lo_cell + (fb * 2 + kind) * (LO_GC + 2);
@@ -198,6 +198,7 @@ __global__ void __launch_bounds__(LG_T) lo_grid_build(DevCtx d) {
     if (c0 <= ncell) cell[c0] = (unsigned short)a;
     if (c0 + 1 <= ncell) cell[c0 + 1] = (unsigned short)b;
   }
+  if (tid == LG_T - 1 && ncell == LO_GC) cell[ncell] = (unsigned short)n;   // (a full grid: the end of the last cell is beyond the words the scan owns)
   __syncthreads();
   auto place = [&](int i, const float4& p) {
     const int c = cell_of(p);
@@ -212,8 +213,15 @@ __global__ void __launch_bounds__(LG_T) lo_grid_build(DevCtx d) {
     geom[4] = __int_as_float(gx); geom[5] = __int_as_float(gy);
   }
 }
+// (ALEGO_LO_GRID toggled off: the buffer's clouds have just been rewritten, so the grid a later scan could find there — if the switch goes back on — is marked absent)
+__global__ void lo_grid_off(DevCtx d) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= d.n_launch * 2) return;
+  const int slot = i / 2 + d.slot0, kind = i & 1;
+  d.lo_geom[(((size_t)slot * 2 + cur_in_flight(d, slot)) * 2 + kind) * 8 + 4] = __int_as_float(0);
+}
 void launch_lo_grid(const DevCtx& d, hipStream_t st) {
-  if (!d.opt_lo_grid) return;
+  if (!d.opt_lo_grid) { ALEGO_LAUNCH(lo_grid_off, dim3((d.n_launch * 2 + 63) / 64), dim3(64), 0, st, d); return; }
   ALEGO_LAUNCH(lo_grid_build, dim3(d.n_launch, 2), dim3(LG_T), 0, st, d);
 }
 
@@ -232,7 +240,7 @@ DEV_INLINE void lo_assoc_body(const DevCtx& d, int box_lds_max, int slot, int qb
   const int qk = kind == 0 ? F_FLAT : F_SHARP, tk = kind == 0 ? F_LFLAT : F_LSHARP;
   const int nq = d.feat_cnt[fc * 4 + qk];
   if (qb0 * LO_QPB >= nq) return;
-  const int nt = d.feat_cnt[fl * 4 + tk];
+  const int nt = (kind == 0 && sc[SC_FE_ERR]) ? 0 : d.feat_cnt[fl * 4 + tk];   // (fe_ring_out gave up on this slot: no less_flat targets, dev_common.h)
   const float4* tg = d.feat[tk] + fl * d.fcap[tk];
   const float4* bx = d.lo_box + (fl * 2 + kind) * d.lo_box_cap * 2;
   const int* roff = d.ring_off + (fl * 2 + (kind == 0 ? 1 : 0)) * (d.NS + 1);
