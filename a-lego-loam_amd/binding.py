@@ -22,7 +22,7 @@ EXPORTS = [
     "alego_ip_process", "alego_lo_process", "alego_lm_process", "alego_scan_process",
     "alego_batch_load", "alego_batch_run", "alego_synchronize", "alego_batch_get_pose", "alego_batch_get_counts",
     "alego_stream", "alego_stream_groups", "alego_profile_enable", "alego_profile_report", "alego_set_lo_params", "alego_set_lm_params", "alego_debug_get", "alego_debug_voxel", "alego_debug_atan2f",
-    "alego_lo_push_imu", "alego_trajectory_enable", "alego_trajectory_get", "alego_debug_check_guards", "alego_debug_math", "alego_debug_std_sort", "alego_debug_eval_blocks", "alego_debug_transform_to_start", "alego_debug_set_option",
+    "alego_lo_push_imu", "alego_lo_get_undistorted", "alego_pose_o2b", "alego_trajectory_enable", "alego_trajectory_get", "alego_debug_check_guards", "alego_debug_math", "alego_debug_std_sort", "alego_debug_eval_blocks", "alego_debug_transform_to_start", "alego_debug_set_option",
     "alego_lm_keyframe_count", "alego_lm_get_keyframe", "alego_lm_set_keypose", "alego_lm_reset_window", "alego_lm_apply_correction",
     "alego_lm_add_keyframe", "alego_pc2_to_points", "alego_replay_create", "alego_replay_load", "alego_replay_assign",
     "alego_dist_unique_id", "alego_dist_init", "alego_dist_shutdown", "alego_dist_allreduce_probe", "alego_stream_setup", "alego_stream_run",
@@ -61,6 +61,17 @@ class Pose(C.Structure):
 
     def as_dict(self):
         return dict(t=np.array(self.t[:]), q=np.array(self.q[:]), params=np.array(self.params[:]), valid=int(self.valid))
+
+
+def pose_o2b(t, q, tf_b2l):
+    """alego_pose_o2b: (t, q = w x y z) of /odom -> /laser and the 4 x 4 base_link -> laser mount -> (t, q) of /odom -> /base_link (LO.cpp:588-608)"""
+    a, b = Pose(), Pose()
+    a.t[:] = list(t); a.q[:] = list(q)
+    m = np.ascontiguousarray(tf_b2l, np.float64).reshape(16)
+    rc = lib().alego_pose_o2b(C.byref(a), m.ctypes.data, C.byref(b))
+    if rc != 0:
+        raise AlegoError(f"alego_pose_o2b failed ({rc})")
+    return np.array(b.t[:]), np.array(b.q[:])
 
 
 class KeyFrame(C.Structure):
@@ -151,6 +162,10 @@ def lib():
         L.alego_trajectory_get.argtypes = [C.c_void_p, C.c_int, C.c_int32, C.c_int32, C.c_void_p]
         L.alego_lo_push_imu.restype = C.c_int
         L.alego_lo_push_imu.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int32]
+        L.alego_lo_get_undistorted.restype = C.c_int
+        L.alego_lo_get_undistorted.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int32]
+        L.alego_pose_o2b.restype = C.c_int
+        L.alego_pose_o2b.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.alego_debug_check_guards.restype = C.c_int
         L.alego_debug_check_guards.argtypes = [C.c_char_p, C.c_int]
         L.alego_debug_std_sort.restype = C.c_int
@@ -561,6 +576,12 @@ class Handle:
         out = np.empty((max(n, 0), 14), np.float64)
         self._check(lib().alego_trajectory_get(self._h, slot, first, max(n, 0), out.ctypes.data), "alego_trajectory_get")
         return out
+
+    def undistorted(self, slot=0):
+        """/undistorted: the de-skewed segmented cloud of the slot's last scan (deskew_mode = 1), [M, 4] f32"""
+        out = np.zeros((self.N, 4), np.float32)
+        n = self._check(lib().alego_lo_get_undistorted(self._h, slot, out.ctypes.data, out.shape[0]), "alego_lo_get_undistorted")
+        return out[:n].copy()
 
     def push_imu(self, samples, slot=0):
         """samples[n, 11]: stamp, orientation w x y z, linear_acceleration xyz, angular_velocity xyz (sensor_msgs/Imu)"""

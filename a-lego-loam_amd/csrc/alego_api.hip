@@ -746,6 +746,63 @@ int alego_set_lm_params(alego_handle* h, int slot, const double* p6) {
   return lm_host_set_params(h->lm, slot, p6, &h->err);
 }
 
+// /undistorted (laserOdometry.cpp:56,718-725): the de-skewed segmented cloud of the slot's last scan
+int alego_lo_get_undistorted(alego_handle* h, int slot, alego_point* out, int32_t cap) {
+  if (int r = check_slot(h, slot)) return r;
+  if (!h->P.deskew_mode) { h->err = "alego_lo_get_undistorted: deskew_mode is 0 (adjustDistortion is not run: laserOdometry.cpp:115)"; return ALEGO_ERR_ARG; }
+  if (cap < 0 || (cap > 0 && !out)) return ALEGO_ERR_ARG;
+  hipSetDevice(h->device);
+  int M = 0;
+  HIP_TRY(h, hipMemcpyAsync(&M, h->d.scal + (size_t)slot * SC_COUNT + SC_M, 4, hipMemcpyDeviceToHost, stream_of(h, slot)));
+  HIP_TRY(h, hipStreamSynchronize(stream_of(h, slot)));
+  if (M > cap) return ALEGO_ERR_CAPACITY;
+  if (M > 0) HIP_TRY(h, hipMemcpy(out, h->d.seg_dsk + (size_t)slot * h->d.N, (size_t)M * sizeof(alego_point), hipMemcpyDeviceToHost));
+  return M;
+}
+
+// The standalone LaserOdometry node publishes /odom/lidar as /odom -> /base_link: tf_o2b = tf_o2l * tf_b2l^-1, quaternion from its rotation block
+// (LO.cpp:588-608; the nodelet publishes /odom -> /laser as it is, laserOdometry.cpp:513-529).  Host arithmetic only (a publishing convention, not part
+// of the hot path): general 4 x 4 inverse by Gauss-Jordan with partial pivoting, Eigen's Quaterniond(Matrix3d) (largest-diagonal branch selection).
+int alego_pose_o2b(const alego_pose* o2l, const double* tf_b2l, alego_pose* o2b) {
+  if (!o2l || !tf_b2l || !o2b) return ALEGO_ERR_ARG;
+  double A[4][8];
+  for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) { A[i][j] = tf_b2l[4 * i + j]; A[i][4 + j] = i == j ? 1.0 : 0.0; }
+  for (int c = 0; c < 4; ++c) {
+    int piv = c;
+    for (int r = c + 1; r < 4; ++r) if (std::fabs(A[r][c]) > std::fabs(A[piv][c])) piv = r;
+    if (!(std::fabs(A[piv][c]) > 0.0)) return ALEGO_ERR_ARG;   // singular (or NaN) mount transform
+    if (piv != c) for (int j = 0; j < 8; ++j) std::swap(A[piv][j], A[c][j]);
+    const double inv = 1.0 / A[c][c];
+    for (int j = 0; j < 8; ++j) A[c][j] *= inv;
+    for (int r = 0; r < 4; ++r) if (r != c) { const double f = A[r][c]; if (f != 0.0) for (int j = 0; j < 8; ++j) A[r][j] -= f * A[c][j]; }
+  }
+  const double w = o2l->q[0], x = o2l->q[1], y = o2l->q[2], z = o2l->q[3];
+  const double T[4][4] = {{1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y), o2l->t[0]},
+                          {2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x), o2l->t[1]},
+                          {2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y), o2l->t[2]},
+                          {0, 0, 0, 1}};
+  double M[4][4];
+  for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) { double acc = 0; for (int k = 0; k < 4; ++k) acc += T[i][k] * A[k][4 + j]; M[i][j] = acc; }
+  *o2b = *o2l;
+  for (int i = 0; i < 3; ++i) o2b->t[i] = M[i][3];
+  double q[4];   // w, x, y, z
+  double t = M[0][0] + M[1][1] + M[2][2];
+  if (t > 0.0) {
+    t = std::sqrt(t + 1.0); q[0] = 0.5 * t; t = 0.5 / t;
+    q[1] = (M[2][1] - M[1][2]) * t; q[2] = (M[0][2] - M[2][0]) * t; q[3] = (M[1][0] - M[0][1]) * t;
+  } else {
+    int i = 0;
+    if (M[1][1] > M[0][0]) i = 1;
+    if (M[2][2] > M[i][i]) i = 2;
+    const int j = (i + 1) % 3, k = (j + 1) % 3;
+    t = std::sqrt(M[i][i] - M[j][j] - M[k][k] + 1.0);
+    q[1 + i] = 0.5 * t; t = 0.5 / t;
+    q[0] = (M[k][j] - M[j][k]) * t; q[1 + j] = (M[j][i] + M[i][j]) * t; q[1 + k] = (M[k][i] + M[i][k]) * t;
+  }
+  for (int i = 0; i < 4; ++i) o2b->q[i] = q[i];
+  return ALEGO_OK;
+}
+
 // imuHandler (laserOdometry.cpp:761-802): the per-sample trigonometry here, ring bookkeeping + dead reckoning on the device
 int alego_lo_push_imu(alego_handle* h, int slot, const alego_imu* smp, int32_t n) {
   if (int r = check_slot(h, slot)) return r;

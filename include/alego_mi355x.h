@@ -198,6 +198,15 @@ typedef struct alego_imu {
   double angular_velocity[3];     /* carried by the message, unused by the reference (:787-789) */
 } alego_imu;
 int alego_lo_push_imu(alego_handle* h, int slot, const alego_imu* samples, int32_t n);
+/* /undistorted (src/laserOdometry.cpp:56,718-725; src/LO.cpp:127,797-804): the de-skewed segmented cloud of `slot`'s last scan, as adjustDistortion
+ * publishes it when somebody subscribes.  Returns the number of points, ALEGO_ERR_ARG when deskew_mode = 0 (the reference then never publishes on the
+ * topic either: the call is commented out at laserOdometry.cpp:115), ALEGO_ERR_CAPACITY when `cap` is too small. */
+int alego_lo_get_undistorted(alego_handle* h, int slot, alego_point* out, int32_t cap);
+/* The STANDALONE LaserOdometry node's frame convention (src/LO.cpp:588-608): /odom/lidar is published as /odom -> /base_link with
+ * tf_o2b = tf_o2l * tf_b2l^-1 (tf_b2l: base_link -> laser mount, row-major 4 x 4; identity at LO.cpp:121), its quaternion taken from the rotation
+ * block; the nodelet (src/laserOdometry.cpp:513-529) publishes /odom -> /laser unchanged.  Host arithmetic: `o2l` is what alego_lo_process returned,
+ * `o2b` gets t and q (params / valid copied).  ALEGO_ERR_ARG for a singular tf_b2l. */
+int alego_pose_o2b(const alego_pose* o2l, const double* tf_b2l, alego_pose* o2b);
 
 /* ---- state access for parity tests (teacher forcing) ---------------------- */
 int alego_set_lo_params(alego_handle* h, int slot, const double* p6);

@@ -25,9 +25,16 @@ class LaserOdometry : public nodelet::Nodelet {
     pub_corner_less_ = nh_.advertise<sensor_msgs::PointCloud2>("/corner_less", 10);
     pub_surf_ = nh_.advertise<sensor_msgs::PointCloud2>("/surf", 10);
     pub_surf_less_ = nh_.advertise<sensor_msgs::PointCloud2>("/surf_less", 10);
+    pub_undistorted_pc_ = nh_.advertise<sensor_msgs::PointCloud2>("/undistorted", 10);   // :56 (published by adjustDistortion, :718-725: only with deskew_mode = 1)
     pub_odom_ = nh_.advertise<nav_msgs::Odometry>("/odom/lidar", 10);
     pub_surf_last_ = nh_.advertise<sensor_msgs::PointCloud2>("/surf_last", 10);
     pub_corner_last_ = nh_.advertise<sensor_msgs::PointCloud2>("/corner_last", 10);
+    pub_outlier_last_ = nh_.advertise<sensor_msgs::PointCloud2>("/outlier_last", 10);   // :60 (advertised; the reference never publishes on it)
+    // frames of /odom/lidar: 0 (default) the nodelet's /odom -> /laser (:513-529); 1 the standalone node's /odom -> /base_link with
+    // tf_o2b = tf_o2l * tf_b2l^-1 (LO.cpp:588-608; tf_b2l_ is the identity there, LO.cpp:121 — a host with a calibrated mount sets it here)
+    pnh.param("standalone_frames", standalone_frames_, standalone_frames_);
+    for (int i = 0; i < 16; ++i) tf_b2l_[i] = (i % 5 == 0) ? 1.0 : 0.0;
+    undist_.resize(n_);
     sub_seg_ = nh_.subscribe<sensor_msgs::PointCloud2>("/segmented_cloud", 10, &LaserOdometry::segCloudHandler, this);
     sub_info_ = nh_.subscribe<alego::cloud_info>("/seg_info", 10, &LaserOdometry::segInfoHandler, this);
     sub_outlier_ = nh_.subscribe<sensor_msgs::PointCloud2>("/outlier", 10, &LaserOdometry::outlierHandler, this);
@@ -99,15 +106,22 @@ class LaserOdometry : public nodelet::Nodelet {
       };
       pub(pub_corner_, f.sharp, f.n_sharp); pub(pub_corner_less_, f.less_sharp, f.n_less_sharp);   // :299-314
       pub(pub_surf_, f.flat, f.n_flat); pub(pub_surf_less_, f.less_flat, f.n_less_flat);
-      if (!(flags & ALEGO_FLAG_LO_INIT)) {                                                           // :513-529
+      if (pub_undistorted_pc_.getNumSubscribers() > 0) {                                             // :718-725
+        int nu;
+        { alego_ros::HandleLock lock(h_); nu = alego_lo_get_undistorted(h_, 0, undist_.data(), n_); }
+        if (nu >= 0) pub(pub_undistorted_pc_, undist_.data(), nu);   // (ALEGO_ERR_ARG: deskew_mode = 0, adjustDistortion is not run — nothing to publish, as in the reference)
+      }
+      if (!(flags & ALEGO_FLAG_LO_INIT)) {                                                           // :513-529 / LO.cpp:588-608
+        const char* child = standalone_frames_ ? "/base_link" : "/laser";
+        if (standalone_frames_) { alego_pose b; if (alego_pose_o2b(&odom, tf_b2l_, &b) == ALEGO_OK) odom = b; }
         nav_msgs::OdometryPtr o(new nav_msgs::Odometry);
-        o->header.frame_id = "/odom"; o->child_frame_id = "/laser"; o->header.stamp = seg->header.stamp;
+        o->header.frame_id = "/odom"; o->child_frame_id = child; o->header.stamp = seg->header.stamp;
         o->pose.pose.position.x = odom.t[0]; o->pose.pose.position.y = odom.t[1]; o->pose.pose.position.z = odom.t[2];
         o->pose.pose.orientation.w = odom.q[0]; o->pose.pose.orientation.x = odom.q[1]; o->pose.pose.orientation.y = odom.q[2]; o->pose.pose.orientation.z = odom.q[3];
         pub_odom_.publish(o);
         tf::Transform t;
         tf::poseMsgToTF(o->pose.pose, t);
-        tf_.sendTransform(tf::StampedTransform(t, o->header.stamp, "/odom", "/laser"));
+        tf_.sendTransform(tf::StampedTransform(t, o->header.stamp, "/odom", child));
       }
       // /surf_last and /corner_last are published on every frame, also the initialising one (:537-546)
       sensor_msgs::PointCloud2Ptr ms(new sensor_msgs::PointCloud2), mc(new sensor_msgs::PointCloud2);
@@ -118,14 +132,16 @@ class LaserOdometry : public nodelet::Nodelet {
 
   ros::NodeHandle nh_;
   ros::Subscriber sub_seg_, sub_info_, sub_outlier_, sub_imu_;
-  ros::Publisher pub_corner_, pub_corner_less_, pub_surf_, pub_surf_less_, pub_odom_, pub_surf_last_, pub_corner_last_;
+  ros::Publisher pub_corner_, pub_corner_less_, pub_surf_, pub_surf_less_, pub_undistorted_pc_, pub_odom_, pub_surf_last_, pub_corner_last_, pub_outlier_last_;
+  int standalone_frames_ = 0;
+  double tf_b2l_[16];
   tf::TransformBroadcaster tf_;
   std::mutex m_buf_;
   std::queue<sensor_msgs::PointCloud2ConstPtr> seg_buf_, outlier_buf_;
   std::queue<alego::cloud_infoConstPtr> info_buf_;
   alego_handle* h_ = nullptr;
   int n_ = 0;
-  std::vector<alego_point> seg_pts_, sharp_, less_sharp_, flat_, less_flat_;
+  std::vector<alego_point> seg_pts_, sharp_, less_sharp_, flat_, less_flat_, undist_;
 };
 
 }  // namespace loam

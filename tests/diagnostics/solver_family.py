@@ -12,7 +12,7 @@ sys.path.insert(0, ROOT)
 import numpy as np
 
 def worker(mode, stream, scans, device):
-    """per-scan map translation of one free run: mode 'qr' | 'normal' (oracle) or 'device'"""
+    """per-scan map pose (t, q: 7 numbers) of one free run: mode 'qr' | 'normal' | ... (oracle, ORACLE_SOLVER) or 'device'"""
     from alego_loader import load_package; load_package()
     from alego_amd import synth
     p = synth.default_params(16, 1800)
@@ -22,14 +22,14 @@ def worker(mode, stream, scans, device):
         h = binding.Handle(p)
         for k in range(scans):
             _, _, mp = h.scan_process(synth.scan(p, k, stream=stream), stages=7)
-            out.append(mp["t"].tolist())
+            out.append(mp["t"].tolist() + mp["q"].tolist())
         h.close()
     else:
         from oracle import oracle_py as O
         o = O.Oracle(p)
         for k in range(scans):
             o.process_scan(synth.scan(p, k, stream=stream))
-            out.append(o.get("map_pose")[:3].tolist())
+            out.append(o.get("map_pose")[:7].tolist())
     print(json.dumps(out))
 
 def run(mode, stream, scans):
@@ -42,7 +42,7 @@ def run(mode, stream, scans):
     return np.array(json.loads(r.stdout.strip().splitlines()[-1]))
 
 def horizon(a, b, tol=1e-4):
-    e = np.linalg.norm(a - b, axis=1)
+    e = np.linalg.norm(a[:, :3] - b[:, :3], axis=1)
     bad = np.nonzero(e > tol)[0]
     return (int(bad[0]) if bad.size else None), float(e.max()), float(e[-1])
 

@@ -815,6 +815,7 @@ def test_motion_deskew_device_vs_oracle(params_a):
         o.lo()
         flags, feat, odom = h.lo_process(seg)
         assert_bit_equal(h.debug_get("undistorted"), o.get("undistorted"), f"scan {k} de-skewed cloud")
+        assert_bit_equal(h.undistorted().reshape(-1), np.asarray(o.get("undistorted")).reshape(-1), f"scan {k} /undistorted through alego_lo_get_undistorted")
         assert_bit_equal(h.debug_get("imu_ptr"), o.get("imu_ptr"), f"scan {k} imu_ptr_last_/front_/last_iter_")
         assert_bit_equal(h.debug_get("imu_ring"), o.get("imu_ring"), f"scan {k} IMU ring")
         _fe_compare(h, o, feat, f"deskew scan {k}")

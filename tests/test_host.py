@@ -168,3 +168,28 @@ def test_loop_detect_and_oracle_icp(params_a):
         w = O.transform_cloud(pose, frames[0][2])[:, :3].astype(np.float64)
         return w @ T[:3, :3].astype(np.float64).T + T[:3, 3].astype(np.float64)
     assert np.abs(world(bad, r2["T"]) - world(poses[n - 1], r["T"])).max() < 0.05
+
+
+def test_pose_o2b_standalone_frame_convention():
+    """alego_pose_o2b = LO.cpp:588-608: tf_o2b = tf_o2l * tf_b2l^-1, quaternion of its rotation block — against numpy (4 x 4 inverse, matrix product) and
+    scipy's rotation-matrix -> quaternion, for random poses and random (also non-rigid: the reference inverts a general Matrix4d) mounts."""
+    from scipy.spatial.transform import Rotation as R
+    rng = np.random.default_rng(5)
+    for trial in range(50):
+        q = rng.normal(size=4); q /= np.linalg.norm(q)
+        t = rng.normal(size=3) * 10
+        B = np.eye(4)
+        if trial:
+            B[:3, :3] = R.from_rotvec(rng.normal(size=3)).as_matrix()
+            B[:3, 3] = rng.normal(size=3)
+        T = np.eye(4)
+        T[:3, :3] = R.from_quat([q[1], q[2], q[3], q[0]]).as_matrix()
+        T[:3, 3] = t
+        want = T @ np.linalg.inv(B)
+        tb, qb = binding.pose_o2b(t, q, B)
+        np.testing.assert_allclose(tb, want[:3, 3], rtol=0, atol=1e-12)
+        wq = R.from_matrix(want[:3, :3]).as_quat()      # x y z w
+        wq = np.array([wq[3], wq[0], wq[1], wq[2]])
+        assert min(np.abs(qb - wq).max(), np.abs(qb + wq).max()) < 1e-12
+    with pytest.raises(binding.AlegoError):
+        binding.pose_o2b([0, 0, 0], [1, 0, 0, 0], np.zeros((4, 4)))

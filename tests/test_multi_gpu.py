@@ -142,3 +142,47 @@ def test_streams_sharded_across_ranks_rccl(world):
 @pytest.mark.parametrize("world", [1, 2])
 def test_one_registration_sharded_across_ranks_rccl(world):
     _run(_worker_sharded_registration, world)
+
+
+def _bench_under_launcher(extra, port_off, timeout=900):
+    """`python -m torch.distributed.run --nproc-per-node 1 bench.py --gpus 1 ...` exactly as the driver launches the N > 1 points of the scaling curve
+    (ALEGO_BENCH_FORCE_DIST=1 makes the one rank create the RCCL process group, barrier and gather through it as N ranks would)."""
+    import json
+    import subprocess
+    env = dict(os.environ, ALEGO_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("ALEGO_STREAM_GROUPS", None)
+    port = 29900 + (os.getpid() % 200) + port_off
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "1"] + extra
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert lines, r.stdout[-2000:]
+    return json.loads(lines[-1])
+
+
+def test_bench_launcher_path_self_check():
+    """the launcher path of bench.py — what the driver's first multi-GPU run goes through — inside the suite: one rank under
+    torch.distributed.run on an RCCL process group, 256 streams in stream groups, `--self-check`: after the timed region the rank's slot 0 must equal,
+    bit for bit, a one-slot handle that replays the same bag (exit code 3 and bit_equal = false otherwise)."""
+    j = _bench_under_launcher(["--steps", "10", "--warmup", "2", "--streams", "256", "--bags", "2", "--prime", "60", "--self-check",
+                               "--no-cpu", "--no-check", "--no-isolated"], 0)
+    assert j["n_gpus"] == 1 and j["ranks_seen_by_rccl"] == 1 and j["scaling"] == "weak"
+    assert j["self_check"]["bit_equal"] is True and j["self_check"]["ranks_checked"] == 1, j["self_check"]
+    assert j["truncated_streams"] == 0 and j["value"] > 0
+    assert abs(j["value"] - 256 * 10 / (j["ms_per_step"] * 10 / 1e3)) / j["value"] < 1e-3      # value = streams x steps / timed region
+    assert j["roofline"]["kernel"] in ("ip_fused_h", "ip_fused_w", "ip_fused") and j["roofline"]["frac"] > 0
+    assert len(j["roofline_top3"]) == 3 and all(a["share_of_device_time"] >= b["share_of_device_time"] for a, b in zip(j["roofline_top3"], j["roofline_top3"][1:]))
+
+
+def test_bench_shard_registration_line_labels_the_expected_slowdown():
+    """config 5 as a bench line at world = 1: the registration on the sharded kernel sequence (one RCCL all-reduce per solver evaluation) with the fused
+    solver timed next to it on the same streams, so that a reader of the first N > 1 run sees `shard_vs_fused` and its `expected` note instead of
+    discovering negative strong scaling."""
+    j = _bench_under_launcher(["--steps", "8", "--warmup", "2", "--streams", "8", "--bags", "1", "--prime", "40", "--shard-registration",
+                               "--no-cpu", "--no-check", "--no-profile"], 1)
+    assert j["scaling"] == "strong" and "sharded" in j["config"]["parallelism"]
+    sv = j["shard_vs_fused"]
+    assert sv["world"] == 1 and sv["fused_scans_per_s"] > 0 and sv["sharded_scans_per_s"] > 0 and "expected" in sv
+    assert abs(sv["sharded_scans_per_s"] - j["value"]) / j["value"] < 1e-3
+    assert j["shard_allreduce"]["doubles"] == 32

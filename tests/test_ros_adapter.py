@@ -28,7 +28,7 @@ def test_every_library_call_of_the_adapters_is_under_the_handle_lock():
     import re
     for src in ("imageProjection.cpp", "laserOdometry.cpp", "laserMapping.cpp"):
         text = open(os.path.join(ROOT, "ros_adapter", src)).read()
-        for m in re.finditer(r"alego_(ip_process|lo_process|lm_process|lo_push_imu|lm_get_keyframe)\(h_", text):
+        for m in re.finditer(r"alego_(ip_process|lo_process|lm_process|lo_push_imu|lo_get_undistorted|lm_get_keyframe)\(h_", text):
             before = text[:m.start()]
             lock = before.rfind("alego_ros::HandleLock")
             assert lock >= 0, f"{src}: {m.group(0)} without a HandleLock before it"
@@ -52,3 +52,17 @@ def test_nodelets_on_one_shared_handle_equal_the_chained_entry_point():
     got = json.loads(r.stdout.strip().splitlines()[-1])
     assert got["differing"] == 0 and got["worst_odom_abs"] == 0.0 and got["worst_map_abs"] == 0.0, got
     assert got["odom_msgs"] == 13 and got["mapped_msgs"] == 13 and got["lm_frames"] == 13, got   # the first scan only initialises LaserOdometry (:316-324)
+
+
+@pytest.mark.gpu
+def test_standalone_frame_convention_and_advertised_topics():
+    """with the private parameter standalone_frames = 1 LaserOdometry publishes /odom/lidar as the standalone node does —
+    /odom -> /base_link, tf_o2b = tf_o2l * tf_b2l^-1 (LO.cpp:588-608; tf_b2l = identity as at LO.cpp:121, so position equals and the quaternion goes through
+    a rotation matrix and back) — and the nodelet advertises /undistorted and /outlier_last like the reference (laserOdometry.cpp:56,60)."""
+    exe = os.path.join(MOCK, "harness")
+    r = subprocess.run([exe, "8", "standalone"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.returncode, r.stdout[-500:], r.stderr[-2000:])
+    got = json.loads(r.stdout.strip().splitlines()[-1])
+    assert got["child_frame"] == "/base_link" and got["topics_advertised"] == 2, got
+    assert got["differing"] == 0 and got["worst_odom_abs"] < 1e-14 and got["worst_map_abs"] < 1e-12, got
+    assert got["undistorted_msgs"] == 0      # deskew_mode = 0: advertised, never published (the reference's adjustDistortion call is commented out, :115)
