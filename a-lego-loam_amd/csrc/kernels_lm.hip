@@ -451,11 +451,16 @@ __global__ void __launch_bounds__(128) lm_knn(DevCtx d, LmCtx L) {
       rs[r] = in ? a0 : 0;
       re[r] = in ? a1 : 0;
     }
+    // (x, y) as one packed pair: v_pk_add_f32 / v_pk_mul_f32 are IEEE operations on both halves, the sum keeps the reference's order
+    // ((dx^2 + dy^2) + dz^2; 0 + dx^2 = dx^2 exactly) — 6 instead of 8 VALU instructions per candidate, same bits
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    const v2f sxy = {sx, sy};
     auto consider = [&](const float4& a) {
-      float dist = 0.f, df;
-      df = sx - a.x; dist += df * df;
-      df = sy - a.y; dist += df * df;
-      df = sz - a.z; dist += df * df;
+      const v2f axy = {a.x, a.y};
+      const v2f dxy = sxy - axy, sq = dxy * dxy;
+      const float dzv = sz - a.z;
+      float dist = sq.x + sq.y;
+      dist += dzv * dzv;
       const u64k key = ((u64k)(uint32_t)d_f2i(dist) << 32) | (uint32_t)__float_as_int(a.w);   // dist >= 0: its bit pattern orders like its value
       if (key < kmax && (uint32_t)d_f2i(dist) < limbits) {   // (limbits: a neighbour at knn_max_dist or beyond can never be part of an ACCEPTED query — see `ok` below)
         // (a set that is not full yet holds KNONE entries, which are its maximum; equal KNONE entries are all "the maximum": only one may be replaced)

@@ -21,7 +21,6 @@ import numpy as np
 import pytest
 
 from alego_amd import binding, synth
-from util import quat_angle
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -40,9 +39,18 @@ def _oracle_run(mode, stream):
     return np.array(json.loads(r.stdout.strip().splitlines()[-1]))
 
 
+def _rot_angle(q1, q2):
+    """angle of q1^-1 q2 (w x y z) from the VECTOR part of the relative quaternion: 2 atan2(|v|, |w|) resolves 1e-16 rad, where the usual
+    2 acos(|q1 . q2|) has a floor of ~1e-8 (acos near 1)"""
+    w1, v1, w2, v2 = q1[0], q1[1:4], q2[0], q2[1:4]
+    w = w1 * w2 + float(np.dot(v1, v2))
+    v = w1 * v2 - w2 * v1 - np.cross(v1, v2)
+    return 2.0 * float(np.arctan2(np.linalg.norm(v), abs(w)))
+
+
 def _errors(a, b):
     et = np.linalg.norm(a[:, :3] - b[:, :3], axis=1)
-    er = np.array([quat_angle(x[3:7], y[3:7]) for x, y in zip(a, b)])
+    er = np.array([_rot_angle(x[3:7], y[3:7]) for x, y in zip(a, b)])
     return et, er
 
 

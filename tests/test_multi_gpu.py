@@ -171,7 +171,7 @@ def test_bench_launcher_path_self_check():
     assert j["self_check"]["bit_equal"] is True and j["self_check"]["ranks_checked"] == 1, j["self_check"]
     assert j["truncated_streams"] == 0 and j["value"] > 0
     assert abs(j["value"] - 256 * 10 / (j["ms_per_step"] * 10 / 1e3)) / j["value"] < 1e-3      # value = streams x steps / timed region
-    assert j["roofline"]["kernel"] in ("ip_fused_h", "ip_fused_w", "ip_fused") and j["roofline"]["frac"] > 0
+    assert j["roofline"]["frac"] > 0 and j["roofline"]["in_B_scan"] is True   # (with 64 streams per launch the latency-bound lo_solve leads the device time, not ip_fused_h)
     assert len(j["roofline_top3"]) == 3 and all(a["share_of_device_time"] >= b["share_of_device_time"] for a, b in zip(j["roofline_top3"], j["roofline_top3"][1:]))
 
 
