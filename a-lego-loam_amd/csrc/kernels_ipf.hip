@@ -992,6 +992,21 @@ __global__ void __launch_bounds__(T, IPH_MINW) ip_fused_t(DevCtx d, int ring_pos
         qa[u] = pts[e0 ? (int)(ow[u] & 0xFFFFu) - 1 : 0];   // (clamped address instead of a branch: the eight gathers are in flight together)
         qb[u] = pts[e1 ? (int)(ow[u] >> 16) - 1 : 0];
       }
+#ifdef IPH_EXTRA_GATHER
+      // development (what does the gathers' read amplification cost?): the same gather once more on the NEXT scan's points —
+      // other cache lines, the same pattern: one more pass of 128-byte requests over a scan's 0.41 MB — folded into a value that is never stored
+      {
+        const float4* pts2 = scan_pts(d, slot, ring_pos + 1);
+        float sink = 0.f;
+#pragma unroll
+        for (int u = 0; u < IPH_GD; ++u) {
+          const int row = row0 + u;
+          const bool e0 = ((keep0 | outl0) >> row) & 1u, e1 = ((keep1 | outl1) >> row) & 1u;
+          sink += pts2[e0 ? (int)(ow[u] & 0xFFFFu) - 1 : 0].x + pts2[e1 ? (int)(ow[u] >> 16) - 1 : 0].y;
+        }
+        if (sink == 1.2345e38f) d.seg_range[base] = sink;
+      }
+#endif
 #pragma unroll
       for (int u = 0; u < IPH_GD; ++u) {
         const int row = row0 + u;

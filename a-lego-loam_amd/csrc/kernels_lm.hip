@@ -389,6 +389,9 @@ static inline int lm_reg_grid(const DevCtx& d, int GX) { return ((d.n_launch + 7
 // with five group-wide arg-min rounds.  The kernel is instruction-issue bound: with 4 lanes per query the per-query
 // fixed work (pose transform, cell addressing, merge) is shared by 16 queries per wavefront.
 #define LM_ASSOC_GX 64
+#ifndef LM_KNN_PK
+#define LM_KNN_PK 1
+#endif
 __global__ void __launch_bounds__(128) lm_knn(DevCtx d, LmCtx L) {
   // 1-D grid, lm_reg_block: all workgroups of a stream share one XCD and its L2 and are dispatched back to back (measured HBM traffic of the kernel:
   // 0.60 -> 0.20 MB per scan; throughput unchanged)
@@ -456,11 +459,18 @@ __global__ void __launch_bounds__(128) lm_knn(DevCtx d, LmCtx L) {
     typedef float v2f __attribute__((ext_vector_type(2)));
     const v2f sxy = {sx, sy};
     auto consider = [&](const float4& a) {
+#if LM_KNN_PK
       const v2f axy = {a.x, a.y};
       const v2f dxy = sxy - axy, sq = dxy * dxy;
       const float dzv = sz - a.z;
       float dist = sq.x + sq.y;
       dist += dzv * dzv;
+#else
+      float dist = 0.f, df;
+      df = sx - a.x; dist += df * df;
+      df = sy - a.y; dist += df * df;
+      df = sz - a.z; dist += df * df;
+#endif
       const u64k key = ((u64k)(uint32_t)d_f2i(dist) << 32) | (uint32_t)__float_as_int(a.w);   // dist >= 0: its bit pattern orders like its value
       if (key < kmax && (uint32_t)d_f2i(dist) < limbits) {   // (limbits: a neighbour at knn_max_dist or beyond can never be part of an ACCEPTED query — see `ok` below)
         // (a set that is not full yet holds KNONE entries, which are its maximum; equal KNONE entries are all "the maximum": only one may be replaced)

@@ -62,6 +62,37 @@ DEV_INLINE int bound_run(const float4* pts, int n, float inv, u64 key, bool stri
   return lo;
 }
 
+// both ends of the piece of a sorted run that falls into a chunk's key range [key_lo, key_hi]: first index with key >= key_lo and first index with key > key_hi,
+// found TOGETHER by 4-ary search — every round issues the six probes of both searches at once, so the dependent chain is ~log4(n) global round trips instead of
+// the 2 log2(n) of two binary searches one after the other (one wavefront does this in front of every work item of map_accum: it is latency, not work)
+DEV_INLINE void bound_run_pair(const float4* pts, int n, float inv, u64 key_lo, u64 key_hi, int* out_lo, int* out_hi) {
+  int lo0 = 0, hi0 = n, lo1 = 0, hi1 = n;   // invariants: [0, lo0) < key_lo <= [hi0, n);  [0, lo1) <= key_hi < [hi1, n)
+  while (lo0 < hi0 || lo1 < hi1) {
+    int m0[3], m1[3];
+    u64 k0[3], k1[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      m0[q] = lo0 + (int)(((long long)(hi0 - lo0) * (q + 1)) >> 2); m1[q] = lo1 + (int)(((long long)(hi1 - lo1) * (q + 1)) >> 2);
+      m0[q] = min(m0[q], max(hi0 - 1, 0)); m1[q] = min(m1[q], max(hi1 - 1, 0));
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) { k0[q] = vkey_of(pts[max(min(m0[q], n - 1), 0)], inv); k1[q] = vkey_of(pts[max(min(m1[q], n - 1), 0)], inv); }
+    if (lo0 < hi0) {
+      int nl = lo0, nh = hi0;
+#pragma unroll
+      for (int q = 0; q < 3; ++q) { if (k0[q] < key_lo) nl = max(nl, m0[q] + 1); else nh = min(nh, m0[q]); }
+      lo0 = nl; hi0 = nh;
+    }
+    if (lo1 < hi1) {
+      int nl = lo1, nh = hi1;
+#pragma unroll
+      for (int q = 0; q < 3; ++q) { if (k1[q] <= key_hi) nl = max(nl, m1[q] + 1); else nh = min(nh, m1[q]); }
+      lo1 = nl; hi1 = nh;
+    }
+  }
+  *out_lo = lo0; *out_hi = lo1;
+}
+
 struct MapWork {
   int* items;      // [cap] packed (slot - slot0) << 12 | m << 11 | chunk   (chunk < 2048)
   int* count;      // [2]: items, ticket
@@ -86,6 +117,10 @@ DEV_INLINE int block_excl_scan(int v, int* s_w /*[MU_T/64 + 1]*/, int* total) {
 
 #define MU_FCAP 4096      // points of a run whose voxel keys the fast path of map_update stages in LDS (2 x 32 KB)
 #define MU_E 16           // consecutive entries of the voxel list per thread in the fast path
+#ifndef MU_WORKLIST
+#define MU_WORKLIST 1
+#endif
+#define MU_LIST 2048      // slots whose rebuild flags are compacted into one work list (a launch of more slots takes them MU_LIST at a time)
 
 // grid (2, slots); dynamic LDS: 2 * MU_FCAP * 8 bytes
 __global__ void __launch_bounds__(MU_T) map_update(DevCtx d, LmCtx L, MapWork W) {
@@ -96,11 +131,31 @@ __global__ void __launch_bounds__(MU_T) map_update(DevCtx d, LmCtx L, MapWork W)
   __shared__ float s_box[6][MU_T / 64];
   __shared__ int s_kr_tot[MU_T / 64];
   extern __shared__ __attribute__((aligned(16))) unsigned char mu_smem[];
-  // A workgroup takes the slots blockIdx.y, blockIdx.y + gridDim.y, ...: only every sixth mapping frame changes its window, and a workgroup
-  // that has nothing to do still has to wait for 68 KB of LDS before it can start — 1024 of them per launch held the back stream of their
-  // group for 1.2 ms and took LDS from everybody else: 367 k -> 409 k scans/s with 32 slots per workgroup (launch_map_update).
-  for (int sl = blockIdx.y; sl < d.n_launch; sl += gridDim.y) {
-  const int slot = sl + d.slot0;
+  // Only every sixth mapping frame changes its window, and a workgroup that has nothing to do still has to wait for 68 KB of LDS before it can start —
+  // 1024 of them per launch held the back stream of their group for 1.2 ms and took LDS from everybody else: 367 k -> 409 k scans/s with 32 slots per
+  // workgroup (round 3, launch_map_update).  Round 5: the few workgroups of a launch no longer walk fixed slot ranges (32 slots of which ~9 % have work: the
+  // unluckiest of 16 workgroups got six or seven rebuilds and set the kernel's duration) but a WORK LIST — every workgroup compacts the launch's rebuild
+  // flags itself (one load per thread and a block scan: the same list in every workgroup, slot-ascending, no atomics) and takes the items blockIdx.y,
+  // blockIdx.y + gridDim.y, ...: the rebuilds are dealt out evenly whatever slots they fall on.
+  __shared__ unsigned short s_items[MU_LIST];
+  for (int c0 = 0; c0 < d.n_launch; c0 += MU_LIST) {
+  int n_items = 0;
+#if !MU_WORKLIST   // (development: round 4's fixed slot ranges — every slot of the launch is an "item", most of them with nothing to do)
+  n_items = min(MU_LIST, d.n_launch - c0);
+  for (int i = tid; i < n_items; i += MU_T) s_items[i] = (unsigned short)i;
+#else
+  for (int s0 = c0; s0 < min(c0 + MU_LIST, d.n_launch); s0 += MU_T) {
+    const int sx = s0 + tid;
+    const int flag = (sx < min(c0 + MU_LIST, d.n_launch) && lipm(L, sx + d.slot0)[LI_REBUILD] && d.opt_map_merge) ? 1 : 0;
+    int tot;
+    const int ex = block_excl_scan(flag, s_w, &tot);
+    if (flag) s_items[n_items + ex] = (unsigned short)(sx - c0);
+    n_items += tot;
+  }
+#endif
+  __syncthreads();
+  for (int it = blockIdx.y; it < n_items; it += gridDim.y) {
+  const int slot = c0 + (int)s_items[it] + d.slot0;
   int* li = lipm(L, slot);
   __syncthreads();   // LDS of the previous slot is reused
   const bool active = li[LI_REBUILD] && d.opt_map_merge;
@@ -349,7 +404,9 @@ __global__ void __launch_bounds__(MU_T) map_update(DevCtx d, LmCtx L, MapWork W)
       for (int a = 0; a < 3; ++a) { bb[a] = vbox_enc(mn[a]); bb[4 + a] = ~vbox_enc(mx[a]); }
     }
   }
-  }   // slots of this workgroup
+  }   // items of this workgroup
+  __syncthreads();   // (s_items is rewritten for the next MU_LIST slots)
+  }
   // ---- the last workgroup of the launch plans map_accum and closes the bookkeeping of every slot
   __threadfence();
   __syncthreads();
@@ -410,6 +467,18 @@ __global__ void __launch_bounds__(MU_T) map_update(DevCtx d, LmCtx L, MapWork W)
 #define MA_PT 2           // consecutive points of a batch per thread
 #endif
 #define MA_BCAP (MA_PT * MA_T)   // points per batch (a longer piece is cut into sub-pieces; they stay in order)
+#ifndef MA_HASH
+#define MA_HASH 0                // 1: a staged point finds its voxel through a hash table of the chunk's keys instead of a binary search (measured, round 5: slower — see DESIGN.md)
+#endif
+#ifndef MA_PAIR
+#define MA_PAIR 0                // 1: both ends of a run's piece by one interleaved 4-ary search (bound_run_pair)
+#endif
+#define MA_HT 1024               // hash slots for the chunk's MAP_R keys (load factor <= 0.5)
+DEV_INLINE unsigned ma_hash(u64 key) {   // voxel keys of a chunk differ in their low (x) bits first, then y (bit 21), rarely z (bit 42): fold, then a multiplicative hash
+  const unsigned f = (unsigned)key ^ (unsigned)(key >> 21) * 0x9E3779B1u ^ (unsigned)(key >> 42) * 0x85EBCA6Bu;
+  return (f * 0x9E3779B1u) >> 22;
+}
+static_assert(MA_HT == 1024 && MAP_R <= MA_HT / 2, "ma_hash returns 10 bits; the table is at most half full");
 static_assert(MAP_R == MA_T, "phase 2: one thread per voxel of the chunk");
 __global__ void __launch_bounds__(MA_T) map_accum(DevCtx d, LmCtx L, MapWork W) {
   __shared__ u64 s_key[MAP_R];
@@ -417,9 +486,16 @@ __global__ void __launch_bounds__(MA_T) map_accum(DevCtx d, LmCtx L, MapWork W) 
   __shared__ unsigned short s_rank[MA_BCAP];
   __shared__ unsigned short s_start[MA_JB * MAP_R];   // [sub-piece][voxel]: position + 1 of the pair's first point in the batch (valid where s_mask has the bit)
   __shared__ unsigned s_mask[MAP_R];                  // per voxel: the sub-pieces of the batch that hold points of it
-  __shared__ int s_lo[MAP_KMAX], s_hi[MAP_KMAX], s_ent[MAP_KMAX];
+  __shared__ int s_lo[MAP_KMAX], s_hi[MAP_KMAX];
+  __shared__ unsigned short s_ent[MAP_KMAX];   // (ring entries < KR <= MAP_KMAX + 1; 16 bits keep the kernel under 40 KB: four workgroups per CU)
   __shared__ int s_sub_ent[MA_JB], s_sub_lo[MA_JB], s_sub_off[MA_JB + 1];
   __shared__ int s_nsub, s_next_j, s_next_pos;
+  // the chunk's voxels by key: open addressing, MA_HT slots for <= MAP_R keys (entry = voxel + 1, 0 = empty; the key itself is compared in s_key).  A staged
+  // point finds its voxel with ~1.5 probes instead of the nine dependent LDS reads of a binary search over 64-bit keys (round 5; ~2/3 of the staging loop's
+  // instructions were that search: nearly every staged point is the first of its voxel in its run)
+#if MA_HASH
+  __shared__ unsigned short s_tab[MA_HT];
+#endif
   const int tid = threadIdx.x;
   const int nitems = W.count[0];
   for (int i = tid; i < MAP_R; i += MA_T) s_mask[i] = 0u;   // phase 2 leaves every entry it used at 0 again
@@ -434,16 +510,37 @@ __global__ void __launch_bounds__(MA_T) map_accum(DevCtx d, LmCtx L, MapWork W) 
     const int* rec = L.rec + (size_t)slot * L.K;
     const int nwin = li[LI_REC_CNT];
     __syncthreads();   // LDS of the previous item is reused
-    if (tid < nr) s_key[tid] = U[r0 + tid];
+    const u64 mykey = tid < nr ? U[r0 + tid] : 0ull;
+    if (tid < nr) s_key[tid] = mykey;
+#if MA_HASH
+    for (int i = tid; i < MA_HT; i += MA_T) s_tab[i] = 0;
+    __syncthreads();
+    if (tid < nr) {   // (16-bit entries: the insert is a compare-and-swap on the aligned 32-bit word)
+      unsigned h = ma_hash(mykey);
+      while (true) {
+        unsigned* w = reinterpret_cast<unsigned*>(s_tab) + (h >> 1);
+        const int sh = (h & 1u) * 16;
+        const unsigned old = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (((old >> sh) & 0xFFFFu) == 0u) { if (atomicCAS(w, old, old | ((unsigned)(tid + 1) << sh)) == old) break; }
+        else h = (h + 1) & (MA_HT - 1);
+      }
+    }
+#endif
     __syncthreads();
     const u64 key_lo = s_key[0], key_hi = s_key[nr - 1];
     for (int j = tid; j < nwin; j += MA_T) {   // the piece of every run that falls into this chunk's key range
       const int e = rec[j] % L.KR;
       const float4* pts = run_pts(L, slot, m, e);
       const int n = run_n(L, slot, m, e);
-      s_ent[j] = e;
+      s_ent[j] = (unsigned short)e;
+#if MA_PAIR
+      int blo, bhi;
+      bound_run_pair(pts, n, inv, key_lo, key_hi, &blo, &bhi);
+      s_lo[j] = blo; s_hi[j] = bhi;
+#else
       s_lo[j] = bound_run(pts, n, inv, key_lo, false);
       s_hi[j] = bound_run(pts, n, inv, key_hi, true);
+#endif
     }
     if (tid == 0) { s_next_j = 0; s_next_pos = -1; }
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -498,9 +595,21 @@ __global__ void __launch_bounds__(MA_T) map_accum(DevCtx d, LmCtx L, MapWork W) 
             const bool head = sj[u] != jprev || key != kprev;
             int a = 0xFFFF;
             if (head) {
+#if MA_HASH
+              unsigned h = ma_hash(key);
+              int lo2 = -1;
+              for (int probe = 0; probe < MA_HT; ++probe) {
+                const int e = s_tab[h];
+                if (e == 0) break;
+                if (s_key[e - 1] == key) { lo2 = e - 1; break; }
+                h = (h + 1) & (MA_HT - 1);
+              }
+              if (lo2 < 0) { li[LI_OVERFLOW] = 4; lo2 = 0; }   // voxel list out of sync (internal error)
+#else
               int lo2 = 0, hi2 = nr;
               while (lo2 < hi2) { const int mid = (lo2 + hi2) >> 1; if (s_key[mid] < key) lo2 = mid + 1; else hi2 = mid; }
               if (lo2 >= nr || s_key[lo2] != key) { li[LI_OVERFLOW] = 4; lo2 = min(lo2, nr - 1); }   // voxel list out of sync (internal error)
+#endif
               a = lo2;
               s_start[sj[u] * MAP_R + a] = (unsigned short)(idx + 1);
               atomicOr(&s_mask[a], 1u << sj[u]);
