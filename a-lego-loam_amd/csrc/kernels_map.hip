@@ -480,7 +480,7 @@ DEV_INLINE unsigned ma_hash(u64 key) {   // voxel keys of a chunk differ in thei
 }
 static_assert(MA_HT == 1024 && MAP_R <= MA_HT / 2, "ma_hash returns 10 bits; the table is at most half full");
 static_assert(MAP_R == MA_T, "phase 2: one thread per voxel of the chunk");
-__global__ void __launch_bounds__(MA_T) map_accum(DevCtx d, LmCtx L, MapWork W) {
+__global__ void __launch_bounds__(MA_T, 8) map_accum(DevCtx d, LmCtx L, MapWork W) {   // 8 wavefronts per SIMD = 64 VGPRs: four of these workgroups per CU (what the 38 KB of LDS allow); a variant at 67 VGPRs ran three per CU and cost the bench 1.5 %
   __shared__ u64 s_key[MAP_R];
   __shared__ float4 s_pts[MA_BCAP];
   __shared__ unsigned short s_rank[MA_BCAP];

@@ -633,7 +633,7 @@ def main():
         if with_term:   # the dominant kernel: largest share of the device time among those with a §8(d) term of their own
             out["roofline"] = dict(with_term[0], map_rebuilds_per_launch=round(rebuilds / max(kern[with_term[0]["kernel"]]["launches"], 1), 2))
         out["roofline_top3"] = roofs[:3]        # the three largest kernels by device time, whatever their term
-        out["roofline_all"] = {r["kernel"]: dict(frac=r["frac"], frac_isolated=r.get("frac_isolated"), traffic_over_algorithmic=(round(r["traffic"] / r["algorithmic_bytes_per_launch"], 2) if r["traffic"] and r["algorithmic_bytes_per_launch"] else None),
+        out["roofline_all"] = {r["kernel"]: dict(frac=r["frac"], frac_isolated=r.get("frac_isolated"), traffic_over_algorithmic=(round(r["traffic"] / r["algorithmic_bytes_per_launch"], 2) if r["traffic"] and (r["algorithmic_bytes_per_launch"] or 0) > 1024 * per else None),   # (the solvers' 104 bytes of pose are not a traffic yardstick)
                                                  share=r["share_of_device_time"], in_B_scan=r["in_B_scan"]) for r in roofs if r["frac"] is not None}
         # the device's counterpart of cpu_baseline.lo_opt_ms_per_frame (the reference README's "optimisation" time per frame, README.md:50,54):
         # LaserOdometry's two ceres::Solve calls = two lo_solve launches per scan, each advancing `per` streams

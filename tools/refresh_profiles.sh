@@ -34,6 +34,9 @@ python tools/pmc_traffic.py /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE "$PER" 16 > 
 [ "$MODE" = "traffic" ] && { ls -la gpurun_out/${R}_*; exit 0; }
 # SQ counters (occupancy / issue statistics quoted in DESIGN.md section 4): one stream group, 512 streams
 rm -rf /tmp/pmc_sq
-ALEGO_STREAM_GROUPS=1 timeout 1500 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD GRBM_GUI_ACTIVE --kernel-trace -d /tmp/pmc_sq -o sq --output-format csv -- python bench.py --streams 512 --steps 6 --warmup 0 --prime 700 --no-cpu --no-profile --no-check --no-isolated < /dev/null > /tmp/pmc_sq.log 2>&1
-python tools/pmc_agg.py /tmp/pmc_sq 12 > gpurun_out/${R}_pmc_sq.json
+ALEGO_STREAM_GROUPS=1 timeout 1500 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --kernel-trace -d /tmp/pmc_sq -o sq --output-format csv -- python bench.py --streams 512 --steps 6 --warmup 0 --prime 700 --no-cpu --no-profile --no-check --no-isolated < /dev/null > /tmp/pmc_sq.log 2>&1
+python tools/pmc_agg.py /tmp/pmc_sq 12 512 > gpurun_out/${R}_pmc_sq.json
+# read requests by size (round 5): nearly every request of this pipeline is 128 bytes wide, so exact read bytes = 128 x TCC_EA0_RDREQ_128B + 64 x ..._64B + 32 x ..._32B
+rm -rf /tmp/pmc_any
+bash tools/pmc_any.sh gpurun_out/${R}_pmc_rdreq.json TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_128B_sum TCC_EA0_RDREQ_64B_sum
 ls -la gpurun_out/${R}_*
