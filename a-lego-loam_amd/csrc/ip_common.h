@@ -170,19 +170,35 @@ __device__ __attribute__((noinline)) inline bool ip_is_ground_ref(double dx, dou
   return fabs(angle - mount) < thres;
 }
 __device__ __attribute__((noinline)) inline bool edge_angle_ref(double y, double x, double theta) { return atan2(y, x) > theta; }
-DEV_INLINE bool ip_is_ground(const DevCtx& d, float fx, float fy, float fz) {
+// (round 5: the two margins are taken in "signed square" space — f(x) = sign(x) x^2 is strictly increasing, so f(dz) - f(tan h) has the sign of dz - tan h —
+//  which needs h^2 = dx^2 + dy^2 instead of the fp64 square root (~30 instructions of the ~48 this test took; it runs for 20 cell pairs per column pair).
+//  dx^2, dy^2, dz^2 are exact in fp64 (24-bit factors), the other products round at 1e-16: the 1e-9 band around zero still belongs to the reference expression.)
+// 1 = ground, 0 = not ground, -1 = the margins cannot decide (within 1e-9 of a bound, or the shortcut is disabled: NaN tans)
+DEV_INLINE int ip_ground_margins(double tan_lo, double tan_hi, float fx, float fy, float fz) {
   const double dx = (double)fx, dy = (double)fy, dz = (double)fz;
-  const double hq = sqrt(dx * dx + dy * dy);
-  const double m1 = dz - d.tan_g_lo * hq, m2 = d.tan_g_hi * hq - dz, tol = 1e-9 * (fabs(dz) + hq);
-  if (m1 > tol && m2 > tol) return true;
-  if (m1 < -tol || m2 < -tol) return false;
-  return ip_is_ground_ref(dx, dy, dz, d.P.sensor_mount_ang, d.P.ground_angle_thres);
+  const double h2 = dx * dx + dy * dy, z2 = dz * dz;
+  const double l2 = (tan_lo * tan_lo) * h2, u2 = (tan_hi * tan_hi) * h2;   // (tan h)^2 of the two bounds
+  const double sz = copysign(z2, dz);
+  const double m1 = sz - copysign(l2, tan_lo), m2 = copysign(u2, tan_hi) - sz;
+  const double t1 = 1e-9 * (z2 + l2), t2 = 1e-9 * (z2 + u2);
+  const bool yes = m1 > t1 && m2 > t2, no = m1 < -t1 || m2 < -t2;
+  return yes ? 1 : (no ? 0 : -1);
+}
+DEV_INLINE bool ip_is_ground(const DevCtx& d, float fx, float fy, float fz) {
+  const int g = ip_ground_margins(d.tan_g_lo, d.tan_g_hi, fx, fy, fz);
+  if (g >= 0) return g != 0;
+  return ip_is_ground_ref((double)fx, (double)fy, (double)fz, d.P.sensor_mount_ang, d.P.ground_angle_thres);
 }
 
 // atan2(y, x) > theta for y > 0, x > 0 (y = d2 sin a, x = d1 - d2 cos a with d1 >= d2 > 0 and 0 < a < pi/2).
 // tan is monotone on (0, pi/2): the comparison is decided by the sign of y - x tan(theta) whenever that difference is
 // far (1e-9 relative) from zero — rounding errors of either form are ~1e-16 — and by the reference expression itself
 // otherwise.  Saves two fp64 atan2 per cell on all but a vanishing fraction of the edges.
+// the same decision without the reference expression: 1 / 0, or -1 when the margin cannot decide
+DEV_INLINE int edge_angle_margin(double y, double x, double tan_theta) {
+  const double xt = x * tan_theta, m = y - xt;
+  return fabs(m) > 1e-9 * (y + fabs(xt)) ? (m > 0.0 ? 1 : 0) : -1;
+}
 DEV_INLINE bool edge_angle_gt(double y, double x, double theta, double tan_theta) {
   const double xt = x * tan_theta, m = y - xt;
   if (fabs(m) > 1e-9 * (y + fabs(xt))) return m > 0.0;

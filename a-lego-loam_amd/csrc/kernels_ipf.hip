@@ -733,6 +733,11 @@ __global__ void __launch_bounds__(T, IPH_MINW) ip_fused_t(DevCtx d, int ring_pos
     }
     unsigned redge0 = 0, redge1 = 0, down0 = 0, down1 = 0;
     if (colv) {
+      // (the constants of the edge predicate as values of their own: read straight from `d` they belong to the 16-register tuple one s_load of the kernel
+      // argument brought in; the kernel uses more uniform values than there are SGPRs, the allocator parks that tuple in VGPR lanes and read all 16 lanes
+      // back in front of every one of the 64 edge sites)
+      double k_sax = d.sin_ax, k_cax = d.cos_ax, k_say = d.sin_ay, k_cay = d.cos_ay, k_tan = d.tan_theta, k_theta = P.seg_theta;
+      asm volatile("" : "+s"(k_sax), "+s"(k_cax), "+s"(k_say), "+s"(k_cay), "+s"(k_tan), "+s"(k_theta));
 #pragma unroll
       for (int row = 0; row < IPF2_ROWS; ++row) {
         if (row < NS) {
@@ -740,22 +745,22 @@ __global__ void __launch_bounds__(T, IPH_MINW) ip_fused_t(DevCtx d, int ring_pos
             const double r0 = (double)rng0[row];
             if ((act1 >> row) & 1u) {   // same row, seg_alpha_x (:258-261)
               const double r1 = (double)rng1[row], d1 = fmax(r0, r1), d2 = fmin(r0, r1);
-              if (edge_angle_gt(d2 * d.sin_ax, d1 - d2 * d.cos_ax, P.seg_theta, d.tan_theta)) redge0 |= 1u << row;
+              if (edge_angle_gt(d2 * k_sax, d1 - d2 * k_cax, k_theta, k_tan)) redge0 |= 1u << row;
             }
             if (row + 1 < NS && ((act0 >> (row + 1)) & 1u)) {   // same column, seg_alpha_y (:262-265)
               const double r1 = (double)rng0[row + 1 < IPF2_ROWS ? row + 1 : row], d1 = fmax(r0, r1), d2 = fmin(r0, r1);
-              if (edge_angle_gt(d2 * d.sin_ay, d1 - d2 * d.cos_ay, P.seg_theta, d.tan_theta)) down0 |= 1u << row;
+              if (edge_angle_gt(d2 * k_say, d1 - d2 * k_cay, k_theta, k_tan)) down0 |= 1u << row;
             }
           }
           if ((act1 >> row) & 1u) {
             const double r0 = (double)rng1[row];
             if ((nb_act >> row) & 1u) {
               const double r1 = (double)nbr[row], d1 = fmax(r0, r1), d2 = fmin(r0, r1);
-              if (edge_angle_gt(d2 * d.sin_ax, d1 - d2 * d.cos_ax, P.seg_theta, d.tan_theta)) redge1 |= 1u << row;
+              if (edge_angle_gt(d2 * k_sax, d1 - d2 * k_cax, k_theta, k_tan)) redge1 |= 1u << row;
             }
             if (row + 1 < NS && ((act1 >> (row + 1)) & 1u)) {
               const double r1 = (double)rng1[row + 1 < IPF2_ROWS ? row + 1 : row], d1 = fmax(r0, r1), d2 = fmin(r0, r1);
-              if (edge_angle_gt(d2 * d.sin_ay, d1 - d2 * d.cos_ay, P.seg_theta, d.tan_theta)) down1 |= 1u << row;
+              if (edge_angle_gt(d2 * k_say, d1 - d2 * k_cay, k_theta, k_tan)) down1 |= 1u << row;
             }
           }
         }
