@@ -490,6 +490,22 @@ __global__ void __launch_bounds__(IPF2_T) ip_fused(DevCtx d, int ring_pos, int k
 #ifndef IPH_GD
 #define IPH_GD 4
 #endif
+// A field of the kernel argument read where it is needed instead of at the kernel's entry (round 5).  The compiler loads every member of the by-value DevCtx
+// it finds used anywhere with a handful of wide s_loads in the entry block — 101 dwords for ip_fused_t — and they all stay live to their last use: more uniform
+// values than there are SGPRs, parked in VGPR lanes and read back (v_readlane_b32) at their uses.  The output arrays are only touched by phase D: fetched there,
+// through a pointer the optimiser cannot identify with the argument, they occupy nothing during phases A-C.
+typedef const __attribute__((address_space(4))) char* IphKarg;
+template <class F> DEV_INLINE F iph_karg(unsigned off) {
+  IphKarg kp = (IphKarg)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(kp));
+  return *reinterpret_cast<const __attribute__((address_space(4))) F*>(kp + off);
+}
+// the whole argument struct of one phase: `d` and `P` are shadowed by references into the kernel-argument segment obtained through a pointer the optimiser cannot
+// identify with the by-value parameter, so the members a phase uses are loaded at its start (scalar loads, a handful per phase) and are dead at its end
+#define IPH_PHASE_CTX IphKarg iph_k_ = (IphKarg)__builtin_amdgcn_kernarg_segment_ptr(); asm volatile("" : "+s"(iph_k_)); \
+  const DevCtx& d = *(const DevCtx*)(const char*)iph_k_; const alego_params& P = d.P; (void)P
+#define IPH_LATE(field) iph_karg<decltype(DevCtx::field)>((unsigned)offsetof(DevCtx, field))   // (DevCtx is the kernel's first argument: offset 0 of the segment)
+
 // first_r / first_act (phase B) and the count tables (phase D) are never live together: one area (the wide instantiation has 16 bytes of
 // LDS to spare at 16 x 4000)
 template <int NW, int NP>
@@ -564,6 +580,7 @@ __global__ void __launch_bounds__(T, IPH_MINW) ip_fused_t(DevCtx d, int ring_pos
   __syncthreads();
   const int n = scan_count(d, slot, ring_pos);
   const float4* pts = scan_pts(d, slot, ring_pos);
+  { IPH_PHASE_CTX;   // (d and P of this phase: the kernel argument read afresh — see IPH_PHASE_CTX)
   {
     int* s_list = reinterpret_cast<int*>(fcol);
     const int list_cap = 2 * H;   // 8 H bytes
@@ -645,8 +662,10 @@ __global__ void __launch_bounds__(T, IPH_MINW) ip_fused_t(DevCtx d, int ring_pos
     }
   }
 
+  }
   IPH_STOP(1);
   // ---------------- phase B: ranges, ground, edges — one column pair per thread and pass ----------------
+  { IPH_PHASE_CTX;   // (d and P of this phase: the kernel argument read afresh — see IPH_PHASE_CTX)
 #pragma unroll 1
   for (int p = 0; p < NP; ++p) {
     const int pi = tid + p * T, c0 = 2 * pi, c1 = c0 + 1;
@@ -783,8 +802,10 @@ __global__ void __launch_bounds__(T, IPH_MINW) ip_fused_t(DevCtx d, int ring_pos
   }
   __syncthreads();   // every read of the owner image has happened: its LDS becomes the parent array
 
+  }
   IPH_STOP(2);
   // ---------------- phase C: connected components over vertical runs (ip_fused's steps, column by column from the masks in LDS) ----------------
+  { IPH_PHASE_CTX;   // (d and P of this phase: the kernel argument read afresh — see IPH_PHASE_CTX)
   // a cell starts a run when it is active and no down-edge reaches it from below; a run's representative is its first (lowest) cell
   const int ncol = NP * 2;   // columns of a thread: 2 (tid + p T) + k
   auto col_of = [&](int q) -> int { return 2 * (tid + (q >> 1) * T) + (q & 1); };
@@ -898,8 +919,10 @@ __global__ void __launch_bounds__(T, IPH_MINW) ip_fused_t(DevCtx d, int ring_pos
   }
   // (fcol entries are read and written by their own thread only from here on: no barrier)
 
+  }
   IPH_STOP(3);
   // ---------------- phase D: ordered compaction (:158-191) ----------------
+  { IPH_PHASE_CTX;   // (d and P of this phase: the kernel argument read afresh — see IPH_PHASE_CTX)
   const unsigned all16 = 0xFFFFu;
   const unsigned rowgt = P.ground_scan_id >= 15 ? 0u : (P.ground_scan_id < 0 ? all16 : (all16 & ~((2u << P.ground_scan_id) - 1u)));   // rows > ground_scan_id
   // keep | outliers << 16 of column c; feasible roots (label_cnt_ numbering, :303-306)
@@ -955,16 +978,19 @@ __global__ void __launch_bounds__(T, IPH_MINW) ip_fused_t(DevCtx d, int ring_pos
     }
   }
   __syncthreads();
+  int* const o_rs = IPH_LATE(ring_start) + slot * NS; int* const o_re = IPH_LATE(ring_end) + slot * NS; int* const o_sc = IPH_LATE(scal) + slot * SC_COUNT;   // (fetched in uniform code)
   if (tid < NS) {   // startRingIndex / endRingIndex (:161,:190)
     const int row = tid;
-    d.ring_start[slot * NS + row] = (int)S.u.cnt[0][row * NP * NW] + 5;
-    d.ring_end[slot * NS + row] = (row + 1 < IPF2_ROWS ? (int)S.u.cnt[0][(row + 1) * NP * NW] : S.tot[0]) - 1 - 5;
+    o_rs[row] = (int)S.u.cnt[0][row * NP * NW] + 5;
+    o_re[row] = (row + 1 < IPF2_ROWS ? (int)S.u.cnt[0][(row + 1) * NP * NW] : S.tot[0]) - 1 - 5;
   }
   if (tid == 0) {
-    int* sc = d.scal + slot * SC_COUNT;
+    int* sc = o_sc;
     sc[SC_M] = S.tot[0]; sc[SC_NOUT] = S.tot[1]; sc[SC_NFEAS] = S.tot[2];
   }
   const unsigned long long below = (1ull << lane) - 1ull;
+  float4* const o_pts = IPH_LATE(seg_pts) + base; uint8_t* const o_gnd = IPH_LATE(seg_ground) + base; int* const o_col = IPH_LATE(seg_col) + base;
+  float* const o_rng = IPH_LATE(seg_range) + base; float4* const o_out = IPH_LATE(outlier) + base; int* const o_lab = IPH_LATE(cc_label) + base;
 #pragma unroll 1
   for (int p = 0; p < NP; ++p) {
     const int pi = tid + p * T, c0 = 2 * pi, c1 = c0 + 1;
@@ -1024,12 +1050,12 @@ __global__ void __launch_bounds__(T, IPH_MINW) ip_fused_t(DevCtx d, int ring_pos
           const float4 q = qa[u];
           const float4 pp = make_float4(q.x, q.y, q.z, (float)(row + c0 / 10000.0));   // :101
           if (k0) {
-            d.seg_pts[base + lk] = pp;
-            d.seg_ground[base + lk] = (uint8_t)((ground0 >> row) & 1u);
-            d.seg_col[base + lk] = c0;
-            d.seg_range[base + lk] = sqrtf(q.x * q.x + q.y * q.y + q.z * q.z);   // = the range image's value (:99,:184)
+            o_pts[lk] = pp;
+            o_gnd[lk] = (uint8_t)((ground0 >> row) & 1u);
+            o_col[lk] = c0;
+            o_rng[lk] = sqrtf(q.x * q.x + q.y * q.y + q.z * q.z);   // = the range image's value (:99,:184)
           } else {
-            d.outlier[base + lo] = pp;
+            o_out[lo] = pp;
           }
         }
         if (k1 | o1) {
@@ -1037,12 +1063,12 @@ __global__ void __launch_bounds__(T, IPH_MINW) ip_fused_t(DevCtx d, int ring_pos
           const float4 pp = make_float4(q.x, q.y, q.z, (float)(row + c1 / 10000.0));
           const int l1 = lk + (k0 ? 1 : 0), lo1 = lo + (o0 ? 1 : 0);
           if (k1) {
-            d.seg_pts[base + l1] = pp;
-            d.seg_ground[base + l1] = (uint8_t)((ground1 >> row) & 1u);
-            d.seg_col[base + l1] = c1;
-            d.seg_range[base + l1] = sqrtf(q.x * q.x + q.y * q.y + q.z * q.z);
+            o_pts[l1] = pp;
+            o_gnd[l1] = (uint8_t)((ground1 >> row) & 1u);
+            o_col[l1] = c1;
+            o_rng[l1] = sqrtf(q.x * q.x + q.y * q.y + q.z * q.z);
           } else {
-            d.outlier[base + lo1] = pp;
+            o_out[lo1] = pp;
           }
         }
       }
@@ -1053,11 +1079,12 @@ __global__ void __launch_bounds__(T, IPH_MINW) ip_fused_t(DevCtx d, int ring_pos
         const unsigned long long bf0 = __ballot((fr0 >> row) & 1u), bf1 = __ballot((fr1 >> row) & 1u);
         if (colv && row < NS) {
           const int nf = (int)S.u.cnt[2][(row * NP + p) * NW + wave] + (int)(__popcll(bf0 & below) + __popcll(bf1 & below));
-          if ((root0 >> row) & 1u) d.cc_label[base + row * H + c0] = ((fr0 >> row) & 1u) ? nf + 1 : 0;
-          if ((root1 >> row) & 1u) d.cc_label[base + row * H + c1] = ((fr1 >> row) & 1u) ? nf + ((fr0 >> row) & 1u) + 1 : 0;
+          if ((root0 >> row) & 1u) o_lab[row * H + c0] = ((fr0 >> row) & 1u) ? nf + 1 : 0;
+          if ((root1 >> row) & 1u) o_lab[row * H + c1] = ((fr1 >> row) & 1u) ? nf + ((fr0 >> row) & 1u) + 1 : 0;
         }
       }
     }
+  }
   }
 }
 
