@@ -315,6 +315,15 @@ int alego_create(const alego_params* params, int device, int n_slots, int ring_l
     if (!rc && (hipMemcpy(rtd, rt.data(), rt.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
                 hipMemcpy(ctd, ct.data(), ct.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess)) { h->err = "upload of the projection tables failed"; rc = ALEGO_ERR_HIP; }
     d.ip_rowtab = rtd; d.ip_coltab = ctd;
+    {  // col / 10000.0 of every column (the fraction of the intensity row + col / 10000.0, imageProjection.cpp:101): one IEEE fp64 division each, done here once
+       // instead of ~35 instructions per emitted cell on the device; the sum with the row and the rounding to f32 stay where they were
+      std::vector<double> cf(d.H);
+      for (int c = 0; c < d.H; ++c) cf[c] = c / 10000.0;
+      double* cfd = nullptr;
+      rc |= dalloc(h, &cfd, (size_t)d.H);
+      if (!rc && hipMemcpy(cfd, cf.data(), cf.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) { h->err = "upload of the column table failed"; rc = ALEGO_ERR_HIP; }
+      d.ip_colfrac = cfd;
+    }
     d.ip_fast = 0;
     if (params->laser_type == ALEGO_LASER_UNIFORM && ry > 1e-3 && std::fabs(((double)NS + 2.5) * ry - params->ang_bottom) < 80.0 && std::fabs(-3.5 * ry - params->ang_bottom) < 80.0) d.ip_fast |= 1;
     if (rx > 1e-3 && std::fabs((double)d.H * rx - 360.0) < 1e-9 && d.ip_ncb < (1 << 20)) d.ip_fast |= 2;

@@ -56,6 +56,7 @@ struct DevCtx {
   // c = ip_cmin .. ip_cmin + ip_ncb - 1; ip_fast bit 0 = rows usable (uniform laser), bit 1 = columns usable (H * ang_res_x == 360)
   const double2* ip_rowtab;
   const double2* ip_coltab;
+  const double* ip_colfrac;               // [H] col / 10000.0 (host fp64 division): the fractional part of a segmented point's intensity (imageProjection.cpp:101)
   int ip_cmin, ip_ncb, ip_fast;
   unsigned h_magic;                       // floor(2^32 / H) + 1: cell / H == umulhi(cell, h_magic) for every cell < 2^32 / H
   double tan_g_lo, tan_g_hi;              // tan of (sensor_mount_ang -/+ ground_angle_thres) (ground test shortcut; NaN disables)

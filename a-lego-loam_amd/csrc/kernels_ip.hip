@@ -452,7 +452,7 @@ __global__ void __launch_bounds__(CC_LDS_THREADS) cc_lds(DevCtx d, int ring_pos,
     }
     if (kp || ol) {
       float4 p = pts[ip_owner_index(d.owner[base + v])];
-      p.w = (float)(row + col / 10000.0);  // :101
+      p.w = (float)(row + d.ip_colfrac[col]);  // :101
       if (kp) {
         d.seg_pts[base + line] = p;
         d.seg_ground[base + line] = fi[v] & 1;
@@ -761,7 +761,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(8, 8))) __launch_bounds__(CC_
       if (row > 0) d.ring_end[slot * d.NS + row - 1] = line - 1 - 5;
     }
     if (kp || ol) {
-      const float4 p = make_float4(q.x, q.y, q.z, (float)(row + col / 10000.0));
+      const float4 p = make_float4(q.x, q.y, q.z, (float)(row + d.ip_colfrac[col]));
       if (kp) {
         d.seg_pts[base + line] = p;
         d.seg_ground[base + line] = (uint8_t)(flag_of(k) & 1);
@@ -928,7 +928,7 @@ __global__ void __launch_bounds__(IP_BLOCK) ip_compact(DevCtx d, int ring_pos) {
     if (c == 1 || c == 2) {
       const int o = ip_owner_index(d.owner[base + v]);
       float4 p = pts[o];
-      p.w = (float)(row + col / 10000.0);  // :101
+      p.w = (float)(row + d.ip_colfrac[col]);  // :101
       if (c == 1) {
         const int line = run_k + wk + (int)__popcll(bk & below);
         d.seg_pts[base + line] = p;

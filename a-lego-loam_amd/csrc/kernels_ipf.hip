@@ -398,6 +398,7 @@ __global__ void __launch_bounds__(IPF2_T) ip_fused(DevCtx d, int ring_pos, int k
   IPF_TICK(9);
   const unsigned long long below = (1ull << lane) - 1ull;
   const unsigned* own16w = reinterpret_cast<const unsigned*>(own16);
+  const double cf0 = d.ip_colfrac[min(c0, H - 1)], cf1 = d.ip_colfrac[min(c1, H - 1)];   // c / 10000.0 (host division, alego_api.hip)
 #pragma unroll
   for (int row0 = 0; row0 < IPF2_ROWS; row0 += 4) {
     float4 qa[4], qb[4];
@@ -418,7 +419,7 @@ __global__ void __launch_bounds__(IPF2_T) ip_fused(DevCtx d, int ring_pos, int k
       const int lo = S.cnt[1][row * IPF2_NW + wave] + (int)(__popcll(bo0 & below) + __popcll(bo1 & below));
       if (k0 | o0) {
         const float4 q = qa[u];
-        const float4 p = make_float4(q.x, q.y, q.z, (float)(row + c0 / 10000.0));   // :101
+        const float4 p = make_float4(q.x, q.y, q.z, (float)(row + cf0));   // :101
         if (k0) {
           d.seg_pts[base + lk] = p;
           d.seg_ground[base + lk] = (uint8_t)((ground0 >> row) & 1u);
@@ -430,7 +431,7 @@ __global__ void __launch_bounds__(IPF2_T) ip_fused(DevCtx d, int ring_pos, int k
       }
       if (k1 | o1) {
         const float4 q = qb[u];
-        const float4 p = make_float4(q.x, q.y, q.z, (float)(row + c1 / 10000.0));
+        const float4 p = make_float4(q.x, q.y, q.z, (float)(row + cf1));
         const int l1 = lk + (k0 ? 1 : 0), lo1 = lo + (o0 ? 1 : 0);
         if (k1) {
           d.seg_pts[base + l1] = p;
@@ -1001,6 +1002,7 @@ __global__ void __launch_bounds__(T, IPH_MINW) ip_fused_t(DevCtx d, int ring_pos
       col_sets(c0, m0, keep0, outl0, fr0); col_sets(c1, m1, keep1, outl1, fr1);
       ground0 = m0.a; ground1 = m1.a; root0 = m0.x; root1 = m1.x;
     }
+    const double cf0 = d.ip_colfrac[min(c0, H - 1)], cf1 = d.ip_colfrac[min(c1, H - 1)];   // c / 10000.0 (host division: two fp64 divisions per pass and thread less)
 #if IPH_OWN_AHEAD
     unsigned owa[IPF2_ROWS];   // the packed owners of all sixteen rows at once: one round trip in front of the gathers instead of one per group of rows
 #pragma unroll
@@ -1048,7 +1050,7 @@ __global__ void __launch_bounds__(T, IPH_MINW) ip_fused_t(DevCtx d, int ring_pos
         const int lo = (int)S.u.cnt[1][e] + (int)(__popcll(bo0 & below) + __popcll(bo1 & below));
         if (k0 | o0) {
           const float4 q = qa[u];
-          const float4 pp = make_float4(q.x, q.y, q.z, (float)(row + c0 / 10000.0));   // :101
+          const float4 pp = make_float4(q.x, q.y, q.z, (float)(row + cf0));   // :101
           if (k0) {
             o_pts[lk] = pp;
             o_gnd[lk] = (uint8_t)((ground0 >> row) & 1u);
@@ -1060,7 +1062,7 @@ __global__ void __launch_bounds__(T, IPH_MINW) ip_fused_t(DevCtx d, int ring_pos
         }
         if (k1 | o1) {
           const float4 q = qb[u];
-          const float4 pp = make_float4(q.x, q.y, q.z, (float)(row + c1 / 10000.0));
+          const float4 pp = make_float4(q.x, q.y, q.z, (float)(row + cf1));
           const int l1 = lk + (k0 ? 1 : 0), lo1 = lo + (o0 ? 1 : 0);
           if (k1) {
             o_pts[l1] = pp;
