@@ -7,7 +7,7 @@ steps = sys.argv[2] if len(sys.argv) > 2 else "60"
 # (round 5: the current kernel set.  lm_solve runs a second time from the optimum the first run found — one evaluation, a lower bound.  lo_solve_t cannot be
 #  doubled: its second phase-1 run integrates the pose twice, the trajectories leave the map and LaserMapping reports a capacity error; map_update neither:
 #  its second run would take "one run out, one run in" from a list that has already changed.)
-kernels = (os.environ.get("ALEGO_DUP_LIST") or ",ip_fused_h,fe_cand,fe_pickc,fe_ring_out,lo_grid_build,lo_assoc<0>,lo_assoc<1>,lo_solve_t,vox_small,"
+kernels = (os.environ.get("ALEGO_DUP_LIST") or ",ip_fused_h,fe_cand,fe_pickc,fe_ring_out,lo_grid_build,lo_assoc<0>,lo_assoc<1>,vox_small,"
            "lm_grid_build,lm_knn,lm_fit,map_accum,lm_solve,lm_stage").split(",")
 base = None
 for k in kernels:
