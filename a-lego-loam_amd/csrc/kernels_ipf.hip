@@ -574,7 +574,7 @@ __global__ void __launch_bounds__(T, IPH_MINW) ip_fused_t(DevCtx d, int ring_pos
   unsigned* own_g = d.ipf_own + (size_t)slot * (N / 2);                                      // the packed owners between phase B and phase D
   __shared__ IphShared<NW, NP> S;
   const int hpairs = H / 2;
-
+  IPF_TICK(0);
   // ---------------- phase A: projection (as ip_fused; 16-bit owners) ----------------
   for (int v = tid; v < N / 2; v += T) own16w[v] = 0u;
   if (tid == 0) S.nlist = 0;
@@ -665,6 +665,7 @@ __global__ void __launch_bounds__(T, IPH_MINW) ip_fused_t(DevCtx d, int ring_pos
 
   }
   IPH_STOP(1);
+  IPF_TICK(1);
   // ---------------- phase B: ranges, ground, edges — one column pair per thread and pass ----------------
   { IPH_PHASE_CTX;   // (d and P of this phase: the kernel argument read afresh — see IPH_PHASE_CTX)
 #pragma unroll 1
@@ -805,6 +806,7 @@ __global__ void __launch_bounds__(T, IPH_MINW) ip_fused_t(DevCtx d, int ring_pos
 
   }
   IPH_STOP(2);
+  IPF_TICK(3);
   // ---------------- phase C: connected components over vertical runs (ip_fused's steps, column by column from the masks in LDS) ----------------
   { IPH_PHASE_CTX;   // (d and P of this phase: the kernel argument read afresh — see IPH_PHASE_CTX)
   // a cell starts a run when it is active and no down-edge reaches it from below; a run's representative is its first (lowest) cell
@@ -922,6 +924,7 @@ __global__ void __launch_bounds__(T, IPH_MINW) ip_fused_t(DevCtx d, int ring_pos
 
   }
   IPH_STOP(3);
+  IPF_TICK(8);
   // ---------------- phase D: ordered compaction (:158-191) ----------------
   { IPH_PHASE_CTX;   // (d and P of this phase: the kernel argument read afresh — see IPH_PHASE_CTX)
   const unsigned all16 = 0xFFFFu;
@@ -989,6 +992,7 @@ __global__ void __launch_bounds__(T, IPH_MINW) ip_fused_t(DevCtx d, int ring_pos
     int* sc = o_sc;
     sc[SC_M] = S.tot[0]; sc[SC_NOUT] = S.tot[1]; sc[SC_NFEAS] = S.tot[2];
   }
+  IPF_TICK(9);
   const unsigned long long below = (1ull << lane) - 1ull;
   float4* const o_pts = IPH_LATE(seg_pts) + base; uint8_t* const o_gnd = IPH_LATE(seg_ground) + base; int* const o_col = IPH_LATE(seg_col) + base;
   float* const o_rng = IPH_LATE(seg_range) + base; float4* const o_out = IPH_LATE(outlier) + base; int* const o_lab = IPH_LATE(cc_label) + base;
@@ -1088,6 +1092,7 @@ __global__ void __launch_bounds__(T, IPH_MINW) ip_fused_t(DevCtx d, int ring_pos
     }
   }
   }
+  IPF_TICK(10);
 }
 
 static constexpr auto ip_fused_h = ip_fused_t<IPH_T, IPH_NP>;
