@@ -111,18 +111,31 @@ DEV_INLINE int ip_point_cell(const DevCtx& d, const float4 p, bool* valid_out) {
 // add < 1.5e-6 rad, the product with 180 / (pi res) two roundings of a value <= 1.5 H: 4e-6 rad and 4e-7 H cells in total are charged, twice
 // over, in the margins below (at least 0.02 columns / 0.005 rows).  Nothing here has to be bit-exact, so FMA contraction is allowed.
 // Returns true when decided: *cell_out = row * H + col, or -1 when the point has no cell (filtered, non-finite, outside the image).
-DEV_INLINE bool ip_point_quick(const DevCtx& d, const float4 p, float mr, float mc, bool* valid_out, int* cell_out) {
-  const alego_params& P = d.P;
+// the uniform values of ip_point_quick, converted once (round 5: read from the kernel argument inside ip_fused_t's point loop they were 18 scalar loads and
+// 8 v_cvt_f32_f64 per iteration of four points)
+struct IpQuickConst {
+  float th2;          // near_thres^2 as the reference squares it (f32), < 0: no near filter
+  float ang_bottom, inv_res_y, col_scale;   // (float)P.ang_bottom, (float)(1 / ang_res_y), 57.29577951f * (float)(1 / ang_res_x)
+  float two_h;        // (float)(2 H)
+  int H, NS, dense, fast;
+};
+DEV_INLINE IpQuickConst ip_quick_const(const DevCtx& d) {
+  IpQuickConst c;
+  const float th = (float)d.P.near_thres;
+  c.th2 = d.P.near_filter ? th * th : -1.0f;
+  c.ang_bottom = (float)d.P.ang_bottom; c.inv_res_y = (float)d.inv_res_y; c.col_scale = 57.29577951f * (float)d.inv_res_x;
+  c.two_h = (float)(2 * d.H);
+  c.H = d.H; c.NS = d.NS; c.dense = d.P.input_is_dense != 0; c.fast = (d.ip_fast & 3) == 3;
+  return c;
+}
+DEV_INLINE bool ip_point_quick(const IpQuickConst& c, const float4 p, float mr, float mc, bool* valid_out, int* cell_out) {
   const bool finite = isfinite(p.x) && isfinite(p.y) && isfinite(p.z);
-  bool valid = finite || P.input_is_dense != 0;
-  if (valid && P.near_filter) {
-    const float th = (float)P.near_thres;
-    if (p.x * p.x + p.y * p.y + p.z * p.z < th * th) valid = false;  // IP.cpp:91 (same expression as ip_point_cell)
-  }
+  bool valid = finite || c.dense;
+  if (valid && p.x * p.x + p.y * p.y + p.z * p.z < c.th2) valid = false;  // IP.cpp:91 (same expression as ip_point_cell; th2 < 0: filter off, NaN compares false)
   *valid_out = valid;
   *cell_out = -1;
   if (!(valid && finite)) return true;
-  if ((d.ip_fast & 3) != 3) return false;
+  if (!c.fast) return false;
   bool ok;
   int rfl, col;
   {
@@ -131,7 +144,7 @@ DEV_INLINE bool ip_point_quick(const DevCtx& d, const float4 p, float mr, float 
     const float t = p.z * __builtin_amdgcn_rcpf(hf), t2 = t * t;
     ok = hf > 1e-3f && hf < 1e6f && fabsf(t) < 0.6f;
     const float a = t * (0.99997726f + t2 * (-0.33262347f + t2 * (0.19354346f + t2 * (-0.11643287f + t2 * (0.05265332f + t2 * -0.01172120f)))));
-    const float r0 = (a * 57.29577951f + (float)P.ang_bottom) * (float)d.inv_res_y + 0.5f;
+    const float r0 = (a * 57.29577951f + c.ang_bottom) * c.inv_res_y + 0.5f;
     const float rf = floorf(r0), fr = r0 - rf;
     ok = ok && fr >= mr && fr <= 1.0f - mr && rf >= -64.0f && rf <= 4096.0f;
     rfl = (int)rf;
@@ -142,16 +155,19 @@ DEV_INLINE bool ip_point_quick(const DevCtx& d, const float4 p, float mr, float 
     b = ay > ax ? 1.57079633f - b : b;
     b = p.x < 0.0f ? 3.14159265f - b : b;
     b = p.y < 0.0f ? -b : b;
-    const float c0 = (6.28318531f - b) * (57.29577951f * (float)d.inv_res_x);   // (-atan2f(y, x) + 2 pi) * 180 / pi / ang_res_x (:87-95)
+    const float c0 = (6.28318531f - b) * c.col_scale;   // (-atan2f(y, x) + 2 pi) * 180 / pi / ang_res_x (:87-95)
     const float cf = floorf(c0), fc = c0 - cf;
-    ok = ok && fc >= mc && fc <= 1.0f - mc && cf >= 0.0f && cf < (float)(2 * d.H);
+    ok = ok && fc >= mc && fc <= 1.0f - mc && cf >= 0.0f && cf < c.two_h;
     col = (int)cf;
   }
   if (!ok) return false;   // (a NaN anywhere fails a comparison above)
   const int row = rfl >= 0 ? rfl : (rfl == -1 ? 0 : -1);   // (int)r truncates: r in (-1, 1) is row 0
-  if (col >= d.H) col -= d.H;
-  if (row >= 0 && row < d.NS && col >= 0 && col < d.H) *cell_out = col + row * d.H;
+  if (col >= c.H) col -= c.H;
+  if (row >= 0 && row < c.NS && col >= 0 && col < c.H) *cell_out = col + row * c.H;
   return true;
+}
+DEV_INLINE bool ip_point_quick(const DevCtx& d, const float4 p, float mr, float mc, bool* valid_out, int* cell_out) {
+  return ip_point_quick(ip_quick_const(d), p, mr, mc, valid_out, cell_out);
 }
 // the margins of ip_point_quick (cells) for this sensor
 DEV_INLINE void ip_quick_margins(const DevCtx& d, float* mr, float* mc) {

@@ -587,6 +587,7 @@ __global__ void __launch_bounds__(T, IPH_MINW) ip_fused_t(DevCtx d, int ring_pos
     const int list_cap = 2 * H;   // 8 H bytes
     float qmr, qmc;
     ip_quick_margins(d, &qmr, &qmc);
+    const IpQuickConst qc = ip_quick_const(d);
     int vmin = 0x7fffffff, vmax = -1, nvalid = 0;
 #if IPH_PREFETCH
     float4 pnx[4];   // the next iteration's points are in flight while this one's are projected
@@ -612,7 +613,7 @@ __global__ void __launch_bounds__(T, IPH_MINW) ip_fused_t(DevCtx d, int ring_pos
         const int i = i0 + u * T;
         bool valid = false, defer = false;
         int cell = -1;
-        if (i < n) defer = !ip_point_quick(d, pin[u], qmr, qmc, &valid, &cell);
+        if (i < n) defer = !ip_point_quick(qc, pin[u], qmr, qmc, &valid, &cell);
         if (cell >= 0) iph_max16(own16w, cell, (unsigned)(i + 1));   // later points overwrite earlier ones (:102-103)
         if (valid) { vmin = min(vmin, i); vmax = max(vmax, i); ++nvalid; }
         const unsigned long long dm = __ballot(defer);
