@@ -169,6 +169,45 @@ DEV_INLINE bool ip_point_quick(const IpQuickConst& c, const float4 p, float mr, 
 DEV_INLINE bool ip_point_quick(const DevCtx& d, const float4 p, float mr, float mc, bool* valid_out, int* cell_out) {
   return ip_point_quick(ip_quick_const(d), p, mr, mc, valid_out, cell_out);
 }
+// the same decision without a branch (ip_fused_t's point loop evaluates four points per iteration: the early returns above were four nests of exec-mask
+// bookkeeping): every expression is evaluated for every point — a non-finite or filtered point only produces values nobody looks at — and the three
+// outcomes are selected at the end.  Returns "decided"; *cell_out as above.
+DEV_INLINE bool ip_point_quick_bf(const IpQuickConst& c, const float4 p, float mr, float mc, bool* valid_out, int* cell_out) {
+  const bool finite = isfinite(p.x) && isfinite(p.y) && isfinite(p.z);
+  const bool valid = (finite || c.dense) && !(p.x * p.x + p.y * p.y + p.z * p.z < c.th2);
+  bool ok;
+  int rfl, col;
+  {
+#pragma clang fp contract(fast)
+    const float h2 = p.x * p.x + p.y * p.y, hf = __builtin_amdgcn_sqrtf(h2);
+    const float t = p.z * __builtin_amdgcn_rcpf(hf), t2 = t * t;
+    ok = hf > 1e-3f && hf < 1e6f && fabsf(t) < 0.6f;
+    const float a = t * (0.99997726f + t2 * (-0.33262347f + t2 * (0.19354346f + t2 * (-0.11643287f + t2 * (0.05265332f + t2 * -0.01172120f)))));
+    const float r0 = (a * 57.29577951f + c.ang_bottom) * c.inv_res_y + 0.5f;
+    const float rf = floorf(r0), fr = r0 - rf;
+    ok = ok && fr >= mr && fr <= 1.0f - mr && rf >= -64.0f && rf <= 4096.0f;
+    rfl = (int)rf;
+    const float ax = fabsf(p.x), ay = fabsf(p.y), mn = fminf(ax, ay), mx = fmaxf(ax, ay);
+    ok = ok && mx > 1e-3f && mx < 1e6f;
+    const float u = mn * __builtin_amdgcn_rcpf(mx), u2 = u * u;
+    float b = u * (0.99997726f + u2 * (-0.33262347f + u2 * (0.19354346f + u2 * (-0.11643287f + u2 * (0.05265332f + u2 * -0.01172120f)))));
+    b = ay > ax ? 1.57079633f - b : b;
+    b = p.x < 0.0f ? 3.14159265f - b : b;
+    b = p.y < 0.0f ? -b : b;
+    const float c0 = (6.28318531f - b) * c.col_scale;
+    const float cf = floorf(c0), fc = c0 - cf;
+    ok = ok && fc >= mc && fc <= 1.0f - mc && cf >= 0.0f && cf < c.two_h;
+    col = (int)cf;
+  }
+  const bool live = valid && finite;            // the point can have a cell at all
+  const bool dec = live && c.fast && ok;        // ... and the estimate decides it
+  const int row = rfl >= 0 ? rfl : (rfl == -1 ? 0 : -1);
+  col = col >= c.H ? col - c.H : col;
+  const bool in = row >= 0 && row < c.NS && col >= 0 && col < c.H;
+  *valid_out = valid;
+  *cell_out = (dec && in) ? col + row * c.H : -1;
+  return !live || dec;
+}
 // the margins of ip_point_quick (cells) for this sensor
 DEV_INLINE void ip_quick_margins(const DevCtx& d, float* mr, float* mc) {
   *mr = fmaxf(0.005f, 8e-6f * 57.29577951f * (float)d.inv_res_y + 1e-5f);

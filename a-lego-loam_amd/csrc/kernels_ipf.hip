@@ -608,22 +608,53 @@ __global__ void __launch_bounds__(T, IPH_MINW) ip_fused_t(DevCtx d, int ring_pos
 #pragma unroll
       for (int u = 0; u < 4; ++u) pin[u] = pts[min(i0 + u * T, n - 1)];
 #endif
+      // the four points of the iteration side by side: decisions without branches, the four owner words fetched together, one ballot for the (rare) deferrals
+      int cellv[4];
+      bool deferv[4];
+      bool anydefer = false;
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int i = i0 + u * T;
-        bool valid = false, defer = false;
-        int cell = -1;
-        if (i < n) defer = !ip_point_quick(qc, pin[u], qmr, qmc, &valid, &cell);
-        if (cell >= 0) iph_max16(own16w, cell, (unsigned)(i + 1));   // later points overwrite earlier ones (:102-103)
-        if (valid) { vmin = min(vmin, i); vmax = max(vmax, i); ++nvalid; }
-        const unsigned long long dm = __ballot(defer);
-        if (dm) {   // wavefront-aggregated append
-          int lb = 0;
-          if (lane == 0) lb = atomicAdd(&S.nlist, (int)__popcll(dm));
-          lb = __shfl(lb, 0, 64);
-          if (defer) {
-            const int pos = lb + (int)__popcll(dm & ((1ull << lane) - 1ull));
-            if (pos < list_cap) s_list[pos] = i;
+        const bool in = i < n;
+        bool valid;
+        int cell;
+        const bool dec = ip_point_quick_bf(qc, pin[u], qmr, qmc, &valid, &cell);
+        cellv[u] = in ? cell : -1;
+        deferv[u] = in && !dec;
+        anydefer |= deferv[u];
+        const bool v = in && valid;
+        vmin = min(vmin, v ? i : 0x7fffffff); vmax = max(vmax, v ? i : -1); nvalid += v ? 1 : 0;
+      }
+      unsigned oldw[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) oldw[u] = __hip_atomic_load(own16w + (max(cellv[u], 0) >> 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {   // later points overwrite earlier ones (:102-103): a 16-bit maximum through the aligned word (iph_max16, its first read hoisted)
+        if (cellv[u] >= 0) {
+          unsigned* w = own16w + (cellv[u] >> 1);
+          const int sh = (cellv[u] & 1) * 16;
+          const unsigned val = (unsigned)(i0 + u * T + 1);
+          unsigned old = oldw[u];
+          while (((old >> sh) & 0xFFFFu) < val) {
+            const unsigned nw = (old & ~(0xFFFFu << sh)) | (val << sh);
+            const unsigned got = atomicCAS(w, old, nw);
+            if (got == old) break;
+            old = got;
+          }
+        }
+      }
+      if (__ballot(anydefer)) {   // wavefront-aggregated append
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const unsigned long long dm = __ballot(deferv[u]);
+          if (dm) {
+            int lb = 0;
+            if (lane == 0) lb = atomicAdd(&S.nlist, (int)__popcll(dm));
+            lb = __shfl(lb, 0, 64);
+            if (deferv[u]) {
+              const int pos = lb + (int)__popcll(dm & ((1ull << lane) - 1ull));
+              if (pos < list_cap) s_list[pos] = i0 + u * T;
+            }
           }
         }
       }
