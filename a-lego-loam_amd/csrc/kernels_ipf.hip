@@ -511,13 +511,17 @@ template <class F> DEV_INLINE F iph_karg(unsigned off) {
 // LDS to spare at 16 x 4000)
 template <int NW, int NP>
 struct IphShared {
+  static_assert(3 * NW >= IPF2_ROWS + 1, "the next-pass column shares the area of the phase-A reduction");
   union {
     struct { float first_r[NW][IPF2_ROWS]; unsigned first_act[NW]; } b;   // ranges / active mask of the first column of every wavefront of the pass in flight
     unsigned short cnt[3][IPF2_ROWS * NP * NW];   // per (row, pass, wavefront) = column-ascending inside a row: kept cells, outliers, feasible roots -> exclusive prefixes (< 65536)
   } u;
   float col0_r[IPF2_ROWS];             // column 0 (right neighbour of the last column, :241-248)
   unsigned col0_act;
-  int red[3][NW];
+  union {
+    int red[3][NW];                                            // phase A: per-wavefront first / last valid point, valid count
+    struct { float np_r[IPF2_ROWS]; unsigned np_act; } np;     // phase B: the first column of the NEXT pass (right neighbour of this pass's last column), one row per lane
+  };
   int wtot[3][IPF2_ROWS * NP * NW / 64];
   int tot[3];
   int nlist;
@@ -752,6 +756,24 @@ __global__ void __launch_bounds__(T, IPH_MINW) ip_fused_t(DevCtx d, int ring_pos
       for (int r = 0; r < IPF2_ROWS; ++r) S.col0_r[r] = rng0[r];
       S.col0_act = act0;
     }
+    // The first column of the NEXT pass is the right neighbour of this pass's last column.  Sixteen lanes of the last wavefront take one row each — ONE gather
+    // round trip — where the pass's last thread used to walk the sixteen rows on its own, every gather waiting for the one before it (~25 us with the
+    // whole workgroup waiting at the next barrier; round 5, found in the ISA).  Same points, same differences, same predicates.
+    {
+      const int pil = (T - 1) + p * T;   // the pair of the pass's last thread
+      if (p + 1 < NP && pil < hpairs - 1 && wave == NW - 1 && lane < IPF2_ROWS) {
+        const int row = lane, cx = 2 * pil + 2;
+        const unsigned ow = row < NS ? (own16w[(row * H + cx) >> 1] & 0xFFFFu) : 0u;
+        const float4 q = pts[max((int)ow - 1, 0)];
+        const bool ok = ow != 0u;
+        const float lx = __shfl_up(q.x, 1, 64), ly = __shfl_up(q.y, 1, 64), lz = __shfl_up(q.z, 1, 64);
+        const bool lok = __shfl_up(ok ? 1 : 0, 1, 64) != 0;
+        const bool g = row >= 1 && row - 1 < P.ground_scan_id && ok && lok && ip_is_ground(d, q.x - lx, q.y - ly, q.z - lz);
+        const unsigned gm = (unsigned)__ballot(g) & 0xFFFFu, fm = (unsigned)__ballot(ok) & 0xFFFFu;
+        S.np.np_r[row] = ok ? sqrtf(q.x * q.x + q.y * q.y + q.z * q.z) : -1.0f;
+        if (lane == 0) S.np.np_act = fm & ~(gm | (gm >> 1));   // (a ground pair (row - 1, row) marks both of its rows, :128-129)
+      }
+    }
     __syncthreads();
     // the column to the right of c1: the next thread's first column; column 0 behind the last one (:241-248); the first column of the
     // NEXT pass behind this pass's last thread, which gathers that one column itself
@@ -768,21 +790,9 @@ __global__ void __launch_bounds__(T, IPH_MINW) ip_fused_t(DevCtx d, int ring_pos
       nb_act = wrap ? S.col0_act : S.u.b.first_act[sw];
     }
     if (nextpass) {
-      const int cx = c0 + 2;   // (< H: not the wrap)
-      unsigned fl = 0, gd = 0;
-      float lx = 0, ly = 0, lz = 0;
-      bool lok = false;
 #pragma unroll
-      for (int row = 0; row < IPF2_ROWS; ++row) {
-        const unsigned ow = row < NS ? (own16w[(row * H + cx) >> 1] & 0xFFFFu) : 0u;
-        const float4 q = pts[max((int)ow - 1, 0)];
-        const bool ok = ow != 0u;
-        nbr[row] = ok ? sqrtf(q.x * q.x + q.y * q.y + q.z * q.z) : -1.0f;
-        if (ok) fl |= 1u << row;
-        if (row >= 1 && row - 1 < P.ground_scan_id && ok && lok && ip_is_ground(d, q.x - lx, q.y - ly, q.z - lz)) gd |= 3u << (row - 1);
-        lx = q.x; ly = q.y; lz = q.z; lok = ok;
-      }
-      nb_act = fl & ~gd;
+      for (int r = 0; r < IPF2_ROWS; ++r) nbr[r] = S.np.np_r[r];
+      nb_act = S.np.np_act;
     }
     unsigned redge0 = 0, redge1 = 0, down0 = 0, down1 = 0;
     if (colv) {
