@@ -762,7 +762,7 @@ int alego_lo_get_undistorted(alego_handle* h, int slot, alego_point* out, int32_
   if (cap < 0 || (cap > 0 && !out)) return ALEGO_ERR_ARG;
   hipSetDevice(h->device);
   int M = 0;
-  HIP_TRY(h, hipMemcpyAsync(&M, h->d.scal + (size_t)slot * SC_COUNT + SC_M, 4, hipMemcpyDeviceToHost, stream_of(h, slot)));
+  HIP_TRY(h, hipMemcpyAsync(&M, h->d.scal + (size_t)slot * SC_COUNT + SC_M_DSK, 4, hipMemcpyDeviceToHost, stream_of(h, slot)));   // lo_deskew's own count, not SC_M
   HIP_TRY(h, hipStreamSynchronize(stream_of(h, slot)));
   if (M > cap) return ALEGO_ERR_CAPACITY;
   if (M > 0) HIP_TRY(h, hipMemcpy(out, h->d.seg_dsk + (size_t)slot * h->d.N, (size_t)M * sizeof(alego_point), hipMemcpyDeviceToHost));
@@ -1012,6 +1012,12 @@ int alego_debug_set_option(alego_handle* h, const char* name, int value) {
   else if (s == "ALEGO_LO_GRID") d.opt_lo_grid = value != 0;
   else if (s == "ALEGO_FE_SPIN") d.opt_fo_spin = value;
   else if (s == "ALEGO_FE_PAD8") d.opt_fo_pad8 = value != 0;
+  else if (s == "ALEGO_FE_ERR_CLEAR") {   // the per-slot reset of the sticky SC_FE_ERR (dev_common.h): value = slot, -1 = every slot; the caller has drained the handle's streams
+    if (value < -1 || value >= d.n_slots) return ALEGO_ERR_ARG;
+    HIP_TRY(h, hipDeviceSynchronize());
+    if (value >= 0) HIP_TRY(h, hipMemset(d.scal + (size_t)value * SC_COUNT + SC_FE_ERR, 0, 4));
+    else HIP_TRY(h, hipMemset2D(d.scal + SC_FE_ERR, SC_COUNT * sizeof(int), 0, 4, d.n_slots));
+  }
   else if (s == "ALEGO_MAP_MERGE") { if (int r = lm_host_set_map_merge(h->lm, value != 0, &h->err)) return r; d.opt_map_merge = value != 0; }
   else if (s == "ALEGO_IP_FAST") d.ip_fast = h->ip_fast_capable & value;
   else if (s == "ALEGO_POKE_GUARD") { HIP_TRY(h, hipMemset(d.scal + (size_t)d.n_slots * SC_COUNT + value, 0xFF, 4)); }   // tests of the guard pages: a write `value` ints past the end of an array
@@ -1130,7 +1136,7 @@ int alego_debug_get(alego_handle* h, int slot, const char* name, void* out, int 
   else if (s == "parent") set(d.parent + base, d.N, 2);
   else if (s == "seg_cloud") set(d.seg_pts + base, (size_t)M * 4, 0);
   else if (s == "outlier") set(d.outlier + base, (size_t)sc[SC_NOUT] * 4, 0);
-  else if (s == "undistorted" && d.P.deskew_mode) set(d.seg_dsk + base, (size_t)M * 4, 0);
+  else if (s == "undistorted" && d.P.deskew_mode) set(d.seg_dsk + base, (size_t)sc[SC_M_DSK] * 4, 0);
   else if (s == "imu_ptr") set(d.imu_ptr + (size_t)slot * 4, 3, 2);
   else if (s == "imu_ring") set(d.imu_ring + (size_t)slot * ALEGO_IMU_Q * 10, ALEGO_IMU_Q * 10, 1);
   else if (s == "seg_ground") set(d.seg_ground + base, M, 3);

@@ -31,10 +31,12 @@ enum {
   SC_LM_FLAGS,
   SC_PVALID_OUT,  // valid input points of the last projected scan (SC_PVALID is an accumulator, cleared by ip_front)
   SC_FE_EPOCH,    // feature-extraction launches of this slot so far (fe_front increments it; tags the ring counts fe_ring_out's workgroups publish to each other)
-  SC_FE_ERR,      // != 0 (sticky for the life of the handle: there is no per-slot reset, the host that gets ALEGO_ERR_HIP destroys the handle): a workgroup of fe_ring_out gave up waiting for the counts of the rings below it; the slot's less_flat
-                  // cloud is then treated as EMPTY by everything that reads it (lo_grid_build, lo_assoc, lm_stage) and the host gets ALEGO_ERR_HIP (fetch_pose)
+  SC_FE_ERR,      // != 0: a workgroup of fe_ring_out gave up waiting for the counts of the rings below it; the slot's less_flat cloud is then treated as EMPTY by
+                  // everything that reads it (lo_grid_build, lo_assoc, lm_stage) and the host gets ALEGO_ERR_HIP (fetch_pose).  Sticky until the host clears it
+                  // with alego_debug_set_option("ALEGO_FE_ERR_CLEAR", slot) (-1: every slot) — a slot that gave up once keeps failing loudly, never silently
   SC_FE_TICKET,   // fe_ring_out: rings of this launch handed out so far (a workgroup's ring = its ticket, so the rings it waits for belong to workgroups that
                   // are already running whatever order the dispatchers place them in; fe_pickc resets it)
+  SC_M_DSK,       // points lo_deskew wrote into seg_dsk (/undistorted): its own count, because ImageProjection of the NEXT scan may rewrite SC_M before a host fetches the cloud
   SC_COUNT = 32
 };
 

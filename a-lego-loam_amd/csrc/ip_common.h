@@ -186,7 +186,7 @@ DEV_INLINE bool ip_point_quick_bf(const IpQuickConst& c, const float4 p, float m
     const float r0 = (a * 57.29577951f + c.ang_bottom) * c.inv_res_y + 0.5f;
     const float rf = floorf(r0), fr = r0 - rf;
     ok = ok && fr >= mr && fr <= 1.0f - mr && rf >= -64.0f && rf <= 4096.0f;
-    rfl = (int)rf;
+    rfl = (int)(ok ? rf : 0.0f);   // (a float -> int conversion of NaN / inf / out-of-range values is undefined: convert only what the checks above admitted)
     const float ax = fabsf(p.x), ay = fabsf(p.y), mn = fminf(ax, ay), mx = fmaxf(ax, ay);
     ok = ok && mx > 1e-3f && mx < 1e6f;
     const float u = mn * __builtin_amdgcn_rcpf(mx), u2 = u * u;
@@ -197,7 +197,7 @@ DEV_INLINE bool ip_point_quick_bf(const IpQuickConst& c, const float4 p, float m
     const float c0 = (6.28318531f - b) * c.col_scale;
     const float cf = floorf(c0), fc = c0 - cf;
     ok = ok && fc >= mc && fc <= 1.0f - mc && cf >= 0.0f && cf < c.two_h;
-    col = (int)cf;
+    col = (int)(ok ? cf : 0.0f);
   }
   const bool live = valid && finite;            // the point can have a cell at all
   const bool dec = live && c.fast && ok;        // ... and the estimate decides it

@@ -446,7 +446,7 @@ extern "C" void alego_fo_times(long long* out) { (void)hipMemcpyFromSymbol(out, 
 #ifndef FO_TICK_RING
 #define FO_TICK_RING 8
 #endif
-#define FO_TICK(k) do { if (threadIdx.x == 0 && blockIdx.y == FO_TICK_RING && blockIdx.x == 0) fo_times[k] = wall_clock64(); } while (0)
+#define FO_TICK(k) do { if (threadIdx.x == 0 && ring == FO_TICK_RING && blockIdx.x == 0) fo_times[k] = wall_clock64(); } while (0)
 #elif defined(FO_STOP_AFTER)
 // development (instruction counts per phase, tools/fo_phase_counts.sh): the ring stops after phase FO_STOP_AFTER — its count is published first so that no ring above it spins
 #define FO_TICK(k) do { if ((k) == FO_STOP_AFTER) { if (threadIdx.x == 0) __hip_atomic_store(&d.fe_sync[(size_t)slot * NS + ring], (epoch << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; } } while (0)
@@ -827,7 +827,7 @@ __global__ void __launch_bounds__(FO_BLOCK) fe_ring_out(DevCtx d) {
       __syncthreads();
       FO_TICK(12);
 #ifdef ALEGO_TIMING
-      if (tid == 0 && blockIdx.y == FO_TICK_RING && blockIdx.x == 0) { int mxb = 0; for (int b = 0; b < nb; ++b) mxb = max(mxb, s_boff[b + 1] - s_boff[b]); fo_times[16] = n_all; fo_times[17] = nruns; fo_times[18] = nrv; fo_times[19] = nb; fo_times[20] = mxb; }
+      if (tid == 0 && ring == FO_TICK_RING && blockIdx.x == 0) { int mxb = 0; for (int b = 0; b < nb; ++b) mxb = max(mxb, s_boff[b + 1] - s_boff[b]); fo_times[16] = n_all; fo_times[17] = nruns; fo_times[18] = nrv; fo_times[19] = nb; fo_times[20] = mxb; }
 #endif
       for (int t = tid; t < nrv; t += FO_BLOCK) {
         const uint32_t mine = keyed ? k_tmp[t] : 0u;

@@ -18,6 +18,7 @@
 // Against ip_project + ip_front + cc_lds16: no owner / flag images in HBM, no tag reset protocol between workgroups, one launch
 // instead of three, and the per-cell passes of cc_lds16 (29 cells x 10 passes per thread) become bit operations on 16-bit
 // row masks.  HBM traffic: 16 P in, one gather of the filled cells, one of the kept cells, 25 M + 16 O out.
+#include <type_traits>
 #include <algorithm>
 #include <cstdlib>
 #include "dev_common.h"
@@ -1139,6 +1140,13 @@ __global__ void __launch_bounds__(T, IPH_MINW) ip_fused_t(DevCtx d, int ring_pos
 
 static constexpr auto ip_fused_h = ip_fused_t<IPH_T, IPH_NP>;
 static constexpr auto ip_fused_w = ip_fused_t<IPW_T, IPW_NP>;
+// IPH_PHASE_CTX / IPH_LATE read DevCtx members at offsetof(DevCtx, member) of the kernel-argument segment: that is only the by-value argument `d` while DevCtx is the
+// FIRST explicit parameter of ip_fused_t (offset 0 of the segment, HSA code-object ABI) and a plain-layout struct.  Enforced here, not by a comment:
+template <class F> struct iph_first_arg;
+template <class A0, class... R> struct iph_first_arg<void (*)(A0, R...)> { typedef A0 type; };
+static_assert(std::is_same<iph_first_arg<decltype(&ip_fused_t<IPH_T, IPH_NP>)>::type, DevCtx>::value && std::is_same<iph_first_arg<decltype(&ip_fused_t<IPW_T, IPW_NP>)>::type, DevCtx>::value,
+              "ip_fused_t: DevCtx must stay the first kernel parameter (IPH_PHASE_CTX / IPH_LATE read it at offset 0 of the kernel-argument segment)");
+static_assert(std::is_standard_layout<DevCtx>::value && std::is_trivially_copyable<DevCtx>::value, "DevCtx is passed by value and re-read through offsetof()");
 
 void launch_ip_fused(const DevCtx& d, int ring_pos, bool keep_images, hipStream_t st) {
   if (d.opt_ip_half && iph_eligible(d)) { ALEGO_LAUNCH(ip_fused_h, dim3(d.n_launch), dim3(IPH_T), iph_lds_bytes(d) + iph_pad(), st, d, ring_pos, keep_images ? 1 : 0); return; }

@@ -814,6 +814,7 @@ __global__ void __launch_bounds__(DSK_T) lo_deskew(DevCtx d) {
   int* ptr = d.imu_ptr + (size_t)slot * 4;
   const double* ring = d.imu_ring + (size_t)slot * ALEGO_IMU_Q * 10;
   const int last = ptr[0], it0 = ptr[2];
+  if (tid == 0) d.scal[(size_t)slot * SC_COUNT + SC_M_DSK] = M;   // (what alego_lo_get_undistorted copies: SC_M belongs to ImageProjection, which may already be a scan ahead)
   if (!(last > 0)) {                                                                  // :593
     for (int i = tid; i < M; i += DSK_T) out[i] = in[i];
     return;

@@ -13,7 +13,7 @@
 //   ceres::Solve, TrustRegionMinimizer + LevenbergMarquardtStrategy + DENSE_QR +
 //     HuberLoss corrector (Ceres 1.13/1.14 defaults)              -> ceres_like_solve()
 //   Eigen AngleAxis/Quaternion composition, SelfAdjointEigenSolver<Matrix3d>,
-//     colPivHouseholderQr 5x3 least squares                       -> quat_*, eig3(), qr_solve()
+//     colPivHouseholderQr 5x3 least squares                       -> quat_*, eig3(), colpiv_qr_solve()
 //   GTSAM iSAM2 with a prior + chain of between factors and no loop closure
 //     (estimate == initial values)                                -> key pose pass-through
 // Where those libraries leave an order unspecified (unstable std::sort ties,
@@ -478,6 +478,108 @@ void qr_solve(double* A, double* b, int m, int n, double* x, double* v) {
     for (int j = k + 1; j < n; ++j) s -= A[(size_t)j * m + k] * x[j];
     x[k] = s / A[(size_t)k * m + k];
   }
+}
+// Eigen::ColPivHouseholderQR<Matrix<double, M, N>>::compute() + solve() (Eigen 3.3.x: ColPivHouseholderQR.h computeInPlace / _solve_impl, Householder.h
+// makeHouseholder / applyHouseholderOnTheLeft) — what `matA0.colPivHouseholderQr().solve(matB0)` of laserMapping.cpp:435 runs.  Restated from the published
+// algorithm (Eigen is not in this image; SURVEY.md B: 3.3.4 is an era guess, 3.3.0 - 3.4.0 share this code):
+//   * column norms up front; at step k the remaining column of largest (down-dated) norm is swapped into place;
+//   * nonzero_pivots = first k whose pivot column has  norm^2 < (max initial norm * eps)^2 / rows * (rows - k)   ("Track the number of meaningful pivots", bug 941);
+//   * Householder reflector with beta = -sign(c0) * ||col||, essential = tail / (c0 - beta), tau = (beta - c0) / beta; nothing to do when the tail is <= DBL_MIN;
+//   * LAPACK xGEQP3's norm down-date (LAWN 176) with recomputation when the estimate has lost half its digits;
+//   * solve: c = H_{r-1} ... H_0 b with r = nonzero_pivots, back-substitution on the leading r x r triangle, x[perm[i]] = c[i] for i < r and **0 for i >= r**
+//     (a rank-deficient neighbourhood — collinear or coincident map points — gets a FINITE basic solution, not a division by a ~1e-17 pivot).
+// Note solve() uses nonzeroPivots() (the tiny threshold above), not rank() / setThreshold(): that is Eigen's code, and what this follows.
+// Sums run in index order (Eigen's unrolled / SSE reductions of these 3- to 5-element vectors may associate differently: last-bit differences, no test can pin
+// them without Eigen).  A is m x n column-major and is overwritten by the factorisation; m <= 8, n <= 8.
+int colpiv_qr_solve(double* A, const double* b_in, int m, int n, double* x) {
+  const double eps = 2.220446049250313e-16, tiny = 2.2250738585072014e-308;
+  const int size = m < n ? m : n;
+  double hc[8], nu[8], nd[8], c[8];
+  int trans[8], perm[8];
+  double maxn = 0;
+  for (int k = 0; k < n; ++k) {
+    double s2 = 0;
+    for (int i = 0; i < m; ++i) s2 += A[k * m + i] * A[k * m + i];
+    nd[k] = nu[k] = std::sqrt(s2);
+    if (nu[k] > maxn) maxn = nu[k];
+  }
+  const double threshold_helper = (maxn * eps) * (maxn * eps) / (double)m;
+  const double downdate_threshold = std::sqrt(eps);
+  int nonzero = size;
+  for (int k = 0; k < size; ++k) {
+    int big = k;
+    for (int j = k + 1; j < n; ++j) if (nu[j] > nu[big]) big = j;            // maxCoeff: the first of equal maxima
+    const double big_sq = nu[big] * nu[big];
+    if (nonzero == size && big_sq < threshold_helper * (double)(m - k)) nonzero = k;
+    trans[k] = big;
+    if (big != k) {
+      for (int i = 0; i < m; ++i) std::swap(A[k * m + i], A[big * m + i]);
+      std::swap(nu[k], nu[big]); std::swap(nd[k], nd[big]);
+    }
+    double* col = A + k * m;
+    double tail2 = 0;
+    for (int i = k + 1; i < m; ++i) tail2 += col[i] * col[i];
+    const double c0 = col[k];
+    double beta, tau;
+    if (tail2 <= tiny) { tau = 0; beta = c0; for (int i = k + 1; i < m; ++i) col[i] = 0; }
+    else {
+      beta = std::sqrt(c0 * c0 + tail2);
+      if (c0 >= 0) beta = -beta;
+      for (int i = k + 1; i < m; ++i) col[i] = col[i] / (c0 - beta);
+      tau = (beta - c0) / beta;
+    }
+    hc[k] = tau;
+    col[k] = beta;
+    if (m - k == 1) { for (int j = k + 1; j < n; ++j) A[j * m + k] *= 1.0 - tau; }
+    else if (tau != 0) {
+      for (int j = k + 1; j < n; ++j) {
+        double* cj = A + j * m;
+        double t = 0;
+        for (int i = k + 1; i < m; ++i) t += col[i] * cj[i];
+        t += cj[k];
+        cj[k] -= tau * t;
+        for (int i = k + 1; i < m; ++i) cj[i] -= tau * col[i] * t;
+      }
+    }
+    for (int j = k + 1; j < n; ++j) {
+      if (nu[j] != 0) {
+        double t = std::fabs(A[j * m + k]) / nu[j];
+        t = (1.0 + t) * (1.0 - t);
+        t = t < 0 ? 0 : t;
+        const double q = nu[j] / nd[j];
+        const double t2 = t * (q * q);
+        if (t2 <= downdate_threshold) {
+          double s2 = 0;
+          for (int i = k + 1; i < m; ++i) s2 += A[j * m + i] * A[j * m + i];
+          nd[j] = nu[j] = std::sqrt(s2);
+        } else nu[j] *= std::sqrt(t);
+      }
+    }
+  }
+  for (int k = 0; k < n; ++k) perm[k] = k;
+  for (int k = 0; k < size; ++k) std::swap(perm[k], perm[trans[k]]);
+  if (nonzero == 0) { for (int k = 0; k < n; ++k) x[k] = 0; return 0; }
+  for (int i = 0; i < m; ++i) c[i] = b_in[i];
+  for (int k = 0; k < nonzero; ++k) {       // (H_0 H_1 ...)^T b : H_0 first
+    const double tau = hc[k];
+    const double* col = A + k * m;
+    if (m - k == 1) c[k] *= 1.0 - tau;
+    else if (tau != 0) {
+      double t = 0;
+      for (int i = k + 1; i < m; ++i) t += col[i] * c[i];
+      t += c[k];
+      c[k] -= tau * t;
+      for (int i = k + 1; i < m; ++i) c[i] -= tau * col[i] * t;
+    }
+  }
+  for (int k = nonzero - 1; k >= 0; --k) {  // triangularView<Upper>().solveInPlace
+    double sum = c[k];
+    for (int j = k + 1; j < nonzero; ++j) sum -= A[j * m + k] * c[j];
+    c[k] = sum / A[k * m + k];
+  }
+  for (int i = 0; i < nonzero; ++i) x[perm[i]] = c[i];
+  for (int i = nonzero; i < n; ++i) x[perm[i]] = 0;
+  return nonzero;
 }
 void qr_solve(std::vector<double>& A, std::vector<double>& b, int m, int n, double* x) {
   std::vector<double> v(m);
@@ -1399,13 +1501,13 @@ struct LaserMapping {
         Pt sel; point_associate_to_map(laser_surf_total_ds[i], sel);
         if (kd_surf_map.knn(sel, 5, nidx, ndist) < 5) continue;
         if ((double)ndist[4] < P.knn_max_dist) {
-          double A[15], b[5] = {-1.0, -1.0, -1.0, -1.0, -1.0}, hv[5];   // Matrix<double, 5, 3> / Matrix<double, 5, 1>: fixed size, no heap
+          double A[15], b[5] = {-1.0, -1.0, -1.0, -1.0, -1.0};   // Matrix<double, 5, 3> / Matrix<double, 5, 1>: fixed size, no heap
           for (int j = 0; j < 5; ++j) {
             const Pt& m = surf_from_map_ds[nidx[j]];
             A[0 * 5 + j] = m.x; A[1 * 5 + j] = m.y; A[2 * 5 + j] = m.z;
           }
           double norm[3];
-          qr_solve(A, b, 5, 3, norm, hv);
+          colpiv_qr_solve(A, b, 5, 3, norm);   // matA0.colPivHouseholderQr().solve(matB0), :435
           double nn = std::sqrt(norm[0] * norm[0] + norm[1] * norm[1] + norm[2] * norm[2]);
           double negative_OA_dot_norm = 1 / nn;
           for (int a = 0; a < 3; ++a) norm[a] /= nn;
@@ -1886,6 +1988,8 @@ int oracle_knn(const alego_point* cloud, int n, const alego_point* q, int nq, in
 }
 
 void oracle_eig3(const double* A9, double* lam3, double* V9) { eig3(A9, lam3, V9); }
+// Eigen::ColPivHouseholderQR compute + solve of an m x n column-major system (m, n <= 8); A is overwritten.  Returns nonzeroPivots().
+int oracle_colpiv_qr_solve(double* A, const double* b, int m, int n, double* x) { return (m < 1 || n < 1 || m > 8 || n > 8) ? -1 : colpiv_qr_solve(A, b, m, n, x); }
 
 // ---- loop closure (src/laserMapping.cpp:652-824) ------------------------------------------------------------------------------
 // detectLoopClosure :760-790: the key pose nearest to the current position (radius search, ascending distance) that is more than

@@ -46,6 +46,8 @@ def lib():
         L.oracle_solve.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_double, C.c_void_p]
         L.oracle_knn.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.oracle_eig3.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.oracle_colpiv_qr_solve.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.oracle_colpiv_qr_solve.restype = C.c_int
         for f in ("oracle_atan2f_array", "oracle_hypotf_array", "oracle_libm_atan2f_array", "oracle_libm_hypotf_array"):
             getattr(L, f).argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.oracle_lm_set_keypose.argtypes = [C.c_void_p, C.c_int, C.c_void_p]

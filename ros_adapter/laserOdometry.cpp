@@ -90,11 +90,14 @@ class LaserOdometry : public nodelet::Nodelet {
       in.orientation[0] = info->startOrientation; in.orientation[1] = info->endOrientation; in.orientation[2] = info->orientationDiff;
       in.stamp = seg->header.stamp.toSec();   // t1 (:111)
       alego_pose odom;
-      int flags;
+      int flags, nu = -1;
       {
         alego_ros::HandleLock lock(h_);
         flags = alego_lo_process(h_, &in, &f, &odom);
         if (flags < 0) { NODELET_ERROR("alego_lo_process: %s", alego_last_error(h_)); continue; }
+        // /undistorted is fetched under the SAME lock as the scan's LaserOdometry step: the three nodelets share slot 0, and ImageProjection of the
+        // next scan may otherwise run in between (the getter also reads lo_deskew's own point count, SC_M_DSK, not ImageProjection's)
+        if (pub_undistorted_pc_.getNumSubscribers() > 0) nu = alego_lo_get_undistorted(h_, 0, undist_.data(), n_);
       }
       std_msgs::Header hd = seg->header;
       hd.frame_id = "/laser";
@@ -106,11 +109,7 @@ class LaserOdometry : public nodelet::Nodelet {
       };
       pub(pub_corner_, f.sharp, f.n_sharp); pub(pub_corner_less_, f.less_sharp, f.n_less_sharp);   // :299-314
       pub(pub_surf_, f.flat, f.n_flat); pub(pub_surf_less_, f.less_flat, f.n_less_flat);
-      if (pub_undistorted_pc_.getNumSubscribers() > 0) {                                             // :718-725
-        int nu;
-        { alego_ros::HandleLock lock(h_); nu = alego_lo_get_undistorted(h_, 0, undist_.data(), n_); }
-        if (nu >= 0) pub(pub_undistorted_pc_, undist_.data(), nu);   // (ALEGO_ERR_ARG: deskew_mode = 0, adjustDistortion is not run — nothing to publish, as in the reference)
-      }
+      if (nu >= 0) pub(pub_undistorted_pc_, undist_.data(), nu);   // :718-725 (ALEGO_ERR_ARG: deskew_mode = 0, adjustDistortion is not run — nothing to publish, as in the reference)
       if (!(flags & ALEGO_FLAG_LO_INIT)) {                                                           // :513-529 / LO.cpp:588-608
         const char* child = standalone_frames_ ? "/base_link" : "/laser";
         if (standalone_frames_) { alego_pose b; if (alego_pose_o2b(&odom, tf_b2l_, &b) == ALEGO_OK) odom = b; }

@@ -202,6 +202,99 @@ def test_kdtree_knn_equals_brute_force():
         assert_bit_equal(dist[i], d[order], f"query {i} distances")
 
 
+def _plane_neighbourhoods(rng):
+    """(name, 5 x 3 points) cases for the plane fit of laserMapping.cpp:425-452: what a voxel-filtered map hands the 5-NN search."""
+    out = []
+    for k in range(300):      # well-conditioned: five noisy points of a random plane 5 - 60 m from the origin
+        n = rng.standard_normal(3); n /= np.linalg.norm(n)
+        u = np.cross(n, rng.standard_normal(3)); u /= np.linalg.norm(u); v = np.cross(n, u)
+        c = n * rng.uniform(5, 60)
+        out.append(("plane", c + np.outer(rng.uniform(-0.5, 0.5, 5), u) + np.outer(rng.uniform(-0.5, 0.5, 5), v) + rng.normal(0, 0.01, (5, 3))))
+    for k in range(300):      # near-collinear: a line with 1e-7 .. 1e-3 of lateral noise (a pole, the edge of a wall)
+        d = rng.standard_normal(3); d /= np.linalg.norm(d)
+        out.append(("near_collinear", rng.normal(0, 20, 3) + np.outer(np.linspace(-0.8, 0.8, 5), d) + rng.normal(0, 10.0 ** rng.uniform(-7, -3), (5, 3))))
+    for k in range(100):      # exactly collinear along an axis: two columns are constant (axis-aligned, quantised surfaces)
+        a = rng.integers(0, 3)
+        p = np.tile(np.round(rng.normal(0, 20, 3) * 4) / 4, (5, 1)); p[:, a] += np.arange(5) * 0.4
+        out.append(("axis_collinear", p))
+    for k in range(100):      # exactly collinear, f32 coordinates, general direction
+        d = rng.standard_normal(3)
+        out.append(("collinear", (rng.normal(0, 20, 3) + np.outer(np.arange(5.0), d)).astype(np.float32).astype(np.float64)))
+    for k in range(50):       # five coincident points / four coincident + one
+        p = np.tile(rng.normal(0, 20, 3), (5, 1))
+        if k % 2: p[4] += rng.normal(0, 0.3, 3)
+        out.append(("duplicates", p))
+    for k in range(100):      # a plane through the origin (n . p = 0: A x = -1 has no solution; the least-squares one is finite)
+        n = rng.standard_normal(3); n /= np.linalg.norm(n)
+        q = rng.normal(0, 5, (5, 3)); q -= np.outer(q @ n, n)
+        out.append(("through_origin", q + rng.normal(0, 1e-3, (5, 3))))
+    for a in range(3):        # ... exactly: one coordinate identically zero
+        q = rng.normal(0, 5, (5, 3)); q[:, a] = 0.0
+        out.append(("zero_column", q))
+    out.append(("zero", np.zeros((5, 3))))
+    return out
+
+
+def test_plane_fit_is_eigens_column_pivoted_qr():
+    """`matA0.colPivHouseholderQr().solve(matB0)` (laserMapping.cpp:435): the oracle's colpiv_qr_solve restates Eigen 3.3's ColPivHouseholderQR (pivoting by the largest
+    remaining column norm, nonzeroPivots() by Eigen's tiny threshold, components beyond it ZERO) — checked against LAPACK's pivoted QR (scipy.linalg.qr(pivoting=True): the
+    same pivot rule) used as the independent statement of "basic solution of rank r", and against numpy.linalg.lstsq where the system has full rank.  The rank itself is
+    re-derived from LAPACK's R diagonal with Eigen's published threshold, cases within a factor 16 of it excepted (there the two roundings may legitimately differ).
+    Round-5 review: the unpivoted Householder QR this replaces divided by a ~1e-17 pivot on collinear / coincident neighbourhoods; Eigen returns a finite normal there."""
+    import scipy.linalg
+    rng = np.random.default_rng(77)
+    L = O.lib()
+    eps = np.finfo(np.float64).eps
+    seen = {}
+    for name, pts in _plane_neighbourhoods(rng):
+        A = np.asfortranarray(pts.astype(np.float64))
+        b = -np.ones(5)
+        Aw = A.copy(order="F")
+        x = np.full(3, np.nan)
+        r = L.oracle_colpiv_qr_solve(Aw.ctypes.data, b.ctypes.data, 5, 3, x.ctypes.data)
+        if name == "zero":   # Eigen's test is a strict `<` against a threshold that is itself 0 here: all three pivots count, 0 / 0 — kept as Eigen has it (five map points
+            assert r == 3    # at the origin cannot come out of a VoxelGrid: its output points lie in distinct voxels)
+            continue
+        assert np.all(np.isfinite(x)), (name, pts, x)
+        Q, R, P = scipy.linalg.qr(A, pivoting=True)
+        diag = np.abs(np.diag(R))
+        maxn = np.sqrt((A * A).sum(axis=0)).max()
+        helper = (maxn * eps) ** 2 / 5.0
+        want_r, sure = 3, True
+        for k in range(3):
+            t = helper * (5 - k)
+            if diag[k] ** 2 < t * 16 and diag[k] ** 2 > t / 16: sure = False
+            if diag[k] ** 2 < t: want_r = k; break
+        if sure: assert r == want_r, (name, pts, r, want_r, diag, helper)
+        seen.setdefault(name, set()).add(r)
+        # pivot order: LAPACK's choice wherever the competing column norms are clearly apart
+        # basic solution of rank r from LAPACK's factorisation
+        xr = np.zeros(3)
+        if r > 0:
+            c = (Q.T @ b)[:r]
+            xr[P[:r]] = scipy.linalg.solve_triangular(R[:r, :r], c)
+        # same pivots? (ties between nearly equal column norms may swap: then compare through the residual instead)
+        cond = diag[0] / max(diag[r - 1], 1e-300) if r > 0 else 1.0
+        scale = max(np.abs(xr).max(), 1e-300)
+        if r == 3:
+            np.testing.assert_allclose(x, xr, rtol=0, atol=1e-12 * cond * scale, err_msg=name)
+            xl = np.linalg.lstsq(A, b, rcond=None)[0]
+            if cond < 1e6: np.testing.assert_allclose(x, xl, rtol=0, atol=1e-10 * cond * np.abs(xl).max(), err_msg=name)
+        else:
+            # rank deficient: the zeroed components are exactly zero, the others solve the reduced problem; with a different (tied) pivot choice the
+            # basic solution differs but the residual is the same least-squares residual
+            assert np.count_nonzero(x) <= r, (name, x, r)
+            res, res_r = np.linalg.norm(A @ x - b), np.linalg.norm(A @ xr - b)
+            assert abs(res - res_r) <= 1e-9 * max(1.0, res_r), (name, res, res_r)
+            if sure and np.all(np.abs(np.diff(np.sqrt((A * A).sum(axis=0)))) > 1e-6 * maxn):
+                np.testing.assert_allclose(x, xr, rtol=0, atol=1e-9 * scale, err_msg=name)
+    # every family reached the rank it was built for
+    assert seen["plane"] == {3} and seen["near_collinear"] == {3} and seen["zero_column"] == {2}
+    assert seen["axis_collinear"] == {2}, seen
+    assert seen["duplicates"] <= {1, 2} and 1 in seen["duplicates"], seen
+    assert 3 in seen["through_origin"]
+
+
 def test_eig3_against_numpy_eigh():
     """The oracle's eig3 (cyclic Jacobi with a relative stopping test, standing in for Eigen::SelfAdjointEigenSolver<Matrix3d>, laserMapping.cpp:394)
     against numpy.linalg.eigh: scatter matrices of five near-collinear points (what lm_fit feeds it), generic ones, near-degenerate and zero ones.
