@@ -309,36 +309,120 @@ DEV_INLINE void d_eig3(const double Ain[9], double lam[3], double vmax[3], doubl
   vmax[0] = V[0 * 3 + imax]; vmax[1] = V[1 * 3 + imax]; vmax[2] = V[2 * 3 + imax];
 }
 
-// least squares min ||A x - b|| for a 5x3 system by Householder QR (the oracle's qr_solve specialised)
-DEV_INLINE void d_qr53(double A[3][5], double b[5], double x[3]) {
+// Eigen::ColPivHouseholderQR<Matrix<double, 5, 3>>::compute() + solve() (laserMapping.cpp:435) — the oracle's colpiv_qr_solve (oracle/oracle.cpp, where the algorithm's
+// source in Eigen 3.3 is cited step by step) specialised to 5 x 3 with everything in registers: the column of largest remaining norm is swapped into place (selects
+// over static indices, no indexed register access), Householder reflector (beta, essential, tau) as Householder.h builds it, LAPACK's norm down-date, nonzeroPivots()
+// by Eigen's threshold, and the components past it ZERO — a collinear / coincident neighbourhood gets a finite basic solution instead of a division by a ~1e-17 pivot.
+// Same operations in the same order as the oracle, fp64, -ffp-contract=off.  A[c][i] = column c, row i (overwritten).
+DEV_INLINE void d_colpiv_qr53(double A[3][5], const double b[5], double x[3]) {
+  const double eps = 2.220446049250313e-16, tiny = 2.2250738585072014e-308;
+  double nu[3], nd[3], hc[3], c[5];
+  int perm[3] = {0, 1, 2};
+  double maxn = 0;
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
-    double norm2 = 0;
-    for (int i = k; i < 5; ++i) norm2 += A[k][i] * A[k][i];
-    const double norm = sqrt(norm2);
-    if (norm == 0.0) continue;
-    const double alpha = A[k][k] > 0 ? -norm : norm;
-    double v[5];
-    for (int i = k; i < 5; ++i) v[i] = A[k][i];
-    v[k] -= alpha;
-    double vn2 = 0;
-    for (int i = k; i < 5; ++i) vn2 += v[i] * v[i];
-    if (vn2 == 0.0) continue;
-    for (int j = k; j < 3; ++j) {
-      double dot = 0;
-      for (int i = k; i < 5; ++i) dot += v[i] * A[j][i];
-      const double f = 2.0 * dot / vn2;
-      for (int i = k; i < 5; ++i) A[j][i] -= f * v[i];
-    }
-    double dot = 0;
-    for (int i = k; i < 5; ++i) dot += v[i] * b[i];
-    const double f = 2.0 * dot / vn2;
-    for (int i = k; i < 5; ++i) b[i] -= f * v[i];
+    double s2 = 0;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) s2 += A[k][i] * A[k][i];
+    nd[k] = nu[k] = sqrt(s2);
+    if (nu[k] > maxn) maxn = nu[k];
   }
+  const double threshold_helper = (maxn * eps) * (maxn * eps) / 5.0;
+  const double downdate_threshold = 1.4901161193847656e-08;   // sqrt(eps), exact
+  int nonzero = 3;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    int big = k;
+    double nbig = nu[k];
+#pragma unroll
+    for (int j = k + 1; j < 3; ++j) if (nu[j] > nbig) { big = j; nbig = nu[j]; }   // maxCoeff: the first of equal maxima
+    if (nonzero == 3 && nbig * nbig < threshold_helper * (double)(5 - k)) nonzero = k;
+#pragma unroll
+    for (int j = k + 1; j < 3; ++j)
+      if (big == j) {
+#pragma unroll
+        for (int i = 0; i < 5; ++i) { const double t = A[k][i]; A[k][i] = A[j][i]; A[j][i] = t; }
+        { const double t = nu[k]; nu[k] = nu[j]; nu[j] = t; }
+        { const double t = nd[k]; nd[k] = nd[j]; nd[j] = t; }
+        { const int t = perm[k]; perm[k] = perm[j]; perm[j] = t; }   // (transposition k of the sequence applied on the right: the oracle's perm after all swaps)
+      }
+    double tail2 = 0;
+#pragma unroll
+    for (int i = k + 1; i < 5; ++i) tail2 += A[k][i] * A[k][i];
+    const double c0 = A[k][k];
+    double beta, tau;
+    if (tail2 <= tiny) {
+      tau = 0; beta = c0;
+#pragma unroll
+      for (int i = k + 1; i < 5; ++i) A[k][i] = 0;
+    } else {
+      beta = sqrt(c0 * c0 + tail2);
+      if (c0 >= 0) beta = -beta;
+#pragma unroll
+      for (int i = k + 1; i < 5; ++i) A[k][i] = A[k][i] / (c0 - beta);
+      tau = (beta - c0) / beta;
+    }
+    hc[k] = tau;
+    A[k][k] = beta;
+    if (tau != 0) {
+#pragma unroll
+      for (int j = k + 1; j < 3; ++j) {
+        double t = 0;
+#pragma unroll
+        for (int i = k + 1; i < 5; ++i) t += A[k][i] * A[j][i];
+        t += A[j][k];
+        A[j][k] -= tau * t;
+#pragma unroll
+        for (int i = k + 1; i < 5; ++i) A[j][i] -= tau * A[k][i] * t;
+      }
+    }
+#pragma unroll
+    for (int j = k + 1; j < 3; ++j) {
+      if (nu[j] != 0) {
+        double t = fabs(A[j][k]) / nu[j];
+        t = (1.0 + t) * (1.0 - t);
+        t = t < 0 ? 0 : t;
+        const double q = nu[j] / nd[j];
+        const double t2 = t * (q * q);
+        if (t2 <= downdate_threshold) {
+          double s2 = 0;
+#pragma unroll
+          for (int i = k + 1; i < 5; ++i) s2 += A[j][i] * A[j][i];
+          nd[j] = nu[j] = sqrt(s2);
+        } else nu[j] *= sqrt(t);
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 5; ++i) c[i] = b[i];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const double tau = hc[k];
+    if (k < nonzero && tau != 0) {
+      double t = 0;
+#pragma unroll
+      for (int i = k + 1; i < 5; ++i) t += A[k][i] * c[i];
+      t += c[k];
+      c[k] -= tau * t;
+#pragma unroll
+      for (int i = k + 1; i < 5; ++i) c[i] -= tau * A[k][i] * t;
+    }
+  }
+#pragma unroll
   for (int k = 2; k >= 0; --k) {
-    double s = b[k];
-    for (int j = k + 1; j < 3; ++j) s -= A[j][k] * x[j];
-    x[k] = s / A[k][k];
+    if (k < nonzero) {
+      double sum = c[k];
+#pragma unroll
+      for (int j = k + 1; j < 3; ++j) if (j < nonzero) sum -= A[j][k] * c[j];
+      c[k] = sum / A[k][k];
+    } else c[k] = 0.0;
+  }
+#pragma unroll
+  for (int o = 0; o < 3; ++o) {
+    double v = 0.0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) if (perm[i] == o) v = c[i];
+    x[o] = v;
   }
 }
 
@@ -586,7 +670,7 @@ __global__ void __launch_bounds__(128) lm_fit(DevCtx d, LmCtx L) {
       mx[j] = m.x; my[j] = m.y; mz[j] = m.z;
       A[0][j] = m.x; A[1][j] = m.y; A[2][j] = m.z; b[j] = -1.0;
     }
-    d_qr53(A, b, nrm);
+    d_colpiv_qr53(A, b, nrm);   // :435
     const double nn = sqrt(nrm[0] * nrm[0] + nrm[1] * nrm[1] + nrm[2] * nrm[2]);
     const double dd = 1 / nn;
 #pragma unroll

@@ -17,6 +17,7 @@ The CPU legs (rank 0, N = 1) run the oracle on exactly the scan sequence of stre
 streams 0..C-1 (cpu_replicas), BASELINE.md §2.
 """
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -417,6 +418,188 @@ def rank_self_check(p, h, args, rank, world, dist, device, steps_done, stages):
     return res
 
 
+def roofline_rows(kern, iso, counts, p, per, groups, rebuilds, with_traffic=True):
+    """one roofline row per kernel of a HIP-event profile pass (`kern`: kernel_table of the pass; `iso`: the same launch shape alone on the chip, or None):
+    algorithmic bytes per launch (kernel_bytes x the `per` streams a launch advances) / the kernel's average launch duration, against the HBM peak"""
+    roofs = []
+    for name in kern:  # kernels in the order of their share of the device time
+        rb = rebuilds / max(kern[name]["launches"], 1) / per  # map rebuilds per launch and stream
+        kb = kernel_bytes(name, counts, p.n_scan, p.horizon_scan, rb, p.recent_keyframe_num)
+        base = name.strip("()").split("<")[0]
+        r = dict(bound="hbm", kernel=name, achieved=None, peak=HBM_PEAK / 1e9, unit="GB/s", frac=None, traffic=pmc_traffic(name, per) if with_traffic else None,   # (the committed --pmc passes belong to the headline workload)
+                 algorithmic_bytes_per_launch=None, in_B_scan=base not in BOUNDARY_ONLY, streams_per_launch=per,
+                 concurrent_stream_groups=groups, avg_launch_us=kern[name]["avg_us"], share_of_device_time=kern[name]["share"])
+        if kb:
+            ach = kb * per / (kern[name]["avg_us"] * 1e-6)
+            r.update(achieved=round(ach / 1e9, 3), frac=round(ach / HBM_PEAK, 6), algorithmic_bytes_per_launch=int(kb * per))
+        else:
+            r.update(note="no byte term: the kernel only moves intermediates of its stage (candidate lists, bookkeeping)")
+        if iso is not None and name in iso:
+            r.update(isolated_launch_us=iso[name]["avg_us"])
+            if kb:
+                r.update(achieved_isolated=round(kb * per / (iso[name]["avg_us"] * 1e-6) / 1e9, 3), frac_isolated=round(kb * per / (iso[name]["avg_us"] * 1e-6) / HBM_PEAK, 6))
+        roofs.append(r)
+    return roofs
+
+
+def dominant_roofline(roofs, kern, rebuilds):
+    with_term = [r for r in roofs if r["frac"] is not None and r["in_B_scan"]]
+    if not with_term:
+        return None
+    return dict(with_term[0], map_rebuilds_per_launch=round(rebuilds / max(kern[with_term[0]["kernel"]]["launches"], 1), 2))
+
+
+def parity_sample(p, device, scans=20, stages=7):
+    """`scans` synthetic scans of this configuration through a one-slot device handle and the oracle, every scan started from the oracle's LO / LM params_
+    (teacher forcing, the contract of the parity tests): index outputs bit for bit, poses against the 1e-4 tolerance."""
+    from oracle import oracle_py
+    h, o = binding.Handle(p, device=device), oracle_py.Oracle(p)
+    exact, checked, et, er = 0, 0, [0.0], [0.0]
+    for k in range(scans):
+        pts = synth.scan(p, k)
+        h.set_lo_params(o.get("lo_params"))
+        if stages & 4:
+            h.set_lm_params(o.get("lm_params"))
+        o.process_scan(pts, stages)
+        _, odom, mp = h.scan_process(pts, stages=stages)
+        if k == 0:
+            continue
+        checked += 1
+        m = o.get("seg_cloud").shape[0]
+        same = all(np.array_equal(h.debug_get(g), o.get(g)) for g in ("seg_col", "seg_ground", "sharp_idx", "less_sharp_idx", "flat_idx"))
+        same = same and np.array_equal(h.debug_get("point_label")[5:m - 5], o.get("point_label")[5:m - 5])
+        for g in ("seg_cloud", "less_flat") + (("lm_surf_map_ds",) if stages & 4 else ()):
+            same = same and np.array_equal(bits(h.debug_get(g)), bits(o.get(g)))
+        exact += bool(same)
+        want = o.get("map_pose") if stages & 4 else o.get("odom_pose")
+        got = mp if stages & 4 else odom
+        et.append(float(np.linalg.norm(got["t"] - want[:3]))); er.append(quat_angle(got["q"], want[3:]))
+    h.close()
+    return dict(scans=scans, mode="teacher-forced, device vs oracle", index_outputs_bit_exact=f"{exact}/{checked} scans", trans_max_m=max(et), rot_max_rad=max(er),
+                within_tolerance=bool(exact == checked and max(et) < 1e-4 and max(er) < 1e-4))
+
+
+def config_line(p, device, streams, n_bags, prime, warmup, steps, stages=7, bags=None, shard=False, parity_scans=20, extra=None, one_group=False):
+    """One more single-GPU configuration of BASELINE.json measured the way the headline is: `streams` resident streams on `n_bags` bags, `prime` untimed
+    scans, `warmup` untimed steps, then exactly `steps` timed steps between device synchronisations; a HIP-event pass of another `steps` steps gives the
+    per-kernel durations its roofline is computed from; a 20-scan teacher-forced sample against the oracle gives its parity line."""
+    import torch
+    if bags is None:
+        bags = make_bags(p, n_bags, first_stream=0)
+    with env_override("ALEGO_STREAM_GROUPS", "1") if (shard or one_group) else contextlib.nullcontext():
+        h = binding.Handle(p, device=device, n_slots=streams, ring_len=1)
+    if shard:
+        D.shard_registration(h, None, 0, 1)   # world 1: the split solver (pack / evaluate / all-reduce / step launches) without partners
+    setup_replay(h, bags, streams)
+    st = stages | binding.REPLAY_BAG
+    h.batch_run(0, prime + warmup, st)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    h.batch_run(prime + warmup, steps, st, sync=False)
+    h.synchronize()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    step = prime + warmup + steps
+    cs = [h.batch_get_counts(s_) for s_ in range(0, streams, max(1, streams // 32))]
+    counts = {k: int(round(float(np.mean([c[k] for c in cs])))) for k in cs[0]}
+    trunc = 0
+    for s_ in range(streams):
+        try:
+            h.batch_get_pose(s_)
+        except binding.AlegoError:
+            trunc += 1
+    groups, per = h.stream_groups()
+    rebuilds0 = sum(h.batch_get_counts(s_)["n_rebuild"] for s_ in range(streams))
+    h.profile_enable(True)
+    h.batch_run(step, steps, st)
+    kern = kernel_table(h.profile_report())
+    h.profile_enable(False)
+    rebuilds = sum(h.batch_get_counts(s_)["n_rebuild"] for s_ in range(streams)) - rebuilds0
+    h.close()
+    value = streams * steps / dt
+    ab = algorithmic_bytes(counts, p.n_scan)
+    b_scan = ab["B_scan"] if stages & 4 else ab["B_IP"] + ab["B_FE"] + ab["B_LO"]
+    roofs = roofline_rows(kern, None, counts, p, per, groups, rebuilds, with_traffic=False)
+    out = dict(streams=streams, stream_groups=groups, bags=len(bags), primed_scans=prime, warmup=warmup, steps=steps, ms_per_step=round(1e3 * dt / steps, 4), value=round(value, 1), unit="scans/s",
+               stages="IP->LO->LM" if stages & 4 else "IP->LO", local_map_keyframes=p.recent_keyframe_num, truncated_streams=trunc,
+               pipeline_roofline=dict(B_scan=int(b_scan), achieved_GBps=round(value * b_scan / 1e9, 3), frac_of_hbm_peak=round(value * b_scan / HBM_PEAK, 6)),
+               roofline=dominant_roofline(roofs, kern, rebuilds), kernels_top5={k: kern[k] for k in list(kern)[:5]})
+    if parity_scans:
+        out["parity_sample"] = parity_sample(p, device, parity_scans, stages)
+    if extra:
+        out.update(extra)
+    return out, kern, per
+
+
+def all_configs(args, p_head, bags_head, device, head_kern, head_per, single, cpu):
+    """BASELINE.json's other single-GPU configurations, each as a line of its own: streams, steps, ms_per_step, value = streams x steps / time,
+    a 20-scan teacher-forced parity sample, its own roofline.  The headline (config 3 / 4 at 2048 streams) is the top-level line; config 1 is the CPU leg
+    (`cpu_baseline`); configs 4 and 5 at N > 1 are the driver's multi-GPU runs."""
+    cfg = {}
+    t_all = time.perf_counter()
+    # ---- config 2: ONE 16x1800 scan through IP -> LaserOdometry two-step; the README's budget (surf 5, corner 10 iterations, README.md:54) and HEAD's 5 / 5
+    # (laserOdometry.cpp:415,489).  "ms per frame" three ways: one stream alone (every kernel of a scan behind the previous one), amortised over a resident batch,
+    # and the two lo_solve launches alone (what the README's "optimisation" time covers); the oracle's two solves timed on this host beside them.
+    from oracle import oracle_py
+    c2 = {}
+    for tag, (i_s, i_c) in (("budget_5_10", (5, 10)), ("budget_5_5", (5, 5))):
+        p = p_head.copy()
+        p.lo_iters_surf, p.lo_iters_corner = i_s, i_c
+        line, kern, per = config_line(p, device, args.streams, 0, 64, 10, 40, stages=3, bags=bags_head)
+        h1 = binding.Handle(p, device=device, n_slots=1, ring_len=1)
+        setup_replay(h1, [bags_head[0]], 1)
+        h1.batch_run(0, 64, 3 | binding.REPLAY_BAG)
+        t1 = time.perf_counter()
+        h1.batch_run(64, 400, 3 | binding.REPLAY_BAG)
+        one = (time.perf_counter() - t1) / 400
+        h1.close()
+        o = oracle_py.Oracle(p)
+        n_o, t_o, solve_ms = 0, time.perf_counter(), 0.0
+        for k in range(150):
+            o.process_scan(bags_head[0][k], 3)
+            if k >= 10:
+                solve_ms += float(o.get("timing_ms")[5]); n_o += 1
+        cpu_frame_ms = 1e3 * (time.perf_counter() - t_o) / 150
+        los = [k for k in kern if "lo_solve" in k]
+        line.update(lo_iterations=dict(surf=i_s, corner=i_c),
+                    device_ms_per_frame=dict(one_stream_alone=round(1e3 * one, 4), amortised_in_batch=round(line["ms_per_step"] / line["streams"], 6),
+                                             lo_solve_two_launches_amortised=(round(2 * kern[los[0]]["avg_us"] / 1e3 / per, 6) if los else None),
+                                             lo_solve_launch_us_under_load=(kern[los[0]]["avg_us"] if los else None)),
+                    cpu_ms_per_frame=dict(oracle_ip_fe_lo=round(cpu_frame_ms, 4), oracle_two_solves=round(solve_ms / max(n_o, 1), 4), cores=1),
+                    reference_readme_ms_per_frame=(2.13 if (i_s, i_c) == (5, 10) else None),
+                    reference_readme_note="README.md:54, robo_0529.bag, Ceres, hardware not stated: context, not a baseline")
+        c2[tag] = line
+    cfg["config2_ip_lo_two_step_16x1800"] = c2
+    # ---- config 3 as written: ONE bag stream at unbounded rate (measured by single_stream() above: lifted into the block)
+    if single:
+        steps3 = max(args.steps, 200)
+        cfg["config3_one_bag_stream_16x1800"] = dict(streams=1, steps=steps3, primed_scans=args.prime, value=single["single_stream_scans_per_s"], unit="scans/s",
+                                                     ms_per_step=round(1e3 / single["single_stream_scans_per_s"], 4), serial_replay_scans_per_s=single["single_stream_serial_scans_per_s"],
+                                                     local_map_keyframes=p_head.recent_keyframe_num, note=single["single_stream_note"],
+                                                     parity_sample="the headline's `parity` block: the same one-stream scan sequence, every scan compared",
+                                                     roofline=dict(bound="latency", note="one stream = two sequential kernel chains (LaserOdometry ~150 us, LaserMapping ~150 us per scan); no kernel of it is "
+                                                                                         "bandwidth-bound: B_scan x value = %.4f of the HBM peak" % ((single["single_stream_scans_per_s"] * 2.59e6) / HBM_PEAK)))
+    # ---- the reference's own compiled geometry, 16 x 4000 (utility.h:50-55)
+    p = synth.default_params(16, 4000)
+    cfg["geometry_16x4000_reference_compiled"], _, _ = config_line(p, device, 768, 8, LAP, 10, 60)
+    # ---- config 5's shape at N = 1: 64 x 2048 with a 200-key-frame local map; fused solver, then the registration split as for N ranks (world 1)
+    p = synth.default_params(64, 2048)
+    p.recent_keyframe_num = 200
+    p.kf_cap_surf, p.kf_cap_outlier = 8192, 2048
+    bags5 = make_bags(p, 4, first_stream=0)
+    fused, _, _ = config_line(p, device, 512, 4, 2400, 10, 40, bags=bags5)
+    cfg["config5_shape_64x2048_k200_fused"] = fused
+    fused1, _, _ = config_line(p, device, 512, 4, 2400, 10, 40, bags=bags5, one_group=True, parity_scans=0)
+    shard, _, _ = config_line(p, device, 512, 4, 2400, 10, 40, bags=bags5, shard=True, parity_scans=0)
+    frames = max(40 // max(p.lm_every, 1), 1)
+    shard["shard_vs_fused"] = dict(fused_scans_per_s=fused1["value"], sharded_scans_per_s=shard["value"], fused_ms_per_step=fused1["ms_per_step"], sharded_ms_per_step=shard["ms_per_step"],
+                                   extra_ms_per_mapping_frame=round((shard["ms_per_step"] - fused1["ms_per_step"]) * 40 / frames, 4), world=1,
+                                   note="both on ONE stream group (the collectives of a communicator must not overlap); the fused line above runs 4 groups: %.1f scans/s" % fused["value"])
+    cfg["config5_shape_64x2048_k200_sharded_world1"] = shard
+    cfg["_seconds"] = round(time.perf_counter() - t_all, 1)
+    return cfg
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -440,6 +623,7 @@ def main():
     ap.add_argument("--self-check", action="store_true", help="after the timed region rank 0 replays, on its own GPU, the stream every rank's slot 0 ran and compares the poses "
                                                               "bit for bit; always on at N > 1 (--no-self-check turns it off)")
     ap.add_argument("--no-self-check", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the `configs` block (BASELINE.json's other single-GPU configurations, each timed as a line of its own)")
     args = ap.parse_args()
 
     rank, local, world = D.env()
@@ -598,6 +782,9 @@ def main():
         if not args.no_check and not shard:
             out["timed_handle_check"] = timed_handle_check(h, p, bags, B, step, local, omt)
     h.close()
+    if rank == 0 and world == 1 and not shard and not args.no_configs and not args.no_cpu and args.geometry.lower() == "16x1800" and args.keyframes == 0:
+        single = {k: out[k] for k in ("single_stream_scans_per_s", "single_stream_serial_scans_per_s", "single_stream_note") if k in out}
+        out["configs"] = all_configs(args, p, bags, local, kern, per, single if len(single) == 3 else None, out.get("cpu_baseline"))
     if rank == 0 and kern is not None:
         # the same launch shape (`per` streams per launch) ALONE on the chip: one stream group, nothing else resident
         iso = None
@@ -611,27 +798,10 @@ def main():
             iso = kernel_table(hi.profile_report())
             hi.close()
             out["kernels_isolated"] = {k: v["avg_us"] for k, v in iso.items()}   # one stream group alone on the chip: every launch by itself
-        roofs = []
-        for name in kern:  # kernels in the order of their share of the device time
-            rb = rebuilds / max(kern[name]["launches"], 1) / per  # map rebuilds per launch and stream
-            kb = kernel_bytes(name, counts, p.n_scan, p.horizon_scan, rb, p.recent_keyframe_num)
-            base = name.strip("()").split("<")[0]
-            r = dict(bound="hbm", kernel=name, achieved=None, peak=HBM_PEAK / 1e9, unit="GB/s", frac=None, traffic=pmc_traffic(name, per),
-                     algorithmic_bytes_per_launch=None, in_B_scan=base not in BOUNDARY_ONLY, streams_per_launch=per,
-                     concurrent_stream_groups=groups, avg_launch_us=kern[name]["avg_us"], share_of_device_time=kern[name]["share"])
-            if kb:
-                ach = kb * per / (kern[name]["avg_us"] * 1e-6)
-                r.update(achieved=round(ach / 1e9, 3), frac=round(ach / HBM_PEAK, 6), algorithmic_bytes_per_launch=int(kb * per))
-            else:
-                r.update(note="no byte term: the kernel only moves intermediates of its stage (candidate lists, bookkeeping)")
-            if iso is not None and name in iso:
-                r.update(isolated_launch_us=iso[name]["avg_us"])
-                if kb:
-                    r.update(achieved_isolated=round(kb * per / (iso[name]["avg_us"] * 1e-6) / 1e9, 3), frac_isolated=round(kb * per / (iso[name]["avg_us"] * 1e-6) / HBM_PEAK, 6))
-            roofs.append(r)
-        with_term = [r for r in roofs if r["frac"] is not None and r["in_B_scan"]]
-        if with_term:   # the dominant kernel: largest share of the device time among those with a §8(d) term of their own
-            out["roofline"] = dict(with_term[0], map_rebuilds_per_launch=round(rebuilds / max(kern[with_term[0]["kernel"]]["launches"], 1), 2))
+        roofs = roofline_rows(kern, iso, counts, p, per, groups, rebuilds)
+        dom = dominant_roofline(roofs, kern, rebuilds)
+        if dom:   # the dominant kernel: largest share of the device time among those with a §8(d) term of their own
+            out["roofline"] = dom
         out["roofline_top3"] = roofs[:3]        # the three largest kernels by device time, whatever their term
         out["roofline_all"] = {r["kernel"]: dict(frac=r["frac"], frac_isolated=r.get("frac_isolated"), traffic_over_algorithmic=(round(r["traffic"] / r["algorithmic_bytes_per_launch"], 2) if r["traffic"] and (r["algorithmic_bytes_per_launch"] or 0) > 1024 * per else None),   # (the solvers' 104 bytes of pose are not a traffic yardstick)
                                                  share=r["share_of_device_time"], in_B_scan=r["in_B_scan"]) for r in roofs if r["frac"] is not None}

@@ -1350,6 +1350,7 @@ struct LaserMapping {
   int n_corner_corr = 0, n_surf_corr = 0;
   std::vector<int> corner_corr_q, surf_corr_q;  // accepted query indices (first outer iteration)
   std::vector<double> blocks14;                 // the residual blocks of the first outer iteration: type, cp, a, b, c, d
+  std::vector<int> plane_rank_hist = std::vector<int>(4, 0);   // first outer iteration: plane fits by nonzeroPivots() (tests: were rank-deficient neighbourhoods reached?)
   SolveSummary sums[2];
   double params_iter[2][6];
   double t_map_ms = 0, t_ds_ms = 0, t_tree_ms = 0, t_assoc_ms = 0, t_solve_ms = 0;
@@ -1497,6 +1498,7 @@ struct LaserMapping {
           }
         }
       }
+      if (iter_cnt == 0) plane_rank_hist.assign(4, 0);
       for (int i = 0; i < (int)laser_surf_total_ds.size(); ++i) {  // :419-462
         Pt sel; point_associate_to_map(laser_surf_total_ds[i], sel);
         if (kd_surf_map.knn(sel, 5, nidx, ndist) < 5) continue;
@@ -1507,7 +1509,8 @@ struct LaserMapping {
             A[0 * 5 + j] = m.x; A[1 * 5 + j] = m.y; A[2 * 5 + j] = m.z;
           }
           double norm[3];
-          colpiv_qr_solve(A, b, 5, 3, norm);   // matA0.colPivHouseholderQr().solve(matB0), :435
+          const int rank = colpiv_qr_solve(A, b, 5, 3, norm);   // matA0.colPivHouseholderQr().solve(matB0), :435
+          if (iter_cnt == 0) ++plane_rank_hist[rank];
           double nn = std::sqrt(norm[0] * norm[0] + norm[1] * norm[1] + norm[2] * norm[2]);
           double negative_OA_dot_norm = 1 / nn;
           for (int a = 0; a < 3; ++a) norm[a] /= nn;
@@ -1689,6 +1692,17 @@ int oracle_lm(void* h) {
   Quat q{c->odom_pose[3], c->odom_pose[4], c->odom_pose[5], c->odom_pose[6]};
   c->lm.process(c->lo.corner_last, c->lo.surf_last, c->ip.outlier_cloud, c->odom_pose, q, c->map_pose);
   c->t_lm_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  return (c->lm.ran_body ? 1 : 0) | (c->lm.optimized ? 2 : 0) | (c->lm.keyframe_added ? 4 : 0);
+}
+
+// LaserMapping fed with host clouds and an /odom/lidar pose (t xyz, q wxyz) — the checker's counterpart of alego_lm_process, for tests that construct the
+// /corner_last, /surf_last, /outlier messages themselves (laserOdomHandler + one mainLoop body, laserMapping.cpp:102-131,154-166).
+int oracle_lm_process(void* h, const alego_point* cl, int nc, const alego_point* sl, int ns, const alego_point* ol, int no, const double* odom7) {
+  Ctx* c = (Ctx*)h;
+  std::vector<Pt> vc(cl, cl + nc), vs(sl, sl + ns), vo(ol, ol + no);
+  for (int i = 0; i < 7; ++i) c->odom_pose[i] = odom7[i];
+  Quat q{odom7[3], odom7[4], odom7[5], odom7[6]};
+  c->lm.process(vc, vs, vo, c->odom_pose, q, c->map_pose);
   return (c->lm.ran_body ? 1 : 0) | (c->lm.optimized ? 2 : 0) | (c->lm.keyframe_added ? 4 : 0);
 }
 
@@ -1899,6 +1913,7 @@ int oracle_get(void* h, const char* name, const void** ptr, int* count, int* dty
   if (s == "lm_surf_total_ds") return cloud(lm.laser_surf_total_ds);
   if (s == "lm_corner_corr_q") { *dtype = ORACLE_I32; return ret(lm.corner_corr_q, ptr, count); }
   if (s == "lm_surf_corr_q") { *dtype = ORACLE_I32; return ret(lm.surf_corr_q, ptr, count); }
+  if (s == "lm_plane_rank_hist") { *dtype = ORACLE_I32; return ret(lm.plane_rank_hist, ptr, count); }
   if (s == "lm_blocks14") { *dtype = ORACLE_F64; return ret(lm.blocks14, ptr, count); }
   if (s == "lm_keyposes") { *dtype = ORACLE_F32; *ptr = lm.keyposes.data(); *count = (int)lm.keyposes.size() * 6; return 0; }
   if (s == "lm_map2odom") {

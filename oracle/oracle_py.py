@@ -54,6 +54,8 @@ def lib():
         L.oracle_lm_reset_window.argtypes = [C.c_void_p]
         L.oracle_lm_apply_correction.argtypes = [C.c_void_p, C.c_void_p]
         L.oracle_lm_add_keyframe.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        L.oracle_lm_process.restype = C.c_int
+        L.oracle_lm_process.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
         L.oracle_lm_keyframe.restype = C.c_int
         L.oracle_lm_keyframe.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]
         L.oracle_transform_to_start.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
@@ -112,6 +114,12 @@ class Oracle:
 
     def lm(self):
         return lib().oracle_lm(self._h)
+
+    def lm_process(self, corner_last, surf_last, outlier, odom7):
+        """LaserMapping on host clouds + an /odom/lidar pose (t xyz, q wxyz): the checker's counterpart of alego_lm_process."""
+        c, s, o = self._pts(corner_last), self._pts(surf_last), self._pts(outlier)
+        od = np.ascontiguousarray(odom7, dtype=np.float64)
+        return lib().oracle_lm_process(self._h, c.ctypes.data, c.shape[0], s.ctypes.data, s.shape[0], o.ctypes.data, o.shape[0], od.ctypes.data)
 
     def process_scan(self, pts, stages=7):
         a = self._pts(pts)

@@ -629,6 +629,48 @@ def test_lm_process_host_entry(params_a):
     h.close()
 
 
+def test_plane_fit_on_rank_deficient_neighbourhoods():
+    """laserMapping.cpp:435 `matA0.colPivHouseholderQr().solve(matB0)` on a constructed map (util.rank_deficient_plane_scene): 75 queries whose five nearest map
+    points are collinear — 25 exactly (axis-aligned: Eigen's nonzeroPivots() = 2, the normal's third pivot component is ZERO), 25 collinear up to f32 rounding, 25
+    with 1e-5 of lateral noise — among ~3000 ordinary ones.  Device (lm_fit: d_colpiv_qr53) vs oracle (colpiv_qr_solve): accepted-query lists equal, every plane's
+    unit normal and distance equal to 1e-12 (the same fp64 operations in the same order; bit-equality is reported), solver summaries and poses as in every LM test."""
+    from util import rank_deficient_plane_scene
+    mods, frames = rank_deficient_plane_scene()
+    p = synth.default_params(16, 1800)
+    for k, v in mods.items():
+        setattr(p, k, v)
+    h, o = binding.Handle(p), O.Oracle(p)
+    kf_cap_c = p.n_less_sharp * p.n_sectors * p.n_scan
+    worst, nbit, ntot, rank2 = 0.0, 0, 0, 0
+    for i, (c, s, ol, od) in enumerate(frames):
+        h.set_lm_params(o.get("lm_params"))
+        o.lm_process(c, s, ol, od)
+        flags, mp = h.lm_process(c, s, ol, dict(t=od[:3], q=od[3:]))
+        _lm_compare(h, o, i, f"frame {i}")
+        want = o.get("map_pose")
+        assert np.abs(mp["t"] - want[:3]).max() < POSE_TOL and quat_angle(mp["q"], want[3:]) < POSE_TOL
+        if i == 0:
+            continue
+        gi = h.debug_get("lm_info")
+        blocks = h.debug_get("lm_blocks").reshape(-1, 8)
+        sb = blocks[kf_cap_c:kf_cap_c + gi[23]]
+        got = sb[sb[:, 7] == 3.0]
+        b14 = o.get("lm_blocks14").reshape(-1, 14)
+        wantp = b14[b14[:, 0] == 3]
+        assert got.shape[0] == wantp.shape[0] > 2500
+        assert np.isfinite(got[:, :7]).all()
+        np.testing.assert_allclose(got[:, 0:3], wantp[:, 4:7], rtol=0, atol=1e-12, err_msg=f"frame {i} plane normals")
+        np.testing.assert_allclose(got[:, 6], wantp[:, 13], rtol=1e-12, atol=0, err_msg=f"frame {i} plane distances")
+        worst = max(worst, np.abs(got[:, 0:3] - wantp[:, 4:7]).max())
+        nbit += int((got[:, 0:3].view(np.uint64) == np.ascontiguousarray(wantp[:, 4:7]).view(np.uint64)).all(axis=1).sum()); ntot += got.shape[0]
+        rank2 += int(o.get("lm_plane_rank_hist")[2])
+        # a rank-2 fit leaves one component of the normal exactly zero: the same planes on both sides
+        assert_bit_equal(np.nonzero((got[:, 0:3] == 0).any(axis=1))[0], np.nonzero((wantp[:, 4:7] == 0).any(axis=1))[0], f"frame {i} planes with a zeroed component")
+    assert rank2 >= 50, rank2
+    print(f"plane fits: {ntot} planes, {nbit} bit-equal normals, max |dn| {worst:.2e}; {rank2} rank-2 neighbourhoods")
+    h.close()
+
+
 @pytest.mark.parametrize("n,leaf,kind", [(0, 0.4, "gauss"), (1, 0.4, "gauss"), (37, 0.4, "gauss"), (3000, 0.4, "gauss"), (8192, 0.8, "gauss"),
                                          (8193, 0.8, "gauss"), (60000, 0.4, "gauss"), (60000, 0.8, "dense"), (120000, 0.8, "wall"),
                                          (5000, 0.001, "gauss"), (20000, 50.0, "gauss")])

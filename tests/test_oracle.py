@@ -295,6 +295,32 @@ def test_plane_fit_is_eigens_column_pivoted_qr():
     assert 3 in seen["through_origin"]
 
 
+def test_constructed_scene_reaches_rank_deficient_plane_fits():
+    """The constructed LaserMapping scene of util.rank_deficient_plane_scene (the input of the -m gpu test of the same name): 25 of its 75 isolated five-point
+    'rails' are exactly collinear along an axis, their queries' plane fits have nonzeroPivots() = 2 — and the oracle, following Eigen's column-pivoted QR, returns a
+    finite unit normal for every one of them and accepts the plane (the five points lie on it), where the unpivoted QR of rounds 1 - 5 divided by a ~1e-17 pivot."""
+    from util import rank_deficient_plane_scene
+    mods, frames = rank_deficient_plane_scene()
+    p = synth.default_params(16, 1800)
+    for k, v in mods.items():
+        setattr(p, k, v)
+    o = O.Oracle(p)
+    hist = []
+    for c, s, ol, od in frames:
+        o.lm_process(c, s, ol, od)
+        hist.append(o.get("lm_plane_rank_hist").copy())
+        b = o.get("lm_blocks14").reshape(-1, 14)
+        assert np.isfinite(b).all()
+        planes = b[b[:, 0] == 3]
+        if len(planes):
+            np.testing.assert_allclose(np.linalg.norm(planes[:, 4:7], axis=1), 1.0, rtol=0, atol=1e-12)
+    assert hist[0].sum() == 0                      # frame 0: empty map, becomes key frame 0
+    assert hist[1][2] == 25 and hist[2][2] == 25   # the axis-aligned rails: rank 2
+    assert hist[1][3] > 2500 and hist[1][0] == hist[1][1] == 0
+    info = o.get("lm_info")
+    assert info[1] == 1 and info[4] > 2500         # the last frame optimised against > 2500 planes
+
+
 def test_eig3_against_numpy_eigh():
     """The oracle's eig3 (cyclic Jacobi with a relative stopping test, standing in for Eigen::SelfAdjointEigenSolver<Matrix3d>, laserMapping.cpp:394)
     against numpy.linalg.eigh: scatter matrices of five near-collinear points (what lm_fit feeds it), generic ones, near-degenerate and zero ones.

@@ -47,3 +47,71 @@ def imu_stream(t0, t1, rate=100.0, yaw_rate=0.3, acc=(0.4, -0.2, 0.0), tilt=(0.0
         out[i, 5:8] = (acc[0] - g * np.sin(p), acc[1] + g * np.cos(p) * np.sin(r), acc[2] + g * np.cos(p) * np.cos(r))
         out[i, 8:11] = (0.0, 0.0, yaw_rate)
     return out
+
+
+def rank_deficient_plane_scene(seed=3):
+    """A constructed LaserMapping input for the plane fit of laserMapping.cpp:425-452: a map frame (frame 0: ground, two walls, poles) that also holds isolated
+    'rails' — five map points on a line, 0.3 - 0.45 m apart, nothing else within 1.5 m — and follow-up frames whose surf cloud has points next to the middle of
+    every rail, so that their five nearest neighbours are exactly those five collinear points (d5^2 < 1).  Rail kinds: axis-aligned with exactly representable
+    coordinates (two constant columns: rank 2 by any arithmetic), a general direction in f32, and near-collinear (1e-5 of lateral noise: rank 3, condition ~1e5).
+    Returns (params_mods, frames): frames[i] = (corner_last, surf_last, outlier, odom7) in the lidar frame of frame i; odom7 = t xyz + q wxyz."""
+    rng = np.random.default_rng(seed)
+    mods = dict(lm_leaf_corner=0.2, lm_leaf_surf=0.2, lm_leaf_outlier=0.4, lm_every=1, min_keyframe_dist=0.05)
+    g = np.mgrid[-12:12.01:0.5, -12:12.01:0.5].reshape(2, -1).T
+    ground = np.c_[g, np.full(len(g), -1.7)] + rng.normal(0, 0.01, (len(g), 3))
+    w = np.mgrid[-6:6.01:0.4, -1.5:2.01:0.4].reshape(2, -1).T
+    wall_a = np.c_[np.full(len(w), 8.0), w] + rng.normal(0, 0.01, (len(w), 3))
+    wall_b = np.c_[w[:, 0], np.full(len(w), -7.0), w[:, 1]] + rng.normal(0, 0.01, (len(w), 3))
+    poles = []
+    for px, py in ((5, 5), (-5, 4), (4, -5), (-6, -3), (2, 9), (-9, 1), (9, -2), (0, -10)):
+        z = np.arange(-1.5, 2.01, 0.25)
+        poles.append(np.c_[np.full(len(z), px), np.full(len(z), py), z] + rng.normal(0, 0.005, (len(z), 3)))
+    poles = np.concatenate(poles)
+    rails, mids = [], []
+    k = 0
+    for zi, z0 in enumerate((4.0, 6.5, 9.0)):
+        for xi in range(-2, 3):
+            for yi in range(-2, 3):
+                c = np.array([xi * 3.0, yi * 3.0, z0])
+                kind = k % 3
+                if kind == 0:      # axis-aligned, coordinates on a 1/16 grid (exact in f32 and through the identity key pose)
+                    a = (k // 3) % 3
+                    pts = np.tile(np.round(c * 16) / 16 + 1 / 32, (5, 1)); pts[:, a] += (np.arange(5) - 2) * 0.3125
+                elif kind == 1:    # a general direction, f32-rounded
+                    d = rng.standard_normal(3); d /= np.linalg.norm(d)
+                    pts = c + np.outer((np.arange(5) - 2) * 0.45, d)
+                else:              # near-collinear
+                    d = rng.standard_normal(3); d /= np.linalg.norm(d)
+                    pts = c + np.outer((np.arange(5) - 2) * 0.45, d) + rng.normal(0, 1e-5, (5, 3))
+                rails.append(pts.astype(np.float32).astype(np.float64)); mids.append(c)
+                k += 1
+    rails = np.concatenate(rails); mids = np.array(mids)
+
+    def cloud(xyz, inten=0.0):
+        out = np.zeros((len(xyz), 4), np.float32)
+        out[:, :3] = xyz; out[:, 3] = inten
+        return out
+
+    def pose(i):   # the platform's true pose at frame i: a slow drive with a slight turn
+        yaw = 0.012 * i
+        return np.array([0.12 * i, 0.05 * i, 0.0]), yaw
+
+    def to_lidar(xyz, i):
+        t, yaw = pose(i)
+        c, s = np.cos(yaw), np.sin(yaw)
+        R = np.array([[c, -s, 0], [s, c, 0], [0, 0, 1]])
+        return (xyz - t) @ R     # R^T (p - t)
+
+    frames = []
+    for i in range(4):
+        t, yaw = pose(i)
+        od = np.r_[t + (rng.normal(0, 0.01, 3) if i else 0), np.cos((yaw + (0.002 if i else 0)) / 2), 0.0, 0.0, np.sin((yaw + (0.002 if i else 0)) / 2)]
+        if i == 0:
+            surf = np.concatenate([ground, wall_a, wall_b, rails])
+        else:   # the same world seen again (fresh noise) + query points next to the middle of every rail (lateral offset 2 - 15 cm)
+            q = mids + rng.normal(0, 0.05, mids.shape)
+            surf = np.concatenate([ground + rng.normal(0, 0.01, ground.shape), wall_a + rng.normal(0, 0.01, wall_a.shape), wall_b + rng.normal(0, 0.01, wall_b.shape), q])
+        corner = poles + (rng.normal(0, 0.005, poles.shape) if i else 0)
+        outl = np.c_[rng.uniform(-10, 10, (40, 2)), rng.uniform(-1, 1, 40)]
+        frames.append((cloud(to_lidar(corner, i)), cloud(to_lidar(surf, i)), cloud(to_lidar(outl, i)), od))
+    return mods, frames
