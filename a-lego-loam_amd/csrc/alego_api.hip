@@ -257,6 +257,7 @@ int alego_create(const alego_params* params, int device, int n_slots, int ring_l
   d.opt_ip_half = env_int("ALEGO_IP_HALF", 1) != 0;
   d.opt_cc_fused = env_int("ALEGO_CC_FUSED", 1) != 0;
   d.opt_cc_tile = env_int("ALEGO_CC_TILE", 1) != 0;
+  d.opt_ip_band = env_int("ALEGO_IP_BAND", 1) != 0;
   d.opt_fe_pick1 = env_int("ALEGO_FE_PICK1", 0) != 0;
   d.opt_fe_fused = env_int("ALEGO_FE_FUSED", 1) != 0;
   d.opt_fe_cand = env_int("ALEGO_FE_CAND", 0);
@@ -273,6 +274,8 @@ int alego_create(const alego_params* params, int device, int n_slots, int ring_l
   rc |= dalloc(h, &d.parent, B * N); rc |= dalloc(h, &d.cc_size, B * N); rc |= dalloc(h, &d.cc_rows, B * N);
   rc |= dalloc(h, &d.label_img, B * N); rc |= dalloc(h, &d.cc_label, B * N); rc |= dalloc(h, &d.row_cnt, B * NS * 4);
   rc |= dalloc(h, &d.scal, B * SC_COUNT);
+  d.ipb_col = nullptr; d.ipb_off = nullptr;
+  if (d.NS > 16 && d.NS <= 64) { rc |= dalloc(h, &d.ipb_col, B * IPB_NM * d.H); rc |= dalloc(h, &d.ipb_off, B * 3 * 64 * ((d.H + 63) / 64)); }   // the banded mask path (kernels_ipb.hip)
   d.ipf_own = nullptr;
   if (d.NS <= 16 && d.N <= 65535 && (d.H & 1) == 0) rc |= dalloc(h, &d.ipf_own, B * (N / 2), false);
   rc |= dalloc(h, &d.seg_pts, B * N); rc |= dalloc(h, &d.seg_ground, B * N); rc |= dalloc(h, &d.seg_col, B * N);
@@ -1005,6 +1008,12 @@ int alego_debug_set_option(alego_handle* h, const char* name, int value) {
   else if (s == "ALEGO_IP_FUSED") d.opt_ip_fused = value != 0;
   else if (s == "ALEGO_IP_HALF") d.opt_ip_half = value != 0;
   else if (s == "ALEGO_CC_TILE") d.opt_cc_tile = value != 0;
+  else if (s == "ALEGO_IP_BAND") {   // the banded path expects the component statistics at zero between scans (it re-zeroes what it touched); the cc_stats path leaves them set
+    HIP_TRY(h, hipDeviceSynchronize());
+    HIP_TRY(h, hipMemset(d.cc_size, 0, (size_t)d.n_slots * d.N * sizeof(int)));
+    HIP_TRY(h, hipMemset(d.cc_rows, 0, (size_t)d.n_slots * d.N * sizeof(unsigned long long)));
+    d.opt_ip_band = value != 0;
+  }
   else if (s == "ALEGO_FE_PICK1") d.opt_fe_pick1 = value != 0;
   else if (s == "ALEGO_FE_FUSED") d.opt_fe_fused = value != 0;
   else if (s == "ALEGO_FE_CAND") d.opt_fe_cand = value;

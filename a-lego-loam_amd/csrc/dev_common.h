@@ -40,6 +40,7 @@ enum {
   SC_COUNT = 32
 };
 
+#define IPB_NM 9
 #define IP_OWNER_TAG 0x40000000   // any tagged entry beats every plain one (index or -1) in ip_project's atomicMax
 
 // feature cloud kinds
@@ -96,6 +97,10 @@ struct DevCtx {
   int* parent;          // [slot][N] union-find parent (root = min linear index of the component)
   int* cc_size;         // [slot][N] per-root size, later per-root label
   unsigned long long* cc_rows;  // [slot][N] per-root row bitmask
+  unsigned long long* ipb_col;   // [slot][IPB_NM][H] the banded path's 64-bit row masks of every column (kernels_ipb.hip): ground, active, down-edges, right-edges, band roots |
+                                 // keep, outlier, feasible roots, final roots (null: not allocated — sensors of <= 16 rings)
+  int* ipb_off;         // [slot][3][64][chunks of 64 columns] row-major exclusive offsets of the ordered compaction: kept cells, outliers, feasible roots
+  int opt_ip_band;      // ALEGO_IP_BAND    1: sensors of 17 - 64 rings take the banded mask path (ip_project + ipb_band + ipb_merge + ipb_emit); 0: ip_front + cc_* + ip_rowcount + ip_compact
   unsigned* ipf_own;    // [slot][N / 2] ip_fused_h: the packed 16-bit owners of two adjacent columns between its phases B and D (null: not allocated)
   int* label_img;       // [slot][N] label_mat_
   int* cc_label;        // [slot][N] per-root label_cnt_ number (0 = infeasible)

@@ -971,6 +971,8 @@ bool ipf_eligible(const DevCtx& d);
 bool ipw_eligible(const DevCtx& d);
 void launch_ip_fused(const DevCtx& d, int ring_pos, bool keep_images, hipStream_t st);
 int ipf_configure(const DevCtx& d);
+bool ipb_eligible(const DevCtx& d);
+void launch_ipb(const DevCtx& d, int ring_pos, bool keep_images, hipStream_t st);
 
 void launch_ip(const DevCtx& d, int ring_pos, bool want_labels, hipStream_t st) {
   if (d.opt_ip_fused && (ipf_eligible(d) || (d.opt_ip_half && ipw_eligible(d)))) {   // one workgroup per stream, everything between the input points and cloud_info on chip (kernels_ipf.hip)
@@ -983,6 +985,11 @@ void launch_ip(const DevCtx& d, int ring_pos, bool want_labels, hipStream_t st) 
   const dim3 gN((d.N + IP_BLOCK - 1) / IP_BLOCK, d.n_launch);
   const dim3 gN4((d.N + IP_BLOCK * IP_PW - 1) / (IP_BLOCK * IP_PW), d.n_launch), gP4((d.Pcap + IP_BLOCK * IP_PW - 1) / (IP_BLOCK * IP_PW), d.n_launch);
   ALEGO_LAUNCH(ip_project, gP4, dim3(IP_BLOCK), 0, st, d, ring_pos);
+  if (d.opt_ip_band && ipb_eligible(d)) {   // 17 - 64 rings: column bands + row masks (kernels_ipb.hip)
+    launch_ipb(d, ring_pos, want_labels || d.n_launch == 1, st);
+    if (want_labels) hipLaunchKernelGGL(ip_labels, gN, dim3(IP_BLOCK), 0, st, d);
+    return;
+  }
   const bool lds_cc = lds16 || d.N <= CC_LDS_MAXN, lds_stats = lds16;
   const bool keep_images = want_labels || d.n_launch == 1;   // the single-scan entry points / tests read the range and root images back
   ALEGO_LAUNCH(ip_front, dim3((d.H + IPF_W - 2) / (IPF_W - 1), d.n_launch), dim3(IPF_W), (size_t)d.NS * IPF_W * 4 + IPF_W * 8, st, d, ring_pos,

@@ -33,8 +33,9 @@ def _ip_compare(h, o, pts, tag):
 
 @pytest.mark.parametrize("geom,variant", [((16, 1800), None), ((16, 1800), "ALEGO_IP_FUSED"), ((16, 1800), "ALEGO_IP_FUSED,ALEGO_CC_FUSED"), ((16, 1800), "ALEGO_IP_FAST"),
                                           ((16, 1024), None), ((12, 2048), None), ((5, 64), None), ((16, 1800), "ALEGO_IP_FUSED,ALEGO_IP_FAST"),
-                                          ((16, 4000), None), ((64, 2048), None), ((64, 2048), "ALEGO_CC_TILE"),
-                                          ((32, 2048), None), ((40, 1800), None),
+                                          ((16, 4000), None), ((64, 2048), None), ((64, 2048), "ALEGO_IP_BAND"), ((64, 2048), "ALEGO_IP_BAND,ALEGO_CC_TILE"),
+                                          ((32, 2048), None), ((40, 1800), None), ((32, 2048), "ALEGO_IP_BAND"), ((40, 1800), "ALEGO_IP_BAND"),
+                                          ((24, 320), None), ((17, 70), None), ((64, 4000), None), ((48, 1000), None),
                                           ((16, 1800), "ALEGO_IP_HALF"), ((16, 1024), "ALEGO_IP_HALF"), ((12, 2048), "ALEGO_IP_HALF"), ((5, 64), "ALEGO_IP_HALF"),
                                           ((16, 1800), "ALEGO_IP_HALF,ALEGO_IP_FAST"), ((16, 4000), "ALEGO_IP_HALF"), ((16, 4094), None), ((14, 3000), None)])
 def test_ip_bit_exact(geom, variant, monkeypatch):
@@ -42,9 +43,10 @@ def test_ip_bit_exact(geom, variant, monkeypatch):
     a CU, one launch: 16x1800, 16x1024, 12x2048, 5x64; ALEGO_IP_HALF=0: ip_fused, the same pipeline with 1024 threads and the whole CU); wider images of up to
     16 rings and 65 535 cells (16x4000 — the reference's own geometry —, 16x4094, 14x3000) run the same kernel with 1024 threads and all of a CU's LDS
     (ip_fused_w; ALEGO_IP_HALF=0 sends them down the multi-kernel path); ALEGO_IP_FUSED=0 selects the multi-kernel path: 16x1800 then runs cc_lds16; ALEGO_CC_FUSED=0 keeps its union-find but
-    compacts with the separate ip_rowcount + ip_compact kernels; 16x4000 runs cc_lds16 at 126 KB of LDS; 64x2048, 32x2048 and 40x1800
-    (bands of 256 / 512 / 409 + 164 columns) are labelled band by band in LDS and stitched at the seams (cc_tile + cc_seam +
-    cc_stats), ALEGO_CC_TILE=0 keeps the global-memory union-find (cc_runs + cc_link).
+    compacts with the separate ip_rowcount + ip_compact kernels; 16x4000 runs cc_lds16 at 126 KB of LDS.  Sensors of 17 - 64 rings — 64x2048 (config 5), 32x2048,
+    40x1800 (7 bands + one of 8 columns, a last chunk of 8 columns), 24x320, 17x70 (one partial band), 64x4000, 48x1000 — run the banded mask path (round 6:
+    ip_project + ipb_band + ipb_merge + ipb_emit, kernels_ipb.hip); ALEGO_IP_BAND=0 keeps the seven-kernel path, whose images are labelled band by band
+    in LDS and stitched at the seams (cc_tile + cc_seam + cc_stats), ALEGO_CC_TILE=0 the global-memory union-find (cc_runs + cc_link).
     ALEGO_IP_FAST=0 projects every point with the reference expressions (normally only the points within 2.5e-4 cells of a
     cell boundary take them; the rest are placed by the boundary tables)."""
     for v in (variant or "").split(","):
@@ -424,6 +426,37 @@ def test_batch_slots_independent(params_a):
         _, odomb, _ = hb.batch_get_pose(s)
         assert_bit_equal(odomb["t"], odom1["t"], f"slot {s} odometry translation")
         assert_bit_equal(odomb["q"], odom1["q"], f"slot {s} odometry rotation")
+        h1.close()
+    hb.close()
+
+
+@pytest.mark.parametrize("geom", [(64, 2048), (40, 1800)])
+def test_band_path_in_a_batch_equals_the_seven_kernel_path(geom, monkeypatch):
+    """The banded ImageProjection (kernels_ipb.hip) in a batch launch — several slots per launch, no images kept, statistics entries re-zeroed scan after
+    scan — against one-slot handles on the seven-kernel path (ALEGO_IP_BAND=0) over 6 scans: segmented cloud, cloud_info arrays, outliers, ring indices and the
+    odometry they lead to, bit for bit; then the option is switched on a live handle (the banded path needs the statistics at zero: alego_debug_set_option clears them)."""
+    p = synth.default_params(*geom)
+    nslot, nscan = 3, 6
+    hb = binding.Handle(p, n_slots=nslot, ring_len=nscan)
+    for s in range(nslot):
+        for k in range(nscan):
+            hb.batch_load(s, k, synth.scan(p, k, stream=s))
+    hb.batch_run(0, nscan, stages=3)
+    monkeypatch.setenv("ALEGO_IP_BAND", "0")
+    for s in range(nslot):
+        h1 = binding.Handle(p)
+        for k in range(nscan):
+            _, odom1, _ = h1.scan_process(synth.scan(p, k, stream=s), stages=3)
+        _, odomb, _ = hb.batch_get_pose(s)
+        for name in ("seg_cloud", "seg_col", "seg_range", "seg_ground", "outlier", "ring_start", "ring_end", "less_sharp", "less_flat"):
+            assert_bit_equal(hb.debug_get(name, slot=s), h1.debug_get(name), f"slot {s} {name}")
+        assert_bit_equal(odomb["t"], odom1["t"], f"slot {s} odometry translation")
+        assert_bit_equal(odomb["q"], odom1["q"], f"slot {s} odometry rotation")
+        if s == 0:   # the same handle, switched to the banded path and back, against the oracle
+            o = O.Oracle(p)
+            for k, band in ((0, 1), (1, 1), (2, 0), (3, 1), (4, 0), (5, 1)):
+                h1.set_option("ALEGO_IP_BAND", band)
+                _ip_compare(h1, o, synth.scan(p, k, stream=7), f"{geom} scan {k} band={band}")
         h1.close()
     hb.close()
 
