@@ -27,9 +27,20 @@
 #define IPB_TW 256            // columns per band = threads of ipb_band; a band has <= 256 x 64 = 16384 cells: 16-bit parents
 #define IPB_NWV (IPB_TW / 64)
 #define IPB_MT 1024           // threads of ipb_merge
+#define IPB_LINK_CAP 1024      // seam edges of an image: bands x rings <= (4096 / 256) x 64
 #define IPB_ET 256            // threads of ipb_emit (4 chunks of 64 columns)
+#ifndef IPB_EP
+#define IPB_EP 4               // row parts of ipb_emit
+#endif
 
 typedef unsigned long long u64;
+#ifdef ALEGO_TIMING   // development (tools/ipb_timing.py): wall-clock ticks (100 MHz) of workgroup 0 / slot 0 at the phase boundaries of the three kernels
+__device__ long long ipb_times[48];
+extern "C" void alego_ipb_times(long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(ipb_times), sizeof(long long) * 48); }
+#define IPB_TICK(k) do { if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) ipb_times[k] = wall_clock64(); } while (0)
+#else
+#define IPB_TICK(k)
+#endif
 DEV_INLINE u64 ipb_low(int r) { return (2ull << r) - 1ull; }                 // bits 0..r (r = 63: all)
 DEV_INLINE int ipb_head(u64 rs, int r) { return 63 - __clzll((long long)(rs & ipb_low(r))); }   // the run start at or below row r
 DEV_INLINE u64* ipb_mask(const DevCtx& d, int slot, int k) { return (u64*)d.ipb_col + ((size_t)slot * IPB_NM + k) * d.H; }
@@ -51,17 +62,23 @@ DEV_INLINE int ipb_find_ro(const int* parent, int v) {
   while (curr > (next = ipb_ld(parent + curr))) curr = next;
   return curr;
 }
-DEV_INLINE void ipb_union(int* parent, int a, int b) {
+// returns the root this call put under another one (every root is linked at most once, by exactly one successful compare-and-swap), -1 if none
+DEV_INLINE int ipb_union(int* parent, int a, int b) {
   int ra = ipb_find(parent, a), rb = ipb_find(parent, b);
   bool repeat;
+  int linked = -1;
   do {
     repeat = false;
     if (ra != rb) {
       int ret;
-      if (ra < rb) { if ((ret = atomicCAS(parent + rb, rb, ra)) != rb) { rb = ret; repeat = true; } }
-      else { if ((ret = atomicCAS(parent + ra, ra, rb)) != ra) { ra = ret; repeat = true; } }
+      if (ra < rb) { if ((ret = atomicCAS(parent + rb, rb, ra)) != rb) { rb = ret; repeat = true; } else linked = rb; }
+      else { if ((ret = atomicCAS(parent + ra, ra, rb)) != ra) { ra = ret; repeat = true; } else linked = ra; }
     }
   } while (repeat);
+  return linked;
+}
+DEV_INLINE bool ipb_feasible(const alego_params& P, int sz, u64 rows) {   // imageProjection.cpp:282-301
+  return sz >= P.seg_big_num || (sz >= P.seg_valid_point_num && (int)__popcll(rows) >= P.seg_valid_line_num);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -94,6 +111,7 @@ __global__ void __launch_bounds__(IPB_TW) ipb_band(DevCtx d, int ring_pos, int k
       ori[0] = so; ori[1] = eo; ori[2] = eo - so;
     }
   }
+  IPB_TICK(0);
   int* owner = d.owner + base;
   // ---- ranges + ground, bottom-up; rows in batches of 8: the owner indices of a batch, then its point gathers, are independent loads ----
   float rng[64];
@@ -101,13 +119,20 @@ __global__ void __launch_bounds__(IPB_TW) ipb_band(DevCtx d, int ring_pos, int k
   {
     float lx = 0, ly = 0, lz = 0;
     bool lower_ok = false;
+    int obn[8];   // the NEXT batch's owner words: in flight while this batch's points are gathered (and issued before this batch's write-backs, which the compiler must keep behind them)
+#pragma unroll
+    for (int u = 0; u < 8; ++u) obn[u] = (have && u < NS) ? owner[u * H + col] : -1;
 #pragma unroll
     for (int row0 = 0; row0 < 64; row0 += 8) {
       if (row0 < NS) {   // (uniform)
         int ob[8];
         float4 pb[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) ob[u] = (have && row0 + u < NS) ? owner[(row0 + u) * H + col] : -1;
+        for (int u = 0; u < 8; ++u) ob[u] = obn[u];
+        if (row0 + 8 < 64 && row0 + 8 < NS) {
+#pragma unroll
+          for (int u = 0; u < 8; ++u) obn[u] = (have && row0 + 8 + u < NS) ? owner[(row0 + 8 + u) * H + col] : -1;
+        }
         // entries of this scan carry the tag, everything else is stale.  The plain form is written back (= the reset for the next scan) except for the band's
         // FIRST column, which the band to the left reads as its halo, possibly much later: it stays tagged here and ipb_merge strips it (cf. ip_front)
 #pragma unroll
@@ -137,6 +162,7 @@ __global__ void __launch_bounds__(IPB_TW) ipb_band(DevCtx d, int ring_pos, int k
       }
     }
   }
+  IPB_TICK(1);
   const u64 act = filled & ~ground;
   s_a[tid] = have ? act : 0ull;
   if (lane == 0) {
@@ -158,6 +184,7 @@ __global__ void __launch_bounds__(IPB_TW) ipb_band(DevCtx d, int ring_pos, int k
     if (lane == 0) s_a[TW] = fb & ~(gb | (gb >> 1));
   }
   __syncthreads();
+  IPB_TICK(2);
   // ---- edge predicates: right (seg_alpha_x, :258-261) and down (seg_alpha_y, :262-265) ----
   u64 ex = 0, ey = 0;
   {
@@ -185,10 +212,12 @@ __global__ void __launch_bounds__(IPB_TW) ipb_band(DevCtx d, int ring_pos, int k
     }
   }
   if (H <= 1) ex = 0;
+  IPB_TICK(3);
   const u64 rs = act & ~(ey << 1);   // run starts: active cells the cell below has no down-edge to
   s_y[tid] = ey; s_rs[tid] = rs;
   for (u64 m = rs; m; m &= m - 1) { const int r = __ffsll((long long)m) - 1; par[r * IPB_TW + tid] = (uint16_t)(r * IPB_TW + tid); }
   __syncthreads();
+  IPB_TICK(4);
   // ---- unions over the right-edges inside the band that join different run pairs (an edge is skipped when the cell below already links the same two runs) ----
   if (tid + 1 < TW) {
     const u64 rs_n = s_rs[tid + 1], ey_n = s_y[tid + 1];
@@ -198,6 +227,7 @@ __global__ void __launch_bounds__(IPB_TW) ipb_band(DevCtx d, int ring_pos, int k
     }
   }
   __syncthreads();
+  IPB_TICK(5);
   // ---- per run: band root (global linear index), size and row mask into the root's entries ----
   u64 rootm = 0;
   if (have) {
@@ -221,6 +251,7 @@ __global__ void __launch_bounds__(IPB_TW) ipb_band(DevCtx d, int ring_pos, int k
         fimg[row * H + col] = (uint8_t)(((ground >> row) & 1ull) | (((act >> row) & 1ull) << 1) | (((ex >> row) & 1ull) << 2) | (((ey >> row) & 1ull) << 3));
     }
   }
+  IPB_TICK(6);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -239,32 +270,47 @@ __global__ void __launch_bounds__(IPB_MT) ipb_merge(DevCtx d, int keep) {
   u64 *MK = ipb_mask(d, slot, 5), *MO = ipb_mask(d, slot, 6), *MF = ipb_mask(d, slot, 7), *MRf = ipb_mask(d, slot, 8);
   extern __shared__ __attribute__((aligned(16))) unsigned char ipb_smem[];
   unsigned short* s_cnt = reinterpret_cast<unsigned short*>(ipb_smem);   // [3][64][nch] counts, then exclusive prefixes inside a row
-  __shared__ int s_rowtot[3][64], s_rowbase[3][64], s_tot[3];
+  __shared__ int s_rowtot[3][64], s_rowbase[3][64], s_tot[3], s_nlink;
+  __shared__ int s_link[IPB_LINK_CAP];
+  IPB_TICK(10);
   // the owner entries ipb_band left tagged (the first column of every band) -> plain form / -1
   for (int j = tid; j < nb * NS; j += IPB_MT) {
     const int row = j / nb, col = (j - row * nb) * IPB_TW;
     const int v = owner[row * H + col];
     owner[row * H + col] = (v >= 0 && (v & IP_OWNER_TAG)) ? (v & ~IP_OWNER_TAG) : -1;
   }
-  // seams: the right-edges of every band's last column (incl. the wrap-around column, :241-248)
+  // seams: the right-edges of every band's last column (incl. the wrap-around column, :241-248).  A root that a seam puts under another one is noted (once: by the
+  // thread whose compare-and-swap linked it)
+  if (tid == 0) s_nlink = 0;
+  __syncthreads();
   for (int e = tid; e < nb * NS; e += IPB_MT) {
     const int t = e / NS, row = e - t * NS;
     const int col = min((t + 1) * IPB_TW, H) - 1, cn = col + 1 == H ? 0 : col + 1;
     if ((Mx[col] >> row) & 1ull) {
       const u64 rl = Ma[col] & ~(My[col] << 1), rr = Ma[cn] & ~(My[cn] << 1);
-      ipb_union(parent, ipb_head(rl, row) * H + col, ipb_head(rr, row) * H + cn);
+      const int linked = ipb_union(parent, ipb_head(rl, row) * H + col, ipb_head(rr, row) * H + cn);
+      if (linked >= 0) s_link[atomicAdd(&s_nlink, 1)] = linked;   // (at most one per seam edge: nb * NS <= IPB_LINK_CAP)
     }
   }
   __syncthreads();
-  // statistics of the band roots a seam has put under another root
-  for (int col = tid; col < H; col += IPB_MT) {
-    for (u64 m = Mr[col]; m; m &= m - 1) {
-      const int v = (__ffsll((long long)m) - 1) * H + col;
-      const int R = ipb_find_ro(parent, v);
-      if (R != v) { atomicAdd(&csz[R], ipb_ld(csz + v)); atomicOr(&crw[R], ipb_ld64(crw + v)); }
-    }
+  IPB_TICK(11);
+  // statistics of the linked roots go to their final root, and the totals of a joined component back into every root of it: whichever band root a run's parent
+  // entry names, its entries then hold its component's size and row mask (ipb_band left every other band root's own, final, figures there)
+  const int nlink = s_nlink;
+  for (int j = tid; j < nlink; j += IPB_MT) {
+    const int v = s_link[j], R = ipb_find_ro(parent, v);
+    atomicAdd(&csz[R], ipb_ld(csz + v)); atomicOr(&crw[R], ipb_ld64(crw + v));
   }
   __syncthreads();
+  IPB_TICK(12);
+  for (int j = tid; j < nlink; j += IPB_MT) {
+    const int v = s_link[j], R = ipb_find_ro(parent, v);
+    const int sz = ipb_ld(csz + R);
+    const u64 rw = ipb_ld64(crw + R);
+    ipb_st(csz + v, sz); __hip_atomic_store(crw + v, rw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  IPB_TICK(13);
   // per column: keep / outlier masks (:164-188), feasible roots; per (row, chunk) counts by ballots
   const u64 above = P.ground_scan_id >= 63 ? 0ull : ~ipb_low(P.ground_scan_id);   // rows > ground_scan_id
   for (int ch = wave; ch < nch; ch += IPB_MT / 64) {
@@ -272,17 +318,28 @@ __global__ void __launch_bounds__(IPB_MT) ipb_merge(DevCtx d, int keep) {
     u64 K = 0, O = 0, F = 0, Rf = 0;
     if (col < H) {
       const u64 g = Mg[col], a = Ma[col], y = My[col];
-      for (u64 m = a & ~(y << 1); m; m &= m - 1) {
-        const int r = __ffsll((long long)m) - 1, vh = r * H + col;
-        const int R = ipb_find_ro(parent, vh);
-        const int sz = ipb_ld(csz + R);
-        bool feas = sz >= P.seg_big_num;
-        if (!feas && sz >= P.seg_valid_point_num) feas = __popcll(ipb_ld64(crw + R)) >= P.seg_valid_line_num;   // :282-301
-        const int e = __ffsll((long long)(~y & ~(ipb_low(r) >> 1))) - 1;
-        const u64 runm = ipb_low(e) & ~(ipb_low(r) >> 1);
-        if (feas) K |= runm;
-        if (R == vh) { Rf |= 1ull << r; if (feas) F |= 1ull << r; }
-        if (keep & 1) { for (int k = r; k <= e; ++k) ipb_st(parent + k * H + col, R); }
+      for (u64 m = a & ~(y << 1); m;) {   // four runs per iteration: their loads are independent (a run = two dependent L2 round trips)
+        int r[4], v[4], b[4], z[4];
+        u64 w[4];
+        bool on[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { on[q] = m != 0; r[q] = on[q] ? __ffsll((long long)m) - 1 : r[0]; m &= m - 1; v[q] = r[q] * H + col; }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) b[q] = ipb_ld(parent + v[q]);   // a band root (ipb_band wrote it; path halving only ever replaces it by a root further up the chain)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { z[q] = ipb_ld(csz + b[q]); w[q] = ipb_ld64(crw + b[q]); }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          if (!on[q]) continue;
+          const bool f = ipb_feasible(P, z[q], w[q]);
+          const int e = __ffsll((long long)(~y & ~(ipb_low(r[q]) >> 1))) - 1;
+          if (f) K |= ipb_low(e) & ~(ipb_low(r[q]) >> 1);
+          if (b[q] == v[q]) { Rf |= 1ull << r[q]; if (f) F |= 1ull << r[q]; }
+          if (keep & 1) {   // the per-cell root image (ip_labels, alego_debug_get("parent"))
+            const int R = ipb_find_ro(parent, v[q]);
+            for (int k = r[q]; k <= e; ++k) ipb_st(parent + k * H + col, R);
+          }
+        }
       }
       if (col % 5 == 0) O = a & ~K & above;                              // :165-171
       if (col % 5 == 0 || col <= 4 || col >= H - 5) K |= g;               // :173-176
@@ -297,6 +354,7 @@ __global__ void __launch_bounds__(IPB_MT) ipb_merge(DevCtx d, int keep) {
     s_cnt[(0 * 64 + lane) * nch + ch] = (unsigned short)ck; s_cnt[(1 * 64 + lane) * nch + ch] = (unsigned short)co; s_cnt[(2 * 64 + lane) * nch + ch] = (unsigned short)cf;
   }
   __syncthreads();
+  IPB_TICK(14);
   if (tid < 192) {   // exclusive prefix inside every row (chunks ascending = columns ascending)
     const int ty = tid >> 6, row = tid & 63;
     int run = 0;
@@ -310,6 +368,7 @@ __global__ void __launch_bounds__(IPB_MT) ipb_merge(DevCtx d, int keep) {
     s_tot[tid] = run;
   }
   __syncthreads();
+  IPB_TICK(15);
   int* off = d.ipb_off + (size_t)slot * 3 * 64 * nch;
   for (int j = tid; j < 3 * 64 * nch; j += IPB_MT) { const int tr = j / nch; off[j] = s_rowbase[tr >> 6][tr & 63] + (int)s_cnt[j]; }
   if (tid < NS) {
@@ -317,10 +376,12 @@ __global__ void __launch_bounds__(IPB_MT) ipb_merge(DevCtx d, int keep) {
     d.ring_end[slot * NS + tid] = s_rowbase[0][tid] + s_rowtot[0][tid] - 1 - 5;     // :190
   }
   if (tid == 0) { int* sc = d.scal + slot * SC_COUNT; sc[SC_M] = s_tot[0]; sc[SC_NOUT] = s_tot[1]; sc[SC_NFEAS] = s_tot[2]; }
+  IPB_TICK(16);
   // the statistics entries go back to zero for the next scan (every entry ipb_band or the merge above touched belongs to a band root)
   for (int col = tid; col < H; col += IPB_MT) {
     for (u64 m = Mr[col]; m; m &= m - 1) { const int v = (__ffsll((long long)m) - 1) * H + col; csz[v] = 0; crw[v] = 0ull; }
   }
+  IPB_TICK(17);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -328,9 +389,11 @@ __global__ void __launch_bounds__(IPB_MT) ipb_merge(DevCtx d, int keep) {
 // ---------------------------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(IPB_ET) ipb_emit(DevCtx d, int ring_pos, int keep) {
   const int slot = blockIdx.y + d.slot0, tid = threadIdx.x, lane = tid & 63;
-  const int H = d.H, NS = d.NS, nch = (H + 63) / 64;
-  const int ch = blockIdx.x * (IPB_ET / 64) + (tid >> 6);
+  const int H = d.H, NS = d.NS, nch = (H + 63) / 64, nblk = (nch + IPB_ET / 64 - 1) / (IPB_ET / 64);
+  const int part = blockIdx.x / nblk;                                   // rows [part * rpp, (part + 1) * rpp): four times the wavefronts, a quarter of the dependent load chain each
+  const int ch = (blockIdx.x - part * nblk) * (IPB_ET / 64) + (tid >> 6);
   if (ch >= nch) return;
+  const int rpp = ((NS + 4 * IPB_EP - 1) / (4 * IPB_EP)) * 4, rlo = part * rpp, rhi = min(NS, rlo + rpp);
   const int col = ch * 64 + lane;
   const bool have = col < H;
   const int cc = have ? col : H - 1;
@@ -338,22 +401,30 @@ __global__ void __launch_bounds__(IPB_ET) ipb_emit(DevCtx d, int ring_pos, int k
   const float4* pts = scan_pts(d, slot, ring_pos);
   const int* owner = d.owner + base;
   const u64 K = have ? ipb_mask(d, slot, 5)[cc] : 0ull, O = have ? ipb_mask(d, slot, 6)[cc] : 0ull, G = ipb_mask(d, slot, 0)[cc];
+  const u64 KO = K | O;
   const double cf = d.ip_colfrac[cc];
   const int* offk = d.ipb_off + ((size_t)slot * 3 + 0) * 64 * nch + ch;
   const int* offo = d.ipb_off + ((size_t)slot * 3 + 1) * 64 * nch + ch;
   const u64 below = (1ull << lane) - 1ull;
-  for (int row0 = 0; row0 < NS; row0 += 4) {
-    if (__ballot((((K | O) >> row0) & 0xFull) != 0) == 0) continue;   // (uniform)
+  int obn[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) obn[u] = ((KO >> min(rlo + u, 63)) & 1ull) && rlo + u < rhi ? owner[(rlo + u) * H + cc] : 0;
+  for (int row0 = rlo; row0 < rhi; row0 += 4) {
     int ob[4];
     float4 pb[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) { const int row = min(row0 + u, NS - 1); ob[u] = (((K | O) >> (row0 + u)) & 1ull) ? (owner[row * H + cc] & ~IP_OWNER_TAG) : 0; }
+    for (int u = 0; u < 4; ++u) ob[u] = obn[u] & ~IP_OWNER_TAG;
+    if (row0 + 4 < rhi) {   // the next group's owner words, in flight while this group's points are gathered and written
+#pragma unroll
+      for (int u = 0; u < 4; ++u) obn[u] = ((KO >> min(row0 + 4 + u, 63)) & 1ull) && row0 + 4 + u < rhi ? owner[(row0 + 4 + u) * H + cc] : 0;
+    }
+    if (__ballot(((KO >> row0) & 0xFull) != 0) == 0) continue;   // (uniform)
 #pragma unroll
     for (int u = 0; u < 4; ++u) pb[u] = pts[ob[u]];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int row = row0 + u;
-      if (row >= NS) break;
+      if (row >= rhi) break;
       const bool k = (K >> row) & 1ull, o = (O >> row) & 1ull;
       const u64 bk = __ballot(k), bo = __ballot(o);
       if (k | o) {
@@ -371,7 +442,7 @@ __global__ void __launch_bounds__(IPB_ET) ipb_emit(DevCtx d, int ring_pos, int k
       }
     }
   }
-  if (keep & 1) {   // label_cnt_ numbering of the feasible roots in discovery (row-major) order, 0 for the others (:303-306)
+  if ((keep & 1) && part == 0) {   // label_cnt_ numbering of the feasible roots in discovery (row-major) order, 0 for the others (:303-306)
     const u64 F = have ? ipb_mask(d, slot, 7)[cc] : 0ull, Rf = have ? ipb_mask(d, slot, 8)[cc] : 0ull;
     const int* offf = d.ipb_off + ((size_t)slot * 3 + 2) * 64 * nch + ch;
     for (int row = 0; row < NS; ++row) {
@@ -389,5 +460,5 @@ void launch_ipb(const DevCtx& d, int ring_pos, bool keep_images, hipStream_t st)
   const int nb = (d.H + IPB_TW - 1) / IPB_TW, nch = (d.H + 63) / 64;
   ALEGO_LAUNCH(ipb_band, dim3(nb, d.n_launch), dim3(IPB_TW), 0, st, d, ring_pos, keep_images ? 1 : 0);
   ALEGO_LAUNCH(ipb_merge, dim3(d.n_launch), dim3(IPB_MT), ipb_merge_lds(d), st, d, keep_images ? 1 : 0);
-  ALEGO_LAUNCH(ipb_emit, dim3((nch + IPB_ET / 64 - 1) / (IPB_ET / 64), d.n_launch), dim3(IPB_ET), 0, st, d, ring_pos, keep_images ? 1 : 0);
+  ALEGO_LAUNCH(ipb_emit, dim3(IPB_EP * ((nch + IPB_ET / 64 - 1) / (IPB_ET / 64)), d.n_launch), dim3(IPB_ET), 0, st, d, ring_pos, keep_images ? 1 : 0);
 }
