@@ -41,23 +41,36 @@ __global__ void __launch_bounds__(IP_BLOCK) ip_project(DevCtx d, int ring_pos) {
   __syncthreads();
   float qmr, qmc;
   ip_quick_margins(d, &qmr, &qmc);
+  const IpQuickConst qc = ip_quick_const(d);
   const int lane = lane_id();
+  // the IP_PW points side by side (round 6, as ip_fused_t's point loop since round 5): decisions without branches (ip_point_quick_bf), one test for the (rare) deferrals
+  bool deferv[IP_PW];
+  bool anydefer = false;
 #pragma unroll
   for (int u = 0; u < IP_PW; ++u) {
     const int i = i0 + u * IP_BLOCK;
-    bool valid = false, defer = false;
-    int cell = -1;
-    if (i < n) defer = !ip_point_quick(d, pin[u], qmr, qmc, &valid, &cell);
-    if (cell >= 0)
+    const bool in = i < n;
+    bool valid;
+    int cell;
+    const bool dec = ip_point_quick_bf(qc, pin[u], qmr, qmc, &valid, &cell);
+    deferv[u] = in && !dec;
+    anydefer |= deferv[u];
+    if (in && cell >= 0)
       atomicMax(&d.owner[(size_t)slot * d.N + cell], IP_OWNER_TAG | i);  // later points overwrite earlier ones (:102-103);
         // whatever the previous scan left in the cell (a plain index or -1, see ip_front) loses against a tagged entry: no reset pass
-    if (valid) { vmin = min(vmin, i); vmax = max(vmax, i); ++nvalid; }
-    const unsigned long long dm = __ballot(defer);
-    if (dm) {
-      int b0 = 0;
-      if (lane == 0) b0 = atomicAdd(&s_ndef, (int)__popcll(dm));
-      b0 = __shfl(b0, 0, 64);
-      if (defer) s_def[b0 + (int)__popcll(dm & ((1ull << lane) - 1ull))] = i;   // (at most IP_BLOCK * IP_PW entries: one per point of the workgroup)
+    const bool v = in && valid;
+    vmin = min(vmin, v ? i : 0x7fffffff); vmax = max(vmax, v ? i : -1); nvalid += v ? 1 : 0;
+  }
+  if (__ballot(anydefer)) {
+#pragma unroll
+    for (int u = 0; u < IP_PW; ++u) {
+      const unsigned long long dm = __ballot(deferv[u]);
+      if (dm) {
+        int b0 = 0;
+        if (lane == 0) b0 = atomicAdd(&s_ndef, (int)__popcll(dm));
+        b0 = __shfl(b0, 0, 64);
+        if (deferv[u]) s_def[b0 + (int)__popcll(dm & ((1ull << lane) - 1ull))] = i0 + u * IP_BLOCK;   // (at most IP_BLOCK * IP_PW entries: one per point of the workgroup)
+      }
     }
   }
   __syncthreads();
