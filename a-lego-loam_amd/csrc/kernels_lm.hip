@@ -1009,8 +1009,7 @@ __global__ void lm_apply_correction(DevCtx d, LmCtx L, int slot, const double* r
 // The host enqueues the worst-case sequence (lm_outer_iters x (1 + lm_max_iters) evaluations); kernels of a finished solve return at once.
 // Same evaluation code, same row order and same reduction as lm_solve: with one rank the result is bit-identical to it.
 static_assert(sizeof(LmState) <= 64 * sizeof(double), "LmHost allocates 64 doubles per slot for the sharded solve's state");
-__global__ void __launch_bounds__(LM_SOLVE_T) lm_shard_pack(DevCtx d, LmCtx L) {
-  const int slot = blockIdx.x + d.slot0;
+DEV_INLINE void lm_shard_pack_dev(const DevCtx& d, const LmCtx& L, int slot) {
   int* li = lip(L, slot);
   int* ctl = L.shard_ctl + (size_t)slot * 8;
   double* part = L.shard_part + (size_t)slot * 32;
@@ -1031,9 +1030,23 @@ __global__ void __launch_bounds__(LM_SOLVE_T) lm_shard_pack(DevCtx d, LmCtx L) {
     li[LI_OPTIMIZED] = 1;
   }
 }
+__global__ void __launch_bounds__(LM_SOLVE_T) lm_shard_pack(DevCtx d, LmCtx L) { lm_shard_pack_dev(d, L, blockIdx.x + d.slot0); }
 
-__global__ void __launch_bounds__(LM_SOLVE_T) lm_shard_eval(DevCtx d, LmCtx L, int which) {
+DEV_INLINE void lm_shard_step_dev(const DevCtx& d, const LmCtx& L, int slot, int first);
+DEV_INLINE void lm_shard_next_outer_dev(const LmCtx& L, int slot);
+// pre (round 6: what used to be separate one-thread-per-slot launches between two evaluations runs at the head of the next evaluation's own workgroup, so an
+// evaluation is ONE launch around its all-reduce instead of two or three):  LM_PRE_PACK = lm_shard_pack (the first evaluation of a frame), LM_PRE_STEP_FIRST /
+// LM_PRE_STEP = lm_shard_step on the sums the all-reduce has just delivered, LM_PRE_STEP_NEXT = that step followed by lm_shard_next_outer (the first evaluation of
+// a further outer iteration).  A workgroup is one slot: its thread 0 does exactly what the slot's thread of the separate launch did.
+enum { LM_PRE_NONE = 0, LM_PRE_PACK, LM_PRE_STEP_FIRST, LM_PRE_STEP, LM_PRE_STEP_NEXT };
+__global__ void __launch_bounds__(LM_SOLVE_T) lm_shard_eval(DevCtx d, LmCtx L, int which, int pre) {
   const int slot = blockIdx.x + d.slot0;
+  if (pre == LM_PRE_PACK) lm_shard_pack_dev(d, L, slot);
+  else if (pre != LM_PRE_NONE && threadIdx.x == 0) {
+    lm_shard_step_dev(d, L, slot, pre == LM_PRE_STEP_FIRST ? 1 : 0);
+    if (pre == LM_PRE_STEP_NEXT) lm_shard_next_outer_dev(L, slot);
+  }
+  if (pre != LM_PRE_NONE) { __threadfence_block(); __syncthreads(); }   // (the control words, the candidate and the packed rows are read back by the whole workgroup)
   const int* ctl = L.shard_ctl + (size_t)slot * 8;
   if (ctl[2] || ctl[4] || ctl[1] != LM_EVAL) return;   // solve finished / guard failed: the all-reduce still runs, on stale partials nobody reads
   extern __shared__ __attribute__((aligned(16))) unsigned char lm_smem[];
@@ -1059,10 +1072,7 @@ __global__ void __launch_bounds__(LM_SOLVE_T) lm_shard_eval(DevCtx d, LmCtx L, i
 }
 
 // one thread per slot.  first: the evaluation just summed was the one at params_ (start of an outer iteration)
-__global__ void lm_shard_step(DevCtx d, LmCtx L, int first) {
-  const int s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= d.n_launch) return;
-  const int slot = s + d.slot0;
+DEV_INLINE void lm_shard_step_dev(const DevCtx& d, const LmCtx& L, int slot, int first) {
   int* ctl = L.shard_ctl + (size_t)slot * 8;
   if (ctl[4]) return;
   int* li = lip(L, slot);
@@ -1099,11 +1109,13 @@ __global__ void lm_shard_step(DevCtx d, LmCtx L, int first) {
   }
 }
 
-// between two outer iterations: the next ceres::Solve starts from the params_ the last one left (:360)
-__global__ void lm_shard_next_outer(DevCtx d, LmCtx L) {
+__global__ void lm_shard_step(DevCtx d, LmCtx L, int first) {
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= d.n_launch) return;
-  int* ctl = L.shard_ctl + (size_t)(s + d.slot0) * 8;
+  if (s < d.n_launch) lm_shard_step_dev(d, L, s + d.slot0, first);
+}
+// between two outer iterations: the next ceres::Solve starts from the params_ the last one left (:360)
+DEV_INLINE void lm_shard_next_outer_dev(const LmCtx& L, int slot) {
+  int* ctl = L.shard_ctl + (size_t)slot * 8;
   if (ctl[4]) return;
   ctl[3] += 1; ctl[2] = 0; ctl[1] = LM_EVAL;
 }
@@ -1144,18 +1156,17 @@ int launch_lm_register(const DevCtx& d, const LmCtx& L, hipStream_t st, int (*al
     double* part = L.shard_part + (size_t)d.slot0 * 32;
     const size_t cnt = (size_t)d.n_launch * 32;
     const dim3 g1((d.n_launch + 63) / 64), b1(64);
-    ALEGO_LAUNCH(lm_shard_pack, dim3(d.n_launch), dim3(LM_SOLVE_T), 0, st, d, L);
+    // per evaluation ONE launch + the all-reduce (round 6; before: pack | eval, all-reduce, step | next_outer as separate launches — 86 launches per mapping frame,
+    // now 43): the step on the sums of evaluation k runs at the head of evaluation k + 1's workgroups, a last stand-alone step closes the frame
     for (int outer = 0; outer < d.P.lm_outer_iters; ++outer) {
-      if (outer) ALEGO_LAUNCH(lm_shard_next_outer, g1, b1, 0, st, d, L);
-      ALEGO_LAUNCH(lm_shard_eval, dim3(d.n_launch), dim3(LM_SOLVE_T), LM_SOLVE_RED_BYTES, st, d, L, 0);
+      ALEGO_LAUNCH(lm_shard_eval, dim3(d.n_launch), dim3(LM_SOLVE_T), LM_SOLVE_RED_BYTES, st, d, L, 0, outer == 0 ? (int)LM_PRE_PACK : (int)LM_PRE_STEP_NEXT);
       if (int rc = allreduce(ar_ctx, part, cnt, st)) return rc;
-      ALEGO_LAUNCH(lm_shard_step, g1, b1, 0, st, d, L, 1);
       for (int it = 0; it < d.P.lm_max_iters; ++it) {
-        ALEGO_LAUNCH(lm_shard_eval, dim3(d.n_launch), dim3(LM_SOLVE_T), LM_SOLVE_RED_BYTES, st, d, L, 1);
+        ALEGO_LAUNCH(lm_shard_eval, dim3(d.n_launch), dim3(LM_SOLVE_T), LM_SOLVE_RED_BYTES, st, d, L, 1, it == 0 ? (int)LM_PRE_STEP_FIRST : (int)LM_PRE_STEP);
         if (int rc = allreduce(ar_ctx, part, cnt, st)) return rc;
-        ALEGO_LAUNCH(lm_shard_step, g1, b1, 0, st, d, L, 0);
       }
     }
+    ALEGO_LAUNCH(lm_shard_step, g1, b1, 0, st, d, L, d.P.lm_max_iters == 0 ? 1 : 0);
   } else {
   ALEGO_LAUNCH(lm_solve, dim3(d.n_launch), dim3(LM_SOLVE_T), LM_SOLVE_RED_BYTES + L.solve_row_bytes, st, d, L);
   }
