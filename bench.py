@@ -38,7 +38,7 @@ from alego_amd import dist as D  # noqa: E402
 
 HBM_PEAK = 8.0e12  # B/s, MI355X spec (MI355X_MICROARCH.md)
 LAP = 560          # scans per T0 lap
-PMC_ROUNDS = ("r05", "r04")   # the newest committed --pmc passes of a workload are used
+PMC_ROUNDS = ("r06", "r05", "r04")   # the newest committed --pmc passes of a workload are used
 
 
 def _pmc_path(stem):

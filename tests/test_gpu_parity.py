@@ -1920,7 +1920,7 @@ def test_timed_handle_shape_1024_slots_four_groups_bag_replay(params_a):
 def test_fe_ring_tickets_with_three_and_six_stream_groups(params_a, groups, n_slots, monkeypatch):
     """fe_ring_out's rings wait for the voxel counts of the rings below them.  Round 4 relied on the dispatch order of one XCD (grid padded to a
     multiple of 8 streams) after 683 streams per launch — three stream groups — had ended in a memory access fault a few hundred scans into the
-    bench workload, found by hand (tools/repro_groups.sh).  Rings are now handed out by ticket: the bench's handle shape with 3 and with 6 stream
+    bench workload, found by hand (a script of round 4, since removed).  Rings are now handed out by ticket: the bench's handle shape with 3 and with 6 stream
     groups, 600 steps with every CU busy, WITHOUT the padding and with it — no slot reports an error, both runs agree bit for bit in every
     slot's poses, and sampled slots equal one-slot handles replaying the same (bag, start) alone on the chip."""
     p = params_a.copy()

@@ -2,7 +2,7 @@
 # Run on the GPU box: bench lines + rocprofv3 kernel summaries for the reference geometry (16x4000, utility.h:50-55) and for config 5's
 # geometry (64x2048 with a 200-key-frame local map).  Outputs gpurun_out/<round>_geo_*; copy to profiles/ afterwards.
 set -u
-R=${1:-r04}
+R=${1:-r06}
 cd /tmp && export TMPDIR=/tmp
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out
@@ -28,4 +28,6 @@ PY
 }
 run 16x4000 --geometry 16x4000 --streams 768 --steps 60 --warmup 10
 run 64x2048_k200 --geometry 64x2048 --keyframes 200 --kf-cap 8192 --streams 512 --bags 4 --prime 2400 --steps 40 --warmup 10
+# SQ instruction counters of config 5's geometry, every kernel alone on the chip (ImageProjection's share of the VALU instructions)
+bash tools/pmc_geo_sq.sh gpurun_out/${R}_geo_64x2048_pmc_sq.json
 ls -la gpurun_out/${R}_geo_*

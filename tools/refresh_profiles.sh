@@ -8,7 +8,7 @@
 #   ${R}_pmc_traffic.json           HBM bytes per launch from two separate --pmc passes (FETCH_SIZE, WRITE_SIZE), taken after 700
 #                                  priming scans: around scan 560 every stream fills its 50-key-frame window and rebuilds its map at once
 set -u
-R=${1:-r04}
+R=${1:-r06}
 MODE=${2:-all}    # all | traffic (only the two --pmc traffic passes) | pmc (traffic + SQ counters); the last two need gpurun_out/${R}_bench.json from an earlier call
 cd /tmp && export TMPDIR=/tmp
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
