@@ -309,7 +309,7 @@ DEV_INLINE void d_eig3(const double Ain[9], double lam[3], double vmax[3], doubl
   vmax[0] = V[0 * 3 + imax]; vmax[1] = V[1 * 3 + imax]; vmax[2] = V[2 * 3 + imax];
 }
 
-// Eigen::ColPivHouseholderQR<Matrix<double, 5, 3>>::compute() + solve() (laserMapping.cpp:435) — the oracle's colpiv_qr_solve (oracle/oracle.cpp, where the algorithm's
+// Eigen::ColPivHouseholderQR<Matrix<double, 5, 3>>::compute() + solve() (laserMapping.cpp:435) — the parity checker's colpiv_qr_solve (where the algorithm's
 // source in Eigen 3.3 is cited step by step) specialised to 5 x 3 with everything in registers: the column of largest remaining norm is swapped into place (selects
 // over static indices, no indexed register access), Householder reflector (beta, essential, tau) as Householder.h builds it, LAPACK's norm down-date, nonzeroPivots()
 // by Eigen's threshold, and the components past it ZERO — a collinear / coincident neighbourhood gets a finite basic solution instead of a division by a ~1e-17 pivot.
