@@ -461,6 +461,27 @@ def test_band_path_in_a_batch_equals_the_seven_kernel_path(geom, monkeypatch):
     hb.close()
 
 
+@pytest.mark.parametrize("geom", [(64, 2048), (40, 1800), (24, 320)])
+def test_band_path_on_edge_case_scans(geom):
+    """The banded ImageProjection on ONE handle through scans of very different content, one after the other (whatever a scan leaves behind — tagged owner entries,
+    statistics entries, parent entries at run heads — must not leak into the next): a full scan, an empty one, one point, 500 points, azimuth jitter with duplicate
+    cells, NaN returns, azimuths uniform over the column (points next to cell boundaries), every point twice in reverse order (last writer wins), a scan whose
+    ranges are quantised to 0.5 m (huge components that cross every band seam and the wrap-around column), a full scan again.  Bit for bit against the oracle."""
+    p = synth.default_params(*geom)
+    h, o = binding.Handle(p), O.Oracle(p)
+    full = synth.scan(p, 7)
+    rev = np.concatenate([full, full[::-1]])[: p.n_scan * p.horizon_scan]
+    quant = full.copy()
+    r = np.linalg.norm(quant[:, :3], axis=1)
+    quant[:, :3] *= (np.maximum(np.round(r * 2) / 2, 0.5) / np.maximum(r, 1e-6))[:, None]
+    seq = [("full", full), ("empty", full[:0]), ("one point", full[1234:1235]), ("500 points", full[:500]), ("jitter", synth.scan(p, 8, flags=1)),
+           ("nan returns", synth.scan(p, 9, flags=2)), ("uniform azimuth", synth.scan(p, 10, flags=4)), ("twice, reversed", rev), ("quantised ranges", quant.astype(np.float32)),
+           ("full again", synth.scan(p, 11))]
+    for name, pts in seq:
+        _ip_compare(h, o, np.ascontiguousarray(pts, np.float32), f"{geom} {name}")
+    h.close()
+
+
 def _lm_compare(h, o, k, tag):
     oi = o.get("lm_info")
     gi = h.debug_get("lm_info")
