@@ -281,7 +281,7 @@ def quat_angle(q1, q2):
     return 2.0 * float(np.arccos(min(1.0, abs(float(np.dot(q1, q2))))))
 
 
-def cpu_legs(p, bags, prime, seconds=10.0, device=None, n_streams=2048):
+def cpu_legs(p, bags, prime, seconds=10.0, device=None, n_streams=4096):
     """BASELINE.md §2 on the host cores of this box, on the scan sequences the GPU streams replay (slot 0 = bag 0 from scan 0):
     cpu_seq (1 thread, timed after `prime` scans), cpu_pipe3 (IP || LO || LM threads), cpu_replicas (one oracle per core on the
     sequences of slots 0..C-1).  While cpu_seq primes, one-stream device handles process the same scans: SURVEY.md 8(d)'s pose
@@ -533,7 +533,7 @@ def config_line(p, device, streams, n_bags, prime, warmup, steps, stages=7, bags
 
 def all_configs(args, p_head, bags_head, device, head_kern, head_per, single, cpu):
     """BASELINE.json's other single-GPU configurations, each as a line of its own: streams, steps, ms_per_step, value = streams x steps / time,
-    a 20-scan teacher-forced parity sample, its own roofline.  The headline (config 3 / 4 at 2048 streams) is the top-level line; config 1 is the CPU leg
+    a 20-scan teacher-forced parity sample, its own roofline.  The headline (config 3 / 4 at `--streams` resident streams) is the top-level line; config 1 is the CPU leg
     (`cpu_baseline`); configs 4 and 5 at N > 1 are the driver's multi-GPU runs."""
     cfg = {}
     t_all = time.perf_counter()
@@ -605,12 +605,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--streams", type=int, default=2048, help="independent streams resident per GPU")
+    ap.add_argument("--streams", type=int, default=4096, help="independent streams resident per GPU (round 6: 4096 — 2048 / 3072 / 4096 measured 467 / 475 / 480 k scans/s in one call; "
+                                                               "they fit because --kf-cap sizes the key-frame rings to the data instead of the worst case)")
     ap.add_argument("--bags", type=int, default=8, help="recorded 560-scan streams resident per GPU (shared by the streams)")
     ap.add_argument("--prime", type=int, default=LAP, help="untimed scans per stream to fill the local map (one lap fills 50 key frames)")
     ap.add_argument("--geometry", default="16x1800", help="n_scan x horizon_scan: 16x1800 (BASELINE metric), 16x4000, 64x2048")
     ap.add_argument("--keyframes", type=int, default=0, help="local-map window (0 = reference default 50; config 5 uses 200)")
-    ap.add_argument("--kf-cap", type=int, default=0, help="points per key-frame surf cloud (alego_params.kf_cap_surf; outliers a quarter of it); 0 = worst case")
+    ap.add_argument("--kf-cap", type=int, default=-1, help="points per key-frame surf cloud (alego_params.kf_cap_surf; outliers a quarter of it); 0 = worst case (n_scan x horizon_scan: "
+                                                            "90 MB per stream at 16x1800 / K = 50); default: 8192 at 16x1800 (the lap's key frames hold <= 4.4 k: 16 MB per stream), "
+                                                            "worst case elsewhere.  A key frame that does not fit is truncated and REPORTED (truncated_streams, ALEGO_ERR_CAPACITY)")
     ap.add_argument("--sort-mode", type=int, default=0, help="2 = feature picks in libstdc++ std::sort tie order (alego_params.sort_mode)")
     ap.add_argument("--shard-registration", action="store_true",
                     help="BASELINE config 5: every rank replays the SAME streams and each scan-to-map registration is split over the ranks "
@@ -642,6 +645,8 @@ def main():
         dist = D.init("nccl", torch.device("cuda", local))  # RCCL: only the barrier + max-over-ranks use it
 
     ns, hs = (int(v) for v in args.geometry.lower().split("x"))
+    if args.kf_cap < 0:
+        args.kf_cap = 8192 if (ns, hs) == (16, 1800) and args.keyframes == 0 else 0
     set_pmc_file(args.geometry, args.keyframes)
     p = synth.default_params(ns, hs)
     if args.keyframes > 0:
