@@ -581,16 +581,18 @@ def all_configs(args, p_head, bags_head, device, head_kern, head_per, single, cp
                                                                                          "bandwidth-bound: B_scan x value = %.4f of the HBM peak" % ((single["single_stream_scans_per_s"] * 2.59e6) / HBM_PEAK)))
     # ---- the reference's own compiled geometry, 16 x 4000 (utility.h:50-55)
     p = synth.default_params(16, 4000)
-    cfg["geometry_16x4000_reference_compiled"], _, _ = config_line(p, device, 768, 8, LAP, 10, 60)
+    p.kf_cap_surf, p.kf_cap_outlier = 16384, 4096   # (the lap's key frames hold <= 9 k surf points; worst case = 64 000: 768 streams where 2 304 fit — 258 / 277 / 287 k scans/s at 768 / 1 536 / 2 304 in one call)
+    cfg["geometry_16x4000_reference_compiled"], _, _ = config_line(p, device, 2304, 8, LAP, 10, 60)
     # ---- config 5's shape at N = 1: 64 x 2048 with a 200-key-frame local map; fused solver, then the registration split as for N ranks (world 1)
     p = synth.default_params(64, 2048)
     p.recent_keyframe_num = 200
     p.kf_cap_surf, p.kf_cap_outlier = 8192, 2048
     bags5 = make_bags(p, 4, first_stream=0)
-    fused, _, _ = config_line(p, device, 512, 4, 2400, 10, 40, bags=bags5)
+    S5 = 768   # (512 / 768 streams: 122.5 / 127.4 k scans/s in one call; 1 024 do not fit)
+    fused, _, _ = config_line(p, device, S5, 4, 2400, 10, 40, bags=bags5)
     cfg["config5_shape_64x2048_k200_fused"] = fused
-    fused1, _, _ = config_line(p, device, 512, 4, 2400, 10, 40, bags=bags5, one_group=True, parity_scans=0)
-    shard, _, _ = config_line(p, device, 512, 4, 2400, 10, 40, bags=bags5, shard=True, parity_scans=0)
+    fused1, _, _ = config_line(p, device, S5, 4, 2400, 10, 40, bags=bags5, one_group=True, parity_scans=0)
+    shard, _, _ = config_line(p, device, S5, 4, 2400, 10, 40, bags=bags5, shard=True, parity_scans=0)
     frames = max(40 // max(p.lm_every, 1), 1)
     shard["shard_vs_fused"] = dict(fused_scans_per_s=fused1["value"], sharded_scans_per_s=shard["value"], fused_ms_per_step=fused1["ms_per_step"], sharded_ms_per_step=shard["ms_per_step"],
                                    extra_ms_per_mapping_frame=round((shard["ms_per_step"] - fused1["ms_per_step"]) * 40 / frames, 4), world=1,

@@ -26,8 +26,8 @@ PY
   python tools/pmc_traffic.py /tmp/pmcg_FETCH_SIZE /tmp/pmcg_WRITE_SIZE "$per" 16 > gpurun_out/${R}_geo_${tag}_pmc_traffic.json
   tail -c 600 gpurun_out/${R}_geo_${tag}.json; echo; head -8 gpurun_out/${R}_geo_${tag}_kernel_stats.csv
 }
-run 16x4000 --geometry 16x4000 --streams 768 --steps 60 --warmup 10
-run 64x2048_k200 --geometry 64x2048 --keyframes 200 --kf-cap 8192 --streams 512 --bags 4 --prime 2400 --steps 40 --warmup 10
+run 16x4000 --geometry 16x4000 --kf-cap 16384 --streams 2304 --steps 60 --warmup 10
+run 64x2048_k200 --geometry 64x2048 --keyframes 200 --kf-cap 8192 --streams 768 --bags 4 --prime 2400 --steps 40 --warmup 10
 # SQ instruction counters of config 5's geometry, every kernel alone on the chip (ImageProjection's share of the VALU instructions)
 bash tools/pmc_geo_sq.sh gpurun_out/${R}_geo_64x2048_pmc_sq.json
 ls -la gpurun_out/${R}_geo_*
