@@ -1,5 +1,5 @@
 """Long run on the bench workload (bag replay): many steps on many streams, then every stream's flags / poses are checked for device
-errors (capacity, internal "voxel list out of sync") and non-finite values.  usage: soak.py [streams] [steps]"""
+errors (capacity, internal "voxel list out of sync") and non-finite values.  usage: soak.py [streams] [steps] [geometry, e.g. 64x2048] [keyframes] [kf_cap]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -8,7 +8,10 @@ from alego_amd import binding, synth
 import bench
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 3000
-p = synth.default_params(16, 1800)
+geo = tuple(int(v) for v in (sys.argv[3] if len(sys.argv) > 3 else '16x1800').split('x'))
+p = synth.default_params(*geo)
+if len(sys.argv) > 4 and int(sys.argv[4]) > 0: p.recent_keyframe_num = int(sys.argv[4])
+if len(sys.argv) > 5 and int(sys.argv[5]) > 0: p.kf_cap_surf, p.kf_cap_outlier = int(sys.argv[5]), max(256, int(sys.argv[5]) // 4)
 bags = bench.make_bags(p, 4, 0)
 h = binding.Handle(p, n_slots=B, ring_len=1)
 bench.setup_replay(h, bags, B)
