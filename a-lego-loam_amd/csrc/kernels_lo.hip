@@ -98,9 +98,20 @@ DEV_INLINE uint32_t row_bits(unsigned long long ballot, int lane) { return (uint
 #ifdef ALEGO_TIMING
 __device__ long long la_times[12];
 extern "C" void alego_la_times(long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(la_times), sizeof(long long) * 12); }
+__device__ unsigned long long la_cnt[8];   // [kind * 4 + ...]: wavefront sweeps, walk_eval turns of the pass, surviving boxes (summed over rows), window boxes (summed over rows)
+extern "C" void alego_la_counts(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(la_cnt), sizeof(unsigned long long) * 8); }
+#define LA_COUNT(i, v) do { atomicAdd(&la_cnt[kind * 4 + (i)], (unsigned long long)(v)); } while (0)
 #define LA_TICK(k) do { if (threadIdx.x == 0 && slot == d.slot0 && qb0 == 0 && kind == 0) la_times[k] = wall_clock64(); } while (0)
+#define LA_TICK0 LA_TICK(0)
+#elif defined(LA_STOP_AFTER)
+// development (instruction counts per phase, tools/la_phase_counts.sh): a sweep ends after phase LA_STOP_AFTER (its queries get no correspondence)
+#define LA_TICK(k) if ((k) == LA_STOP_AFTER) continue
+#define LA_TICK0
+#define LA_COUNT(i, v)
 #else
 #define LA_TICK(k)
+#define LA_TICK0
+#define LA_COUNT(i, v)
 #endif
 // ---- the target grid (round 4) ----------------------------------------------------------------------------------------------------
 // pcl::KdTreeFLANN::nearestKSearch(sel, 1, ...) (:341,:430) is an EXACT nearest neighbour; the boxes answer it with ~12 boxes of 32 targets per
@@ -247,7 +258,7 @@ DEV_INLINE void lo_assoc_body(const DevCtx& d, int box_lds_max, int slot, int qb
   const int* boff = d.ring_boff + (fl * 2 + (kind == 0 ? 1 : 0)) * (d.NS + 1);
   const int nch = nt > 0 ? boff[d.NS] : 0;
   const double* st = d.lo_state + (size_t)slot * LO_STATE_N;
-  LA_TICK(0);
+  LA_TICK0;
   __shared__ float s_sel[LO_QPB][4];
   __shared__ double s_pose[12];
   __shared__ float4 s_box[2 * BOXCAP];   // the boxes are read by every query of the workgroup: LDS when they fit
@@ -479,19 +490,32 @@ DEV_INLINE void lo_assoc_body(const DevCtx& d, int box_lds_max, int slot, int qb
     const double boundS = __longlong_as_double((long long)row16_min_u64((unsigned long long)__double_as_longlong(inS)));
     LA_TICK(6);
     const double boundO = __longlong_as_double((long long)row16_min_u64((unsigned long long)__double_as_longlong(inO)));
-    for (int it = 0; __ballot(cw0 + it * 16 <= cw1); ++it) {
-      const int c0 = cw0 + it * 16, c = c0 + l16;
-      bool take = false;
-      if (c <= cw1 && c != cseedS && c != cseedO) {
-        bool inS, inO;
-        box_class(c, inS, inO);
-        const double lb = lb_f64(c);
-        take = (inS && lb <= boundS) || (inO && lb <= boundO);
+    // (round 6) the survivors of up to FOUR groups of 16 boxes are collected in one 64-bit mask per row before any of them is evaluated: the few boxes that survive
+    // (one or two per ring of the window) lie in different groups, and evaluating group by group spent a half-empty walk_eval turn on most of them
+    if (lane == 0) LA_COUNT(0, 1);
+    if (l16 == 0) LA_COUNT(3, max(cw1 - cw0 + 1, 0));
+    for (int it0 = 0; __ballot(cw0 + it0 * 16 <= cw1); it0 += 4) {
+      const int cbase = cw0 + it0 * 16;
+      unsigned long long surv = 0ull;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int c = cbase + g * 16 + l16;
+        if (!__ballot(c <= cw1)) break;   // (uniform)
+        bool take = false;
+        if (c <= cw1 && c != cseedS && c != cseedO) {
+          bool inS, inO;
+          box_class(c, inS, inO);
+          const double lb = lb_f64(c);
+          take = (inS && lb <= boundS) || (inO && lb <= boundO);
+        }
+        surv |= (unsigned long long)row_bits(__ballot(take), lane) << (16 * g);
       }
-      uint32_t surv = row_bits(__ballot(take), lane);
-      while (__ballot(surv != 0)) {
+      if (l16 == 0) LA_COUNT(2, __popcll(surv));
+      while (__ballot(surv != 0ull)) {
+        if (lane == 0) LA_COUNT(1, 1);
         int cb[LO_NB];
-        pop_boxes(surv, c0, cb);
+#pragma unroll
+        for (int u = 0; u < LO_NB; ++u) { cb[u] = surv ? cbase + __ffsll((long long)surv) - 1 : -1; surv &= surv - 1ull; }   // 0 stays 0
         walk_eval(cb);
       }
     }
