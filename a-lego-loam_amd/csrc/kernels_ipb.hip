@@ -456,7 +456,7 @@ __global__ void __launch_bounds__(IPB_ET) ipb_emit(DevCtx d, int ring_pos, int k
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------------------------
-bool ipb_eligible(const DevCtx& d) { return d.ipb_col != nullptr && d.NS > 16 && d.NS <= 64 && d.H >= 64 && d.H <= 32768; }
+bool ipb_eligible(const DevCtx& d) { return d.ipb_col != nullptr && d.NS > 16 && d.NS <= 64 && d.H >= 64 && (d.H + IPB_TW - 1) / IPB_TW * d.NS <= IPB_LINK_CAP; }   // (seam edges = bands x rings: the linked-root list of ipb_merge)
 size_t ipb_merge_lds(const DevCtx& d) { return (size_t)3 * 64 * ((d.H + 63) / 64) * sizeof(unsigned short); }
 void launch_ipb(const DevCtx& d, int ring_pos, bool keep_images, hipStream_t st) {
   const int nb = (d.H + IPB_TW - 1) / IPB_TW, nch = (d.H + 63) / 64;
