@@ -541,7 +541,7 @@ class Handle:
         self._check(lib().alego_set_lm_params(self._h, slot, a.ctypes.data), "alego_set_lm_params")
 
     def debug_get(self, name, slot=0, cap_bytes=None):
-        cap = cap_bytes or (self.N * 64 + 4096)
+        cap = cap_bytes or max(self.N * 64 + 4096, 8 << 20)
         buf = np.empty(cap, np.uint8)
         cnt, dt = C.c_int(), C.c_int()
         self._check(lib().alego_debug_get(self._h, slot, name.encode(), buf.ctypes.data, cap, C.byref(cnt), C.byref(dt)),

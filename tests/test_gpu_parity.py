@@ -35,7 +35,7 @@ def _ip_compare(h, o, pts, tag):
                                           ((16, 1024), None), ((12, 2048), None), ((5, 64), None), ((16, 1800), "ALEGO_IP_FUSED,ALEGO_IP_FAST"),
                                           ((16, 4000), None), ((64, 2048), None), ((64, 2048), "ALEGO_IP_BAND"), ((64, 2048), "ALEGO_IP_BAND,ALEGO_CC_TILE"),
                                           ((32, 2048), None), ((40, 1800), None), ((32, 2048), "ALEGO_IP_BAND"), ((40, 1800), "ALEGO_IP_BAND"),
-                                          ((24, 320), None), ((17, 70), None), ((64, 4000), None), ((48, 1000), None),
+                                          ((24, 320), None), ((17, 70), None), ((64, 4000), None), ((48, 1000), None), ((64, 4096), None), ((17, 4096), None), ((33, 257), None),
                                           ((16, 1800), "ALEGO_IP_HALF"), ((16, 1024), "ALEGO_IP_HALF"), ((12, 2048), "ALEGO_IP_HALF"), ((5, 64), "ALEGO_IP_HALF"),
                                           ((16, 1800), "ALEGO_IP_HALF,ALEGO_IP_FAST"), ((16, 4000), "ALEGO_IP_HALF"), ((16, 4094), None), ((14, 3000), None)])
 def test_ip_bit_exact(geom, variant, monkeypatch):
@@ -479,6 +479,28 @@ def test_band_path_on_edge_case_scans(geom):
            ("full again", synth.scan(p, 11))]
     for name, pts in seq:
         _ip_compare(h, o, np.ascontiguousarray(pts, np.float32), f"{geom} {name}")
+    h.close()
+
+
+@pytest.mark.parametrize("geom", [(32, 1024), (40, 1800), (24, 320), (64, 1024)])
+def test_full_loop_on_sensors_between_16_and_64_rings(geom):
+    """IP -> LO -> LM teacher-forced on ring counts that only the banded ImageProjection serves (17 - 64 rings; 64 x 2048 itself: test_full_loop_teacher_forced,
+    test_config5_geometry_200_keyframe_window): what the bands hand on — segmented cloud, ring indices, ground flags — feeds feature extraction, both registrations and
+    the maps; every scan's index outputs and filtered maps bit for bit, poses within 1e-4."""
+    p = synth.default_params(*geom)
+    h, o = binding.Handle(p), O.Oracle(p)
+    for k in range(8):
+        pts = synth.scan(p, k)
+        h.set_lo_params(o.get("lo_params"))
+        h.set_lm_params(o.get("lm_params"))
+        o.process_scan(pts)
+        flags, odom, mp = h.scan_process(pts, stages=7)
+        if k == 0:
+            continue
+        _index_outputs_compare(h, o, f"{geom} scan {k}")
+        _lm_compare(h, o, k, f"{geom} scan {k}")
+        want = o.get("map_pose")
+        assert np.abs(mp["t"] - want[:3]).max() < POSE_TOL and quat_angle(mp["q"], want[3:]) < POSE_TOL, (geom, k)
     h.close()
 
 
