@@ -1633,6 +1633,34 @@ def test_allocation_guards_detect_a_stray_write():
     assert "clean 0" in r.stdout and "poked 1" in r.stdout, (r.stdout, r.stderr[-500:])
 
 
+def test_band_path_leaves_allocation_guards_intact():
+    """The banded ImageProjection (kernels_ipb.hip) under ALEGO_DEBUG_CANARY=1 — guard pages around every device allocation — on full bands, a partial last band
+    (40 x 1800), a single partial band (17 x 70), an odd width (33 x 257) and the widest image (64 x 4096): batch launches, the single-scan entry points with label
+    images, jittered and empty scans; no guard may be touched."""
+    import os, subprocess, sys
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "from alego_loader import load_package; load_package()\n"
+        "from alego_amd import binding, synth\n"
+        "for geom in ((64, 2048), (40, 1800), (17, 70), (33, 257), (64, 4096)):\n"
+        "    p = synth.default_params(*geom)\n"
+        "    hb = binding.Handle(p, n_slots=3, ring_len=4)\n"
+        "    for s in range(3):\n"
+        "        for k in range(4): hb.batch_load(s, k, synth.scan(p, k, stream=s))\n"
+        "    hb.batch_run(0, 12, 7 | binding.REPLAY_PINGPONG)\n"
+        "    h1 = binding.Handle(p)\n"
+        "    for k in range(3):\n"
+        "        h1.scan_process(synth.scan(p, k), stages=7, want_outputs=True)\n"
+        "        h1.ip_process(synth.scan(p, k, flags=1), want_labels=True)\n"
+        "    h1.ip_process(synth.scan(p, 0)[:0], want_labels=True)\n"
+        "    print(geom, 'damaged', binding.check_guards()[0])\n"
+        "    hb.close(); h1.close()\n"
+    ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ALEGO_DEBUG_CANARY="1")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+    assert r.stdout.count("damaged 0") == 5, (r.stdout, r.stderr[-800:])
+
+
 def test_unusual_geometries_in_one_process():
     """Tiny and odd sensors through the whole loop, one handle after the other in the same process (an out-of-bounds read of
     cc_lds16's output phase for images of fewer than 1024 cells only faulted once another handle's memory lay next to it), and
